@@ -1,0 +1,291 @@
+"""CPU oracle for the CPC-audio train-step hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is imported by the product
+package ``cpc_audio_amd``; only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may use it, and only as the checker /
+reported CPU baseline -- never as the thing that is shipped or measured as the
+GPU path.
+
+This is a from-scratch, functional (no nn.Module) restatement in plain torch
+CPU ops of the algorithm the reference implements in
+
+  * cpc/model.py:50-58      ChannelNorm.forward
+  * cpc/model.py:83-105     CPCEncoder (5 strided Conv1d + norm + ReLU)
+  * cpc/model.py:175-204    CPCAR (multi-layer GRU, batch_first, h0 carry)
+  * cpc/model.py:286-289    CPCModel.forward
+  * cpc/criterion/criterion.py:97-118    PredictionNetwork.forward (linear heads)
+  * cpc/criterion/criterion.py:174-219   sampleClean (negative sampling)
+  * cpc/criterion/criterion.py:225-257   CPCUnsupersivedCriterion.forward
+
+Parameters are passed as a flat dict whose keys are the reference's state-dict
+keys (``gEncoder.conv0.weight`` ... ``wPrediction.predictors.11.weight``) so the
+same tensors can be loaded into the reference modules, this oracle and the HIP
+build.
+
+Parity pin: ``oracle/make_golden.py`` imports the reference from
+``/root/reference`` (torch 2.10.0 CPU) and asserts this oracle reproduces its
+outputs and gradients on identical weights, inputs and negative indices; the
+golden vectors it writes are committed under ``tests/golden/`` and re-checked by
+``tests/test_oracle_golden.py`` wherever the reference is absent.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+Tensor = torch.Tensor
+
+# (kernel, stride, padding) of conv0..conv4 -- cpc/model.py:83-92
+ENCODER_GEOMETRY: Tuple[Tuple[int, int, int], ...] = (
+    (10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
+DOWNSAMPLING = 160  # cpc/model.py:94
+CHANNEL_NORM_EPS = 1e-5  # cpc/model.py:29
+
+
+# --------------------------------------------------------------------------
+# deterministic parameter recipe
+# --------------------------------------------------------------------------
+def param_shapes(hidden_encoder: int = 256, hidden_gar: int = 256,
+                 n_levels_gru: int = 2, n_predicts: int = 12) -> "Dict[str, Tuple[int, ...]]":
+    """Reference state-dict keys and shapes, in reference key order
+    (model first, then criterion) -- SURVEY.md section 8b [measured]."""
+    C, H = hidden_encoder, hidden_gar
+    shapes: Dict[str, Tuple[int, ...]] = {}
+    cin = 1
+    for i, (k, _, _) in enumerate(ENCODER_GEOMETRY):
+        shapes[f"gEncoder.conv{i}.weight"] = (C, cin, k)
+        shapes[f"gEncoder.conv{i}.bias"] = (C,)
+        shapes[f"gEncoder.batchNorm{i}.weight"] = (1, C, 1)
+        shapes[f"gEncoder.batchNorm{i}.bias"] = (1, C, 1)
+        cin = C
+    for l in range(n_levels_gru):
+        din = C if l == 0 else H
+        shapes[f"gAR.baseNet.weight_ih_l{l}"] = (3 * H, din)
+        shapes[f"gAR.baseNet.weight_hh_l{l}"] = (3 * H, H)
+        shapes[f"gAR.baseNet.bias_ih_l{l}"] = (3 * H,)
+        shapes[f"gAR.baseNet.bias_hh_l{l}"] = (3 * H,)
+    for k in range(n_predicts):
+        shapes[f"wPrediction.predictors.{k}.weight"] = (C, H)
+    return shapes
+
+
+def make_params(seed: int = 0, head_scale: float = 1.0, **arch) -> Dict[str, Tensor]:
+    """Fill every tensor from ONE cpu generator, in key order.
+
+    conv / GRU / linear weights ~ randn / sqrt(fan_in); biases 0.1*randn;
+    norm weight 1 + 0.1*randn; norm bias 0.1*randn.  ``head_scale`` multiplies the
+    prediction-head weights so the logits leave the O(1e-3) regime in which every
+    head's loss sits at ln(129) regardless of bugs.
+    """
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out: Dict[str, Tensor] = {}
+    for name, shape in param_shapes(**arch).items():
+        r = torch.randn(shape, generator=g, dtype=torch.float32)
+        if "batchNorm" in name:
+            t = 1.0 + 0.1 * r if name.endswith("weight") else 0.1 * r
+        elif name.endswith("bias") or ".bias_" in name:
+            t = 0.1 * r
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = r / math.sqrt(fan_in)
+            if name.startswith("wPrediction"):
+                t = t * head_scale
+        out[name] = t.contiguous()
+    return out
+
+
+def make_waveform(batch: int, length: int = 20480, seed: int = 1234) -> Tensor:
+    """Synthetic white noise 0.1*N(0,1) clamped to [-1,1], (B,1,L) fp32 --
+    SURVEY.md section 8d / BASELINE.md section 3."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (0.1 * torch.randn(batch, 1, length, generator=g)).clamp_(-1.0, 1.0)
+
+
+# --------------------------------------------------------------------------
+# encoder -- cpc/model.py:50-58, 99-105
+# --------------------------------------------------------------------------
+def channel_norm(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor],
+                 eps: float = CHANNEL_NORM_EPS) -> Tensor:
+    """Per-(b,t) normalisation over the CHANNEL axis of an (B,C,T) tensor with the
+    UNBIASED variance (divisor C-1) -- cpc/model.py:52-57 (x.var default)."""
+    C = x.shape[1]
+    mu = x.sum(dim=1, keepdim=True) / C
+    d = x - mu
+    var = (d * d).sum(dim=1, keepdim=True) / (C - 1)
+    y = d * torch.rsqrt(var + eps)
+    if weight is not None:
+        y = y * weight + bias
+    return y
+
+
+def encoder_forward(p: Dict[str, Tensor], wave: Tensor,
+                    collect: Optional[List[Tensor]] = None) -> Tensor:
+    """(B,1,L) -> (B,C,L/160): relu(norm(conv_i(x))) for i in 0..4 -- model.py:99-105."""
+    x = wave
+    for i, (_, s, pad) in enumerate(ENCODER_GEOMETRY):
+        x = torch.nn.functional.conv1d(x, p[f"gEncoder.conv{i}.weight"],
+                                       p[f"gEncoder.conv{i}.bias"], stride=s, padding=pad)
+        x = channel_norm(x, p[f"gEncoder.batchNorm{i}.weight"], p[f"gEncoder.batchNorm{i}.bias"])
+        x = torch.relu(x)
+        if collect is not None:
+            collect.append(x)
+    return x
+
+
+# --------------------------------------------------------------------------
+# autoregressor -- cpc/model.py:175-204 (torch.nn.GRU semantics, gate order r,z,n)
+# --------------------------------------------------------------------------
+def gru_forward(p: Dict[str, Tensor], x: Tensor, n_levels: int = 2,
+                h0: Optional[Tensor] = None, prefix: str = "gAR.baseNet."
+                ) -> Tuple[Tensor, Tensor]:
+    """x (B,S,Din) -> (y (B,S,H), hN (n_levels,B,H)).
+
+      r = sigmoid(W_ir x + b_ir + W_hr h + b_hr)
+      z = sigmoid(W_iz x + b_iz + W_hz h + b_hz)
+      n = tanh   (W_in x + b_in + r * (W_hn h + b_hn))
+      h'= (1 - z) * n + z * h
+    The input projection of all S steps is done up front (one GEMM), the recurrent
+    part is S dependent steps -- the same split the HIP path uses.
+    """
+    B, S, _ = x.shape
+    inp = x
+    h_last = []
+    for l in range(n_levels):
+        w_ih, w_hh = p[f"{prefix}weight_ih_l{l}"], p[f"{prefix}weight_hh_l{l}"]
+        b_ih, b_hh = p[f"{prefix}bias_ih_l{l}"], p[f"{prefix}bias_hh_l{l}"]
+        H = w_hh.shape[1]
+        gi = inp.reshape(B * S, -1) @ w_ih.t() + b_ih
+        gi = gi.view(B, S, 3 * H)
+        h = inp.new_zeros(B, H) if h0 is None else h0[l]
+        outs = []
+        for t in range(S):
+            gh = h @ w_hh.t() + b_hh
+            i_r, i_z, i_n = gi[:, t].split(H, dim=1)
+            h_r, h_z, h_n = gh.split(H, dim=1)
+            r = torch.sigmoid(i_r + h_r)
+            z = torch.sigmoid(i_z + h_z)
+            n = torch.tanh(i_n + r * h_n)
+            h = (1.0 - z) * n + z * h
+            outs.append(h)
+        inp = torch.stack(outs, dim=1)
+        h_last.append(h)
+    return inp, torch.stack(h_last, dim=0)
+
+
+def model_forward(p: Dict[str, Tensor], wave: Tensor, n_levels: int = 2,
+                  h0: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """CPCModel.forward -- model.py:286-289.  Returns (c (B,S,H), z (B,S,C), hN)."""
+    z = encoder_forward(p, wave).permute(0, 2, 1)
+    c, hN = gru_forward(p, z, n_levels=n_levels, h0=h0)
+    return c, z, hN
+
+
+# --------------------------------------------------------------------------
+# criterion -- cpc/criterion/criterion.py
+# --------------------------------------------------------------------------
+def draw_negative_indices(batch: int, seq: int, window: int, n_neg: int,
+                          generator: Optional[torch.Generator] = None,
+                          device: str = "cpu") -> Tuple[Tensor, Tensor]:
+    """The two randint calls of sampleClean, in the reference's order
+    (criterion.py:181-189): batchIdx in [0,B) FIRST, then seqIdx in [1,S); both
+    flat with n_neg*window*batch elements."""
+    n = n_neg * window * batch
+    batch_idx = torch.randint(low=0, high=batch, size=(n,), generator=generator, device=device)
+    seq_idx = torch.randint(low=1, high=seq, size=(n,), generator=generator, device=device)
+    return batch_idx, seq_idx
+
+
+def negative_rows(batch_idx: Tensor, seq_idx: Tensor, batch: int, seq: int,
+                  window: int, n_neg: int) -> Tensor:
+    """Flat (b,n,t)-ordered draws -> row ids into z.view(B*S,C), shape (B,N,W):
+    row = ((seqIdx + t) mod S) + batchIdx*S  -- criterion.py:191-199."""
+    t = torch.arange(window, device=seq_idx.device).view(1, 1, window)
+    s = torch.remainder(seq_idx.view(batch, n_neg, window) + t, seq)
+    return s + batch_idx.view(batch, n_neg, window) * seq
+
+
+def head_weights(p: Dict[str, Tensor], n_predicts: int) -> List[Tensor]:
+    return [p[f"wPrediction.predictors.{k}.weight"] for k in range(n_predicts)]
+
+
+def criterion_logits(p: Dict[str, Tensor], c: Tensor, z: Tensor, ext_rows: Tensor,
+                     n_predicts: int = 12) -> List[Tensor]:
+    """Per head k (k=1..K) the (B, 1+N, W) score tensor the reference builds at
+    criterion.py:108-116: mean over the feature dim of (W_k c_t) * candidate, with
+    candidate 0 the positive z_{t+k} (criterion.py:210-216) and candidates 1..N the
+    negatives shared by all heads (criterion.py:200-201).  Negatives are gathered
+    once; nothing of size (B,1+N,W,C) per head is materialised."""
+    B, S, C = z.shape
+    W = S - n_predicts
+    cw = c[:, :W]
+    neg = z.reshape(B * S, C)[ext_rows.reshape(-1)].view(B, -1, W, C)  # (B,N,W,C)
+    out = []
+    for k, wk in enumerate(head_weights(p, n_predicts), start=1):
+        pred = cw @ wk.t()                                    # (B,W,C)  criterion.py:108
+        pos = (pred * z[:, k:k + W]).mean(dim=2)              # (B,W)
+        negs = (pred.unsqueeze(1) * neg).mean(dim=3)          # (B,N,W)  criterion.py:116
+        out.append(torch.cat((pos.unsqueeze(1), negs), dim=1))
+    return out
+
+
+def criterion_forward(p: Dict[str, Tensor], c: Tensor, z: Tensor, ext_rows: Tensor,
+                      n_predicts: int = 12) -> Tuple[Tensor, Tensor]:
+    """-> (losses (1,K), acc (1,K)) -- criterion.py:248-257: per-head cross entropy
+    against class 0, mean over the B*W rows; accuracy = fraction of rows whose
+    arg-max is class 0."""
+    B, S, _ = z.shape
+    W = S - n_predicts
+    losses, accs = [], []
+    for lg in criterion_logits(p, c, z, ext_rows, n_predicts):
+        rows = lg.permute(0, 2, 1).reshape(B * W, -1)         # criterion.py:249-250
+        lse = torch.logsumexp(rows, dim=1)
+        losses.append((lse - rows[:, 0]).mean().view(1, 1))   # CE(target=0), mean
+        accs.append((rows.argmax(dim=1) == 0).float().sum().view(1, 1))
+    return torch.cat(losses, dim=1), torch.cat(accs, dim=1) / (W * B)
+
+
+# --------------------------------------------------------------------------
+# one full train step (forward + backward of the summed loss) -- train.py:83-87
+# --------------------------------------------------------------------------
+def train_step(p: Dict[str, Tensor], wave: Tensor, batch_idx: Tensor, seq_idx: Tensor,
+               n_predicts: int = 12, n_neg: int = 128, n_levels: int = 2,
+               h0: Optional[Tensor] = None):
+    """Forward + ``losses.sum().backward()``.  Returns a dict with c, z, losses, acc
+    and ``grads`` keyed like ``p``.  ``p`` tensors are treated as leaves."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    c, z, hN = model_forward(leaves, wave, n_levels=n_levels, h0=h0)
+    B, S, _ = z.shape
+    W = S - n_predicts
+    ext = negative_rows(batch_idx, seq_idx, B, S, W, n_neg)
+    losses, acc = criterion_forward(leaves, c, z, ext, n_predicts)
+    losses.sum().backward()
+    return {"c": c.detach(), "z": z.detach(), "hN": hN.detach(), "losses": losses.detach(),
+            "acc": acc.detach(), "ext": ext,
+            "grads": {k: v.grad for k, v in leaves.items()}}
+
+
+class CpuTrainer:
+    """The CPU baseline that bench.py times: forward + backward + Adam, the same
+    step as cpc/train.py:83-91 with torch.optim.Adam(lr=2e-4, betas=(0.9,0.999),
+    eps=1e-8) (train.py:335-337, cpc_default_config.py:25-40)."""
+
+    def __init__(self, p: Dict[str, Tensor], n_predicts=12, n_neg=128, n_levels=2):
+        self.p = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+        self.opt = torch.optim.Adam(list(self.p.values()), lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+        self.n_predicts, self.n_neg, self.n_levels = n_predicts, n_neg, n_levels
+
+    def step(self, wave: Tensor) -> Tensor:
+        c, z, _ = model_forward(self.p, wave, n_levels=self.n_levels)
+        B, S, _ = z.shape
+        W = S - self.n_predicts
+        bi, si = draw_negative_indices(B, S, W, self.n_neg)
+        ext = negative_rows(bi, si, B, S, W, self.n_neg)
+        losses, _ = criterion_forward(self.p, c, z, ext, self.n_predicts)
+        losses.sum().backward()
+        self.opt.step()
+        self.opt.zero_grad()
+        return losses.detach()
