@@ -1,0 +1,103 @@
+"""ctypes binding of the C ABI declared in include/cpc_hip.h.
+
+The product path loads exactly one library: ``cpc_audio_amd/lib/libcpc_hip.so``, built
+by hipcc for gfx950 (``python -m cpc_audio_amd.build``).  If it is missing or fails to
+load, every op raises -- there is NO CPU / eager fallback.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcpc_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_long
+_F = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/cpc_hip.h one to one
+SIGNATURES = {
+    "cpc_abi_version": (_I, []),
+    "cpc_conv0_forward": (_I, [_P] * 8 + [_I, _I, _P]),
+    "cpc_conv0_backward_scratch_floats": (_L, [_I, _I]),
+    "cpc_conv0_backward": (_I, [_P] * 13 + [_I, _I, _P]),
+    "cpc_conv_layer_forward": (_I, [_P] * 9 + [_I] * 5 + [_P]),
+    "cpc_norm_backward": (_I, [_P] * 9 + [_I, _P]),
+    "cpc_conv_layer_dgrad": (_I, [_P] * 3 + [_I] + [_P] * 8 + [_I] * 5 + [_P]),
+    "cpc_conv_layer_wgrad": (_I, [_P] * 4 + [_I] * 7 + [_P]),
+    "cpc_encoder_layout": (_I, [_I, _I, _P]),
+    "cpc_encoder_forward": (_I, [_P] * 5 + [_I, _I, _P]),
+    "cpc_encoder_backward": (_I, [_P] * 7 + [_I, _I, _P]),
+    "cpc_set_conv_tile": (_I, [_I]),
+}
+
+
+class CpcHipError(RuntimeError):
+    pass
+
+
+class Bound:
+    """Typed view of a loaded library.  ``check`` turns non-zero status into exceptions."""
+
+    def __init__(self, cdll, path):
+        self.path = path
+        self._cdll = cdll
+        missing = []
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(cdll, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+        if missing:
+            raise CpcHipError(f"{path} lacks symbols declared in include/cpc_hip.h: {missing}")
+
+    @staticmethod
+    def check(status, what=""):
+        if status == 0:
+            return
+        if status == 1:
+            raise ValueError(f"cpc_hip {what}: unsupported or inconsistent shape (CPC_ERR_SHAPE)")
+        if status == 2:
+            raise ValueError(f"cpc_hip {what}: bad argument (CPC_ERR_ARG)")
+        raise CpcHipError(f"cpc_hip {what}: HIP error {status - 1000}")
+
+
+def bind(path):
+    return Bound(ctypes.CDLL(path), path)
+
+
+_lock = threading.Lock()
+_bound = None
+
+
+def get():
+    """The product library.  Raises if libcpc_hip.so has not been built."""
+    global _bound
+    if _bound is None:
+        with _lock:
+            if _bound is None:
+                if not os.path.exists(LIB_PATH):
+                    raise CpcHipError(
+                        f"{LIB_PATH} not found: build it with `python -m cpc_audio_amd.build` "
+                        "(hipcc, gfx950).  There is no CPU fallback.")
+                import torch  # noqa: F401  (loads torch's libamdhip64 first so both share one HIP runtime)
+                _bound = bind(LIB_PATH)
+    return _bound
+
+
+def ptr(t):
+    """Device (or host, in emulator tests) pointer of a contiguous tensor; None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "cpc_hip expects contiguous tensors"
+    return t.data_ptr()
+
+
+def ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+    return arr

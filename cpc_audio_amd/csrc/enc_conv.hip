@@ -1,0 +1,661 @@
+// Encoder layers 1..4: Conv1d(256 -> 256, k = 2s) + bias + ChannelNorm + ReLU and their
+// backward, as implicit GEMMs on the exact-f32 matrix pipe.
+//
+// Reference: cpc/model.py:85-92 (conv1: k8 s4 p2; conv2-4: k4 s2 p1), :50-58
+// (ChannelNorm), :101-104 (relu(norm(conv))).
+//
+// Layout: activations are channels-last (B, L, C) in HBM, so
+//   * the im2col row of output step t is the CONTIGUOUS window x[b, t*s-p : t*s-p+k, :]
+//     (k*256 floats): the conv is a plain NT GEMM  out[M=B*Lout, 256] = A[M, k*256] . Wp^T
+//     with overlapping A rows and zero padding expressed by RowMap (gemm_tile.h);
+//   * a block owns whole rows (all 256 output channels), so ChannelNorm's mean /
+//     unbiased variance are reductions of accumulator registers (half-wave
+//     shuffles + a 4-entry LDS exchange across the 4 N-waves) and the layer writes
+//     its normalised (xhat) and rectified (y) rows straight from registers;
+//   * dgrad (k = 2s) is s independent "phase" GEMMs with K = 512: input step tau with
+//     (tau+p) = q*s + r receives  dx[q-1] . W[:,:,r+s] + dx[q] . W[:,:,r], again a
+//     contiguous 2-row window of the (B, Lout, C) gradient; its epilogue applies the
+//     PREVIOUS layer's ReLU'/ChannelNorm backward in registers and emits that layer's
+//     pre-norm gradient plus per-block column partials for d(norm weight/bias) and
+//     d(conv bias);
+//   * wgrad is a TN GEMM  dWp[256, k*256] = dx^T . A  split over row ranges, reduced
+//     in a fixed order and permuted back to PyTorch's (O, I, W) layout.
+#include <algorithm>
+
+#include "cpc_common.h"
+#include "cpc_internal.h"
+#include "gemm_tile.h"
+
+namespace cpc {
+
+// ------------------------------------------------------------------ weight re-layouts
+// (O,I,W) -> Wp[co][kk*C + ci]  (K-major rows for the forward NT GEMM)
+__global__ __launch_bounds__(256) void permute_w_fwd_kernel(const float* __restrict__ w,
+                                                            float* __restrict__ wp, int k) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)kC * k * kC;
+    if (idx >= total) return;
+    const int co = (int)(idx / (k * kC));
+    const int rem = (int)(idx - (long)co * k * kC);
+    const int kk = rem >> kCLog2, ci = rem & (kC - 1);
+    wp[idx] = w[((long)co * kC + ci) * k + kk];
+}
+
+// (O,I,W) -> Wd[r][ci][j*C + co] = W[co][ci][r + (1-j)*s],  r < s, j in {0,1}
+__global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __restrict__ w,
+                                                              float* __restrict__ wd, int s) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)s * kC * 2 * kC;
+    if (idx >= total) return;
+    const int k = 2 * s;
+    const int r = (int)(idx / (kC * 2 * kC));
+    const int rem = (int)(idx - (long)r * kC * 2 * kC);
+    const int ci = rem / (2 * kC);
+    const int jc = rem - ci * 2 * kC;
+    const int j = jc >> kCLog2, co = jc & (kC - 1);
+    wd[idx] = w[((long)co * kC + ci) * k + r + (1 - j) * s];
+}
+
+// ------------------------------------------------------------------ forward
+template <int BM>
+struct ConvCfg {
+    static constexpr int WAVES_M = BM >= 128 ? 2 : 1;
+    using Tile = NtTile<BM, kC, WAVES_M, 4>;
+};
+
+template <int BM>
+__global__ __launch_bounds__(ConvCfg<BM>::Tile::NTHREADS) void conv_fwd_kernel(
+    RowMap am, const float* __restrict__ wp, int K, const float* __restrict__ bias,
+    const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
+    float* __restrict__ xhat, float* __restrict__ rstd_out) {
+    using Tile = typename ConvCfg<BM>::Tile;
+    constexpr int TM = Tile::TM, TN = Tile::TN;
+    __shared__ float smem[Tile::SMEM_FLOATS];
+    __shared__ float red[BM][4];
+    const int m0 = blockIdx.x * BM;
+    f32x16 acc[TM][TN];
+    zero_acc(acc);
+    Tile::run(acc, am, m0, wp, K, 0, K, smem);
+
+    const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 3;
+    int col[TN];
+    float gw[TN], gb[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        col[tn] = Tile::c_col(tn);
+        const float bc = bias[col[tn]];
+        gw[tn] = nw[col[tn]];
+        gb[tn] = nb[col[tn]];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] += bc;
+    }
+    // ---- ChannelNorm statistics, two passes over the accumulators (cpc/model.py:52-54)
+    float mean[TM][16], rstd[TM][16];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) v += acc[tm][tn][r];
+            v = half_wave_sum(v);
+            if ((lane & 31) == 0) red[Tile::c_row(tm, r)][wn] = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = Tile::c_row(tm, r);
+            mean[tm][r] = ((red[row][0] + red[row][1]) + (red[row][2] + red[row][3])) * (1.0f / kC);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const float d = acc[tm][tn][r] - mean[tm][r];
+                v = fmaf(d, d, v);
+            }
+            v = half_wave_sum(v);
+            if ((lane & 31) == 0) red[Tile::c_row(tm, r)][wn] = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = Tile::c_row(tm, r);
+            const float var = ((red[row][0] + red[row][1]) + (red[row][2] + red[row][3])) * (1.0f / (kC - 1));
+            rstd[tm][r] = 1.0f / sqrtf(var + kNormEps);
+            const int m = m0 + row;
+            if (m < am.M) {
+                if (wn == 0 && (lane & 31) == 0) rstd_out[m] = rstd[tm][r];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const float xh = (acc[tm][tn][r] - mean[tm][r]) * rstd[tm][r];
+                    xhat[(long)m * kC + col[tn]] = xh;
+                    y[(long)m * kC + col[tn]] = fmaxf(fmaf(xh, gw[tn], gb[tn]), 0.f);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------ norm backward helpers
+// ReLU' + ChannelNorm backward for one row (cpc/model.py:50-58 differentiated):
+//   dyh = dy * [y > 0];  dxh = dyh * w;
+//   dx  = rstd * (dxh - mean_c(dxh) - xhat * sum_c(dxh*xhat) / (C-1))      (unbiased variance)
+// plus column sums  d(norm w) += dyh*xhat,  d(norm b) += dyh,  d(conv bias) += dx.
+
+// stand-alone version for the top layer (its dy comes from autograd, not from a dgrad GEMM)
+constexpr int NB_ROWS = 32;   // rows per block (8 per wave)
+__global__ __launch_bounds__(256) void norm_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ y,
+    const float* __restrict__ rstd, const float* __restrict__ nw, float* __restrict__ dx,
+    float* __restrict__ colpart, int M) {
+    __shared__ float red[4][3][kC];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = lane * 4;
+    const float4 w4 = *reinterpret_cast<const float4*>(nw + c);
+    const float gw[4] = {w4.x, w4.y, w4.z, w4.w};
+    float cs[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cs[a][q] = 0.f;
+    for (int rr = wv; rr < NB_ROWS; rr += 4) {
+        const int m = blockIdx.x * NB_ROWS + rr;
+        if (m >= M) break;                     // wave-uniform
+        const float4 g4 = *reinterpret_cast<const float4*>(dy + (long)m * kC + c);
+        const float4 x4 = *reinterpret_cast<const float4*>(xhat + (long)m * kC + c);
+        const float4 y4 = *reinterpret_cast<const float4*>(y + (long)m * kC + c);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const float xh[4] = {x4.x, x4.y, x4.z, x4.w};
+        const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+        const float rs = rstd[m];
+        float dxh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float dyh = yv[q] > 0.f ? g[q] : 0.f;
+            cs[0][q] = fmaf(dyh, xh[q], cs[0][q]);
+            cs[1][q] += dyh;
+            dxh[q] = dyh * gw[q];
+            s1 += dxh[q];
+            s2 = fmaf(dxh[q], xh[q], s2);
+        }
+        s1 = wave_sum(s1) * (1.0f / kC);
+        s2 = wave_sum(s2) * (1.0f / (kC - 1));
+        float4 o;
+        float ov[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ov[q] = rs * (dxh[q] - s1 - xh[q] * s2);
+            cs[2][q] += ov[q];
+        }
+        o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
+        *reinterpret_cast<float4*>(dx + (long)m * kC + c) = o;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wv][a][c + q] = cs[a][q];
+    __syncthreads();
+    float* prow = colpart + (long)blockIdx.x * (3 * kC);
+    for (int i = tid; i < 3 * kC; i += 256) {
+        const int a = i >> kCLog2, cc = i & (kC - 1);
+        prow[i] = (red[0][a][cc] + red[1][a][cc]) + (red[2][a][cc] + red[3][a][cc]);
+    }
+}
+
+// ------------------------------------------------------------------ dgrad (+ fused norm backward)
+// grid = (row tiles over B*(Lout+1), s phases).  am = 2-row windows over dx of THIS layer.
+template <int BM, bool FUSE>
+__global__ __launch_bounds__(ConvCfg<BM>::Tile::NTHREADS) void conv_dgrad_kernel(
+    RowMap am, const float* __restrict__ wd, int s, int p, int Lin,
+    const float* __restrict__ xhat_prev, const float* __restrict__ y_prev,
+    const float* __restrict__ rstd_prev, const float* __restrict__ nw_prev,
+    float* __restrict__ dprev, float* __restrict__ colpart) {
+    using Tile = typename ConvCfg<BM>::Tile;
+    constexpr int TM = Tile::TM, TN = Tile::TN, WAVES_M = ConvCfg<BM>::WAVES_M;
+    __shared__ float smem[Tile::SMEM_FLOATS];
+    __shared__ float red[2][BM][4];
+    __shared__ float colsum[3][kC];
+    const int m0 = blockIdx.x * BM;
+    const int ph = blockIdx.y;
+    f32x16 acc[TM][TN];
+    zero_acc(acc);
+    Tile::run(acc, am, m0, wd + (long)ph * kC * 2 * kC, 2 * kC, 0, 2 * kC, smem);
+
+    const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 3;
+    int col[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) col[tn] = Tile::c_col(tn);
+
+    // output row of every accumulator row: m -> (b, q) -> tau = q*s + ph - p
+    int orow[TM][16];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + Tile::c_row(tm, r);
+            int o = -1;
+            if (m < am.M) {
+                const int b = m / am.R, q = m - b * am.R;
+                const int tau = q * s + ph - p;
+                if ((unsigned)tau < (unsigned)Lin) o = b * Lin + tau;
+            }
+            orow[tm][r] = o;
+        }
+
+    if (!FUSE) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (orow[tm][r] >= 0) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) dprev[(long)orow[tm][r] * kC + col[tn]] = acc[tm][tn][r];
+                }
+        return;
+    }
+
+    float gw[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) gw[tn] = nw_prev[col[tn]];
+    for (int i = threadIdx.x; i < 3 * kC; i += Tile::NTHREADS) (&colsum[0][0])[i] = 0.f;
+
+    f32x16 xh[TM][TN];
+    float cs_w[TN], cs_b[TN], cs_c[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) { cs_w[tn] = 0.f; cs_b[tn] = 0.f; cs_c[tn] = 0.f; }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = orow[tm][r];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                float xv = 0.f, dxh = 0.f;
+                if (o >= 0) {
+                    xv = xhat_prev[(long)o * kC + col[tn]];
+                    const float yv = y_prev[(long)o * kC + col[tn]];
+                    const float dyh = yv > 0.f ? acc[tm][tn][r] : 0.f;
+                    cs_w[tn] = fmaf(dyh, xv, cs_w[tn]);
+                    cs_b[tn] += dyh;
+                    dxh = dyh * gw[tn];
+                }
+                xh[tm][tn][r] = xv;
+                acc[tm][tn][r] = dxh;
+                s1 += dxh;
+                s2 = fmaf(dxh, xv, s2);
+            }
+            s1 = half_wave_sum(s1);
+            s2 = half_wave_sum(s2);
+            if ((lane & 31) == 0) {
+                red[0][Tile::c_row(tm, r)][wn] = s1;
+                red[1][Tile::c_row(tm, r)][wn] = s2;
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = orow[tm][r];
+            const int row = Tile::c_row(tm, r);
+            const float S1 = ((red[0][row][0] + red[0][row][1]) + (red[0][row][2] + red[0][row][3])) * (1.0f / kC);
+            const float S2 = ((red[1][row][0] + red[1][row][1]) + (red[1][row][2] + red[1][row][3])) * (1.0f / (kC - 1));
+            if (o >= 0) {
+                const float rs = rstd_prev[o];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const float dx = rs * (acc[tm][tn][r] - S1 - xh[tm][tn][r] * S2);
+                    cs_c[tn] += dx;
+                    dprev[(long)o * kC + col[tn]] = dx;
+                }
+            }
+        }
+    // column partials: merge the two half-waves, then the WAVES_M waves sharing a column
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        float a = cs_w[tn], b2 = cs_b[tn], c2 = cs_c[tn];
+        a += __shfl_xor(a, 32);
+        b2 += __shfl_xor(b2, 32);
+        c2 += __shfl_xor(c2, 32);
+        if (lane < 32) {
+            if (WAVES_M == 1) {
+                colsum[0][col[tn]] = a; colsum[1][col[tn]] = b2; colsum[2][col[tn]] = c2;
+            } else {          // two contributions per column: the sum is order-independent
+                atomicAdd(&colsum[0][col[tn]], a);
+                atomicAdd(&colsum[1][col[tn]], b2);
+                atomicAdd(&colsum[2][col[tn]], c2);
+            }
+        }
+    }
+    __syncthreads();
+    float* prow = colpart + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (3 * kC);
+    for (int i = threadIdx.x; i < 3 * kC; i += Tile::NTHREADS) prow[i] = (&colsum[0][0])[i];
+}
+
+// ------------------------------------------------------------------ wgrad
+using WgTile = TnTile<128, 128, 2, 2>;
+// grid = (K/128, 2, S);  part[z][co][K]
+__global__ __launch_bounds__(WgTile::NTHREADS) void conv_wgrad_kernel(
+    RowMap dxm, RowMap im, int K, int rows_per_split, float* __restrict__ part) {
+    __shared__ float smem[WgTile::SMEM_FLOATS];
+    const int n0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
+    const int mbeg = blockIdx.z * rows_per_split;
+    const int mend = min(dxm.M, mbeg + rows_per_split);
+    f32x16 acc[WgTile::TM][WgTile::TN];
+    zero_acc(acc);
+    WgTile::run(acc, dxm, c0, im, n0, mbeg, mend, smem);
+    float* out = part + (long)blockIdx.z * kC * K;
+#pragma unroll
+    for (int tm = 0; tm < WgTile::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = c0 + WgTile::c_row(tm, r);
+#pragma unroll
+            for (int tn = 0; tn < WgTile::TN; ++tn)
+                out[(long)row * K + n0 + WgTile::c_col(tn)] = acc[tm][tn][r];
+        }
+}
+
+// dW[co][ci][kk] = sum_z part[z][co][kk*C + ci]   (fixed summation order)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int S,
+                                                           int k, float* __restrict__ dw) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)kC * k * kC;
+    if (idx >= total) return;
+    float sum = 0.f;
+    for (int z = 0; z < S; ++z) sum += part[(long)z * total + idx];
+    const int co = (int)(idx / (k * kC));
+    const int rem = (int)(idx - (long)co * k * kC);
+    const int kk = rem >> kCLog2, ci = rem & (kC - 1);
+    dw[((long)co * kC + ci) * k + kk] = sum;
+}
+
+// ------------------------------------------------------------------ host side
+struct ConvGeom { int k, s, p; };
+static const ConvGeom kGeom[5] = {{10, 5, 3}, {8, 4, 2}, {4, 2, 1}, {4, 2, 1}, {4, 2, 1}};
+
+static inline long align64(long v) { return (v + 63) & ~63L; }
+
+struct EncLayout {
+    int L[5];
+    long y[4], xhat[5], rstd[5], mean0;    // offsets (floats) into the saved workspace
+    long saved_total;
+    long wp[5];                            // forward scratch: permuted weights (1..4)
+    long fwd_total;
+    // backward scratch
+    long wd[5], dx[5], dy0, part, colpart, tmp, small, conv0;
+    long bwd_total;
+    int wg_splits[5], wg_rows[5];
+};
+
+static int g_force_bm = 0;   // 0 = choose by problem size; 32/64/128 = tuning / test override
+static int pick_bm(int M) {
+    if (g_force_bm) return g_force_bm;
+    return M >= 128 * 512 ? 128 : (M >= 64 * 512 ? 64 : 32);
+}
+
+static bool enc_layout(int B, int Lw, EncLayout& e) {
+    int lin = Lw;
+    for (int i = 0; i < 5; ++i) {
+        if (lin + 2 * kGeom[i].p < kGeom[i].k) return false;
+        e.L[i] = conv_out_len(lin, kGeom[i].k, kGeom[i].s, kGeom[i].p);
+        if (e.L[i] <= 0) return false;
+        lin = e.L[i];
+    }
+    long o = 0;
+    for (int i = 0; i < 4; ++i) { e.y[i] = o; o += align64((long)B * e.L[i] * kC); }
+    e.xhat[0] = -1;
+    for (int i = 1; i < 5; ++i) { e.xhat[i] = o; o += align64((long)B * e.L[i] * kC); }
+    for (int i = 0; i < 5; ++i) { e.rstd[i] = o; o += align64((long)B * e.L[i]); }
+    e.mean0 = o; o += align64((long)B * e.L[0]);
+    e.saved_total = o;
+
+    o = 0;
+    e.wp[0] = -1;
+    for (int i = 1; i < 5; ++i) { e.wp[i] = o; o += (long)kC * kGeom[i].k * kC; }
+    e.fwd_total = o;
+
+    o = 0;
+    e.wd[0] = -1;
+    for (int i = 1; i < 5; ++i) { e.wd[i] = o; o += (long)kC * kGeom[i].k * kC; }
+    e.dx[0] = -1;
+    for (int i = 1; i < 5; ++i) { e.dx[i] = o; o += align64((long)B * e.L[i] * kC); }
+    e.dy0 = o; o += align64((long)B * e.L[0] * kC);
+    long part_max = 0, col_max = 0;
+    for (int i = 1; i < 5; ++i) {
+        const int M = B * e.L[i], K = kGeom[i].k * kC;
+        const int tiles = 2 * (K / 128);
+        int S = cdiv(768, tiles);                       // aim for >= 768 blocks
+        int rows = cdiv(cdiv(M, S), 16) * 16;
+        if (rows < 256) rows = 256;
+        S = cdiv(M, rows);
+        e.wg_splits[i] = S; e.wg_rows[i] = rows;
+        part_max = std::max(part_max, (long)S * kC * K);
+        // dgrad of layer i (i >= 2) writes colpart of layer i-1; norm_bwd writes layer 4's
+        if (i >= 2) {
+            const int Md = B * (e.L[i] + 1);
+            col_max = std::max(col_max, (long)cdiv(Md, pick_bm(Md)) * kGeom[i].s);
+        }
+    }
+    col_max = std::max(col_max, (long)cdiv(B * e.L[4], NB_ROWS));
+    e.part = o; o += align64(part_max);
+    e.colpart = o; o += align64(col_max * 3 * kC);
+    e.tmp = o; o += align64(64L * 3 * kC);
+    e.small = o; o += align64(5L * 3 * kC);
+    e.conv0 = o; o += align64(cpc_conv0_backward_scratch_floats(B, Lw));
+    e.bwd_total = o;
+    return true;
+}
+
+template <int BM>
+static void launch_conv_fwd(const RowMap& am, const float* wp, int K, const float* bias,
+                            const float* nw, const float* nb, float* y, float* xhat, float* rstd,
+                            hipStream_t st) {
+    hipLaunchKernelGGL((conv_fwd_kernel<BM>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM>::Tile::NTHREADS),
+                       0, st, am, wp, K, bias, nw, nb, y, xhat, rstd);
+}
+
+template <int BM, bool FUSE>
+static void launch_conv_dgrad(const RowMap& am, const float* wd, int s, int p, int Lin,
+                              const float* xhat_prev, const float* y_prev, const float* rstd_prev,
+                              const float* nw_prev, float* dprev, float* colpart, hipStream_t st) {
+    hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE>), dim3(cdiv(am.M, BM), s),
+                       dim3(ConvCfg<BM>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
+                       rstd_prev, nw_prev, dprev, colpart);
+}
+
+}  // namespace cpc
+
+using namespace cpc;
+
+extern "C" int cpc_set_conv_tile(int bm) {
+    CPC_RETURN_IF(bm != 0 && bm != 32 && bm != 64 && bm != 128, CPC_ERR_ARG);
+    g_force_bm = bm;
+    return 0;
+}
+
+// One conv layer forward (layers 1..4): x (B,Lin,C) -> y, xhat (B,Lout,C), rstd (B*Lout).
+// wp is scratch for the permuted weight (256*k*256 floats).
+extern "C" int cpc_conv_layer_forward(const float* x, const float* w, const float* bias,
+                                      const float* nw, const float* nb, float* wp, float* y,
+                                      float* xhat, float* rstd, int B, int Lin, int k, int s, int p,
+                                      void* stream) {
+    CPC_RETURN_IF(B <= 0 || Lin <= 0 || k != 2 * s || Lin + 2 * p < k, CPC_ERR_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const int Lout = conv_out_len(Lin, k, s, p);
+    const long nw_elems = (long)kC * k * kC;
+    hipLaunchKernelGGL(permute_w_fwd_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wp, k);
+    const RowMap am = conv_rows(x, B, Lin, Lout, s, p);
+    const int K = k * kC;
+    switch (pick_bm(am.M)) {
+        case 128: launch_conv_fwd<128>(am, wp, K, bias, nw, nb, y, xhat, rstd, st); break;
+        case 64: launch_conv_fwd<64>(am, wp, K, bias, nw, nb, y, xhat, rstd, st); break;
+        default: launch_conv_fwd<32>(am, wp, K, bias, nw, nb, y, xhat, rstd, st); break;
+    }
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ReLU'/ChannelNorm backward of a whole (M,256) activation: dy -> dx, plus
+// small3 = [d norm.weight | d norm.bias | d conv.bias] (3*256 floats).
+// colpart: cdiv(M,32)*768 floats, tmp: 64*768 floats.
+extern "C" int cpc_norm_backward(const float* dy, const float* xhat, const float* y,
+                                 const float* rstd, const float* nw, float* dx, float* colpart,
+                                 float* tmp, float* small3, int M, void* stream) {
+    CPC_RETURN_IF(M <= 0, CPC_ERR_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = cdiv(M, NB_ROWS);
+    hipLaunchKernelGGL(norm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, xhat, y, rstd, nw, dx, colpart, M);
+    CPC_LAUNCH_CHECK();
+    return rows_sum(colpart, nblk, 3 * kC, tmp, small3, st);
+}
+
+// dgrad of one conv layer (k = 2s).  dx: (B,Lout,C) pre-norm gradient of THIS layer.
+// fuse != 0: also applies the previous layer's ReLU'/ChannelNorm backward and writes that
+//   layer's pre-norm gradient to dprev (B,Lin,C) and its small3 gradients;
+// fuse == 0: writes the gradient w.r.t. the previous layer's OUTPUT to dprev.
+extern "C" int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, int fuse,
+                                    const float* xhat_prev, const float* y_prev,
+                                    const float* rstd_prev, const float* nw_prev, float* dprev,
+                                    float* colpart, float* tmp, float* small3, int B, int Lin, int k,
+                                    int s, int p, void* stream) {
+    CPC_RETURN_IF(B <= 0 || Lin <= 0 || k != 2 * s || Lin + 2 * p < k, CPC_ERR_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const int Lout = conv_out_len(Lin, k, s, p);
+    const long nw_elems = (long)kC * k * kC;
+    hipLaunchKernelGGL(permute_w_dgrad_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wd, s);
+    // 2-row windows [q-1, q] over dx, q in [0, Lout]
+    RowMap am;
+    am.base = dx; am.R = Lout + 1; am.bstride = (long)Lout * kC; am.rstride = kC; am.off = -kC;
+    am.tmul = 1; am.tadd = -1; am.Lin = Lout; am.M = B * (Lout + 1);
+    const int bm = pick_bm(am.M);
+    const int nblk = cdiv(am.M, bm) * s;
+    if (fuse) {
+        switch (bm) {
+            case 128: launch_conv_dgrad<128, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, st); break;
+            case 64: launch_conv_dgrad<64, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, st); break;
+            default: launch_conv_dgrad<32, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, st); break;
+        }
+        CPC_LAUNCH_CHECK();
+        return rows_sum(colpart, nblk, 3 * kC, tmp, small3, st);
+    }
+    switch (bm) {
+        case 128: launch_conv_dgrad<128, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, st); break;
+        case 64: launch_conv_dgrad<64, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, st); break;
+        default: launch_conv_dgrad<32, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, st); break;
+    }
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// wgrad of one conv layer: dW (256,256,k) = sum over rows of dx (B,Lout,C) (x) im2col(x).
+// part: splits*256*k*256 floats of scratch.
+extern "C" int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part, float* dW, int B,
+                                    int Lin, int k, int s, int p, int splits, int rows_per_split,
+                                    void* stream) {
+    CPC_RETURN_IF(B <= 0 || Lin <= 0 || Lin + 2 * p < k || splits <= 0 || rows_per_split <= 0, CPC_ERR_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    const int Lout = conv_out_len(Lin, k, s, p);
+    const int K = k * kC;
+    const RowMap dxm = plain_rows(dx, B * Lout, kC);
+    const RowMap im = conv_rows(x, B, Lin, Lout, s, p);
+    CPC_RETURN_IF((long)splits * rows_per_split < dxm.M, CPC_ERR_SHAPE);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(K / 128, 2, splits), dim3(WgTile::NTHREADS), 0, st, dxm,
+                       im, K, rows_per_split, part);
+    const long total = (long)kC * k * kC;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, part, splits, k, dW);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- composite encoder -------------------------------------------------------------
+// sizes[0] = saved workspace floats, [1] = forward scratch floats, [2] = backward scratch floats,
+// [3..7] = L0..L4, [8..11] = offsets of y0..y3, [12..15] = offsets of xhat1..4,
+// [16..20] = offsets of rstd0..4, [21] = offset of mean0   (all in floats, into `saved`)
+extern "C" int cpc_encoder_layout(int B, int L, long* sizes) {
+    EncLayout e;
+    CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
+    sizes[0] = e.saved_total; sizes[1] = e.fwd_total; sizes[2] = e.bwd_total;
+    for (int i = 0; i < 5; ++i) sizes[3 + i] = e.L[i];
+    for (int i = 0; i < 4; ++i) sizes[8 + i] = e.y[i];
+    for (int i = 1; i < 5; ++i) sizes[11 + i] = e.xhat[i];
+    for (int i = 0; i < 5; ++i) sizes[16 + i] = e.rstd[i];
+    sizes[21] = e.mean0;
+    return 0;
+}
+
+// params: 20 pointers in the reference's state-dict order
+//   conv{i}.weight, conv{i}.bias, batchNorm{i}.weight, batchNorm{i}.bias  for i = 0..4
+extern "C" int cpc_encoder_forward(const float* wave, const float* const* params, float* saved,
+                                   float* scratch, float* z, int B, int L, void* stream) {
+    EncLayout e;
+    CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
+    int rc = cpc_conv0_forward(wave, params[0], params[1], params[2], params[3], saved + e.y[0],
+                               saved + e.mean0, saved + e.rstd[0], B, L, stream);
+    if (rc) return rc;
+    for (int i = 1; i < 5; ++i) {
+        float* yo = i == 4 ? z : saved + e.y[i];
+        rc = cpc_conv_layer_forward(saved + e.y[i - 1], params[4 * i], params[4 * i + 1], params[4 * i + 2],
+                                    params[4 * i + 3], scratch + e.wp[i], yo, saved + e.xhat[i],
+                                    saved + e.rstd[i], B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// grads: 20 output pointers in the same order as params (each overwritten).
+extern "C" int cpc_encoder_backward(const float* wave, const float* const* params,
+                                    const float* saved, const float* z, const float* dz,
+                                    float* scratch, float* const* grads, int B, int L, void* stream) {
+    EncLayout e;
+    CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    float* colpart = scratch + e.colpart;
+    float* tmp = scratch + e.tmp;
+    float* small = scratch + e.small;          // [5][3][256]
+    // top layer: ReLU'/norm backward of dz
+    int rc = cpc_norm_backward(dz, saved + e.xhat[4], z, saved + e.rstd[4], params[18], scratch + e.dx[4],
+                               colpart, tmp, small + 4 * 3 * kC, B * e.L[4], stream);
+    if (rc) return rc;
+    for (int i = 4; i >= 1; --i) {
+        const float* xin = saved + e.y[i - 1];
+        rc = cpc_conv_layer_wgrad(scratch + e.dx[i], xin, scratch + e.part, grads[4 * i], B, e.L[i - 1],
+                                  kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], stream);
+        if (rc) return rc;
+        if (i >= 2) {
+            rc = cpc_conv_layer_dgrad(scratch + e.dx[i], params[4 * i], scratch + e.wd[i], 1,
+                                      saved + e.xhat[i - 1], xin, saved + e.rstd[i - 1], params[4 * (i - 1) + 2],
+                                      scratch + e.dx[i - 1], colpart, tmp, small + (i - 1) * 3 * kC, B,
+                                      e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, stream);
+        } else {
+            rc = cpc_conv_layer_dgrad(scratch + e.dx[1], params[4], scratch + e.wd[1], 0, nullptr, nullptr,
+                                      nullptr, nullptr, scratch + e.dy0, nullptr, nullptr, nullptr, B, e.L[0],
+                                      kGeom[1].k, kGeom[1].s, kGeom[1].p, stream);
+        }
+        if (rc) return rc;
+    }
+    rc = cpc_conv0_backward(wave, params[0], params[1], params[2], params[3], saved + e.mean0,
+                            saved + e.rstd[0], scratch + e.dy0, scratch + e.conv0, grads[0], grads[1],
+                            grads[2], grads[3], B, L, stream);
+    if (rc) return rc;
+    // layers 1..4: small[i] = [d norm.weight | d norm.bias | d conv.bias]
+    for (int i = 1; i < 5; ++i) {
+        const float* s3 = small + i * 3 * kC;
+        (void)hipMemcpyAsync(grads[4 * i + 2], s3, sizeof(float) * kC, hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(grads[4 * i + 3], s3 + kC, sizeof(float) * kC, hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(grads[4 * i + 1], s3 + 2 * kC, sizeof(float) * kC, hipMemcpyDeviceToDevice, st);
+    }
+    CPC_LAUNCH_CHECK();
+    return 0;
+}

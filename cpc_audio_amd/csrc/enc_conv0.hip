@@ -1,0 +1,249 @@
+// Encoder layer 0:  conv0 (1 -> 256, k=10, s=5, p=3) + bias + ChannelNorm + ReLU, fused.
+//
+// Reference: cpc/model.py:83 (conv0), :50-58 (ChannelNorm), :100 (relu(norm(conv))).
+//
+// This is the one HBM-bound layer of the stack (21 MFLOP vs 4.2 MB of output per
+// 1.28 s window, ~5 FLOP/B): the waveform window of a tile is staged once in LDS
+// (coalesced contiguous read), every wave owns whole time steps so all 256
+// channels of a step live in one wavefront (4 per lane), the mean / unbiased
+// variance are wavefront-shuffle reductions, and the normalised, rectified row is
+// written exactly once as one coalesced 1 KB row of the channels-last (B, L0, C)
+// activation.  Only mean and rstd (8 B per step) are kept for the backward pass,
+// which recomputes the 10-tap conv instead of re-reading a 4 MB pre-norm tensor.
+#include "cpc_common.h"
+#include "cpc_internal.h"
+
+namespace cpc {
+
+constexpr int K0 = 10, S0 = 5, P0 = 3;     // conv0 geometry, cpc/model.py:83
+constexpr int C0_TT = 32;                  // time steps per block (8 per wave)
+constexpr int C0_NS = S0 * C0_TT + (K0 - S0);   // staged samples per block
+
+__global__ __launch_bounds__(256) void conv0_fwd_kernel(
+    const float* __restrict__ wave, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, int L, int L0) {
+    __shared__ float smp[C0_NS];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * C0_TT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* wb = wave + (long)b * L;
+    const int s_begin = t0 * S0 - P0;
+    for (int i = tid; i < C0_NS; i += 256) {
+        int s = s_begin + i;
+        smp[i] = ((unsigned)s < (unsigned)L) ? wb[s] : 0.f;
+    }
+    float wr[4][K0], br[4], gw[4], gb[4];
+    const int c = lane * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < K0; ++j) wr[q][j] = w[(c + q) * K0 + j];
+        br[q] = bias[c + q];
+        gw[q] = nw[c + q];
+        gb[q] = nb[c + q];
+    }
+    __syncthreads();
+    for (int tt = wv; tt < C0_TT; tt += 4) {
+        const int t = t0 + tt;
+        if (t >= L0) break;                      // wave-uniform
+        float x[4] = {br[0], br[1], br[2], br[3]};
+#pragma unroll
+        for (int j = 0; j < K0; ++j) {
+            const float sv = smp[tt * S0 + j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = fmaf(wr[q][j], sv, x[q]);
+        }
+        const float mu = wave_sum((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / kC);
+        float d[4], v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { d[q] = x[q] - mu; v = fmaf(d[q], d[q], v); }
+        v = wave_sum(v);
+        const float rstd = 1.0f / sqrtf(v * (1.0f / (kC - 1)) + kNormEps);
+        float4 o;
+        o.x = fmaxf(fmaf(d[0] * rstd, gw[0], gb[0]), 0.f);
+        o.y = fmaxf(fmaf(d[1] * rstd, gw[1], gb[1]), 0.f);
+        o.z = fmaxf(fmaf(d[2] * rstd, gw[2], gb[2]), 0.f);
+        o.w = fmaxf(fmaf(d[3] * rstd, gw[3], gb[3]), 0.f);
+        const long row = (long)b * L0 + t;
+        *reinterpret_cast<float4*>(y + row * kC + c) = o;
+        if (lane == 0) { mean_out[row] = mu; rstd_out[row] = rstd; }
+    }
+}
+
+// Backward of layer 0.  Per time step it recomputes conv0 -> xhat from the waveform and
+// the saved (mean, rstd), applies relu'/norm backward to the incoming dY (gradient
+// w.r.t. the post-ReLU activation, produced by conv1's dgrad) and accumulates, in
+// registers, the gradients of conv0.weight (256x10), conv0.bias, batchNorm0.weight and
+// batchNorm0.bias.  The waveform needs no gradient (cpc/train.py:81-87), so there is
+// no dgrad.  Each block reduces its waves through LDS and writes one partial row
+// [13][256] to `part`; a second tiny kernel sums the partial rows in a fixed order
+// (deterministic, no float atomics).
+constexpr int C0B_TT = 64;                 // time steps per block in backward (16 per wave)
+constexpr int C0B_NS = S0 * C0B_TT + (K0 - S0);
+constexpr int C0_NACC = K0 + 3;            // 10 weight taps, conv bias, norm weight, norm bias
+
+__global__ __launch_bounds__(256) void conv0_bwd_kernel(
+    const float* __restrict__ wave, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ nw, const float* __restrict__ nb, const float* __restrict__ mean_in,
+    const float* __restrict__ rstd_in, const float* __restrict__ dy, float* __restrict__ part,
+    int L, int L0) {
+    __shared__ float smp[C0B_NS];
+    __shared__ float red[4][C0_NACC][kC];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * C0B_TT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* wb = wave + (long)b * L;
+    const int s_begin = t0 * S0 - P0;
+    for (int i = tid; i < C0B_NS; i += 256) {
+        int s = s_begin + i;
+        smp[i] = ((unsigned)s < (unsigned)L) ? wb[s] : 0.f;
+    }
+    float wr[4][K0], br[4], gw[4], gb[4];
+    const int c = lane * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < K0; ++j) wr[q][j] = w[(c + q) * K0 + j];
+        br[q] = bias[c + q];
+        gw[q] = nw[c + q];
+        gb[q] = nb[c + q];
+    }
+    float acc[4][C0_NACC];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < C0_NACC; ++j) acc[q][j] = 0.f;
+    __syncthreads();
+    for (int tt = wv; tt < C0B_TT; tt += 4) {
+        const int t = t0 + tt;
+        if (t >= L0) break;                      // wave-uniform
+        const long row = (long)b * L0 + t;
+        const float4 g4 = *reinterpret_cast<const float4*>(dy + row * kC + c);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const float mu = mean_in[row], rstd = rstd_in[row];
+        float sv[K0];
+#pragma unroll
+        for (int j = 0; j < K0; ++j) sv[j] = smp[tt * S0 + j];
+        float xh[4], dxh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x = br[q];
+#pragma unroll
+            for (int j = 0; j < K0; ++j) x = fmaf(wr[q][j], sv[j], x);
+            xh[q] = (x - mu) * rstd;
+            const float yv = fmaf(xh[q], gw[q], gb[q]);
+            const float dyh = yv > 0.f ? g[q] : 0.f;        // relu'
+            acc[q][K0 + 1] = fmaf(dyh, xh[q], acc[q][K0 + 1]);   // d batchNorm0.weight
+            acc[q][K0 + 2] += dyh;                               // d batchNorm0.bias
+            dxh[q] = dyh * gw[q];
+            s1 += dxh[q];
+            s2 = fmaf(dxh[q], xh[q], s2);
+        }
+        s1 = wave_sum(s1) * (1.0f / kC);
+        s2 = wave_sum(s2) * (1.0f / (kC - 1));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float dx = rstd * (dxh[q] - s1 - xh[q] * s2);
+            acc[q][K0] += dx;                                    // d conv0.bias
+#pragma unroll
+            for (int j = 0; j < K0; ++j) acc[q][j] = fmaf(dx, sv[j], acc[q][j]);   // d conv0.weight
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < C0_NACC; ++j) red[wv][j][c + q] = acc[q][j];
+    __syncthreads();
+    float* prow = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (C0_NACC * kC);
+    for (int i = tid; i < C0_NACC * kC; i += 256) {
+        const int j = i / kC, cc = i - j * kC;
+        prow[i] = (red[0][j][cc] + red[1][j][cc]) + (red[2][j][cc] + red[3][j][cc]);
+    }
+}
+
+// out[i] = sum_r part[r][i] for i < n, rows summed in index order by a 2-level fixed tree.
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ part, int nrows,
+                                                       int n, int rows_per_block,
+                                                       float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(nrows, r0 + rows_per_block);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += part[(long)r * n + i];
+    out[(long)blockIdx.y * n + i] = s;
+}
+
+
+__global__ __launch_bounds__(256) void conv0_scatter_kernel(const float* __restrict__ sum,
+                                                            float* __restrict__ dW0,
+                                                            float* __restrict__ dB0,
+                                                            float* __restrict__ dNW0,
+                                                            float* __restrict__ dNB0) {
+    const int c = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < K0; ++j) dW0[c * K0 + j] = sum[j * kC + c];   // conv0.weight is (256,1,10)
+    dB0[c] = sum[K0 * kC + c];
+    dNW0[c] = sum[(K0 + 1) * kC + c];
+    dNB0[c] = sum[(K0 + 2) * kC + c];
+}
+
+// sums `nrows` rows of length n in `part` into out[0:n]; `tmp` holds >= 64*n floats.
+int rows_sum(const float* part, int nrows, int n, float* tmp, float* out, hipStream_t stream) {
+    if (nrows <= 0) { (void)hipMemsetAsync(out, 0, sizeof(float) * n, stream); return 0; }
+    int groups = nrows > 64 ? 64 : 1;
+    const int rpb = cdiv(nrows, groups);
+    groups = cdiv(nrows, rpb);
+    if (groups == 1) {
+        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 256), 1), dim3(256), 0, stream, part, nrows, n, nrows, out);
+    } else {
+        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 256), groups), dim3(256), 0, stream, part, nrows, n, rpb, tmp);
+        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 256), 1), dim3(256), 0, stream, tmp, groups, n, groups, out);
+    }
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cpc
+
+using namespace cpc;
+
+extern "C" int cpc_conv0_forward(const float* wave, const float* w, const float* bias,
+                                 const float* nw, const float* nb, float* y, float* mean,
+                                 float* rstd, int B, int L, void* stream) {
+    CPC_RETURN_IF(B <= 0 || L < K0 - 2 * P0, CPC_ERR_SHAPE);
+    const int L0 = conv_out_len(L, K0, S0, P0);
+    hipLaunchKernelGGL(conv0_fwd_kernel, dim3(cdiv(L0, C0_TT), B), dim3(256), 0, (hipStream_t)stream,
+                       wave, w, bias, nw, nb, y, mean, rstd, L, L0);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" long cpc_conv0_backward_scratch_floats(int B, int L) {
+    const int L0 = conv_out_len(L, K0, S0, P0);
+    return ((long)cdiv(L0, C0B_TT) * B + 65) * (C0_NACC * kC);
+}
+
+// grads: dW0 (256*10), dB0 (256), dNW0 (256), dNB0 (256) -- overwritten, not accumulated.
+extern "C" int cpc_conv0_backward(const float* wave, const float* w, const float* bias,
+                                  const float* nw, const float* nb, const float* mean,
+                                  const float* rstd, const float* dy, float* scratch, float* dW0,
+                                  float* dB0, float* dNW0, float* dNB0, int B, int L, void* stream) {
+    CPC_RETURN_IF(B <= 0 || L < K0 - 2 * P0, CPC_ERR_SHAPE);
+    const int L0 = conv_out_len(L, K0, S0, P0);
+    const int nblk = cdiv(L0, C0B_TT) * B;
+    const int n = C0_NACC * kC;
+    float* part = scratch;                        // [nblk][13][256]
+    float* tmp = scratch + (long)nblk * n;        // 64 rows for the first reduction level
+    float* sum = tmp + 64L * n;                   // final [13][256]
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv0_bwd_kernel, dim3(cdiv(L0, C0B_TT), B), dim3(256), 0, st, wave, w, bias,
+                       nw, nb, mean, rstd, dy, part, L, L0);
+    CPC_LAUNCH_CHECK();
+    int rc = rows_sum(part, nblk, n, tmp, sum, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv0_scatter_kernel, dim3(1), dim3(256), 0, st, sum, dW0, dB0, dNW0, dNB0);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}

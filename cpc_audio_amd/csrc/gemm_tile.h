@@ -1,0 +1,329 @@
+// f32-MFMA tile main loops shared by the conv (implicit GEMM), GRU-projection and
+// prediction-head kernels.
+//
+// gfx950 has exact-f32 MFMA (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD = the f32
+// vector peak, bit-identical to an fmaf chain), so the contraction-heavy layers
+// run on the matrix pipe without giving up the 1e-4 fp32 parity bar
+// (/opt/skills/guides/cdna_hip_programming.md section 3).
+//
+// Operand conventions (lane l of a wave64, 32x32x2 form):
+//   A fragment: A[i = l&31][k = l>>5]      B fragment: B[k = l>>5][j = l&31]
+//   C/D:        col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5), reg in [0,16)
+// Inside one BK=16 chunk the contraction index is visited as
+//   kq in {0,1}, j in 0..3:   half-wave h = l>>5 supplies k = 8*kq + 4*h + j
+// so a K-contiguous ("K-major") LDS row is read with ONE ds_read_b128 per 4 MFMA
+// steps, and both operands use the same pairing (the sum over k is order-free).
+#pragma once
+#include "cpc_common.h"
+
+namespace cpc {
+
+// Maps GEMM row m of an operand to memory.  Row m belongs to batch item b = m / R
+// at position t = m % R and starts at  base + b*bstride + t*rstride + off.
+// Element k of that row is a real element iff 0 <= t*tmul + tadd + (k >> 8) < Lin,
+// otherwise it reads as zero: that is how conv zero-padding and the ragged ends of
+// the transposed-conv windows are expressed without padded buffers.
+struct RowMap {
+    const float* base;
+    int R;
+    long bstride;
+    int rstride;
+    int off;
+    int tmul;
+    int tadd;
+    int Lin;
+    int M;
+};
+
+static inline RowMap plain_rows(const float* base, int M, int ld) {
+    RowMap r;
+    r.base = base; r.R = M > 0 ? M : 1; r.bstride = 0; r.rstride = ld; r.off = 0;
+    r.tmul = 0; r.tadd = 0; r.Lin = 0x7fffffff; r.M = M;
+    return r;
+}
+
+// im2col rows of an (B, Lin, C) channels-last activation for a conv (k, s, p):
+// row (b,t) is the contiguous window x[b, t*s-p : t*s-p+k, :]  (k*C floats).
+static inline RowMap conv_rows(const float* x, int B, int Lin, int Lout, int s, int p) {
+    RowMap r;
+    r.base = x; r.R = Lout; r.bstride = (long)Lin * kC; r.rstride = s * kC; r.off = -p * kC;
+    r.tmul = s; r.tadd = -p; r.Lin = Lin; r.M = B * Lout;
+    return r;
+}
+
+struct RowRef {
+    const float* ptr;
+    int tau0;
+};
+
+__device__ __forceinline__ RowRef resolve_row(const RowMap& rm, int m, int mlimit) {
+    RowRef r;
+    if (m < mlimit) {
+        int b = m / rm.R;
+        int t = m - b * rm.R;
+        r.ptr = rm.base + (long)b * rm.bstride + (long)t * rm.rstride + rm.off;
+        r.tau0 = t * rm.tmul + rm.tadd;
+    } else {
+        r.ptr = rm.base;
+        r.tau0 = -(1 << 30);
+    }
+    return r;
+}
+
+__device__ __forceinline__ float4 load_row4(const RowRef& r, int k, int Lin) {
+    int tau = r.tau0 + (k >> kCLog2);
+    if ((unsigned)tau < (unsigned)Lin) return *reinterpret_cast<const float4*>(r.ptr + k);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ float f4c(const float4& v, int j) {
+    return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+}
+
+// ---------------------------------------------------------------------------
+// NT tile:  acc[BM x BN] += A[m0.., 0:K] * B[n0.., 0:K]^T, both operands K-major.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+struct NtTile {
+    static constexpr int BK = 16;
+    static constexpr int LDK = BK + 4;   // 80-byte rows: 16B aligned, conflict-free b128 reads
+    static constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    static constexpr int TM = WM / 32, TN = WN / 32;
+    static constexpr int A_SLOTS = BM * (BK / 4), B_SLOTS = BN * (BK / 4);
+    static constexpr int A_PER = (A_SLOTS + NTHREADS - 1) / NTHREADS;
+    static constexpr int B_PER = (B_SLOTS + NTHREADS - 1) / NTHREADS;
+    static constexpr int STAGE = (BM + BN) * LDK;
+    static constexpr int SMEM_FLOATS = 2 * STAGE;
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+
+    // row of the C tile (relative to m0) held in accumulator register `reg` of tile tm
+    __device__ static __forceinline__ int c_row(int tm, int reg) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        return (wave / WAVES_N) * WM + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    }
+    // column of the C tile (relative to n0) held by this lane for tile tn
+    __device__ static __forceinline__ int c_col(int tn) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        return (wave % WAVES_N) * WN + tn * 32 + (lane & 31);
+    }
+
+    __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int m0,
+                               const float* __restrict__ Bmat, int ldb, int n0, int K,
+                               float* smem) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+        RowRef ar[A_PER];
+        int a_k[A_PER], a_lds[A_PER];
+        bool a_on[A_PER];
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int slot = tid + i * NTHREADS;
+            a_on[i] = slot < A_SLOTS;
+            int r = slot >> 2, kv = slot & 3;
+            ar[i] = resolve_row(am, m0 + r, a_on[i] ? am.M : 0);
+            a_k[i] = kv * 4;
+            a_lds[i] = r * LDK + kv * 4;
+        }
+        const float* bp[B_PER];
+        int b_lds[B_PER];
+        bool b_on[B_PER];
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            int slot = tid + i * NTHREADS;
+            b_on[i] = slot < B_SLOTS;
+            int r = b_on[i] ? (slot >> 2) : 0, kv = slot & 3;
+            bp[i] = Bmat + (long)(n0 + r) * ldb + kv * 4;
+            b_lds[i] = BM * LDK + r * LDK + kv * 4;
+        }
+
+        float4 ra[A_PER], rb[B_PER];
+        const int nk = K / BK;
+
+auto gload = [&](int kc_) __attribute__((always_inline)) {
+            const int k0 = kc_ * BK;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) ra[i] = load_row4(ar[i], k0 + a_k[i], am.Lin);
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+        };
+        auto sstore = [&](int st_) __attribute__((always_inline)) {
+            float* s0 = smem + st_ * STAGE;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i)
+                if (a_on[i]) *reinterpret_cast<float4*>(s0 + a_lds[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i)
+                if (b_on[i]) *reinterpret_cast<float4*>(s0 + b_lds[i]) = rb[i];
+        };
+
+        gload(0);
+        sstore(0);
+        __syncthreads();
+
+        const int arow = wm * WM + (lane & 31);
+        const int brow = wn * WN + (lane & 31);
+        const int kofs = 4 * (lane >> 5);
+
+        auto compute = [&](int cur) __attribute__((always_inline)) {
+            const float* As = smem + cur * STAGE;
+            const float* Bs = As + BM * LDK;
+#pragma unroll
+            for (int kq = 0; kq < BK / 8; ++kq) {
+                float4 af[TM], bf[TN];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    af[tm] = *reinterpret_cast<const float4*>(As + (arow + tm * 32) * LDK + kq * 8 + kofs);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    bf[tn] = *reinterpret_cast<const float4*>(Bs + (brow + tn * 32) * LDK + kq * 8 + kofs);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                f4c(af[tm], j), f4c(bf[tn], j), acc[tm][tn], 0, 0, 0);
+            }
+        };
+        for (int kc = 0; kc + 1 < nk; ++kc) {
+            gload(kc + 1);
+            compute(kc & 1);
+            sstore((kc & 1) ^ 1);
+            __syncthreads();
+        }
+        compute((nk - 1) & 1);
+        __syncthreads();
+    }
+};
+
+// ---------------------------------------------------------------------------
+// TN tile:  acc[BM x BN] += sum_{m in [mbeg,mend)} A[m, c0..c0+BM)^T (x) B[m, n0..n0+BN)
+// The contraction index is the ROW index of both operands ("M-major" LDS tiles,
+// conflict-free ds_read_b32 with consecutive lanes on consecutive columns).
+// Used for every weight gradient: dW = dOut^T . In.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+struct TnTile {
+    static constexpr int BK = 16;
+    static constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    static constexpr int TM = WM / 32, TN = WN / 32;
+    static constexpr int A_SLOTS = BK * (BM / 4), B_SLOTS = BK * (BN / 4);
+    static constexpr int A_PER = (A_SLOTS + NTHREADS - 1) / NTHREADS;
+    static constexpr int B_PER = (B_SLOTS + NTHREADS - 1) / NTHREADS;
+    static constexpr int STAGE = BK * (BM + BN);
+    static constexpr int SMEM_FLOATS = 2 * STAGE;
+
+    __device__ static __forceinline__ int c_row(int tm, int reg) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        return (wave / WAVES_N) * WM + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    }
+    __device__ static __forceinline__ int c_col(int tn) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        return (wave % WAVES_N) * WN + tn * 32 + (lane & 31);
+    }
+
+    __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int c0,
+                               const RowMap& bm, int n0, int mbeg, int mend, float* smem) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+        int a_row[A_PER], a_col[A_PER];
+        bool a_on[A_PER];
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int slot = tid + i * NTHREADS;
+            a_on[i] = slot < A_SLOTS;
+            a_row[i] = slot / (BM / 4);
+            a_col[i] = (slot % (BM / 4)) * 4;
+        }
+        int b_row[B_PER], b_col[B_PER];
+        bool b_on[B_PER];
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            int slot = tid + i * NTHREADS;
+            b_on[i] = slot < B_SLOTS;
+            b_row[i] = slot / (BN / 4);
+            b_col[i] = (slot % (BN / 4)) * 4;
+        }
+        float4 ra[A_PER], rb[B_PER];
+        const int nk = (mend - mbeg + BK - 1) / BK;
+
+auto gload = [&](int kc_) __attribute__((always_inline)) {
+            const int mm = mbeg + kc_ * BK;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const RowRef r = resolve_row(am, mm + a_row[i], a_on[i] ? mend : 0);
+                ra[i] = load_row4(r, c0 + a_col[i], am.Lin);
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) {
+                const RowRef r = resolve_row(bm, mm + b_row[i], b_on[i] ? mend : 0);
+                rb[i] = load_row4(r, n0 + b_col[i], bm.Lin);
+            }
+        };
+        auto sstore = [&](int st_) __attribute__((always_inline)) {
+            float* s0 = smem + st_ * STAGE;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i)
+                if (a_on[i]) *reinterpret_cast<float4*>(s0 + a_row[i] * BM + a_col[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i)
+                if (b_on[i]) *reinterpret_cast<float4*>(s0 + BK * BM + b_row[i] * BN + b_col[i]) = rb[i];
+        };
+
+        if (nk <= 0) return;
+        gload(0);
+        sstore(0);
+        __syncthreads();
+
+        const int acol = wm * WM + (lane & 31);
+        const int bcol = wn * WN + (lane & 31);
+        const int kh = 4 * (lane >> 5);
+
+        auto compute = [&](int cur) __attribute__((always_inline)) {
+            const float* As = smem + cur * STAGE;
+            const float* Bs = As + BK * BM;
+#pragma unroll
+            for (int kq = 0; kq < BK / 8; ++kq) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = kq * 8 + kh + j;
+                    float a[TM], b[TN];
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) a[tm] = As[kk * BM + acol + tm * 32];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[kk * BN + bcol + tn * 32];
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+                }
+            }
+        };
+        for (int kc = 0; kc + 1 < nk; ++kc) {
+            gload(kc + 1);
+            compute(kc & 1);
+            sstore((kc & 1) ^ 1);
+            __syncthreads();
+        }
+        compute((nk - 1) & 1);
+        __syncthreads();
+    }
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+}
+
+}  // namespace cpc

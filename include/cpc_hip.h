@@ -1,0 +1,82 @@
+/* cpc_hip.h -- C ABI of libcpc_hip.so, the MI355X (gfx950) implementation of the
+ * CPC-audio train-step hot path.
+ *
+ * The reference (facebookresearch/CPC_audio) has no FFI: its hot path is a set of
+ * torch.nn.Module classes.  This ABI is what those modules' forward/backward bind to
+ * in the drop-in package (cpc_audio_amd/model.py, criterion.py via ctypes); each entry
+ * point cites the reference code it replaces.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (or int32 where stated), owned by the
+ *     caller (torch's caching allocator); nothing is allocated or retained here;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no syncs;
+ *   - activations are channels-last: (B, L, C) with C = 256 contiguous;
+ *   - return value 0 = ok, CPC_ERR_* = argument error, 1000+e = hipError_t e.
+ */
+#ifndef CPC_HIP_H
+#define CPC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPC_OK 0
+#define CPC_ERR_SHAPE 1        /* unsupported / inconsistent sizes */
+#define CPC_ERR_ARG 2          /* null pointer or bad flag */
+
+/* ABI version, bumped on any signature change. */
+int cpc_abi_version(void);
+
+/* ---------------------------------------------------------------- encoder ----
+ * CPCEncoder.forward, cpc/model.py:99-105:  5 x relu(ChannelNorm(conv_i(x))).
+ * ChannelNorm: cpc/model.py:50-58 (mean / UNBIASED variance over channels, eps 1e-5).
+ */
+
+/* Layer 0 (conv0 1->256 k10 s5 p3, model.py:83,100) fused with norm + ReLU.
+ * wave (B,L); w (256,1,10); bias,nw,nb (256); y (B,L0,256); mean,rstd (B*L0). */
+int cpc_conv0_forward(const float* wave, const float* w, const float* bias, const float* nw,
+                      const float* nb, float* y, float* mean, float* rstd, int B, int L,
+                      void* stream);
+long cpc_conv0_backward_scratch_floats(int B, int L);
+/* Backward of layer 0 (no dgrad: the waveform needs no gradient, train.py:81-87).
+ * dy = gradient w.r.t. y.  Outputs dW0 (256,1,10), dB0, dNW0, dNB0 (256) are overwritten. */
+int cpc_conv0_backward(const float* wave, const float* w, const float* bias, const float* nw,
+                       const float* nb, const float* mean, const float* rstd, const float* dy,
+                       float* scratch, float* dW0, float* dB0, float* dNW0, float* dNB0, int B,
+                       int L, void* stream);
+
+/* Layers 1..4 (256->256, k = 2s; model.py:85-92,101-104): x (B,Lin,256) ->
+ * y = relu(norm(conv)) and xhat (pre-affine normalised), both (B,Lout,256); rstd (B*Lout).
+ * w is PyTorch (O,I,W); wp is 256*k*256 floats of scratch. */
+int cpc_conv_layer_forward(const float* x, const float* w, const float* bias, const float* nw,
+                           const float* nb, float* wp, float* y, float* xhat, float* rstd, int B,
+                           int Lin, int k, int s, int p, void* stream);
+/* ReLU' + ChannelNorm backward over M rows; small3 = [d norm.w | d norm.b | d conv.bias]. */
+int cpc_norm_backward(const float* dy, const float* xhat, const float* y, const float* rstd,
+                      const float* nw, float* dx, float* colpart, float* tmp, float* small3, int M,
+                      void* stream);
+int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, int fuse,
+                         const float* xhat_prev, const float* y_prev, const float* rstd_prev,
+                         const float* nw_prev, float* dprev, float* colpart, float* tmp,
+                         float* small3, int B, int Lin, int k, int s, int p, void* stream);
+int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part, float* dW, int B, int Lin,
+                         int k, int s, int p, int splits, int rows_per_split, void* stream);
+
+/* Tuning / test knob: rows per block of the conv GEMM tiles (0 = auto, 32, 64, 128). */
+int cpc_set_conv_tile(int bm);
+
+/* Whole encoder.  params / grads: 20 pointers in the reference's state-dict order
+ * (conv{i}.weight, conv{i}.bias, batchNorm{i}.weight, batchNorm{i}.bias, i = 0..4).
+ * cpc_encoder_layout fills sizes[0..21]: [0] saved floats, [1] fwd scratch floats,
+ * [2] bwd scratch floats, [3..7] L0..L4, then offsets into `saved` (see enc_conv.hip). */
+int cpc_encoder_layout(int B, int L, long* sizes);
+int cpc_encoder_forward(const float* wave, const float* const* params, float* saved,
+                        float* scratch, float* z, int B, int L, void* stream);
+int cpc_encoder_backward(const float* wave, const float* const* params, const float* saved,
+                         const float* z, const float* dz, float* scratch, float* const* grads,
+                         int B, int L, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPC_HIP_H */

@@ -1,0 +1,35 @@
+"""Helpers for the emulator-backed kernel tests (CPU, no GPU needed).
+
+The kernels are compiled for x86 against tests/hipemu (a SIMT interpreter) and called
+through the same C ABI and the same ctypes signature table as the product library."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+
+_emu = None
+
+
+def emu():
+    global _emu
+    if _emu is None:
+        import build_emu
+        from cpc_audio_amd import _lib
+        try:
+            path = build_emu.build()
+        except Exception as e:  # no host clang: cannot emulate
+            pytest.skip(f"emulator build unavailable: {e}")
+        _emu = _lib.bind(path)
+    return _emu
+
+
+def P(t):
+    return None if t is None else t.data_ptr()
+
+
+def rel_err(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()

@@ -1,0 +1,56 @@
+"""Build the kernels for the host SIMT emulator (TEST TOOL ONLY, see include/hip/hip_runtime.h).
+The same .hip sources as the product library, compiled as x86 C++ by clang."""
+import concurrent.futures as cf
+import glob
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "cpc_audio_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libcpc_emu.so")
+
+
+def _cxx():
+    for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("clang++ not found")
+
+
+def build(force=False):
+    os.makedirs(OUT, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(HERE, "hipemu.cpp")]
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + \
+        glob.glob(os.path.join(HERE, "include", "hip", "*.h"))
+    hdr_m = max(os.path.getmtime(h) for h in hdrs)
+    flags = ["-O2", "-std=c++17", "-fPIC", "-x", "c++", "-I", os.path.join(HERE, "include"),
+             "-ffp-contract=off", "-Wno-unused-value", "-Wno-unknown-pragmas", "-Wno-pass-failed",
+             "-Wno-unused-variable"]
+    jobs, objs = [], []
+    for s in srcs:
+        o = os.path.join(OUT, os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_m):
+            jobs.append((s, o))
+
+    def cc(job):
+        s, o = job
+        r = subprocess.run([_cxx(), *flags, "-c", s, "-o", o], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"emu compile failed for {s}:\n{r.stderr[-6000:]}")
+
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=8) as ex:
+            list(ex.map(cc, jobs))
+    if jobs or not os.path.exists(LIB):
+        r = subprocess.run([_cxx(), "-shared", "-fPIC", *objs, "-o", LIB, "-lpthread"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"emu link failed:\n{r.stderr[-4000:]}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build())

@@ -1,0 +1,239 @@
+// hipemu -- a tiny host-side SIMT interpreter for HIP kernels.
+//
+// TEST TOOL ONLY.  It exists so that the index / layout logic of the gfx950
+// kernels in cpc_audio_amd/csrc can be unit-tested in a container with no GPU:
+// the SAME .hip sources are compiled for x86 with this directory first on the
+// include path, so `#include <hip/hip_runtime.h>` resolves here.  The product
+// package never loads the emulated library (cpc_audio_amd/_lib.py only ever opens
+// libcpc_hip.so built by hipcc for gfx950); only tests/test_emu_*.py do.
+//
+// Model: every HIP thread of a block is a user-level fiber; the fibers of one
+// block run on one OS thread in lane order, each until it reaches a barrier or a
+// wave collective (shuffle / MFMA).  Different blocks run on different OS threads.
+// `__shared__` becomes `static thread_local` (one copy per OS thread == per
+// resident block).  Wave size is 64.  MFMA fragment layouts follow
+// /opt/skills/guides/cdna_hip_programming.md section 3.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define HIPEMU 1
+
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+
+typedef struct ihipStream_t* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum hipMemcpyKind { hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+
+namespace hipemu {
+
+enum { RUNNABLE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, DONE = 3 };
+constexpr int WAVE = 64;
+
+struct Fiber {
+    void* sp = nullptr;
+    char* stack = nullptr;
+    int state = DONE;
+    int lin = 0;          // linear thread id in block
+    dim3 tid;
+};
+
+struct WaveBuf {          // double-buffered exchange area for collectives
+    uint32_t a[2][WAVE];
+    uint32_t b[2][WAVE];
+    int phase = 0;        // parity of the collective currently being deposited
+    int waiting = 0;
+    int live = 0;
+};
+
+struct BlockCtx {
+    dim3 bid, bdim, gdim;
+    int nthreads = 0;
+    int block_waiting = 0;
+    int live = 0;
+    std::vector<Fiber> fibers;
+    std::vector<WaveBuf> waves;
+    void* main_sp = nullptr;
+    const std::function<void()>* body = nullptr;
+};
+
+extern thread_local BlockCtx* blk;
+extern thread_local Fiber* cur;
+
+void yield_to_main();           // implemented in hipemu.cpp
+void launch_impl(dim3 grid, dim3 block, const std::function<void()>& body);
+
+inline int lane_id() { return cur->lin & (WAVE - 1); }
+inline WaveBuf& my_wave() { return blk->waves[cur->lin / WAVE]; }
+
+// all live lanes of the calling wave rendezvous here
+inline void wave_sync() {
+    WaveBuf& w = my_wave();
+    cur->state = WAIT_WAVE;
+    yield_to_main();
+}
+
+inline void block_sync() {
+    cur->state = WAIT_BLOCK;
+    yield_to_main();
+}
+
+template <class T> inline uint32_t bits(T v) { static_assert(sizeof(T) == 4, "32-bit only"); uint32_t u; memcpy(&u, &v, 4); return u; }
+template <class T> inline T unbits(uint32_t u) { T v; memcpy(&v, &u, 4); return v; }
+
+// deposit one 32-bit value per lane, rendezvous, return the buffer to read from
+inline const uint32_t* exchange(uint32_t v) {
+    WaveBuf& w = my_wave();
+    int ph = w.phase;                 // all lanes see the same phase for this collective
+    w.a[ph][lane_id()] = v;
+    wave_sync();
+    return w.a[ph];
+}
+
+template <class T> inline T shfl_idx(T v, int src) {
+    const uint32_t* buf = exchange(bits(v));
+    return unbits<T>(buf[src & (WAVE - 1)]);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+inline f32x16 mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) {
+    WaveBuf& w = my_wave();
+    int ph = w.phase, l = lane_id();
+    w.a[ph][l] = bits(a);
+    w.b[ph][l] = bits(b);
+    wave_sync();
+    const uint32_t* A = w.a[ph];      // A[i][k] = A[i + 32k]
+    const uint32_t* B = w.b[ph];      // B[k][j] = B[j + 32k]
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k)
+            acc = fmaf(unbits<float>(A[row + 32 * k]), unbits<float>(B[col + 32 * k]), acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
+inline f32x4 mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) {
+    WaveBuf& w = my_wave();
+    int ph = w.phase, l = lane_id();
+    w.a[ph][l] = bits(a);
+    w.b[ph][l] = bits(b);
+    wave_sync();
+    const uint32_t* A = w.a[ph];      // A[i][k] = A[i + 16k]
+    const uint32_t* B = w.b[ph];      // B[k][j] = B[j + 16k]
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k)
+            acc = fmaf(unbits<float>(A[row + 16 * k]), unbits<float>(B[col + 16 * k]), acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::cur->tid)
+#define blockIdx (hipemu::blk->bid)
+#define blockDim (hipemu::blk->bdim)
+#define gridDim (hipemu::blk->gdim)
+#define warpSize 64
+
+static inline void __syncthreads() { hipemu::block_sync(); }
+template <class T> static inline T __shfl(T v, int src, int width = 64) {
+    int l = hipemu::lane_id();
+    int base = l & ~(width - 1);
+    return hipemu::shfl_idx(v, base + (src & (width - 1)));
+}
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+    (void)width;
+    return hipemu::shfl_idx(v, hipemu::lane_id() ^ mask);
+}
+template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int l = hipemu::lane_id();
+    int src = l + (int)d;
+    if ((src & ~(width - 1)) != (l & ~(width - 1))) src = l;
+    return hipemu::shfl_idx(v, src);
+}
+template <class T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+    int l = hipemu::lane_id();
+    int src = l - (int)d;
+    if (src < 0 || (src & ~(width - 1)) != (l & ~(width - 1))) src = l;
+    return hipemu::shfl_idx(v, src);
+}
+
+static inline float atomicAdd(float* p, float v) {
+    uint32_t* u = reinterpret_cast<uint32_t*>(p);
+    uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED);
+    for (;;) {
+        float f;
+        memcpy(&f, &old, 4);
+        f += v;
+        uint32_t nu;
+        memcpy(&nu, &f, 4);
+        if (__atomic_compare_exchange_n(u, &old, nu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+            float r;
+            memcpy(&r, &old, 4);
+            return r;
+        }
+    }
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline void unsafeAtomicAdd(float* p, float v) { (void)atomicAdd(p, v); }
+
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline float __fdividef(float a, float b) { return a / b; }
+
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_f32_32x32x2f32
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu::mfma_f32_16x16x4f32
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...)                  \
+    do {                                                                            \
+        (void)(smem); (void)(stream);                                               \
+        hipemu::launch_impl((grid), (block), [&]() { kernel(__VA_ARGS__); });       \
+    } while (0)
