@@ -122,15 +122,44 @@ def channel_norm(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor],
     return y
 
 
+class _ReluTieAware(torch.autograd.Function):
+    """relu(x) whose DERIVATIVE, for elements with |x| < eps only, is taken from
+    ``pos_override`` instead of [x > 0].
+
+    Two correct fp32 implementations round a pre-activation of ~1e-7 to different
+    sides of zero about once per million elements; the forward values then differ by
+    < eps (harmless) but d relu / dx flips between 0 and 1, which changes that whole
+    row's ChannelNorm gradient.  Gradient-parity tests therefore hand the device
+    path's mask ([y_device > 0]) to the oracle for those numerically tied elements;
+    everywhere else the oracle uses its own mask."""
+
+    @staticmethod
+    def forward(ctx, x, pos_override, eps):
+        mask = torch.where(x.abs() < eps, pos_override, x > 0)
+        ctx.save_for_backward(mask)
+        return torch.relu(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask, None, None
+
+
 def encoder_forward(p: Dict[str, Tensor], wave: Tensor,
-                    collect: Optional[List[Tensor]] = None) -> Tensor:
-    """(B,1,L) -> (B,C,L/160): relu(norm(conv_i(x))) for i in 0..4 -- model.py:99-105."""
+                    collect: Optional[List[Tensor]] = None,
+                    relu_override: Optional[Sequence[Tensor]] = None,
+                    tie_eps: float = 1e-5) -> Tensor:
+    """(B,1,L) -> (B,C,L/160): relu(norm(conv_i(x))) for i in 0..4 -- model.py:99-105.
+    ``relu_override``: optional per-layer bool tensors (B,C,L_i), see _ReluTieAware."""
     x = wave
     for i, (_, s, pad) in enumerate(ENCODER_GEOMETRY):
         x = torch.nn.functional.conv1d(x, p[f"gEncoder.conv{i}.weight"],
                                        p[f"gEncoder.conv{i}.bias"], stride=s, padding=pad)
         x = channel_norm(x, p[f"gEncoder.batchNorm{i}.weight"], p[f"gEncoder.batchNorm{i}.bias"])
-        x = torch.relu(x)
+        if relu_override is not None:
+            x = _ReluTieAware.apply(x, relu_override[i], tie_eps)
+        else:
+            x = torch.relu(x)
         if collect is not None:
             collect.append(x)
     return x
@@ -177,9 +206,10 @@ def gru_forward(p: Dict[str, Tensor], x: Tensor, n_levels: int = 2,
 
 
 def model_forward(p: Dict[str, Tensor], wave: Tensor, n_levels: int = 2,
-                  h0: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+                  h0: Optional[Tensor] = None,
+                  relu_override: Optional[Sequence[Tensor]] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """CPCModel.forward -- model.py:286-289.  Returns (c (B,S,H), z (B,S,C), hN)."""
-    z = encoder_forward(p, wave).permute(0, 2, 1)
+    z = encoder_forward(p, wave, relu_override=relu_override).permute(0, 2, 1)
     c, hN = gru_forward(p, z, n_levels=n_levels, h0=h0)
     return c, z, hN
 
@@ -253,11 +283,12 @@ def criterion_forward(p: Dict[str, Tensor], c: Tensor, z: Tensor, ext_rows: Tens
 # --------------------------------------------------------------------------
 def train_step(p: Dict[str, Tensor], wave: Tensor, batch_idx: Tensor, seq_idx: Tensor,
                n_predicts: int = 12, n_neg: int = 128, n_levels: int = 2,
-               h0: Optional[Tensor] = None):
+               h0: Optional[Tensor] = None,
+               relu_override: Optional[Sequence[Tensor]] = None):
     """Forward + ``losses.sum().backward()``.  Returns a dict with c, z, losses, acc
     and ``grads`` keyed like ``p``.  ``p`` tensors are treated as leaves."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
-    c, z, hN = model_forward(leaves, wave, n_levels=n_levels, h0=h0)
+    c, z, hN = model_forward(leaves, wave, n_levels=n_levels, h0=h0, relu_override=relu_override)
     B, S, _ = z.shape
     W = S - n_predicts
     ext = negative_rows(batch_idx, seq_idx, B, S, W, n_neg)

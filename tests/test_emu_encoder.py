@@ -16,15 +16,15 @@ def _params(seed=0):
                for n, w in (("conv", "weight"), ("conv", "bias"), ("batchNorm", "weight"), ("batchNorm", "bias"))]
 
 
-def _oracle_encoder(p, wave, dz):
+def _oracle_encoder(p, wave, dz, relu_override=None):
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("gEncoder")}
     acts = []
-    z = O.encoder_forward(leaves, wave, collect=acts).permute(0, 2, 1)
+    z = O.encoder_forward(leaves, wave, collect=acts, relu_override=relu_override).permute(0, 2, 1)
     (z * dz).sum().backward()
     return z.detach(), [a.detach().permute(0, 2, 1).contiguous() for a in acts], leaves
 
 
-@pytest.mark.parametrize("B,L,bm", [(2, 1280, 0), (1, 1370, 64), (1, 1600, 128)])
+@pytest.mark.parametrize("B,L,bm", [(2, 1280, 0), (1, 1370, 64), (1, 1600, 128), (3, 1290, 128)])
 def test_encoder_forward_backward_emulated(B, L, bm):
     lib = emu()
     assert lib.cpc_set_conv_tile(bm) == 0
@@ -42,7 +42,9 @@ def test_encoder_forward_backward_emulated(B, L, bm):
         rc = lib.cpc_encoder_forward(P(wave), parr, P(saved), P(fscr), P(z), B, L, None)
         assert rc == 0
         dz = torch.randn(B, Ls[4], 256)
-        z_ref, acts, leaves = _oracle_encoder(p, wave, dz)
+        # ReLU derivative of numerically tied pre-activations follows the device path (see oracle)
+        ys = [saved[sizes[8 + i]: sizes[8 + i] + B * Ls[i] * 256].view(B, Ls[i], 256) for i in range(4)] + [z]
+        z_ref, acts, leaves = _oracle_encoder(p, wave, dz, [(y > 0).permute(0, 2, 1) for y in ys])
         assert z_ref.shape == z.shape
         # intermediate activations y0..y3 live in the saved workspace
         for i in range(4):
@@ -58,9 +60,12 @@ def test_encoder_forward_backward_emulated(B, L, bm):
         assert rc == 0
         names = [f"gEncoder.{n}{i}.{w}" for i in range(5)
                  for n, w in (("conv", "weight"), ("conv", "bias"), ("batchNorm", "weight"), ("batchNorm", "bias"))]
+        bad = {}
         for n, g in zip(names, grads):
             ref = leaves[n].grad
-            assert torch.isfinite(g).all(), n
-            assert rel_err(g.view_as(ref), ref) < 2e-5, (n, rel_err(g.view_as(ref), ref))
+            e = rel_err(g.view_as(ref), ref) if torch.isfinite(g).all() else float("inf")
+            if not e < 2e-5:
+                bad[n] = e
+        assert not bad, bad
     finally:
         lib.cpc_set_conv_tile(0)

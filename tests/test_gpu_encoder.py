@@ -1,0 +1,80 @@
+"""Encoder HIP kernels on a real MI355X vs the CPU oracle (through the C ABI)."""
+import ctypes
+
+import pytest
+import torch
+
+from oracle import cpc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _names():
+    return [f"gEncoder.{n}{i}.{w}" for i in range(5)
+            for n, w in (("conv", "weight"), ("conv", "bias"), ("batchNorm", "weight"), ("batchNorm", "bias"))]
+
+
+def _run(lib, B, L, dev, pseed=0, bm=0):
+    from cpc_audio_amd._lib import ptr as P
+    p = O.make_params(seed=pseed)
+    plist = [p[n].contiguous().to(dev) for n in _names()]
+    wave = O.make_waveform(B, L, seed=5)
+    sizes = (ctypes.c_long * 22)()
+    assert lib.cpc_set_conv_tile(bm) == 0
+    assert lib.cpc_encoder_layout(B, L, sizes) == 0
+    Ls = [sizes[3 + i] for i in range(5)]
+    saved = torch.full((sizes[0],), float("nan"), device=dev)
+    fscr = torch.empty(max(1, sizes[1]), device=dev)
+    z = torch.full((B, Ls[4], 256), float("nan"), device=dev)
+    wd = wave.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    parr = (ctypes.c_void_p * 20)(*[P(t) for t in plist])
+    lib.check(lib.cpc_encoder_forward(P(wd), parr, P(saved), P(fscr), P(z), B, L, st), "encoder_forward")
+    g = torch.Generator().manual_seed(11)
+    dz = torch.randn(B, Ls[4], 256, generator=g)
+    bscr = torch.empty(sizes[2], device=dev)
+    grads = [torch.full_like(t, float("nan")) for t in plist]
+    garr = (ctypes.c_void_p * 20)(*[P(t) for t in grads])
+    dzd = dz.to(dev)
+    lib.check(lib.cpc_encoder_backward(P(wd), parr, P(saved), P(z), P(dzd), P(bscr), garr, B, L, st),
+              "encoder_backward")
+    torch.cuda.synchronize()
+    lib.cpc_set_conv_tile(0)
+    # oracle
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("gEncoder")}
+    acts = []
+    # ReLU derivative of numerically tied pre-activations follows the device path (see oracle)
+    ys = [saved[sizes[8 + i]: sizes[8 + i] + B * Ls[i] * 256].view(B, Ls[i], 256).cpu() for i in range(4)] + [z.cpu()]
+    zr = O.encoder_forward(leaves, wave, collect=acts,
+                           relu_override=[(y > 0).permute(0, 2, 1) for y in ys]).permute(0, 2, 1)
+    (zr * dz).sum().backward()
+    return dict(z=z.cpu(), z_ref=zr.detach(), grads=[g_.cpu() for g_ in grads],
+                ref_grads=[leaves[n].grad for n in _names()], saved=saved, sizes=sizes, Ls=Ls, acts=acts)
+
+
+@pytest.mark.parametrize("B,L,bm", [(2, 20480, 0), (3, 20480, 128), (1, 4330, 64), (8, 20480, 0)])
+def test_encoder_matches_oracle(B, L, bm):
+    dev = _dev()
+    from cpc_audio_amd import _lib
+    lib = _lib.get()
+    r = _run(lib, B, L, dev, bm=bm)
+    # encoder output within 1e-4 of the CPU reference path (north-star tolerance); expect ~1e-5
+    err = (r["z"] - r["z_ref"]).abs().max().item()
+    assert err < 1e-4, err
+    for i in range(4):
+        off = r["sizes"][8 + i]
+        yi = r["saved"][off: off + B * r["Ls"][i] * 256].view(B, r["Ls"][i], 256).cpu()
+        e = (yi - r["acts"][i].permute(0, 2, 1)).abs().max().item()
+        assert e < 1e-4, (i, e)
+    bad = {}
+    for n, g, ref in zip(_names(), r["grads"], r["ref_grads"]):
+        rel = ((g.view_as(ref) - ref).norm() / (ref.norm() + 1e-30)).item() if torch.isfinite(g).all() else float("inf")
+        if not rel < 1e-4:
+            bad[n] = rel
+    assert not bad, bad
