@@ -1,11 +1,25 @@
 // Internal (non-ABI) helpers shared between translation units of libcpc_hip.
 #pragma once
 #include "cpc_common.h"
+#include "gemm_tile.h"
 
 namespace cpc {
 
 // out[0:n] = sum over `nrows` rows of `part` (row length n), summed in a fixed order.
 // tmp must hold 64*n floats.
 int rows_sum(const float* part, int nrows, int n, float* tmp, float* out, hipStream_t stream);
+
+// C[M,N] = A . B[N,K]^T (+ bias);  N % 128 == 0, K % 16 == 0
+int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc, int N,
+            int K, hipStream_t st);
+// C[N1,N2] (+)= sum_m A[m,:N1]^T (x) B[m,:N2];  part: tn_gemm_part_floats(M,N1,N2) floats
+void tn_gemm_plan(int M, int N1, int N2, int* splits, int* rows);
+long tn_gemm_part_floats(int M, int N1, int N2);
+int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, float* C, int accumulate,
+            hipStream_t st);
+// out[Cn][R] = in[R][Cn]^T
+int transpose(const float* in, float* out, int R, int Cn, hipStream_t st);
+
+static inline long align64l(long v) { return (v + 63) & ~63L; }
 
 }  // namespace cpc

@@ -1,0 +1,155 @@
+// Plain f32-MFMA GEMMs used around the recurrent and contrastive kernels:
+//   nt_gemm:  C[M,N]   = A[M,K] . B[N,K]^T (+ bias[N])         (projections, heads, dX)
+//   tn_gemm:  C[N1,N2] (+)= sum_m A[m,N1]^T (x) B[m,N2]         (every weight gradient)
+// plus a tiled transpose.  Row addressing of A (and B for tn) goes through RowMap so
+// that batch-strided views (c[:, :W], h_{t-1} = y[:, t-1]) need no copies.
+#include "cpc_common.h"
+#include "cpc_internal.h"
+#include "gemm_tile.h"
+
+namespace cpc {
+
+using NtG = NtTile<128, 128, 2, 2>;
+using TnG = TnTile<128, 128, 2, 2>;
+
+__global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const float* __restrict__ Bmat,
+                                                                int ldb, const float* __restrict__ bias,
+                                                                float* __restrict__ C, long ldc, int K) {
+    __shared__ float smem[NtG::SMEM_FLOATS];
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    f32x16 acc[NtG::TM][NtG::TN];
+    zero_acc(acc);
+    NtG::run(acc, am, m0, Bmat, ldb, n0, K, smem);
+#pragma unroll
+    for (int tn = 0; tn < NtG::TN; ++tn) {
+        const int col = n0 + NtG::c_col(tn);
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < NtG::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + NtG::c_row(tm, r);
+                if (m < am.M) C[(long)m * ldc + col] = acc[tm][tn][r] + bv;
+            }
+    }
+}
+
+// grid = (N2/128, N1/128, S); part[z][N1][N2]
+__global__ __launch_bounds__(TnG::NTHREADS) void tn_gemm_kernel(RowMap am, RowMap bm, int N2,
+                                                                int rows_per_split,
+                                                                float* __restrict__ part, long zstride) {
+    __shared__ float smem[TnG::SMEM_FLOATS];
+    const int n0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
+    const int mbeg = blockIdx.z * rows_per_split;
+    const int mend = min(am.M, mbeg + rows_per_split);
+    f32x16 acc[TnG::TM][TnG::TN];
+    zero_acc(acc);
+    TnG::run(acc, am, c0, bm, n0, mbeg, mend, smem);
+    float* out = part + (long)blockIdx.z * zstride;
+#pragma unroll
+    for (int tm = 0; tm < TnG::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = c0 + TnG::c_row(tm, r);
+#pragma unroll
+            for (int tn = 0; tn < TnG::TN; ++tn)
+                out[(long)row * N2 + n0 + TnG::c_col(tn)] = acc[tm][tn][r];
+        }
+}
+
+__global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restrict__ part, int S,
+                                                           long n, float* __restrict__ C, int accumulate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    float s = accumulate ? C[idx] : 0.f;
+    for (int z = 0; z < S; ++z) s += part[(long)z * n + idx];
+    C[idx] = s;
+}
+
+// out[c][r] = in[r][c]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        int R, int Cn) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cn) ? in[(long)r * Cn + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < Cn && r < R) out[(long)c * R + r] = tile[tx][i];
+    }
+}
+
+int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc,
+            int N, int K, hipStream_t st) {
+    if (am.M <= 0) return 0;
+    if (N % 128 != 0 || K % 16 != 0 || K < 16) return CPC_ERR_SHAPE;
+    hipLaunchKernelGGL(nt_gemm_kernel, dim3(cdiv(am.M, 128), N / 128), dim3(NtG::NTHREADS), 0, st, am, Bmat,
+                       ldb, bias, C, ldc, K);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+long tn_gemm_part_floats(int M, int N1, int N2) {
+    int splits, rows;
+    tn_gemm_plan(M, N1, N2, &splits, &rows);
+    return (long)splits * N1 * N2;
+}
+
+void tn_gemm_plan(int M, int N1, int N2, int* splits, int* rows) {
+    const int tiles = (N1 / 128) * (N2 / 128);
+    int S = cdiv(768, tiles > 0 ? tiles : 1);
+    int r = cdiv(cdiv(M, S), 16) * 16;
+    if (r < 256) r = 256;
+    S = cdiv(M, r);
+    if (S < 1) S = 1;
+    *splits = S;
+    *rows = r;
+}
+
+int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, float* C, int accumulate,
+            hipStream_t st) {
+    if (N1 % 128 != 0 || N2 % 128 != 0 || am.M != bm.M) return CPC_ERR_SHAPE;
+    const long n = (long)N1 * N2;
+    if (am.M <= 0) {
+        if (!accumulate) (void)hipMemsetAsync(C, 0, sizeof(float) * n, st);
+        return 0;
+    }
+    int S, rows;
+    tn_gemm_plan(am.M, N1, N2, &S, &rows);
+    hipLaunchKernelGGL(tn_gemm_kernel, dim3(N2 / 128, N1 / 128, S), dim3(TnG::NTHREADS), 0, st, am, bm, N2,
+                       rows, part, n);
+    hipLaunchKernelGGL(split_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, S, n, C, accumulate);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+int transpose(const float* in, float* out, int R, int Cn, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cn, 32), cdiv(R, 32)), dim3(256), 0, st, in, out, R, Cn);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cpc
+
+using namespace cpc;
+
+// C[M,N] = A[M,K] . B[N,K]^T + bias   (lda/ldb/ldc in floats; bias may be NULL)
+extern "C" int cpc_gemm_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C,
+                           int ldc, int M, int N, int K, void* stream) {
+    CPC_RETURN_IF(!A || !B || !C, CPC_ERR_ARG);
+    return nt_gemm(plain_rows(A, M, lda), B, ldb, bias, C, ldc, N, K, (hipStream_t)stream);
+}
+
+extern "C" long cpc_gemm_tn_scratch_floats(int M, int N1, int N2) { return tn_gemm_part_floats(M, N1, N2); }
+
+// C[N1,N2] (+)= A[M,N1]^T . B[M,N2]
+extern "C" int cpc_gemm_tn(const float* A, int lda, const float* B, int ldb, float* part, float* C, int M,
+                           int N1, int N2, int accumulate, void* stream) {
+    CPC_RETURN_IF(!A || !B || !C || !part, CPC_ERR_ARG);
+    return tn_gemm(plain_rows(A, M, lda), N1, plain_rows(B, M, ldb), N2, part, C, accumulate,
+                   (hipStream_t)stream);
+}

@@ -1,0 +1,287 @@
+// CPCAR: multi-layer GRU autoregressor (torch.nn.GRU semantics, batch_first, gate order r,z,n).
+//
+// Reference: cpc/model.py:175-176 (nn.GRU(dimEncoded, dimOutput, num_layers, batch_first=True)),
+// :185-204 (forward, optional carried hidden state).
+//
+//   r = sigmoid(W_ir x + b_ir + W_hr h + b_hr)        z = sigmoid(W_iz x + b_iz + W_hz h + b_hz)
+//   n = tanh   (W_in x + b_in + r * (W_hn h + b_hn))   h' = (1 - z) * n + z * h
+//
+// Structure on MI355X:
+//   * the input projection of all S steps is ONE f32-MFMA GEMM (gemm.hip);
+//   * the recurrence is S dependent steps.  Sequences are independent, so a step is
+//     tiled over (16 batch rows) x (16 hidden units) x 3 gates = 64 workgroups at B = 64;
+//     inside a workgroup the 4 waves split the K = 256 contraction (split-K), each wave
+//     pulls its h / W_hh slices straight into MFMA fragments (float4 per lane, 4 k-steps
+//     per load), the partial 16x16 tiles meet in LDS and the gate non-linearities are
+//     applied by one thread per (b, j).  Step-to-step ordering is the stream order of
+//     the launches (a dependent kernel boundary costs ~1.5 us on this chip, less than a
+//     software grid barrier);
+//   * backward (BPTT) mirrors it with K = 768:  dh_t = dY_t + dh_{t+1} * z_{t+1}
+//     + dGh_{t+1} . W_hh,  then the gate derivatives; all weight gradients are batched
+//     TN GEMMs over the B*S rows afterwards.
+#include "cpc_common.h"
+#include "cpc_internal.h"
+#include "gemm_tile.h"
+
+namespace cpc {
+
+constexpr int kH = kC;          // hidden size (north-star config: 256)
+constexpr int kG = 3 * kH;
+
+// ------------------------------------------------------------------ forward step
+// grid = (H/16, ceil(B/16)), 256 threads.
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(
+    const float* __restrict__ hprev, long hp_bstride, const float* __restrict__ whh,
+    const float* __restrict__ bhh, const float* __restrict__ gi, float* __restrict__ y,
+    float* __restrict__ Rg, float* __restrict__ Zg, float* __restrict__ Ng, float* __restrict__ GHN,
+    float* __restrict__ hN, int B, int S, int t) {
+    __shared__ float part[4][3][256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int koff = 64 * w + 4 * kq;
+
+    float4 a[4];
+    {
+        const bool ok = hprev != nullptr && (b0 + i) < B;
+        const float* ap = hprev + (ok ? (long)(b0 + i) * hp_bstride + koff : 0);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+            a[ii] = ok ? *reinterpret_cast<const float4*>(ap + 16 * ii) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* wp = whh + (long)(g * kH + j0 + i) * kH + koff;
+        float4 bw[4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) bw[ii] = *reinterpret_cast<const float4*>(wp + 16 * ii);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii], jj), f4c(bw[ii], jj), acc[g], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[w][g][(kq * 4 + r) * 16 + i] = acc[g][r];
+    __syncthreads();
+
+    const int row = tid >> 4, col = tid & 15;
+    const int b = b0 + row, j = j0 + col;
+    if (b >= B) return;
+    float gh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+        gh[g] = ((part[0][g][tid] + part[1][g][tid]) + (part[2][g][tid] + part[3][g][tid])) + bhh[g * kH + j];
+    const long bt = (long)b * S + t;
+    const float* gip = gi + bt * kG;
+    const float hp = hprev ? hprev[(long)b * hp_bstride + j] : 0.f;
+    const float r = sigmoidf_(gip[j] + gh[0]);
+    const float z = sigmoidf_(gip[kH + j] + gh[1]);
+    const float n = tanhf(gip[2 * kH + j] + r * gh[2]);
+    const float h = (1.0f - z) * n + z * hp;
+    y[bt * kH + j] = h;
+    Rg[bt * kH + j] = r;
+    Zg[bt * kH + j] = z;
+    Ng[bt * kH + j] = n;
+    GHN[bt * kH + j] = gh[2];
+    if (hN) hN[(long)b * kH + j] = h;
+}
+
+// ------------------------------------------------------------------ backward step
+// dh_t = dY_t + dh_{t+1} * z_{t+1} + dGh_{t+1} . W_hh      (terms with t+1 absent at t = S-1)
+__global__ __launch_bounds__(256) void gru_step_bwd_kernel(
+    const float* __restrict__ whhT, const float* __restrict__ dY, const float* __restrict__ y,
+    const float* __restrict__ h0, const float* __restrict__ Rg, const float* __restrict__ Zg,
+    const float* __restrict__ Ng, const float* __restrict__ GHN, float* __restrict__ dGi,
+    float* __restrict__ dGh, float* __restrict__ DH, int B, int S, int t) {
+    __shared__ float part[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const bool has_next = (t + 1) < S;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_next) {                                   // block-uniform
+        const int koff = 192 * w + 4 * kq;
+        const bool ok = (b0 + i) < B;
+        const float* ap = dGh + (ok ? ((long)(b0 + i) * S + t + 1) * kG + koff : 0);
+        const float* wp = whhT + (long)(j0 + i) * kG + koff;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 a[6], bw[6];
+#pragma unroll
+            for (int ii = 0; ii < 6; ++ii) {
+                a[ii] = ok ? *reinterpret_cast<const float4*>(ap + 16 * (half * 6 + ii)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bw[ii] = *reinterpret_cast<const float4*>(wp + 16 * (half * 6 + ii));
+            }
+#pragma unroll
+            for (int ii = 0; ii < 6; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii], jj), f4c(bw[ii], jj), acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[w][(kq * 4 + r) * 16 + i] = acc[r];
+    __syncthreads();
+
+    const int row = tid >> 4, col = tid & 15;
+    const int b = b0 + row, j = j0 + col;
+    if (b >= B) return;
+    const long bt = (long)b * S + t;
+    float dh = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + dY[bt * kH + j];
+    if (has_next) dh = fmaf(DH[(bt + 1) * kH + j], Zg[(bt + 1) * kH + j], dh);
+    const float r = Rg[bt * kH + j], z = Zg[bt * kH + j], n = Ng[bt * kH + j], ghn = GHN[bt * kH + j];
+    const float hp = t > 0 ? y[(bt - 1) * kH + j] : (h0 ? h0[(long)b * kH + j] : 0.f);
+    const float dn = dh * (1.0f - z);
+    const float dzg = dh * (hp - n);
+    const float dan = dn * (1.0f - n * n);
+    const float daz = dzg * z * (1.0f - z);
+    const float dar = dan * ghn * r * (1.0f - r);
+    float* gi = dGi + bt * kG;
+    float* gh = dGh + bt * kG;
+    gi[j] = dar;            gh[j] = dar;
+    gi[kH + j] = daz;       gh[kH + j] = daz;
+    gi[2 * kH + j] = dan;   gh[2 * kH + j] = dan * r;
+    DH[bt * kH + j] = dh;
+}
+
+// ------------------------------------------------------------------ host side
+struct GruLayout {
+    long R[8], Z[8], N[8], GHN[8], Y[8];     // saved (per layer); Y only for l < nl-1
+    long saved_total;
+    long gi, fwd_total;                      // forward scratch
+    long whhT, wihT, dGi, dGh, DH, mid[2], part, tmp, bwd_total;
+};
+
+static bool gru_layout(int B, int S, int nl, GruLayout& g) {
+    if (B <= 0 || S <= 0 || nl <= 0 || nl > 8) return false;
+    const long bsh = align64l((long)B * S * kH);
+    long o = 0;
+    for (int l = 0; l < nl; ++l) {
+        g.R[l] = o; o += bsh;
+        g.Z[l] = o; o += bsh;
+        g.N[l] = o; o += bsh;
+        g.GHN[l] = o; o += bsh;
+        g.Y[l] = -1;
+        if (l < nl - 1) { g.Y[l] = o; o += bsh; }
+    }
+    g.saved_total = o;
+    g.gi = 0;
+    g.fwd_total = align64l((long)B * S * kG);
+    o = 0;
+    g.whhT = o; o += (long)kH * kG;
+    g.wihT = o; o += (long)kH * kG;
+    g.dGi = o; o += align64l((long)B * S * kG);
+    g.dGh = o; o += align64l((long)B * S * kG);
+    g.DH = o; o += bsh;
+    g.mid[0] = o; o += bsh;
+    g.mid[1] = o; o += bsh;
+    g.part = o; o += align64l(tn_gemm_part_floats(B * S, kG, kH));
+    g.tmp = o; o += align64l(64L * kG);
+    g.bwd_total = o;
+    return true;
+}
+
+}  // namespace cpc
+
+using namespace cpc;
+
+// sizes[0] = saved floats, [1] = forward scratch floats, [2] = backward scratch floats
+extern "C" int cpc_gru_layout(int B, int S, int nl, long* sizes) {
+    GruLayout g;
+    CPC_RETURN_IF(!gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
+    sizes[0] = g.saved_total; sizes[1] = g.fwd_total; sizes[2] = g.bwd_total;
+    return 0;
+}
+
+// x (B,S,256); h0 NULL or (nl,B,256); params: weight_ih, weight_hh, bias_ih, bias_hh per layer
+// (torch.nn.GRU state-dict order); y (B,S,256) = last layer's output; hN (nl,B,256) final states.
+extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* const* params, float* saved,
+                               float* scratch, float* y, float* hN, int B, int S, int nl, void* stream) {
+    GruLayout g;
+    CPC_RETURN_IF(!gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!x || !params || !saved || !scratch || !y || !hN, CPC_ERR_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    const float* in = x;
+    float* gi = scratch + g.gi;
+    for (int l = 0; l < nl; ++l) {
+        const float* wih = params[4 * l], *whh = params[4 * l + 1], *bih = params[4 * l + 2], *bhh = params[4 * l + 3];
+        float* out = (l == nl - 1) ? y : saved + g.Y[l];
+        int rc = nt_gemm(plain_rows(in, B * S, kH), wih, kH, bih, gi, kG, kG, kH, st);
+        if (rc) return rc;
+        const float* h0l = h0 ? h0 + (long)l * B * kH : nullptr;
+        const dim3 grid(kH / 16, cdiv(B, 16));
+        for (int t = 0; t < S; ++t) {
+            const float* hprev = t == 0 ? h0l : out + (long)(t - 1) * kH;
+            const long hstride = t == 0 ? kH : (long)S * kH;
+            hipLaunchKernelGGL(gru_step_fwd_kernel, grid, dim3(256), 0, st, hprev, hstride, whh, bhh, gi, out,
+                               saved + g.R[l], saved + g.Z[l], saved + g.N[l], saved + g.GHN[l],
+                               t == S - 1 ? hN + (long)l * B * kH : nullptr, B, S, t);
+        }
+        CPC_LAUNCH_CHECK();
+        in = out;
+    }
+    return 0;
+}
+
+// dy (B,S,256) -> dx (B,S,256) and grads[4*nl] (same order as params; overwritten).
+// h0 receives no gradient (the reference detaches the carried state, cpc/model.py:194-198).
+extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* const* params,
+                                const float* saved, const float* y, const float* dy, float* scratch,
+                                float* dx, float* const* grads, int B, int S, int nl, void* stream) {
+    GruLayout g;
+    CPC_RETURN_IF(!gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!x || !params || !saved || !scratch || !y || !dy || !dx || !grads, CPC_ERR_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    float* whhT = scratch + g.whhT, *wihT = scratch + g.wihT;
+    float* dGi = scratch + g.dGi, *dGh = scratch + g.dGh, *DH = scratch + g.DH;
+    const int M = B * S;
+    const float* dYl = dy;
+    for (int l = nl - 1; l >= 0; --l) {
+        const float* wih = params[4 * l], *whh = params[4 * l + 1];
+        const float* in = l == 0 ? x : saved + g.Y[l - 1];
+        const float* out = (l == nl - 1) ? y : saved + g.Y[l];
+        const float* h0l = h0 ? h0 + (long)l * B * kH : nullptr;
+        float* dXl = l == 0 ? dx : scratch + g.mid[l & 1];
+        int rc = transpose(whh, whhT, kG, kH, st);       // (3H,H) -> (H,3H)
+        if (rc) return rc;
+        rc = transpose(wih, wihT, kG, kH, st);
+        if (rc) return rc;
+        const dim3 grid(kH / 16, cdiv(B, 16));
+        for (int t = S - 1; t >= 0; --t)
+            hipLaunchKernelGGL(gru_step_bwd_kernel, grid, dim3(256), 0, st, whhT, dYl, out, h0l,
+                               saved + g.R[l], saved + g.Z[l], saved + g.N[l], saved + g.GHN[l], dGi, dGh, DH,
+                               B, S, t);
+        CPC_LAUNCH_CHECK();
+        // weight / bias gradients over all B*S rows
+        const RowMap gim = plain_rows(dGi, M, kG), ghm = plain_rows(dGh, M, kG);
+        rc = tn_gemm(gim, kG, plain_rows(in, M, kH), kH, scratch + g.part, grads[4 * l], 0, st);
+        if (rc) return rc;
+        // h_{t-1} rows: y[b, t-1] (zero row at t = 0; the h0 term is added below)
+        RowMap hm;
+        hm.base = out; hm.R = S; hm.bstride = (long)S * kH; hm.rstride = kH; hm.off = -kH;
+        hm.tmul = 1; hm.tadd = -1; hm.Lin = S; hm.M = M;
+        rc = tn_gemm(ghm, kG, hm, kH, scratch + g.part, grads[4 * l + 1], 0, st);
+        if (rc) return rc;
+        if (h0l) {   // + dGh[:,0,:]^T . h0
+            RowMap g0;
+            g0.base = dGh; g0.R = 1; g0.bstride = (long)S * kG; g0.rstride = 0; g0.off = 0;
+            g0.tmul = 0; g0.tadd = 0; g0.Lin = 0x7fffffff; g0.M = B;
+            rc = tn_gemm(g0, kG, plain_rows(h0l, B, kH), kH, scratch + g.part, grads[4 * l + 1], 1, st);
+            if (rc) return rc;
+        }
+        rc = rows_sum(dGi, M, kG, scratch + g.tmp, grads[4 * l + 2], st);
+        if (rc) return rc;
+        rc = rows_sum(dGh, M, kG, scratch + g.tmp, grads[4 * l + 3], st);
+        if (rc) return rc;
+        // dX = dGi . W_ih   (as NT against W_ih^T)
+        rc = nt_gemm(gim, wihT, kG, nullptr, dXl, kH, kH, kG, st);
+        if (rc) return rc;
+        dYl = dXl;
+    }
+    return 0;
+}

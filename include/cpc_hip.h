@@ -76,6 +76,29 @@ int cpc_encoder_backward(const float* wave, const float* const* params, const fl
                          const float* z, const float* dz, float* scratch, float* const* grads,
                          int B, int L, void* stream);
 
+/* ------------------------------------------------------------ plain GEMMs ----
+ * C[M,N] = A[M,K] . B[N,K]^T + bias[N]   (N % 128 == 0, K % 16 == 0; bias may be NULL).
+ * This is torch.nn.Linear's arithmetic (criterion.py:90-91,108; the GRU projections). */
+int cpc_gemm_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C,
+                int ldc, int M, int N, int K, void* stream);
+/* C[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (N1, N2 % 128 == 0): every weight gradient. */
+long cpc_gemm_tn_scratch_floats(int M, int N1, int N2);
+int cpc_gemm_tn(const float* A, int lda, const float* B, int ldb, float* part, float* C, int M,
+                int N1, int N2, int accumulate, void* stream);
+
+/* ------------------------------------------------------------ autoregressor ----
+ * CPCAR.forward, cpc/model.py:185-204: nn.GRU(256, 256, num_layers=nl, batch_first=True)
+ * (model.py:175-176) with optional initial state h0 (the carried `self.hidden`, :193-198).
+ * params / grads: weight_ih_l, weight_hh_l, bias_ih_l, bias_hh_l for l = 0..nl-1
+ * (torch state-dict order, gate rows r,z,n).  x, y, dy, dx: (B,S,256); h0, hN: (nl,B,256).
+ * cpc_gru_layout fills sizes[0..2] = saved / forward-scratch / backward-scratch floats. */
+int cpc_gru_layout(int B, int S, int nl, long* sizes);
+int cpc_gru_forward(const float* x, const float* h0, const float* const* params, float* saved,
+                    float* scratch, float* y, float* hN, int B, int S, int nl, void* stream);
+int cpc_gru_backward(const float* x, const float* h0, const float* const* params,
+                     const float* saved, const float* y, const float* dy, float* scratch, float* dx,
+                     float* const* grads, int B, int S, int nl, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
