@@ -17,7 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcpc_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
-         "-Wno-unused-result"]
+         "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
 def _hipcc():

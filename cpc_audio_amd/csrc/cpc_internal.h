@@ -11,7 +11,7 @@ int rows_sum(const float* part, int nrows, int n, float* tmp, float* out, hipStr
 
 // C[M,N] = A . B[N,K]^T (+ bias);  N % 128 == 0, K % 16 == 0
 int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc, int N,
-            int K, hipStream_t st);
+            int K, hipStream_t st, int c_R = 0, long c_bstride = 0);
 // C[N1,N2] (+)= sum_m A[m,:N1]^T (x) B[m,:N2];  part: tn_gemm_part_floats(M,N1,N2) floats
 void tn_gemm_plan(int M, int N1, int N2, int* splits, int* rows);
 long tn_gemm_part_floats(int M, int N1, int N2);

@@ -12,9 +12,12 @@ namespace cpc {
 using NtG = NtTile<128, 128, 2, 2>;
 using TnG = TnTile<128, 128, 2, 2>;
 
+// Output row m goes to C + m*ldc, or, when c_R > 0, to C + (m / c_R)*c_bstride + (m % c_R)*ldc
+// (a batch-strided view such as dc[:, :W]).
 __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const float* __restrict__ Bmat,
                                                                 int ldb, const float* __restrict__ bias,
-                                                                float* __restrict__ C, long ldc, int K) {
+                                                                float* __restrict__ C, long ldc, int K,
+                                                                int c_R, long c_bstride) {
     __shared__ float smem[NtG::SMEM_FLOATS];
     const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
     f32x16 acc[NtG::TM][NtG::TN];
@@ -29,7 +32,11 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + NtG::c_row(tm, r);
-                if (m < am.M) C[(long)m * ldc + col] = acc[tm][tn][r] + bv;
+                if (m < am.M) {
+                    long ro = (long)m * ldc;
+                    if (c_R > 0) { const int cb = m / c_R; ro = cb * c_bstride + (long)(m - cb * c_R) * ldc; }
+                    C[ro + col] = acc[tm][tn][r] + bv;
+                }
             }
     }
 }
@@ -84,11 +91,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc,
-            int N, int K, hipStream_t st) {
+            int N, int K, hipStream_t st, int c_R, long c_bstride) {
     if (am.M <= 0) return 0;
     if (N % 128 != 0 || K % 16 != 0 || K < 16) return CPC_ERR_SHAPE;
     hipLaunchKernelGGL(nt_gemm_kernel, dim3(cdiv(am.M, 128), N / 128), dim3(NtG::NTHREADS), 0, st, am, Bmat,
-                       ldb, bias, C, ldc, K);
+                       ldb, bias, C, ldc, K, c_R, c_bstride);
     CPC_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,357 @@
+// InfoNCE criterion: K linear prediction heads, shared negatives, batched dot-product scoring,
+// per-head cross entropy against class 0 (the positive) and arg-max accuracy.
+//
+// Reference: cpc/criterion/criterion.py
+//   :90-91,108   pred_k = W_k c_t                      (nn.Linear, bias-free)
+//   :174-219     sampleClean: negatives z[ext[b,n,t]] drawn ONCE, shared by all K heads;
+//                positive for head k is z[b, t+k]
+//   :115-116     score = mean over the 256 features of pred_k * candidate   (dot / 256)
+//   :248-257     CE(target 0) averaged over the B*W rows; acc = [argmax == 0] averaged
+//
+// The reference materialises (B, 1+N, W, 256) candidates per head (11.8 GB at B = 64).
+// Here nothing of that size exists: for every (b,t) one wavefront forms the dense
+// (heads x negatives) score matrix  P[16 x 256] . Neg^T[256 x N]  on the matrix pipe
+// (v_mfma_f32_16x16x4_f32; the 12 heads are padded to the 16-row tile), gathering the
+// negative rows of z straight from L2 / Infinity Cache into MFMA B-fragments (z for the
+// whole batch is 8.4 MB), and folds the log-softmax online.  Only the (B*W, K, 1+N)
+// logits and K log-sum-exps per row are kept for the backward pass.
+//
+// Backward per (b,t):
+//   dPred[16 x 256] = dS[16 x N] . Neg[N x 256]        (gather again, MFMA)
+//   dNeg [N x 256]  = dS^T[N x 16] . P[16 x 256]       (MFMA) -> atomically added into dz[ext]
+// then the head GEMMs:  dc = dPred . W,  dW_k = dPred_k^T . c   (gemm.hip).
+#include "cpc_common.h"
+#include "cpc_internal.h"
+#include "gemm_tile.h"
+
+namespace cpc {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+
+// ------------------------------------------------------------------ forward scores
+// one wavefront per (b,t) row; 4 rows per block.  pred: [BW][K*C]; ext: [BW][N] row ids into z.
+__global__ __launch_bounds__(256) void nce_fwd_kernel(
+    const float* __restrict__ pred, const float* __restrict__ z, const int* __restrict__ ext,
+    float* __restrict__ logits, float* __restrict__ lse_out, float* __restrict__ rowstat, int BW, int W,
+    int S, int K, int N) {
+    const int lane = threadIdx.x & 63;
+    const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bt >= BW) return;                           // whole wave leaves together
+    const int b = bt / W, t = bt - b * W;
+    const int i = lane & 15, kq = lane >> 4;
+    const bool hv = i < K;
+    const float inv = 1.0f / kC;
+
+    float4 pa[16];
+    {
+        const float* pp = pred + ((long)bt * K + (hv ? i : 0)) * kC + 4 * kq;
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) pa[ii] = hv ? ld4(pp + 16 * ii) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // positives: head h <-> z[b, t+h+1].  They go through the SAME MFMA chain as the negatives
+    // (a 16-column tile whose column j is head j's positive row; the diagonal is kept), so a
+    // negative that happens to be the positive row scores bit-identically and the arg-max tie
+    // resolves to class 0 exactly as in the reference (criterion.py:253).
+    float posl[4], m[4], s[4], mneg[4];
+    {
+        const float* zp = z + ((long)b * S + t + (hv ? i : 0) + 1) * kC + 4 * kq;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) {
+            const float4 bf = ld4(zp + 16 * ii);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(pa[ii], jj), f4c(bf, jj), acc, 0, 0, 0);
+        }
+        // acc[r] on lane (col, q) = score(head 4q+r, positive row of head col); diagonal: col == 4q+r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            posl[r] = __shfl(acc[r], (4 * kq + r) + 16 * kq) * inv;
+            m[r] = posl[r];
+            s[r] = (i == 0) ? 1.0f : 0.0f;              // the positive enters the sum once
+            mneg[r] = -3.0e38f;
+        }
+    }
+    for (int nt = 0; nt < N / 16; ++nt) {
+        const int row = ext[(long)bt * N + nt * 16 + i];
+        const float* zr = z + (long)row * kC + 4 * kq;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) {
+            const float4 bf = ld4(zr + 16 * ii);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(pa[ii], jj), f4c(bf, jj), acc, 0, 0, 0);
+        }
+        // acc[r] = score of head 4kq+r against negative nt*16+i
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int head = 4 * kq + r;
+            const float l = acc[r] * inv;
+            if (head < K) logits[((long)bt * K + head) * (N + 1) + 1 + nt * 16 + i] = l;
+            mneg[r] = fmaxf(mneg[r], l);
+            const float mn = fmaxf(m[r], l);
+            s[r] = s[r] * expf(m[r] - mn) + expf(l - mn);
+            m[r] = mn;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const float m2 = __shfl_xor(m[r], off), s2 = __shfl_xor(s[r], off);
+            const float mn = fmaxf(m[r], m2);
+            s[r] = s[r] * expf(m[r] - mn) + s2 * expf(m2 - mn);
+            m[r] = mn;
+            mneg[r] = fmaxf(mneg[r], __shfl_xor(mneg[r], off));
+        }
+        const int head = 4 * kq + r;
+        if (i == 0 && head < K) {
+            const float lse = m[r] + logf(s[r]);
+            logits[((long)bt * K + head) * (N + 1)] = posl[r];
+            lse_out[(long)bt * K + head] = lse;
+            rowstat[(long)bt * 2 * K + head] = lse - posl[r];                      // CE(target 0)
+            rowstat[(long)bt * 2 * K + K + head] = posl[r] >= mneg[r] ? 1.f : 0.f; // argmax == 0
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void nce_finalize_kernel(const float* __restrict__ sums, float* __restrict__ losses,
+                                                         float* __restrict__ acc, int K, float inv_rows) {
+    const int k = threadIdx.x;
+    if (k < K) { losses[k] = sums[k] * inv_rows; acc[k] = sums[K + k] * inv_rows; }
+}
+
+// gscale[k] = dL/dloss_k / (B*W) / C
+__global__ __launch_bounds__(64) void nce_gscale_kernel(const float* __restrict__ gloss, float* __restrict__ gscale,
+                                                        int K, float f) {
+    const int k = threadIdx.x;
+    if (k < K) gscale[k] = gloss[k] * f;
+}
+
+// ------------------------------------------------------------------ backward: dPred
+__global__ __launch_bounds__(256) void nce_bwd_dpred_kernel(
+    const float* __restrict__ z, const int* __restrict__ ext, const float* __restrict__ logits,
+    const float* __restrict__ lse, const float* __restrict__ gscale, float* __restrict__ dpred, int BW,
+    int W, int S, int K, int N) {
+    const int lane = threadIdx.x & 63;
+    const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bt >= BW) return;
+    const int b = bt / W, t = bt - b * W;
+    const int i = lane & 15, kq = lane >> 4;
+    const bool hv = i < K;
+    const float gs = hv ? gscale[i] : 0.f;
+    const float ls = hv ? lse[(long)bt * K + i] : 0.f;
+    const float* lp = logits + ((long)bt * K + (hv ? i : 0)) * (N + 1) + 1 + 4 * kq;
+    const int* ep = ext + (long)bt * N + 4 * kq;
+    f32x4 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ii = 0; ii < N / 16; ++ii) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const float a = hv ? gs * expf(lp[16 * ii + jj] - ls) : 0.f;   // d score[head i][n]
+            const int row = ep[16 * ii + jj];                            // n = 16 ii + 4 kq + jj
+            const float* zr = z + (long)row * kC + 4 * i;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 bv = ld4(zr + 64 * u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[u * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f4c(bv, e), acc[u * 4 + e], 0, 0, 0);
+            }
+        }
+    }
+    // C layout: head = 4kq + r, channel = 64u + 4i + e
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int head = 4 * kq + r;
+        if (head < K) {
+            const float d0 = gscale[head] * (expf(logits[((long)bt * K + head) * (N + 1)] - lse[(long)bt * K + head]) - 1.0f);
+            const float* zp = z + ((long)b * S + t + head + 1) * kC + 4 * i;
+            float* op = dpred + ((long)bt * K + head) * kC + 4 * i;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 zv = ld4(zp + 64 * u);
+                float4 o;
+                o.x = fmaf(d0, zv.x, acc[u * 4 + 0][r]);
+                o.y = fmaf(d0, zv.y, acc[u * 4 + 1][r]);
+                o.z = fmaf(d0, zv.z, acc[u * 4 + 2][r]);
+                o.w = fmaf(d0, zv.w, acc[u * 4 + 3][r]);
+                *reinterpret_cast<float4*>(op + 64 * u) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward: dz (scatter)
+__global__ __launch_bounds__(256) void nce_bwd_dz_kernel(
+    const float* __restrict__ pred, const int* __restrict__ ext, const float* __restrict__ logits,
+    const float* __restrict__ lse, const float* __restrict__ gscale, float* __restrict__ dz, int BW, int W,
+    int S, int K, int N) {
+    const int lane = threadIdx.x & 63;
+    const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bt >= BW) return;
+    const int b = bt / W, t = bt - b * W;
+    const int i = lane & 15, kq = lane >> 4;
+    // B operand: P[head 4s+kq][channels 64u + 4i + e]
+    float4 pb[4][4];
+    float gs[4], ls[4];
+    const float* lp[4];
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) {
+        const int head = 4 * sx + kq;
+        const bool hv = head < K;
+        gs[sx] = hv ? gscale[head] : 0.f;
+        ls[sx] = hv ? lse[(long)bt * K + head] : 0.f;
+        lp[sx] = logits + ((long)bt * K + (hv ? head : 0)) * (N + 1);
+        const float* pp = pred + ((long)bt * K + (hv ? head : 0)) * kC + 4 * i;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pb[sx][u] = hv ? ld4(pp + 64 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int nt = 0; nt < N / 16; ++nt) {
+        f32x4 acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            const float a = gs[sx] * expf(lp[sx][1 + nt * 16 + i] - ls[sx]);   // d score[head 4sx+kq][n = nt*16+i]
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[u * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f4c(pb[sx][u], e), acc[u * 4 + e], 0, 0, 0);
+        }
+        // C layout: negative n = nt*16 + 4kq + r, channel = 64u + 4i + e
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ext[(long)bt * N + nt * 16 + 4 * kq + r];
+            float* dst = dz + (long)row * kC + 4 * i;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(dst + 64 * u + e, acc[u * 4 + e][r]);
+        }
+    }
+    // positives: dz[b, t+k] += d score[k][pos] * P[k]
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) {
+        const int head = 4 * sx + kq;
+        if (head < K) {
+            const float d0 = gs[sx] * (expf(lp[sx][0] - ls[sx]) - 1.0f);
+            float* dst = dz + ((long)b * S + t + head + 1) * kC + 4 * i;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(dst + 64 * u + e, d0 * f4c(pb[sx][u], e));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct NceLayout {
+    int W, BW;
+    long pred, logits, lse, saved_total;
+    long rowstat, tmp, sums, fwd_total;
+    long dpred, wallT, part, gscale, bwd_total;
+};
+
+static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
+    if (B <= 0 || K <= 0 || K > 16 || S <= K || N <= 0 || N % 16 != 0) return false;
+    n.W = S - K;
+    n.BW = B * n.W;
+    long o = 0;
+    n.pred = o; o += align64l((long)n.BW * K * kC);
+    n.logits = o; o += align64l((long)n.BW * K * (N + 1));
+    n.lse = o; o += align64l((long)n.BW * K);
+    n.saved_total = o;
+    o = 0;
+    n.rowstat = o; o += align64l((long)n.BW * 2 * K);
+    n.tmp = o; o += align64l(64L * 2 * K);
+    n.sums = o; o += 64;
+    n.fwd_total = o;
+    o = 0;
+    n.dpred = o; o += align64l((long)n.BW * K * kC);
+    n.wallT = o; o += (long)kC * K * kC;
+    n.part = o; o += align64l(tn_gemm_part_floats(n.BW, K * kC, kC));
+    n.gscale = o; o += 64;
+    n.bwd_total = o;
+    return true;
+}
+
+static RowMap window_rows(const float* c, int B, int S, int W) {     // rows (b, t < W) of a (B,S,256) tensor
+    RowMap r;
+    r.base = c; r.R = W; r.bstride = (long)S * kC; r.rstride = kC; r.off = 0;
+    r.tmul = 0; r.tadd = 0; r.Lin = 0x7fffffff; r.M = B * W;
+    return r;
+}
+
+}  // namespace cpc
+
+using namespace cpc;
+
+extern "C" int cpc_nce_layout(int B, int S, int K, int N, long* sizes) {
+    NceLayout n;
+    CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    sizes[0] = n.saved_total; sizes[1] = n.fwd_total; sizes[2] = n.bwd_total;
+    sizes[3] = n.pred; sizes[4] = n.logits; sizes[5] = n.lse;
+    return 0;
+}
+
+// c (B,S,256) context, z (B,S,256) encoder output, wall (K*256, 256) = the K head weights stacked,
+// ext (B*W, N) int32 rows into z.view(B*S,256) [i.e. criterion.py:199's extIdx laid out (b,t,n)].
+// losses, acc: K floats each (criterion.py:256-257).
+extern "C" int cpc_nce_forward(const float* c, const float* z, const float* wall, const int* ext, float* saved,
+                               float* scratch, float* losses, float* acc, int B, int S, int K, int N,
+                               void* stream) {
+    NceLayout n;
+    CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!c || !z || !wall || !ext || !saved || !scratch || !losses || !acc, CPC_ERR_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    float* pred = saved + n.pred;
+    int rc = nt_gemm(window_rows(c, B, S, n.W), wall, kC, nullptr, pred, (long)K * kC, K * kC, kC, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nce_fwd_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
+                       saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N);
+    CPC_LAUNCH_CHECK();
+    rc = rows_sum(scratch + n.rowstat, n.BW, 2 * K, scratch + n.tmp, scratch + n.sums, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(64), 0, st, scratch + n.sums, losses, acc, K,
+                       1.0f / (float)n.BW);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// gloss: K upstream gradients dL/dloss_k (device).  Outputs (overwritten): dc, dz (B,S,256), dwall (K*256,256).
+extern "C" int cpc_nce_backward(const float* c, const float* z, const float* wall, const int* ext,
+                                const float* saved, const float* gloss, float* scratch, float* dc, float* dz,
+                                float* dwall, int B, int S, int K, int N, void* stream) {
+    NceLayout n;
+    CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!c || !z || !wall || !ext || !saved || !gloss || !scratch || !dc || !dz || !dwall, CPC_ERR_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    const float* pred = saved + n.pred, *logits = saved + n.logits, *lse = saved + n.lse;
+    float* dpred = scratch + n.dpred, *gscale = scratch + n.gscale, *wallT = scratch + n.wallT;
+    hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale, K,
+                       1.0f / ((float)n.BW * (float)kC));
+    (void)hipMemsetAsync(dz, 0, sizeof(float) * (size_t)B * S * kC, st);
+    (void)hipMemsetAsync(dc, 0, sizeof(float) * (size_t)B * S * kC, st);
+    const dim3 grid(cdiv(n.BW, 4));
+    hipLaunchKernelGGL(nce_bwd_dpred_kernel, grid, dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
+                       n.W, S, K, N);
+    hipLaunchKernelGGL(nce_bwd_dz_kernel, grid, dim3(256), 0, st, pred, ext, logits, lse, gscale, dz, n.BW, n.W,
+                       S, K, N);
+    CPC_LAUNCH_CHECK();
+    // dc[:, :W] = dPred . Wall  (NT against Wall^T [256][K*256])
+    int rc = transpose(wall, wallT, K * kC, kC, st);
+    if (rc) return rc;
+    rc = nt_gemm(plain_rows(dpred, n.BW, K * kC), wallT, K * kC, nullptr, dc, kC, kC, K * kC, st, n.W,
+                 (long)S * kC);
+    if (rc) return rc;
+    // dW_k = dPred_k^T . c[:, :W]
+    return tn_gemm(plain_rows(dpred, n.BW, K * kC), K * kC, window_rows(c, B, S, n.W), kC, scratch + n.part,
+                   dwall, 0, st);
+}

@@ -99,6 +99,26 @@ int cpc_gru_backward(const float* x, const float* h0, const float* const* params
                      const float* saved, const float* y, const float* dy, float* scratch, float* dx,
                      float* const* grads, int B, int S, int nl, void* stream);
 
+/* ---------------------------------------------------------------- criterion ----
+ * CPCUnsupersivedCriterion.forward (criterion.py:225-257) with linear prediction heads
+ * (PredictionNetwork, criterion.py:90-91,97-118) and the negatives of sampleClean
+ * (criterion.py:174-219) supplied as row indices.
+ *   c, z : (B,S,256) context / encoded features;  W = S - K windows per sequence
+ *   wall : (K*256, 256) the K head weights `wPrediction.predictors.k.weight` stacked
+ *   ext  : (B*W, N) int32, ext[(b*W+t)*N + n] = row of z.view(B*S,256) used as negative n
+ *          of window (b,t)  ==  criterion.py:199's extIdx[b,n,t]
+ *   losses, acc : K floats (criterion.py:256-257)
+ * K <= 16, N % 16 == 0.  sizes[0..2] = saved / fwd-scratch / bwd-scratch floats,
+ * sizes[3..5] = offsets of pred, logits (B*W,K,1+N), lse (B*W,K) inside `saved`. */
+int cpc_nce_layout(int B, int S, int K, int N, long* sizes);
+int cpc_nce_forward(const float* c, const float* z, const float* wall, const int* ext, float* saved,
+                    float* scratch, float* losses, float* acc, int B, int S, int K, int N,
+                    void* stream);
+/* gloss: K upstream gradients dL/dloss_k.  dc, dz (B,S,256) and dwall are overwritten. */
+int cpc_nce_backward(const float* c, const float* z, const float* wall, const int* ext,
+                     const float* saved, const float* gloss, float* scratch, float* dc, float* dz,
+                     float* dwall, int B, int S, int K, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

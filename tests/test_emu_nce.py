@@ -1,0 +1,50 @@
+"""InfoNCE criterion kernels (csrc/nce.hip) on the host SIMT emulator vs the oracle."""
+import ctypes
+
+import pytest
+import torch
+
+from emu_util import P, emu, rel_err
+from oracle import cpc_oracle as O
+
+
+@pytest.mark.parametrize("B,S,K,N,scale", [(2, 20, 12, 16, 1.0), (3, 19, 5, 32, 40.0)])
+def test_nce_forward_backward_emulated(B, S, K, N, scale):
+    lib = emu()
+    torch.manual_seed(2)
+    W = S - K
+    p = O.make_params(seed=4, n_predicts=K, head_scale=scale)
+    heads = O.head_weights(p, K)
+    wall = torch.cat(heads, dim=0).contiguous()
+    c = torch.tanh(torch.randn(B, S, 256))
+    z = torch.relu(torch.randn(B, S, 256))
+    g = torch.Generator().manual_seed(9)
+    bi, si = O.draw_negative_indices(B, S, W, N, generator=g)
+    ext = O.negative_rows(bi, si, B, S, W, N)                       # (B,N,W)
+    ext_t = ext.permute(0, 2, 1).contiguous().to(torch.int32)       # (B,W,N)
+    sizes = (ctypes.c_long * 6)()
+    assert lib.cpc_nce_layout(B, S, K, N, sizes) == 0
+    saved = torch.full((sizes[0],), float("nan"))
+    fscr = torch.full((sizes[1],), float("nan"))
+    losses = torch.full((K,), float("nan")); acc = torch.full((K,), float("nan"))
+    assert lib.cpc_nce_forward(P(c), P(z), P(wall), P(ext_t), P(saved), P(fscr), P(losses), P(acc), B, S, K, N, None) == 0
+    leaves = {f"wPrediction.predictors.{k}.weight": heads[k].clone().requires_grad_(True) for k in range(K)}
+    cr = c.clone().requires_grad_(True); zr = z.clone().requires_grad_(True)
+    lr, ar = O.criterion_forward(leaves, cr, zr, ext, K)
+    assert (losses - lr[0]).abs().max().item() < 1e-5, (losses, lr)
+    assert (acc - ar[0]).abs().max().item() < 1e-6
+    lg = O.criterion_logits(leaves, cr, zr, ext, K)
+    mine = saved[sizes[4]: sizes[4] + B * W * K * (N + 1)].view(B, W, K, N + 1)
+    for k in range(K):
+        assert (mine[:, :, k, :].permute(0, 2, 1) - lg[k]).abs().max().item() < 1e-5
+    gl = torch.randn(K)
+    (lr[0] * gl).sum().backward()
+    bscr = torch.full((sizes[2],), float("nan"))
+    dc = torch.full((B, S, 256), float("nan")); dz = torch.full((B, S, 256), float("nan"))
+    dwall = torch.full((K * 256, 256), float("nan"))
+    assert lib.cpc_nce_backward(P(c), P(z), P(wall), P(ext_t), P(saved), P(gl), P(bscr), P(dc), P(dz), P(dwall),
+                                B, S, K, N, None) == 0
+    assert rel_err(dc, cr.grad) < 1e-5
+    assert rel_err(dz, zr.grad) < 1e-5
+    ref_dw = torch.cat([leaves[f"wPrediction.predictors.{k}.weight"].grad for k in range(K)], dim=0)
+    assert rel_err(dwall, ref_dw) < 1e-5
