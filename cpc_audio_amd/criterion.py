@@ -1,0 +1,122 @@
+"""Drop-in replacements for the hot-path classes of the reference's cpc/criterion/criterion.py.
+
+Same class names (including the reference's spelling ``CPCUnsupersivedCriterion``,
+exported at cpc/criterion/__init__.py:5-6), constructor signatures and state-dict keys
+(``wPrediction.predictors.{k}.weight``).  forward/backward of the criterion run in the
+fused InfoNCE kernels of libcpc_hip.so; negatives are never materialised.
+"""
+import torch
+import torch.nn as nn
+
+from .ops import InfoNCEFunction
+
+
+class PredictionNetwork(nn.Module):
+    """cpc/criterion/criterion.py:44-118, linear heads (the ``else`` branch at :89-95, i.e.
+    ``--rnnMode linear``): K bias-free nn.Linear(dimOutputAR, dimOutputEncoder)."""
+
+    def __init__(self, nPredicts, dimOutputAR, dimOutputEncoder, rnnMode=None, dropout=False,
+                 sizeInputSeq=116):
+        super().__init__()
+        if rnnMode in ("RNN", "LSTM", "ffd", "conv4", "conv8", "conv12", "transformer"):
+            raise NotImplementedError(f"rnnMode={rnnMode!r}: the HIP criterion implements the linear "
+                                      "prediction heads (--rnnMode linear, the north-star configuration)")
+        if dropout:
+            raise NotImplementedError("dropout on the predictions is not implemented in the fused criterion")
+        if dimOutputAR != 256 or dimOutputEncoder != 256:
+            raise NotImplementedError("the HIP criterion is built for hiddenGar == hiddenEncoder == 256")
+        if nPredicts > 16:
+            raise NotImplementedError("the fused score kernel holds at most 16 heads per wavefront tile")
+        self.predictors = nn.ModuleList()
+        self.RESIDUAL_STD = 0.01
+        self.dimOutputAR = dimOutputAR
+        self.dropout = None
+        for _ in range(nPredicts):
+            self.predictors.append(nn.Linear(dimOutputAR, dimOutputEncoder, bias=False))
+
+    def stacked_weight(self):
+        """(K*256, 256): the K head weights stacked along the output dimension."""
+        return torch.cat([p.weight for p in self.predictors], dim=0)
+
+    def forward(self, c, candidates):
+        """Reference API (criterion.py:97-118) on materialised candidates; kept for callers
+        that use PredictionNetwork directly.  The criterion below does not go through it."""
+        assert len(candidates) == len(self.predictors)
+        out = []
+        for k in range(len(self.predictors)):
+            locC = self.predictors[k](c)
+            locC = locC.view(locC.size(0), 1, locC.size(1), locC.size(2))
+            out.append((locC * candidates[k]).mean(dim=3))
+        return out
+
+
+class BaseCriterion(nn.Module):
+    """cpc/criterion/criterion.py:121-127."""
+
+    def warmUp(self):
+        return False
+
+    def update(self):
+        return
+
+
+class CPCUnsupersivedCriterion(BaseCriterion):
+    """cpc/criterion/criterion.py:139-257."""
+
+    def __init__(self,
+                 nPredicts,             # Number of steps
+                 dimOutputAR,           # Dimension of G_ar
+                 dimOutputEncoder,      # Dimension of the convolutional net
+                 negativeSamplingExt,   # Number of negative samples to draw
+                 mode=None,
+                 rnnMode=False,
+                 dropout=False,
+                 speakerEmbedding=0,
+                 nSpeakers=0,
+                 sizeInputSeq=128):
+        super().__init__()
+        if speakerEmbedding > 0:
+            raise NotImplementedError("speakerEmbedding is deprecated in the reference "
+                                      "(cpc_default_config.py:69-71) and not implemented here")
+        self.speakerEmb = None
+        self.wPrediction = PredictionNetwork(nPredicts, dimOutputAR, dimOutputEncoder, rnnMode=rnnMode,
+                                             dropout=dropout, sizeInputSeq=sizeInputSeq - nPredicts)
+        self.nPredicts = nPredicts
+        self.negativeSamplingExt = negativeSamplingExt
+        if negativeSamplingExt % 16 != 0:
+            raise NotImplementedError("negativeSamplingExt must be a multiple of 16 (MFMA tile width)")
+        self.lossCriterion = nn.CrossEntropyLoss()   # kept for API parity; the fused kernel computes it
+        if mode not in [None, "reverse"]:
+            raise ValueError("Invalid mode")
+        self.mode = mode
+
+    def drawNegatives(self, batchSize, seqSize, windowSize, device):
+        """The two draws of sampleClean in the reference's order (criterion.py:181-189):
+        batchIdx in [0,B) first, then seqIdx in [1,S), both flat in (b,n,t) order."""
+        n = self.negativeSamplingExt * windowSize * batchSize
+        batchIdx = torch.randint(low=0, high=batchSize, size=(n,), device=device)
+        seqIdx = torch.randint(low=1, high=seqSize, size=(n,), device=device)
+        return batchIdx, seqIdx
+
+    def negativeRows(self, batchIdx, seqIdx, batchSize, seqSize, windowSize):
+        """criterion.py:191-199: row = ((seqIdx + t) mod S) + batchIdx*S, returned as the
+        (B, W, N) int32 layout the score kernel reads."""
+        N = self.negativeSamplingExt
+        t = torch.arange(windowSize, device=seqIdx.device).view(1, 1, windowSize)
+        s = torch.remainder(seqIdx.view(batchSize, N, windowSize) + t, seqSize)
+        ext = s + batchIdx.view(batchSize, N, windowSize) * seqSize
+        return ext.permute(0, 2, 1).contiguous().to(torch.int32)
+
+    def forward(self, cFeature, encodedData, label, negatives=None):
+        """-> (losses (1,K), acc (1,K)) as criterion.py:256-257.  ``negatives`` optionally
+        supplies (batchIdx, seqIdx) instead of drawing them (parity tests)."""
+        if self.mode == "reverse":
+            encodedData = torch.flip(encodedData, [1])
+            cFeature = torch.flip(cFeature, [1])
+        batchSize, seqSize, _ = cFeature.size()
+        windowSize = seqSize - self.nPredicts
+        if negatives is None:
+            negatives = self.drawNegatives(batchSize, seqSize, windowSize, cFeature.device)
+        ext = self.negativeRows(negatives[0], negatives[1], batchSize, seqSize, windowSize)
+        losses, acc = InfoNCEFunction.apply(cFeature, encodedData, self.wPrediction.stacked_weight(), ext)
+        return losses.view(1, -1), acc.view(1, -1)

@@ -485,17 +485,14 @@ extern "C" int cpc_set_conv_tile(int bm) {
     return 0;
 }
 
-// One conv layer forward (layers 1..4): x (B,Lin,C) -> y, xhat (B,Lout,C), rstd (B*Lout).
-// wp is scratch for the permuted weight (256*k*256 floats).
-extern "C" int cpc_conv_layer_forward(const float* x, const float* w, const float* bias,
-                                      const float* nw, const float* nb, float* wp, float* y,
-                                      float* xhat, float* rstd, int B, int Lin, int k, int s, int p,
-                                      void* stream) {
+// The forward GEMM kernel alone, on an already permuted weight wp[co][kk*C+ci] (exactly one
+// kernel launch: this is what bench.py times for the roofline figure).
+extern "C" int cpc_conv_gemm_forward(const float* x, const float* wp, const float* bias, const float* nw,
+                                     const float* nb, float* y, float* xhat, float* rstd, int B, int Lin,
+                                     int k, int s, int p, void* stream) {
     CPC_RETURN_IF(B <= 0 || Lin <= 0 || k != 2 * s || Lin + 2 * p < k, CPC_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     const int Lout = conv_out_len(Lin, k, s, p);
-    const long nw_elems = (long)kC * k * kC;
-    hipLaunchKernelGGL(permute_w_fwd_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wp, k);
     const RowMap am = conv_rows(x, B, Lin, Lout, s, p);
     const int K = k * kC;
     switch (pick_bm(am.M)) {
@@ -505,6 +502,18 @@ extern "C" int cpc_conv_layer_forward(const float* x, const float* w, const floa
     }
     CPC_LAUNCH_CHECK();
     return 0;
+}
+
+// One conv layer forward (layers 1..4): x (B,Lin,C) -> y, xhat (B,Lout,C), rstd (B*Lout).
+// wp is scratch for the permuted weight (256*k*256 floats).
+extern "C" int cpc_conv_layer_forward(const float* x, const float* w, const float* bias,
+                                      const float* nw, const float* nb, float* wp, float* y,
+                                      float* xhat, float* rstd, int B, int Lin, int k, int s, int p,
+                                      void* stream) {
+    CPC_RETURN_IF(B <= 0 || Lin <= 0 || k != 2 * s || Lin + 2 * p < k, CPC_ERR_SHAPE);
+    const long nw_elems = (long)kC * k * kC;
+    hipLaunchKernelGGL(permute_w_fwd_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, k);
+    return cpc_conv_gemm_forward(x, wp, bias, nw, nb, y, xhat, rstd, B, Lin, k, s, p, stream);
 }
 
 // ReLU'/ChannelNorm backward of a whole (M,256) activation: dy -> dx, plus

@@ -1,0 +1,144 @@
+"""Drop-in replacements for the hot-path modules of the reference's cpc/model.py.
+
+Same class names, constructor signatures, attributes and state-dict keys
+(gEncoder.conv{i}.{weight,bias}, gEncoder.batchNorm{i}.{weight,bias} of shape (1,C,1),
+gAR.baseNet.{weight,bias}_{ih,hh}_l{n}), so reference checkpoints load and the
+reference's cpc/train.py loop can drive these modules unchanged.
+forward/backward run in the HIP kernels of libcpc_hip.so.
+"""
+import torch
+import torch.nn as nn
+
+from .ops import EncoderFunction, GruFunction
+
+
+class ChannelNorm(nn.Module):
+    """cpc/model.py:25-58.  Inside CPCEncoder the normalisation is fused into the conv
+    kernels; this module owns the affine parameters (checkpoint keys) and, when called on
+    its own, evaluates the same formula with torch ops (not on the train-step hot path)."""
+
+    def __init__(self, numFeatures, epsilon=1e-05, affine=True):
+        super().__init__()
+        if affine:
+            self.weight = nn.parameter.Parameter(torch.Tensor(1, numFeatures, 1))
+            self.bias = nn.parameter.Parameter(torch.Tensor(1, numFeatures, 1))
+        else:
+            self.weight = None
+            self.bias = None
+        self.epsilon = epsilon
+        self.p = 0
+        self.affine = affine
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.affine:
+            torch.nn.init.ones_(self.weight)
+            torch.nn.init.zeros_(self.bias)
+
+    def forward(self, x):
+        cumMean = x.mean(dim=1, keepdim=True)
+        cumVar = x.var(dim=1, keepdim=True)
+        x = (x - cumMean) * torch.rsqrt(cumVar + self.epsilon)
+        if self.weight is not None:
+            x = x * self.weight + self.bias
+        return x
+
+
+class CPCEncoder(nn.Module):
+    """cpc/model.py:61-105: five strided Conv1d + ChannelNorm + ReLU, downsampling 160.
+
+    conv{i} / batchNorm{i} are parameter containers with the reference's names, shapes and
+    default initialisation; forward runs cpc_encoder_forward (HIP)."""
+
+    def __init__(self, sizeHidden=512, normMode="layerNorm"):
+        super().__init__()
+        validModes = ["batchNorm", "instanceNorm", "ID", "layerNorm"]
+        if normMode not in validModes:
+            raise ValueError(f"Norm mode must be in {validModes}")
+        if normMode != "layerNorm":
+            raise NotImplementedError("the HIP encoder implements normMode='layerNorm' (ChannelNorm), "
+                                      "the reference default (cpc_default_config.py:60-63)")
+        if sizeHidden != 256:
+            raise NotImplementedError("the HIP encoder is built for hiddenEncoder == 256 "
+                                      "(cpc_default_config.py:17)")
+        self.dimEncoded = sizeHidden
+        self.conv0 = nn.Conv1d(1, sizeHidden, 10, stride=5, padding=3)
+        self.batchNorm0 = ChannelNorm(sizeHidden)
+        self.conv1 = nn.Conv1d(sizeHidden, sizeHidden, 8, stride=4, padding=2)
+        self.batchNorm1 = ChannelNorm(sizeHidden)
+        self.conv2 = nn.Conv1d(sizeHidden, sizeHidden, 4, stride=2, padding=1)
+        self.batchNorm2 = ChannelNorm(sizeHidden)
+        self.conv3 = nn.Conv1d(sizeHidden, sizeHidden, 4, stride=2, padding=1)
+        self.batchNorm3 = ChannelNorm(sizeHidden)
+        self.conv4 = nn.Conv1d(sizeHidden, sizeHidden, 4, stride=2, padding=1)
+        self.batchNorm4 = ChannelNorm(sizeHidden)
+        self.DOWNSAMPLING = 160
+
+    def getDimOutput(self):
+        return self.conv4.out_channels
+
+    def _flat_params(self):
+        out = []
+        for i in range(5):
+            conv, norm = getattr(self, f"conv{i}"), getattr(self, f"batchNorm{i}")
+            out += [conv.weight, conv.bias, norm.weight, norm.bias]
+        return out
+
+    def forward(self, x):
+        """(B,1,L) -> (B,C,L/160), as the reference.  The kernels work channels-last, so the
+        result is a (B,C,S) VIEW of a contiguous (B,S,C) tensor; CPCModel's permute(0,2,1)
+        (model.py:287) therefore yields a contiguous (B,S,C) z at no cost."""
+        z = EncoderFunction.apply(x, *self._flat_params())
+        return z.permute(0, 2, 1)
+
+
+class CPCAR(nn.Module):
+    """cpc/model.py:155-204.  baseNet is a torch.nn.GRU used as the parameter container
+    (same keys / gate layout); forward runs cpc_gru_forward (HIP)."""
+
+    def __init__(self, dimEncoded, dimOutput, keepHidden, nLevelsGRU, mode="GRU", reverse=False):
+        super().__init__()
+        self.RESIDUAL_STD = 0.1
+        if mode in ("LSTM", "RNN"):
+            raise NotImplementedError(f"arMode={mode!r}: the HIP autoregressor implements the GRU "
+                                      "(the north-star configuration, --arMode GRU)")
+        if dimEncoded != 256 or dimOutput != 256:
+            raise NotImplementedError("the HIP GRU is built for hiddenEncoder == hiddenGar == 256")
+        self.baseNet = nn.GRU(dimEncoded, dimOutput, num_layers=nLevelsGRU, batch_first=True)
+        self.hidden = None
+        self.keepHidden = keepHidden
+        self.reverse = reverse
+
+    def getDimOutput(self):
+        return self.baseNet.hidden_size
+
+    def _flat_params(self):
+        out = []
+        for l in range(self.baseNet.num_layers):
+            out += [getattr(self.baseNet, f"{n}_l{l}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        return out
+
+    def forward(self, x):
+        if self.reverse:
+            x = torch.flip(x, [1])
+        x, h = GruFunction.apply(x, self.hidden, *self._flat_params())
+        if self.keepHidden:
+            self.hidden = h.detach()
+        # For better modularity, a sequence's order should be preserved by each module
+        if self.reverse:
+            x = torch.flip(x, [1])
+        return x
+
+
+class CPCModel(nn.Module):
+    """cpc/model.py:276-289."""
+
+    def __init__(self, encoder, AR):
+        super().__init__()
+        self.gEncoder = encoder
+        self.gAR = AR
+
+    def forward(self, batchData, label):
+        encodedData = self.gEncoder(batchData).permute(0, 2, 1)
+        cFeature = self.gAR(encodedData)
+        return cFeature, encodedData, label

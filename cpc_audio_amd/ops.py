@@ -1,0 +1,173 @@
+"""torch.autograd.Function wrappers over the C ABI (include/cpc_hip.h).
+
+Each Function is one node of the autograd graph for a whole stage of the hot path
+(encoder / autoregressor / criterion), so the Python overhead per train step is three
+forward and three backward calls.  All device memory (outputs, saved activations,
+scratch) comes from torch's caching allocator; kernels are enqueued on torch's current
+stream of the input's device.  There is no CPU implementation: CPU tensors raise.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ptr as _p
+
+_HID = 256
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"cpc_audio_amd.{what}: expected a tensor on an AMD GPU (got {t.device}); "
+                           "this package has no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"cpc_audio_amd.{what}: fp32 expected, got {t.dtype}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptrs(ts):
+    return (ctypes.c_void_p * len(ts))(*[_p(t) for t in ts])
+
+
+_layout_cache = {}
+
+# Parity tests set KEEP_DEBUG = True to look at the encoder's saved activations (the ReLU
+# masks of the device path, see oracle/cpc_oracle._ReluTieAware).  Never used by the product.
+KEEP_DEBUG = False
+debug_last = {}
+
+
+def _layout(kind, fn, n, *args):
+    key = (kind,) + args
+    v = _layout_cache.get(key)
+    if v is None:
+        sizes = (ctypes.c_long * n)()
+        _lib.Bound.check(fn(*args, sizes), kind)
+        v = tuple(sizes)
+        _layout_cache[key] = v
+    return v
+
+
+class EncoderFunction(torch.autograd.Function):
+    """wave (B,1,L) + the 20 encoder parameters (state-dict order) -> z (B, L/160, 256)."""
+
+    @staticmethod
+    def forward(ctx, wave, *params):
+        _require_cuda(wave, "EncoderFunction")
+        lib = _lib.get()
+        B, ch, L = wave.shape
+        if ch != 1:
+            raise ValueError("CPCEncoder expects (B,1,L) waveforms")
+        wave = wave.contiguous()
+        params = [p.detach().contiguous() for p in params]
+        with torch.cuda.device(wave.device):
+            sizes = _layout("encoder_layout", lib.cpc_encoder_layout, 22, B, L)
+            saved = torch.empty(sizes[0], device=wave.device, dtype=torch.float32)
+            scratch = torch.empty(max(1, sizes[1]), device=wave.device, dtype=torch.float32)
+            z = torch.empty(B, sizes[7], _HID, device=wave.device, dtype=torch.float32)
+            lib.check(lib.cpc_encoder_forward(_p(wave), _ptrs(params), _p(saved), _p(scratch), _p(z), B, L,
+                                              _stream()), "encoder_forward")
+        ctx.save_for_backward(wave, saved, z, *params)
+        ctx.dims = (B, L, sizes[2])
+        if KEEP_DEBUG:
+            debug_last["encoder"] = (saved, sizes, z)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.get()
+        wave, saved, z, *params = ctx.saved_tensors
+        B, L, nscr = ctx.dims
+        dz = dz.contiguous()
+        with torch.cuda.device(wave.device):
+            scratch = torch.empty(nscr, device=wave.device, dtype=torch.float32)
+            grads = [torch.empty_like(p) for p in params]
+            lib.check(lib.cpc_encoder_backward(_p(wave), _ptrs(params), _p(saved), _p(z), _p(dz), _p(scratch),
+                                               _ptrs(grads), B, L, _stream()), "encoder_backward")
+        return (None, *grads)
+
+
+class GruFunction(torch.autograd.Function):
+    """x (B,S,256), h0 (nl,B,256) or None, 4*nl GRU parameters -> y (B,S,256), hN (nl,B,256)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, *params):
+        _require_cuda(x, "GruFunction")
+        lib = _lib.get()
+        B, S, D = x.shape
+        nl = len(params) // 4
+        if D != _HID or params[1].shape != (3 * _HID, _HID):
+            raise NotImplementedError("the HIP GRU is built for dimEncoded == dimOutput == 256")
+        x = x.contiguous()
+        params = [p.detach().contiguous() for p in params]
+        h0c = None if h0 is None else h0.detach().contiguous()
+        with torch.cuda.device(x.device):
+            sizes = _layout("gru_layout", lib.cpc_gru_layout, 3, B, S, nl)
+            saved = torch.empty(sizes[0], device=x.device, dtype=torch.float32)
+            scratch = torch.empty(sizes[1], device=x.device, dtype=torch.float32)
+            y = torch.empty(B, S, _HID, device=x.device, dtype=torch.float32)
+            hN = torch.empty(nl, B, _HID, device=x.device, dtype=torch.float32)
+            lib.check(lib.cpc_gru_forward(_p(x), _p(h0c), _ptrs(params), _p(saved), _p(scratch), _p(y), _p(hN),
+                                          B, S, nl, _stream()), "gru_forward")
+        ctx.save_for_backward(x, saved, y, *params)
+        ctx.h0 = h0c
+        ctx.dims = (B, S, nl, sizes[2])
+        ctx.mark_non_differentiable(hN)
+        return y, hN
+
+    @staticmethod
+    def backward(ctx, dy, _dhN):
+        lib = _lib.get()
+        x, saved, y, *params = ctx.saved_tensors
+        B, S, nl, nscr = ctx.dims
+        dy = dy.contiguous()
+        with torch.cuda.device(x.device):
+            scratch = torch.empty(nscr, device=x.device, dtype=torch.float32)
+            dx = torch.empty_like(x)
+            grads = [torch.empty_like(p) for p in params]
+            lib.check(lib.cpc_gru_backward(_p(x), _p(ctx.h0), _ptrs(params), _p(saved), _p(y), _p(dy),
+                                           _p(scratch), _p(dx), _ptrs(grads), B, S, nl, _stream()), "gru_backward")
+        return (dx, None, *grads)
+
+
+class InfoNCEFunction(torch.autograd.Function):
+    """c, z (B,S,256), wall (K*256,256), ext (B,W,N) int32 -> losses (K), acc (K)."""
+
+    @staticmethod
+    def forward(ctx, c, z, wall, ext):
+        _require_cuda(c, "InfoNCEFunction")
+        lib = _lib.get()
+        B, S, H = c.shape
+        K = wall.shape[0] // _HID
+        W, N = ext.shape[1], ext.shape[2]
+        if H != _HID or z.shape != (B, S, _HID) or W != S - K or ext.dtype != torch.int32:
+            raise ValueError("InfoNCEFunction: inconsistent shapes")
+        c, z, wall, ext = c.contiguous(), z.contiguous(), wall.detach().contiguous(), ext.contiguous()
+        with torch.cuda.device(c.device):
+            sizes = _layout("nce_layout", lib.cpc_nce_layout, 6, B, S, K, N)
+            saved = torch.empty(sizes[0], device=c.device, dtype=torch.float32)
+            scratch = torch.empty(sizes[1], device=c.device, dtype=torch.float32)
+            losses = torch.empty(K, device=c.device, dtype=torch.float32)
+            acc = torch.empty(K, device=c.device, dtype=torch.float32)
+            lib.check(lib.cpc_nce_forward(_p(c), _p(z), _p(wall), _p(ext), _p(saved), _p(scratch), _p(losses),
+                                          _p(acc), B, S, K, N, _stream()), "nce_forward")
+        ctx.save_for_backward(c, z, wall, ext, saved)
+        ctx.dims = (B, S, K, N, sizes[2])
+        ctx.mark_non_differentiable(acc)
+        return losses, acc
+
+    @staticmethod
+    def backward(ctx, gloss, _gacc):
+        lib = _lib.get()
+        c, z, wall, ext, saved = ctx.saved_tensors
+        B, S, K, N, nscr = ctx.dims
+        gloss = gloss.contiguous()
+        with torch.cuda.device(c.device):
+            scratch = torch.empty(nscr, device=c.device, dtype=torch.float32)
+            dc, dz, dwall = torch.empty_like(c), torch.empty_like(z), torch.empty_like(wall)
+            lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(saved), _p(gloss), _p(scratch),
+                                           _p(dc), _p(dz), _p(dwall), B, S, K, N, _stream()), "nce_backward")
+        return dc, dz, dwall, None

@@ -1,0 +1,47 @@
+"""Minimal train-step harness with the semantics of the reference's cpc/train.py:trainStep
+(:78-99): forward, ``allLosses.sum().backward()``, gradient SUM-all-reduce across ranks (in
+place of nn.DataParallel's reduce-add), Adam step, zero_grad.  Builders mirror
+cpc/feature_loader.py:124-153 and cpc/train.py:24-51 for the north-star configuration
+(--arMode GRU --nLevelsGRU 2 --rnnMode linear)."""
+import torch
+
+from .criterion import CPCUnsupersivedCriterion
+from .dist import FlatGradAllReduce
+from .model import CPCAR, CPCEncoder, CPCModel
+
+
+def build_model(hiddenEncoder=256, hiddenGar=256, nLevelsGRU=2, keepHidden=False, reverse=False):
+    enc = CPCEncoder(hiddenEncoder, "layerNorm")
+    ar = CPCAR(hiddenEncoder, hiddenGar, keepHidden, nLevelsGRU, mode="GRU", reverse=reverse)
+    return CPCModel(enc, ar)
+
+
+def build_criterion(nPredicts=12, hiddenGar=256, hiddenEncoder=256, negativeSamplingExt=128,
+                    sizeWindow=20480, downsampling=160, mode=None):
+    return CPCUnsupersivedCriterion(nPredicts, hiddenGar, hiddenEncoder, negativeSamplingExt, mode=mode,
+                                    rnnMode="linear", dropout=False, sizeInputSeq=sizeWindow // downsampling)
+
+
+def load_flat_params(model, criterion, params):
+    """Load a dict keyed like the reference's state dicts (gEncoder.*, gAR.*, wPrediction.*)."""
+    model.load_state_dict({k: v for k, v in params.items() if not k.startswith("wPrediction")}, strict=True)
+    criterion.load_state_dict({k: v for k, v in params.items() if k.startswith("wPrediction")}, strict=True)
+
+
+class Trainer:
+    def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.model, self.criterion = model, criterion
+        params = list(criterion.parameters()) + list(model.parameters())      # train.py:332
+        fused = all(p.is_cuda for p in params)     # one fused multi-tensor kernel on the GPU
+        self.optimizer = torch.optim.Adam(params, lr=lr, betas=betas, eps=eps, fused=fused)  # train.py:335-337
+        self.allreduce = FlatGradAllReduce(params)
+
+    def step(self, batchData, label, negatives=None):
+        c_feature, encoded_data, label = self.model(batchData, label)
+        allLosses, allAcc = self.criterion(c_feature, encoded_data, label, negatives=negatives)
+        totLoss = allLosses.sum()
+        totLoss.backward()
+        self.allreduce()
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        return allLosses.detach(), allAcc.detach()

@@ -51,6 +51,10 @@ int cpc_conv0_backward(const float* wave, const float* w, const float* bias, con
 int cpc_conv_layer_forward(const float* x, const float* w, const float* bias, const float* nw,
                            const float* nb, float* wp, float* y, float* xhat, float* rstd, int B,
                            int Lin, int k, int s, int p, void* stream);
+/* The forward GEMM kernel alone on an already permuted weight wp[co][kk*256+ci] (one launch). */
+int cpc_conv_gemm_forward(const float* x, const float* wp, const float* bias, const float* nw,
+                          const float* nb, float* y, float* xhat, float* rstd, int B, int Lin, int k,
+                          int s, int p, void* stream);
 /* ReLU' + ChannelNorm backward over M rows; small3 = [d norm.w | d norm.b | d conv.bias]. */
 int cpc_norm_backward(const float* dy, const float* xhat, const float* y, const float* rstd,
                       const float* nw, float* dx, float* colpart, float* tmp, float* small3, int M,

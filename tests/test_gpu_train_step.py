@@ -1,0 +1,77 @@
+"""Whole train-step forward/backward of the drop-in modules on a real MI355X vs the CPU oracle
+and vs the committed golden vectors (the REFERENCE's results)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _hip_step(p, wave, bidx, sidx, dev):
+    from cpc_audio_amd import ops
+    from cpc_audio_amd.train import build_criterion, build_model, load_flat_params
+    model, crit = build_model().to(dev), build_criterion().to(dev)
+    load_flat_params(model, crit, p)
+    model.train(); crit.train()
+    ops.KEEP_DEBUG = True
+    c, z, _ = model(wave.to(dev), torch.zeros(wave.shape[0], dtype=torch.long, device=dev))
+    saved, sizes, zz = ops.debug_last["encoder"]
+    ops.KEEP_DEBUG = False
+    z.retain_grad(); c.retain_grad()
+    losses, acc = crit(c, z, None, negatives=(bidx.to(dev), sidx.to(dev)))
+    losses.sum().backward()
+    torch.cuda.synchronize()
+    B = wave.shape[0]
+    Ls = [sizes[3 + i] for i in range(5)]
+    ys = [saved[sizes[8 + i]: sizes[8 + i] + B * Ls[i] * 256].view(B, Ls[i], 256).cpu() for i in range(4)] + [zz.cpu()]
+    grads = {}
+    for k, v in model.state_dict(keep_vars=True).items():
+        grads[k] = v.grad.cpu()
+    for k, v in crit.state_dict(keep_vars=True).items():
+        grads[k] = v.grad.cpu()
+    return dict(c=c.detach().cpu(), z=z.detach().cpu(), losses=losses.detach().cpu(), acc=acc.detach().cpu(),
+                grads=grads, dz=z.grad.cpu(), dc=c.grad.cpu(), masks=[(y > 0).permute(0, 2, 1) for y in ys])
+
+
+@pytest.mark.parametrize("case", ["b2_init", "b2_hot", "b8_cfg1"])
+def test_train_step_matches_oracle_and_reference_golden(case, golden_dir):
+    dev = _dev()
+    with open(os.path.join(golden_dir, "meta.json")) as f:
+        m = json.load(f)["cases"][case]
+    fx = np.load(os.path.join(golden_dir, f"{case}.npz"))
+    B = m["batch"]
+    p = O.make_params(seed=m["param_seed"], head_scale=m["head_scale"])
+    wave = O.make_waveform(B, 20480, seed=m["wave_seed"])
+    bidx = torch.from_numpy(fx["batch_idx"].astype(np.int64))
+    sidx = torch.from_numpy(fx["seq_idx"].astype(np.int64))
+    hip = _hip_step(p, wave, bidx, sidx, dev)
+    ora = O.train_step(p, wave, bidx, sidx, relu_override=hip["masks"])
+
+    # --- north-star tolerance: encoder/context outputs and InfoNCE loss within 1e-4 (fp32)
+    assert (hip["z"] - ora["z"]).abs().max().item() < 1e-4
+    assert (hip["c"] - ora["c"]).abs().max().item() < 1e-4
+    assert (hip["losses"] - ora["losses"]).abs().max().item() < 1e-4
+    # ... and against the REFERENCE's own numbers (golden fixture)
+    assert np.abs(hip["losses"].numpy() - fx["losses"]).max() < 1e-4
+    assert np.abs(hip["acc"].numpy() - fx["acc"]).max() <= 2.0 / (116 * B) + 1e-7
+    if m["full"]:
+        assert np.abs(hip["z"][:, ::16, :].numpy() - fx["z_slice"]).max() < 1e-4
+        assert np.abs(hip["c"][:, ::16, :].numpy() - fx["c_slice"]).max() < 1e-4
+    # --- gradients (beyond the north-star bar): relative 1e-4 on every parameter
+    bad = {}
+    for k, g in ora["grads"].items():
+        rel = ((hip["grads"][k] - g).norm() / (g.norm() + 1e-30)).item()
+        if not rel < 2e-4:
+            bad[k] = rel
+    assert not bad, bad
