@@ -39,7 +39,7 @@ SIGNATURES = {
     "cpc_gru_backward": (_I, [_P] * 9 + [_I, _I, _I, _P]),
     "cpc_nce_layout": (_I, [_I, _I, _I, _I, _P]),
     "cpc_nce_forward": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
-    "cpc_nce_backward": (_I, [_P] * 10 + [_I, _I, _I, _I, _P]),
+    "cpc_nce_backward": (_I, [_P] * 12 + [_I, _I, _I, _I, _P]),
 }
 
 

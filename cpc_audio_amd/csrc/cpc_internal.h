@@ -6,7 +6,8 @@
 namespace cpc {
 
 // out[0:n] = sum over `nrows` rows of `part` (row length n), summed in a fixed order.
-// tmp must hold 64*n floats.
+// tmp must hold kRowsSumGroups*n floats.
+constexpr int kRowsSumGroups = 128;
 int rows_sum(const float* part, int nrows, int n, float* tmp, float* out, hipStream_t stream);
 
 // C[M,N] = A . B[N,K]^T (+ bias);  N % 128 == 0, K % 16 == 0

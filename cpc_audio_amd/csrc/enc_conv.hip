@@ -381,6 +381,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     dw[((long)co * kC + ci) * k + kk] = sum;
 }
 
+struct GradPtrs { float* p[12]; };
+// small[i] = [d norm.weight | d norm.bias | d conv.bias] of layer i+1 -> the 12 parameter-gradient tensors
+__global__ __launch_bounds__(256) void small_to_grads_kernel(const float* __restrict__ small, GradPtrs g) {
+    const int q = blockIdx.x;                 // 0..11 : layer (q/3)+1, item q%3
+    g.p[q][threadIdx.x] = small[(long)(q / 3 + 1) * 3 * kC + (q % 3) * kC + threadIdx.x];
+}
+
 // ------------------------------------------------------------------ host side
 struct ConvGeom { int k, s, p; };
 static const ConvGeom kGeom[5] = {{10, 5, 3}, {8, 4, 2}, {4, 2, 1}, {4, 2, 1}, {4, 2, 1}};
@@ -402,7 +409,9 @@ struct EncLayout {
 static int g_force_bm = 0;   // 0 = choose by problem size; 32/64/128 = tuning / test override
 static int pick_bm(int M) {
     if (g_force_bm) return g_force_bm;
-    return M >= 128 * 512 ? 128 : (M >= 64 * 512 ? 64 : 32);
+    // measured on MI355X (tools/bench_kernels.py): 128-row tiles win as soon as they give ~256 blocks
+    // (the 256-column weight tile is re-read from L2 once per block); below that the 32-row tile wins.
+    return M >= 32000 ? 128 : 32;
 }
 
 static bool enc_layout(int B, int Lw, EncLayout& e) {
@@ -451,7 +460,7 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     col_max = std::max(col_max, (long)cdiv(B * e.L[4], NB_ROWS));
     e.part = o; o += align64(part_max);
     e.colpart = o; o += align64(col_max * 3 * kC);
-    e.tmp = o; o += align64(64L * 3 * kC);
+    e.tmp = o; o += align64((long)kRowsSumGroups * 3 * kC);
     e.small = o; o += align64(5L * 3 * kC);
     e.conv0 = o; o += align64(cpc_conv0_backward_scratch_floats(B, Lw));
     e.bwd_total = o;
@@ -518,7 +527,7 @@ extern "C" int cpc_conv_layer_forward(const float* x, const float* w, const floa
 
 // ReLU'/ChannelNorm backward of a whole (M,256) activation: dy -> dx, plus
 // small3 = [d norm.weight | d norm.bias | d conv.bias] (3*256 floats).
-// colpart: cdiv(M,32)*768 floats, tmp: 64*768 floats.
+// colpart: cdiv(M,32)*768 floats, tmp: kRowsSumGroups*768 floats.
 extern "C" int cpc_norm_backward(const float* dy, const float* xhat, const float* y,
                                  const float* rstd, const float* nw, float* dx, float* colpart,
                                  float* tmp, float* small3, int M, void* stream) {
@@ -659,12 +668,13 @@ extern "C" int cpc_encoder_backward(const float* wave, const float* const* param
                             grads[2], grads[3], B, L, stream);
     if (rc) return rc;
     // layers 1..4: small[i] = [d norm.weight | d norm.bias | d conv.bias]
+    GradPtrs gp;
     for (int i = 1; i < 5; ++i) {
-        const float* s3 = small + i * 3 * kC;
-        (void)hipMemcpyAsync(grads[4 * i + 2], s3, sizeof(float) * kC, hipMemcpyDeviceToDevice, st);
-        (void)hipMemcpyAsync(grads[4 * i + 3], s3 + kC, sizeof(float) * kC, hipMemcpyDeviceToDevice, st);
-        (void)hipMemcpyAsync(grads[4 * i + 1], s3 + 2 * kC, sizeof(float) * kC, hipMemcpyDeviceToDevice, st);
+        gp.p[(i - 1) * 3 + 0] = grads[4 * i + 2];
+        gp.p[(i - 1) * 3 + 1] = grads[4 * i + 3];
+        gp.p[(i - 1) * 3 + 2] = grads[4 * i + 1];
     }
+    hipLaunchKernelGGL(small_to_grads_kernel, dim3(12), dim3(256), 0, st, small, gp);
     CPC_LAUNCH_CHECK();
     return 0;
 }

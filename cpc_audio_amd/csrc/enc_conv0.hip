@@ -162,19 +162,34 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(
     }
 }
 
-// out[i] = sum_r part[r][i] for i < n, rows summed in index order by a 2-level fixed tree.
+// out[g][i] = sum of rows [g*rows_per_group, (g+1)*rows_per_group) of part (row length n).
+// Block = 32 columns x 8 row lanes; fixed summation order (deterministic).
 __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ part, int nrows,
-                                                       int n, int rows_per_block,
+                                                       int n, int rows_per_group,
                                                        float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int r0 = blockIdx.y * rows_per_block;
-    const int r1 = min(nrows, r0 + rows_per_block);
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += part[(long)r * n + i];
-    out[(long)blockIdx.y * n + i] = s;
+    __shared__ float red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + tx;
+    const int r0 = blockIdx.y * rows_per_group;
+    const int r1 = min(nrows, r0 + rows_per_group);
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int r = r0 + ty;
+        for (; r + 8 < r1; r += 16) {
+            s0 += part[(long)r * n + i];
+            s1 += part[(long)(r + 8) * n + i];
+        }
+        if (r < r1) s0 += part[(long)r * n + i];
+    }
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += red[q][tx];
+        out[(long)blockIdx.y * n + i] = s;
+    }
 }
-
 
 __global__ __launch_bounds__(256) void conv0_scatter_kernel(const float* __restrict__ sum,
                                                             float* __restrict__ dW0,
@@ -189,17 +204,17 @@ __global__ __launch_bounds__(256) void conv0_scatter_kernel(const float* __restr
     dNB0[c] = sum[(K0 + 2) * kC + c];
 }
 
-// sums `nrows` rows of length n in `part` into out[0:n]; `tmp` holds >= 64*n floats.
+// sums `nrows` rows of length n in `part` into out[0:n]; `tmp` holds >= kRowsSumGroups*n floats.
 int rows_sum(const float* part, int nrows, int n, float* tmp, float* out, hipStream_t stream) {
     if (nrows <= 0) { (void)hipMemsetAsync(out, 0, sizeof(float) * n, stream); return 0; }
-    int groups = nrows > 64 ? 64 : 1;
-    const int rpb = cdiv(nrows, groups);
-    groups = cdiv(nrows, rpb);
+    int groups = nrows > 64 ? kRowsSumGroups : 1;
+    const int rpg = cdiv(nrows, groups);
+    groups = cdiv(nrows, rpg);
     if (groups == 1) {
-        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 256), 1), dim3(256), 0, stream, part, nrows, n, nrows, out);
+        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 32), 1), dim3(256), 0, stream, part, nrows, n, nrows, out);
     } else {
-        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 256), groups), dim3(256), 0, stream, part, nrows, n, rpb, tmp);
-        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 256), 1), dim3(256), 0, stream, tmp, groups, n, groups, out);
+        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 32), groups), dim3(256), 0, stream, part, nrows, n, rpg, tmp);
+        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 32), 1), dim3(256), 0, stream, tmp, groups, n, groups, out);
     }
     CPC_LAUNCH_CHECK();
     return 0;
@@ -222,7 +237,7 @@ extern "C" int cpc_conv0_forward(const float* wave, const float* w, const float*
 
 extern "C" long cpc_conv0_backward_scratch_floats(int B, int L) {
     const int L0 = conv_out_len(L, K0, S0, P0);
-    return ((long)cdiv(L0, C0B_TT) * B + 65) * (C0_NACC * kC);
+    return ((long)cdiv(L0, C0B_TT) * B + kRowsSumGroups + 1) * (C0_NACC * kC);
 }
 
 // grads: dW0 (256*10), dB0 (256), dNW0 (256), dNB0 (256) -- overwritten, not accumulated.
@@ -235,8 +250,8 @@ extern "C" int cpc_conv0_backward(const float* wave, const float* w, const float
     const int nblk = cdiv(L0, C0B_TT) * B;
     const int n = C0_NACC * kC;
     float* part = scratch;                        // [nblk][13][256]
-    float* tmp = scratch + (long)nblk * n;        // 64 rows for the first reduction level
-    float* sum = tmp + 64L * n;                   // final [13][256]
+    float* tmp = scratch + (long)nblk * n;        // rows for the first reduction level
+    float* sum = tmp + (long)kRowsSumGroups * n;  // final [13][256]
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv0_bwd_kernel, dim3(cdiv(L0, C0B_TT), B), dim3(256), 0, st, wave, w, bias,
                        nw, nb, mean, rstd, dy, part, L, L0);

@@ -9,17 +9,19 @@
 
 namespace cpc {
 
-using NtG = NtTile<128, 128, 2, 2>;
+using NtBig = NtTile<128, 128, 2, 2>;     // 128x128 block, 64x64 per wave
+using NtSmall = NtTile<64, 64, 2, 2>;      // 64x64 block: used when the big tiling cannot fill 256 CUs
 using TnG = TnTile<128, 128, 2, 2>;
 
 // Output row m goes to C + m*ldc, or, when c_R > 0, to C + (m / c_R)*c_bstride + (m % c_R)*ldc
 // (a batch-strided view such as dc[:, :W]).
+template <class NtG, int BMN>
 __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const float* __restrict__ Bmat,
                                                                 int ldb, const float* __restrict__ bias,
                                                                 float* __restrict__ C, long ldc, int K,
                                                                 int c_R, long c_bstride) {
     __shared__ float smem[NtG::SMEM_FLOATS];
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int m0 = blockIdx.x * BMN, n0 = blockIdx.y * BMN;
     f32x16 acc[NtG::TM][NtG::TN];
     zero_acc(acc);
     NtG::run(acc, am, m0, Bmat, ldb, n0, K, smem);
@@ -94,8 +96,13 @@ int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, flo
             int N, int K, hipStream_t st, int c_R, long c_bstride) {
     if (am.M <= 0) return 0;
     if (N % 128 != 0 || K % 16 != 0 || K < 16) return CPC_ERR_SHAPE;
-    hipLaunchKernelGGL(nt_gemm_kernel, dim3(cdiv(am.M, 128), N / 128), dim3(NtG::NTHREADS), 0, st, am, Bmat,
-                       ldb, bias, C, ldc, K, c_R, c_bstride);
+    if ((long)cdiv(am.M, 128) * (N / 128) >= 384) {
+        hipLaunchKernelGGL((nt_gemm_kernel<NtBig, 128>), dim3(cdiv(am.M, 128), N / 128), dim3(NtBig::NTHREADS), 0,
+                           st, am, Bmat, ldb, bias, C, ldc, K, c_R, c_bstride);
+    } else {
+        hipLaunchKernelGGL((nt_gemm_kernel<NtSmall, 64>), dim3(cdiv(am.M, 64), N / 64), dim3(NtSmall::NTHREADS), 0,
+                           st, am, Bmat, ldb, bias, C, ldc, K, c_R, c_bstride);
+    }
     CPC_LAUNCH_CHECK();
     return 0;
 }

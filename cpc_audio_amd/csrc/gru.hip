@@ -181,7 +181,7 @@ static bool gru_layout(int B, int S, int nl, GruLayout& g) {
     g.mid[0] = o; o += bsh;
     g.mid[1] = o; o += bsh;
     g.part = o; o += align64l(tn_gemm_part_floats(B * S, kG, kH));
-    g.tmp = o; o += align64l(64L * kG);
+    g.tmp = o; o += align64l((long)kRowsSumGroups * kG);
     g.bwd_total = o;
     return true;
 }

@@ -18,7 +18,7 @@
 //
 // Backward per (b,t):
 //   dPred[16 x 256] = dS[16 x N] . Neg[N x 256]        (gather again, MFMA)
-//   dNeg [N x 256]  = dS^T[N x 16] . P[16 x 256]       (MFMA) -> atomically added into dz[ext]
+//   dNeg [N x 256]  = dS^T[N x 16] . P[16 x 256]       (MFMA) -> rows of V, gathered per z row
 // then the head GEMMs:  dc = dPred . W,  dW_k = dPred_k^T . c   (gemm.hip).
 #include "cpc_common.h"
 #include "cpc_internal.h"
@@ -187,15 +187,19 @@ __global__ __launch_bounds__(256) void nce_bwd_dpred_kernel(
     }
 }
 
-// ------------------------------------------------------------------ backward: dz (scatter)
-__global__ __launch_bounds__(256) void nce_bwd_dz_kernel(
-    const float* __restrict__ pred, const int* __restrict__ ext, const float* __restrict__ logits,
-    const float* __restrict__ lse, const float* __restrict__ gscale, float* __restrict__ dz, int BW, int W,
-    int S, int K, int N) {
+// ------------------------------------------------------------------ backward: dz
+// Every candidate (negative n or positive k of window (b,t)) contributes one 256-float row to
+// dz[its row of z].  Destinations are random, so instead of 32k float atomics per window the
+// contributions are first written as rows of V (slot = bt*(N+K) + candidate, plain coalesced
+// 16-byte stores straight from the MFMA accumulators), then reduced per destination row by
+// nce_gather_rows_kernel through a destination-sorted slot list: no atomics, no memset,
+// bit-reproducible.
+__global__ __launch_bounds__(256) void nce_bwd_dz_rows_kernel(
+    const float* __restrict__ pred, const float* __restrict__ logits, const float* __restrict__ lse,
+    const float* __restrict__ gscale, float* __restrict__ V, int BW, int K, int N) {
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bt >= BW) return;
-    const int b = bt / W, t = bt - b * W;
     const int i = lane & 15, kq = lane >> 4;
     // B operand: P[head 4s+kq][channels 64u + 4i + e]
     float4 pb[4][4];
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(256) void nce_bwd_dz_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u) pb[sx][u] = hv ? ld4(pp + 64 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float* vrow = V + (long)bt * (N + K) * kC + 4 * i;
     for (int nt = 0; nt < N / 16; ++nt) {
         f32x4 acc[16];
 #pragma unroll
@@ -228,27 +233,64 @@ __global__ __launch_bounds__(256) void nce_bwd_dz_kernel(
         // C layout: negative n = nt*16 + 4kq + r, channel = 64u + 4i + e
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = ext[(long)bt * N + nt * 16 + 4 * kq + r];
-            float* dst = dz + (long)row * kC + 4 * i;
+            float* dst = vrow + (long)(nt * 16 + 4 * kq + r) * kC;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(dst + 64 * u + e, acc[u * 4 + e][r]);
+            for (int u = 0; u < 4; ++u) {
+                float4 o;
+                o.x = acc[u * 4 + 0][r]; o.y = acc[u * 4 + 1][r]; o.z = acc[u * 4 + 2][r]; o.w = acc[u * 4 + 3][r];
+                *reinterpret_cast<float4*>(dst + 64 * u) = o;
+            }
         }
     }
-    // positives: dz[b, t+k] += d score[k][pos] * P[k]
+    // positives: candidate slot N + head carries d score[head][pos] * P[head]
 #pragma unroll
     for (int sx = 0; sx < 4; ++sx) {
         const int head = 4 * sx + kq;
         if (head < K) {
             const float d0 = gs[sx] * (expf(lp[sx][0] - ls[sx]) - 1.0f);
-            float* dst = dz + ((long)b * S + t + head + 1) * kC + 4 * i;
+            float* dst = vrow + (long)(N + head) * kC;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(dst + 64 * u + e, d0 * f4c(pb[sx][u], e));
+            for (int u = 0; u < 4; ++u) {
+                float4 o;
+                o.x = d0 * pb[sx][u].x; o.y = d0 * pb[sx][u].y; o.z = d0 * pb[sx][u].z; o.w = d0 * pb[sx][u].w;
+                *reinterpret_cast<float4*>(dst + 64 * u) = o;
+            }
         }
     }
+}
+
+// dz[j] = sum of V rows whose destination is j:  slots perm[row_ptr[j] .. row_ptr[j+1]).
+// One wavefront per destination row, 4 channels per lane, 4 independent row loads in flight.
+__global__ __launch_bounds__(256) void nce_gather_rows_kernel(const float* __restrict__ V,
+                                                              const int* __restrict__ perm,
+                                                              const int* __restrict__ row_ptr,
+                                                              float* __restrict__ dz, int nrows) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= nrows) return;
+    const int beg = row_ptr[j], end = row_ptr[j + 1];
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    int p = beg;
+    for (; p + 4 <= end; p += 4) {
+        const float4 v0 = ld4(V + (long)perm[p] * kC + 4 * lane);
+        const float4 v1 = ld4(V + (long)perm[p + 1] * kC + 4 * lane);
+        const float4 v2 = ld4(V + (long)perm[p + 2] * kC + 4 * lane);
+        const float4 v3 = ld4(V + (long)perm[p + 3] * kC + 4 * lane);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; p < end; ++p) {
+        const float4 v0 = ld4(V + (long)perm[p] * kC + 4 * lane);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    float4 o;
+    o.x = (a0.x + a1.x) + (a2.x + a3.x);
+    o.y = (a0.y + a1.y) + (a2.y + a3.y);
+    o.z = (a0.z + a1.z) + (a2.z + a3.z);
+    o.w = (a0.w + a1.w) + (a2.w + a3.w);
+    *reinterpret_cast<float4*>(dz + (long)j * kC + 4 * lane) = o;
 }
 
 // ------------------------------------------------------------------ host side
@@ -256,7 +298,7 @@ struct NceLayout {
     int W, BW;
     long pred, logits, lse, saved_total;
     long rowstat, tmp, sums, fwd_total;
-    long dpred, wallT, part, gscale, bwd_total;
+    long dpred, wallT, part, gscale, V, bwd_total;
 };
 
 static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
@@ -270,7 +312,7 @@ static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     n.saved_total = o;
     o = 0;
     n.rowstat = o; o += align64l((long)n.BW * 2 * K);
-    n.tmp = o; o += align64l(64L * 2 * K);
+    n.tmp = o; o += align64l((long)kRowsSumGroups * 2 * K);
     n.sums = o; o += 64;
     n.fwd_total = o;
     o = 0;
@@ -278,6 +320,7 @@ static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     n.wallT = o; o += (long)kC * K * kC;
     n.part = o; o += align64l(tn_gemm_part_floats(n.BW, K * kC, kC));
     n.gscale = o; o += 64;
+    n.V = o; o += align64l((long)n.BW * (N + K) * kC);
     n.bwd_total = o;
     return true;
 }
@@ -326,24 +369,29 @@ extern "C" int cpc_nce_forward(const float* c, const float* z, const float* wall
 }
 
 // gloss: K upstream gradients dL/dloss_k (device).  Outputs (overwritten): dc, dz (B,S,256), dwall (K*256,256).
+// perm / row_ptr: the candidate slots (slot = (b*W+t)*(N+K) + j; j < N negative j, j >= N positive
+// of head j-N, whose destination row is b*S + t + (j-N) + 1) sorted by destination row of z:
+// row_ptr has B*S+1 entries, perm[row_ptr[r] .. row_ptr[r+1]) are the slots landing on row r.
 extern "C" int cpc_nce_backward(const float* c, const float* z, const float* wall, const int* ext,
-                                const float* saved, const float* gloss, float* scratch, float* dc, float* dz,
-                                float* dwall, int B, int S, int K, int N, void* stream) {
+                                const int* perm, const int* row_ptr, const float* saved, const float* gloss,
+                                float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K, int N,
+                                void* stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
-    CPC_RETURN_IF(!c || !z || !wall || !ext || !saved || !gloss || !scratch || !dc || !dz || !dwall, CPC_ERR_ARG);
+    CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc || !dz || !dwall, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     const float* pred = saved + n.pred, *logits = saved + n.logits, *lse = saved + n.lse;
     float* dpred = scratch + n.dpred, *gscale = scratch + n.gscale, *wallT = scratch + n.wallT;
     hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale, K,
                        1.0f / ((float)n.BW * (float)kC));
-    (void)hipMemsetAsync(dz, 0, sizeof(float) * (size_t)B * S * kC, st);
     (void)hipMemsetAsync(dc, 0, sizeof(float) * (size_t)B * S * kC, st);
     const dim3 grid(cdiv(n.BW, 4));
     hipLaunchKernelGGL(nce_bwd_dpred_kernel, grid, dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
                        n.W, S, K, N);
-    hipLaunchKernelGGL(nce_bwd_dz_kernel, grid, dim3(256), 0, st, pred, ext, logits, lse, gscale, dz, n.BW, n.W,
-                       S, K, N);
+    hipLaunchKernelGGL(nce_bwd_dz_rows_kernel, grid, dim3(256), 0, st, pred, logits, lse, gscale, scratch + n.V,
+                       n.BW, K, N);
+    hipLaunchKernelGGL(nce_gather_rows_kernel, dim3(cdiv(B * S, 4)), dim3(256), 0, st, scratch + n.V, perm, row_ptr,
+                       dz, B * S);
     CPC_LAUNCH_CHECK();
     // dc[:, :W] = dPred . Wall  (NT against Wall^T [256][K*256])
     int rc = transpose(wall, wallT, K * kC, kC, st);

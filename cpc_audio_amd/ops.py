@@ -133,6 +133,22 @@ class GruFunction(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+def candidate_destinations(ext, B, S, K):
+    """(perm, row_ptr) for cpc_nce_backward: the B*W*(N+K) candidate slots sorted (stably) by the
+    row of z.view(B*S,256) their gradient lands on.  ext: (B,W,N) int32 negative rows; the K
+    positives of window (b,t) land on rows b*S + t + k, k = 1..K (criterion.py:210-215)."""
+    W = ext.shape[1]
+    dev = ext.device
+    b = torch.arange(B, device=dev, dtype=torch.int32).view(B, 1, 1)
+    t = torch.arange(W, device=dev, dtype=torch.int32).view(1, W, 1)
+    k = torch.arange(1, K + 1, device=dev, dtype=torch.int32).view(1, 1, K)
+    dest = torch.cat([ext, b * S + t + k], dim=2).reshape(-1)
+    sorted_dest, perm = torch.sort(dest, stable=True)
+    bounds = torch.arange(B * S + 1, device=dev, dtype=torch.int32)
+    row_ptr = torch.searchsorted(sorted_dest, bounds)
+    return perm.to(torch.int32), row_ptr.to(torch.int32)
+
+
 class InfoNCEFunction(torch.autograd.Function):
     """c, z (B,S,256), wall (K*256,256), ext (B,W,N) int32 -> losses (K), acc (K)."""
 
@@ -154,7 +170,8 @@ class InfoNCEFunction(torch.autograd.Function):
             acc = torch.empty(K, device=c.device, dtype=torch.float32)
             lib.check(lib.cpc_nce_forward(_p(c), _p(z), _p(wall), _p(ext), _p(saved), _p(scratch), _p(losses),
                                           _p(acc), B, S, K, N, _stream()), "nce_forward")
-        ctx.save_for_backward(c, z, wall, ext, saved)
+            perm, row_ptr = candidate_destinations(ext, B, S, K)
+        ctx.save_for_backward(c, z, wall, ext, saved, perm, row_ptr)
         ctx.dims = (B, S, K, N, sizes[2])
         ctx.mark_non_differentiable(acc)
         return losses, acc
@@ -162,12 +179,13 @@ class InfoNCEFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _gacc):
         lib = _lib.get()
-        c, z, wall, ext, saved = ctx.saved_tensors
+        c, z, wall, ext, saved, perm, row_ptr = ctx.saved_tensors
         B, S, K, N, nscr = ctx.dims
         gloss = gloss.contiguous()
         with torch.cuda.device(c.device):
             scratch = torch.empty(nscr, device=c.device, dtype=torch.float32)
             dc, dz, dwall = torch.empty_like(c), torch.empty_like(z), torch.empty_like(wall)
-            lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(saved), _p(gloss), _p(scratch),
-                                           _p(dc), _p(dz), _p(dwall), B, S, K, N, _stream()), "nce_backward")
+            lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
+                                           _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
+                                           _stream()), "nce_backward")
         return dc, dz, dwall, None

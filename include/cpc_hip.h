@@ -118,10 +118,14 @@ int cpc_nce_layout(int B, int S, int K, int N, long* sizes);
 int cpc_nce_forward(const float* c, const float* z, const float* wall, const int* ext, float* saved,
                     float* scratch, float* losses, float* acc, int B, int S, int K, int N,
                     void* stream);
-/* gloss: K upstream gradients dL/dloss_k.  dc, dz (B,S,256) and dwall are overwritten. */
+/* gloss: K upstream gradients dL/dloss_k.  dc, dz (B,S,256) and dwall are overwritten.
+ * perm (B*W*(N+K)) / row_ptr (B*S+1): candidate slots sorted by destination row of z (slot =
+ * (b*W+t)*(N+K)+j; j<N: negative j -> row ext[..j]; j>=N: positive of head j-N -> row b*S+t+j-N+1);
+ * they turn the gradient scatter into an atomics-free, reproducible gather. */
 int cpc_nce_backward(const float* c, const float* z, const float* wall, const int* ext,
-                     const float* saved, const float* gloss, float* scratch, float* dc, float* dz,
-                     float* dwall, int B, int S, int K, int N, void* stream);
+                     const int* perm, const int* row_ptr, const float* saved, const float* gloss,
+                     float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K, int N,
+                     void* stream);
 
 #ifdef __cplusplus
 }

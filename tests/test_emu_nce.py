@@ -42,8 +42,10 @@ def test_nce_forward_backward_emulated(B, S, K, N, scale):
     bscr = torch.full((sizes[2],), float("nan"))
     dc = torch.full((B, S, 256), float("nan")); dz = torch.full((B, S, 256), float("nan"))
     dwall = torch.full((K * 256, 256), float("nan"))
-    assert lib.cpc_nce_backward(P(c), P(z), P(wall), P(ext_t), P(saved), P(gl), P(bscr), P(dc), P(dz), P(dwall),
-                                B, S, K, N, None) == 0
+    from cpc_audio_amd.ops import candidate_destinations
+    perm, row_ptr = candidate_destinations(ext_t, B, S, K)
+    assert lib.cpc_nce_backward(P(c), P(z), P(wall), P(ext_t), P(perm), P(row_ptr), P(saved), P(gl), P(bscr), P(dc),
+                                P(dz), P(dwall), B, S, K, N, None) == 0
     assert rel_err(dc, cr.grad) < 1e-5
     assert rel_err(dz, zr.grad) < 1e-5
     ref_dw = torch.cat([leaves[f"wPrediction.predictors.{k}.weight"].grad for k in range(K)], dim=0)
