@@ -1,0 +1,70 @@
+"""The C-ABI library builds for gfx950, loads, and exports every symbol include/cpc_hip.h declares
+(no kernel is launched: this runs without a GPU)."""
+import os
+import re
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "cpc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cpc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_signature_table_agree():
+    from cpc_audio_amd import _lib
+    assert _declared() == sorted(_lib.SIGNATURES.keys())
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    from cpc_audio_amd import _lib, build
+    path = build.build()
+    bound = _lib.bind(path)          # raises if any declared symbol is missing
+    assert bound.cpc_abi_version() >= 1
+    # argument validation happens before any launch, so it is testable without a GPU
+    import ctypes
+    sizes = (ctypes.c_long * 22)()
+    assert bound.cpc_encoder_layout(0, 20480, sizes) == 1          # CPC_ERR_SHAPE
+    assert bound.cpc_encoder_layout(2, 20480, sizes) == 0 and sizes[7] == 128
+    assert bound.cpc_nce_layout(2, 128, 17, 128, sizes) == 1        # K > 16
+    assert bound.cpc_nce_layout(2, 128, 12, 100, sizes) == 1        # N % 16
+    assert bound.cpc_set_conv_tile(48) == 2                         # CPC_ERR_ARG
+
+
+def test_product_has_no_cpu_path():
+    import torch
+    from cpc_audio_amd.train import build_model
+    model = build_model()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        model(torch.zeros(1, 1, 20480), torch.zeros(1, dtype=torch.long))
+
+
+def test_module_api_matches_reference_surface():
+    """Names, constructor signatures, attributes and state-dict keys of the drop-in modules
+    (SURVEY.md section 8b)."""
+    from cpc_audio_amd.criterion import CPCUnsupersivedCriterion
+    from cpc_audio_amd.model import CPCAR, CPCEncoder, CPCModel
+    from oracle import cpc_oracle as O
+    enc = CPCEncoder(256, "layerNorm")
+    ar = CPCAR(256, 256, False, 2, mode="GRU", reverse=False)
+    m = CPCModel(enc, ar)
+    crit = CPCUnsupersivedCriterion(12, 256, 256, 128, mode=None, rnnMode="linear", dropout=False,
+                                    nSpeakers=0, speakerEmbedding=0, sizeInputSeq=128)
+    keys = list(m.state_dict().keys()) + list(crit.state_dict().keys())
+    shapes = O.param_shapes()
+    assert keys == list(shapes.keys())
+    for k, v in list(m.state_dict().items()) + list(crit.state_dict().items()):
+        assert tuple(v.shape) == shapes[k], k
+    assert enc.DOWNSAMPLING == 160 and enc.dimEncoded == 256 and enc.getDimOutput() == 256
+    assert ar.getDimOutput() == 256 and ar.hidden is None and ar.keepHidden is False
+    assert crit.warmUp() is False and crit.update() is None
+    with pytest.raises(ValueError):
+        CPCEncoder(256, "nope")
+    with pytest.raises(ValueError):
+        CPCUnsupersivedCriterion(12, 256, 256, 128, mode="bogus")
