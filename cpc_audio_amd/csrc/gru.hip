@@ -149,12 +149,238 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(
     DH[bt * kH + j] = dh;
 }
 
+// ------------------------------------------------------------------ two-layer wavefront
+// The north-star autoregressor has exactly two layers.  Launch s (s = 0..S) runs layer 0's step
+// t = s and layer 1's step t = s-1 side by side (blockIdx.z = layer), so the 2*S dependent steps
+// become S+1 dependent launches.  Layer 1 forms its input projection W_ih1 h0_t on the fly
+// (waves 4-7) next to the recurrent product W_hh1 h1_{t-1} (waves 0-3); layer 0 reads the batched
+// projection and splits its recurrent product over all 8 waves.  Gate inputs are fetched before
+// the MFMA chain so their latency overlaps it.
+struct Gru2Fwd {
+    const float* x_gi0;        // layer 0: precomputed W_ih0 x + b_ih0, (B,S,3H)
+    const float* h0[2];        // initial states (B,H) or NULL
+    const float* whh[2];
+    const float* bhh[2];
+    const float* wih1;         // layer 1 input weights (3H,H)
+    const float* bih1;
+    float* y[2];               // layer outputs (B,S,H)
+    float* R[2]; float* Z[2]; float* N[2]; float* GHN[2];
+    float* hN;                 // (2,B,H)
+    int B, S;
+};
+
+__device__ __forceinline__ void mfma_slice(f32x4 (&acc)[3], const float* __restrict__ arow, bool ok,
+                                           const float* __restrict__ w, int j0i, int koff, int nii) {
+    // acc[g] += A[16 x (16*nii)] . W[g*H + j0 + i][koff ...]^T for the three gates
+    float4 a[4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+        a[ii] = (ok && ii < nii) ? *reinterpret_cast<const float4*>(arow + koff + 16 * ii) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float* wp = w + (long)(g * kH + j0i) * kH + koff;
+        float4 bw[4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+            bw[ii] = ii < nii ? *reinterpret_cast<const float4*>(wp + 16 * ii) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+            if (ii < nii) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii], jj), f4c(bw[ii], jj), acc[g], 0, 0, 0);
+            }
+    }
+}
+
+// grid = (H/16, ceil(B/16), 2), 512 threads
+__global__ __launch_bounds__(512) void gru2_fwd_kernel(Gru2Fwd p, int s) {
+    __shared__ float part[8][3][256];
+    const int layer = blockIdx.z;
+    const int t = layer == 0 ? s : s - 1;
+    if (t < 0 || t >= p.S) return;                         // block-uniform
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int B = p.B, S = p.S;
+    const float* yl = p.y[layer];
+    const float* hprev = t == 0 ? p.h0[layer] : yl + (long)(t - 1) * kH;
+    const long hstride = t == 0 ? kH : (long)S * kH;
+
+    // ---- gate-math operands, fetched early (threads 0..255 own one (b, j) each)
+    const int row = (tid & 255) >> 4, col = tid & 15;
+    const int b = b0 + row, j = j0 + col;
+    const bool gate_thread = tid < 256 && b < B;
+    const long bt = (long)b * S + t;
+    float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, hp = 0.f, bh[3] = {0.f, 0.f, 0.f};
+    if (gate_thread) {
+        if (layer == 0) {
+            const float* gip = p.x_gi0 + bt * kG;
+            gi_r = gip[j]; gi_z = gip[kH + j]; gi_n = gip[2 * kH + j];
+        } else {
+            gi_r = p.bih1[j]; gi_z = p.bih1[kH + j]; gi_n = p.bih1[2 * kH + j];
+        }
+        hp = hprev ? hprev[(long)b * hstride + j] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bh[g] = p.bhh[layer][g * kH + j];
+    }
+
+    // ---- split-K MFMA
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool bok = (b0 + i) < B;
+    if (layer == 0) {                    // recurrent product over 8 waves, 32 k each
+        const bool ok = bok && hprev != nullptr;
+        const float* arow = hprev + (ok ? (long)(b0 + i) * hstride : 0);
+        mfma_slice(acc, arow, ok, p.whh[0], j0 + i, 32 * w + 4 * kq, 2);
+    } else if (w < 4) {                  // recurrent product W_hh1 h1_{t-1}
+        const bool ok = bok && hprev != nullptr;
+        const float* arow = hprev + (ok ? (long)(b0 + i) * hstride : 0);
+        mfma_slice(acc, arow, ok, p.whh[1], j0 + i, 64 * w + 4 * kq, 4);
+    } else {                             // input projection W_ih1 h0_t
+        const float* arow = p.y[0] + (bok ? ((long)(b0 + i) * S + t) * kH : 0);
+        mfma_slice(acc, arow, bok, p.wih1, j0 + i, 64 * (w - 4) + 4 * kq, 4);
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[w][g][(kq * 4 + r) * 16 + i] = acc[g][r];
+    __syncthreads();
+    if (!gate_thread) return;
+
+    float gh[3];
+    const int e = tid;                   // == row*16 + col
+    if (layer == 0) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            gh[g] = (((part[0][g][e] + part[1][g][e]) + (part[2][g][e] + part[3][g][e])) +
+                     ((part[4][g][e] + part[5][g][e]) + (part[6][g][e] + part[7][g][e]))) + bh[g];
+    } else {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            gh[g] = ((part[0][g][e] + part[1][g][e]) + (part[2][g][e] + part[3][g][e])) + bh[g];
+        gi_r += (part[4][0][e] + part[5][0][e]) + (part[6][0][e] + part[7][0][e]);
+        gi_z += (part[4][1][e] + part[5][1][e]) + (part[6][1][e] + part[7][1][e]);
+        gi_n += (part[4][2][e] + part[5][2][e]) + (part[6][2][e] + part[7][2][e]);
+    }
+    const float r = sigmoidf_(gi_r + gh[0]);
+    const float z = sigmoidf_(gi_z + gh[1]);
+    const float n = tanhf(gi_n + r * gh[2]);
+    const float h = (1.0f - z) * n + z * hp;
+    p.y[layer][bt * kH + j] = h;
+    p.R[layer][bt * kH + j] = r;
+    p.Z[layer][bt * kH + j] = z;
+    p.N[layer][bt * kH + j] = n;
+    p.GHN[layer][bt * kH + j] = gh[2];
+    if (t == S - 1) p.hN[((long)layer * B + b) * kH + j] = h;
+}
+
+struct Gru2Bwd {
+    const float* dy;           // gradient w.r.t. the top layer's output (B,S,H)
+    const float* whhT[2];      // (H,3H) transposed recurrent weights, index = layer
+    const float* wih1T;        // (H,3H): W_ih of layer 1 transposed
+    const float* y[2];
+    const float* h0[2];
+    const float* R[2]; const float* Z[2]; const float* N[2]; const float* GHN[2];
+    float* dGi[2]; float* dGh[2]; float* DH[2];
+    int B, S;
+};
+
+__device__ __forceinline__ f32x4 mfma_slice1(f32x4 acc, const float* __restrict__ arow, bool ok,
+                                             const float* __restrict__ wrow, int koff, int nii) {
+    // acc += A[16 x 16*nii] . W^T slice, single output tile (K-major rows of length 3H)
+#pragma unroll
+    for (int base = 0; base < 12; base += 6) {
+        if (base >= nii) break;
+        float4 a[6], bw[6];
+#pragma unroll
+        for (int ii = 0; ii < 6; ++ii) {
+            const bool on = base + ii < nii;
+            a[ii] = (ok && on) ? *reinterpret_cast<const float4*>(arow + koff + 16 * (base + ii)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bw[ii] = on ? *reinterpret_cast<const float4*>(wrow + koff + 16 * (base + ii)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 6; ++ii)
+            if (base + ii < nii) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii], jj), f4c(bw[ii], jj), acc, 0, 0, 0);
+            }
+    }
+    return acc;
+}
+
+// Launch s (s = 0..S): blockIdx.z = 0 -> top layer (1) step t = S-1-s; blockIdx.z = 1 -> bottom
+// layer (0) step t = S-s, whose incoming gradient dGi1_t . W_ih1 is formed on the fly (waves 4-7).
+__global__ __launch_bounds__(512) void gru2_bwd_kernel(Gru2Bwd p, int s) {
+    __shared__ float part[8][256];
+    const int layer = blockIdx.z == 0 ? 1 : 0;
+    const int S = p.S, B = p.B;
+    const int t = layer == 1 ? S - 1 - s : S - s;
+    if (t < 0 || t >= S) return;                           // block-uniform
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const bool has_next = (t + 1) < S;
+
+    const int row = (tid & 255) >> 4, col = tid & 15;
+    const int b = b0 + row, j = j0 + col;
+    const bool gate_thread = tid < 256 && b < B;
+    const long bt = (long)b * S + t;
+    float dh0 = 0.f, r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hp = 0.f;
+    if (gate_thread) {
+        if (layer == 1) dh0 = p.dy[bt * kH + j];
+        if (has_next) dh0 = fmaf(p.DH[layer][(bt + 1) * kH + j], p.Z[layer][(bt + 1) * kH + j], dh0);
+        r = p.R[layer][bt * kH + j]; z = p.Z[layer][bt * kH + j];
+        n = p.N[layer][bt * kH + j]; ghn = p.GHN[layer][bt * kH + j];
+        hp = t > 0 ? p.y[layer][(bt - 1) * kH + j] : (p.h0[layer] ? p.h0[layer][(long)b * kH + j] : 0.f);
+    }
+
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool bok = (b0 + i) < B;
+    if (layer == 1) {                     // dGh1_{t+1} . W_hh1 over 8 waves, 96 k each
+        if (has_next) {
+            const float* arow = p.dGh[1] + (bok ? ((long)(b0 + i) * S + t + 1) * kG : 0);
+            acc = mfma_slice1(acc, arow, bok, p.whhT[1] + (long)(j0 + i) * kG, 96 * w + 4 * kq, 6);
+        }
+    } else if (w < 4) {                   // dGh0_{t+1} . W_hh0, 192 k per wave
+        if (has_next) {
+            const float* arow = p.dGh[0] + (bok ? ((long)(b0 + i) * S + t + 1) * kG : 0);
+            acc = mfma_slice1(acc, arow, bok, p.whhT[0] + (long)(j0 + i) * kG, 192 * w + 4 * kq, 12);
+        }
+    } else {                              // incoming gradient dGi1_t . W_ih1
+        const float* arow = p.dGi[1] + (bok ? ((long)(b0 + i) * S + t) * kG : 0);
+        acc = mfma_slice1(acc, arow, bok, p.wih1T + (long)(j0 + i) * kG, 192 * (w - 4) + 4 * kq, 12);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) part[w][(kq * 4 + rr) * 16 + i] = acc[rr];
+    __syncthreads();
+    if (!gate_thread) return;
+    const int e = tid;
+    const float dh = (((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) +
+                      ((part[4][e] + part[5][e]) + (part[6][e] + part[7][e]))) + dh0;
+    const float dn = dh * (1.0f - z);
+    const float dzg = dh * (hp - n);
+    const float dan = dn * (1.0f - n * n);
+    const float daz = dzg * z * (1.0f - z);
+    const float dar = dan * ghn * r * (1.0f - r);
+    float* gi = p.dGi[layer] + bt * kG;
+    float* gh = p.dGh[layer] + bt * kG;
+    gi[j] = dar;            gh[j] = dar;
+    gi[kH + j] = daz;       gh[kH + j] = daz;
+    gi[2 * kH + j] = dan;   gh[2 * kH + j] = dan * r;
+    p.DH[layer][bt * kH + j] = dh;
+}
+
 // ------------------------------------------------------------------ host side
 struct GruLayout {
     long R[8], Z[8], N[8], GHN[8], Y[8];     // saved (per layer); Y only for l < nl-1
     long saved_total;
     long gi, fwd_total;                      // forward scratch
-    long whhT, wihT, dGi, dGh, DH, mid[2], part, tmp, bwd_total;
+    long whhT, wihT, dGi, dGh, DH, mid[2], part, tmp;
+    long whhT2, wihT2, dGi2, dGh2, DH2;      // second set for the two-layer wavefront
+    long bwd_total;
 };
 
 static bool gru_layout(int B, int S, int nl, GruLayout& g) {
@@ -182,6 +408,11 @@ static bool gru_layout(int B, int S, int nl, GruLayout& g) {
     g.mid[1] = o; o += bsh;
     g.part = o; o += align64l(tn_gemm_part_floats(B * S, kG, kH));
     g.tmp = o; o += align64l((long)kRowsSumGroups * kG);
+    g.whhT2 = o; o += (long)kH * kG;
+    g.wihT2 = o; o += (long)kH * kG;
+    g.dGi2 = o; o += align64l((long)B * S * kG);
+    g.dGh2 = o; o += align64l((long)B * S * kG);
+    g.DH2 = o; o += bsh;
     g.bwd_total = o;
     return true;
 }
@@ -208,6 +439,25 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
     hipStream_t st = (hipStream_t)stream;
     const float* in = x;
     float* gi = scratch + g.gi;
+    if (nl == 2) {                                   // two-layer wavefront (see gru2_fwd_kernel)
+        int rc = nt_gemm(plain_rows(x, B * S, kH), params[0], kH, params[2], gi, kG, kG, kH, st);
+        if (rc) return rc;
+        Gru2Fwd p;
+        p.x_gi0 = gi;
+        for (int l = 0; l < 2; ++l) {
+            p.h0[l] = h0 ? h0 + (long)l * B * kH : nullptr;
+            p.whh[l] = params[4 * l + 1];
+            p.bhh[l] = params[4 * l + 3];
+            p.R[l] = saved + g.R[l]; p.Z[l] = saved + g.Z[l]; p.N[l] = saved + g.N[l]; p.GHN[l] = saved + g.GHN[l];
+        }
+        p.wih1 = params[4]; p.bih1 = params[6];
+        p.y[0] = saved + g.Y[0]; p.y[1] = y;
+        p.hN = hN; p.B = B; p.S = S;
+        const dim3 grid(kH / 16, cdiv(B, 16), 2);
+        for (int s = 0; s <= S; ++s) hipLaunchKernelGGL(gru2_fwd_kernel, grid, dim3(512), 0, st, p, s);
+        CPC_LAUNCH_CHECK();
+        return 0;
+    }
     for (int l = 0; l < nl; ++l) {
         const float* wih = params[4 * l], *whh = params[4 * l + 1], *bih = params[4 * l + 2], *bhh = params[4 * l + 3];
         float* out = (l == nl - 1) ? y : saved + g.Y[l];
@@ -240,6 +490,56 @@ extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* co
     float* whhT = scratch + g.whhT, *wihT = scratch + g.wihT;
     float* dGi = scratch + g.dGi, *dGh = scratch + g.dGh, *DH = scratch + g.DH;
     const int M = B * S;
+    if (nl == 2) {                                   // two-layer wavefront (see gru2_bwd_kernel)
+        float* whhT_[2] = {scratch + g.whhT, scratch + g.whhT2};
+        float* wihT_[2] = {scratch + g.wihT, scratch + g.wihT2};
+        float* dGi_[2] = {scratch + g.dGi, scratch + g.dGi2};
+        float* dGh_[2] = {scratch + g.dGh, scratch + g.dGh2};
+        float* DH_[2] = {scratch + g.DH, scratch + g.DH2};
+        Gru2Bwd p;
+        p.dy = dy; p.B = B; p.S = S;
+        int rc = 0;
+        for (int l = 0; l < 2; ++l) {
+            rc = transpose(params[4 * l + 1], whhT_[l], kG, kH, st);
+            if (rc) return rc;
+            rc = transpose(params[4 * l], wihT_[l], kG, kH, st);
+            if (rc) return rc;
+            p.whhT[l] = whhT_[l];
+            p.y[l] = l == 1 ? y : saved + g.Y[0];
+            p.h0[l] = h0 ? h0 + (long)l * B * kH : nullptr;
+            p.R[l] = saved + g.R[l]; p.Z[l] = saved + g.Z[l]; p.N[l] = saved + g.N[l]; p.GHN[l] = saved + g.GHN[l];
+            p.dGi[l] = dGi_[l]; p.dGh[l] = dGh_[l]; p.DH[l] = DH_[l];
+        }
+        p.wih1T = wihT_[1];
+        const dim3 grid(kH / 16, cdiv(B, 16), 2);
+        for (int s = 0; s <= S; ++s) hipLaunchKernelGGL(gru2_bwd_kernel, grid, dim3(512), 0, st, p, s);
+        CPC_LAUNCH_CHECK();
+        for (int l = 0; l < 2; ++l) {
+            const float* in = l == 0 ? x : saved + g.Y[0];
+            const float* out = p.y[l];
+            const RowMap gim = plain_rows(dGi_[l], M, kG), ghm = plain_rows(dGh_[l], M, kG);
+            rc = tn_gemm(gim, kG, plain_rows(in, M, kH), kH, scratch + g.part, grads[4 * l], 0, st);
+            if (rc) return rc;
+            RowMap hm;
+            hm.base = out; hm.R = S; hm.bstride = (long)S * kH; hm.rstride = kH; hm.off = -kH;
+            hm.tmul = 1; hm.tadd = -1; hm.Lin = S; hm.M = M;
+            rc = tn_gemm(ghm, kG, hm, kH, scratch + g.part, grads[4 * l + 1], 0, st);
+            if (rc) return rc;
+            if (p.h0[l]) {
+                RowMap g0;
+                g0.base = dGh_[l]; g0.R = 1; g0.bstride = (long)S * kG; g0.rstride = 0; g0.off = 0;
+                g0.tmul = 0; g0.tadd = 0; g0.Lin = 0x7fffffff; g0.M = B;
+                rc = tn_gemm(g0, kG, plain_rows(p.h0[l], B, kH), kH, scratch + g.part, grads[4 * l + 1], 1, st);
+                if (rc) return rc;
+            }
+            rc = rows_sum(dGi_[l], M, kG, scratch + g.tmp, grads[4 * l + 2], st);
+            if (rc) return rc;
+            rc = rows_sum(dGh_[l], M, kG, scratch + g.tmp, grads[4 * l + 3], st);
+            if (rc) return rc;
+        }
+        // dx = dGi0 . W_ih0
+        return nt_gemm(plain_rows(dGi_[0], M, kG), wihT_[0], kG, nullptr, dx, kH, kH, kG, st);
+    }
     const float* dYl = dy;
     for (int l = nl - 1; l >= 0; --l) {
         const float* wih = params[4 * l], *whh = params[4 * l + 1];

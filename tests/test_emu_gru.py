@@ -27,7 +27,7 @@ def test_gemm_nt_tn_emulated():
     assert rel_err(C, 2 * C0) < 1e-6
 
 
-@pytest.mark.parametrize("B,S,nl,use_h0", [(3, 6, 2, False), (17, 4, 1, True), (2, 5, 2, True)])
+@pytest.mark.parametrize("B,S,nl,use_h0", [(3, 6, 2, False), (17, 4, 1, True), (2, 5, 2, True), (2, 3, 3, True), (20, 1, 2, False)])
 def test_gru_forward_backward_emulated(B, S, nl, use_h0):
     lib = emu()
     torch.manual_seed(1)
