@@ -19,6 +19,7 @@ _F = ctypes.c_float
 # name -> (restype, argtypes); mirrors include/cpc_hip.h one to one
 SIGNATURES = {
     "cpc_abi_version": (_I, []),
+    "cpc_set_mfma_mode": (_I, [_I]),
     "cpc_conv0_forward": (_I, [_P] * 8 + [_I, _I, _P]),
     "cpc_conv0_backward_scratch_floats": (_L, [_I, _I]),
     "cpc_conv0_backward": (_I, [_P] * 13 + [_I, _I, _P]),

@@ -21,6 +21,10 @@ int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, flo
 // out[Cn][R] = in[R][Cn]^T
 int transpose(const float* in, float* out, int R, int Cn, hipStream_t st);
 
+// 1 (default): NT GEMMs run on the bf16 matrix pipe with 3-piece split operands (NtTileX3, fp32-level
+// accuracy); 0: exact-f32 MFMA (NtTile).  Set through cpc_set_mfma_mode().
+extern int g_mfma_mode;
+
 static inline long align64l(long v) { return (v + 63) & ~63L; }
 
 }  // namespace cpc

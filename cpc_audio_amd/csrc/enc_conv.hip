@@ -21,6 +21,7 @@
 //   * wgrad is a TN GEMM  dWp[256, k*256] = dx^T . A  split over row ranges, reduced
 //     in a fixed order and permuted back to PyTorch's (O, I, W) layout.
 #include <algorithm>
+#include <type_traits>
 
 #include "cpc_common.h"
 #include "cpc_internal.h"
@@ -57,18 +58,18 @@ __global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------ forward
-template <int BM>
+template <int BM, bool X3>
 struct ConvCfg {
     static constexpr int WAVES_M = BM >= 128 ? 2 : 1;
-    using Tile = NtTile<BM, kC, WAVES_M, 4>;
+    using Tile = typename std::conditional<X3, NtTileX3<BM, kC, WAVES_M, 4>, NtTile<BM, kC, WAVES_M, 4>>::type;
 };
 
-template <int BM>
-__global__ __launch_bounds__(ConvCfg<BM>::Tile::NTHREADS) void conv_fwd_kernel(
+template <int BM, bool X3>
+__global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS)) void conv_fwd_kernel(
     RowMap am, const float* __restrict__ wp, int K, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
     float* __restrict__ xhat, float* __restrict__ rstd_out) {
-    using Tile = typename ConvCfg<BM>::Tile;
+    using Tile = typename ConvCfg<BM, X3>::Tile;
     constexpr int TM = Tile::TM, TN = Tile::TN;
     __shared__ float smem[Tile::SMEM_FLOATS];
     __shared__ float red[BM][4];
@@ -214,14 +215,14 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
 
 // ------------------------------------------------------------------ dgrad (+ fused norm backward)
 // grid = (row tiles over B*(Lout+1), s phases).  am = 2-row windows over dx of THIS layer.
-template <int BM, bool FUSE>
-__global__ __launch_bounds__(ConvCfg<BM>::Tile::NTHREADS) void conv_dgrad_kernel(
+template <int BM, bool FUSE, bool X3>
+__global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS)) void conv_dgrad_kernel(
     RowMap am, const float* __restrict__ wd, int s, int p, int Lin,
     const float* __restrict__ xhat_prev, const float* __restrict__ y_prev,
     const float* __restrict__ rstd_prev, const float* __restrict__ nw_prev,
     float* __restrict__ dprev, float* __restrict__ colpart) {
-    using Tile = typename ConvCfg<BM>::Tile;
-    constexpr int TM = Tile::TM, TN = Tile::TN, WAVES_M = ConvCfg<BM>::WAVES_M;
+    using Tile = typename ConvCfg<BM, X3>::Tile;
+    constexpr int TM = Tile::TM, TN = Tile::TN, WAVES_M = ConvCfg<BM, X3>::WAVES_M;
     __shared__ float smem[Tile::SMEM_FLOATS];
     __shared__ float red[2][BM][4];
     __shared__ float colsum[3][kC];
@@ -471,17 +472,26 @@ template <int BM>
 static void launch_conv_fwd(const RowMap& am, const float* wp, int K, const float* bias,
                             const float* nw, const float* nb, float* y, float* xhat, float* rstd,
                             hipStream_t st) {
-    hipLaunchKernelGGL((conv_fwd_kernel<BM>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM>::Tile::NTHREADS),
-                       0, st, am, wp, K, bias, nw, nb, y, xhat, rstd);
+    if (g_mfma_mode == 1 && K % 32 == 0)
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, true>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, true>::Tile::NTHREADS),
+                           0, st, am, wp, K, bias, nw, nb, y, xhat, rstd);
+    else
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, false>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, false>::Tile::NTHREADS),
+                           0, st, am, wp, K, bias, nw, nb, y, xhat, rstd);
 }
 
 template <int BM, bool FUSE>
 static void launch_conv_dgrad(const RowMap& am, const float* wd, int s, int p, int Lin,
                               const float* xhat_prev, const float* y_prev, const float* rstd_prev,
                               const float* nw_prev, float* dprev, float* colpart, hipStream_t st) {
-    hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE>), dim3(cdiv(am.M, BM), s),
-                       dim3(ConvCfg<BM>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
-                       rstd_prev, nw_prev, dprev, colpart);
+    if (g_mfma_mode == 1)
+        hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE, true>), dim3(cdiv(am.M, BM), s),
+                           dim3(ConvCfg<BM, true>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
+                           rstd_prev, nw_prev, dprev, colpart);
+    else
+        hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE, false>), dim3(cdiv(am.M, BM), s),
+                           dim3(ConvCfg<BM, false>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
+                           rstd_prev, nw_prev, dprev, colpart);
 }
 
 }  // namespace cpc

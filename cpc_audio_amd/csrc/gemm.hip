@@ -11,6 +11,8 @@ namespace cpc {
 
 using NtBig = NtTile<128, 128, 2, 2>;     // 128x128 block, 64x64 per wave
 using NtSmall = NtTile<64, 64, 2, 2>;      // 64x64 block: used when the big tiling cannot fill 256 CUs
+using NtBigX3 = NtTileX3<128, 128, 2, 2>;  // the same on the bf16 pipe with 3-piece split operands
+using NtSmallX3 = NtTileX3<64, 64, 2, 2>;
 using TnG = TnTile<128, 128, 2, 2>;
 
 // Output row m goes to C + m*ldc, or, when c_R > 0, to C + (m / c_R)*c_bstride + (m % c_R)*ldc
@@ -96,13 +98,21 @@ int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, flo
             int N, int K, hipStream_t st, int c_R, long c_bstride) {
     if (am.M <= 0) return 0;
     if (N % 128 != 0 || K % 16 != 0 || K < 16) return CPC_ERR_SHAPE;
-    if ((long)cdiv(am.M, 128) * (N / 128) >= 384) {
-        hipLaunchKernelGGL((nt_gemm_kernel<NtBig, 128>), dim3(cdiv(am.M, 128), N / 128), dim3(NtBig::NTHREADS), 0,
-                           st, am, Bmat, ldb, bias, C, ldc, K, c_R, c_bstride);
-    } else {
-        hipLaunchKernelGGL((nt_gemm_kernel<NtSmall, 64>), dim3(cdiv(am.M, 64), N / 64), dim3(NtSmall::NTHREADS), 0,
-                           st, am, Bmat, ldb, bias, C, ldc, K, c_R, c_bstride);
-    }
+    const bool big = (long)cdiv(am.M, 128) * (N / 128) >= 384;
+    const bool x3 = g_mfma_mode == 1 && K % 32 == 0;
+    const dim3 gb(cdiv(am.M, 128), N / 128), gs(cdiv(am.M, 64), N / 64);
+    if (big && x3)
+        hipLaunchKernelGGL((nt_gemm_kernel<NtBigX3, 128>), gb, dim3(NtBigX3::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
+                           ldc, K, c_R, c_bstride);
+    else if (big)
+        hipLaunchKernelGGL((nt_gemm_kernel<NtBig, 128>), gb, dim3(NtBig::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
+                           ldc, K, c_R, c_bstride);
+    else if (x3)
+        hipLaunchKernelGGL((nt_gemm_kernel<NtSmallX3, 64>), gs, dim3(NtSmallX3::NTHREADS), 0, st, am, Bmat, ldb, bias,
+                           C, ldc, K, c_R, c_bstride);
+    else
+        hipLaunchKernelGGL((nt_gemm_kernel<NtSmall, 64>), gs, dim3(NtSmall::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
+                           ldc, K, c_R, c_bstride);
     CPC_LAUNCH_CHECK();
     return 0;
 }

@@ -200,6 +200,180 @@ auto gload = [&](int kc_) __attribute__((always_inline)) {
 };
 
 // ---------------------------------------------------------------------------
+// NtTileX3: the same NT product on the bf16 matrix pipe with fp32-level accuracy.
+//
+// Every fp32 operand x is split BY TRUNCATION into three bf16 pieces when it is staged into
+// LDS:  h = top 16 bits of x,  m = top 16 bits of (x - h),  l = top 16 bits of (x - h - m)
+// (both subtractions are exact in fp32), so x = h + m + l up to 2^-24 |x|.  A product
+// a*b is then accumulated in fp32 as  ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh  (the three
+// dropped terms are <= 2^-24 |ab|; bf16 x bf16 products are exact in the fp32 accumulator).
+// Six v_mfma_f32_32x32x16_bf16 (32 cycles, 16 k) replace eight v_mfma_f32_32x32x2_f32
+// (64 cycles, 2 k): 2.67x the f32-MFMA rate at the same parity bar.
+//
+// LDS: three bf16 planes per operand, K-major rows of BK = 32 halves padded to 40 (80 B: 16-byte
+// aligned, conflict-free ds_read_b128 over 16-lane groups).  One LDS stage (92 KB at 128 x 256)
+// with register prefetch of the next chunk: load(kc+1) | compute(kc) | barrier | split+store |
+// barrier.
+// ---------------------------------------------------------------------------
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(m);
+    l = __float_as_uint(r2) & 0xFFFF0000u;
+}
+
+// four floats -> three 8-byte groups of four bf16 (element 0 in the low half of .x)
+__device__ __forceinline__ void split3_pack4(const float4& v, uint2& ph, uint2& pm, uint2& pl) {
+    unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+    split3(v.x, h0, m0, l0);
+    split3(v.y, h1, m1, l1);
+    split3(v.z, h2, m2, l2);
+    split3(v.w, h3, m3, l3);
+    ph = make_uint2((h0 >> 16) | h1, (h2 >> 16) | h3);
+    pm = make_uint2((m0 >> 16) | m1, (m2 >> 16) | m3);
+    pl = make_uint2((l0 >> 16) | l1, (l2 >> 16) | l3);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+struct NtTileX3 {
+    static constexpr int BK = 32;
+    static constexpr int LDH = BK + 8;   // halves per LDS row
+    static constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    static constexpr int TM = WM / 32, TN = WN / 32;
+    static constexpr int A_SLOTS = BM * (BK / 4), B_SLOTS = BN * (BK / 4);
+    static constexpr int A_PER = (A_SLOTS + NTHREADS - 1) / NTHREADS;
+    static constexpr int B_PER = (B_SLOTS + NTHREADS - 1) / NTHREADS;
+    static constexpr int PLANE_A = BM * LDH, PLANE_B = BN * LDH;          // halves
+    static constexpr int SMEM_FLOATS = 3 * (PLANE_A + PLANE_B) / 2;
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+
+    __device__ static __forceinline__ int c_row(int tm, int reg) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        return (wave / WAVES_N) * WM + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    }
+    __device__ static __forceinline__ int c_col(int tn) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        return (wave % WAVES_N) * WN + tn * 32 + (lane & 31);
+    }
+
+    __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int m0,
+                               const float* __restrict__ Bmat, int ldb, int n0, int K,
+                               float* smem_f) {
+        unsigned short* smem = reinterpret_cast<unsigned short*>(smem_f);
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+        RowRef ar[A_PER];
+        int a_k[A_PER], a_lds[A_PER];
+        bool a_on[A_PER];
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int slot = tid + i * NTHREADS;
+            a_on[i] = slot < A_SLOTS;
+            const int r = slot >> 3, kv = slot & 7;
+            ar[i] = resolve_row(am, m0 + r, a_on[i] ? am.M : 0);
+            a_k[i] = kv * 4;
+            a_lds[i] = r * LDH + kv * 4;
+        }
+        const float* bp[B_PER];
+        int b_lds[B_PER];
+        bool b_on[B_PER];
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int slot = tid + i * NTHREADS;
+            b_on[i] = slot < B_SLOTS;
+            const int r = b_on[i] ? (slot >> 3) : 0, kv = slot & 7;
+            bp[i] = Bmat + (long)(n0 + r) * ldb + kv * 4;
+            b_lds[i] = 3 * PLANE_A + r * LDH + kv * 4;
+        }
+        float4 ra[A_PER], rb[B_PER];
+        const int nk = K / BK;
+
+        auto gload = [&](int kc_) __attribute__((always_inline)) {
+            const int k0 = kc_ * BK;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) ra[i] = load_row4(ar[i], k0 + a_k[i], am.Lin);
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+        };
+        auto sstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i)
+                if (a_on[i]) {
+                    uint2 ph, pm, pl;
+                    split3_pack4(ra[i], ph, pm, pl);
+                    *reinterpret_cast<uint2*>(smem + a_lds[i]) = ph;
+                    *reinterpret_cast<uint2*>(smem + PLANE_A + a_lds[i]) = pm;
+                    *reinterpret_cast<uint2*>(smem + 2 * PLANE_A + a_lds[i]) = pl;
+                }
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i)
+                if (b_on[i]) {
+                    uint2 ph, pm, pl;
+                    split3_pack4(rb[i], ph, pm, pl);
+                    *reinterpret_cast<uint2*>(smem + b_lds[i]) = ph;
+                    *reinterpret_cast<uint2*>(smem + PLANE_B + b_lds[i]) = pm;
+                    *reinterpret_cast<uint2*>(smem + 2 * PLANE_B + b_lds[i]) = pl;
+                }
+        };
+        const int arow = wm * WM + (lane & 31);
+        const int brow = wn * WN + (lane & 31);
+        const int kofs = 8 * (lane >> 5);
+        auto compute = [&]() __attribute__((always_inline)) {
+            const unsigned short* As = smem;
+            const unsigned short* Bs = smem + 3 * PLANE_A;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[tm][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(
+                            As + pl * PLANE_A + (arow + tm * 32) * LDH + ks * 16 + kofs));
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bf[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(
+                            Bs + pl * PLANE_B + (brow + tn * 32) * LDH + ks * 16 + kofs));
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        f32x16 c = acc[tm][tn];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][2], bf[tn][0], c, 0, 0, 0);   // l*h
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][2], c, 0, 0, 0);   // h*l
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bf[tn][1], c, 0, 0, 0);   // m*m
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bf[tn][0], c, 0, 0, 0);   // m*h
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][1], c, 0, 0, 0);   // h*m
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][0], c, 0, 0, 0);   // h*h
+                        acc[tm][tn] = c;
+                    }
+            }
+        };
+
+        gload(0);
+        sstore();
+        __syncthreads();
+        for (int kc = 0; kc + 1 < nk; ++kc) {
+            gload(kc + 1);
+            compute();
+            __syncthreads();
+            sstore();
+            __syncthreads();
+        }
+        compute();
+        __syncthreads();
+    }
+};
+
+// ---------------------------------------------------------------------------
 // TN tile:  acc[BM x BN] += sum_{m in [mbeg,mend)} A[m, c0..c0+BM)^T (x) B[m, n0..n0+BN)
 // The contraction index is the ROW index of both operands ("M-major" LDS tiles,
 // conflict-free ds_read_b32 with consecutive lanes on consecutive columns).

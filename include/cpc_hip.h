@@ -27,6 +27,12 @@ extern "C" {
 /* ABI version, bumped on any signature change. */
 int cpc_abi_version(void);
 
+/* Arithmetic of the NT GEMMs (conv forward/dgrad, projections, heads):
+ *   1 (default) bf16 matrix pipe, fp32 operands split by truncation into three bf16 pieces, six
+ *     bf16 MFMAs per product, fp32 accumulate: error <= 2^-23 per product (fp32 level), 2.67x the rate;
+ *   0 exact-f32 MFMA (v_mfma_f32_32x32x2_f32). */
+int cpc_set_mfma_mode(int mode);
+
 /* ---------------------------------------------------------------- encoder ----
  * CPCEncoder.forward, cpc/model.py:99-105:  5 x relu(ChannelNorm(conv_i(x))).
  * ChannelNorm: cpc/model.py:50-58 (mean / UNBIASED variance over channels, eps 1e-5).

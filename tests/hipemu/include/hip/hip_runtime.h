@@ -41,6 +41,8 @@ struct dim3 {
 struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct int2 { int x, y; };
+struct alignas(8) uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 struct alignas(16) int4 { int x, y, z, w; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
@@ -74,6 +76,8 @@ struct Fiber {
 struct WaveBuf {          // double-buffered exchange area for collectives
     uint32_t a[2][WAVE];
     uint32_t b[2][WAVE];
+    uint16_t va[2][WAVE][8];   // 8 x 16-bit operand fragments (bf16 MFMA)
+    uint16_t vb[2][WAVE][8];
     int phase = 0;        // parity of the collective currently being deposited
     int waiting = 0;
     int live = 0;
@@ -169,6 +173,30 @@ inline f32x4 mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) {
     return c;
 }
 
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+inline float bf16_bits_to_float(uint16_t h) { return unbits<float>((uint32_t)h << 16); }
+
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[i = l&31][k = 8*(l>>5) + e], B[k = 8*(l>>5) + e][j = l&31]
+inline f32x16 mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) {
+    WaveBuf& w = my_wave();
+    int ph = w.phase, l = lane_id();
+    memcpy(w.va[ph][l], &a, 16);
+    memcpy(w.vb[ph][l], &b, 16);
+    wave_sync();
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k)
+            acc = fmaf(bf16_bits_to_float(w.va[ph][row + 32 * (k >> 3)][k & 7]),
+                       bf16_bits_to_float(w.vb[ph][col + 32 * (k >> 3)][k & 7]), acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur->tid)
@@ -228,6 +256,9 @@ static inline float __fdividef(float a, float b) { return a / b; }
 
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu::mfma_f32_16x16x4f32
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu::mfma_f32_32x32x16_bf16
+static inline unsigned __float_as_uint(float x) { return hipemu::bits(x); }
+static inline float __uint_as_float(unsigned u) { return hipemu::unbits<float>(u); }
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

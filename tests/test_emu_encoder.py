@@ -24,10 +24,13 @@ def _oracle_encoder(p, wave, dz, relu_override=None):
     return z.detach(), [a.detach().permute(0, 2, 1).contiguous() for a in acts], leaves
 
 
-@pytest.mark.parametrize("B,L,bm", [(2, 1280, 0), (1, 1370, 64), (1, 1600, 128), (3, 1290, 128)])
-def test_encoder_forward_backward_emulated(B, L, bm):
+@pytest.mark.parametrize("B,L,bm,mode", [(2, 1280, 0, 1), (1, 1370, 64, 1), (1, 1600, 128, 1), (3, 1290, 128, 0),
+                                          (2, 1280, 0, 0)])
+def test_encoder_forward_backward_emulated(B, L, bm, mode):
+    """mode 1: NT GEMMs on the bf16 pipe with 3-piece split operands; mode 0: exact-f32 MFMA."""
     lib = emu()
     assert lib.cpc_set_conv_tile(bm) == 0
+    assert lib.cpc_set_mfma_mode(mode) == 0
     try:
         torch.manual_seed(0)
         p, plist = _params()
@@ -69,3 +72,4 @@ def test_encoder_forward_backward_emulated(B, L, bm):
         assert not bad, bad
     finally:
         lib.cpc_set_conv_tile(0)
+        lib.cpc_set_mfma_mode(1)

@@ -20,13 +20,14 @@ def _names():
             for n, w in (("conv", "weight"), ("conv", "bias"), ("batchNorm", "weight"), ("batchNorm", "bias"))]
 
 
-def _run(lib, B, L, dev, pseed=0, bm=0):
+def _run(lib, B, L, dev, pseed=0, bm=0, mode=1):
     from cpc_audio_amd._lib import ptr as P
     p = O.make_params(seed=pseed)
     plist = [p[n].contiguous().to(dev) for n in _names()]
     wave = O.make_waveform(B, L, seed=5)
     sizes = (ctypes.c_long * 22)()
     assert lib.cpc_set_conv_tile(bm) == 0
+    assert lib.cpc_set_mfma_mode(mode) == 0
     assert lib.cpc_encoder_layout(B, L, sizes) == 0
     Ls = [sizes[3 + i] for i in range(5)]
     saved = torch.full((sizes[0],), float("nan"), device=dev)
@@ -46,6 +47,7 @@ def _run(lib, B, L, dev, pseed=0, bm=0):
               "encoder_backward")
     torch.cuda.synchronize()
     lib.cpc_set_conv_tile(0)
+    lib.cpc_set_mfma_mode(1)
     # oracle
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("gEncoder")}
     acts = []
@@ -58,12 +60,14 @@ def _run(lib, B, L, dev, pseed=0, bm=0):
                 ref_grads=[leaves[n].grad for n in _names()], saved=saved, sizes=sizes, Ls=Ls, acts=acts)
 
 
-@pytest.mark.parametrize("B,L,bm", [(2, 20480, 0), (3, 20480, 128), (1, 4330, 64), (8, 20480, 0)])
-def test_encoder_matches_oracle(B, L, bm):
+@pytest.mark.parametrize("B,L,bm,mode", [(2, 20480, 0, 1), (3, 20480, 128, 1), (1, 4330, 64, 1), (8, 20480, 0, 1),
+                                          (3, 20480, 0, 0), (2, 10240, 32, 0)])
+def test_encoder_matches_oracle(B, L, bm, mode):
+    """mode 1 = bf16 pipe with 3-piece split operands (default), mode 0 = exact-f32 MFMA."""
     dev = _dev()
     from cpc_audio_amd import _lib
     lib = _lib.get()
-    r = _run(lib, B, L, dev, bm=bm)
+    r = _run(lib, B, L, dev, bm=bm, mode=mode)
     # encoder output within 1e-4 of the CPU reference path (north-star tolerance); expect ~1e-5
     err = (r["z"] - r["z_ref"]).abs().max().item()
     assert err < 1e-4, err

@@ -71,8 +71,9 @@ def main():
     out["conv0_fwd_GBps"] = (B * Ls[0] * 256 * 4 + B * L * 4) / t / 1e6
     macs = {1: 536870912, 2: 134217728, 3: 67108864, 4: 33554432}
     geom = {1: (8, 4, 2), 2: (4, 2, 1), 3: (4, 2, 1), 4: (4, 2, 1)}
-    for bm in (0, 32, 64, 128):
+    for bm, mode in ((0, 1), (0, 0), (32, 1), (128, 1), (64, 1)):
         lib.cpc_set_conv_tile(bm)
+        lib.cpc_set_mfma_mode(mode)
         for i in (1, 2, 3, 4):
             k, s, pd = geom[i]
             xin = saved[sizes[8 + i - 1]: sizes[8 + i - 1] + B * Ls[i - 1] * 256]
@@ -85,9 +86,10 @@ def main():
                 lib.check(lib.cpc_conv_layer_forward(P(xin), P(plist[4 * i]), P(plist[4 * i + 1]), P(plist[4 * i + 2]),
                                                      P(plist[4 * i + 3]), P(wp), P(yo), P(xh), P(rs), B, Ls[i - 1], k, s, pd, st))
             t = timeit(cf)
-            out[f"conv{i}_fwd_bm{bm}_ms"] = t
-            out[f"conv{i}_fwd_bm{bm}_TFLOPs"] = 2 * macs[i] * B / t / 1e9
+            out[f"conv{i}_fwd_bm{bm}_mode{mode}_ms"] = round(t, 4)
+            out[f"conv{i}_fwd_bm{bm}_mode{mode}_TFLOPs"] = round(2 * macs[i] * B / t / 1e9, 1)
     lib.cpc_set_conv_tile(0)
+    lib.cpc_set_mfma_mode(1)
     print(json.dumps(out, indent=1))
 
 
