@@ -345,10 +345,15 @@ __global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS)) void conv_dgrad_
 }
 
 // ------------------------------------------------------------------ wgrad
-using WgTile = TnTile<128, 128, 2, 2>;
+template <bool X3>
+struct WgCfg {
+    using Tile = typename std::conditional<X3, TnTileX3<128, 128, 2, 2>, TnTile<128, 128, 2, 2>>::type;
+};
 // grid = (K/128, 2, S);  part[z][co][K]
-__global__ __launch_bounds__(WgTile::NTHREADS) void conv_wgrad_kernel(
+template <bool X3>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(
     RowMap dxm, RowMap im, int K, int rows_per_split, float* __restrict__ part) {
+    using WgTile = typename WgCfg<X3>::Tile;
     __shared__ float smem[WgTile::SMEM_FLOATS];
     const int n0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
     const int mbeg = blockIdx.z * rows_per_split;
@@ -447,7 +452,7 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
         const int M = B * e.L[i], K = kGeom[i].k * kC;
         const int tiles = 2 * (K / 128);
         int S = cdiv(768, tiles);                       // aim for >= 768 blocks
-        int rows = cdiv(cdiv(M, S), 16) * 16;
+        int rows = cdiv(cdiv(M, S), 32) * 32;
         if (rows < 256) rows = 256;
         S = cdiv(M, rows);
         e.wg_splits[i] = S; e.wg_rows[i] = rows;
@@ -599,8 +604,12 @@ extern "C" int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part
     const RowMap dxm = plain_rows(dx, B * Lout, kC);
     const RowMap im = conv_rows(x, B, Lin, Lout, s, p);
     CPC_RETURN_IF((long)splits * rows_per_split < dxm.M, CPC_ERR_SHAPE);
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(K / 128, 2, splits), dim3(WgTile::NTHREADS), 0, st, dxm,
-                       im, K, rows_per_split, part);
+    if (g_mfma_mode == 1)
+        hipLaunchKernelGGL((conv_wgrad_kernel<true>), dim3(K / 128, 2, splits), dim3(256), 0, st, dxm, im, K,
+                           rows_per_split, part);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<false>), dim3(K / 128, 2, splits), dim3(256), 0, st, dxm, im, K,
+                           rows_per_split, part);
     const long total = (long)kC * k * kC;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, part, splits, k, dW);
     CPC_LAUNCH_CHECK();

@@ -14,6 +14,7 @@ using NtSmall = NtTile<64, 64, 2, 2>;      // 64x64 block: used when the big til
 using NtBigX3 = NtTileX3<128, 128, 2, 2>;  // the same on the bf16 pipe with 3-piece split operands
 using NtSmallX3 = NtTileX3<64, 64, 2, 2>;
 using TnG = TnTile<128, 128, 2, 2>;
+using TnGX3 = TnTileX3<128, 128, 2, 2>;
 
 // Output row m goes to C + m*ldc, or, when c_R > 0, to C + (m / c_R)*c_bstride + (m % c_R)*ldc
 // (a batch-strided view such as dc[:, :W]).
@@ -46,9 +47,9 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
 }
 
 // grid = (N2/128, N1/128, S); part[z][N1][N2]
-__global__ __launch_bounds__(TnG::NTHREADS) void tn_gemm_kernel(RowMap am, RowMap bm, int N2,
-                                                                int rows_per_split,
-                                                                float* __restrict__ part, long zstride) {
+template <class TnG>
+__global__ __launch_bounds__(256) void tn_gemm_kernel(RowMap am, RowMap bm, int N2, int rows_per_split,
+                                                      float* __restrict__ part, long zstride) {
     __shared__ float smem[TnG::SMEM_FLOATS];
     const int n0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
     const int mbeg = blockIdx.z * rows_per_split;
@@ -126,7 +127,7 @@ long tn_gemm_part_floats(int M, int N1, int N2) {
 void tn_gemm_plan(int M, int N1, int N2, int* splits, int* rows) {
     const int tiles = (N1 / 128) * (N2 / 128);
     int S = cdiv(768, tiles > 0 ? tiles : 1);
-    int r = cdiv(cdiv(M, S), 16) * 16;
+    int r = cdiv(cdiv(M, S), 32) * 32;
     if (r < 256) r = 256;
     S = cdiv(M, r);
     if (S < 1) S = 1;
@@ -144,8 +145,12 @@ int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, flo
     }
     int S, rows;
     tn_gemm_plan(am.M, N1, N2, &S, &rows);
-    hipLaunchKernelGGL(tn_gemm_kernel, dim3(N2 / 128, N1 / 128, S), dim3(TnG::NTHREADS), 0, st, am, bm, N2,
-                       rows, part, n);
+    if (g_mfma_mode == 1)
+        hipLaunchKernelGGL((tn_gemm_kernel<TnGX3>), dim3(N2 / 128, N1 / 128, S), dim3(256), 0, st, am, bm, N2, rows,
+                           part, n);
+    else
+        hipLaunchKernelGGL((tn_gemm_kernel<TnG>), dim3(N2 / 128, N1 / 128, S), dim3(256), 0, st, am, bm, N2, rows,
+                           part, n);
     hipLaunchKernelGGL(split_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, S, n, C, accumulate);
     CPC_LAUNCH_CHECK();
     return 0;

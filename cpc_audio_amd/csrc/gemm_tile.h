@@ -238,6 +238,40 @@ __device__ __forceinline__ void split3_pack4(const float4& v, uint2& ph, uint2& 
     pl = make_uint2((l0 >> 16) | l1, (l2 >> 16) | l3);
 }
 
+// One BK-deep chunk of the split-bf16 product from K-major bf16 planes in LDS.
+// planes: [h | m | l], each `plane` halves; rows of LDH halves.  The six partial products of a
+// k-step are issued product-major so that consecutive MFMAs hit different accumulators.
+template <int TM, int TN, int BK, int LDH>
+__device__ __forceinline__ void x3_compute(f32x16 (&acc)[TM][TN], const unsigned short* As, int planeA,
+                                           const unsigned short* Bs, int planeB, int arow, int brow, int kofs) {
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                af[tm][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(
+                    As + pl * planeA + (arow + tm * 32) * LDH + ks * 16 + kofs));
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bf[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(
+                    Bs + pl * planeB + (brow + tn * 32) * LDH + ks * 16 + kofs));
+        // (A piece, B piece): l*h, h*l, m*m, m*h, h*m, h*h  -- small terms first
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][PA[q]], bf[tn][PB[q]], acc[tm][tn], 0, 0, 0);
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 struct NtTileX3 {
     static constexpr int BK = 32;
@@ -325,37 +359,7 @@ struct NtTileX3 {
         const int brow = wn * WN + (lane & 31);
         const int kofs = 8 * (lane >> 5);
         auto compute = [&]() __attribute__((always_inline)) {
-            const unsigned short* As = smem;
-            const unsigned short* Bs = smem + 3 * PLANE_A;
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 af[TM][3], bf[TN][3];
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        af[tm][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(
-                            As + pl * PLANE_A + (arow + tm * 32) * LDH + ks * 16 + kofs));
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        bf[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(
-                            Bs + pl * PLANE_B + (brow + tn * 32) * LDH + ks * 16 + kofs));
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) {
-                        f32x16 c = acc[tm][tn];
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][2], bf[tn][0], c, 0, 0, 0);   // l*h
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][2], c, 0, 0, 0);   // h*l
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bf[tn][1], c, 0, 0, 0);   // m*m
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bf[tn][0], c, 0, 0, 0);   // m*h
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][1], c, 0, 0, 0);   // h*m
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][0], c, 0, 0, 0);   // h*h
-                        acc[tm][tn] = c;
-                    }
-            }
+            x3_compute<TM, TN, BK, LDH>(acc, smem, PLANE_A, smem + 3 * PLANE_A, PLANE_B, arow, brow, kofs);
         };
 
         gload(0);
@@ -486,6 +490,128 @@ auto gload = [&](int kc_) __attribute__((always_inline)) {
             __syncthreads();
         }
         compute((nk - 1) & 1);
+        __syncthreads();
+    }
+};
+
+// ---------------------------------------------------------------------------
+// TnTileX3: the TN product (contraction over the row index m) on the bf16 pipe with 3-piece split
+// operands.  bf16 MFMA fragments want 8 consecutive contraction indices per lane, so the loader
+// transposes while staging: each thread fetches a 4(m) x 4(column) block (four float4 loads from
+// four consecutive rows), splits it, and writes, per column and plane, 4 consecutive-m halves with
+// one 8-byte LDS store.  LDS then holds the same K-major planes as NtTileX3 ([column][m]) and the
+// compute step is shared.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+struct TnTileX3 {
+    static constexpr int BK = 32;
+    static constexpr int LDH = BK + 8;
+    static constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    static constexpr int TM = WM / 32, TN = WN / 32;
+    static constexpr int A_BLK = (BK / 4) * (BM / 4), B_BLK = (BK / 4) * (BN / 4);    // 4x4 blocks
+    static constexpr int A_PER = (A_BLK + NTHREADS - 1) / NTHREADS;
+    static constexpr int B_PER = (B_BLK + NTHREADS - 1) / NTHREADS;
+    static constexpr int PLANE_A = BM * LDH, PLANE_B = BN * LDH;
+    static constexpr int SMEM_FLOATS = 3 * (PLANE_A + PLANE_B) / 2;
+
+    __device__ static __forceinline__ int c_row(int tm, int reg) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        return (wave / WAVES_N) * WM + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    }
+    __device__ static __forceinline__ int c_col(int tn) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        return (wave % WAVES_N) * WN + tn * 32 + (lane & 31);
+    }
+
+    // 4 rows x 4 columns of fp32 -> for each column (x,y,z,w of the float4s) the three planes of its
+    // 4 consecutive-m halves, stored at column-major LDS rows.
+    __device__ static __forceinline__ void store_block(unsigned short* base, int plane, int col0, int mofs,
+                                                       const float4 (&v)[4]) {
+        unsigned h[4][4], m[4][4], l[4][4];      // [row][col]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            split3(v[r].x, h[r][0], m[r][0], l[r][0]);
+            split3(v[r].y, h[r][1], m[r][1], l[r][1]);
+            split3(v[r].z, h[r][2], m[r][2], l[r][2]);
+            split3(v[r].w, h[r][3], m[r][3], l[r][3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned short* dst = base + (col0 + c) * LDH + mofs;
+            *reinterpret_cast<uint2*>(dst) = make_uint2((h[0][c] >> 16) | h[1][c], (h[2][c] >> 16) | h[3][c]);
+            *reinterpret_cast<uint2*>(dst + plane) = make_uint2((m[0][c] >> 16) | m[1][c], (m[2][c] >> 16) | m[3][c]);
+            *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2((l[0][c] >> 16) | l[1][c], (l[2][c] >> 16) | l[3][c]);
+        }
+    }
+
+    __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int c0,
+                               const RowMap& bm, int n0, int mbeg, int mend, float* smem_f) {
+        unsigned short* smem = reinterpret_cast<unsigned short*>(smem_f);
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+        int a_m[A_PER], a_c[A_PER], b_m[B_PER], b_c[B_PER];
+        bool a_on[A_PER], b_on[B_PER];
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int blk = tid + i * NTHREADS;
+            a_on[i] = blk < A_BLK;
+            a_m[i] = (blk / (BM / 4)) * 4;
+            a_c[i] = (blk % (BM / 4)) * 4;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int blk = tid + i * NTHREADS;
+            b_on[i] = blk < B_BLK;
+            b_m[i] = (blk / (BN / 4)) * 4;
+            b_c[i] = (blk % (BN / 4)) * 4;
+        }
+        float4 ra[A_PER][4], rb[B_PER][4];
+        const int nk = (mend - mbeg + BK - 1) / BK;
+        if (nk <= 0) return;
+
+        auto gload = [&](int kc_) __attribute__((always_inline)) {
+            const int mm = mbeg + kc_ * BK;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const RowRef rr = resolve_row(am, mm + a_m[i] + r, a_on[i] ? mend : 0);
+                    ra[i][r] = load_row4(rr, c0 + a_c[i], am.Lin);
+                }
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const RowRef rr = resolve_row(bm, mm + b_m[i] + r, b_on[i] ? mend : 0);
+                    rb[i][r] = load_row4(rr, n0 + b_c[i], bm.Lin);
+                }
+        };
+        auto sstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i)
+                if (a_on[i]) store_block(smem, PLANE_A, a_c[i], a_m[i], ra[i]);
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i)
+                if (b_on[i]) store_block(smem + 3 * PLANE_A, PLANE_B, b_c[i], b_m[i], rb[i]);
+        };
+        const int arow = wm * WM + (lane & 31);
+        const int brow = wn * WN + (lane & 31);
+        const int kofs = 8 * (lane >> 5);
+        auto compute = [&]() __attribute__((always_inline)) {
+            x3_compute<TM, TN, BK, LDH>(acc, smem, PLANE_A, smem + 3 * PLANE_A, PLANE_B, arow, brow, kofs);
+        };
+        gload(0);
+        sstore();
+        __syncthreads();
+        for (int kc = 0; kc + 1 < nk; ++kc) {
+            gload(kc + 1);
+            compute();
+            __syncthreads();
+            sstore();
+            __syncthreads();
+        }
+        compute();
         __syncthreads();
     }
 };

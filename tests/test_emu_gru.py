@@ -8,10 +8,19 @@ from emu_util import P, emu, rel_err
 from oracle import cpc_oracle as O
 
 
-def test_gemm_nt_tn_emulated():
+@pytest.mark.parametrize("mode", [1, 0])
+def test_gemm_nt_tn_emulated(mode):
     lib = emu()
+    assert lib.cpc_set_mfma_mode(mode) == 0
+    try:
+        _gemm_checks(lib)
+    finally:
+        lib.cpc_set_mfma_mode(1)
+
+
+def _gemm_checks(lib):
     torch.manual_seed(0)
-    M, N, K = 200, 256, 48
+    M, N, K = 200, 256, 96
     A = torch.randn(M, K); Bm = torch.randn(N, K); bias = torch.randn(N)
     C = torch.full((M, N), float("nan"))
     assert lib.cpc_gemm_nt(P(A), K, P(Bm), K, P(bias), P(C), N, M, N, K, None) == 0
