@@ -210,10 +210,11 @@ auto gload = [&](int kc_) __attribute__((always_inline)) {
 // Six v_mfma_f32_32x32x16_bf16 (32 cycles, 16 k) replace eight v_mfma_f32_32x32x2_f32
 // (64 cycles, 2 k): 2.67x the f32-MFMA rate at the same parity bar.
 //
-// LDS: three bf16 planes per operand, K-major rows of BK = 32 halves padded to 40 (80 B: 16-byte
-// aligned, conflict-free ds_read_b128 over 16-lane groups).  One LDS stage (92 KB at 128 x 256)
-// with register prefetch of the next chunk: load(kc+1) | compute(kc) | barrier | split+store |
-// barrier.
+// LDS: three bf16 planes per operand, K-major rows of BK halves padded by 8 (16-byte aligned,
+// conflict-free ds_read_b128 over 16-lane groups).  Default: BK = 32, ONE LDS stage (92 KB at
+// 128 x 256) with register prefetch: load(kc+1) | compute(kc) | barrier | split+store | barrier.
+// The double-buffered BK = 16 form (STAGES = 2, 110 KB) measured slower on MI355X (conv1 152 vs 162
+// TFLOP/s-equivalent, conv3 65 vs 107: more LDS per block, twice the barriers per k).
 // ---------------------------------------------------------------------------
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -272,10 +273,11 @@ __device__ __forceinline__ void x3_compute(f32x16 (&acc)[TM][TN], const unsigned
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1>
 struct NtTileX3 {
-    static constexpr int BK = 32;
-    static constexpr int LDH = BK + 8;   // halves per LDS row
+    static constexpr int BK = BK_;       // 32 with one LDS stage (default), or 16 double-buffered
+    static constexpr int LDH = BK + 8;   // halves per LDS row (80 B / 48 B: 16-byte aligned, conflict-free b128)
+    static constexpr int SPR = BK / 4;   // float4 slots per row
     static constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     static constexpr int TM = WM / 32, TN = WN / 32;
@@ -283,8 +285,10 @@ struct NtTileX3 {
     static constexpr int A_PER = (A_SLOTS + NTHREADS - 1) / NTHREADS;
     static constexpr int B_PER = (B_SLOTS + NTHREADS - 1) / NTHREADS;
     static constexpr int PLANE_A = BM * LDH, PLANE_B = BN * LDH;          // halves
-    static constexpr int SMEM_FLOATS = 3 * (PLANE_A + PLANE_B) / 2;
+    static constexpr int STAGE_H = 3 * (PLANE_A + PLANE_B);               // halves per stage
+    static constexpr int SMEM_FLOATS = STAGES * STAGE_H / 2;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+    static_assert(STAGES == 1 || STAGES == 2, "one or two LDS stages");
 
     __device__ static __forceinline__ int c_row(int tm, int reg) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -298,7 +302,7 @@ struct NtTileX3 {
     __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int m0,
                                const float* __restrict__ Bmat, int ldb, int n0, int K,
                                float* smem_f) {
-        unsigned short* smem = reinterpret_cast<unsigned short*>(smem_f);
+        unsigned short* smem0 = reinterpret_cast<unsigned short*>(smem_f);
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
@@ -309,7 +313,7 @@ struct NtTileX3 {
         for (int i = 0; i < A_PER; ++i) {
             const int slot = tid + i * NTHREADS;
             a_on[i] = slot < A_SLOTS;
-            const int r = slot >> 3, kv = slot & 7;
+            const int r = slot / SPR, kv = slot % SPR;
             ar[i] = resolve_row(am, m0 + r, a_on[i] ? am.M : 0);
             a_k[i] = kv * 4;
             a_lds[i] = r * LDH + kv * 4;
@@ -321,7 +325,7 @@ struct NtTileX3 {
         for (int i = 0; i < B_PER; ++i) {
             const int slot = tid + i * NTHREADS;
             b_on[i] = slot < B_SLOTS;
-            const int r = b_on[i] ? (slot >> 3) : 0, kv = slot & 7;
+            const int r = b_on[i] ? (slot / SPR) : 0, kv = slot % SPR;
             bp[i] = Bmat + (long)(n0 + r) * ldb + kv * 4;
             b_lds[i] = 3 * PLANE_A + r * LDH + kv * 4;
         }
@@ -335,7 +339,8 @@ struct NtTileX3 {
 #pragma unroll
             for (int i = 0; i < B_PER; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
         };
-        auto sstore = [&]() __attribute__((always_inline)) {
+        auto sstore = [&](int st_) __attribute__((always_inline)) {
+            unsigned short* smem = smem0 + st_ * STAGE_H;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
                 if (a_on[i]) {
@@ -358,21 +363,32 @@ struct NtTileX3 {
         const int arow = wm * WM + (lane & 31);
         const int brow = wn * WN + (lane & 31);
         const int kofs = 8 * (lane >> 5);
-        auto compute = [&]() __attribute__((always_inline)) {
+        auto compute = [&](int st_) __attribute__((always_inline)) {
+            const unsigned short* smem = smem0 + st_ * STAGE_H;
             x3_compute<TM, TN, BK, LDH>(acc, smem, PLANE_A, smem + 3 * PLANE_A, PLANE_B, arow, brow, kofs);
         };
 
         gload(0);
-        sstore();
+        sstore(0);
         __syncthreads();
-        for (int kc = 0; kc + 1 < nk; ++kc) {
-            gload(kc + 1);
-            compute();
-            __syncthreads();
-            sstore();
-            __syncthreads();
+        if (STAGES == 2) {
+            for (int kc = 0; kc + 1 < nk; ++kc) {
+                gload(kc + 1);
+                compute(kc & 1);
+                sstore((kc & 1) ^ 1);
+                __syncthreads();
+            }
+            compute((nk - 1) & 1);
+        } else {
+            for (int kc = 0; kc + 1 < nk; ++kc) {
+                gload(kc + 1);
+                compute(0);
+                __syncthreads();
+                sstore(0);
+                __syncthreads();
+            }
+            compute(0);
         }
-        compute();
         __syncthreads();
     }
 };
@@ -502,9 +518,9 @@ auto gload = [&](int kc_) __attribute__((always_inline)) {
 // one 8-byte LDS store.  LDS then holds the same K-major planes as NtTileX3 ([column][m]) and the
 // compute step is shared.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1>
 struct TnTileX3 {
-    static constexpr int BK = 32;
+    static constexpr int BK = BK_;
     static constexpr int LDH = BK + 8;
     static constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -513,7 +529,8 @@ struct TnTileX3 {
     static constexpr int A_PER = (A_BLK + NTHREADS - 1) / NTHREADS;
     static constexpr int B_PER = (B_BLK + NTHREADS - 1) / NTHREADS;
     static constexpr int PLANE_A = BM * LDH, PLANE_B = BN * LDH;
-    static constexpr int SMEM_FLOATS = 3 * (PLANE_A + PLANE_B) / 2;
+    static constexpr int STAGE_H = 3 * (PLANE_A + PLANE_B);
+    static constexpr int SMEM_FLOATS = STAGES * STAGE_H / 2;
 
     __device__ static __forceinline__ int c_row(int tm, int reg) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -547,7 +564,7 @@ struct TnTileX3 {
 
     __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int c0,
                                const RowMap& bm, int n0, int mbeg, int mend, float* smem_f) {
-        unsigned short* smem = reinterpret_cast<unsigned short*>(smem_f);
+        unsigned short* smem0 = reinterpret_cast<unsigned short*>(smem_f);
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int wm = wave / WAVES_N, wn = wave % WAVES_N;
         int a_m[A_PER], a_c[A_PER], b_m[B_PER], b_c[B_PER];
@@ -587,7 +604,8 @@ struct TnTileX3 {
                     rb[i][r] = load_row4(rr, n0 + b_c[i], bm.Lin);
                 }
         };
-        auto sstore = [&]() __attribute__((always_inline)) {
+        auto sstore = [&](int st_) __attribute__((always_inline)) {
+            unsigned short* smem = smem0 + st_ * STAGE_H;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
                 if (a_on[i]) store_block(smem, PLANE_A, a_c[i], a_m[i], ra[i]);
@@ -598,20 +616,31 @@ struct TnTileX3 {
         const int arow = wm * WM + (lane & 31);
         const int brow = wn * WN + (lane & 31);
         const int kofs = 8 * (lane >> 5);
-        auto compute = [&]() __attribute__((always_inline)) {
+        auto compute = [&](int st_) __attribute__((always_inline)) {
+            const unsigned short* smem = smem0 + st_ * STAGE_H;
             x3_compute<TM, TN, BK, LDH>(acc, smem, PLANE_A, smem + 3 * PLANE_A, PLANE_B, arow, brow, kofs);
         };
         gload(0);
-        sstore();
+        sstore(0);
         __syncthreads();
-        for (int kc = 0; kc + 1 < nk; ++kc) {
-            gload(kc + 1);
-            compute();
-            __syncthreads();
-            sstore();
-            __syncthreads();
+        if (STAGES == 2) {
+            for (int kc = 0; kc + 1 < nk; ++kc) {
+                gload(kc + 1);
+                compute(kc & 1);
+                sstore((kc & 1) ^ 1);
+                __syncthreads();
+            }
+            compute((nk - 1) & 1);
+        } else {
+            for (int kc = 0; kc + 1 < nk; ++kc) {
+                gload(kc + 1);
+                compute(0);
+                __syncthreads();
+                sstore(0);
+                __syncthreads();
+            }
+            compute(0);
         }
-        compute();
         __syncthreads();
     }
 };
