@@ -349,19 +349,27 @@ template <bool X3>
 struct WgCfg {
     using Tile = typename std::conditional<X3, TnTileX3<128, 128, 2, 2>, TnTile<128, 128, 2, 2>>::type;
 };
-// grid = (K/128, 2, S);  part[z][co][K]
+// 1-D grid of 8 * T * ceil(S/8) blocks, T = 2*K/128 output tiles; part[z][co][K].
+// XCD-aware mapping: the dispatcher places block b on XCD b % 8 (observed, speed only), and every
+// output tile of one row split z re-reads the same dx / activation rows, so all T tiles of a split
+// are given to ONE XCD (z % 8): its L2 fetches those rows once instead of eight L2s fetching them
+// eight times (the rows do not fit any single L2: 335 MB for layer 1 at B = 64).
 template <bool X3>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
-    RowMap dxm, RowMap im, int K, int rows_per_split, float* __restrict__ part) {
+    RowMap dxm, RowMap im, int K, int rows_per_split, int S, float* __restrict__ part) {
     using WgTile = typename WgCfg<X3>::Tile;
     __shared__ float smem[WgTile::SMEM_FLOATS];
-    const int n0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
-    const int mbeg = blockIdx.z * rows_per_split;
+    const int T = 2 * (K / 128);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = slot % T, z = (slot / T) * 8 + xcd;
+    if (z >= S) return;                                  // block-uniform
+    const int n0 = (tile >> 1) * 128, c0 = (tile & 1) * 128;
+    const int mbeg = z * rows_per_split;
     const int mend = min(dxm.M, mbeg + rows_per_split);
     f32x16 acc[WgTile::TM][WgTile::TN];
     zero_acc(acc);
     WgTile::run(acc, dxm, c0, im, n0, mbeg, mend, smem);
-    float* out = part + (long)blockIdx.z * kC * K;
+    float* out = part + (long)z * kC * K;
 #pragma unroll
     for (int tm = 0; tm < WgTile::TM; ++tm)
 #pragma unroll
@@ -604,12 +612,11 @@ extern "C" int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part
     const RowMap dxm = plain_rows(dx, B * Lout, kC);
     const RowMap im = conv_rows(x, B, Lin, Lout, s, p);
     CPC_RETURN_IF((long)splits * rows_per_split < dxm.M, CPC_ERR_SHAPE);
+    const dim3 grid(8 * 2 * (K / 128) * cdiv(splits, 8));
     if (g_mfma_mode == 1)
-        hipLaunchKernelGGL((conv_wgrad_kernel<true>), dim3(K / 128, 2, splits), dim3(256), 0, st, dxm, im, K,
-                           rows_per_split, part);
+        hipLaunchKernelGGL((conv_wgrad_kernel<true>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part);
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<false>), dim3(K / 128, 2, splits), dim3(256), 0, st, dxm, im, K,
-                           rows_per_split, part);
+        hipLaunchKernelGGL((conv_wgrad_kernel<false>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part);
     const long total = (long)kC * k * kC;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, part, splits, k, dW);
     CPC_LAUNCH_CHECK();

@@ -46,18 +46,23 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
     }
 }
 
-// grid = (N2/128, N1/128, S); part[z][N1][N2]
+// 1-D grid of 8 * T * ceil(S/8) blocks, T = (N1/128)*(N2/128) output tiles; part[z][N1][N2].
+// XCD-aware: all tiles of one row split run on one XCD (see conv_wgrad_kernel).
 template <class TnG>
-__global__ __launch_bounds__(256) void tn_gemm_kernel(RowMap am, RowMap bm, int N2, int rows_per_split,
-                                                      float* __restrict__ part, long zstride) {
+__global__ __launch_bounds__(256) void tn_gemm_kernel(RowMap am, RowMap bm, int N1, int N2, int rows_per_split,
+                                                      int S, float* __restrict__ part, long zstride) {
     __shared__ float smem[TnG::SMEM_FLOATS];
-    const int n0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
-    const int mbeg = blockIdx.z * rows_per_split;
+    const int tn2 = N2 / 128, T = (N1 / 128) * tn2;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = slot % T, z = (slot / T) * 8 + xcd;
+    if (z >= S) return;                                  // block-uniform
+    const int n0 = (tile % tn2) * 128, c0 = (tile / tn2) * 128;
+    const int mbeg = z * rows_per_split;
     const int mend = min(am.M, mbeg + rows_per_split);
     f32x16 acc[TnG::TM][TnG::TN];
     zero_acc(acc);
     TnG::run(acc, am, c0, bm, n0, mbeg, mend, smem);
-    float* out = part + (long)blockIdx.z * zstride;
+    float* out = part + (long)z * zstride;
 #pragma unroll
     for (int tm = 0; tm < TnG::TM; ++tm)
 #pragma unroll
@@ -145,12 +150,11 @@ int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, flo
     }
     int S, rows;
     tn_gemm_plan(am.M, N1, N2, &S, &rows);
+    const dim3 grid(8 * (N1 / 128) * (N2 / 128) * cdiv(S, 8));
     if (g_mfma_mode == 1)
-        hipLaunchKernelGGL((tn_gemm_kernel<TnGX3>), dim3(N2 / 128, N1 / 128, S), dim3(256), 0, st, am, bm, N2, rows,
-                           part, n);
+        hipLaunchKernelGGL((tn_gemm_kernel<TnGX3>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n);
     else
-        hipLaunchKernelGGL((tn_gemm_kernel<TnG>), dim3(N2 / 128, N1 / 128, S), dim3(256), 0, st, am, bm, N2, rows,
-                           part, n);
+        hipLaunchKernelGGL((tn_gemm_kernel<TnG>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n);
     hipLaunchKernelGGL(split_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, S, n, C, accumulate);
     CPC_LAUNCH_CHECK();
     return 0;

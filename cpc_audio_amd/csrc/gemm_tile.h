@@ -70,6 +70,33 @@ __device__ __forceinline__ RowRef resolve_row(const RowMap& rm, int m, int mlimi
     return r;
 }
 
+// (batch, position) of a row, advanced without divisions (rows of a tile chunk are consecutive).
+struct RowCursor {
+    int b, t;
+};
+__device__ __forceinline__ RowCursor cursor_at(const RowMap& rm, int m) {
+    RowCursor c;
+    c.b = m / rm.R;
+    c.t = m - c.b * rm.R;
+    return c;
+}
+__device__ __forceinline__ RowCursor cursor_plus(const RowMap& rm, RowCursor c, int n) {
+    c.t += n;
+    while (c.t >= rm.R) { c.t -= rm.R; c.b += 1; }
+    return c;
+}
+__device__ __forceinline__ RowRef cursor_ref(const RowMap& rm, const RowCursor& c, bool valid) {
+    RowRef r;
+    if (valid) {
+        r.ptr = rm.base + (long)c.b * rm.bstride + (long)c.t * rm.rstride + rm.off;
+        r.tau0 = c.t * rm.tmul + rm.tadd;
+    } else {
+        r.ptr = rm.base;
+        r.tau0 = -(1 << 30);
+    }
+    return r;
+}
+
 __device__ __forceinline__ float4 load_row4(const RowRef& r, int k, int Lin) {
     int tau = r.tau0 + (k >> kCLog2);
     if ((unsigned)tau < (unsigned)Lin) return *reinterpret_cast<const float4*>(r.ptr + k);
@@ -242,24 +269,32 @@ __device__ __forceinline__ void split3_pack4(const float4& v, uint2& ph, uint2& 
 // One BK-deep chunk of the split-bf16 product from K-major bf16 planes in LDS.
 // planes: [h | m | l], each `plane` halves; rows of LDH halves.  The six partial products of a
 // k-step are issued product-major so that consecutive MFMAs hit different accumulators.
-template <int TM, int TN, int BK, int LDH>
+// SWZ: rows were written with their 16-byte k-pairs XOR-swizzled by ((row >> 3) & (BK/8 - 1)) (the
+// transposing TN loader does that to keep its 8-byte column stores bank-conflict free).
+template <int TM, int TN, int BK, int LDH, bool SWZ = false>
 __device__ __forceinline__ void x3_compute(f32x16 (&acc)[TM][TN], const unsigned short* As, int planeA,
                                            const unsigned short* Bs, int planeB, int arow, int brow, int kofs) {
+    constexpr int SWM = BK / 8 - 1;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
         bf16x8 af[TM][3], bf[TN][3];
+        const int pair = (ks * 16 + kofs) >> 3;
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                af[tm][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(
-                    As + pl * planeA + (arow + tm * 32) * LDH + ks * 16 + kofs));
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+        for (int tm = 0; tm < TM; ++tm) {
+            const int row = arow + tm * 32;
+            const int ko = SWZ ? ((pair ^ ((row >> 3) & SWM)) << 3) : (ks * 16 + kofs);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                bf[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(
-                    Bs + pl * planeB + (brow + tn * 32) * LDH + ks * 16 + kofs));
+                af[tm][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(As + pl * planeA + row * LDH + ko));
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int row = brow + tn * 32;
+            const int ko = SWZ ? ((pair ^ ((row >> 3) & SWM)) << 3) : (ks * 16 + kofs);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bf[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(Bs + pl * planeB + row * LDH + ko));
+        }
         // (A piece, B piece): l*h, h*l, m*m, m*h, h*m, h*h  -- small terms first
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
         constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
@@ -446,17 +481,24 @@ struct TnTile {
         float4 ra[A_PER], rb[B_PER];
         const int nk = (mend - mbeg + BK - 1) / BK;
 
-auto gload = [&](int kc_) __attribute__((always_inline)) {
+RowCursor ca[A_PER], cb[B_PER];
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) ca[i] = cursor_at(am, mbeg + a_row[i]);
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) cb[i] = cursor_at(bm, mbeg + b_row[i]);
+        auto gload = [&](int kc_) __attribute__((always_inline)) {
             const int mm = mbeg + kc_ * BK;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
-                const RowRef r = resolve_row(am, mm + a_row[i], a_on[i] ? mend : 0);
+                const RowRef r = cursor_ref(am, ca[i], a_on[i] && (mm + a_row[i]) < mend);
                 ra[i] = load_row4(r, c0 + a_col[i], am.Lin);
+                ca[i] = cursor_plus(am, ca[i], BK);
             }
 #pragma unroll
             for (int i = 0; i < B_PER; ++i) {
-                const RowRef r = resolve_row(bm, mm + b_row[i], b_on[i] ? mend : 0);
+                const RowRef r = cursor_ref(bm, cb[i], b_on[i] && (mm + b_row[i]) < mend);
                 rb[i] = load_row4(r, n0 + b_col[i], bm.Lin);
+                cb[i] = cursor_plus(bm, cb[i], BK);
             }
         };
         auto sstore = [&](int st_) __attribute__((always_inline)) {
@@ -553,9 +595,13 @@ struct TnTileX3 {
             split3(v[r].z, h[r][2], m[r][2], l[r][2]);
             split3(v[r].w, h[r][3], m[r][3], l[r][3]);
         }
+        // 4-row block `mofs/4` of column group col0/4 goes to k-slot (mofs/4) ^ 2*((col0/8) & SWM): with the
+        // (8 column groups x 2 row blocks) lane order below, a 16-lane group then covers 16 distinct banks.
+        constexpr int SWM = BK / 8 - 1;
+        const int mphys = (((mofs >> 2) ^ (2 * ((col0 >> 3) & SWM))) << 2);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            unsigned short* dst = base + (col0 + c) * LDH + mofs;
+            unsigned short* dst = base + (col0 + c) * LDH + mphys;
             *reinterpret_cast<uint2*>(dst) = make_uint2((h[0][c] >> 16) | h[1][c], (h[2][c] >> 16) | h[3][c]);
             *reinterpret_cast<uint2*>(dst + plane) = make_uint2((m[0][c] >> 16) | m[1][c], (m[2][c] >> 16) | m[3][c]);
             *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2((l[0][c] >> 16) | l[1][c], (l[2][c] >> 16) | l[3][c]);
@@ -573,36 +619,51 @@ struct TnTileX3 {
         for (int i = 0; i < A_PER; ++i) {
             const int blk = tid + i * NTHREADS;
             a_on[i] = blk < A_BLK;
-            a_m[i] = (blk / (BM / 4)) * 4;
-            a_c[i] = (blk % (BM / 4)) * 4;
+            // 16 consecutive lanes = 8 column groups x 2 row blocks (128-byte global segments, and the
+            // swizzled LDS stores of a 16-lane group land on 16 distinct banks)
+            const int g = (blk & 7) + 8 * ((blk >> 4) % (BM / 32));
+            const int mb = ((blk >> 3) & 1) + 2 * ((blk >> 4) / (BM / 32));
+            a_m[i] = mb * 4;
+            a_c[i] = g * 4;
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int blk = tid + i * NTHREADS;
             b_on[i] = blk < B_BLK;
-            b_m[i] = (blk / (BN / 4)) * 4;
-            b_c[i] = (blk % (BN / 4)) * 4;
+            const int g = (blk & 7) + 8 * ((blk >> 4) % (BN / 32));
+            const int mb = ((blk >> 3) & 1) + 2 * ((blk >> 4) / (BN / 32));
+            b_m[i] = mb * 4;
+            b_c[i] = g * 4;
         }
         float4 ra[A_PER][4], rb[B_PER][4];
         const int nk = (mend - mbeg + BK - 1) / BK;
         if (nk <= 0) return;
 
+        RowCursor ca[A_PER], cb[B_PER];          // first row of this thread's 4x4 block in the current chunk
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) ca[i] = cursor_at(am, mbeg + a_m[i]);
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) cb[i] = cursor_at(bm, mbeg + b_m[i]);
         auto gload = [&](int kc_) __attribute__((always_inline)) {
             const int mm = mbeg + kc_ * BK;
 #pragma unroll
-            for (int i = 0; i < A_PER; ++i)
+            for (int i = 0; i < A_PER; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const RowRef rr = resolve_row(am, mm + a_m[i] + r, a_on[i] ? mend : 0);
+                    const RowRef rr = cursor_ref(am, cursor_plus(am, ca[i], r), a_on[i] && (mm + a_m[i] + r) < mend);
                     ra[i][r] = load_row4(rr, c0 + a_c[i], am.Lin);
                 }
+                ca[i] = cursor_plus(am, ca[i], BK);
+            }
 #pragma unroll
-            for (int i = 0; i < B_PER; ++i)
+            for (int i = 0; i < B_PER; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const RowRef rr = resolve_row(bm, mm + b_m[i] + r, b_on[i] ? mend : 0);
+                    const RowRef rr = cursor_ref(bm, cursor_plus(bm, cb[i], r), b_on[i] && (mm + b_m[i] + r) < mend);
                     rb[i][r] = load_row4(rr, n0 + b_c[i], bm.Lin);
                 }
+                cb[i] = cursor_plus(bm, cb[i], BK);
+            }
         };
         auto sstore = [&](int st_) __attribute__((always_inline)) {
             unsigned short* smem = smem0 + st_ * STAGE_H;
@@ -618,7 +679,7 @@ struct TnTileX3 {
         const int kofs = 8 * (lane >> 5);
         auto compute = [&](int st_) __attribute__((always_inline)) {
             const unsigned short* smem = smem0 + st_ * STAGE_H;
-            x3_compute<TM, TN, BK, LDH>(acc, smem, PLANE_A, smem + 3 * PLANE_A, PLANE_B, arow, brow, kofs);
+            x3_compute<TM, TN, BK, LDH, true>(acc, smem, PLANE_A, smem + 3 * PLANE_A, PLANE_B, arow, brow, kofs);
         };
         gload(0);
         sstore(0);
