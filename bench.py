@@ -24,7 +24,11 @@ sys.path.insert(0, ROOT)
 
 AUDIO_S_PER_SEQ = 20480 / 16000.0
 F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (same guide)
+X3_PRODUCTS = 6                   # bf16 MFMAs issued per fp32 product in the split-bf16 tiles (gemm_tile.h)
 HBM_PEAK_GBPS = 8000.0
+# HBM bytes per launch at B = 64 from the PMC counters (profiles/r1_pmc_roofline_kernels.md)
+PMC_TRAFFIC_B64 = {"conv1_fwd": 692.1e6, "conv0_fwd": 277.8e6}
 
 
 def parse():
@@ -52,7 +56,7 @@ def hip_event_time(fn, iters, warm=3):
 
 
 def roofline_probe(B, dev):
-    """Roofline of the dominant kernel, conv_fwd_kernel<128> on layer 1 (k8 s4, 256->256): the
+    """Roofline of the dominant kernel, conv_fwd_kernel<128,true> on layer 1 (k8 s4, 256->256): the
     implicit-GEMM + ChannelNorm + ReLU kernel.  Algorithmic work per 1.28 s window (SURVEY.md
     section 8d): 536,870,912 MAC = 1.0737 GFLOP; one launch processes B windows."""
     from cpc_audio_amd import _lib
@@ -73,9 +77,17 @@ def roofline_probe(B, dev):
     ms = hip_event_time(f, iters=20)
     flops = 2.0 * 536870912 * B
     ach = flops / (ms * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "conv_fwd_kernel<128> (encoder layer 1, f32 MFMA implicit GEMM + ChannelNorm + ReLU)",
-            "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None, "ms_per_launch": round(ms, 4), "flop_per_launch": flops}
+    # The kernel runs on the bf16 matrix pipe with 3-piece split operands: every algorithmic fp32 FLOP
+    # costs 6 bf16 MFMA FLOPs, so the roof for ALGORITHMIC FLOP/s is 2500 / 6 = 416.7 TFLOP/s.
+    peak = BF16_MFMA_PEAK_TFLOPS / X3_PRODUCTS
+    roof = {"bound": "mfma",
+            "kernel": "conv_fwd_kernel<128,true> (encoder layer 1: implicit GEMM on the bf16 pipe with 3-piece split "
+                      "fp32 operands, fp32 accumulate, + ChannelNorm + ReLU)",
+            "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": PMC_TRAFFIC_B64["conv1_fwd"] if B == 64 else None,
+            "ms_per_launch": round(ms, 4), "flop_per_launch": flops,
+            "bf16_mfma_TFLOPs": round(ach * X3_PRODUCTS, 1), "bf16_mfma_peak": BF16_MFMA_PEAK_TFLOPS,
+            "vs_f32_mfma_peak": round(ach / F32_MFMA_PEAK_TFLOPS, 4)}
     # the HBM-bound layer (conv0 + norm + ReLU): algorithmic bytes = waveform read + one activation write
     L = 20480
     wave = torch.randn(B, L, device=dev) * 0.1
@@ -90,7 +102,8 @@ def roofline_probe(B, dev):
     byts = B * (L * 4 + L0 * 256 * 4 + 2 * L0 * 4)
     g = byts / (ms0 * 1e-3) / 1e9
     hbm = {"bound": "hbm", "kernel": "conv0_fwd_kernel (conv0 + ChannelNorm + ReLU)", "achieved": round(g, 1),
-           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(g / HBM_PEAK_GBPS, 4), "traffic": None,
+           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(g / HBM_PEAK_GBPS, 4),
+           "traffic": PMC_TRAFFIC_B64["conv0_fwd"] if B == 64 else None,
            "ms_per_launch": round(ms0, 4), "bytes_per_launch": byts}
     return roof, hbm
 
@@ -175,7 +188,8 @@ def main():
         out = {
             "metric": "audio-seconds/sec (train step)", "value": round(value, 1), "unit": "audio-s/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * el / a.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (GEMMs: fp32 operands split into 3 bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate)",
             "data": "synthetic white noise 0.1*N(0,1) clamped to [-1,1], resident in HBM; random-init weights",
             "config": {"workload": "default CPC train step (conv encoder + 2-layer GRU + K=12 InfoNCE, 128 negatives), "
                                    f"{world}x{B}x20480 fp32 (BASELINE.json configs[1] at fp32)",

@@ -65,7 +65,7 @@ struct ConvCfg {
 };
 
 template <int BM, bool X3>
-__global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS)) void conv_fwd_kernel(
+__global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_fwd_kernel(
     RowMap am, const float* __restrict__ wp, int K, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
     float* __restrict__ xhat, float* __restrict__ rstd_out) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
 // ------------------------------------------------------------------ dgrad (+ fused norm backward)
 // grid = (row tiles over B*(Lout+1), s phases).  am = 2-row windows over dx of THIS layer.
 template <int BM, bool FUSE, bool X3>
-__global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS)) void conv_dgrad_kernel(
+__global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_dgrad_kernel(
     RowMap am, const float* __restrict__ wd, int s, int p, int Lin,
     const float* __restrict__ xhat_prev, const float* __restrict__ y_prev,
     const float* __restrict__ rstd_prev, const float* __restrict__ nw_prev,

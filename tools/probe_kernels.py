@@ -1,0 +1,20 @@
+"""Launch the two roofline kernels a few times (for rocprofv3 --pmc runs):
+conv_fwd_kernel<128,X3> on encoder layer 1 and conv0_fwd_kernel, B = 64."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cpc_audio_amd import _lib
+from cpc_audio_amd._lib import ptr as P
+lib = _lib.get(); dev = torch.device("cuda:0")
+B, Lin, k, s, p = 64, 4096, 8, 4, 2
+x = torch.randn(B, Lin, 256, device=dev).relu_(); wp = torch.randn(256, k * 256, device=dev) / 45
+bias = torch.randn(256, device=dev) * 0.1; nw = torch.ones(256, device=dev); nb = torch.zeros(256, device=dev)
+y = torch.empty(B, 1024, 256, device=dev); xh = torch.empty_like(y); rs = torch.empty(B * 1024, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+L = 20480
+wave = torch.randn(B, L, device=dev) * 0.1; w0 = torch.randn(256, 10, device=dev) * 0.3
+y0 = torch.empty(B, 4096, 256, device=dev); m0 = torch.empty(B * 4096, device=dev); r0 = torch.empty(B * 4096, device=dev)
+for _ in range(5):
+    lib.check(lib.cpc_conv_gemm_forward(P(x), P(wp), P(bias), P(nw), P(nb), P(y), P(xh), P(rs), B, Lin, k, s, p, st))
+    lib.check(lib.cpc_conv0_forward(P(wave), P(w0), P(bias), P(nw), P(nb), P(y0), P(m0), P(r0), B, L, st))
+torch.cuda.synchronize()
+print("done")
