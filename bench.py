@@ -149,12 +149,11 @@ def main():
     if a.gpus != world and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
-    from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
-    from oracle import cpc_oracle as O     # only for the deterministic parameter recipe + cpu baseline
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model
 
     B = a.batch
-    model, crit = build_model().to(dev), build_criterion().to(dev)
-    load_flat_params(model, crit, O.make_params(seed=0))      # identical weights on every rank
+    torch.manual_seed(0)                       # random-init weights (the reference's default initialisers),
+    model, crit = build_model().to(dev), build_criterion().to(dev)   # identical on every rank
     trainer = Trainer(model, crit)
     g = torch.Generator().manual_seed(1234 + rank)
     wave = (0.1 * torch.randn(B, 1, 20480, generator=g)).clamp_(-1, 1).to(dev)

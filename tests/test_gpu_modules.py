@@ -1,0 +1,130 @@
+"""Module-level behaviour on a real MI355X vs the CPU oracle: hidden-state carry (keepHidden /
+samplingType=sequential, BASELINE config 5), reverse mode, other K / N / window lengths, and one
+complete optimiser step."""
+import pytest
+import torch
+
+from oracle import cpc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_gru_hidden_carry_matches_oracle():
+    """CPCAR(keepHidden=True): the final state of call 1 seeds call 2 (cpc/model.py:193-198)."""
+    dev = _dev()
+    from cpc_audio_amd.model import CPCAR
+    p = O.make_params(seed=2)
+    ar = CPCAR(256, 256, True, 2, mode="GRU").to(dev)
+    ar.load_state_dict({k[len("gAR."):]: v for k, v in p.items() if k.startswith("gAR.")})
+    g = torch.Generator().manual_seed(0)
+    x1, x2 = torch.randn(5, 40, 256, generator=g), torch.randn(5, 40, 256, generator=g)
+    y1 = ar(x1.to(dev))
+    assert ar.hidden is not None and not ar.hidden.requires_grad
+    x2d = x2.to(dev).requires_grad_(True)
+    y2 = ar(x2d)
+    dy = torch.randn(5, 40, 256, generator=g)
+    (y2 * dy.to(dev)).sum().backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("gAR.")}
+    r1, h1 = O.gru_forward(leaves, x1)
+    x2r = x2.clone().requires_grad_(True)
+    r2, _ = O.gru_forward(leaves, x2r, h0=h1.detach())
+    (r2 * dy).sum().backward()
+    assert (y1.detach().cpu() - r1).abs().max().item() < 1e-4
+    assert (y2.detach().cpu() - r2).abs().max().item() < 1e-4
+    assert _rel(x2d.grad.cpu(), x2r.grad) < 1e-4
+    for n, prm in ar.baseNet.named_parameters():
+        assert _rel(prm.grad.cpu(), leaves["gAR.baseNet." + n].grad) < 1e-4, n
+
+
+def test_reverse_mode_matches_flipped_oracle():
+    """cpc_mode='reverse': CPCAR(reverse=True) and criterion mode='reverse' flip time
+    (cpc/model.py:187-188,202-203; criterion.py:227-229)."""
+    dev = _dev()
+    from cpc_audio_amd.criterion import CPCUnsupersivedCriterion
+    from cpc_audio_amd.model import CPCAR
+    p = O.make_params(seed=3, head_scale=64.0)
+    ar = CPCAR(256, 256, False, 2, mode="GRU", reverse=True).to(dev)
+    ar.load_state_dict({k[len("gAR."):]: v for k, v in p.items() if k.startswith("gAR.")})
+    crit = CPCUnsupersivedCriterion(12, 256, 256, 128, mode="reverse", rnnMode="linear", sizeInputSeq=128).to(dev)
+    crit.load_state_dict({k: v for k, v in p.items() if k.startswith("wPrediction")})
+    g = torch.Generator().manual_seed(1)
+    B, S = 3, 128
+    z = torch.relu(torch.randn(B, S, 256, generator=g))
+    c = ar(z.to(dev))
+    cr, _ = O.gru_forward(p, torch.flip(z, [1]))
+    cr = torch.flip(cr, [1])
+    assert (c.cpu() - cr).abs().max().item() < 1e-4
+    bi, si = O.draw_negative_indices(B, S, S - 12, 128, generator=g)
+    losses, acc = crit(c, z.to(dev), None, negatives=(bi.to(dev), si.to(dev)))
+    ext = O.negative_rows(bi, si, B, S, S - 12, 128)
+    lr, ar_ = O.criterion_forward(p, torch.flip(cr, [1]), torch.flip(z, [1]), ext)
+    assert (losses.cpu() - lr).abs().max().item() < 1e-4
+    assert (acc.cpu() - ar_).abs().max().item() <= 2.0 / (116 * B) + 1e-7
+
+
+@pytest.mark.parametrize("K,N,L", [(5, 256, 10240), (16, 64, 20480), (12, 512, 20480)])
+def test_other_heads_negatives_and_window(K, N, L):
+    """nPredicts != 12, large-negative stress (BASELINE config 5 sweeps N in {128,256,512}) and a
+    shorter window (S = L/160)."""
+    dev = _dev()
+    from cpc_audio_amd.train import build_criterion, build_model, load_flat_params
+    B = 2
+    S = L // 160
+    p = O.make_params(seed=5, head_scale=128.0, n_predicts=K)
+    model = build_model().to(dev)
+    crit = build_criterion(nPredicts=K, negativeSamplingExt=N, sizeWindow=L).to(dev)
+    load_flat_params(model, crit, p)
+    wave = O.make_waveform(B, L, seed=9)
+    g = torch.Generator().manual_seed(4)
+    bi, si = O.draw_negative_indices(B, S, S - K, N, generator=g)
+    c, z, _ = model(wave.to(dev), None)
+    losses, acc = crit(c, z, None, negatives=(bi.to(dev), si.to(dev)))
+    losses.sum().backward()
+    ora = O.train_step(p, wave, bi, si, n_predicts=K, n_neg=N)
+    assert (z.detach().cpu() - ora["z"]).abs().max().item() < 1e-4
+    assert (c.detach().cpu() - ora["c"]).abs().max().item() < 1e-4
+    assert (losses.detach().cpu() - ora["losses"]).abs().max().item() < 1e-4
+    for k_ in range(K):
+        name = f"wPrediction.predictors.{k_}.weight"
+        assert _rel(crit.wPrediction.predictors[k_].weight.grad.cpu(), ora["grads"][name]) < 2e-4, name
+    assert _rel(model.gAR.baseNet.weight_hh_l1.grad.cpu(), ora["grads"]["gAR.baseNet.weight_hh_l1"]) < 2e-4
+
+
+def test_trainer_step_updates_parameters_like_cpu_adam():
+    """forward + sum().backward() + Adam (cpc/train.py:83-91) vs the same step on the CPU oracle."""
+    dev = _dev()
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
+    B = 2
+    p = O.make_params(seed=6, head_scale=64.0)
+    model, crit = build_model().to(dev), build_criterion().to(dev)
+    load_flat_params(model, crit, p)
+    tr = Trainer(model, crit)
+    wave = O.make_waveform(B, 20480, seed=3)
+    g = torch.Generator().manual_seed(8)
+    bi, si = O.draw_negative_indices(B, 128, 116, 128, generator=g)
+    losses, _ = tr.step(wave.to(dev), None, negatives=(bi.to(dev), si.to(dev)))
+    ora = O.train_step(p, wave, bi, si)
+    cpu = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    opt = torch.optim.Adam(list(cpu.values()), lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+    for k, v in cpu.items():
+        v.grad = ora["grads"][k]
+    opt.step()
+    assert (losses.cpu() - ora["losses"]).abs().max().item() < 1e-4
+    new = dict(model.state_dict())
+    new.update(crit.state_dict())
+    worst = max((new[k].cpu() - cpu[k].detach()).abs().max().item() for k in cpu)
+    # Adam's first step moves every weight by ~lr; allow a few sign flips of near-zero gradients
+    assert worst <= 4.1e-4, worst
+    frac_far = max(((new[k].cpu() - cpu[k].detach()).abs() > 1e-6).float().mean().item() for k in cpu)
+    assert frac_far < 1e-3, frac_far
+    assert all(prm.grad is None or float(prm.grad.abs().sum()) == 0.0 for prm in model.parameters())
