@@ -65,12 +65,14 @@ def roofline_probe(B, dev):
     Lin, k, s, p = 4096, 8, 4, 2
     Lout = 1024
     x = torch.randn(B, Lin, 256, device=dev).relu_()
-    wp = torch.randn(256, k * 256, device=dev) / 45.0
+    w = torch.randn(256, 256, k, device=dev) / 45.0
+    wp = torch.empty(256 * k * 256 * 3 // 2, device=dev)
     bias, nw, nb = torch.randn(256, device=dev) * 0.1, torch.ones(256, device=dev), torch.zeros(256, device=dev)
     y = torch.empty(B, Lout, 256, device=dev)
     xh = torch.empty_like(y)
     rs = torch.empty(B * Lout, device=dev)
     st = torch.cuda.current_stream().cuda_stream
+    lib.check(lib.cpc_conv_weight_relayout(P(w), P(wp), k, st))
 
     def f():
         lib.check(lib.cpc_conv_gemm_forward(P(x), P(wp), P(bias), P(nw), P(nb), P(y), P(xh), P(rs), B, Lin, k, s, p, st))

@@ -24,6 +24,7 @@ SIGNATURES = {
     "cpc_conv0_backward_scratch_floats": (_L, [_I, _I]),
     "cpc_conv0_backward": (_I, [_P] * 13 + [_I, _I, _P]),
     "cpc_conv_layer_forward": (_I, [_P] * 9 + [_I] * 5 + [_P]),
+    "cpc_conv_weight_relayout": (_I, [_P, _P, _I, _P]),
     "cpc_conv_gemm_forward": (_I, [_P] * 8 + [_I] * 5 + [_P]),
     "cpc_norm_backward": (_I, [_P] * 9 + [_I, _P]),
     "cpc_conv_layer_dgrad": (_I, [_P] * 3 + [_I] + [_P] * 8 + [_I] * 5 + [_P]),

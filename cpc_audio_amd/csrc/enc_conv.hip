@@ -30,21 +30,32 @@
 namespace cpc {
 
 // ------------------------------------------------------------------ weight re-layouts
-// (O,I,W) -> Wp[co][kk*C + ci]  (K-major rows for the forward NT GEMM)
+// (O,I,W) -> Wp[co][kk*C + ci]  (K-major rows for the forward NT GEMM).
+// split != 0: Wp is written as three bf16 planes [3][total] (the pre-split B operand of NtTileX3).
 __global__ __launch_bounds__(256) void permute_w_fwd_kernel(const float* __restrict__ w,
-                                                            float* __restrict__ wp, int k) {
+                                                            float* __restrict__ wp, int k, int split) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)kC * k * kC;
     if (idx >= total) return;
     const int co = (int)(idx / (k * kC));
     const int rem = (int)(idx - (long)co * k * kC);
     const int kk = rem >> kCLog2, ci = rem & (kC - 1);
-    wp[idx] = w[((long)co * kC + ci) * k + kk];
+    const float v = w[((long)co * kC + ci) * k + kk];
+    if (split) {
+        unsigned h, m, l;
+        split3(v, h, m, l);
+        unsigned short* o = reinterpret_cast<unsigned short*>(wp);
+        o[idx] = (unsigned short)(h >> 16);
+        o[total + idx] = (unsigned short)(m >> 16);
+        o[2 * total + idx] = (unsigned short)(l >> 16);
+    } else {
+        wp[idx] = v;
+    }
 }
 
 // (O,I,W) -> Wd[r][ci][j*C + co] = W[co][ci][r + (1-j)*s],  r < s, j in {0,1}
 __global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __restrict__ w,
-                                                              float* __restrict__ wd, int s) {
+                                                              float* __restrict__ wd, int s, int split) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)s * kC * 2 * kC;
     if (idx >= total) return;
@@ -54,14 +65,30 @@ __global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __res
     const int ci = rem / (2 * kC);
     const int jc = rem - ci * 2 * kC;
     const int j = jc >> kCLog2, co = jc & (kC - 1);
-    wd[idx] = w[((long)co * kC + ci) * k + r + (1 - j) * s];
+    const float v = w[((long)co * kC + ci) * k + r + (1 - j) * s];
+    if (split) {
+        unsigned h, m, l;
+        split3(v, h, m, l);
+        unsigned short* o = reinterpret_cast<unsigned short*>(wd);
+        o[idx] = (unsigned short)(h >> 16);
+        o[total + idx] = (unsigned short)(m >> 16);
+        o[2 * total + idx] = (unsigned short)(l >> 16);
+    } else {
+        wd[idx] = v;
+    }
 }
 
 // ------------------------------------------------------------------ forward
 template <int BM, bool X3>
 struct ConvCfg {
     static constexpr int WAVES_M = BM >= 128 ? 2 : 1;
-    using Tile = typename std::conditional<X3, NtTileX3<BM, kC, WAVES_M, 4>, NtTile<BM, kC, WAVES_M, 4>>::type;
+    // 128-row tiles: two LDS stages of 16 k with the skewed (store-first / MFMA-first) wave schedule
+    // (pre-split weight planes, BSPLIT = true, measured slower: 162 vs 176 TF on layer 1 -- three 8-byte loads per
+    //  slot instead of one 16-byte load cost more than the VALU they save)
+    static constexpr bool kPreSplitW = false;
+    using X3Tile = typename std::conditional<BM == 128, NtTileX3<BM, kC, WAVES_M, 4, 16, 2, true, kPreSplitW>,
+                                             NtTileX3<BM, kC, WAVES_M, 4, 32, 1, false, kPreSplitW>>::type;
+    using Tile = typename std::conditional<X3, X3Tile, NtTile<BM, kC, WAVES_M, 4>>::type;
 };
 
 template <int BM, bool X3>
@@ -76,7 +103,8 @@ __global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 
     const int m0 = blockIdx.x * BM;
     f32x16 acc[TM][TN];
     zero_acc(acc);
-    Tile::run(acc, am, m0, wp, K, 0, K, smem);
+    if constexpr (X3) Tile::run(acc, am, m0, wp, K, 0, K, smem, (long)kC * K);   // plane stride used only if pre-split
+    else Tile::run(acc, am, m0, wp, K, 0, K, smem);
 
     const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 3;
     int col[TN];
@@ -230,7 +258,11 @@ __global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 
     const int ph = blockIdx.y;
     f32x16 acc[TM][TN];
     zero_acc(acc);
-    Tile::run(acc, am, m0, wd + (long)ph * kC * 2 * kC, 2 * kC, 0, 2 * kC, smem);
+    if constexpr (X3 && ConvCfg<BM, X3>::kPreSplitW)   // wd = 3 bf16 planes of [s][256][512]
+        Tile::run(acc, am, m0, reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(wd) + (long)ph * kC * 2 * kC),
+                  2 * kC, 0, 2 * kC, smem, (long)s * kC * 2 * kC);
+    else
+        Tile::run(acc, am, m0, wd + (long)ph * kC * 2 * kC, 2 * kC, 0, 2 * kC, smem);
 
     const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 3;
     int col[TN];
@@ -446,12 +478,13 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
 
     o = 0;
     e.wp[0] = -1;
-    for (int i = 1; i < 5; ++i) { e.wp[i] = o; o += (long)kC * kGeom[i].k * kC; }
+    // 1.5x: in split-bf16 mode the re-laid-out weight is three bf16 planes (6 bytes per weight)
+    for (int i = 1; i < 5; ++i) { e.wp[i] = o; o += align64((long)kC * kGeom[i].k * kC * 3 / 2); }
     e.fwd_total = o;
 
     o = 0;
     e.wd[0] = -1;
-    for (int i = 1; i < 5; ++i) { e.wd[i] = o; o += (long)kC * kGeom[i].k * kC; }
+    for (int i = 1; i < 5; ++i) { e.wd[i] = o; o += align64((long)kC * kGeom[i].k * kC * 3 / 2); }
     e.dx[0] = -1;
     for (int i = 1; i < 5; ++i) { e.dx[i] = o; o += align64((long)B * e.L[i] * kC); }
     e.dy0 = o; o += align64((long)B * e.L[0] * kC);
@@ -517,7 +550,18 @@ extern "C" int cpc_set_conv_tile(int bm) {
     return 0;
 }
 
-// The forward GEMM kernel alone, on an already permuted weight wp[co][kk*C+ci] (exactly one
+// Weight re-layout for the forward GEMM: PyTorch (O,I,W) -> K-major rows wp[co][kk*C+ci]; in the default
+// split-bf16 mode wp holds three bf16 planes.  wp must have room for 256*k*256*3/2 floats.
+extern "C" int cpc_conv_weight_relayout(const float* w, float* wp, int k, void* stream) {
+    CPC_RETURN_IF(!w || !wp || k <= 0, CPC_ERR_ARG);
+    const long nw_elems = (long)kC * k * kC;
+    hipLaunchKernelGGL(permute_w_fwd_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, k,
+                       (g_mfma_mode == 1 && ConvCfg<128, true>::kPreSplitW) ? 1 : 0);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// The forward GEMM kernel alone, on a weight prepared by cpc_conv_weight_relayout (exactly one
 // kernel launch: this is what bench.py times for the roofline figure).
 extern "C" int cpc_conv_gemm_forward(const float* x, const float* wp, const float* bias, const float* nw,
                                      const float* nb, float* y, float* xhat, float* rstd, int B, int Lin,
@@ -543,8 +587,8 @@ extern "C" int cpc_conv_layer_forward(const float* x, const float* w, const floa
                                       float* xhat, float* rstd, int B, int Lin, int k, int s, int p,
                                       void* stream) {
     CPC_RETURN_IF(B <= 0 || Lin <= 0 || k != 2 * s || Lin + 2 * p < k, CPC_ERR_SHAPE);
-    const long nw_elems = (long)kC * k * kC;
-    hipLaunchKernelGGL(permute_w_fwd_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, k);
+    int rc = cpc_conv_weight_relayout(w, wp, k, stream);
+    if (rc) return rc;
     return cpc_conv_gemm_forward(x, wp, bias, nw, nb, y, xhat, rstd, B, Lin, k, s, p, stream);
 }
 
@@ -575,7 +619,8 @@ extern "C" int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, 
     hipStream_t st = (hipStream_t)stream;
     const int Lout = conv_out_len(Lin, k, s, p);
     const long nw_elems = (long)kC * k * kC;
-    hipLaunchKernelGGL(permute_w_dgrad_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wd, s);
+    hipLaunchKernelGGL(permute_w_dgrad_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wd, s,
+                       (g_mfma_mode == 1 && ConvCfg<128, true>::kPreSplitW) ? 1 : 0);
     // 2-row windows [q-1, q] over dx, q in [0, Lout]
     RowMap am;
     am.base = dx; am.R = Lout + 1; am.bstride = (long)Lout * kC; am.rstride = kC; am.off = -kC;

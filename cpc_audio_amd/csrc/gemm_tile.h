@@ -14,6 +14,8 @@
 // so a K-contiguous ("K-major") LDS row is read with ONE ds_read_b128 per 4 MFMA
 // steps, and both operands use the same pairing (the sum over k is order-free).
 #pragma once
+#include <type_traits>
+
 #include "cpc_common.h"
 
 namespace cpc {
@@ -97,10 +99,16 @@ __device__ __forceinline__ RowRef cursor_ref(const RowMap& rm, const RowCursor& 
     return r;
 }
 
-__device__ __forceinline__ float4 load_row4(const RowRef& r, int k, int Lin) {
-    int tau = r.tau0 + (k >> kCLog2);
-    if ((unsigned)tau < (unsigned)Lin) return *reinterpret_cast<const float4*>(r.ptr + k);
-    return make_float4(0.f, 0.f, 0.f, 0.f);
+// Branch-free: an out-of-range element reads a safe address and is zeroed afterwards, so the loads of a
+// tile are straight-line code and the compiler can keep several chunks in flight behind counted
+// s_waitcnt vmcnt(N) (a branch around a load makes it drain with vmcnt(0)).
+__device__ __forceinline__ float4 load_row4(const RowRef& r, int k, int Lin, const float* safe) {
+    const int tau = r.tau0 + (k >> kCLog2);
+    const bool ok = (unsigned)tau < (unsigned)Lin;
+    const float* p = ok ? r.ptr + k : safe;
+    float4 v = *reinterpret_cast<const float4*>(p);
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
 }
 
 __device__ __forceinline__ float f4c(const float4& v, int j) {
@@ -171,7 +179,7 @@ struct NtTile {
 auto gload = [&](int kc_) __attribute__((always_inline)) {
             const int k0 = kc_ * BK;
 #pragma unroll
-            for (int i = 0; i < A_PER; ++i) ra[i] = load_row4(ar[i], k0 + a_k[i], am.Lin);
+            for (int i = 0; i < A_PER; ++i) ra[i] = load_row4(ar[i], k0 + a_k[i], am.Lin, am.base);
 #pragma unroll
             for (int i = 0; i < B_PER; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
         };
@@ -271,6 +279,19 @@ __device__ __forceinline__ void split3_pack4(const float4& v, uint2& ph, uint2& 
 // k-step are issued product-major so that consecutive MFMAs hit different accumulators.
 // SWZ: rows were written with their 16-byte k-pairs XOR-swizzled by ((row >> 3) & (BK/8 - 1)) (the
 // transposing TN loader does that to keep its 8-byte column stores bank-conflict free).
+struct BSplitReg { uint2 h, m, l; };      // a 4-k group of a pre-split operand: three planes x four bf16
+
+__device__ __forceinline__ void load_b(float4& dst, const float* p32, const unsigned short*, int k0, long) {
+    dst = *reinterpret_cast<const float4*>(p32 + k0);
+}
+__device__ __forceinline__ void load_b(BSplitReg& dst, const float*, const unsigned short* p16, int k0, long plane) {
+    dst.h = *reinterpret_cast<const uint2*>(p16 + k0);
+    dst.m = *reinterpret_cast<const uint2*>(p16 + plane + k0);
+    dst.l = *reinterpret_cast<const uint2*>(p16 + 2 * plane + k0);
+}
+__device__ __forceinline__ void planes_of(const float4& v, uint2& ph, uint2& pm, uint2& pl) { split3_pack4(v, ph, pm, pl); }
+__device__ __forceinline__ void planes_of(const BSplitReg& v, uint2& ph, uint2& pm, uint2& pl) { ph = v.h; pm = v.m; pl = v.l; }
+
 template <int TM, int TN, int BK, int LDH, bool SWZ = false>
 __device__ __forceinline__ void x3_compute(f32x16 (&acc)[TM][TN], const unsigned short* As, int planeA,
                                            const unsigned short* Bs, int planeB, int arow, int brow, int kofs) {
@@ -308,7 +329,9 @@ __device__ __forceinline__ void x3_compute(f32x16 (&acc)[TM][TN], const unsigned
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1>
+// BSPLIT: the B operand (weights) is already stored as three bf16 planes [3][N][ldb] (written once per
+// step by the weight re-layout kernels), so only the A operand is split while staging.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1, bool SKEW = false, bool BSPLIT = false>
 struct NtTileX3 {
     static constexpr int BK = BK_;       // 32 with one LDS stage (default), or 16 double-buffered
     static constexpr int LDH = BK + 8;   // halves per LDS row (80 B / 48 B: 16-byte aligned, conflict-free b128)
@@ -336,7 +359,7 @@ struct NtTileX3 {
 
     __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int m0,
                                const float* __restrict__ Bmat, int ldb, int n0, int K,
-                               float* smem_f) {
+                               float* smem_f, long bplane = 0) {
         unsigned short* smem0 = reinterpret_cast<unsigned short*>(smem_f);
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -354,6 +377,7 @@ struct NtTileX3 {
             a_lds[i] = r * LDH + kv * 4;
         }
         const float* bp[B_PER];
+        const unsigned short* bp16[B_PER];
         int b_lds[B_PER];
         bool b_on[B_PER];
 #pragma unroll
@@ -362,19 +386,22 @@ struct NtTileX3 {
             b_on[i] = slot < B_SLOTS;
             const int r = b_on[i] ? (slot / SPR) : 0, kv = slot % SPR;
             bp[i] = Bmat + (long)(n0 + r) * ldb + kv * 4;
+            bp16[i] = reinterpret_cast<const unsigned short*>(Bmat) + (long)(n0 + r) * ldb + kv * 4;
             b_lds[i] = 3 * PLANE_A + r * LDH + kv * 4;
         }
-        float4 ra[A_PER], rb[B_PER];
+        using BReg = typename std::conditional<BSPLIT, BSplitReg, float4>::type;
+        float4 ra[A_PER], ra1[A_PER];
+        BReg rb[B_PER], rb1[B_PER];                // second register set for the deep-prefetch schedule
         const int nk = K / BK;
 
-        auto gload = [&](int kc_) __attribute__((always_inline)) {
+        auto gload_to = [&](int kc_, float4 (&ra_)[A_PER], BReg (&rb_)[B_PER]) __attribute__((always_inline)) {
             const int k0 = kc_ * BK;
 #pragma unroll
-            for (int i = 0; i < A_PER; ++i) ra[i] = load_row4(ar[i], k0 + a_k[i], am.Lin);
+            for (int i = 0; i < A_PER; ++i) ra_[i] = load_row4(ar[i], k0 + a_k[i], am.Lin, am.base);
 #pragma unroll
-            for (int i = 0; i < B_PER; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+            for (int i = 0; i < B_PER; ++i) load_b(rb_[i], bp[i], bp16[i], k0, bplane);
         };
-        auto sstore = [&](int st_) __attribute__((always_inline)) {
+        auto sstore_from = [&](int st_, const float4 (&ra)[A_PER], const BReg (&rb)[B_PER]) __attribute__((always_inline)) {
             unsigned short* smem = smem0 + st_ * STAGE_H;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
@@ -389,7 +416,7 @@ struct NtTileX3 {
             for (int i = 0; i < B_PER; ++i)
                 if (b_on[i]) {
                     uint2 ph, pm, pl;
-                    split3_pack4(rb[i], ph, pm, pl);
+                    planes_of(rb[i], ph, pm, pl);
                     *reinterpret_cast<uint2*>(smem + b_lds[i]) = ph;
                     *reinterpret_cast<uint2*>(smem + PLANE_B + b_lds[i]) = pm;
                     *reinterpret_cast<uint2*>(smem + 2 * PLANE_B + b_lds[i]) = pl;
@@ -403,6 +430,47 @@ struct NtTileX3 {
             x3_compute<TM, TN, BK, LDH>(acc, smem, PLANE_A, smem + 3 * PLANE_A, PLANE_B, arow, brow, kofs);
         };
 
+        auto gload = [&](int kc_) __attribute__((always_inline)) { gload_to(kc_, ra, rb); };
+        auto sstore = [&](int st_) __attribute__((always_inline)) { sstore_from(st_, ra, rb); };
+        if (STAGES == 2 && SKEW) {
+            // Deep prefetch: the per-CU global-load rate is (bytes in flight) / latency (~2 us under load),
+            // so FOUR 16-k chunks are kept in flight in four register sets (96 KB per CU at 128 x 256)
+            // instead of one 32-k chunk (48 KB).  Two LDS stages; one barrier per chunk:
+            //   compute(stage kc&1) | split+store chunk kc+1 -> other stage | load chunk kc+4 | barrier
+            float4 ra2[A_PER], ra3[A_PER];
+            BReg rb2[B_PER], rb3[B_PER];
+            gload_to(0, ra, rb);
+            gload_to(min(1, nk - 1), ra1, rb1);
+            gload_to(min(2, nk - 1), ra2, rb2);
+            gload_to(min(3, nk - 1), ra3, rb3);
+            sstore_from(0, ra, rb);
+            __syncthreads();
+            int kc = 0;
+            for (;;) {
+                // kc % 4 == 0: store set 1, reload set 0
+                compute(0);
+                sstore_from(1, ra1, rb1);
+                gload_to(min(kc + 4, nk - 1), ra, rb);
+                __syncthreads();
+                if (++kc >= nk) break;
+                compute(1);
+                sstore_from(0, ra2, rb2);
+                gload_to(min(kc + 4, nk - 1), ra1, rb1);
+                __syncthreads();
+                if (++kc >= nk) break;
+                compute(0);
+                sstore_from(1, ra3, rb3);
+                gload_to(min(kc + 4, nk - 1), ra2, rb2);
+                __syncthreads();
+                if (++kc >= nk) break;
+                compute(1);
+                sstore_from(0, ra, rb);
+                gload_to(min(kc + 4, nk - 1), ra3, rb3);
+                __syncthreads();
+                if (++kc >= nk) break;
+            }
+            return;
+        }
         gload(0);
         sstore(0);
         __syncthreads();
@@ -491,13 +559,13 @@ RowCursor ca[A_PER], cb[B_PER];
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
                 const RowRef r = cursor_ref(am, ca[i], a_on[i] && (mm + a_row[i]) < mend);
-                ra[i] = load_row4(r, c0 + a_col[i], am.Lin);
+                ra[i] = load_row4(r, c0 + a_col[i], am.Lin, am.base);
                 ca[i] = cursor_plus(am, ca[i], BK);
             }
 #pragma unroll
             for (int i = 0; i < B_PER; ++i) {
                 const RowRef r = cursor_ref(bm, cb[i], b_on[i] && (mm + b_row[i]) < mend);
-                rb[i] = load_row4(r, n0 + b_col[i], bm.Lin);
+                rb[i] = load_row4(r, n0 + b_col[i], bm.Lin, bm.base);
                 cb[i] = cursor_plus(bm, cb[i], BK);
             }
         };
@@ -651,7 +719,7 @@ struct TnTileX3 {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const RowRef rr = cursor_ref(am, cursor_plus(am, ca[i], r), a_on[i] && (mm + a_m[i] + r) < mend);
-                    ra[i][r] = load_row4(rr, c0 + a_c[i], am.Lin);
+                    ra[i][r] = load_row4(rr, c0 + a_c[i], am.Lin, am.base);
                 }
                 ca[i] = cursor_plus(am, ca[i], BK);
             }
@@ -660,7 +728,7 @@ struct TnTileX3 {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const RowRef rr = cursor_ref(bm, cursor_plus(bm, cb[i], r), b_on[i] && (mm + b_m[i] + r) < mend);
-                    rb[i][r] = load_row4(rr, n0 + b_c[i], bm.Lin);
+                    rb[i][r] = load_row4(rr, n0 + b_c[i], bm.Lin, bm.base);
                 }
                 cb[i] = cursor_plus(bm, cb[i], BK);
             }

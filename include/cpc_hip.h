@@ -53,11 +53,14 @@ int cpc_conv0_backward(const float* wave, const float* w, const float* bias, con
 
 /* Layers 1..4 (256->256, k = 2s; model.py:85-92,101-104): x (B,Lin,256) ->
  * y = relu(norm(conv)) and xhat (pre-affine normalised), both (B,Lout,256); rstd (B*Lout).
- * w is PyTorch (O,I,W); wp is 256*k*256 floats of scratch. */
+ * w is PyTorch (O,I,W); wp is 256*k*256*3/2 floats of scratch (re-laid-out weight, see below). */
 int cpc_conv_layer_forward(const float* x, const float* w, const float* bias, const float* nw,
                            const float* nb, float* wp, float* y, float* xhat, float* rstd, int B,
                            int Lin, int k, int s, int p, void* stream);
-/* The forward GEMM kernel alone on an already permuted weight wp[co][kk*256+ci] (one launch). */
+/* Weight re-layout (O,I,W) -> K-major rows wp[co][kk*256+ci]; three bf16 planes in the default
+ * split-bf16 mode.  wp: 256*k*256*3/2 floats. */
+int cpc_conv_weight_relayout(const float* w, float* wp, int k, void* stream);
+/* The forward GEMM kernel alone on a weight prepared by cpc_conv_weight_relayout (one launch). */
 int cpc_conv_gemm_forward(const float* x, const float* wp, const float* bias, const float* nw,
                           const float* nb, float* y, float* xhat, float* rstd, int B, int Lin, int k,
                           int s, int p, void* stream);
@@ -65,6 +68,7 @@ int cpc_conv_gemm_forward(const float* x, const float* wp, const float* bias, co
 int cpc_norm_backward(const float* dy, const float* xhat, const float* y, const float* rstd,
                       const float* nw, float* dx, float* colpart, float* tmp, float* small3, int M,
                       void* stream);
+/* wd: 256*k*256*3/2 floats of scratch (per-phase re-laid-out weight). */
 int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, int fuse,
                          const float* xhat_prev, const float* y_prev, const float* rstd_prev,
                          const float* nw_prev, float* dprev, float* colpart, float* tmp,

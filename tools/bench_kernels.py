@@ -80,7 +80,7 @@ def main():
             yo = z if i == 4 else saved[sizes[8 + i]: sizes[8 + i] + B * Ls[i] * 256]
             xh = saved[sizes[11 + i]: sizes[11 + i] + B * Ls[i] * 256]
             rs = saved[sizes[16 + i]: sizes[16 + i] + B * Ls[i]]
-            wp = fscr[:256 * k * 256]
+            wp = torch.empty(256 * k * 256 * 3 // 2, device=dev)
 
             def cf():
                 lib.check(lib.cpc_conv_layer_forward(P(xin), P(plist[4 * i]), P(plist[4 * i + 1]), P(plist[4 * i + 2]),

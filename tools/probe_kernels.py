@@ -6,10 +6,11 @@ from cpc_audio_amd import _lib
 from cpc_audio_amd._lib import ptr as P
 lib = _lib.get(); dev = torch.device("cuda:0")
 B, Lin, k, s, p = 64, 4096, 8, 4, 2
-x = torch.randn(B, Lin, 256, device=dev).relu_(); wp = torch.randn(256, k * 256, device=dev) / 45
+x = torch.randn(B, Lin, 256, device=dev).relu_(); w = torch.randn(256, 256, k, device=dev) / 45; wp = torch.empty(256 * k * 256 * 3 // 2, device=dev)
 bias = torch.randn(256, device=dev) * 0.1; nw = torch.ones(256, device=dev); nb = torch.zeros(256, device=dev)
 y = torch.empty(B, 1024, 256, device=dev); xh = torch.empty_like(y); rs = torch.empty(B * 1024, device=dev)
 st = torch.cuda.current_stream().cuda_stream
+lib.check(lib.cpc_conv_weight_relayout(P(w), P(wp), k, st))
 L = 20480
 wave = torch.randn(B, L, device=dev) * 0.1; w0 = torch.randn(256, 10, device=dev) * 0.3
 y0 = torch.empty(B, 4096, 256, device=dev); m0 = torch.empty(B * 4096, device=dev); r0 = torch.empty(B * 4096, device=dev)
