@@ -14,8 +14,8 @@
 //     pulls its h / W_hh slices straight into MFMA fragments (float4 per lane, 4 k-steps
 //     per load), the partial 16x16 tiles meet in LDS and the gate non-linearities are
 //     applied by one thread per (b, j).  Step-to-step ordering is the stream order of
-//     the launches (a dependent kernel boundary costs ~1.5 us on this chip, less than a
-//     software grid barrier);
+//     the launches (a dependent kernel boundary costs less than a software grid barrier on this
+//     chip; hipGraph replay of the chain measured identical to eager launches, 0.83 ms per 129);
 //   * backward (BPTT) mirrors it with K = 768:  dh_t = dY_t + dh_{t+1} * z_{t+1}
 //     + dGh_{t+1} . W_hh,  then the gate derivatives; all weight gradients are batched
 //     TN GEMMs over the B*S rows afterwards.
