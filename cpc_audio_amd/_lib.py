@@ -40,6 +40,7 @@ SIGNATURES = {
     "cpc_gru_forward": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "cpc_gru_backward": (_I, [_P] * 9 + [_I, _I, _I, _P]),
     "cpc_nce_layout": (_I, [_I, _I, _I, _I, _P]),
+    "cpc_nce_prepare": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
     "cpc_nce_forward": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward": (_I, [_P] * 12 + [_I, _I, _I, _I, _P]),
 }

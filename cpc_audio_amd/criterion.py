@@ -8,7 +8,7 @@ fused InfoNCE kernels of libcpc_hip.so; negatives are never materialised.
 import torch
 import torch.nn as nn
 
-from .ops import InfoNCEFunction
+from .ops import InfoNCEFunction, prepare_negatives
 
 
 class PredictionNetwork(nn.Module):
@@ -99,8 +99,9 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         return batchIdx, seqIdx
 
     def negativeRows(self, batchIdx, seqIdx, batchSize, seqSize, windowSize):
-        """criterion.py:191-199: row = ((seqIdx + t) mod S) + batchIdx*S, returned as the
-        (B, W, N) int32 layout the score kernel reads."""
+        """criterion.py:191-199: row = ((seqIdx + t) mod S) + batchIdx*S, returned as the (B, W, N) int32
+        layout the score kernel reads.  Torch reference of what cpc_nce_prepare computes on the device
+        (used by tests; forward() calls the kernel)."""
         N = self.negativeSamplingExt
         t = torch.arange(windowSize, device=seqIdx.device).view(1, 1, windowSize)
         s = torch.remainder(seqIdx.view(batchSize, N, windowSize) + t, seqSize)
@@ -117,6 +118,8 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         windowSize = seqSize - self.nPredicts
         if negatives is None:
             negatives = self.drawNegatives(batchSize, seqSize, windowSize, cFeature.device)
-        ext = self.negativeRows(negatives[0], negatives[1], batchSize, seqSize, windowSize)
-        losses, acc = InfoNCEFunction.apply(cFeature, encodedData, self.wPrediction.stacked_weight(), ext)
+        ext, perm, row_ptr = prepare_negatives(negatives[0], negatives[1], batchSize, seqSize, self.nPredicts,
+                                               self.negativeSamplingExt)
+        losses, acc = InfoNCEFunction.apply(cFeature, encodedData, self.wPrediction.stacked_weight(), ext, perm,
+                                            row_ptr)
         return losses.view(1, -1), acc.view(1, -1)

@@ -260,29 +260,47 @@ __global__ __launch_bounds__(256) void nce_bwd_dz_rows_kernel(
 }
 
 // dz[j] = sum of V rows whose destination is j:  slots perm[row_ptr[j] .. row_ptr[j+1]).
-// One wavefront per destination row, 4 channels per lane, 4 independent row loads in flight.
-__global__ __launch_bounds__(256) void nce_gather_rows_kernel(const float* __restrict__ V,
-                                                              const int* __restrict__ perm,
-                                                              const int* __restrict__ row_ptr,
-                                                              float* __restrict__ dz, int nrows) {
-    const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= nrows) return;
-    const int beg = row_ptr[j], end = row_ptr[j + 1];
+// One wavefront (= one 64-thread workgroup) per destination row, 4 channels per lane.  The slot list of
+// a row arrives in arbitrary order (nce_fill_kernel places slots with an integer atomic cursor); it is
+// rank-sorted in LDS first, so the floating-point summation order is the ascending slot order whatever
+// the fill order was: results are bit-reproducible and equal to a stable sort by destination.
+constexpr int GATHER_MAX_SORT = 1024;
+__global__ __launch_bounds__(64) void nce_gather_rows_kernel(const float* __restrict__ V,
+                                                             const int* __restrict__ perm,
+                                                             const int* __restrict__ row_ptr,
+                                                             float* __restrict__ dz, int nrows) {
+    __shared__ int raw[GATHER_MAX_SORT];
+    __shared__ int sorted[GATHER_MAX_SORT];
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x;
+    const int beg = row_ptr[j], len = row_ptr[j + 1] - beg;
+    const bool do_sort = len <= GATHER_MAX_SORT;
+    if (do_sort) {
+        for (int i = lane; i < len; i += 64) raw[i] = perm[beg + i];
+        __syncthreads();
+        for (int i = lane; i < len; i += 64) {
+            const int e = raw[i];
+            int rank = 0;
+            for (int q = 0; q < len; ++q) rank += raw[q] < e ? 1 : 0;      // slots are unique
+            sorted[rank] = e;
+        }
+        __syncthreads();
+    }
+    const int* list = do_sort ? sorted : perm + beg;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-    int p = beg;
-    for (; p + 4 <= end; p += 4) {
-        const float4 v0 = ld4(V + (long)perm[p] * kC + 4 * lane);
-        const float4 v1 = ld4(V + (long)perm[p + 1] * kC + 4 * lane);
-        const float4 v2 = ld4(V + (long)perm[p + 2] * kC + 4 * lane);
-        const float4 v3 = ld4(V + (long)perm[p + 3] * kC + 4 * lane);
+    int p = 0;
+    for (; p + 4 <= len; p += 4) {
+        const float4 v0 = ld4(V + (long)list[p] * kC + 4 * lane);
+        const float4 v1 = ld4(V + (long)list[p + 1] * kC + 4 * lane);
+        const float4 v2 = ld4(V + (long)list[p + 2] * kC + 4 * lane);
+        const float4 v3 = ld4(V + (long)list[p + 3] * kC + 4 * lane);
         a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
         a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
         a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
         a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
     }
-    for (; p < end; ++p) {
-        const float4 v0 = ld4(V + (long)perm[p] * kC + 4 * lane);
+    for (; p < len; ++p) {
+        const float4 v0 = ld4(V + (long)list[p] * kC + 4 * lane);
         a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
     }
     float4 o;
@@ -291,6 +309,66 @@ __global__ __launch_bounds__(256) void nce_gather_rows_kernel(const float* __res
     o.z = (a0.z + a1.z) + (a2.z + a3.z);
     o.w = (a0.w + a1.w) + (a2.w + a3.w);
     *reinterpret_cast<float4*>(dz + (long)j * kC + 4 * lane) = o;
+}
+
+// ------------------------------------------------------------------ negative-index preparation
+// Turns the two draws of sampleClean (criterion.py:181-189; int64, flat (b,n,t) order) into what the
+// kernels consume: ext[(b*W+t)*N + n] = ((seqIdx + t) mod S) + batchIdx*S (criterion.py:191-199), and the
+// destination-sorted candidate slot list (perm, row_ptr) used by the backward gather.
+__global__ __launch_bounds__(256) void nce_index_kernel(const long* __restrict__ batchIdx,
+                                                        const long* __restrict__ seqIdx,
+                                                        int* __restrict__ ext, int* __restrict__ dest,
+                                                        int* __restrict__ count, int B, int S, int W, int K,
+                                                        int N) {
+    const long slot = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * W * (N + K);
+    if (slot >= total) return;
+    const int bt = (int)(slot / (N + K)), j = (int)(slot - (long)bt * (N + K));
+    const int b = bt / W, t = bt - b * W;
+    int d;
+    if (j < N) {
+        const long flat = ((long)b * N + j) * W + t;
+        d = (int)((seqIdx[flat] + t) % S) + (int)batchIdx[flat] * S;
+        ext[(long)bt * N + j] = d;
+    } else {
+        d = b * S + t + (j - N) + 1;                    // positive of head j-N (criterion.py:210-215)
+    }
+    dest[slot] = d;
+    atomicAdd(&count[d], 1);
+}
+
+// exclusive scan of count[0..n) -> row_ptr[0..n], cursor[0..n) = row_ptr[0..n)   (single workgroup)
+__global__ __launch_bounds__(1024) void nce_scan_kernel(const int* __restrict__ count, int* __restrict__ row_ptr,
+                                                        int* __restrict__ cursor, int n) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = tid * per, hi = min(n, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += count[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan of the partials
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;                            // exclusive prefix of this thread's chunk
+    for (int i = lo; i < hi; ++i) {
+        row_ptr[i] = run;
+        cursor[i] = run;
+        run += count[i];
+    }
+    if (tid == 1023) row_ptr[n] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void nce_fill_kernel(const int* __restrict__ dest, int* __restrict__ cursor,
+                                                       int* __restrict__ perm, long total) {
+    const long slot = (long)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= total) return;
+    const int pos = atomicAdd(&cursor[dest[slot]], 1);
+    perm[pos] = (int)slot;
 }
 
 // ------------------------------------------------------------------ host side
@@ -344,6 +422,28 @@ extern "C" int cpc_nce_layout(int B, int S, int K, int N, long* sizes) {
     return 0;
 }
 
+// batchIdx, seqIdx: the two int64 draws of sampleClean, B*N*W each, flat in (b,n,t) order.
+// Outputs: ext (B*W*N int32), perm (B*W*(N+K) int32), row_ptr (B*S+1 int32); work: B*W*(N+K) + 2*B*S + 2 ints.
+extern "C" int cpc_nce_prepare(const long* batchIdx, const long* seqIdx, int* ext, int* perm, int* row_ptr,
+                               int* work, int B, int S, int K, int N, void* stream) {
+    NceLayout n;
+    CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!batchIdx || !seqIdx || !ext || !perm || !row_ptr || !work, CPC_ERR_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)n.BW * (N + K);
+    const int rows = B * S;
+    int* dest = work;
+    int* count = work + total;
+    int* cursor = count + rows + 1;
+    (void)hipMemsetAsync(count, 0, sizeof(int) * (rows + 1), st);
+    hipLaunchKernelGGL(nce_index_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, batchIdx, seqIdx, ext, dest, count, B,
+                       S, n.W, K, N);
+    hipLaunchKernelGGL(nce_scan_kernel, dim3(1), dim3(1024), 0, st, count, row_ptr, cursor, rows);
+    hipLaunchKernelGGL(nce_fill_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dest, cursor, perm, total);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
 // c (B,S,256) context, z (B,S,256) encoder output, wall (K*256, 256) = the K head weights stacked,
 // ext (B*W, N) int32 rows into z.view(B*S,256) [i.e. criterion.py:199's extIdx laid out (b,t,n)].
 // losses, acc: K floats each (criterion.py:256-257).
@@ -390,8 +490,7 @@ extern "C" int cpc_nce_backward(const float* c, const float* z, const float* wal
                        n.W, S, K, N);
     hipLaunchKernelGGL(nce_bwd_dz_rows_kernel, grid, dim3(256), 0, st, pred, logits, lse, gscale, scratch + n.V,
                        n.BW, K, N);
-    hipLaunchKernelGGL(nce_gather_rows_kernel, dim3(cdiv(B * S, 4)), dim3(256), 0, st, scratch + n.V, perm, row_ptr,
-                       dz, B * S);
+    hipLaunchKernelGGL(nce_gather_rows_kernel, dim3(B * S), dim3(64), 0, st, scratch + n.V, perm, row_ptr, dz, B * S);
     CPC_LAUNCH_CHECK();
     // dc[:, :W] = dPred . Wall  (NT against Wall^T [256][K*256])
     int rc = transpose(wall, wallT, K * kC, kC, st);

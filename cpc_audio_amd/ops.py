@@ -149,11 +149,29 @@ def candidate_destinations(ext, B, S, K):
     return perm.to(torch.int32), row_ptr.to(torch.int32)
 
 
+def prepare_negatives(batchIdx, seqIdx, B, S, K, N):
+    """(ext (B,W,N), perm, row_ptr) int32 from the two int64 draws of sampleClean -- cpc_nce_prepare."""
+    lib = _lib.get()
+    W = S - K
+    dev = batchIdx.device
+    batchIdx, seqIdx = batchIdx.contiguous(), seqIdx.contiguous()
+    if batchIdx.dtype != torch.int64 or seqIdx.dtype != torch.int64 or batchIdx.numel() != B * N * W:
+        raise ValueError("prepare_negatives: expected two int64 tensors of B*N*W draws")
+    with torch.cuda.device(dev):
+        ext = torch.empty(B, W, N, device=dev, dtype=torch.int32)
+        perm = torch.empty(B * W * (N + K), device=dev, dtype=torch.int32)
+        row_ptr = torch.empty(B * S + 1, device=dev, dtype=torch.int32)
+        work = torch.empty(B * W * (N + K) + 2 * B * S + 2, device=dev, dtype=torch.int32)
+        lib.check(lib.cpc_nce_prepare(_p(batchIdx), _p(seqIdx), _p(ext), _p(perm), _p(row_ptr), _p(work), B, S, K, N,
+                                      _stream()), "nce_prepare")
+    return ext, perm, row_ptr
+
+
 class InfoNCEFunction(torch.autograd.Function):
-    """c, z (B,S,256), wall (K*256,256), ext (B,W,N) int32 -> losses (K), acc (K)."""
+    """c, z (B,S,256), wall (K*256,256), ext (B,W,N) int32, perm, row_ptr -> losses (K), acc (K)."""
 
     @staticmethod
-    def forward(ctx, c, z, wall, ext):
+    def forward(ctx, c, z, wall, ext, perm, row_ptr):
         _require_cuda(c, "InfoNCEFunction")
         lib = _lib.get()
         B, S, H = c.shape
@@ -170,7 +188,6 @@ class InfoNCEFunction(torch.autograd.Function):
             acc = torch.empty(K, device=c.device, dtype=torch.float32)
             lib.check(lib.cpc_nce_forward(_p(c), _p(z), _p(wall), _p(ext), _p(saved), _p(scratch), _p(losses),
                                           _p(acc), B, S, K, N, _stream()), "nce_forward")
-            perm, row_ptr = candidate_destinations(ext, B, S, K)
         ctx.save_for_backward(c, z, wall, ext, saved, perm, row_ptr)
         ctx.dims = (B, S, K, N, sizes[2])
         ctx.mark_non_differentiable(acc)
@@ -188,4 +205,4 @@ class InfoNCEFunction(torch.autograd.Function):
             lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
                                            _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
                                            _stream()), "nce_backward")
-        return dc, dz, dwall, None
+        return dc, dz, dwall, None, None, None

@@ -125,6 +125,11 @@ int cpc_gru_backward(const float* x, const float* h0, const float* const* params
  * K <= 16, N % 16 == 0.  sizes[0..2] = saved / fwd-scratch / bwd-scratch floats,
  * sizes[3..5] = offsets of pred, logits (B*W,K,1+N), lse (B*W,K) inside `saved`. */
 int cpc_nce_layout(int B, int S, int K, int N, long* sizes);
+/* Index preparation: the two int64 draws of sampleClean (criterion.py:181-189; B*N*W each, flat (b,n,t)
+ * order) -> ext (criterion.py:191-199, laid out (b,t,n)) and the destination-sorted candidate slots
+ * (perm, row_ptr) the backward gather uses.  work: B*W*(N+K) + 2*B*S + 2 ints. */
+int cpc_nce_prepare(const long* batchIdx, const long* seqIdx, int* ext, int* perm, int* row_ptr, int* work,
+                    int B, int S, int K, int N, void* stream);
 int cpc_nce_forward(const float* c, const float* z, const float* wall, const int* ext, float* saved,
                     float* scratch, float* losses, float* acc, int B, int S, int K, int N,
                     void* stream);

@@ -43,7 +43,17 @@ def test_nce_forward_backward_emulated(B, S, K, N, scale):
     dc = torch.full((B, S, 256), float("nan")); dz = torch.full((B, S, 256), float("nan"))
     dwall = torch.full((K * 256, 256), float("nan"))
     from cpc_audio_amd.ops import candidate_destinations
-    perm, row_ptr = candidate_destinations(ext_t, B, S, K)
+    perm_ref, row_ptr_ref = candidate_destinations(ext_t, B, S, K)
+    # device-side index preparation must reproduce ext and the destination-sorted slot lists
+    ext_k = torch.full((B, W, N), -1, dtype=torch.int32)
+    perm = torch.full((B * W * (N + K),), -1, dtype=torch.int32)
+    row_ptr = torch.full((B * S + 1,), -1, dtype=torch.int32)
+    work = torch.zeros(B * W * (N + K) + 2 * B * S + 2, dtype=torch.int32)
+    assert lib.cpc_nce_prepare(P(bi), P(si), P(ext_k), P(perm), P(row_ptr), P(work), B, S, K, N, None) == 0
+    assert torch.equal(ext_k, ext_t) and torch.equal(row_ptr, row_ptr_ref)
+    for r in range(B * S):
+        lo, hi = int(row_ptr[r]), int(row_ptr[r + 1])
+        assert sorted(perm[lo:hi].tolist()) == perm_ref[lo:hi].tolist()
     assert lib.cpc_nce_backward(P(c), P(z), P(wall), P(ext_t), P(perm), P(row_ptr), P(saved), P(gl), P(bscr), P(dc),
                                 P(dz), P(dwall), B, S, K, N, None) == 0
     assert rel_err(dc, cr.grad) < 1e-5

@@ -75,3 +75,20 @@ def test_train_step_matches_oracle_and_reference_golden(case, golden_dir):
         if not rel < 2e-4:
             bad[k] = rel
     assert not bad, bad
+
+
+def test_train_step_is_bit_reproducible():
+    """Race / determinism screen: the path has no float atomics (the InfoNCE scatter is
+    a sorted gather, every reduction has a fixed order), so two runs on identical inputs must agree bit for bit."""
+    dev = _dev()
+    B = 4
+    p = O.make_params(seed=11, head_scale=64.0)
+    wave = O.make_waveform(B, 20480, seed=21)
+    g = torch.Generator().manual_seed(5)
+    bidx, sidx = O.draw_negative_indices(B, 128, 116, 128, generator=g)
+    a = _hip_step(p, wave, bidx, sidx, dev)
+    b = _hip_step(p, wave, bidx, sidx, dev)
+    assert torch.equal(a["z"], b["z"]) and torch.equal(a["c"], b["c"]) and torch.equal(a["losses"], b["losses"])
+    assert torch.equal(a["dz"], b["dz"]) and torch.equal(a["dc"], b["dc"])
+    for k in a["grads"]:
+        assert torch.equal(a["grads"][k], b["grads"][k]), k
