@@ -173,6 +173,24 @@ inline f32x4 mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) {
     return c;
 }
 
+// DPP data movement (the subset the kernels use) and v_readlane, as wave collectives
+inline int dpp_src_lane(int ctrl, int l) {
+    const int row = l & ~15, i = l & 15;
+    if (ctrl >= 0 && ctrl <= 0xFF) return (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);       // quad_perm
+    if (ctrl == 0x140) return row | (15 - i);                                              // row_mirror
+    if (ctrl == 0x141) return row | (i < 8 ? 7 - i : 23 - i);                              // row_half_mirror
+    fprintf(stderr, "hipemu: unsupported dpp_ctrl 0x%x\n", ctrl);
+    abort();
+}
+inline int update_dpp(int, int src, int ctrl, int, int, bool) {
+    const uint32_t* buf = exchange((uint32_t)src);
+    return (int)buf[dpp_src_lane(ctrl, lane_id())];
+}
+inline int readlane(int v, int lane) {
+    const uint32_t* buf = exchange((uint32_t)v);
+    return (int)buf[lane & (WAVE - 1)];
+}
+
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -251,6 +269,7 @@ static inline void unsafeAtomicAdd(float* p, float v) { (void)atomicAdd(p, v); }
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
 
@@ -260,6 +279,8 @@ static inline float __fdividef(float a, float b) { return a / b; }
 static inline unsigned __float_as_uint(float x) { return hipemu::bits(x); }
 static inline float __uint_as_float(unsigned u) { return hipemu::unbits<float>(u); }
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_update_dpp hipemu::update_dpp
+#define __builtin_amdgcn_readlane hipemu::readlane
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 
