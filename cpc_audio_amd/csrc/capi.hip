@@ -4,7 +4,7 @@
 
 namespace cpc { int g_mfma_mode = 1; }
 
-extern "C" int cpc_abi_version(void) { return 2; }
+extern "C" int cpc_abi_version(void) { return 3; }
 
 extern "C" int cpc_set_mfma_mode(int mode) {
     CPC_RETURN_IF(mode != 0 && mode != 1, CPC_ERR_ARG);

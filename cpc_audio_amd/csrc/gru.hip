@@ -13,9 +13,14 @@
 //     inside a workgroup the 4 waves split the K = 256 contraction (split-K), each wave
 //     pulls its h / W_hh slices straight into MFMA fragments (float4 per lane, 4 k-steps
 //     per load), the partial 16x16 tiles meet in LDS and the gate non-linearities are
-//     applied by one thread per (b, j).  Step-to-step ordering is the stream order of
-//     the launches (a dependent kernel boundary costs less than a software grid barrier on this
-//     chip; hipGraph replay of the chain measured identical to eager launches, 0.83 ms per 129);
+//     applied by one thread per (b, j);
+//   * the two-layer recurrence of the north-star model runs as ONE persistent launch
+//     (gru2_persist_*_kernel below): every workgroup keeps its weight slice in registers for all S
+//     steps and the step-to-step hand-over goes through the output arrays themselves, pre-filled
+//     with a bit pattern no result can have and polled with cache-bypassing loads.  Measured on
+//     MI355X (tools/probe_sync2.hip): 1.3-1.9 us per hand-over, against 6.4 us for a dependent
+//     kernel launch (hipGraph replay == eager) and 13 us for fence + counter barriers;
+//     the per-step kernels remain for other depths and as the path when the grid cannot be co-resident;
 //   * backward (BPTT) mirrors it with K = 768:  dh_t = dY_t + dh_{t+1} * z_{t+1}
 //     + dGh_{t+1} . W_hh,  then the gate derivatives; all weight gradients are batched
 //     TN GEMMs over the B*S rows afterwards.
@@ -166,6 +171,7 @@ struct Gru2Fwd {
     float* y[2];               // layer outputs (B,S,H)
     float* R[2]; float* Z[2]; float* N[2]; float* GHN[2];
     float* hN;                 // (2,B,H)
+    float* xh[2];              // persistent launch only: hand-over copies of y[l] (see xtile)
     int B, S;
 };
 
@@ -284,6 +290,7 @@ struct Gru2Bwd {
     const float* h0[2];
     const float* R[2]; const float* Z[2]; const float* N[2]; const float* GHN[2];
     float* dGi[2]; float* dGh[2]; float* DH[2];
+    float* xgh[2]; float* xgi1;   // persistent launch only: hand-over copies of dGh[l] and dGi[1]
     int B, S;
 };
 
@@ -373,13 +380,318 @@ __global__ __launch_bounds__(512) void gru2_bwd_kernel(Gru2Bwd p, int s) {
     p.DH[layer][bt * kH + j] = dh;
 }
 
+// ------------------------------------------------------------------ persistent two-layer recurrence
+// One launch for all S steps.  Workgroup (layer, 16 hidden units, 16 sequences) exactly as in the
+// wavefront kernels above and with the same MFMA / summation order (bit-identical results), but
+//   * its W slice is loaded into registers once,
+//   * h_{t-1} (forward) / the gate gradients of step t+1 (backward) are taken from the output arrays
+//     while they are being produced: the host fills them with 0xFFFFFFFF (a NaN payload no arithmetic
+//     result carries), producers store with agent-scope atomics (write-through, global_store sc1) and
+//     consumers poll the fragments they need with agent-scope atomic loads until no lane sees the fill
+//     pattern.  Each 4-byte value validates itself, so there is no flag, counter or fence on the chain.
+// All workgroups must be resident at once (host side checks the occupancy).  Polling is bounded: if
+// a producer never shows up (it cannot, short of a broken device) the wave gives up, lets the fill
+// pattern -- a NaN -- propagate into the outputs and the loss, and the launch still terminates.
+constexpr unsigned kNotReady = 0xFFFFFFFFu;
+constexpr int kSpinLimit = 1 << 20;
+
+__device__ __forceinline__ float4 load4_coherent(const float* p) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                       __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+}
+__device__ __forceinline__ bool ready4(float4 v) {
+    return __float_as_uint(v.x) != kNotReady && __float_as_uint(v.y) != kNotReady &&
+           __float_as_uint(v.z) != kNotReady && __float_as_uint(v.w) != kNotReady;
+}
+__device__ __forceinline__ void store_coherent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Exchange buffers.  Polling the (B,S,*) output arrays directly puts the 16 rows of a tile 128 KB (a power
+// of two) apart -- one memory channel -- and costs 3x the hand-over latency; the hand-over therefore goes
+// through a copy laid out in MFMA-fragment order, [step][batch tile][k/4][row 0..15][4 floats]: one wave
+// fetch = 1 KB contiguous, one step of one tile = 16 KB (forward) / 48 KB (backward) contiguous.
+constexpr int kXStride = 4 * 64;                     // floats between a lane's consecutive fragments (k += 16)
+__device__ __forceinline__ long xtile(int t, int tile, int ntiles, int kwidth) {
+    return ((long)t * ntiles + tile) * 16 * kwidth;
+}
+__device__ __forceinline__ int xpos(int row, int k) { return (k >> 2) * 64 + row * 4 + (k & 3); }
+
+// Fetch NII float4 fragments (k += 16 apart) of this lane's row, re-reading until every lane of the wave
+// has complete data.  Lanes whose row is outside the batch contribute zeros.
+template <int NII>
+__device__ __forceinline__ void poll_row(const float* __restrict__ row, bool ok, float4 (&a)[NII], int& budget) {
+    for (;;) {
+        bool rdy = true;
+#pragma unroll
+        for (int ii = 0; ii < NII; ++ii) {
+            a[ii] = ok ? load4_coherent(row + kXStride * ii) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rdy = rdy && ready4(a[ii]);
+        }
+        if (__all(rdy) || budget <= 0) break;
+        --budget;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int NII>
+__device__ __forceinline__ void load_row_plain(const float* __restrict__ row, bool ok, float4 (&a)[NII]) {
+#pragma unroll
+    for (int ii = 0; ii < NII; ++ii)
+        a[ii] = ok ? *reinterpret_cast<const float4*>(row + 16 * ii) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int NII>
+__device__ __forceinline__ void load_gate_weights(float4 (&bw)[3][NII], const float* __restrict__ w, int j0i, int koff) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ii = 0; ii < NII; ++ii)
+            bw[g][ii] = *reinterpret_cast<const float4*>(w + (long)(g * kH + j0i) * kH + koff + 16 * ii);
+}
+
+template <int NII>
+__device__ __forceinline__ void mfma_gates(f32x4 (&acc)[3], const float4 (&a)[NII], const float4 (&bw)[3][NII]) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ii = 0; ii < NII; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii], jj), f4c(bw[g][ii], jj), acc[g], 0, 0, 0);
+}
+
+struct PersistIds {
+    int layer, j0, b0, tile, ntiles;
+    __device__ PersistIds() {
+        const int G = gridDim.x / 32;               // batch tiles; ids of one tile are G apart
+        const int rest = blockIdx.x / G;
+        ntiles = G;
+        tile = blockIdx.x % G;
+        b0 = tile * 16;
+        layer = rest >> 4;
+        j0 = (rest & 15) * 16;
+    }
+};
+
+// Workgroup = 8 MFMA waves (poll -> MFMA -> partial tile to LDS) + 4 gate waves (one thread per (b, j):
+// partial sums, non-linearities, stores, and the prefetch of the next step's saved operands).  The split
+// keeps the gate threads' global loads/stores -- and their acknowledgements -- off the vmcnt of the polling
+// waves, whose poll -> MFMA -> barrier chain is the critical path of the recurrence.
+constexpr int kPersistThreads = 768;
+constexpr int kMfmaWaves = 8;
+
+template <int LAYER>
+__device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8][3][256], const PersistIds& id) {
+    const int j0 = id.j0, b0 = id.b0;
+    constexpr int NII = LAYER == 0 ? 2 : 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int B = p.B, S = p.S;
+    float* __restrict__ yl = p.y[LAYER];
+
+    if (w < kMfmaWaves) {
+        const int i = lane & 15, kq = lane >> 4;
+        const bool bok = (b0 + i) < B;
+        const bool recurrent = LAYER == 0 || w < 4;  // this wave's product: W_hh h_{t-1}  (else W_ih1 h0_t)
+        const int koff = LAYER == 0 ? 32 * w + 4 * kq : 64 * (w & 3) + 4 * kq;
+        float4 bw[3][NII];
+        load_gate_weights<NII>(bw, recurrent ? p.whh[LAYER] : p.wih1, j0 + i, koff);
+        const float* __restrict__ xsrc = (recurrent ? p.xh[LAYER] : p.xh[0]) + xpos(i, koff);
+        int budget = kSpinLimit;
+        for (int t = 0; t < S; ++t) {
+            float4 a[NII];
+            if (recurrent) {
+                if (t == 0) load_row_plain<NII>(p.h0[LAYER] ? p.h0[LAYER] + (long)(b0 + i) * kH + koff : nullptr,
+                                                bok && p.h0[LAYER] != nullptr, a);
+                else poll_row<NII>(xsrc + xtile(t - 1, id.tile, id.ntiles, kH), bok, a, budget);
+            } else {
+                poll_row<NII>(xsrc + xtile(t, id.tile, id.ntiles, kH), bok, a, budget);
+            }
+            f32x4 acc[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mfma_gates<NII>(acc, a, bw);
+            float (&pt)[8][3][256] = part[t & 1];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pt[w][g][(kq * 4 + r) * 16 + i] = acc[g][r];
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- gate waves
+    const int e = tid - kMfmaWaves * 64;             // == row * 16 + col
+    const int b = b0 + (e >> 4), j = j0 + (e & 15);
+    const bool live = b < B;
+    float bh[3] = {0.f, 0.f, 0.f}, gi[3] = {0.f, 0.f, 0.f}, hp = 0.f;
+    if (live) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bh[g] = p.bhh[LAYER][g * kH + j];
+        if (LAYER == 1) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gi[g] = p.bih1[g * kH + j];
+        } else {
+            const float* gip = p.x_gi0 + (long)b * S * kG;
+            gi[0] = gip[j]; gi[1] = gip[kH + j]; gi[2] = gip[2 * kH + j];
+        }
+        if (p.h0[LAYER]) hp = p.h0[LAYER][(long)b * kH + j];
+    }
+    for (int t = 0; t < S; ++t) {
+        __syncthreads();
+        if (!live) continue;
+        const long bt = (long)b * S + t;
+        float (&pt)[8][3][256] = part[t & 1];
+        float gh[3], gi_r = gi[0], gi_z = gi[1], gi_n = gi[2];
+        if (LAYER == 0) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                gh[g] = (((pt[0][g][e] + pt[1][g][e]) + (pt[2][g][e] + pt[3][g][e])) +
+                         ((pt[4][g][e] + pt[5][g][e]) + (pt[6][g][e] + pt[7][g][e]))) + bh[g];
+        } else {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                gh[g] = ((pt[0][g][e] + pt[1][g][e]) + (pt[2][g][e] + pt[3][g][e])) + bh[g];
+            gi_r += (pt[4][0][e] + pt[5][0][e]) + (pt[6][0][e] + pt[7][0][e]);
+            gi_z += (pt[4][1][e] + pt[5][1][e]) + (pt[6][1][e] + pt[7][1][e]);
+            gi_n += (pt[4][2][e] + pt[5][2][e]) + (pt[6][2][e] + pt[7][2][e]);
+        }
+        const float r = sigmoidf_(gi_r + gh[0]);
+        const float z = sigmoidf_(gi_z + gh[1]);
+        const float n = tanhf(gi_n + r * gh[2]);
+        const float h = (1.0f - z) * n + z * hp;
+        store_coherent(p.xh[LAYER] + xtile(t, id.tile, id.ntiles, kH) + xpos(e >> 4, j), h);   // first: others wait for it
+        yl[bt * kH + j] = h;
+        p.R[LAYER][bt * kH + j] = r;
+        p.Z[LAYER][bt * kH + j] = z;
+        p.N[LAYER][bt * kH + j] = n;
+        p.GHN[LAYER][bt * kH + j] = gh[2];
+        if (t == S - 1) p.hN[((long)LAYER * B + b) * kH + j] = h;
+        hp = h;
+        if (LAYER == 0 && t + 1 < S) {                            // next step's input projection, a step ahead
+            const float* gip = p.x_gi0 + (bt + 1) * kG;
+            gi[0] = gip[j]; gi[1] = gip[kH + j]; gi[2] = gip[2 * kH + j];
+        }
+    }
+}
+
+// grid = 32 * ceil(B/16) workgroups (1-D), 768 threads; xh[0] and xh[1] pre-filled with 0xFF bytes
+__global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_kernel(Gru2Fwd p) {
+    __shared__ float part[2][8][3][256];
+    const PersistIds id;
+    if (id.layer == 0) persist_fwd<0>(p, part, id);
+    else persist_fwd<1>(p, part, id);
+}
+
+template <int LAYER>
+__device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8][256], const PersistIds& id) {
+    const int j0 = id.j0, b0 = id.b0;
+    constexpr int NII = LAYER == 1 ? 6 : 12;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int B = p.B, S = p.S;
+
+    if (w < kMfmaWaves) {
+        const int i = lane & 15, kq = lane >> 4;
+        const bool bok = (b0 + i) < B;
+        const bool recurrent = LAYER == 1 || w < 4;  // dGh_{t+1} . W_hh   (else dGi1_t . W_ih1)
+        const int koff = LAYER == 1 ? 96 * w + 4 * kq : 192 * (w & 3) + 4 * kq;
+        float4 bw[NII];
+        {
+            const float* wrow = (recurrent ? p.whhT[LAYER] : p.wih1T) + (long)(j0 + i) * kG + koff;
+#pragma unroll
+            for (int ii = 0; ii < NII; ++ii) bw[ii] = *reinterpret_cast<const float4*>(wrow + 16 * ii);
+        }
+        const float* __restrict__ xsrc = (recurrent ? p.xgh[LAYER] : p.xgi1) + xpos(i, koff);
+        int budget = kSpinLimit;
+        for (int t = S - 1; t >= 0; --t) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!recurrent || (t + 1) < S) {
+                float4 a[NII];
+                poll_row<NII>(xsrc + xtile(recurrent ? t + 1 : t, id.tile, id.ntiles, kG), bok, a, budget);
+#pragma unroll
+                for (int ii = 0; ii < NII; ++ii)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii], jj), f4c(bw[ii], jj), acc, 0, 0, 0);
+            }
+            float (&pt)[8][256] = part[t & 1];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) pt[w][(kq * 4 + rr) * 16 + i] = acc[rr];
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- gate waves
+    const int e = tid - kMfmaWaves * 64;
+    const int b = b0 + (e >> 4), j = j0 + (e & 15);
+    const bool live = b < B;
+    float dyv = 0.f, r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hp = 0.f;   // operands of the step about to run
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        const long bt = (long)b * S + t;
+        if (LAYER == 1) dyv = p.dy[bt * kH + j];
+        r = p.R[LAYER][bt * kH + j]; z = p.Z[LAYER][bt * kH + j];
+        n = p.N[LAYER][bt * kH + j]; ghn = p.GHN[LAYER][bt * kH + j];
+        hp = t > 0 ? p.y[LAYER][(bt - 1) * kH + j] : (p.h0[LAYER] ? p.h0[LAYER][(long)b * kH + j] : 0.f);
+    };
+    if (live) fetch(S - 1);
+    float dh_next = 0.f, z_next = 0.f;
+    for (int t = S - 1; t >= 0; --t) {
+        __syncthreads();
+        if (!live) continue;
+        const long bt = (long)b * S + t;
+        float (&pt)[8][256] = part[t & 1];
+        float dh0 = LAYER == 1 ? dyv : 0.f;
+        if ((t + 1) < S) dh0 = fmaf(dh_next, z_next, dh0);
+        const float dh = (((pt[0][e] + pt[1][e]) + (pt[2][e] + pt[3][e])) +
+                          ((pt[4][e] + pt[5][e]) + (pt[6][e] + pt[7][e]))) + dh0;
+        const float dn = dh * (1.0f - z);
+        const float dzg = dh * (hp - n);
+        const float dan = dn * (1.0f - n * n);
+        const float daz = dzg * z * (1.0f - z);
+        const float dar = dan * ghn * r * (1.0f - r);
+        float* gi = p.dGi[LAYER] + bt * kG;
+        float* gh = p.dGh[LAYER] + bt * kG;
+        const int row = e >> 4;
+        float* xh = p.xgh[LAYER] + xtile(t, id.tile, id.ntiles, kG);
+        store_coherent(xh + xpos(row, j), dar);                   // polled by this layer's next step
+        store_coherent(xh + xpos(row, kH + j), daz);
+        store_coherent(xh + xpos(row, 2 * kH + j), dan * r);
+        if (LAYER == 1) {                                         // polled by the layer below
+            float* xi = p.xgi1 + xtile(t, id.tile, id.ntiles, kG);
+            store_coherent(xi + xpos(row, j), dar);
+            store_coherent(xi + xpos(row, kH + j), daz);
+            store_coherent(xi + xpos(row, 2 * kH + j), dan);
+        }
+        gh[j] = dar; gh[kH + j] = daz; gh[2 * kH + j] = dan * r;
+        gi[j] = dar; gi[kH + j] = daz; gi[2 * kH + j] = dan;
+        p.DH[LAYER][bt * kH + j] = dh;
+        dh_next = dh;
+        z_next = z;
+        if (t > 0) fetch(t - 1);                                  // a step ahead: HBM latency off the chain
+    }
+}
+
+// grid / block as the forward; xgh[0], xgh[1] and xgi1 pre-filled with 0xFF bytes
+__global__ __launch_bounds__(kPersistThreads) void gru2_persist_bwd_kernel(Gru2Bwd p) {
+    __shared__ float part[2][8][256];
+    const PersistIds id;
+    if (id.layer == 0) persist_bwd<1>(p, part, id);               // the top layer leads
+    else persist_bwd<0>(p, part, id);
+}
+
 // ------------------------------------------------------------------ host side
 struct GruLayout {
     long R[8], Z[8], N[8], GHN[8], Y[8];     // saved (per layer); Y only for l < nl-1
     long saved_total;
-    long gi, fwd_total;                      // forward scratch
+    long gi, xh, xh_floats, fwd_total;       // forward scratch (xh: hand-over buffers of the persistent launch)
     long whhT, wihT, dGi, dGh, DH, mid[2], part, tmp;
     long whhT2, wihT2, dGi2, dGh2, DH2;      // second set for the two-layer wavefront
+    long xg, xg_floats;                      // hand-over buffers of the persistent launch (3 x xg_floats)
     long bwd_total;
 };
 
@@ -396,8 +708,11 @@ static bool gru_layout(int B, int S, int nl, GruLayout& g) {
         if (l < nl - 1) { g.Y[l] = o; o += bsh; }
     }
     g.saved_total = o;
+    const long tiles16 = (long)cdiv(B, 16) * 16;
     g.gi = 0;
-    g.fwd_total = align64l((long)B * S * kG);
+    g.xh = align64l((long)B * S * kG);
+    g.xh_floats = nl == 2 ? align64l((long)S * tiles16 * kH) : 0;
+    g.fwd_total = g.xh + 2 * g.xh_floats;
     o = 0;
     g.whhT = o; o += (long)kH * kG;
     g.wihT = o; o += (long)kH * kG;
@@ -413,6 +728,8 @@ static bool gru_layout(int B, int S, int nl, GruLayout& g) {
     g.dGi2 = o; o += align64l((long)B * S * kG);
     g.dGh2 = o; o += align64l((long)B * S * kG);
     g.DH2 = o; o += bsh;
+    g.xg_floats = nl == 2 ? align64l((long)S * tiles16 * kG) : 0;
+    g.xg = o; o += 3 * g.xg_floats;
     g.bwd_total = o;
     return true;
 }
@@ -420,6 +737,26 @@ static bool gru_layout(int B, int S, int nl, GruLayout& g) {
 }  // namespace cpc
 
 using namespace cpc;
+
+namespace {
+int g_gru_mode = 1;        // 1: persistent two-layer recurrence when the grid fits the device, 0: per-step launches
+
+// true if `nblocks` workgroups of `kernel` (kPersistThreads each) can all be resident at the same time
+template <class K>
+bool fits_resident(K kernel, int nblocks) {
+    int dev = 0, cus = 0, occ = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kPersistThreads, 0) != hipSuccess) return false;
+    return (long)nblocks <= (long)cus * occ;
+}
+}  // namespace
+
+extern "C" int cpc_set_gru_mode(int mode) {
+    if (mode != 0 && mode != 1) return CPC_ERR_ARG;
+    g_gru_mode = mode;
+    return 0;
+}
 
 // sizes[0] = saved floats, [1] = forward scratch floats, [2] = backward scratch floats
 extern "C" int cpc_gru_layout(int B, int S, int nl, long* sizes) {
@@ -453,6 +790,15 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
         p.wih1 = params[4]; p.bih1 = params[6];
         p.y[0] = saved + g.Y[0]; p.y[1] = y;
         p.hN = hN; p.B = B; p.S = S;
+        p.xh[0] = p.xh[1] = nullptr;
+        const int nblocks = 32 * cdiv(B, 16);
+        if (g_gru_mode == 1 && fits_resident(gru2_persist_fwd_kernel, nblocks)) {
+            p.xh[0] = scratch + g.xh; p.xh[1] = scratch + g.xh + g.xh_floats;
+            if (hipMemsetAsync(p.xh[0], 0xFF, 2 * g.xh_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+            hipLaunchKernelGGL(gru2_persist_fwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+            CPC_LAUNCH_CHECK();
+            return 0;
+        }
         const dim3 grid(kH / 16, cdiv(B, 16), 2);
         for (int s = 0; s <= S; ++s) hipLaunchKernelGGL(gru2_fwd_kernel, grid, dim3(512), 0, st, p, s);
         CPC_LAUNCH_CHECK();
@@ -511,8 +857,16 @@ extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* co
             p.dGi[l] = dGi_[l]; p.dGh[l] = dGh_[l]; p.DH[l] = DH_[l];
         }
         p.wih1T = wihT_[1];
-        const dim3 grid(kH / 16, cdiv(B, 16), 2);
-        for (int s = 0; s <= S; ++s) hipLaunchKernelGGL(gru2_bwd_kernel, grid, dim3(512), 0, st, p, s);
+        p.xgh[0] = p.xgh[1] = p.xgi1 = nullptr;
+        const int nblocks = 32 * cdiv(B, 16);
+        if (g_gru_mode == 1 && fits_resident(gru2_persist_bwd_kernel, nblocks)) {
+            p.xgh[0] = scratch + g.xg; p.xgh[1] = scratch + g.xg + g.xg_floats; p.xgi1 = scratch + g.xg + 2 * g.xg_floats;
+            if (hipMemsetAsync(p.xgh[0], 0xFF, 3 * g.xg_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+            hipLaunchKernelGGL(gru2_persist_bwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+        } else {
+            const dim3 grid(kH / 16, cdiv(B, 16), 2);
+            for (int s = 0; s <= S; ++s) hipLaunchKernelGGL(gru2_bwd_kernel, grid, dim3(512), 0, st, p, s);
+        }
         CPC_LAUNCH_CHECK();
         for (int l = 0; l < 2; ++l) {
             const float* in = l == 0 ? x : saved + g.Y[0];

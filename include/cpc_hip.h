@@ -76,6 +76,10 @@ int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, int fuse,
 int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part, float* dW, int B, int Lin,
                          int k, int s, int p, int splits, int rows_per_split, void* stream);
 
+/* 1 (default): the two-layer recurrence runs as one persistent launch whenever all of its workgroups can
+ * be resident at once (gru.hip); 0: one launch per time step.  Both give bit-identical results. */
+int cpc_set_gru_mode(int mode);
+
 /* Tuning / test knob: rows per block of the conv GEMM tiles (0 = auto, 32, 64, 128). */
 int cpc_set_conv_tile(int bm);
 

@@ -11,6 +11,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
 
+# Resident workgroup slots of the emulated device (OS worker threads).  The persistent GRU kernels need
+# all of their 32 * ceil(B/16) workgroups resident at once; 64 covers the B <= 32 cases tested here.
+os.environ.setdefault("HIPEMU_THREADS", "64")
+
 _emu = None
 
 
@@ -21,7 +25,7 @@ def emu():
         from cpc_audio_amd import _lib
         try:
             path = build_emu.build()
-        except Exception as e:  # no host clang: cannot emulate
+        except FileNotFoundError as e:  # no host clang: cannot emulate (a compile ERROR still fails the test)
             pytest.skip(f"emulator build unavailable: {e}")
         _emu = _lib.bind(path)
     return _emu

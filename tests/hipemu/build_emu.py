@@ -17,7 +17,7 @@ def _cxx():
     for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++")):
         if c and os.path.exists(c):
             return c
-    raise RuntimeError("clang++ not found")
+    raise FileNotFoundError("clang++ not found")
 
 
 def build(force=False):

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <sys/mman.h>
 
 // ---- minimal x86-64 SysV context switch: saves callee-saved regs on the old
 // stack, stores old sp, loads new sp, restores and returns into the new fiber.
@@ -128,15 +129,24 @@ static void run_block(BlockCtx& b) {
     blk = nullptr;
 }
 
-void launch_impl(dim3 grid, dim3 block, const std::function<void()>& body) {
-    const long nblocks = (long)grid.x * grid.y * grid.z;
-    const int nthreads = (int)(block.x * block.y * block.z);
-    if (nblocks <= 0 || nthreads <= 0) return;
+// number of workgroups that are resident at a time (= OS worker threads; blocks are dispatched in
+// linear-id order as workers free up, like the hardware dispatcher)
+int worker_count() {
     static int hw = [] {
         const char* e = getenv("HIPEMU_THREADS");
         int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
         return std::max(1, v);
     }();
+    return hw;
+}
+
+void launch_impl(dim3 grid, dim3 block, const std::function<void()>& body) {
+    const long nblocks = (long)grid.x * grid.y * grid.z;
+    const int nthreads = (int)(block.x * block.y * block.z);
+    if (nblocks <= 0 || nthreads <= 0) return;
+    const int hw = worker_count();
+    static const bool trace = getenv("HIPEMU_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "hipemu: launch grid (%u,%u,%u) block %d\n", grid.x, grid.y, grid.z, nthreads);
     const int nworkers = (int)std::min<long>(hw, nblocks);
     std::atomic<long> next{0};
     auto worker = [&]() {
@@ -147,8 +157,12 @@ void launch_impl(dim3 grid, dim3 block, const std::function<void()>& body) {
         b.body = &body;
         b.fibers.resize(nthreads);
         b.waves.resize((nthreads + WAVE - 1) / WAVE);
-        std::vector<char> stacks((size_t)nthreads * STACK_BYTES + 64);
-        for (int i = 0; i < nthreads; ++i) b.fibers[i].stack = stacks.data() + (size_t)i * STACK_BYTES;
+        // lazily committed: only the pages a fiber touches cost memory
+        const size_t stack_bytes = (size_t)nthreads * STACK_BYTES;
+        char* stacks = (char*)mmap(nullptr, stack_bytes, PROT_READ | PROT_WRITE,
+                                   MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (stacks == (char*)MAP_FAILED) { fprintf(stderr, "hipemu: cannot map fiber stacks\n"); abort(); }
+        for (int i = 0; i < nthreads; ++i) b.fibers[i].stack = stacks + (size_t)i * STACK_BYTES;
         for (;;) {
             long id = next.fetch_add(1);
             if (id >= nblocks) break;
@@ -156,6 +170,7 @@ void launch_impl(dim3 grid, dim3 block, const std::function<void()>& body) {
                          (unsigned)(id / ((long)grid.x * grid.y)));
             run_block(b);
         }
+        munmap(stacks, stack_bytes);
     };
     if (nworkers == 1) {
         worker();

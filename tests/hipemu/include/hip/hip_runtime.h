@@ -14,6 +14,7 @@
 // resident block).  Wave size is 64.  MFMA fragment layouts follow
 // /opt/skills/guides/cdna_hip_programming.md section 3.
 #pragma once
+#include <sched.h>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -281,6 +282,29 @@ static inline float __uint_as_float(unsigned u) { return hipemu::unbits<float>(u
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_update_dpp hipemu::update_dpp
 #define __builtin_amdgcn_readlane hipemu::readlane
+// ---- inter-workgroup exchange support (persistent kernels): agent-scope atomics are host atomics,
+// s_sleep hands the OS thread to the other (co-resident) blocks.
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <class T> static inline T hipemu_atomic_load(const T* p, int order) { T v; __atomic_load(p, &v, order); return v; }
+template <class T, class V> static inline void hipemu_atomic_store(T* p, V v, int order) { T t = (T)v; __atomic_store(p, &t, order); }
+#define __hip_atomic_load(p, order, scope) hipemu_atomic_load((p), (order))
+#define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store((p), (v), (order))
+static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
+static inline bool __all(bool pred) {
+    const uint32_t* buf = hipemu::exchange(pred ? 1u : 0u);
+    const int lo = 0, hi = hipemu::WAVE;
+    bool r = true;
+    const int base = (hipemu::cur->lin / hipemu::WAVE) * hipemu::WAVE;
+    for (int l = lo; l < hi; ++l)
+        if (base + l < hipemu::blk->nthreads) r = r && buf[l] != 0;
+    return r;
+}
+// device queries: the "device" has as many CUs as the emulator has worker threads
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+namespace hipemu { int worker_count(); }
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = hipemu::worker_count(); return hipSuccess; }
+template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 

@@ -128,3 +128,34 @@ def test_trainer_step_updates_parameters_like_cpu_adam():
     frac_far = max(((new[k].cpu() - cpu[k].detach()).abs() > 1e-6).float().mean().item() for k in cpu)
     assert frac_far < 1e-3, frac_far
     assert all(prm.grad is None or float(prm.grad.abs().sum()) == 0.0 for prm in model.parameters())
+
+
+@pytest.mark.parametrize("B,S", [(64, 128), (7, 33), (128, 16)])
+def test_gru_persistent_launch_equals_stepwise(B, S):
+    """The single-launch two-layer recurrence (workgroups hand h_t / gate gradients over through the output
+    arrays) and the launch-per-step path share arithmetic and summation order: bit-identical results."""
+    dev = _dev()
+    from cpc_audio_amd import _lib
+    from cpc_audio_amd.model import CPCAR
+    lib = _lib.get()
+    p = O.make_params(seed=4)
+    ar = CPCAR(256, 256, False, 2, mode="GRU").to(dev)
+    ar.load_state_dict({k[len("gAR."):]: v for k, v in p.items() if k.startswith("gAR.")})
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    x = torch.randn(B, S, 256, generator=g).to(dev)
+    dy = torch.randn(B, S, 256, generator=g).to(dev)
+    outs = []
+    for mode in (0, 1, 1):
+        assert lib.cpc_set_gru_mode(mode) == 0
+        try:
+            ar.zero_grad(set_to_none=True)
+            xd = x.clone().requires_grad_(True)
+            y = ar(xd)
+            (y * dy).sum().backward()
+            torch.cuda.synchronize()
+            outs.append([y.detach().clone(), xd.grad.clone()] + [q.grad.clone() for q in ar.parameters()])
+        finally:
+            lib.cpc_set_gru_mode(1)
+    assert all(torch.isfinite(t).all() for t in outs[1])
+    for a, b, c in zip(*outs):
+        assert torch.equal(a, b) and torch.equal(b, c)
