@@ -154,6 +154,17 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(
     DH[bt * kH + j] = dh;
 }
 
+// Fragment-ordered (B,S,256) arrays: [step][batch tile][unit/4][row 0..15][4 floats].  One wave fetch of
+// MFMA operand fragments = 1 KB contiguous, one step of one tile = 16 KB contiguous.  Used for the
+// hand-over buffers of the persistent launch (polling the (B,S,*) output arrays directly would put the 16
+// rows of a tile 128 KB -- a power of two, one memory channel -- apart and costs 3x the hand-over latency)
+// and for the backward coefficient arrays.
+constexpr int kXStride = 4 * 64;                     // floats between a lane's consecutive fragments (k += 16)
+__device__ __forceinline__ long xtile(int t, int tile, int ntiles, int kwidth) {
+    return ((long)t * ntiles + tile) * 16 * kwidth;
+}
+__device__ __forceinline__ int xpos(int row, int k) { return (k >> 2) * 64 + row * 4 + (k & 3); }
+
 // ------------------------------------------------------------------ two-layer wavefront
 // The north-star autoregressor has exactly two layers.  Launch s (s = 0..S) runs layer 0's step
 // t = s and layer 1's step t = s-1 side by side (blockIdx.z = layer), so the 2*S dependent steps
@@ -286,35 +297,76 @@ struct Gru2Bwd {
     const float* dy;           // gradient w.r.t. the top layer's output (B,S,H)
     const float* whhT[2];      // (H,3H) transposed recurrent weights, index = layer
     const float* wih1T;        // (H,3H): W_ih of layer 1 transposed
-    const float* y[2];
-    const float* h0[2];
-    const float* R[2]; const float* Z[2]; const float* N[2]; const float* GHN[2];
+    const float* Z[2];
+    const float* cr[2]; const float* cz[2]; const float* cnh[2]; const float* cni[2];   // see gru_bwd_coef_kernel
     float* dGi[2]; float* dGh[2]; float* DH[2];
-    float* xgh[2]; float* xgi1;   // persistent launch only: hand-over copies of dGh[l] and dGi[1]
+    float* xdh[2];             // persistent launch only: hand-over copies of DH[l] (fragment order)
     int B, S;
 };
 
-__device__ __forceinline__ f32x4 mfma_slice1(f32x4 acc, const float* __restrict__ arow, bool ok,
-                                             const float* __restrict__ wrow, int koff, int nii) {
-    // acc += A[16 x 16*nii] . W^T slice, single output tile (K-major rows of length 3H)
+// Everything in the gate derivatives that does not depend on dh, for all (b, t, j) at once and in fragment
+// order, so that the recurrence itself is   dGi = dh * (cr, cz, cni),  dGh = dh * (cr, cz, cnh):
+//   a = (1-z)(1-n^2)   cni = a   cnh = a r   cr = a ghn r (1-r)   cz = (h_{t-1} - n) z (1-z)
+// grid = B*S*64/256 blocks of 256 threads (one float4 of units per thread)
+__global__ __launch_bounds__(256) void gru_bwd_coef_kernel(
+    const float* __restrict__ R, const float* __restrict__ Z, const float* __restrict__ N,
+    const float* __restrict__ GHN, const float* __restrict__ y, const float* __restrict__ h0,
+    float* __restrict__ cr, float* __restrict__ cz, float* __restrict__ cnh, float* __restrict__ cni, int B, int S) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * S * 64) return;
+    const int u4 = (int)(idx & 63);
+    const long bt = idx >> 6;
+    const int b = (int)(bt / S), t = (int)(bt - (long)b * S);
+    const long src = bt * kH + 4 * u4;
+    const float4 r = *reinterpret_cast<const float4*>(R + src), z = *reinterpret_cast<const float4*>(Z + src);
+    const float4 n = *reinterpret_cast<const float4*>(N + src), g = *reinterpret_cast<const float4*>(GHN + src);
+    float4 hp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t > 0) hp = *reinterpret_cast<const float4*>(y + src - kH);
+    else if (h0) hp = *reinterpret_cast<const float4*>(h0 + (long)b * kH + 4 * u4);
+    float4 ocr, ocz, onh, oni;
 #pragma unroll
-    for (int base = 0; base < 12; base += 6) {
-        if (base >= nii) break;
-        float4 a[6], bw[6];
-#pragma unroll
-        for (int ii = 0; ii < 6; ++ii) {
-            const bool on = base + ii < nii;
-            a[ii] = (ok && on) ? *reinterpret_cast<const float4*>(arow + koff + 16 * (base + ii)) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bw[ii] = on ? *reinterpret_cast<const float4*>(wrow + koff + 16 * (base + ii)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int ii = 0; ii < 6; ++ii)
-            if (base + ii < nii) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii], jj), f4c(bw[ii], jj), acc, 0, 0, 0);
-            }
+    for (int e = 0; e < 4; ++e) {
+        const float re = f4c(r, e), ze = f4c(z, e), ne = f4c(n, e);
+        const float a = (1.0f - ze) * (1.0f - ne * ne);
+        (&oni.x)[e] = a;
+        (&onh.x)[e] = a * re;
+        (&ocr.x)[e] = a * f4c(g, e) * re * (1.0f - re);
+        (&ocz.x)[e] = (f4c(hp, e) - ne) * ze * (1.0f - ze);
     }
+    const long dst = xtile(t, b >> 4, (B + 15) >> 4, kH) + xpos(b & 15, 4 * u4);
+    *reinterpret_cast<float4*>(cr + dst) = ocr;
+    *reinterpret_cast<float4*>(cz + dst) = ocz;
+    *reinterpret_cast<float4*>(cnh + dst) = onh;
+    *reinterpret_cast<float4*>(cni + dst) = oni;
+}
+
+// acc += G[16 rows x (NU*16 units x 3 gates)] . W^T for this lane's unit fragments: k = g*H + unit0 + 16*ii.
+// Order (ii, g, jj) -- shared with the persistent kernel, which rebuilds G from dh and the coefficients.
+template <int NU>
+__device__ __forceinline__ f32x4 mfma_gate_rows(f32x4 acc, const float* __restrict__ grow, bool ok,
+                                                const float* __restrict__ wrow, int unit0) {
+    float4 a[NU][3], bw[NU][3];
+#pragma unroll
+    for (int ii = 0; ii < NU; ++ii)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int k = g * kH + unit0 + 16 * ii;
+            a[ii][g] = *reinterpret_cast<const float4*>(grow + k);      // grow is valid for every lane (row 0 if !ok)
+            bw[ii][g] = *reinterpret_cast<const float4*>(wrow + k);
+        }
+    if (!ok) {
+#pragma unroll
+        for (int ii = 0; ii < NU; ++ii)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) a[ii][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int ii = 0; ii < NU; ++ii)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii][g], jj), f4c(bw[ii][g], jj), acc, 0, 0, 0);
     return acc;
 }
 
@@ -335,30 +387,29 @@ __global__ __launch_bounds__(512) void gru2_bwd_kernel(Gru2Bwd p, int s) {
     const int b = b0 + row, j = j0 + col;
     const bool gate_thread = tid < 256 && b < B;
     const long bt = (long)b * S + t;
-    float dh0 = 0.f, r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hp = 0.f;
+    float dh0 = 0.f, cr = 0.f, cz = 0.f, cnh = 0.f, cni = 0.f;
     if (gate_thread) {
         if (layer == 1) dh0 = p.dy[bt * kH + j];
         if (has_next) dh0 = fmaf(p.DH[layer][(bt + 1) * kH + j], p.Z[layer][(bt + 1) * kH + j], dh0);
-        r = p.R[layer][bt * kH + j]; z = p.Z[layer][bt * kH + j];
-        n = p.N[layer][bt * kH + j]; ghn = p.GHN[layer][bt * kH + j];
-        hp = t > 0 ? p.y[layer][(bt - 1) * kH + j] : (p.h0[layer] ? p.h0[layer][(long)b * kH + j] : 0.f);
+        const long c = xtile(t, blockIdx.y, gridDim.y, kH) + xpos(row, j);
+        cr = p.cr[layer][c]; cz = p.cz[layer][c]; cnh = p.cnh[layer][c]; cni = p.cni[layer][c];
     }
 
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool bok = (b0 + i) < B;
-    if (layer == 1) {                     // dGh1_{t+1} . W_hh1 over 8 waves, 96 k each
+    if (layer == 1) {                     // dGh1_{t+1} . W_hh1 over 8 waves, 32 units x 3 gates each
         if (has_next) {
-            const float* arow = p.dGh[1] + (bok ? ((long)(b0 + i) * S + t + 1) * kG : 0);
-            acc = mfma_slice1(acc, arow, bok, p.whhT[1] + (long)(j0 + i) * kG, 96 * w + 4 * kq, 6);
+            const float* grow = p.dGh[1] + (bok ? ((long)(b0 + i) * S + t + 1) * kG : 0);
+            acc = mfma_gate_rows<2>(acc, grow, bok, p.whhT[1] + (long)(j0 + i) * kG, 32 * w + 4 * kq);
         }
-    } else if (w < 4) {                   // dGh0_{t+1} . W_hh0, 192 k per wave
+    } else if (w < 4) {                   // dGh0_{t+1} . W_hh0, 64 units x 3 gates per wave
         if (has_next) {
-            const float* arow = p.dGh[0] + (bok ? ((long)(b0 + i) * S + t + 1) * kG : 0);
-            acc = mfma_slice1(acc, arow, bok, p.whhT[0] + (long)(j0 + i) * kG, 192 * w + 4 * kq, 12);
+            const float* grow = p.dGh[0] + (bok ? ((long)(b0 + i) * S + t + 1) * kG : 0);
+            acc = mfma_gate_rows<4>(acc, grow, bok, p.whhT[0] + (long)(j0 + i) * kG, 64 * w + 4 * kq);
         }
     } else {                              // incoming gradient dGi1_t . W_ih1
-        const float* arow = p.dGi[1] + (bok ? ((long)(b0 + i) * S + t) * kG : 0);
-        acc = mfma_slice1(acc, arow, bok, p.wih1T + (long)(j0 + i) * kG, 192 * (w - 4) + 4 * kq, 12);
+        const float* grow = p.dGi[1] + (bok ? ((long)(b0 + i) * S + t) * kG : 0);
+        acc = mfma_gate_rows<4>(acc, grow, bok, p.wih1T + (long)(j0 + i) * kG, 64 * (w - 4) + 4 * kq);
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) part[w][(kq * 4 + rr) * 16 + i] = acc[rr];
@@ -367,16 +418,12 @@ __global__ __launch_bounds__(512) void gru2_bwd_kernel(Gru2Bwd p, int s) {
     const int e = tid;
     const float dh = (((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) +
                       ((part[4][e] + part[5][e]) + (part[6][e] + part[7][e]))) + dh0;
-    const float dn = dh * (1.0f - z);
-    const float dzg = dh * (hp - n);
-    const float dan = dn * (1.0f - n * n);
-    const float daz = dzg * z * (1.0f - z);
-    const float dar = dan * ghn * r * (1.0f - r);
     float* gi = p.dGi[layer] + bt * kG;
     float* gh = p.dGh[layer] + bt * kG;
+    const float dar = dh * cr, daz = dh * cz;
     gi[j] = dar;            gh[j] = dar;
     gi[kH + j] = daz;       gh[kH + j] = daz;
-    gi[2 * kH + j] = dan;   gh[2 * kH + j] = dan * r;
+    gi[2 * kH + j] = dh * cni;   gh[2 * kH + j] = dh * cnh;
     p.DH[layer][bt * kH + j] = dh;
 }
 
@@ -410,30 +457,28 @@ __device__ __forceinline__ void store_coherent(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Exchange buffers.  Polling the (B,S,*) output arrays directly puts the 16 rows of a tile 128 KB (a power
-// of two) apart -- one memory channel -- and costs 3x the hand-over latency; the hand-over therefore goes
-// through a copy laid out in MFMA-fragment order, [step][batch tile][k/4][row 0..15][4 floats]: one wave
-// fetch = 1 KB contiguous, one step of one tile = 16 KB (forward) / 48 KB (backward) contiguous.
-constexpr int kXStride = 4 * 64;                     // floats between a lane's consecutive fragments (k += 16)
-__device__ __forceinline__ long xtile(int t, int tile, int ntiles, int kwidth) {
-    return ((long)t * ntiles + tile) * 16 * kwidth;
-}
-__device__ __forceinline__ int xpos(int row, int k) { return (k >> 2) * 64 + row * 4 + (k & 3); }
-
 // Fetch NII float4 fragments (k += 16 apart) of this lane's row, re-reading until every lane of the wave
 // has complete data.  Lanes whose row is outside the batch contribute zeros.
 template <int NII>
 __device__ __forceinline__ void poll_row(const float* __restrict__ row, bool ok, float4 (&a)[NII], int& budget) {
+    // Unconditional loads (a predicated load costs a branch and a full vmcnt(0) each): rows past the batch
+    // are inside the buffer, never written, and masked out below.
+#pragma unroll
+    for (int ii = 0; ii < NII; ++ii) a[ii] = load4_coherent(row + kXStride * ii);
     for (;;) {
         bool rdy = true;
 #pragma unroll
-        for (int ii = 0; ii < NII; ++ii) {
-            a[ii] = ok ? load4_coherent(row + kXStride * ii) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rdy = rdy && ready4(a[ii]);
-        }
-        if (__all(rdy) || budget <= 0) break;
+        for (int ii = 0; ii < NII; ++ii) rdy = rdy && ready4(a[ii]);
+        if (__all(rdy || !ok) || budget <= 0) break;
         --budget;
         __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int ii = 0; ii < NII; ++ii)                          // re-read only what was incomplete
+            if (ok && !ready4(a[ii])) a[ii] = load4_coherent(row + kXStride * ii);
+    }
+    if (!ok) {
+#pragma unroll
+        for (int ii = 0; ii < NII; ++ii) a[ii] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -587,10 +632,32 @@ __global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_kernel(Gru2F
     else persist_fwd<1>(p, part, id);
 }
 
+template <int NU>
+__device__ __forceinline__ void load_coef(float4 (&cf)[NU][3], const float* __restrict__ c0, const float* __restrict__ c1,
+                                          const float* __restrict__ c2, long off, bool ok) {
+    // rows past the batch hold unwritten (in-bounds) memory; their dh operand is zeroed by poll_row, so the
+    // loads stay unconditional (branch-free) and only NaN/Inf garbage must be kept out of 0 * c
+#pragma unroll
+    for (int ii = 0; ii < NU; ++ii) {
+        cf[ii][0] = *reinterpret_cast<const float4*>(c0 + off + kXStride * ii);
+        cf[ii][1] = *reinterpret_cast<const float4*>(c1 + off + kXStride * ii);
+        cf[ii][2] = *reinterpret_cast<const float4*>(c2 + off + kXStride * ii);
+    }
+    if (!ok) {
+#pragma unroll
+        for (int ii = 0; ii < NU; ++ii)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) cf[ii][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// Backward hand-over carries dh (256 values per row), not the 768 gate gradients: the MFMA waves rebuild
+// their operand fragments as dh * coefficient (the very products the gate threads store to dGi / dGh),
+// which cuts the polled volume -- the cost that sets the step time -- to a third.
 template <int LAYER>
 __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8][256], const PersistIds& id) {
+    constexpr int NU = LAYER == 1 ? 2 : 4;           // unit fragments per lane (x 3 gates = MFMA fragments)
     const int j0 = id.j0, b0 = id.b0;
-    constexpr int NII = LAYER == 1 ? 6 : 12;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int B = p.B, S = p.S;
 
@@ -598,26 +665,42 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
         const int i = lane & 15, kq = lane >> 4;
         const bool bok = (b0 + i) < B;
         const bool recurrent = LAYER == 1 || w < 4;  // dGh_{t+1} . W_hh   (else dGi1_t . W_ih1)
-        const int koff = LAYER == 1 ? 96 * w + 4 * kq : 192 * (w & 3) + 4 * kq;
-        float4 bw[NII];
+        const int unit0 = LAYER == 1 ? 32 * w + 4 * kq : 64 * (w & 3) + 4 * kq;
+        float4 bw[NU][3];
         {
-            const float* wrow = (recurrent ? p.whhT[LAYER] : p.wih1T) + (long)(j0 + i) * kG + koff;
+            const float* wrow = (recurrent ? p.whhT[LAYER] : p.wih1T) + (long)(j0 + i) * kG;
 #pragma unroll
-            for (int ii = 0; ii < NII; ++ii) bw[ii] = *reinterpret_cast<const float4*>(wrow + 16 * ii);
+            for (int ii = 0; ii < NU; ++ii)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    bw[ii][g] = *reinterpret_cast<const float4*>(wrow + g * kH + unit0 + 16 * ii);
         }
-        const float* __restrict__ xsrc = (recurrent ? p.xgh[LAYER] : p.xgi1) + xpos(i, koff);
+        const int sl = recurrent ? LAYER : 1;                     // layer whose dh / coefficients this wave reads
+        const float* __restrict__ c0 = p.cr[sl];
+        const float* __restrict__ c1 = p.cz[sl];
+        const float* __restrict__ c2 = recurrent ? p.cnh[sl] : p.cni[sl];
+        const long lane_off = xpos(i, unit0);
+        const float* __restrict__ xsrc = p.xdh[sl] + lane_off;
+        float4 cf[NU][3];
+        if (!recurrent) load_coef<NU>(cf, c0, c1, c2, xtile(S - 1, id.tile, id.ntiles, kH) + lane_off, bok);
         int budget = kSpinLimit;
         for (int t = S - 1; t >= 0; --t) {
+            const int ts = recurrent ? t + 1 : t;                 // step whose gate gradients are this wave's operand
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!recurrent || (t + 1) < S) {
-                float4 a[NII];
-                poll_row<NII>(xsrc + xtile(recurrent ? t + 1 : t, id.tile, id.ntiles, kG), bok, a, budget);
+            if (ts < S) {
+                float4 dh[NU];
+                poll_row<NU>(xsrc + xtile(ts, id.tile, id.ntiles, kH), bok, dh, budget);
 #pragma unroll
-                for (int ii = 0; ii < NII; ++ii)
+                for (int ii = 0; ii < NU; ++ii)
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii], jj), f4c(bw[ii], jj), acc, 0, 0, 0);
+                    for (int g = 0; g < 3; ++g)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(dh[ii], jj) * f4c(cf[ii][g], jj),
+                                                                       f4c(bw[ii][g], jj), acc, 0, 0, 0);
             }
+            if (t > 0)                                            // next iteration's coefficients: step ts - 1
+                load_coef<NU>(cf, c0, c1, c2, xtile(ts - 1, id.tile, id.ntiles, kH) + lane_off, bok);
             float (&pt)[8][256] = part[t & 1];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) pt[w][(kq * 4 + rr) * 16 + i] = acc[rr];
@@ -628,15 +711,17 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
 
     // ---- gate waves
     const int e = tid - kMfmaWaves * 64;
-    const int b = b0 + (e >> 4), j = j0 + (e & 15);
+    const int row = e >> 4;
+    const int b = b0 + row, j = j0 + (e & 15);
     const bool live = b < B;
-    float dyv = 0.f, r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hp = 0.f;   // operands of the step about to run
+    const int xp = xpos(row, j);
+    float dyv = 0.f, z = 0.f, cr = 0.f, cz = 0.f, cnh = 0.f, cni = 0.f;   // operands of the step about to run
     auto fetch = [&](int t) __attribute__((always_inline)) {
         const long bt = (long)b * S + t;
         if (LAYER == 1) dyv = p.dy[bt * kH + j];
-        r = p.R[LAYER][bt * kH + j]; z = p.Z[LAYER][bt * kH + j];
-        n = p.N[LAYER][bt * kH + j]; ghn = p.GHN[LAYER][bt * kH + j];
-        hp = t > 0 ? p.y[LAYER][(bt - 1) * kH + j] : (p.h0[LAYER] ? p.h0[LAYER][(long)b * kH + j] : 0.f);
+        z = p.Z[LAYER][bt * kH + j];
+        const long c = xtile(t, id.tile, id.ntiles, kH) + xp;
+        cr = p.cr[LAYER][c]; cz = p.cz[LAYER][c]; cnh = p.cnh[LAYER][c]; cni = p.cni[LAYER][c];
     };
     if (live) fetch(S - 1);
     float dh_next = 0.f, z_next = 0.f;
@@ -649,34 +734,21 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
         if ((t + 1) < S) dh0 = fmaf(dh_next, z_next, dh0);
         const float dh = (((pt[0][e] + pt[1][e]) + (pt[2][e] + pt[3][e])) +
                           ((pt[4][e] + pt[5][e]) + (pt[6][e] + pt[7][e]))) + dh0;
-        const float dn = dh * (1.0f - z);
-        const float dzg = dh * (hp - n);
-        const float dan = dn * (1.0f - n * n);
-        const float daz = dzg * z * (1.0f - z);
-        const float dar = dan * ghn * r * (1.0f - r);
+        store_coherent(p.xdh[LAYER] + xtile(t, id.tile, id.ntiles, kH) + xp, dh);   // first: others wait for it
         float* gi = p.dGi[LAYER] + bt * kG;
         float* gh = p.dGh[LAYER] + bt * kG;
-        const int row = e >> 4;
-        float* xh = p.xgh[LAYER] + xtile(t, id.tile, id.ntiles, kG);
-        store_coherent(xh + xpos(row, j), dar);                   // polled by this layer's next step
-        store_coherent(xh + xpos(row, kH + j), daz);
-        store_coherent(xh + xpos(row, 2 * kH + j), dan * r);
-        if (LAYER == 1) {                                         // polled by the layer below
-            float* xi = p.xgi1 + xtile(t, id.tile, id.ntiles, kG);
-            store_coherent(xi + xpos(row, j), dar);
-            store_coherent(xi + xpos(row, kH + j), daz);
-            store_coherent(xi + xpos(row, 2 * kH + j), dan);
-        }
-        gh[j] = dar; gh[kH + j] = daz; gh[2 * kH + j] = dan * r;
-        gi[j] = dar; gi[kH + j] = daz; gi[2 * kH + j] = dan;
+        const float dar = dh * cr, daz = dh * cz;
+        gi[j] = dar;            gh[j] = dar;
+        gi[kH + j] = daz;       gh[kH + j] = daz;
+        gi[2 * kH + j] = dh * cni;   gh[2 * kH + j] = dh * cnh;
         p.DH[LAYER][bt * kH + j] = dh;
         dh_next = dh;
         z_next = z;
-        if (t > 0) fetch(t - 1);                                  // a step ahead: HBM latency off the chain
+        if (t > 0) fetch(t - 1);                                  // a step ahead: memory latency off the chain
     }
 }
 
-// grid / block as the forward; xgh[0], xgh[1] and xgi1 pre-filled with 0xFF bytes
+// grid / block as the forward; xdh[0] and xdh[1] pre-filled with 0xFF bytes
 __global__ __launch_bounds__(kPersistThreads) void gru2_persist_bwd_kernel(Gru2Bwd p) {
     __shared__ float part[2][8][256];
     const PersistIds id;
@@ -691,7 +763,7 @@ struct GruLayout {
     long gi, xh, xh_floats, fwd_total;       // forward scratch (xh: hand-over buffers of the persistent launch)
     long whhT, wihT, dGi, dGh, DH, mid[2], part, tmp;
     long whhT2, wihT2, dGi2, dGh2, DH2;      // second set for the two-layer wavefront
-    long xg, xg_floats;                      // hand-over buffers of the persistent launch (3 x xg_floats)
+    long coef, xdh, frag_floats;             // two-layer path: 8 coefficient arrays, 2 hand-over buffers (fragment order)
     long bwd_total;
 };
 
@@ -728,8 +800,9 @@ static bool gru_layout(int B, int S, int nl, GruLayout& g) {
     g.dGi2 = o; o += align64l((long)B * S * kG);
     g.dGh2 = o; o += align64l((long)B * S * kG);
     g.DH2 = o; o += bsh;
-    g.xg_floats = nl == 2 ? align64l((long)S * tiles16 * kG) : 0;
-    g.xg = o; o += 3 * g.xg_floats;
+    g.frag_floats = nl == 2 ? align64l((long)S * tiles16 * kH) : 0;
+    g.coef = o; o += 8 * g.frag_floats;
+    g.xdh = o; o += 2 * g.frag_floats;
     g.bwd_total = o;
     return true;
 }
@@ -844,6 +917,8 @@ extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* co
         float* DH_[2] = {scratch + g.DH, scratch + g.DH2};
         Gru2Bwd p;
         p.dy = dy; p.B = B; p.S = S;
+        const float* yl[2] = {saved + g.Y[0], y};
+        const float* h0l[2] = {h0, h0 ? h0 + (long)B * kH : nullptr};
         int rc = 0;
         for (int l = 0; l < 2; ++l) {
             rc = transpose(params[4 * l + 1], whhT_[l], kG, kH, st);
@@ -851,17 +926,19 @@ extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* co
             rc = transpose(params[4 * l], wihT_[l], kG, kH, st);
             if (rc) return rc;
             p.whhT[l] = whhT_[l];
-            p.y[l] = l == 1 ? y : saved + g.Y[0];
-            p.h0[l] = h0 ? h0 + (long)l * B * kH : nullptr;
-            p.R[l] = saved + g.R[l]; p.Z[l] = saved + g.Z[l]; p.N[l] = saved + g.N[l]; p.GHN[l] = saved + g.GHN[l];
+            p.Z[l] = saved + g.Z[l];
             p.dGi[l] = dGi_[l]; p.dGh[l] = dGh_[l]; p.DH[l] = DH_[l];
+            float* c = scratch + g.coef + 4 * l * g.frag_floats;
+            p.cr[l] = c; p.cz[l] = c + g.frag_floats; p.cnh[l] = c + 2 * g.frag_floats; p.cni[l] = c + 3 * g.frag_floats;
+            p.xdh[l] = scratch + g.xdh + l * g.frag_floats;
+            hipLaunchKernelGGL(gru_bwd_coef_kernel, dim3(cdiv((long)M * 64, 256)), dim3(256), 0, st, saved + g.R[l],
+                               saved + g.Z[l], saved + g.N[l], saved + g.GHN[l], yl[l], h0l[l], c, c + g.frag_floats,
+                               c + 2 * g.frag_floats, c + 3 * g.frag_floats, B, S);
         }
         p.wih1T = wihT_[1];
-        p.xgh[0] = p.xgh[1] = p.xgi1 = nullptr;
         const int nblocks = 32 * cdiv(B, 16);
         if (g_gru_mode == 1 && fits_resident(gru2_persist_bwd_kernel, nblocks)) {
-            p.xgh[0] = scratch + g.xg; p.xgh[1] = scratch + g.xg + g.xg_floats; p.xgi1 = scratch + g.xg + 2 * g.xg_floats;
-            if (hipMemsetAsync(p.xgh[0], 0xFF, 3 * g.xg_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+            if (hipMemsetAsync(p.xdh[0], 0xFF, 2 * g.frag_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
             hipLaunchKernelGGL(gru2_persist_bwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
         } else {
             const dim3 grid(kH / 16, cdiv(B, 16), 2);
@@ -870,7 +947,7 @@ extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* co
         CPC_LAUNCH_CHECK();
         for (int l = 0; l < 2; ++l) {
             const float* in = l == 0 ? x : saved + g.Y[0];
-            const float* out = p.y[l];
+            const float* out = yl[l];
             const RowMap gim = plain_rows(dGi_[l], M, kG), ghm = plain_rows(dGh_[l], M, kG);
             rc = tn_gemm(gim, kG, plain_rows(in, M, kH), kH, scratch + g.part, grads[4 * l], 0, st);
             if (rc) return rc;
@@ -879,11 +956,11 @@ extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* co
             hm.tmul = 1; hm.tadd = -1; hm.Lin = S; hm.M = M;
             rc = tn_gemm(ghm, kG, hm, kH, scratch + g.part, grads[4 * l + 1], 0, st);
             if (rc) return rc;
-            if (p.h0[l]) {
+            if (h0l[l]) {
                 RowMap g0;
                 g0.base = dGh_[l]; g0.R = 1; g0.bstride = (long)S * kG; g0.rstride = 0; g0.off = 0;
                 g0.tmul = 0; g0.tadd = 0; g0.Lin = 0x7fffffff; g0.M = B;
-                rc = tn_gemm(g0, kG, plain_rows(p.h0[l], B, kH), kH, scratch + g.part, grads[4 * l + 1], 1, st);
+                rc = tn_gemm(g0, kG, plain_rows(h0l[l], B, kH), kH, scratch + g.part, grads[4 * l + 1], 1, st);
                 if (rc) return rc;
             }
             rc = rows_sum(dGi_[l], M, kG, scratch + g.tmp, grads[4 * l + 2], st);
