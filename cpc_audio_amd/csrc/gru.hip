@@ -307,16 +307,26 @@ struct Gru2Bwd {
 // Everything in the gate derivatives that does not depend on dh, for all (b, t, j) at once and in fragment
 // order, so that the recurrence itself is   dGi = dh * (cr, cz, cni),  dGh = dh * (cr, cz, cnh):
 //   a = (1-z)(1-n^2)   cni = a   cnh = a r   cr = a ghn r (1-r)   cz = (h_{t-1} - n) z (1-z)
-// grid = B*S*64/256 blocks of 256 threads (one float4 of units per thread)
+// grid = ceil(B/16)*16*S*64/256 blocks of 256 threads (one float4 of units per thread)
 __global__ __launch_bounds__(256) void gru_bwd_coef_kernel(
     const float* __restrict__ R, const float* __restrict__ Z, const float* __restrict__ N,
     const float* __restrict__ GHN, const float* __restrict__ y, const float* __restrict__ h0,
     float* __restrict__ cr, float* __restrict__ cz, float* __restrict__ cnh, float* __restrict__ cni, int B, int S) {
+    const int ntiles = (B + 15) >> 4;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)B * S * 64) return;
+    if (idx >= (long)ntiles * 16 * S * 64) return;
     const int u4 = (int)(idx & 63);
     const long bt = idx >> 6;
     const int b = (int)(bt / S), t = (int)(bt - (long)b * S);
+    const long dst = xtile(t, b >> 4, ntiles, kH) + xpos(b & 15, 4 * u4);
+    if (b >= B) {                                    // padding rows of the last tile: zero, so that the
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);      // recurrence can load them unconditionally
+        *reinterpret_cast<float4*>(cr + dst) = zero;
+        *reinterpret_cast<float4*>(cz + dst) = zero;
+        *reinterpret_cast<float4*>(cnh + dst) = zero;
+        *reinterpret_cast<float4*>(cni + dst) = zero;
+        return;
+    }
     const long src = bt * kH + 4 * u4;
     const float4 r = *reinterpret_cast<const float4*>(R + src), z = *reinterpret_cast<const float4*>(Z + src);
     const float4 n = *reinterpret_cast<const float4*>(N + src), g = *reinterpret_cast<const float4*>(GHN + src);
@@ -333,7 +343,6 @@ __global__ __launch_bounds__(256) void gru_bwd_coef_kernel(
         (&ocr.x)[e] = a * f4c(g, e) * re * (1.0f - re);
         (&ocz.x)[e] = (f4c(hp, e) - ne) * ze * (1.0f - ze);
     }
-    const long dst = xtile(t, b >> 4, (B + 15) >> 4, kH) + xpos(b & 15, 4 * u4);
     *reinterpret_cast<float4*>(cr + dst) = ocr;
     *reinterpret_cast<float4*>(cz + dst) = ocz;
     *reinterpret_cast<float4*>(cnh + dst) = onh;
@@ -341,7 +350,8 @@ __global__ __launch_bounds__(256) void gru_bwd_coef_kernel(
 }
 
 // acc += G[16 rows x (NU*16 units x 3 gates)] . W^T for this lane's unit fragments: k = g*H + unit0 + 16*ii.
-// Order (ii, g, jj) -- shared with the persistent kernel, which rebuilds G from dh and the coefficients.
+// One accumulator per gate, each in (ii, jj) order, combined as (r + z) + n -- shared with the persistent
+// kernel, which rebuilds G from dh and the coefficients.
 template <int NU>
 __device__ __forceinline__ f32x4 mfma_gate_rows(f32x4 acc, const float* __restrict__ grow, bool ok,
                                                 const float* __restrict__ wrow, int unit0) {
@@ -360,14 +370,17 @@ __device__ __forceinline__ f32x4 mfma_gate_rows(f32x4 acc, const float* __restri
 #pragma unroll
             for (int g = 0; g < 3; ++g) a[ii][g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    f32x4 ag[3];                                     // one chain per gate: three independent MFMA streams
+#pragma unroll
+    for (int g = 0; g < 3; ++g) ag[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ii = 0; ii < NU; ++ii)
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii][g], jj), f4c(bw[ii][g], jj), acc, 0, 0, 0);
-    return acc;
+            for (int g = 0; g < 3; ++g)
+                ag[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii][g], jj), f4c(bw[ii][g], jj), ag[g], 0, 0, 0);
+    return acc + ((ag[0] + ag[1]) + ag[2]);
 }
 
 // Launch s (s = 0..S): blockIdx.z = 0 -> top layer (1) step t = S-1-s; blockIdx.z = 1 -> bottom
@@ -501,11 +514,11 @@ __device__ __forceinline__ void load_gate_weights(float4 (&bw)[3][NII], const fl
 template <int NII>
 __device__ __forceinline__ void mfma_gates(f32x4 (&acc)[3], const float4 (&a)[NII], const float4 (&bw)[3][NII]) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int ii = 0; ii < NII; ++ii)
 #pragma unroll
-        for (int ii = 0; ii < NII; ++ii)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int g = 0; g < 3; ++g)              // three independent chains back to back
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii], jj), f4c(bw[g][ii], jj), acc[g], 0, 0, 0);
 }
 
@@ -634,20 +647,14 @@ __global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_kernel(Gru2F
 
 template <int NU>
 __device__ __forceinline__ void load_coef(float4 (&cf)[NU][3], const float* __restrict__ c0, const float* __restrict__ c1,
-                                          const float* __restrict__ c2, long off, bool ok) {
-    // rows past the batch hold unwritten (in-bounds) memory; their dh operand is zeroed by poll_row, so the
-    // loads stay unconditional (branch-free) and only NaN/Inf garbage must be kept out of 0 * c
+                                          const float* __restrict__ c2, long off) {
+    // unconditional and unmasked (the coefficient kernel zero-fills the padding rows): nothing here may
+    // depend on the loaded values, or their latency lands in front of the barrier
 #pragma unroll
     for (int ii = 0; ii < NU; ++ii) {
         cf[ii][0] = *reinterpret_cast<const float4*>(c0 + off + kXStride * ii);
         cf[ii][1] = *reinterpret_cast<const float4*>(c1 + off + kXStride * ii);
         cf[ii][2] = *reinterpret_cast<const float4*>(c2 + off + kXStride * ii);
-    }
-    if (!ok) {
-#pragma unroll
-        for (int ii = 0; ii < NU; ++ii)
-#pragma unroll
-            for (int g = 0; g < 3; ++g) cf[ii][g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -682,7 +689,7 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
         const long lane_off = xpos(i, unit0);
         const float* __restrict__ xsrc = p.xdh[sl] + lane_off;
         float4 cf[NU][3];
-        if (!recurrent) load_coef<NU>(cf, c0, c1, c2, xtile(S - 1, id.tile, id.ntiles, kH) + lane_off, bok);
+        if (!recurrent) load_coef<NU>(cf, c0, c1, c2, xtile(S - 1, id.tile, id.ntiles, kH) + lane_off);
         int budget = kSpinLimit;
         for (int t = S - 1; t >= 0; --t) {
             const int ts = recurrent ? t + 1 : t;                 // step whose gate gradients are this wave's operand
@@ -690,17 +697,21 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
             if (ts < S) {
                 float4 dh[NU];
                 poll_row<NU>(xsrc + xtile(ts, id.tile, id.ntiles, kH), bok, dh, budget);
+                f32x4 ag[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) ag[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ii = 0; ii < NU; ++ii)
 #pragma unroll
-                    for (int g = 0; g < 3; ++g)
+                    for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(dh[ii], jj) * f4c(cf[ii][g], jj),
-                                                                       f4c(bw[ii][g], jj), acc, 0, 0, 0);
+                        for (int g = 0; g < 3; ++g)
+                            ag[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(dh[ii], jj) * f4c(cf[ii][g], jj),
+                                                                         f4c(bw[ii][g], jj), ag[g], 0, 0, 0);
+                acc = acc + ((ag[0] + ag[1]) + ag[2]);
             }
             if (t > 0)                                            // next iteration's coefficients: step ts - 1
-                load_coef<NU>(cf, c0, c1, c2, xtile(ts - 1, id.tile, id.ntiles, kH) + lane_off, bok);
+                load_coef<NU>(cf, c0, c1, c2, xtile(ts - 1, id.tile, id.ntiles, kH) + lane_off);
             float (&pt)[8][256] = part[t & 1];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) pt[w][(kq * 4 + rr) * 16 + i] = acc[rr];
@@ -931,7 +942,7 @@ extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* co
             float* c = scratch + g.coef + 4 * l * g.frag_floats;
             p.cr[l] = c; p.cz[l] = c + g.frag_floats; p.cnh[l] = c + 2 * g.frag_floats; p.cni[l] = c + 3 * g.frag_floats;
             p.xdh[l] = scratch + g.xdh + l * g.frag_floats;
-            hipLaunchKernelGGL(gru_bwd_coef_kernel, dim3(cdiv((long)M * 64, 256)), dim3(256), 0, st, saved + g.R[l],
+            hipLaunchKernelGGL(gru_bwd_coef_kernel, dim3(cdiv((long)cdiv(B, 16) * 16 * S * 64, 256)), dim3(256), 0, st, saved + g.R[l],
                                saved + g.Z[l], saved + g.N[l], saved + g.GHN[l], yl[l], h0l[l], c, c + g.frag_floats,
                                c + 2 * g.frag_floats, c + 3 * g.frag_floats, B, S);
         }
