@@ -95,12 +95,13 @@ def get():
     if _bound is None:
         with _lock:
             if _bound is None:
-                if not os.path.exists(LIB_PATH):
+                path = os.environ.get("CPC_HIP_LIB", LIB_PATH)      # developer override: another build of the same ABI
+                if not os.path.exists(path):
                     raise CpcHipError(
-                        f"{LIB_PATH} not found: build it with `python -m cpc_audio_amd.build` "
+                        f"{path} not found: build it with `python -m cpc_audio_amd.build` "
                         "(hipcc, gfx950).  There is no CPU fallback.")
                 import torch  # noqa: F401  (loads torch's libamdhip64 first so both share one HIP runtime)
-                _bound = bind(LIB_PATH)
+                _bound = bind(path)
     return _bound
 
 

@@ -30,7 +30,9 @@
 namespace cpc {
 
 // ------------------------------------------------------------------ weight re-layouts
-// (O,I,W) -> Wp[co][kk*C + ci]  (K-major rows for the forward NT GEMM).
+// (O,I,W) -> Wp(co, kg = kk*C + ci) for the forward NT GEMM, stored k-blocked: [kg/16][co][kg%16], so that the
+// B tile of one 16-k chunk (256 rows x 64 B) is ONE contiguous 16 KB block instead of 256 half cache lines
+// 8 KB apart (all CUs walk k in lockstep and would hammer the same few L2 channels).
 // split != 0: Wp is written as three bf16 planes [3][total] (the pre-split B operand of NtTileX3).
 __global__ __launch_bounds__(256) void permute_w_fwd_kernel(const float* __restrict__ w,
                                                             float* __restrict__ wp, int k, int split) {
@@ -41,19 +43,21 @@ __global__ __launch_bounds__(256) void permute_w_fwd_kernel(const float* __restr
     const int rem = (int)(idx - (long)co * k * kC);
     const int kk = rem >> kCLog2, ci = rem & (kC - 1);
     const float v = w[((long)co * kC + ci) * k + kk];
+    const long dst = ((long)(rem >> 4) * kC + co) * 16 + (rem & 15);
     if (split) {
         unsigned h, m, l;
         split3(v, h, m, l);
         unsigned short* o = reinterpret_cast<unsigned short*>(wp);
-        o[idx] = (unsigned short)(h >> 16);
-        o[total + idx] = (unsigned short)(m >> 16);
-        o[2 * total + idx] = (unsigned short)(l >> 16);
+        o[dst] = (unsigned short)(h >> 16);
+        o[total + dst] = (unsigned short)(m >> 16);
+        o[2 * total + dst] = (unsigned short)(l >> 16);
     } else {
-        wp[idx] = v;
+        wp[dst] = v;
     }
 }
 
-// (O,I,W) -> Wd[r][ci][j*C + co] = W[co][ci][r + (1-j)*s],  r < s, j in {0,1}
+// (O,I,W) -> Wd[r](ci, kg = j*C + co) = W[co][ci][r + (1-j)*s],  r < s, j in {0,1}; each phase r k-blocked
+// like Wp: [kg/16][ci][kg%16]
 __global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __restrict__ w,
                                                               float* __restrict__ wd, int s, int split) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -66,15 +70,16 @@ __global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __res
     const int jc = rem - ci * 2 * kC;
     const int j = jc >> kCLog2, co = jc & (kC - 1);
     const float v = w[((long)co * kC + ci) * k + r + (1 - j) * s];
+    const long dst = (long)r * kC * 2 * kC + ((long)(jc >> 4) * kC + ci) * 16 + (jc & 15);
     if (split) {
         unsigned h, m, l;
         split3(v, h, m, l);
         unsigned short* o = reinterpret_cast<unsigned short*>(wd);
-        o[idx] = (unsigned short)(h >> 16);
-        o[total + idx] = (unsigned short)(m >> 16);
-        o[2 * total + idx] = (unsigned short)(l >> 16);
+        o[dst] = (unsigned short)(h >> 16);
+        o[total + dst] = (unsigned short)(m >> 16);
+        o[2 * total + dst] = (unsigned short)(l >> 16);
     } else {
-        wd[idx] = v;
+        wd[dst] = v;
     }
 }
 
@@ -103,8 +108,9 @@ __global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 
     const int m0 = blockIdx.x * BM;
     f32x16 acc[TM][TN];
     zero_acc(acc);
-    if constexpr (X3) Tile::run(acc, am, m0, wp, K, 0, K, smem, (long)kC * K);   // plane stride used only if pre-split
-    else Tile::run(acc, am, m0, wp, K, 0, K, smem);
+    if constexpr (X3) Tile::run(acc, am, m0, wp, 16, 0, K, smem, (long)kC * K, kC * 16,    // plane stride used only if pre-split
+                                (int)((blockIdx.x * 4u) % (unsigned)(K / Tile::BK)));
+    else Tile::run(acc, am, m0, wp, 16, 0, K, smem, kC * 16);
 
     const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 3;
     int col[TN];
@@ -260,9 +266,11 @@ __global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 
     zero_acc(acc);
     if constexpr (X3 && ConvCfg<BM, X3>::kPreSplitW)   // wd = 3 bf16 planes of [s][256][512]
         Tile::run(acc, am, m0, reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(wd) + (long)ph * kC * 2 * kC),
-                  2 * kC, 0, 2 * kC, smem, (long)s * kC * 2 * kC);
+                  16, 0, 2 * kC, smem, (long)s * kC * 2 * kC, kC * 16);
+    else if constexpr (X3)
+        Tile::run(acc, am, m0, wd + (long)ph * kC * 2 * kC, 16, 0, 2 * kC, smem, 0, kC * 16);
     else
-        Tile::run(acc, am, m0, wd + (long)ph * kC * 2 * kC, 2 * kC, 0, 2 * kC, smem);
+        Tile::run(acc, am, m0, wd + (long)ph * kC * 2 * kC, 16, 0, 2 * kC, smem, kC * 16);
 
     const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 3;
     int col[TN];

@@ -111,6 +111,15 @@ __device__ __forceinline__ float4 load_row4(const RowRef& r, int k, int Lin, con
     return v;
 }
 
+// Same, but the zeroing is left to the consumer (`ok` travels with the data): a select right behind the load
+// would make the compiler wait for the load one pipeline stage after issuing it instead of four.
+__device__ __forceinline__ float4 load_row4_raw(const RowRef& r, int k, int Lin, const float* safe, bool& ok) {
+    const int tau = r.tau0 + (k >> kCLog2);
+    ok = (unsigned)tau < (unsigned)Lin;
+    const float* p = ok ? r.ptr + k : safe;
+    return *reinterpret_cast<const float4*>(p);
+}
+
 __device__ __forceinline__ float f4c(const float4& v, int j) {
     return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
 }
@@ -143,9 +152,11 @@ struct NtTile {
         return (wave % WAVES_N) * WN + tn * 32 + (lane & 31);
     }
 
+    // bblk: floats between consecutive 16-k groups of a B row: 16 for a plain row-major B (ldb = K), N*16 for
+    // the k-blocked layout [k/16][n][16] (ldb = 16), where one chunk of all rows is one contiguous block
     __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int m0,
                                const float* __restrict__ Bmat, int ldb, int n0, int K,
-                               float* smem) {
+                               float* smem, int bblk = 16) {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
@@ -181,7 +192,7 @@ auto gload = [&](int kc_) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) ra[i] = load_row4(ar[i], k0 + a_k[i], am.Lin, am.base);
 #pragma unroll
-            for (int i = 0; i < B_PER; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+            for (int i = 0; i < B_PER; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + (long)kc_ * bblk);
         };
         auto sstore = [&](int st_) __attribute__((always_inline)) {
             float* s0 = smem + st_ * STAGE;
@@ -281,10 +292,10 @@ __device__ __forceinline__ void split3_pack4(const float4& v, uint2& ph, uint2& 
 // transposing TN loader does that to keep its 8-byte column stores bank-conflict free).
 struct BSplitReg { uint2 h, m, l; };      // a 4-k group of a pre-split operand: three planes x four bf16
 
-__device__ __forceinline__ void load_b(float4& dst, const float* p32, const unsigned short*, int k0, long) {
+__device__ __forceinline__ void load_b(float4& dst, const float* p32, const unsigned short*, long k0, long) {
     dst = *reinterpret_cast<const float4*>(p32 + k0);
 }
-__device__ __forceinline__ void load_b(BSplitReg& dst, const float*, const unsigned short* p16, int k0, long plane) {
+__device__ __forceinline__ void load_b(BSplitReg& dst, const float*, const unsigned short* p16, long k0, long plane) {
     dst.h = *reinterpret_cast<const uint2*>(p16 + k0);
     dst.m = *reinterpret_cast<const uint2*>(p16 + plane + k0);
     dst.l = *reinterpret_cast<const uint2*>(p16 + 2 * plane + k0);
@@ -342,6 +353,7 @@ struct NtTileX3 {
     static constexpr int A_SLOTS = BM * (BK / 4), B_SLOTS = BN * (BK / 4);
     static constexpr int A_PER = (A_SLOTS + NTHREADS - 1) / NTHREADS;
     static constexpr int B_PER = (B_SLOTS + NTHREADS - 1) / NTHREADS;
+    static constexpr bool A_EXACT = A_SLOTS % NTHREADS == 0, B_EXACT = B_SLOTS % NTHREADS == 0;   // no partial slot
     static constexpr int PLANE_A = BM * LDH, PLANE_B = BN * LDH;          // halves
     static constexpr int STAGE_H = 3 * (PLANE_A + PLANE_B);               // halves per stage
     static constexpr int SMEM_FLOATS = STAGES * STAGE_H / 2;
@@ -359,7 +371,10 @@ struct NtTileX3 {
 
     __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int m0,
                                const float* __restrict__ Bmat, int ldb, int n0, int K,
-                               float* smem_f, long bplane = 0) {
+                               float* smem_f, long bplane = 0, int bblk = 16, int rot = 0) {     // bblk: see NtTile::run
+        // rot (pipelined schedule only): this workgroup walks the K chunks starting at chunk `rot` (mod K/BK).
+        // All workgroups of a conv layer otherwise read the same 64-byte channel slice of rows that are a
+        // multiple of 1 KB apart at the same moment, i.e. one L2 channel out of 16.
         unsigned short* smem0 = reinterpret_cast<unsigned short*>(smem_f);
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -385,8 +400,9 @@ struct NtTileX3 {
             const int slot = tid + i * NTHREADS;
             b_on[i] = slot < B_SLOTS;
             const int r = b_on[i] ? (slot / SPR) : 0, kv = slot % SPR;
-            bp[i] = Bmat + (long)(n0 + r) * ldb + kv * 4;
-            bp16[i] = reinterpret_cast<const unsigned short*>(Bmat) + (long)(n0 + r) * ldb + kv * 4;
+            const long bo = (long)(n0 + r) * ldb + (long)(kv >> 2) * bblk + (kv & 3) * 4;
+            bp[i] = Bmat + bo;
+            bp16[i] = reinterpret_cast<const unsigned short*>(Bmat) + bo;
             b_lds[i] = 3 * PLANE_A + r * LDH + kv * 4;
         }
         using BReg = typename std::conditional<BSPLIT, BSplitReg, float4>::type;
@@ -394,19 +410,21 @@ struct NtTileX3 {
         BReg rb[B_PER], rb1[B_PER];                // second register set for the deep-prefetch schedule
         const int nk = K / BK;
 
-        auto gload_to = [&](int kc_, float4 (&ra_)[A_PER], BReg (&rb_)[B_PER]) __attribute__((always_inline)) {
+        auto gload_to = [&](int kc0_, float4 (&ra_)[A_PER], BReg (&rb_)[B_PER]) __attribute__((always_inline)) {
+            int kc_ = kc0_ + rot;
+            kc_ = kc_ >= nk ? kc_ - nk : kc_;
             const int k0 = kc_ * BK;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) ra_[i] = load_row4(ar[i], k0 + a_k[i], am.Lin, am.base);
 #pragma unroll
-            for (int i = 0; i < B_PER; ++i) load_b(rb_[i], bp[i], bp16[i], k0, bplane);
+            for (int i = 0; i < B_PER; ++i) load_b(rb_[i], bp[i], bp16[i], (long)kc_ * (BK / 16) * bblk, bplane);
         };
         auto sstore_from = [&](int st_, const float4 (&ra)[A_PER], const BReg (&rb)[B_PER]) __attribute__((always_inline)) {
             unsigned short* smem = smem0 + st_ * STAGE_H;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
-                if (a_on[i]) {
-                    uint2 ph, pm, pl;
+                if (A_EXACT || a_on[i]) {            // exact tilings stay branch-free: one basic block, so the
+                    uint2 ph, pm, pl;                //  split can be scheduled into the MFMA shadow
                     split3_pack4(ra[i], ph, pm, pl);
                     *reinterpret_cast<uint2*>(smem + a_lds[i]) = ph;
                     *reinterpret_cast<uint2*>(smem + PLANE_A + a_lds[i]) = pm;
@@ -414,7 +432,7 @@ struct NtTileX3 {
                 }
 #pragma unroll
             for (int i = 0; i < B_PER; ++i)
-                if (b_on[i]) {
+                if (B_EXACT || b_on[i]) {
                     uint2 ph, pm, pl;
                     planes_of(rb[i], ph, pm, pl);
                     *reinterpret_cast<uint2*>(smem + b_lds[i]) = ph;
@@ -432,42 +450,122 @@ struct NtTileX3 {
 
         auto gload = [&](int kc_) __attribute__((always_inline)) { gload_to(kc_, ra, rb); };
         auto sstore = [&](int st_) __attribute__((always_inline)) { sstore_from(st_, ra, rb); };
-        if (STAGES == 2 && SKEW) {
-            // Deep prefetch: the per-CU global-load rate is (bytes in flight) / latency (~2 us under load),
-            // so FOUR 16-k chunks are kept in flight in four register sets (96 KB per CU at 128 x 256)
-            // instead of one 32-k chunk (48 KB).  Two LDS stages; one barrier per chunk:
-            //   compute(stage kc&1) | split+store chunk kc+1 -> other stage | load chunk kc+4 | barrier
+        if constexpr (STAGES == 2 && SKEW) {
+            // Software pipeline over 16-k chunks, one barrier per chunk.  In iteration kc a wave
+            //   * issues the LDS reads of chunk kc+1's fragments (other stage, second fragment register set),
+            //   * runs the 6 x TM x TN MFMAs of chunk kc from fragments fetched one iteration earlier,
+            //   * splits chunk kc+2 (VALU) and stores it over chunk kc's stage (free: everybody holds kc in regs),
+            //   * issues the global loads of chunk kc+6;
+            // so LDS reads, VALU and stores all sit in the MFMA shadow (sched_group_barrier below) and neither
+            // LDS latency nor its bandwidth (98 KB of fragment reads per chunk per CU) is exposed after the
+            // barrier.  Global prefetch depth: four register sets = chunks kc+2 .. kc+5 in flight (the per-CU
+            // load rate is bytes-in-flight / latency, ~2 us under load).
+            static_assert(BK == 16, "pipelined schedule is written for one k-step per chunk");
             float4 ra2[A_PER], ra3[A_PER];
             BReg rb2[B_PER], rb3[B_PER];
-            gload_to(0, ra, rb);
-            gload_to(min(1, nk - 1), ra1, rb1);
-            gload_to(min(2, nk - 1), ra2, rb2);
-            gload_to(min(3, nk - 1), ra3, rb3);
-            sstore_from(0, ra, rb);
+            bf16x8 fa[2][TM][3], fb[2][TN][3];
+            auto lfrag = [&](int st_, bf16x8 (&af)[TM][3], bf16x8 (&bf)[TN][3]) __attribute__((always_inline)) {
+                const unsigned short* As = smem0 + st_ * STAGE_H;
+                const unsigned short* Bs = As + 3 * PLANE_A;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[tm][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(
+                                                                     As + pl * PLANE_A + (arow + tm * 32) * LDH + kofs));
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bf[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(
+                                                                     Bs + pl * PLANE_B + (brow + tn * 32) * LDH + kofs));
+            };
+            auto mfma6 = [&](const bf16x8 (&af)[TM][3], const bf16x8 (&bf)[TN][3]) __attribute__((always_inline)) {
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0};      // (A piece, B piece): l*h, h*l, m*m, m*h, h*m, h*h
+                constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][PA[q]], bf[tn][PB[q]], acc[tm][tn], 0, 0, 0);
+            };
+            auto interleave = [&]() __attribute__((always_inline)) {
+                constexpr int NMFMA = TM * TN * 6;
+                constexpr int NRD = 3 * (TM + TN);                         // ds_read_b128 per chunk
+                constexpr int NWR = 3 * (A_PER + B_PER);                   // 8-byte LDS stores per chunk
+#pragma unroll
+                for (int q = 0; q < NMFMA; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+                    if (q < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // VALU
+                    if (q % 8 == 7 && q / 8 < NWR / 3) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);   // DS write
+                    if (q % 8 == 3 && q / 8 < A_PER + B_PER) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                }
+            };
+            bool va[A_PER], va1[A_PER], va2[A_PER], va3[A_PER];
+            auto gload_raw = [&](int kc0_, float4 (&ra_)[A_PER], BReg (&rb_)[B_PER], bool (&ok_)[A_PER]) __attribute__((always_inline)) {
+                int kc_ = kc0_ + rot;
+                kc_ = kc_ >= nk ? kc_ - nk : kc_;
+                const int k0 = kc_ * BK;
+#pragma unroll
+                for (int i = 0; i < A_PER; ++i) ra_[i] = load_row4_raw(ar[i], k0 + a_k[i], am.Lin, am.base, ok_[i]);
+#pragma unroll
+                for (int i = 0; i < B_PER; ++i) load_b(rb_[i], bp[i], bp16[i], (long)kc_ * (BK / 16) * bblk, bplane);
+            };
+            auto sstore_m = [&](int st_, const float4 (&ra_)[A_PER], const BReg (&rb_)[B_PER], const bool (&ok_)[A_PER]) __attribute__((always_inline)) {
+                float4 rz[A_PER];
+#pragma unroll
+                for (int i = 0; i < A_PER; ++i) {
+                    rz[i].x = ok_[i] ? ra_[i].x : 0.f; rz[i].y = ok_[i] ? ra_[i].y : 0.f;
+                    rz[i].z = ok_[i] ? ra_[i].z : 0.f; rz[i].w = ok_[i] ? ra_[i].w : 0.f;
+                }
+                sstore_from(st_, rz, rb_);
+            };
+            gload_raw(0, ra, rb, va);
+            gload_raw(min(1, nk - 1), ra1, rb1, va1);
+            sstore_m(0, ra, rb, va);
+            sstore_m(1, ra1, rb1, va1);
+            gload_raw(min(2, nk - 1), ra, rb, va);
+            gload_raw(min(3, nk - 1), ra1, rb1, va1);
+            gload_raw(min(4, nk - 1), ra2, rb2, va2);
+            gload_raw(min(5, nk - 1), ra3, rb3, va3);
             __syncthreads();
-            int kc = 0;
-            for (;;) {
-                // kc % 4 == 0: store set 1, reload set 0
-                compute(0);
-                sstore_from(1, ra1, rb1);
-                gload_to(min(kc + 4, nk - 1), ra, rb);
+            lfrag(0, fa[0], fb[0]);
+            __syncthreads();        // phase 0 overwrites stage 0: every wave must hold chunk 0's fragments first
+            // nk is a multiple of 4 for every caller (K = 512, 1024, 2048): the four phases form ONE basic block,
+            // so the prefetch loads cannot be sunk into a later phase (which is what the compiler does with
+            // early exits between the phases: one vmcnt(0) drain and a burst of 9 loads every 4 chunks).
+            for (int kc = 0; kc < nk; kc += 4) {
+                lfrag(1, fa[1], fb[1]);
+                mfma6(fa[0], fb[0]);
+                sstore_m(0, ra, rb, va);
+                gload_raw(min(kc + 6, nk - 1), ra, rb, va);
+                interleave();
                 __syncthreads();
-                if (++kc >= nk) break;
-                compute(1);
-                sstore_from(0, ra2, rb2);
-                gload_to(min(kc + 4, nk - 1), ra1, rb1);
+                __builtin_amdgcn_sched_barrier(0);          // nothing moves across a phase boundary
+                lfrag(0, fa[0], fb[0]);
+                mfma6(fa[1], fb[1]);
+                sstore_m(1, ra1, rb1, va1);
+                gload_raw(min(kc + 7, nk - 1), ra1, rb1, va1);
+                interleave();
                 __syncthreads();
-                if (++kc >= nk) break;
-                compute(0);
-                sstore_from(1, ra3, rb3);
-                gload_to(min(kc + 4, nk - 1), ra2, rb2);
+                __builtin_amdgcn_sched_barrier(0);
+                lfrag(1, fa[1], fb[1]);
+                mfma6(fa[0], fb[0]);
+                sstore_m(0, ra2, rb2, va2);
+                gload_raw(min(kc + 8, nk - 1), ra2, rb2, va2);
+                interleave();
                 __syncthreads();
-                if (++kc >= nk) break;
-                compute(1);
-                sstore_from(0, ra, rb);
-                gload_to(min(kc + 4, nk - 1), ra3, rb3);
+                __builtin_amdgcn_sched_barrier(0);
+                lfrag(0, fa[0], fb[0]);
+                mfma6(fa[1], fb[1]);
+                sstore_m(1, ra3, rb3, va3);
+                gload_raw(min(kc + 9, nk - 1), ra3, rb3, va3);
+                interleave();
                 __syncthreads();
-                if (++kc >= nk) break;
+                __builtin_amdgcn_sched_barrier(0);
             }
             return;
         }

@@ -307,6 +307,7 @@ static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...)                  \
     do {                                                                            \
