@@ -37,6 +37,11 @@ SIGNATURES = {
     "cpc_gemm_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "cpc_gemm_tn_scratch_floats": (_L, [_I, _I, _I]),
     "cpc_gemm_tn": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "cpc_nce_scores_forward": (_I, [_P] * 7 + [_I, _I, _I, _I, _P]),
+    "cpc_nce_scores_backward": (_I, [_P] * 10 + [_I, _I, _I, _I, _P]),
+    "cpc_transformer_layout": (_I, [_I, _I, _P]),
+    "cpc_transformer_layer_forward": (_I, [_P] * 5 + [_I, _I, _P]),
+    "cpc_transformer_layer_backward": (_I, [_P] * 7 + [_I, _I, _P]),
     "cpc_gru_layout": (_I, [_I, _I, _I, _P]),
     "cpc_gru_forward": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "cpc_gru_backward": (_I, [_P] * 9 + [_I, _I, _I, _P]),

@@ -8,19 +8,22 @@ fused InfoNCE kernels of libcpc_hip.so; negatives are never materialised.
 import torch
 import torch.nn as nn
 
-from .ops import InfoNCEFunction, prepare_negatives
+from .ops import InfoNCEFunction, InfoNCEScoresFunction, prepare_negatives
 
 
 class PredictionNetwork(nn.Module):
-    """cpc/criterion/criterion.py:44-118, linear heads (the ``else`` branch at :89-95, i.e.
-    ``--rnnMode linear``): K bias-free nn.Linear(dimOutputAR, dimOutputEncoder)."""
+    """cpc/criterion/criterion.py:44-118: K prediction networks.  ``--rnnMode linear`` (the ``else`` branch at
+    :89-95, north-star configuration): K bias-free nn.Linear(dimOutputAR, dimOutputEncoder) fused into the
+    criterion kernels; ``--rnnMode transformer`` (:82-88, BASELINE.json config 4): K one-layer transformers
+    ``buildTransformerAR(dimOutputEncoder, 1, sizeInputSeq, False)`` on the HIP transformer layer
+    (``transformerDropout`` is an addition -- the reference's layers always use 0.1, which has no parity)."""
 
     def __init__(self, nPredicts, dimOutputAR, dimOutputEncoder, rnnMode=None, dropout=False,
-                 sizeInputSeq=116):
+                 sizeInputSeq=116, transformerDropout=0.1):
         super().__init__()
-        if rnnMode in ("RNN", "LSTM", "ffd", "conv4", "conv8", "conv12", "transformer"):
-            raise NotImplementedError(f"rnnMode={rnnMode!r}: the HIP criterion implements the linear "
-                                      "prediction heads (--rnnMode linear, the north-star configuration)")
+        if rnnMode in ("RNN", "LSTM", "ffd", "conv4", "conv8", "conv12"):
+            raise NotImplementedError(f"rnnMode={rnnMode!r}: the HIP criterion implements the linear prediction heads "
+                                      "(--rnnMode linear) and the transformer predictors (--rnnMode transformer)")
         if dropout:
             raise NotImplementedError("dropout on the predictions is not implemented in the fused criterion")
         if dimOutputAR != 256 or dimOutputEncoder != 256:
@@ -31,8 +34,18 @@ class PredictionNetwork(nn.Module):
         self.RESIDUAL_STD = 0.01
         self.dimOutputAR = dimOutputAR
         self.dropout = None
+        self.rnnMode = rnnMode
         for _ in range(nPredicts):
-            self.predictors.append(nn.Linear(dimOutputAR, dimOutputEncoder, bias=False))
+            if rnnMode == "transformer":
+                from .transformers import buildTransformerAR
+                self.predictors.append(buildTransformerAR(dimOutputEncoder, 1, sizeInputSeq, False,
+                                                          dropout=transformerDropout))
+            else:
+                self.predictors.append(nn.Linear(dimOutputAR, dimOutputEncoder, bias=False))
+
+    def predictions(self, c):
+        """c (B,W,256) -> (B,W,K*256): head k at columns k*256.. (the layout the score kernels read)."""
+        return torch.cat([p(c) for p in self.predictors], dim=2)
 
     def stacked_weight(self):
         """(K*256, 256): the K head weights stacked along the output dimension."""
@@ -73,14 +86,16 @@ class CPCUnsupersivedCriterion(BaseCriterion):
                  dropout=False,
                  speakerEmbedding=0,
                  nSpeakers=0,
-                 sizeInputSeq=128):
+                 sizeInputSeq=128,
+                 transformerDropout=0.1):
         super().__init__()
         if speakerEmbedding > 0:
             raise NotImplementedError("speakerEmbedding is deprecated in the reference "
                                       "(cpc_default_config.py:69-71) and not implemented here")
         self.speakerEmb = None
         self.wPrediction = PredictionNetwork(nPredicts, dimOutputAR, dimOutputEncoder, rnnMode=rnnMode,
-                                             dropout=dropout, sizeInputSeq=sizeInputSeq - nPredicts)
+                                             dropout=dropout, sizeInputSeq=sizeInputSeq - nPredicts,
+                                             transformerDropout=transformerDropout)
         self.nPredicts = nPredicts
         self.negativeSamplingExt = negativeSamplingExt
         if negativeSamplingExt % 16 != 0:
@@ -120,6 +135,10 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             negatives = self.drawNegatives(batchSize, seqSize, windowSize, cFeature.device)
         ext, perm, row_ptr = prepare_negatives(negatives[0], negatives[1], batchSize, seqSize, self.nPredicts,
                                                self.negativeSamplingExt)
-        losses, acc = InfoNCEFunction.apply(cFeature, encodedData, self.wPrediction.stacked_weight(), ext, perm,
-                                            row_ptr)
+        if self.wPrediction.rnnMode == "transformer":
+            pred = self.wPrediction.predictions(cFeature[:, :windowSize].contiguous())
+            losses, acc = InfoNCEScoresFunction.apply(pred, encodedData, ext, perm, row_ptr)
+        else:
+            losses, acc = InfoNCEFunction.apply(cFeature, encodedData, self.wPrediction.stacked_weight(), ext, perm,
+                                                row_ptr)
         return losses.view(1, -1), acc.view(1, -1)

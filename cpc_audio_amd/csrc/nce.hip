@@ -410,6 +410,38 @@ static RowMap window_rows(const float* c, int B, int S, int W) {     // rows (b,
     return r;
 }
 
+// scores, log-softmax, per-head loss / accuracy from given predictions
+static int nce_scores_forward(const NceLayout& n, const float* pred, const float* z, const int* ext, float* saved,
+                              float* scratch, float* losses, float* acc, int S, int K, int N, hipStream_t st) {
+    hipLaunchKernelGGL(nce_fwd_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
+                       saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N);
+    CPC_LAUNCH_CHECK();
+    int rc = rows_sum(scratch + n.rowstat, n.BW, 2 * K, scratch + n.tmp, scratch + n.sums, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(64), 0, st, scratch + n.sums, losses, acc, K,
+                       1.0f / (float)n.BW);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// dPred and dz from the upstream per-head gradients
+static int nce_scores_backward(const NceLayout& n, const float* pred, const float* z, const int* ext, const int* perm,
+                               const int* row_ptr, const float* saved, const float* gloss, float* scratch,
+                               float* dpred, float* dz, int B, int S, int K, int N, hipStream_t st) {
+    const float* logits = saved + n.logits, *lse = saved + n.lse;
+    float* gscale = scratch + n.gscale;
+    hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale, K,
+                       1.0f / ((float)n.BW * (float)kC));
+    const dim3 grid(cdiv(n.BW, 4));
+    hipLaunchKernelGGL(nce_bwd_dpred_kernel, grid, dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
+                       n.W, S, K, N);
+    hipLaunchKernelGGL(nce_bwd_dz_rows_kernel, grid, dim3(256), 0, st, pred, logits, lse, gscale, scratch + n.V,
+                       n.BW, K, N);
+    hipLaunchKernelGGL(nce_gather_rows_kernel, dim3(B * S), dim3(64), 0, st, scratch + n.V, perm, row_ptr, dz, B * S);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace cpc
 
 using namespace cpc;
@@ -457,15 +489,28 @@ extern "C" int cpc_nce_forward(const float* c, const float* z, const float* wall
     float* pred = saved + n.pred;
     int rc = nt_gemm(window_rows(c, B, S, n.W), wall, kC, nullptr, pred, (long)K * kC, K * kC, kC, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(nce_fwd_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
-                       saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N);
-    CPC_LAUNCH_CHECK();
-    rc = rows_sum(scratch + n.rowstat, n.BW, 2 * K, scratch + n.tmp, scratch + n.sums, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(64), 0, st, scratch + n.sums, losses, acc, K,
-                       1.0f / (float)n.BW);
-    CPC_LAUNCH_CHECK();
-    return 0;
+    return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, st);
+}
+
+// Same criterion on predictions computed by the caller (any prediction network, e.g. --rnnMode transformer):
+// pred (B*W, K*256), row (b,t), head k at columns k*256...  `saved` keeps logits and lse only.
+extern "C" int cpc_nce_scores_forward(const float* pred, const float* z, const int* ext, float* saved, float* scratch,
+                                      float* losses, float* acc, int B, int S, int K, int N, void* stream) {
+    NceLayout n;
+    CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!pred || !z || !ext || !saved || !scratch || !losses || !acc, CPC_ERR_ARG);
+    return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, (hipStream_t)stream);
+}
+
+// dpred (B*W, K*256) and dz (B,S,256) are overwritten.
+extern "C" int cpc_nce_scores_backward(const float* pred, const float* z, const int* ext, const int* perm,
+                                       const int* row_ptr, const float* saved, const float* gloss, float* scratch,
+                                       float* dpred, float* dz, int B, int S, int K, int N, void* stream) {
+    NceLayout n;
+    CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!pred || !z || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dpred || !dz, CPC_ERR_ARG);
+    return nce_scores_backward(n, pred, z, ext, perm, row_ptr, saved, gloss, scratch, dpred, dz, B, S, K, N,
+                               (hipStream_t)stream);
 }
 
 // gloss: K upstream gradients dL/dloss_k (device).  Outputs (overwritten): dc, dz (B,S,256), dwall (K*256,256).
@@ -480,20 +525,12 @@ extern "C" int cpc_nce_backward(const float* c, const float* z, const float* wal
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc || !dz || !dwall, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
-    const float* pred = saved + n.pred, *logits = saved + n.logits, *lse = saved + n.lse;
-    float* dpred = scratch + n.dpred, *gscale = scratch + n.gscale, *wallT = scratch + n.wallT;
-    hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale, K,
-                       1.0f / ((float)n.BW * (float)kC));
+    float* dpred = scratch + n.dpred, *wallT = scratch + n.wallT;
     (void)hipMemsetAsync(dc, 0, sizeof(float) * (size_t)B * S * kC, st);
-    const dim3 grid(cdiv(n.BW, 4));
-    hipLaunchKernelGGL(nce_bwd_dpred_kernel, grid, dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
-                       n.W, S, K, N);
-    hipLaunchKernelGGL(nce_bwd_dz_rows_kernel, grid, dim3(256), 0, st, pred, logits, lse, gscale, scratch + n.V,
-                       n.BW, K, N);
-    hipLaunchKernelGGL(nce_gather_rows_kernel, dim3(B * S), dim3(64), 0, st, scratch + n.V, perm, row_ptr, dz, B * S);
-    CPC_LAUNCH_CHECK();
+    int rc = nce_scores_backward(n, saved + n.pred, z, ext, perm, row_ptr, saved, gloss, scratch, dpred, dz, B, S, K, N, st);
+    if (rc) return rc;
     // dc[:, :W] = dPred . Wall  (NT against Wall^T [256][K*256])
-    int rc = transpose(wall, wallT, K * kC, kC, st);
+    rc = transpose(wall, wallT, K * kC, kC, st);
     if (rc) return rc;
     rc = nt_gemm(plain_rows(dpred, n.BW, K * kC), wallT, K * kC, nullptr, dc, kC, kC, K * kC, st, n.W,
                  (long)S * kC);

@@ -1,0 +1,552 @@
+// Transformer layer of the reference (cpc/transformers.py), forward + backward, d_model 256, 8 heads of 32,
+// d_ff 2048, sequence length S <= 128 (128 as the auto-regressive network, --arMode transformer; 116 as a
+// prediction network, --rnnMode transformer).  BASELINE.json config 4.
+//
+//   q,k,v = x Wq^T, x Wk^T, x Wv^T                         cpc/transformers.py:60-63, 82-84 (bias-free)
+//   score[i,j] = (q_i.k_j + q_i.P[:, S-1-(i-j)]) / sqrt(32), j <= i      :37-48 (relative positions through the
+//                                                          "z trick": P = Krelpos (32,S) indexed by the distance)
+//   o = softmax(score) v;  y = LN(x + o Wo^T);  out = LN(y + lin2(relu(lin1(y))))      :49, :85, :97-100, :109-110
+// Dropout (0.1, hard-coded in the reference) is not applied: parity is defined for eval / dropout 0.
+//
+// Structure: the seven projections are the library's NT/TN GEMMs (split-bf16 or f32 MFMA, gemm.hip); this
+// file adds the per-head attention kernels (one workgroup per (sequence, head): Q, K, V, P staged in LDS, all
+// products on v_mfma_f32_32x32x2_f32, softmax on the accumulator registers, causal tiles skipped), the fused
+// residual + LayerNorm kernels and ReLU.  The relative-position term is one more small GEMM E = Q.P whose
+// result is read back skewed (E[i][S-1-i+j]); backward un-skews dScore on the fly as an MFMA operand.
+#include "cpc_common.h"
+#include "cpc_internal.h"
+
+namespace cpc {
+
+constexpr int kTH = 8;             // heads
+constexpr int kDk = 32;            // head width
+constexpr int kDff = 2048;
+constexpr int kSmax = 128;         // padded sequence length of the attention tiles
+constexpr int kLdH = kDk + 1;      // LDS row pitch of the (S, 32) operands
+constexpr int kLdS = kSmax + 1;    // LDS row pitch of (., S) operands
+constexpr float kLnEps = 1e-5f;    // nn.LayerNorm default, transformers.py:107-108
+
+__device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float half_max(float v) {       // over the 32 lanes sharing lane >> 5
+    v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 8)); v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 2));  v = fmaxf(v, __shfl_xor(v, 1));
+    return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    return v;
+}
+
+// stage the (S, 32) head slice `col0` of a (B*S, ld) matrix into LDS rows of pitch kLdH, zero-padded to 128 rows
+__device__ __forceinline__ void stage_head(float* dst, const float* __restrict__ src, long row0, int ld, int col0, int S) {
+    for (int e = threadIdx.x; e < kSmax * (kDk / 4); e += blockDim.x) {
+        const int i = e >> 3, c4 = (e & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < S) v = *reinterpret_cast<const float4*>(src + (row0 + i) * ld + col0 + c4);
+        float* d = dst + i * kLdH + c4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+__device__ __forceinline__ void stage_relpos(float* dst, const float* __restrict__ P, int S) {
+    for (int e = threadIdx.x; e < kDk * kSmax; e += blockDim.x) {
+        const int d = e >> 7, c = e & (kSmax - 1);
+        dst[d * kLdS + c] = (P != nullptr && c < S) ? P[d * S + c] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ attention forward
+// grid = B * 8, 256 threads; wave w owns query rows 32w .. 32w+31.
+// qkv (B*S, 768) = [q | k | v]; P = Krelpos (32, S) or NULL; o (B*S, 256); A (B*8, S, S) saved for backward.
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                       float* __restrict__ o, float* __restrict__ A, int S) {
+    __shared__ float lds[3 * kSmax * kLdH + kDk * kLdS + 4 * 32 * kLdS];     // 133 KB of the CU's 160 KB
+    float* Qs = lds;
+    float* Ks = Qs + kSmax * kLdH;
+    float* Vs = Ks + kSmax * kLdH;
+    float* Ps = Vs + kSmax * kLdH;
+    float* Ws = Ps + kDk * kLdS;                     // [4 waves][32][kLdS]: E = Q.P, then the probabilities
+    const int bh = blockIdx.x, b = bh / kTH, h = bh % kTH;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const long row0 = (long)b * S;
+    stage_head(Qs, qkv, row0, 3 * kC, h * kDk, S);
+    stage_head(Ks, qkv, row0, 3 * kC, kC + h * kDk, S);
+    stage_head(Vs, qkv, row0, 3 * kC, 2 * kC + h * kDk, S);
+    stage_relpos(Ps, P, S);
+    __syncthreads();
+    if (32 * w >= S) return;                          // wave-uniform: no query rows here (no barrier follows)
+
+    float* Ww = Ws + w * 32 * kLdS;
+    const float* qrow = Qs + (32 * w + l31) * kLdH;
+    if (P != nullptr) {                               // E[i][c] = q_i . P[:, c]
+#pragma unroll 1
+        for (int ct = 0; ct < 4; ++ct) {
+            f32x16 e;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < kDk / 2; ++kk) {
+                const int k = 2 * kk + khalf;
+                e = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[k], Ps[k * kLdS + ct * 32 + l31], e, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ww[c_row(r, lane) * kLdS + ct * 32 + l31] = e[r];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const float scale = 0.17677669529663687f;         // 1 / sqrt(32)
+    f32x16 sc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[ct][r] = -INFINITY;
+        if (ct <= w) {                                // tiles right of the diagonal are entirely in the future
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* krow = Ks + (ct * 32 + l31) * kLdH;
+#pragma unroll
+            for (int kk = 0; kk < kDk / 2; ++kk) {
+                const int k = 2 * kk + khalf;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[k], krow[k], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = c_row(r, lane), i = 32 * w + il, j = ct * 32 + l31;
+                if (j <= i && i < S) {
+                    const float rel = P != nullptr ? Ww[il * kLdS + (S - 1 - i + j)] : 0.f;
+                    sc[ct][r] = (acc[r] + rel) * scale;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                  // every lane has read E; the buffer now takes the probabilities
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int il = c_row(r, lane), i = 32 * w + il;
+        float m = fmaxf(fmaxf(sc[0][r], sc[1][r]), fmaxf(sc[2][r], sc[3][r]));
+        m = half_max(m);
+        float p[4], s = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            p[ct] = (i < S && sc[ct][r] > -INFINITY) ? expf(sc[ct][r] - m) : 0.f;
+            s += p[ct];
+        }
+        s = half_sum(s);
+        const float inv = i < S ? 1.0f / s : 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const float a = p[ct] * inv;
+            const int j = ct * 32 + l31;
+            Ww[il * kLdS + j] = a;
+            if (i < S && j < S) A[((long)bh * S + i) * S + j] = a;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    f32x16 ov;                                        // o_w = A_w (32 x 32(w+1)) . V
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ov[r] = 0.f;
+    const float* arow = Ww + l31 * kLdS;
+    for (int kk = 0; kk < 16 * (w + 1); ++kk) {
+        const int k = 2 * kk + khalf;
+        ov = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k], Vs[k * kLdH + l31], ov, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = 32 * w + c_row(r, lane);
+        if (i < S) o[(row0 + i) * kC + h * kDk + l31] = ov[r];
+    }
+}
+
+// ------------------------------------------------------------------ attention backward
+// dqkv (B*S, 768) = [dq | dk | dv];  dPpart (B*8, 32, S): per-workgroup partial of dKrelpos (reduced afterwards).
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                       const float* __restrict__ o, const float* __restrict__ A,
+                                                       const float* __restrict__ dO, float* __restrict__ dqkv,
+                                                       float* __restrict__ dPpart, int S) {
+    __shared__ float lds[4 * kSmax * kLdH + kDk * kLdS + kSmax * kLdS];      // 150 KB
+    float* Qs = lds;
+    float* Ks = Qs + kSmax * kLdH;
+    float* Vs = Ks + kSmax * kLdH;
+    float* Gs = Vs + kSmax * kLdH;                    // dO
+    float* Ps = Gs + kSmax * kLdH;
+    float* Ds = Ps + kDk * kLdS;                      // dScore [128][kLdS]
+    __shared__ float rdot[kSmax];
+    const int bh = blockIdx.x, b = bh / kTH, h = bh % kTH;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const long row0 = (long)b * S;
+    stage_head(Qs, qkv, row0, 3 * kC, h * kDk, S);
+    stage_head(Ks, qkv, row0, 3 * kC, kC + h * kDk, S);
+    stage_head(Vs, qkv, row0, 3 * kC, 2 * kC + h * kDk, S);
+    stage_head(Gs, dO, row0, kC, h * kDk, S);
+    stage_relpos(Ps, P, S);
+    if (threadIdx.x < kSmax) {                        // rowdot_i = dO_i . o_i = sum_j dA_ij A_ij
+        const int i = threadIdx.x;
+        float s = 0.f;
+        if (i < S) {
+            const float* g = dO + (row0 + i) * kC + h * kDk;
+            const float* ov = o + (row0 + i) * kC + h * kDk;
+#pragma unroll
+            for (int d = 0; d < kDk; ++d) s = fmaf(g[d], ov[d], s);
+        }
+        rdot[i] = s;
+    }
+    __syncthreads();
+
+    // ---- phase 1: dScore rows of this wave
+    const float scale = 0.17677669529663687f;
+    const float* Abh = A + (long)bh * S * S;
+    {
+        const float* grow = Gs + (32 * w + l31) * kLdH;
+#pragma unroll 1
+        for (int ct = 0; ct < 4; ++ct) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (ct <= w) {
+                const float* vrow = Vs + (ct * 32 + l31) * kLdH;
+#pragma unroll
+                for (int kk = 0; kk < kDk / 2; ++kk) {
+                    const int k = 2 * kk + khalf;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(grow[k], vrow[k], acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 32 * w + c_row(r, lane), j = ct * 32 + l31;
+                float ds = 0.f;
+                if (ct <= w && i < S && j <= i) ds = Abh[(long)i * S + j] * (acc[r] - rdot[i]) * scale;
+                Ds[i * kLdS + j] = ds;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2
+    const int jlim = 32 * (w + 1);                    // causal: this wave's queries see keys < jlim
+    {   // dq_i = sum_j dS_ij k_j + sum_c dE_ic P[:, c],  dE_ic = dS[i][c - (S-1) + i]
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int il = 32 * w + l31;
+        const float* drow = Ds + il * kLdS;
+        for (int kk = 0; kk < jlim / 2; ++kk) {
+            const int j = 2 * kk + khalf;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[j], Ks[j * kLdH + l31], acc, 0, 0, 0);
+        }
+        if (P != nullptr) {
+            for (int kk = 0; kk < kSmax / 2; ++kk) {
+                const int c = 2 * kk + khalf;
+                const int j = c - (S - 1) + il;
+                const float de = (j >= 0 && j <= il && il < S) ? drow[j] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(de, Ps[l31 * kLdS + c], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * w + c_row(r, lane);
+            if (i < S) dqkv[(row0 + i) * 3 * kC + h * kDk + l31] = acc[r];
+        }
+    }
+    {   // dk_j = sum_{i >= j} dS_ij q_i;  dv_j = sum_{i >= j} A_ij dO_i   (rows j of this wave)
+        f32x16 ak, av;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ak[r] = 0.f; av[r] = 0.f; }
+        const int jl = 32 * w + l31;
+        for (int kk = 16 * w; kk < kSmax / 2; ++kk) {
+            const int i = 2 * kk + khalf;
+            ak = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[i * kLdS + jl], Qs[i * kLdH + l31], ak, 0, 0, 0);
+            const float a = (i < S && jl < S) ? Abh[(long)i * S + jl] : 0.f;
+            av = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Gs[i * kLdH + l31], av, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = 32 * w + c_row(r, lane);
+            if (j < S) {
+                dqkv[(row0 + j) * 3 * kC + kC + h * kDk + l31] = ak[r];
+                dqkv[(row0 + j) * 3 * kC + 2 * kC + h * kDk + l31] = av[r];
+            }
+        }
+    }
+    if (P != nullptr) {   // dP[d][c] partial = sum_i q_i[d] dE_ic, columns c of this wave
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int c = 32 * w + l31;
+        for (int kk = 0; kk < kSmax / 2; ++kk) {
+            const int i = 2 * kk + khalf;
+            const int j = c - (S - 1) + i;
+            const float de = (j >= 0 && j <= i && i < S) ? Ds[i * kLdS + j] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[i * kLdH + l31], de, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = c_row(r, lane);
+            if (c < S) dPpart[((long)bh * kDk + d) * S + c] = acc[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ residual + LayerNorm
+// out = LN(a + b) * w + bias, one wavefront per 256-wide row; xhat and rstd are kept for backward.
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ out, float* __restrict__ xhat,
+                                                         float* __restrict__ rstd, int M) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float4 va = *reinterpret_cast<const float4*>(a + row * kC + 4 * lane);
+    const float4 vb = *reinterpret_cast<const float4*>(b + row * kC + 4 * lane);
+    float x[4] = {va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w};
+    const float mu = wave_sum((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / kC);
+    float d[4], q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d[e] = x[e] - mu; q = fmaf(d[e], d[e], q); }
+    const float var = wave_sum(q) * (1.0f / kC);                   // biased, as nn.LayerNorm
+    const float rs = 1.0f / sqrtf(var + kLnEps);
+    const float4 vw = *reinterpret_cast<const float4*>(w + 4 * lane);
+    const float4 vbi = *reinterpret_cast<const float4*>(bias + 4 * lane);
+    float4 xh, y;
+    xh.x = d[0] * rs; xh.y = d[1] * rs; xh.z = d[2] * rs; xh.w = d[3] * rs;
+    y.x = xh.x * vw.x + vbi.x; y.y = xh.y * vw.y + vbi.y; y.z = xh.z * vw.z + vbi.z; y.w = xh.w * vw.w + vbi.w;
+    *reinterpret_cast<float4*>(xhat + row * kC + 4 * lane) = xh;
+    *reinterpret_cast<float4*>(out + row * kC + 4 * lane) = y;
+    if (lane == 0) rstd[row] = rs;
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w  (gradient w.r.t. the SUM a + b);
+// `add` (may be NULL) is added to dx.  Per-workgroup partials of dw = sum dy*xhat and db = sum dy go to
+// part[block][512] (32 rows per workgroup), reduced in a fixed order by rows_sum.
+constexpr int kLnRowsPerBlock = 32;
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                     const float* __restrict__ rstd, const float* __restrict__ w,
+                                                     const float* __restrict__ add, float* __restrict__ dx,
+                                                     float* __restrict__ part, int M) {
+    __shared__ float red[4][2][kC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float4 vw = *reinterpret_cast<const float4*>(w + 4 * lane);
+    float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < kLnRowsPerBlock / 4; ++it) {
+        const long row = (long)blockIdx.x * kLnRowsPerBlock + it * 4 + wv;
+        if (row >= M) break;                                       // wave-uniform
+        const float4 g4 = *reinterpret_cast<const float4*>(dy + row * kC + 4 * lane);
+        const float4 x4 = *reinterpret_cast<const float4*>(xhat + row * kC + 4 * lane);
+        const float gy[4] = {g4.x, g4.y, g4.z, g4.w}, xh[4] = {x4.x, x4.y, x4.z, x4.w};
+        const float ww[4] = {vw.x, vw.y, vw.z, vw.w};
+        float g[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            g[e] = gy[e] * ww[e];
+            s1 += g[e];
+            s2 = fmaf(g[e], xh[e], s2);
+            aw[e] = fmaf(gy[e], xh[e], aw[e]);
+            ab[e] += gy[e];
+        }
+        const float c1 = wave_sum(s1) * (1.0f / kC), c2 = wave_sum(s2) * (1.0f / kC);
+        const float rs = rstd[row];
+        float4 r;
+        r.x = rs * (g[0] - c1 - xh[0] * c2); r.y = rs * (g[1] - c1 - xh[1] * c2);
+        r.z = rs * (g[2] - c1 - xh[2] * c2); r.w = rs * (g[3] - c1 - xh[3] * c2);
+        if (add != nullptr) {
+            const float4 a4 = *reinterpret_cast<const float4*>(add + row * kC + 4 * lane);
+            r.x += a4.x; r.y += a4.y; r.z += a4.z; r.w += a4.w;
+        }
+        *reinterpret_cast<float4*>(dx + row * kC + 4 * lane) = r;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[wv][0][4 * lane + e] = aw[e]; red[wv][1][4 * lane + e] = ab[e]; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * kC; e += 256) {
+        const int which = e >> 8, c = e & (kC - 1);
+        part[(long)blockIdx.x * 2 * kC + e] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    reinterpret_cast<float4*>(x)[i] = v;
+}
+// g *= (y > 0)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = reinterpret_cast<float4*>(g)[i];
+    const float4 a = reinterpret_cast<const float4*>(y)[i];
+    v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+    reinterpret_cast<float4*>(g)[i] = v;
+}
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const float* __restrict__ b, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = reinterpret_cast<float4*>(a)[i];
+    const float4 u = reinterpret_cast<const float4*>(b)[i];
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    reinterpret_cast<float4*>(a)[i] = v;
+}
+
+// ------------------------------------------------------------------ host side
+struct TfLayout {
+    long qkv, A, o, xhat1, rstd1, y, hid, xhat2, rstd2, saved_total;       // saved for backward
+    long fwd_total;                                                        // forward scratch: one (M,256) buffer
+    long ds2, dhid, dyb, ds1, dob, dqkv, w2t, w1t, wot, wqkv, wqkvt, part, lnpart, tmp, dppart, bwd_total;
+};
+
+static bool tf_layout(int B, int S, TfLayout& t) {
+    if (B <= 0 || S <= 0 || S > kSmax) return false;
+    const long M = (long)B * S;
+    long o = 0;
+    t.qkv = o; o += align64l(M * 3 * kC);
+    t.A = o; o += align64l((long)B * kTH * S * S);
+    t.o = o; o += align64l(M * kC);
+    t.xhat1 = o; o += align64l(M * kC);
+    t.rstd1 = o; o += align64l(M);
+    t.y = o; o += align64l(M * kC);
+    t.hid = o; o += align64l(M * kDff);
+    t.xhat2 = o; o += align64l(M * kC);
+    t.rstd2 = o; o += align64l(M);
+    t.saved_total = o;
+    t.fwd_total = align64l(M * kC);
+    o = 0;
+    t.ds2 = o; o += align64l(M * kC);
+    t.dhid = o; o += align64l(M * kDff);
+    t.dyb = o; o += align64l(M * kC);
+    t.ds1 = o; o += align64l(M * kC);
+    t.dob = o; o += align64l(M * kC);
+    t.dqkv = o; o += align64l(M * 3 * kC);
+    t.w2t = o; o += (long)kDff * kC;
+    t.w1t = o; o += (long)kDff * kC;
+    t.wot = o; o += (long)kC * kC;
+    t.wqkv = o; o += 3L * kC * kC;
+    t.wqkvt = o; o += 3L * kC * kC;
+    t.part = o; o += align64l(tn_gemm_part_floats((int)M, kDff, kC));
+    const long nblk = cdiv(M, kLnRowsPerBlock);
+    t.lnpart = o; o += align64l(nblk * 2 * kC);
+    t.tmp = o; o += align64l((long)kRowsSumGroups * (kDk * S > kDff ? kDk * S : kDff));
+    t.dppart = o; o += align64l((long)B * kTH * kDk * S);
+    t.bwd_total = o;
+    return true;
+}
+
+}  // namespace cpc
+
+using namespace cpc;
+
+// sizes[0] = saved floats, [1] = forward scratch floats, [2] = backward scratch floats
+extern "C" int cpc_transformer_layout(int B, int S, long* sizes) {
+    TfLayout t;
+    CPC_RETURN_IF(!tf_layout(B, S, t) || !sizes, CPC_ERR_SHAPE);
+    sizes[0] = t.saved_total; sizes[1] = t.fwd_total; sizes[2] = t.bwd_total;
+    return 0;
+}
+
+// params (13 pointers, state-dict order of the reference's TransformerLayer): multihead.Wo, Wk, Wq, Wv (256,256),
+// multihead.Att.Krelpos (32,S) or NULL (abspos), ln_multihead.weight/bias, ffnetwork.lin1.weight (2048,256)/bias,
+// lin2.weight (256,2048)/bias, ln_ffnetwork.weight/bias.   x, out: (B,S,256).
+extern "C" int cpc_transformer_layer_forward(const float* x, const float* const* params, float* saved, float* scratch,
+                                             float* out, int B, int S, void* stream) {
+    TfLayout t;
+    CPC_RETURN_IF(!tf_layout(B, S, t), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!x || !params || !saved || !scratch || !out, CPC_ERR_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    const int M = B * S;
+    const float *Wo = params[0], *Wk = params[1], *Wq = params[2], *Wv = params[3], *P = params[4];
+    float* qkv = saved + t.qkv;
+    const RowMap xm = plain_rows(x, M, kC);
+    int rc;
+    if ((rc = nt_gemm(xm, Wq, kC, nullptr, qkv, 3 * kC, kC, kC, st))) return rc;
+    if ((rc = nt_gemm(xm, Wk, kC, nullptr, qkv + kC, 3 * kC, kC, kC, st))) return rc;
+    if ((rc = nt_gemm(xm, Wv, kC, nullptr, qkv + 2 * kC, 3 * kC, kC, kC, st))) return rc;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * kTH), dim3(256), 0, st, qkv, P, saved + t.o, saved + t.A, S);
+    CPC_LAUNCH_CHECK();
+    float* att = scratch;
+    if ((rc = nt_gemm(plain_rows(saved + t.o, M, kC), Wo, kC, nullptr, att, kC, kC, kC, st))) return rc;
+    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, att, params[5], params[6],
+                       saved + t.y, saved + t.xhat1, saved + t.rstd1, M);
+    if ((rc = nt_gemm(plain_rows(saved + t.y, M, kC), params[7], kC, params[8], saved + t.hid, kDff, kDff, kC, st))) return rc;
+    hipLaunchKernelGGL(relu_kernel, dim3(cdiv((long)M * kDff / 4, 256)), dim3(256), 0, st, saved + t.hid, (long)M * kDff / 4);
+    float* ff = scratch;
+    if ((rc = nt_gemm(plain_rows(saved + t.hid, M, kDff), params[9], kDff, params[10], ff, kC, kC, kDff, st))) return rc;
+    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, saved + t.y, ff, params[11], params[12],
+                       out, saved + t.xhat2, saved + t.rstd2, M);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// dy (B,S,256) -> dx (B,S,256) and grads[13] (same order as params; grads[4] ignored when params[4] is NULL).
+extern "C" int cpc_transformer_layer_backward(const float* x, const float* const* params, const float* saved,
+                                              const float* dy, float* scratch, float* dx, float* const* grads,
+                                              int B, int S, void* stream) {
+    TfLayout t;
+    CPC_RETURN_IF(!tf_layout(B, S, t), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!x || !params || !saved || !dy || !scratch || !dx || !grads, CPC_ERR_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    const int M = B * S;
+    const long n4 = (long)M * kC / 4;
+    const int nblk = cdiv(M, kLnRowsPerBlock);
+    const float *Wo = params[0], *Wk = params[1], *Wq = params[2], *Wv = params[3], *P = params[4];
+    const float *W1 = params[7], *W2 = params[9];
+    float *ds2 = scratch + t.ds2, *dhid = scratch + t.dhid, *dyb = scratch + t.dyb, *ds1 = scratch + t.ds1;
+    float *dob = scratch + t.dob, *dqkv = scratch + t.dqkv, *part = scratch + t.part, *lnpart = scratch + t.lnpart;
+    float *tmp = scratch + t.tmp;
+    int rc;
+    // out = LN2(y + ff)
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, saved + t.xhat2, saved + t.rstd2, params[11],
+                       (const float*)nullptr, ds2, lnpart, M);
+    if ((rc = rows_sum(lnpart, nblk, 2 * kC, tmp, dhid, st))) return rc;          // dhid as a 512-float staging area
+    (void)hipMemcpyAsync(grads[11], dhid, kC * sizeof(float), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(grads[12], dhid + kC, kC * sizeof(float), hipMemcpyDeviceToDevice, st);
+    // ff = hid W2^T + b2
+    const RowMap ds2m = plain_rows(ds2, M, kC), hidm = plain_rows(saved + t.hid, M, kDff);
+    if ((rc = tn_gemm(ds2m, kC, hidm, kDff, part, grads[9], 0, st))) return rc;   // dW2 (256,2048)
+    if ((rc = rows_sum(ds2, M, kC, tmp, grads[10], st))) return rc;
+    if ((rc = transpose(W2, scratch + t.w2t, kC, kDff, st))) return rc;           // (256,2048) -> (2048,256)
+    if ((rc = nt_gemm(ds2m, scratch + t.w2t, kC, nullptr, dhid, kDff, kDff, kC, st))) return rc;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(cdiv((long)M * kDff / 4, 256)), dim3(256), 0, st, dhid, saved + t.hid,
+                       (long)M * kDff / 4);
+    // hid = relu(y W1^T + b1)
+    const RowMap dhm = plain_rows(dhid, M, kDff), ym = plain_rows(saved + t.y, M, kC);
+    if ((rc = tn_gemm(dhm, kDff, ym, kC, part, grads[7], 0, st))) return rc;      // dW1 (2048,256)
+    if ((rc = rows_sum(dhid, M, kDff, tmp, grads[8], st))) return rc;
+    if ((rc = transpose(W1, scratch + t.w1t, kDff, kC, st))) return rc;           // (2048,256) -> (256,2048)
+    if ((rc = nt_gemm(dhm, scratch + t.w1t, kDff, nullptr, dyb, kC, kC, kDff, st))) return rc;
+    hipLaunchKernelGGL(add_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dyb, ds2, n4);   // dy_total = ds2 + dhid W1
+    // y = LN1(x + att)
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, st, dyb, saved + t.xhat1, saved + t.rstd1, params[5],
+                       (const float*)nullptr, ds1, lnpart, M);
+    if ((rc = rows_sum(lnpart, nblk, 2 * kC, tmp, dhid, st))) return rc;
+    (void)hipMemcpyAsync(grads[5], dhid, kC * sizeof(float), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(grads[6], dhid + kC, kC * sizeof(float), hipMemcpyDeviceToDevice, st);
+    // att = o Wo^T
+    const RowMap ds1m = plain_rows(ds1, M, kC);
+    if ((rc = tn_gemm(ds1m, kC, plain_rows(saved + t.o, M, kC), kC, part, grads[0], 0, st))) return rc;
+    if ((rc = transpose(Wo, scratch + t.wot, kC, kC, st))) return rc;
+    if ((rc = nt_gemm(ds1m, scratch + t.wot, kC, nullptr, dob, kC, kC, kC, st))) return rc;
+    // attention
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * kTH), dim3(256), 0, st, saved + t.qkv, P, saved + t.o,
+                       saved + t.A, dob, dqkv, scratch + t.dppart, S);
+    CPC_LAUNCH_CHECK();
+    if (P != nullptr && (rc = rows_sum(scratch + t.dppart, B * kTH, kDk * S, tmp, grads[4], st))) return rc;
+    // projections
+    const RowMap xm = plain_rows(x, M, kC);
+    if ((rc = tn_gemm(plain_rows(dqkv, M, 3 * kC), kC, xm, kC, part, grads[2], 0, st))) return rc;            // dWq
+    if ((rc = tn_gemm(plain_rows(dqkv + kC, M, 3 * kC), kC, xm, kC, part, grads[1], 0, st))) return rc;       // dWk
+    if ((rc = tn_gemm(plain_rows(dqkv + 2 * kC, M, 3 * kC), kC, xm, kC, part, grads[3], 0, st))) return rc;   // dWv
+    float* wqkv = scratch + t.wqkv;                                               // [Wq; Wk; Wv] (768,256)
+    (void)hipMemcpyAsync(wqkv, Wq, (size_t)kC * kC * sizeof(float), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(wqkv + kC * kC, Wk, (size_t)kC * kC * sizeof(float), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(wqkv + 2 * kC * kC, Wv, (size_t)kC * kC * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if ((rc = transpose(wqkv, scratch + t.wqkvt, 3 * kC, kC, st))) return rc;     // -> (256,768)
+    if ((rc = nt_gemm(plain_rows(dqkv, M, 3 * kC), scratch + t.wqkvt, 3 * kC, nullptr, dx, kC, kC, 3 * kC, st))) return rc;
+    hipLaunchKernelGGL(add_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dx, ds1, n4);   // + the residual branch
+    CPC_LAUNCH_CHECK();
+    return 0;
+}

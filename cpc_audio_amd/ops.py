@@ -206,3 +206,90 @@ class InfoNCEFunction(torch.autograd.Function):
                                            _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
                                            _stream()), "nce_backward")
         return dc, dz, dwall, None, None, None
+
+
+class InfoNCEScoresFunction(torch.autograd.Function):
+    """pred (B,W,K*256) from any prediction network, z (B,S,256), ext, perm, row_ptr -> losses (K), acc (K)."""
+
+    @staticmethod
+    def forward(ctx, pred, z, ext, perm, row_ptr):
+        _require_cuda(pred, "InfoNCEScoresFunction")
+        lib = _lib.get()
+        B, S, H = z.shape
+        W, N = ext.shape[1], ext.shape[2]
+        K = S - W
+        if H != _HID or pred.shape != (B, W, K * _HID) or ext.dtype != torch.int32:
+            raise ValueError("InfoNCEScoresFunction: inconsistent shapes")
+        pred, z, ext = pred.contiguous(), z.contiguous(), ext.contiguous()
+        with torch.cuda.device(z.device):
+            sizes = _layout("nce_layout", lib.cpc_nce_layout, 6, B, S, K, N)
+            saved = torch.empty(sizes[0], device=z.device, dtype=torch.float32)
+            scratch = torch.empty(sizes[1], device=z.device, dtype=torch.float32)
+            losses = torch.empty(K, device=z.device, dtype=torch.float32)
+            acc = torch.empty(K, device=z.device, dtype=torch.float32)
+            lib.check(lib.cpc_nce_scores_forward(_p(pred), _p(z), _p(ext), _p(saved), _p(scratch), _p(losses), _p(acc),
+                                                 B, S, K, N, _stream()), "nce_scores_forward")
+        ctx.save_for_backward(pred, z, ext, saved, perm, row_ptr)
+        ctx.dims = (B, S, K, N, sizes[2])
+        ctx.mark_non_differentiable(acc)
+        return losses, acc
+
+    @staticmethod
+    def backward(ctx, gloss, _gacc):
+        lib = _lib.get()
+        pred, z, ext, saved, perm, row_ptr = ctx.saved_tensors
+        B, S, K, N, nscr = ctx.dims
+        gloss = gloss.contiguous()
+        with torch.cuda.device(z.device):
+            scratch = torch.empty(nscr, device=z.device, dtype=torch.float32)
+            dpred, dz = torch.empty_like(pred), torch.empty_like(z)
+            lib.check(lib.cpc_nce_scores_backward(_p(pred), _p(z), _p(ext), _p(perm), _p(row_ptr), _p(saved), _p(gloss),
+                                                  _p(scratch), _p(dpred), _p(dz), B, S, K, N, _stream()),
+                      "nce_scores_backward")
+        return dpred, dz, None, None, None
+
+
+class TransformerLayerFunction(torch.autograd.Function):
+    """x (B,S,256) + the 13 layer parameters (state-dict order, Krelpos possibly None) -> (B,S,256).
+    One TransformerLayer of cpc/transformers.py:103-111 through cpc_transformer_layer_{forward,backward}."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        _require_cuda(x, "TransformerLayerFunction")
+        lib = _lib.get()
+        B, S, D = x.shape
+        if D != _HID:
+            raise NotImplementedError("the HIP transformer layer is built for d_model == 256")
+        if S > 128:
+            raise NotImplementedError("the HIP attention kernels hold sequences of at most 128 steps")
+        x = x.contiguous()
+        params = [None if p is None else p.detach().contiguous() for p in params]
+        if params[4] is not None and tuple(params[4].shape) != (32, S):
+            raise ValueError(f"Krelpos is {tuple(params[4].shape)}; the layer was built for sequences of "
+                             f"{params[4].shape[1]} steps, got {S} (cpc/transformers.py:22-24)")
+        with torch.cuda.device(x.device):
+            sizes = _layout("transformer_layout", lib.cpc_transformer_layout, 3, B, S)
+            saved = torch.empty(sizes[0], device=x.device, dtype=torch.float32)
+            scratch = torch.empty(sizes[1], device=x.device, dtype=torch.float32)
+            out = torch.empty(B, S, _HID, device=x.device, dtype=torch.float32)
+            lib.check(lib.cpc_transformer_layer_forward(_p(x), _ptrs(params), _p(saved), _p(scratch), _p(out), B, S,
+                                                        _stream()), "transformer_layer_forward")
+        ctx.has_rel = params[4] is not None
+        ctx.save_for_backward(x, saved, *[p for p in params if p is not None])
+        ctx.dims = (B, S, sizes[2])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.get()
+        x, saved, *ps = ctx.saved_tensors
+        params = ps if ctx.has_rel else ps[:4] + [None] + ps[4:]
+        B, S, nscr = ctx.dims
+        dy = dy.contiguous()
+        with torch.cuda.device(x.device):
+            scratch = torch.empty(nscr, device=x.device, dtype=torch.float32)
+            dx = torch.empty_like(x)
+            grads = [None if p is None else torch.empty_like(p) for p in params]
+            lib.check(lib.cpc_transformer_layer_backward(_p(x), _ptrs(params), _p(saved), _p(dy), _p(scratch), _p(dx),
+                                                         _ptrs(grads), B, S, _stream()), "transformer_layer_backward")
+        return (dx, *grads)

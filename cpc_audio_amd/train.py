@@ -10,16 +10,24 @@ from .dist import FlatGradAllReduce
 from .model import CPCAR, CPCEncoder, CPCModel
 
 
-def build_model(hiddenEncoder=256, hiddenGar=256, nLevelsGRU=2, keepHidden=False, reverse=False):
+def build_model(hiddenEncoder=256, hiddenGar=256, nLevelsGRU=2, keepHidden=False, reverse=False, arMode="GRU",
+                sizeWindow=20480, abspos=False, transformerDropout=0.1):
+    """cpc/feature_loader.py:124-153 (getEncoder / getAR) + cpc/train.py:311.  arMode 'GRU' (north star) or
+    'transformer' (BASELINE.json config 4: buildTransformerAR(hiddenEncoder, 1, sizeWindow // 160, abspos))."""
     enc = CPCEncoder(hiddenEncoder, "layerNorm")
-    ar = CPCAR(hiddenEncoder, hiddenGar, keepHidden, nLevelsGRU, mode="GRU", reverse=reverse)
+    if arMode == "transformer":
+        from .transformers import buildTransformerAR
+        ar = buildTransformerAR(hiddenEncoder, 1, sizeWindow // 160, abspos, dropout=transformerDropout)
+    else:
+        ar = CPCAR(hiddenEncoder, hiddenGar, keepHidden, nLevelsGRU, mode=arMode, reverse=reverse)
     return CPCModel(enc, ar)
 
 
 def build_criterion(nPredicts=12, hiddenGar=256, hiddenEncoder=256, negativeSamplingExt=128,
-                    sizeWindow=20480, downsampling=160, mode=None):
+                    sizeWindow=20480, downsampling=160, mode=None, rnnMode="linear", transformerDropout=0.1):
     return CPCUnsupersivedCriterion(nPredicts, hiddenGar, hiddenEncoder, negativeSamplingExt, mode=mode,
-                                    rnnMode="linear", dropout=False, sizeInputSeq=sizeWindow // downsampling)
+                                    rnnMode=rnnMode, dropout=False, sizeInputSeq=sizeWindow // downsampling,
+                                    transformerDropout=transformerDropout)
 
 
 def load_flat_params(model, criterion, params):

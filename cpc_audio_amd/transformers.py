@@ -1,0 +1,128 @@
+"""Drop-in replacement for the reference's cpc/transformers.py (BASELINE.json config 4).
+
+Same class names, constructor signatures, parameter / buffer names (state-dict keys ``multihead.Wo.weight``,
+``multihead.Att.Krelpos``, ``multihead.Att.z``, ``multihead.Att.mask``, ``ln_multihead.*``, ``ffnetwork.lin1.*`` ...)
+and the same ``buildTransformerAR`` factory (cpc/transformers.py:130-139), so checkpoints load both ways.  A
+``TransformerLayer`` runs as ONE fused HIP layer (csrc/transformer.hip); the sub-modules are parameter holders.
+
+Dropout: the reference hard-codes p = 0.1 inside TransformerLayer (cpc/transformers.py:93); the HIP layer has no
+dropout, so training-mode calls require ``dropout=0`` (the constructors keep the argument) and eval-mode calls
+ignore it, which is also the only setting with a defined parity.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .ops import TransformerLayerFunction
+
+
+class ScaledDotProductAttention(nn.Module):
+    """cpc/transformers.py:10-49: holds Krelpos (dk, sizeSeq) and the reference's ``z`` / ``mask`` buffers."""
+
+    def __init__(self, sizeSeq, dk, dropout, relpos=False):
+        super().__init__()
+        self.dropout_p = float(dropout)
+        self.relpos = relpos
+        self.sizeSeq = sizeSeq
+        if relpos:
+            self.Krelpos = nn.Parameter(torch.Tensor(dk, sizeSeq))
+            self.initmat_(self.Krelpos)
+            self.register_buffer("z", torch.zeros(1, sizeSeq, 1))
+        mask = torch.tril(torch.ones(sizeSeq, sizeSeq), diagonal=0)
+        mask = 1 - mask
+        mask[mask == 1] = -float("inf")
+        self.register_buffer("mask", mask.unsqueeze(0))
+
+    def initmat_(self, mat, dim=0):
+        stdv = 1.0 / math.sqrt(mat.size(dim))
+        mat.data.uniform_(-stdv, stdv)
+
+    def forward(self, Q, K, V):
+        raise NotImplementedError("attention runs inside the fused TransformerLayer kernel path")
+
+
+class MultiHeadAttention(nn.Module):
+    """cpc/transformers.py:52-85."""
+
+    def __init__(self, sizeSeq, dropout, dmodel, nheads, abspos):
+        super().__init__()
+        self.Wo = nn.Linear(dmodel, dmodel, bias=False)
+        self.Wk = nn.Linear(dmodel, dmodel, bias=False)
+        self.Wq = nn.Linear(dmodel, dmodel, bias=False)
+        self.Wv = nn.Linear(dmodel, dmodel, bias=False)
+        self.nheads = nheads
+        self.dk = dmodel // nheads
+        self.Att = ScaledDotProductAttention(sizeSeq, self.dk, dropout, not abspos)
+
+    def forward(self, Q, K, V):
+        raise NotImplementedError("attention runs inside the fused TransformerLayer kernel path")
+
+
+class FFNetwork(nn.Module):
+    """cpc/transformers.py:88-100."""
+
+    def __init__(self, din, dout, dff, dropout):
+        super().__init__()
+        self.lin1 = nn.Linear(din, dff, bias=True)
+        self.lin2 = nn.Linear(dff, dout, bias=True)
+        self.relu = nn.ReLU()
+        self.dropout_p = float(dropout)
+
+    def forward(self, x):
+        raise NotImplementedError("the feed-forward block runs inside the fused TransformerLayer kernel path")
+
+
+class TransformerLayer(nn.Module):
+    """cpc/transformers.py:103-111."""
+
+    def __init__(self, sizeSeq=32, dmodel=512, dff=2048, dropout=0.1, nheads=8, abspos=False):
+        super().__init__()
+        if dmodel != 256 or dff != 2048 or nheads != 8:
+            raise NotImplementedError("the HIP transformer layer is built for dmodel=256, dff=2048, nheads=8 "
+                                      "(what buildTransformerAR gives for the 256-d CPC encoder)")
+        if sizeSeq > 128:
+            raise NotImplementedError("the HIP attention kernels hold sequences of at most 128 steps")
+        self.dropout_p = float(dropout)
+        self.multihead = MultiHeadAttention(sizeSeq, dropout, dmodel, nheads, abspos)
+        self.ln_multihead = nn.LayerNorm(dmodel)
+        self.ffnetwork = FFNetwork(dmodel, dmodel, dff, dropout)
+        self.ln_ffnetwork = nn.LayerNorm(dmodel)
+
+    def forward(self, x):
+        if self.training and self.dropout_p > 0:
+            raise NotImplementedError("TransformerLayer in training mode with dropout > 0: the HIP layer applies no "
+                                      "dropout; build it with dropout=0 (buildTransformerAR(..., dropout=0.0))")
+        m, f = self.multihead, self.ffnetwork
+        krel = m.Att.Krelpos if m.Att.relpos else None
+        return TransformerLayerFunction.apply(x, m.Wo.weight, m.Wk.weight, m.Wq.weight, m.Wv.weight, krel,
+                                              self.ln_multihead.weight, self.ln_multihead.bias, f.lin1.weight,
+                                              f.lin1.bias, f.lin2.weight, f.lin2.bias, self.ln_ffnetwork.weight,
+                                              self.ln_ffnetwork.bias)
+
+
+class StaticPositionEmbedding(nn.Module):
+    """cpc/transformers.py:113-127."""
+
+    def __init__(self, seqlen, dmodel):
+        super().__init__()
+        pos = torch.arange(0., seqlen).unsqueeze(1).repeat(1, dmodel)
+        dim = torch.arange(0., dmodel).unsqueeze(0).repeat(seqlen, 1)
+        div = torch.exp(-math.log(10000) * (2 * (dim // 2) / dmodel))
+        pos *= div
+        pos[:, 0::2] = torch.sin(pos[:, 0::2])
+        pos[:, 1::2] = torch.cos(pos[:, 1::2])
+        self.register_buffer("pe", pos.unsqueeze(0))
+
+    def forward(self, x):
+        return x + self.pe[:, :x.size(1), :]
+
+
+def buildTransformerAR(dimEncoded, nLayers, sizeSeq, abspos, dropout=0.1):
+    """cpc/transformers.py:130-139 (``dropout`` is an addition: the reference's layers always use 0.1)."""
+    layerSequence = []
+    if abspos:
+        layerSequence += [StaticPositionEmbedding(sizeSeq, dimEncoded)]
+    layerSequence += [TransformerLayer(sizeSeq=sizeSeq, dmodel=dimEncoded, abspos=abspos, dropout=dropout)
+                      for _ in range(nLayers)]
+    return nn.Sequential(*layerSequence)

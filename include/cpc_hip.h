@@ -117,6 +117,22 @@ int cpc_gru_backward(const float* x, const float* h0, const float* const* params
                      const float* saved, const float* y, const float* dy, float* scratch, float* dx,
                      float* const* grads, int B, int S, int nl, void* stream);
 
+/* ---------------------------------------------------------------- transformer layer ----
+ * One TransformerLayer of cpc/transformers.py:103-111 (buildTransformerAR, :130-139), d_model 256, 8 heads,
+ * d_ff 2048, sequence S <= 128, dropout not applied.  Used as the auto-regressive network (--arMode
+ * transformer, cpc/feature_loader.py:138-141, S = 128) and as a prediction network (--rnnMode transformer,
+ * cpc/criterion/criterion.py:82-88, S = 128 - K).  BASELINE.json config 4.
+ * params / grads: 13 pointers in the reference's state-dict order -- multihead.Wo, Wk, Wq, Wv .weight (256,256),
+ * multihead.Att.Krelpos (32,S) (NULL = abspos layer without the relative term), ln_multihead.weight, .bias,
+ * ffnetwork.lin1.weight (2048,256), .bias, ffnetwork.lin2.weight (256,2048), .bias, ln_ffnetwork.weight, .bias.
+ * sizes[0] = saved floats, [1] = forward scratch floats, [2] = backward scratch floats. */
+int cpc_transformer_layout(int B, int S, long* sizes);
+int cpc_transformer_layer_forward(const float* x, const float* const* params, float* saved, float* scratch,
+                                  float* out, int B, int S, void* stream);
+int cpc_transformer_layer_backward(const float* x, const float* const* params, const float* saved,
+                                   const float* dy, float* scratch, float* dx, float* const* grads,
+                                   int B, int S, void* stream);
+
 /* ---------------------------------------------------------------- criterion ----
  * CPCUnsupersivedCriterion.forward (criterion.py:225-257) with linear prediction heads
  * (PredictionNetwork, criterion.py:90-91,97-118) and the negatives of sampleClean
@@ -145,6 +161,17 @@ int cpc_nce_backward(const float* c, const float* z, const float* wall, const in
                      const int* perm, const int* row_ptr, const float* saved, const float* gloss,
                      float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K, int N,
                      void* stream);
+
+/* The same criterion for predictions formed by the caller -- any prediction network of
+ * cpc/criterion/criterion.py:44-118, e.g. K transformer layers (--rnnMode transformer, :82-88):
+ * pred (B*W, K*256), row (b,t), head k at columns k*256..; implements :115-116 (mean over 256 of pred * candidate)
+ * and :245-257.  Layout / scratch sizes as cpc_nce_layout (the `pred` part of `saved` stays unused).
+ * backward overwrites dpred (B*W, K*256) and dz (B,S,256). */
+int cpc_nce_scores_forward(const float* pred, const float* z, const int* ext, float* saved, float* scratch,
+                           float* losses, float* acc, int B, int S, int K, int N, void* stream);
+int cpc_nce_scores_backward(const float* pred, const float* z, const int* ext, const int* perm,
+                            const int* row_ptr, const float* saved, const float* gloss, float* scratch,
+                            float* dpred, float* dz, int B, int S, int K, int N, void* stream);
 
 #ifdef __cplusplus
 }

@@ -243,7 +243,7 @@ def head_weights(p: Dict[str, Tensor], n_predicts: int) -> List[Tensor]:
 
 
 def criterion_logits(p: Dict[str, Tensor], c: Tensor, z: Tensor, ext_rows: Tensor,
-                     n_predicts: int = 12) -> List[Tensor]:
+                     n_predicts: int = 12, predict=None) -> List[Tensor]:
     """Per head k (k=1..K) the (B, 1+N, W) score tensor the reference builds at
     criterion.py:108-116: mean over the feature dim of (W_k c_t) * candidate, with
     candidate 0 the positive z_{t+k} (criterion.py:210-216) and candidates 1..N the
@@ -254,8 +254,10 @@ def criterion_logits(p: Dict[str, Tensor], c: Tensor, z: Tensor, ext_rows: Tenso
     cw = c[:, :W]
     neg = z.reshape(B * S, C)[ext_rows.reshape(-1)].view(B, -1, W, C)  # (B,N,W,C)
     out = []
-    for k, wk in enumerate(head_weights(p, n_predicts), start=1):
-        pred = cw @ wk.t()                                    # (B,W,C)  criterion.py:108
+    # predict(k0, cw) -> (B,W,C): any other prediction network of criterion.py:62-95 (k0 = 0..K-1), e.g. the
+    # transformer predictors of --rnnMode transformer; default: the linear heads
+    for k in range(1, n_predicts + 1):
+        pred = predict(k - 1, cw) if predict is not None else cw @ p[f"wPrediction.predictors.{k - 1}.weight"].t()  # criterion.py:108
         pos = (pred * z[:, k:k + W]).mean(dim=2)              # (B,W)
         negs = (pred.unsqueeze(1) * neg).mean(dim=3)          # (B,N,W)  criterion.py:116
         out.append(torch.cat((pos.unsqueeze(1), negs), dim=1))
@@ -263,14 +265,14 @@ def criterion_logits(p: Dict[str, Tensor], c: Tensor, z: Tensor, ext_rows: Tenso
 
 
 def criterion_forward(p: Dict[str, Tensor], c: Tensor, z: Tensor, ext_rows: Tensor,
-                      n_predicts: int = 12) -> Tuple[Tensor, Tensor]:
+                      n_predicts: int = 12, predict=None) -> Tuple[Tensor, Tensor]:
     """-> (losses (1,K), acc (1,K)) -- criterion.py:248-257: per-head cross entropy
     against class 0, mean over the B*W rows; accuracy = fraction of rows whose
     arg-max is class 0."""
     B, S, _ = z.shape
     W = S - n_predicts
     losses, accs = [], []
-    for lg in criterion_logits(p, c, z, ext_rows, n_predicts):
+    for lg in criterion_logits(p, c, z, ext_rows, n_predicts, predict):
         rows = lg.permute(0, 2, 1).reshape(B * W, -1)         # criterion.py:249-250
         lse = torch.logsumexp(rows, dim=1)
         losses.append((lse - rows[:, 0]).mean().view(1, 1))   # CE(target=0), mean

@@ -305,6 +305,7 @@ static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 namespace hipemu { int worker_count(); }
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = hipemu::worker_count(); return hipSuccess; }
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
+#define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)

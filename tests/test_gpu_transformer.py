@@ -1,0 +1,114 @@
+"""BASELINE.json config 4 on a real MI355X: the transformer layer as auto-regressive network (--arMode
+transformer) and as the K prediction networks (--rnnMode transformer), vs the CPU oracle
+(oracle/transformer_oracle.py) and the committed reference fixtures.  Dropout 0 (the only setting with a defined
+parity)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpc_oracle as O
+from oracle import transformer_oracle as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("case", ["transformer_ar_b2", "transformer_pred_b2", "transformer_abspos_b1"])
+def test_transformer_layer_matches_oracle_and_reference_fixture(case, golden_dir):
+    dev = _dev()
+    from cpc_audio_amd.transformers import buildTransformerAR
+    with open(os.path.join(golden_dir, "transformer_meta.json")) as f:
+        m = json.load(f)["cases"][case]
+    fx = np.load(os.path.join(golden_dir, case + ".npz"))
+    B, S, abspos = m["batch"], m["size_seq"], m["abspos"]
+    first = 1 if abspos else 0
+    p = T.make_layer_params(m["param_seed"], 256, S, abspos, prefix=f"{first}.")
+    net = buildTransformerAR(256, 1, S, abspos, dropout=0.0).to(dev)
+    missing = net.load_state_dict(p, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith(("Att.z", "Att.mask", ".pe")) for k in missing.missing_keys)
+    net.train()
+    g = torch.Generator().manual_seed(m["input_seed"])
+    x = torch.randn(B, S, 256, generator=g)
+    dy = torch.randn(B, S, 256, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    y = net(xd)
+    (y * dy.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = T.ar_forward(leaves, xr, 1, abspos)
+    (yr * dy).sum().backward()
+    # tolerance: 1e-4 on outputs is the north-star bar; expect ~1e-6
+    assert (y.detach().cpu() - yr).abs().max().item() < 1e-5
+    assert np.abs(y.detach().cpu()[:, ::8, :].numpy() - fx["y_slice"]).max() < 1e-5      # the REFERENCE's values
+    assert _rel(xd.grad.cpu(), xr.grad) < 1e-5
+    bad = {}
+    for k, v in net.named_parameters():
+        r = _rel(v.grad.cpu(), leaves[k].grad)
+        if not r < 1e-5:
+            bad[k] = r
+    assert not bad, bad
+
+
+def test_config4_transformer_ar_and_predictors_train_step():
+    """Whole config-4 step: conv encoder -> transformer AR (S=128) -> 12 transformer predictors (S=116) -> InfoNCE."""
+    dev = _dev()
+    from cpc_audio_amd import ops
+    from cpc_audio_amd.train import build_criterion, build_model
+    B, K, N = 3, 12, 128
+    base = O.make_params(seed=9, head_scale=1.0)
+    p = {k: v for k, v in base.items() if k.startswith("gEncoder.")}
+    p.update(T.make_layer_params(31, 256, 128, False, prefix="gAR.0."))
+    for k in range(K):
+        p.update(T.make_layer_params(40 + k, 256, 116, False, prefix=f"wPrediction.predictors.{k}.0."))
+    model = build_model(arMode="transformer", transformerDropout=0.0).to(dev)
+    crit = build_criterion(rnnMode="transformer", transformerDropout=0.0).to(dev)
+    mm = model.load_state_dict({k: v for k, v in p.items() if not k.startswith("wPrediction")}, strict=False)
+    cm = crit.load_state_dict({k: v for k, v in p.items() if k.startswith("wPrediction")}, strict=False)
+    for miss in (mm, cm):
+        assert not miss.unexpected_keys and all(k.endswith(("Att.z", "Att.mask")) for k in miss.missing_keys), miss
+    model.train(); crit.train()
+    wave = O.make_waveform(B, 20480, seed=77)
+    gen = torch.Generator().manual_seed(3)
+    bidx, sidx = O.draw_negative_indices(B, 128, 116, N, generator=gen)
+    ops.KEEP_DEBUG = True
+    c, z, _ = model(wave.to(dev), torch.zeros(B, dtype=torch.long, device=dev))
+    saved, sizes, zz = ops.debug_last["encoder"]
+    ops.KEEP_DEBUG = False
+    losses, acc = crit(c, z, None, negatives=(bidx.to(dev), sidx.to(dev)))
+    losses.sum().backward()
+    torch.cuda.synchronize()
+    Ls = [sizes[3 + i] for i in range(5)]
+    ys = [saved[sizes[8 + i]: sizes[8 + i] + B * Ls[i] * 256].view(B, Ls[i], 256).cpu() for i in range(4)] + [zz.cpu()]
+    masks = [(y > 0).permute(0, 2, 1) for y in ys]
+
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    zr = O.encoder_forward(leaves, wave, relu_override=masks).permute(0, 2, 1)
+    cr = T.ar_forward(leaves, zr, 1, False, prefix="gAR.")
+    ext = O.negative_rows(bidx, sidx, B, 128, 116, N)
+    lr, ar = O.criterion_forward(leaves, cr, zr, ext, K,
+                                 predict=lambda k, cw: T.layer_forward(leaves, cw, prefix=f"wPrediction.predictors.{k}.0."))
+    lr.sum().backward()
+    assert (z.detach().cpu() - zr.detach()).abs().max().item() < 1e-4
+    assert (c.detach().cpu() - cr.detach()).abs().max().item() < 1e-4
+    assert (losses.detach().cpu() - lr.detach()).abs().max().item() < 1e-4
+    assert (acc.cpu() - ar).abs().max().item() <= 2.0 / (116 * B) + 1e-7
+    bad = {}
+    grads = dict(model.named_parameters()); grads.update(dict(crit.named_parameters()))
+    for k, v in grads.items():
+        r = _rel(v.grad.cpu(), leaves[k].grad)
+        if not r < 2e-4:
+            bad[k] = r
+    assert not bad, bad
