@@ -440,11 +440,13 @@ static bool tf_layout(int B, int S, TfLayout& t) {
 
 using namespace cpc;
 
-// sizes[0] = saved floats, [1] = forward scratch floats, [2] = backward scratch floats
+// sizes[0] = saved floats, [1] = forward scratch floats, [2] = backward scratch floats; [3..7] = offsets inside
+// `saved` of qkv (B*S,768), A (B*8,S,S), o (B*S,256), y (B*S,256), hid (B*S,2048) (for tests / inspection)
 extern "C" int cpc_transformer_layout(int B, int S, long* sizes) {
     TfLayout t;
     CPC_RETURN_IF(!tf_layout(B, S, t) || !sizes, CPC_ERR_SHAPE);
     sizes[0] = t.saved_total; sizes[1] = t.fwd_total; sizes[2] = t.bwd_total;
+    sizes[3] = t.qkv; sizes[4] = t.A; sizes[5] = t.o; sizes[6] = t.y; sizes[7] = t.hid;
     return 0;
 }
 

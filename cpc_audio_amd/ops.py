@@ -268,12 +268,14 @@ class TransformerLayerFunction(torch.autograd.Function):
             raise ValueError(f"Krelpos is {tuple(params[4].shape)}; the layer was built for sequences of "
                              f"{params[4].shape[1]} steps, got {S} (cpc/transformers.py:22-24)")
         with torch.cuda.device(x.device):
-            sizes = _layout("transformer_layout", lib.cpc_transformer_layout, 3, B, S)
+            sizes = _layout("transformer_layout", lib.cpc_transformer_layout, 8, B, S)
             saved = torch.empty(sizes[0], device=x.device, dtype=torch.float32)
             scratch = torch.empty(sizes[1], device=x.device, dtype=torch.float32)
             out = torch.empty(B, S, _HID, device=x.device, dtype=torch.float32)
             lib.check(lib.cpc_transformer_layer_forward(_p(x), _ptrs(params), _p(saved), _p(scratch), _p(out), B, S,
                                                         _stream()), "transformer_layer_forward")
+        if KEEP_DEBUG:                      # parity tests read the FFN's ReLU mask (oracle _ReluTieAware)
+            debug_last.setdefault("transformer", []).append((saved, sizes))
         ctx.has_rel = params[4] is not None
         ctx.save_for_backward(x, saved, *[p for p in params if p is not None])
         ctx.dims = (B, S, sizes[2])

@@ -125,7 +125,8 @@ int cpc_gru_backward(const float* x, const float* h0, const float* const* params
  * params / grads: 13 pointers in the reference's state-dict order -- multihead.Wo, Wk, Wq, Wv .weight (256,256),
  * multihead.Att.Krelpos (32,S) (NULL = abspos layer without the relative term), ln_multihead.weight, .bias,
  * ffnetwork.lin1.weight (2048,256), .bias, ffnetwork.lin2.weight (256,2048), .bias, ln_ffnetwork.weight, .bias.
- * sizes[0] = saved floats, [1] = forward scratch floats, [2] = backward scratch floats. */
+ * sizes[0] = saved floats, [1] = forward scratch floats, [2] = backward scratch floats, [3..7] = offsets inside
+ * `saved` of qkv (B*S,768), A (B*8,S,S), o, y (B*S,256), hid (B*S,2048) = relu(lin1(y)). */
 int cpc_transformer_layout(int B, int S, long* sizes);
 int cpc_transformer_layer_forward(const float* x, const float* const* params, float* saved, float* scratch,
                                   float* out, int B, int S, void* stream);

@@ -103,8 +103,11 @@ def attention_probabilities(q: Tensor, k: Tensor, krelpos: Optional[Tensor]) -> 
     return torch.softmax(score, dim=2)
 
 
-def layer_forward(p: Dict[str, Tensor], x: Tensor, prefix: str = "", collect: Optional[dict] = None) -> Tensor:
-    """One TransformerLayer, x (B, S, d_model) -> (B, S, d_model)."""
+def layer_forward(p: Dict[str, Tensor], x: Tensor, prefix: str = "", collect: Optional[dict] = None,
+                  relu_override: Optional[Tensor] = None) -> Tensor:
+    """One TransformerLayer, x (B, S, d_model) -> (B, S, d_model).
+    ``relu_override``: optional bool (B, S, d_ff) = [hidden_device > 0]; used for the derivative of the
+    feed-forward ReLU at numerically tied pre-activations only (|x| < 1e-5, cpc_oracle._ReluTieAware)."""
     b, s, d = x.shape
     h, dk = N_HEADS, d // N_HEADS
 
@@ -118,7 +121,12 @@ def layer_forward(p: Dict[str, Tensor], x: Tensor, prefix: str = "", collect: Op
     o = torch.bmm(a, v).view(b, h, s, dk).transpose(1, 2).reshape(b, s, d)
     att = o @ p[f"{prefix}multihead.Wo.weight"].t()
     y = F.layer_norm(x + att, (d,), p[f"{prefix}ln_multihead.weight"], p[f"{prefix}ln_multihead.bias"], 1e-5)
-    hid = torch.relu(y @ p[f"{prefix}ffnetwork.lin1.weight"].t() + p[f"{prefix}ffnetwork.lin1.bias"])
+    pre = y @ p[f"{prefix}ffnetwork.lin1.weight"].t() + p[f"{prefix}ffnetwork.lin1.bias"]
+    if relu_override is not None:
+        from .cpc_oracle import _ReluTieAware
+        hid = _ReluTieAware.apply(pre, relu_override, 1e-5)
+    else:
+        hid = torch.relu(pre)
     ff = hid @ p[f"{prefix}ffnetwork.lin2.weight"].t() + p[f"{prefix}ffnetwork.lin2.bias"]
     out = F.layer_norm(y + ff, (d,), p[f"{prefix}ln_ffnetwork.weight"], p[f"{prefix}ln_ffnetwork.bias"], 1e-5)
     if collect is not None:
@@ -126,7 +134,8 @@ def layer_forward(p: Dict[str, Tensor], x: Tensor, prefix: str = "", collect: Op
     return out
 
 
-def ar_forward(p: Dict[str, Tensor], z: Tensor, n_layers: int = 1, abspos: bool = False, prefix: str = "") -> Tensor:
+def ar_forward(p: Dict[str, Tensor], z: Tensor, n_layers: int = 1, abspos: bool = False, prefix: str = "",
+               relu_override=None) -> Tensor:
     """buildTransformerAR(...) as an nn.Sequential (transformers.py:130-139): optional position embedding at
     index 0, then the layers; state-dict keys are '<index>.<layer key>'."""
     x = z
@@ -135,5 +144,6 @@ def ar_forward(p: Dict[str, Tensor], z: Tensor, n_layers: int = 1, abspos: bool 
         x = x + static_position_embedding(z.size(1), z.size(2)).unsqueeze(0)
         first = 1
     for i in range(n_layers):
-        x = layer_forward(p, x, prefix=f"{prefix}{first + i}.")
+        x = layer_forward(p, x, prefix=f"{prefix}{first + i}.",
+                          relu_override=None if relu_override is None else relu_override[i])
     return x

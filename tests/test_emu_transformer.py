@@ -18,7 +18,7 @@ ORDER = ["multihead.Wo.weight", "multihead.Wk.weight", "multihead.Wq.weight", "m
 def run_layer(lib, p, x, dy, S):
     B = x.size(0)
     plist = [p[k].contiguous() if k in p else None for k in ORDER]
-    sizes = (ctypes.c_long * 3)()
+    sizes = (ctypes.c_long * 8)()
     assert lib.cpc_transformer_layout(B, S, sizes) == 0
     saved = torch.full((sizes[0],), float("nan"))
     fscr = torch.full((sizes[1],), float("nan"))

@@ -25,6 +25,14 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
+def _ffn_masks(ops, B_S):
+    """[hid_device > 0] of every transformer layer call recorded under ops.KEEP_DEBUG, in call order."""
+    out = []
+    for (saved, sizes), (B, S) in zip(ops.debug_last["transformer"], B_S):
+        out.append((saved[sizes[7]: sizes[7] + B * S * 2048].view(B, S, 2048) > 0).cpu())
+    return out
+
+
 @pytest.mark.parametrize("case", ["transformer_ar_b2", "transformer_pred_b2", "transformer_abspos_b1"])
 def test_transformer_layer_matches_oracle_and_reference_fixture(case, golden_dir):
     dev = _dev()
@@ -39,16 +47,21 @@ def test_transformer_layer_matches_oracle_and_reference_fixture(case, golden_dir
     missing = net.load_state_dict(p, strict=False)
     assert not missing.unexpected_keys and all(k.endswith(("Att.z", "Att.mask", ".pe")) for k in missing.missing_keys)
     net.train()
+    from cpc_audio_amd import ops
     g = torch.Generator().manual_seed(m["input_seed"])
     x = torch.randn(B, S, 256, generator=g)
     dy = torch.randn(B, S, 256, generator=g)
     xd = x.to(dev).requires_grad_(True)
+    ops.debug_last.pop("transformer", None)
+    ops.KEEP_DEBUG = True
     y = net(xd)
+    ops.KEEP_DEBUG = False
     (y * dy.to(dev)).sum().backward()
     torch.cuda.synchronize()
+    masks = _ffn_masks(ops, [(B, S)])
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     xr = x.clone().requires_grad_(True)
-    yr = T.ar_forward(leaves, xr, 1, abspos)
+    yr = T.ar_forward(leaves, xr, 1, abspos, relu_override=masks)
     (yr * dy).sum().backward()
     # tolerance: 1e-4 on outputs is the north-star bar; expect ~1e-6
     assert (y.detach().cpu() - yr).abs().max().item() < 1e-5
@@ -83,11 +96,13 @@ def test_config4_transformer_ar_and_predictors_train_step():
     wave = O.make_waveform(B, 20480, seed=77)
     gen = torch.Generator().manual_seed(3)
     bidx, sidx = O.draw_negative_indices(B, 128, 116, N, generator=gen)
+    ops.debug_last.pop("transformer", None)
     ops.KEEP_DEBUG = True
     c, z, _ = model(wave.to(dev), torch.zeros(B, dtype=torch.long, device=dev))
     saved, sizes, zz = ops.debug_last["encoder"]
-    ops.KEEP_DEBUG = False
     losses, acc = crit(c, z, None, negatives=(bidx.to(dev), sidx.to(dev)))
+    ops.KEEP_DEBUG = False
+    tmasks = _ffn_masks(ops, [(B, 128)] + [(B, 116)] * K)       # call order: the AR layer, then predictors 0..K-1
     losses.sum().backward()
     torch.cuda.synchronize()
     Ls = [sizes[3 + i] for i in range(5)]
@@ -96,10 +111,11 @@ def test_config4_transformer_ar_and_predictors_train_step():
 
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     zr = O.encoder_forward(leaves, wave, relu_override=masks).permute(0, 2, 1)
-    cr = T.ar_forward(leaves, zr, 1, False, prefix="gAR.")
+    cr = T.ar_forward(leaves, zr, 1, False, prefix="gAR.", relu_override=tmasks[:1])
     ext = O.negative_rows(bidx, sidx, B, 128, 116, N)
     lr, ar = O.criterion_forward(leaves, cr, zr, ext, K,
-                                 predict=lambda k, cw: T.layer_forward(leaves, cw, prefix=f"wPrediction.predictors.{k}.0."))
+                                 predict=lambda k, cw: T.layer_forward(leaves, cw, prefix=f"wPrediction.predictors.{k}.0.",
+                                                                       relu_override=tmasks[1 + k]))
     lr.sum().backward()
     assert (z.detach().cpu() - zr.detach()).abs().max().item() < 1e-4
     assert (c.detach().cpu() - cr.detach()).abs().max().item() < 1e-4
