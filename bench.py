@@ -28,7 +28,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (same guide)
 X3_PRODUCTS = 6                   # bf16 MFMAs issued per fp32 product in the split-bf16 tiles (gemm_tile.h)
 HBM_PEAK_GBPS = 8000.0
 # HBM bytes per launch at B = 64 from the PMC counters (profiles/r1_pmc_roofline_kernels.md)
-PMC_TRAFFIC_B64 = {"conv1_fwd": 692.1e6, "conv0_fwd": 277.8e6}
+PMC_TRAFFIC_B64 = {"conv1_fwd": 805.9e6, "conv0_fwd": 276.5e6}
 
 
 def parse():
