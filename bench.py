@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 AUDIO_S_PER_SEQ = 20480 / 16000.0
 F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (same guide)
-X3_PRODUCTS = 6                   # bf16 MFMAs issued per fp32 product in the split-bf16 tiles (gemm_tile.h)
+X3_PRODUCTS = 3                   # fp16 MFMAs issued per fp32 product in the split-fp16 conv tiles (gemm_tile.h; bf16 split: 6)
 HBM_PEAK_GBPS = 8000.0
 # HBM bytes per launch at B = 64 from the PMC counters (profiles/r1_pmc_roofline_kernels.md)
 PMC_TRAFFIC_B64 = {"conv1_fwd": 805.9e6, "conv0_fwd": 276.5e6}
@@ -56,7 +56,7 @@ def hip_event_time(fn, iters, warm=3):
 
 
 def roofline_probe(B, dev):
-    """Roofline of the dominant kernel, conv_fwd_kernel<128,true> on layer 1 (k8 s4, 256->256): the
+    """Roofline of the dominant kernel, conv_fwd_kernel<128,2> on layer 1 (k8 s4, 256->256): the
     implicit-GEMM + ChannelNorm + ReLU kernel.  Algorithmic work per 1.28 s window (SURVEY.md
     section 8d): 536,870,912 MAC = 1.0737 GFLOP; one launch processes B windows."""
     from cpc_audio_amd import _lib
@@ -70,6 +70,7 @@ def roofline_probe(B, dev):
     y = torch.empty(B, Lout, 256, device=dev)
     xh = torch.empty_like(y)
     rs = torch.empty(B * Lout, device=dev)
+    xamax = torch.zeros(1, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     lib.check(lib.cpc_conv_weight_relayout(P(w), P(wp), k, st))
 
@@ -85,26 +86,28 @@ def roofline_probe(B, dev):
         lib.check(lib.cpc_conv0_forward(P(wave), P(w0), P(bias), P(nw), P(nb), P(y0), P(m0), P(r0), B, L, st))
 
     def f():
-        lib.check(lib.cpc_conv_gemm_forward(P(y0), P(wp), P(bias), P(nw), P(nb), P(y), P(xh), P(rs), B, Lin, k, s, p, st))
+        lib.check(lib.cpc_conv_gemm_forward(P(y0), P(wp), P(bias), P(nw), P(nb), P(y), P(xh), P(rs), P(xamax), B, Lin, k, s, p, st))
 
     # Timed on the activations conv0 actually produces for the bench waveform (MFMA power, and with it the
     # sustained clock, depends on the operand values: dense random inputs run ~15 % slower), 20 launches between
     # one pair of hip events on the launching stream.  rocprofv3 shows 0.35-0.36 ms for the same kernel inside the
     # train step (profiles/README.md); event pairs around every single launch add ~50 us of marker overhead.
     f0()
+    lib.check(lib.cpc_absmax(P(y0), y0.numel(), P(xamax), st))     # operand bound for the fp16-split mode
     ms = hip_event_time(f, iters=20)
     flops = 2.0 * 536870912 * B
     ach = flops / (ms * 1e-3) / 1e12
-    # The kernel runs on the bf16 matrix pipe with 3-piece split operands: every algorithmic fp32 FLOP
-    # costs 6 bf16 MFMA FLOPs, so the roof for ALGORITHMIC FLOP/s is 2500 / 6 = 416.7 TFLOP/s.
+    # The kernel runs on the fp16 matrix pipe (same dense peak as bf16: 2.5 PFLOP/s) with operands split into two
+    # fp16 pieces: every algorithmic fp32 FLOP costs 3 fp16 MFMA FLOPs, so the roof for ALGORITHMIC FLOP/s is
+    # 2500 / 3 = 833 TFLOP/s.
     peak = BF16_MFMA_PEAK_TFLOPS / X3_PRODUCTS
     roof = {"bound": "mfma",
-            "kernel": "conv_fwd_kernel<128,true> (encoder layer 1: implicit GEMM on the bf16 pipe with 3-piece split "
-                      "fp32 operands, fp32 accumulate, + ChannelNorm + ReLU)",
+            "kernel": "conv_fwd_kernel<128,2> (encoder layer 1: implicit GEMM on the fp16 pipe with scaled 2-piece split "
+                      "fp32 operands (hh+hl+lh), fp32 accumulate, + ChannelNorm + ReLU)",
             "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": PMC_TRAFFIC_B64["conv1_fwd"] if B == 64 else None,
             "ms_per_launch": round(ms, 4), "flop_per_launch": flops,
-            "bf16_mfma_TFLOPs": round(ach * X3_PRODUCTS, 1), "bf16_mfma_peak": BF16_MFMA_PEAK_TFLOPS,
+            "f16_mfma_TFLOPs": round(ach * X3_PRODUCTS, 1), "f16_mfma_peak": BF16_MFMA_PEAK_TFLOPS,
             "vs_f32_mfma_peak": round(ach / F32_MFMA_PEAK_TFLOPS, 4)}
     # conv0: algorithmic bytes = waveform read + one activation write (+ mean/rstd)
     ms0 = hip_event_time(f0, iters=20)
@@ -197,7 +200,8 @@ def main():
             "metric": "audio-seconds/sec (train step)", "value": round(value, 1), "unit": "audio-s/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * el / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (GEMMs: fp32 operands split into 3 bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate)",
+            "dtype": "f32 (conv GEMMs: fp32 operands scaled and split into 2 fp16 pieces, 3 fp16 MFMAs per product; other "
+                     "GEMMs: 3 bf16 pieces, 6 bf16 MFMAs per product; fp32 accumulate; fp32-level accuracy)",
             "data": "synthetic white noise 0.1*N(0,1) clamped to [-1,1], resident in HBM; random-init weights",
             "config": {"workload": "default CPC train step (conv encoder + 2-layer GRU + K=12 InfoNCE, 128 negatives), "
                                    f"{world}x{B}x20480 fp32 (BASELINE.json configs[1] at fp32)",

@@ -10,6 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcpc_hip.so")
+DEFAULT_MFMA_MODE = 2      # what libcpc_hip starts in (cpc_set_mfma_mode): conv layers on the fp16 split, GEMMs on the bf16 split
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -25,10 +26,11 @@ SIGNATURES = {
     "cpc_conv0_backward": (_I, [_P] * 13 + [_I, _I, _P]),
     "cpc_conv_layer_forward": (_I, [_P] * 9 + [_I] * 5 + [_P]),
     "cpc_conv_weight_relayout": (_I, [_P, _P, _I, _P]),
-    "cpc_conv_gemm_forward": (_I, [_P] * 8 + [_I] * 5 + [_P]),
-    "cpc_norm_backward": (_I, [_P] * 9 + [_I, _P]),
-    "cpc_conv_layer_dgrad": (_I, [_P] * 3 + [_I] + [_P] * 8 + [_I] * 5 + [_P]),
-    "cpc_conv_layer_wgrad": (_I, [_P] * 4 + [_I] * 7 + [_P]),
+    "cpc_conv_gemm_forward": (_I, [_P] * 9 + [_I] * 5 + [_P]),
+    "cpc_absmax": (_I, [_P, ctypes.c_long, _P, _P]),
+    "cpc_norm_backward": (_I, [_P] * 10 + [_I, _P]),
+    "cpc_conv_layer_dgrad": (_I, [_P] * 3 + [_I] + [_P] * 10 + [_I] * 5 + [_P]),
+    "cpc_conv_layer_wgrad": (_I, [_P] * 6 + [_I] * 7 + [_P]),
     "cpc_encoder_layout": (_I, [_I, _I, _P]),
     "cpc_encoder_forward": (_I, [_P] * 5 + [_I, _I, _P]),
     "cpc_encoder_backward": (_I, [_P] * 7 + [_I, _I, _P]),

@@ -83,34 +83,90 @@ __global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------ operand bounds for the fp16-split mode
+// out = max(out, max_i |x_i|): |x| as uint bits is monotone, so an integer atomicMax gives an order-independent,
+// exact result.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+// Bound of a ChannelNorm output (cpc/model.py:50-58): |xhat| <= sqrt(C-1) (unbiased variance), so
+// |y| <= sqrt(C-1) * max|w| + max|b|; ReLU only shrinks it.  One workgroup of 256 threads.
+__global__ __launch_bounds__(256) void norm_bound_kernel(const float* __restrict__ nw, const float* __restrict__ nb,
+                                                         float* __restrict__ out) {
+    __shared__ float red[2][4];
+    const float w = wave_max(fabsf(nw[threadIdx.x])), b = wave_max(fabsf(nb[threadIdx.x]));
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = w; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float mw = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        const float mb = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        *out = 15.968719f * mw + mb;                             // sqrt(255)
+    }
+}
+
 // ------------------------------------------------------------------ forward
-template <int BM, bool X3>
+// MODE: 0 = exact-f32 MFMA, 1 = three bf16 pieces (6 MFMAs per product), 2 = two fp16 pieces (3 MFMAs per
+// product; operands scaled by powers of two derived from bounds on their max|.|, see gemm_tile.h)
+template <int BM, int MODE>
 struct ConvCfg {
+    static constexpr bool X3 = MODE != 0;
+    // the fp16 split pays where the tile is MFMA-bound (128 rows); the 32/64-row tiles of the short layers are
+    // bound by staging the 256-column weight tile and keep the bf16 split (measured: 108 vs 76 us on layer 3)
+    static constexpr int NP = (MODE == 2 && BM == 128) ? 2 : 3;
+    static constexpr bool H2 = NP == 2;
     static constexpr int WAVES_M = BM >= 128 ? 2 : 1;
     // 128-row tiles: two LDS stages of 16 k with the skewed (store-first / MFMA-first) wave schedule
     // (pre-split weight planes, BSPLIT = true, measured slower: 162 vs 176 TF on layer 1 -- three 8-byte loads per
     //  slot instead of one 16-byte load cost more than the VALU they save)
     static constexpr bool kPreSplitW = false;
-    using X3Tile = typename std::conditional<BM == 128, NtTileX3<BM, kC, WAVES_M, 4, 16, 2, true, kPreSplitW>,
-                                             NtTileX3<BM, kC, WAVES_M, 4, 32, 1, false, kPreSplitW>>::type;
+    using X3Tile = typename std::conditional<BM == 128, NtTileX3<BM, kC, WAVES_M, 4, 16, 2, true, kPreSplitW, NP>,
+                                             NtTileX3<BM, kC, WAVES_M, 4, 32, 1, false, kPreSplitW, NP>>::type;
     using Tile = typename std::conditional<X3, X3Tile, NtTile<BM, kC, WAVES_M, 4>>::type;
 };
 
-template <int BM, bool X3>
-__global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_fwd_kernel(
+// x_amax / w_amax (MODE 2 only): device floats holding upper bounds of max|x| and max|w|
+template <int BM, int MODE>
+__global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_fwd_kernel(
     RowMap am, const float* __restrict__ wp, int K, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
-    float* __restrict__ xhat, float* __restrict__ rstd_out) {
-    using Tile = typename ConvCfg<BM, X3>::Tile;
+    float* __restrict__ xhat, float* __restrict__ rstd_out, const float* __restrict__ x_amax,
+    const float* __restrict__ w_amax) {
+    using Tile = typename ConvCfg<BM, MODE>::Tile;
+    constexpr bool X3 = MODE != 0;
     constexpr int TM = Tile::TM, TN = Tile::TN;
     __shared__ float smem[Tile::SMEM_FLOATS];
     __shared__ float red[BM][4];
     const int m0 = blockIdx.x * BM;
     f32x16 acc[TM][TN];
     zero_acc(acc);
-    if constexpr (X3) Tile::run(acc, am, m0, wp, 16, 0, K, smem, (long)kC * K, kC * 16,    // plane stride used only if pre-split
-                                (int)((blockIdx.x * 4u) % (unsigned)(K / Tile::BK)));
-    else Tile::run(acc, am, m0, wp, 16, 0, K, smem, kC * 16);
+    if constexpr (ConvCfg<BM, MODE>::H2) {
+        const float sa = scale_for_amax(*x_amax), sb = scale_for_amax(*w_amax);
+        Tile::run(acc, am, m0, wp, 16, 0, K, smem, 0, kC * 16, (int)((blockIdx.x * 4u) % (unsigned)(K / Tile::BK)), sa, sb);
+        const float inv = 1.0f / (sa * sb);                      // powers of two: exact
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= inv;
+    } else if constexpr (X3) {
+        Tile::run(acc, am, m0, wp, 16, 0, K, smem, (long)kC * K, kC * 16,    // plane stride used only if pre-split
+                  (int)((blockIdx.x * 4u) % (unsigned)(K / Tile::BK)));
+    } else {
+        Tile::run(acc, am, m0, wp, 16, 0, K, smem, kC * 16);
+    }
 
     const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 3;
     int col[TN];
@@ -189,16 +245,18 @@ __global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 
 
 // stand-alone version for the top layer (its dy comes from autograd, not from a dgrad GEMM)
 constexpr int NB_ROWS = 32;   // rows per block (8 per wave)
+// dx_amax (may be NULL): max|dx| is accumulated into it for the fp16-split GEMMs that consume dx
 __global__ __launch_bounds__(256) void norm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ y,
     const float* __restrict__ rstd, const float* __restrict__ nw, float* __restrict__ dx,
-    float* __restrict__ colpart, int M) {
+    float* __restrict__ colpart, int M, float* __restrict__ dx_amax) {
     __shared__ float red[4][3][kC];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = lane * 4;
     const float4 w4 = *reinterpret_cast<const float4*>(nw + c);
     const float gw[4] = {w4.x, w4.y, w4.z, w4.w};
     float cs[3][4];
+    float amax = 0.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -231,6 +289,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
         for (int q = 0; q < 4; ++q) {
             ov[q] = rs * (dxh[q] - s1 - xh[q] * s2);
             cs[2][q] += ov[q];
+            amax = fmaxf(amax, fabsf(ov[q]));
         }
         o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
         *reinterpret_cast<float4*>(dx + (long)m * kC + c) = o;
@@ -245,18 +304,25 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
         const int a = i >> kCLog2, cc = i & (kC - 1);
         prow[i] = (red[0][a][cc] + red[1][a][cc]) + (red[2][a][cc] + red[3][a][cc]);
     }
+    if (dx_amax != nullptr) {
+        amax = wave_max(amax);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(dx_amax), __float_as_uint(amax));
+    }
 }
 
 // ------------------------------------------------------------------ dgrad (+ fused norm backward)
 // grid = (row tiles over B*(Lout+1), s phases).  am = 2-row windows over dx of THIS layer.
-template <int BM, bool FUSE, bool X3>
-__global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_dgrad_kernel(
+// MODE 2: dx_amax / w_amax bound the operands; prev_amax (FUSE, may be NULL) receives max|dprev|.
+template <int BM, bool FUSE, int MODE>
+__global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_dgrad_kernel(
     RowMap am, const float* __restrict__ wd, int s, int p, int Lin,
     const float* __restrict__ xhat_prev, const float* __restrict__ y_prev,
     const float* __restrict__ rstd_prev, const float* __restrict__ nw_prev,
-    float* __restrict__ dprev, float* __restrict__ colpart) {
-    using Tile = typename ConvCfg<BM, X3>::Tile;
-    constexpr int TM = Tile::TM, TN = Tile::TN, WAVES_M = ConvCfg<BM, X3>::WAVES_M;
+    float* __restrict__ dprev, float* __restrict__ colpart, const float* __restrict__ dx_amax,
+    const float* __restrict__ w_amax, float* __restrict__ prev_amax) {
+    using Tile = typename ConvCfg<BM, MODE>::Tile;
+    constexpr bool X3 = MODE != 0;
+    constexpr int TM = Tile::TM, TN = Tile::TN, WAVES_M = ConvCfg<BM, MODE>::WAVES_M;
     __shared__ float smem[Tile::SMEM_FLOATS];
     __shared__ float red[2][BM][4];
     __shared__ float colsum[3][kC];
@@ -264,7 +330,17 @@ __global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 
     const int ph = blockIdx.y;
     f32x16 acc[TM][TN];
     zero_acc(acc);
-    if constexpr (X3 && ConvCfg<BM, X3>::kPreSplitW)   // wd = 3 bf16 planes of [s][256][512]
+    if constexpr (ConvCfg<BM, MODE>::H2) {
+        const float sa = scale_for_amax(*dx_amax), sb = scale_for_amax(*w_amax);
+        Tile::run(acc, am, m0, wd + (long)ph * kC * 2 * kC, 16, 0, 2 * kC, smem, 0, kC * 16, 0, sa, sb);
+        const float inv = 1.0f / (sa * sb);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= inv;
+    } else if constexpr (X3 && ConvCfg<BM, MODE>::kPreSplitW)   // wd = 3 bf16 planes of [s][256][512]
         Tile::run(acc, am, m0, reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(wd) + (long)ph * kC * 2 * kC),
                   16, 0, 2 * kC, smem, (long)s * kC * 2 * kC, kC * 16);
     else if constexpr (X3)
@@ -311,6 +387,7 @@ __global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 
     for (int i = threadIdx.x; i < 3 * kC; i += Tile::NTHREADS) (&colsum[0][0])[i] = 0.f;
 
     f32x16 xh[TM][TN];
+    float amax = 0.f;
     float cs_w[TN], cs_b[TN], cs_c[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) { cs_w[tn] = 0.f; cs_b[tn] = 0.f; cs_c[tn] = 0.f; }
@@ -358,6 +435,7 @@ __global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 
                 for (int tn = 0; tn < TN; ++tn) {
                     const float dx = rs * (acc[tm][tn][r] - S1 - xh[tm][tn][r] * S2);
                     cs_c[tn] += dx;
+                    amax = fmaxf(amax, fabsf(dx));
                     dprev[(long)o * kC + col[tn]] = dx;
                 }
             }
@@ -382,22 +460,28 @@ __global__ __launch_bounds__((ConvCfg<BM, X3>::Tile::NTHREADS), (BM == 64 ? 2 : 
     __syncthreads();
     float* prow = colpart + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (3 * kC);
     for (int i = threadIdx.x; i < 3 * kC; i += Tile::NTHREADS) prow[i] = (&colsum[0][0])[i];
+    if (prev_amax != nullptr) {
+        amax = wave_max(amax);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(prev_amax), __float_as_uint(amax));
+    }
 }
 
 // ------------------------------------------------------------------ wgrad
-template <bool X3>
+template <int MODE>
 struct WgCfg {
-    using Tile = typename std::conditional<X3, TnTileX3<128, 128, 2, 2>, TnTile<128, 128, 2, 2>>::type;
+    using Tile = typename std::conditional<MODE != 0, TnTileX3<128, 128, 2, 2, 32, 1, MODE == 2 ? 2 : 3>,
+                                           TnTile<128, 128, 2, 2>>::type;
 };
 // 1-D grid of 8 * T * ceil(S/8) blocks, T = 2*K/128 output tiles; part[z][co][K].
 // XCD-aware mapping: the dispatcher places block b on XCD b % 8 (observed, speed only), and every
 // output tile of one row split z re-reads the same dx / activation rows, so all T tiles of a split
 // are given to ONE XCD (z % 8): its L2 fetches those rows once instead of eight L2s fetching them
 // eight times (the rows do not fit any single L2: 335 MB for layer 1 at B = 64).
-template <bool X3>
+template <int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
-    RowMap dxm, RowMap im, int K, int rows_per_split, int S, float* __restrict__ part) {
-    using WgTile = typename WgCfg<X3>::Tile;
+    RowMap dxm, RowMap im, int K, int rows_per_split, int S, float* __restrict__ part,
+    const float* __restrict__ dx_amax, const float* __restrict__ x_amax) {
+    using WgTile = typename WgCfg<MODE>::Tile;
     __shared__ float smem[WgTile::SMEM_FLOATS];
     const int T = 2 * (K / 128);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -408,7 +492,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const int mend = min(dxm.M, mbeg + rows_per_split);
     f32x16 acc[WgTile::TM][WgTile::TN];
     zero_acc(acc);
-    WgTile::run(acc, dxm, c0, im, n0, mbeg, mend, smem);
+    float inv = 1.0f;
+    if constexpr (MODE == 2) {
+        const float sa = scale_for_amax(*dx_amax), sb = scale_for_amax(*x_amax);
+        WgTile::run(acc, dxm, c0, im, n0, mbeg, mend, smem, sa, sb);
+        inv = 1.0f / (sa * sb);
+    } else {
+        WgTile::run(acc, dxm, c0, im, n0, mbeg, mend, smem);
+    }
     float* out = part + (long)z * kC * K;
 #pragma unroll
     for (int tm = 0; tm < WgTile::TM; ++tm)
@@ -417,7 +508,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
             const int row = c0 + WgTile::c_row(tm, r);
 #pragma unroll
             for (int tn = 0; tn < WgTile::TN; ++tn)
-                out[(long)row * K + n0 + WgTile::c_col(tn)] = acc[tm][tn][r];
+                out[(long)row * K + n0 + WgTile::c_col(tn)] = MODE == 2 ? acc[tm][tn][r] * inv : acc[tm][tn][r];
         }
 }
 
@@ -453,9 +544,9 @@ struct EncLayout {
     long y[4], xhat[5], rstd[5], mean0;    // offsets (floats) into the saved workspace
     long saved_total;
     long wp[5];                            // forward scratch: permuted weights (1..4)
-    long fwd_total;
+    long famax, fwd_total;
     // backward scratch
-    long wd[5], dx[5], dy0, part, colpart, tmp, small, conv0;
+    long wd[5], dx[5], dy0, part, colpart, tmp, small, conv0, bamax;
     long bwd_total;
     int wg_splits[5], wg_rows[5];
 };
@@ -488,6 +579,7 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     e.wp[0] = -1;
     // 1.5x: in split-bf16 mode the re-laid-out weight is three bf16 planes (6 bytes per weight)
     for (int i = 1; i < 5; ++i) { e.wp[i] = o; o += align64((long)kC * kGeom[i].k * kC * 3 / 2); }
+    e.famax = o; o += 64;                  // per-layer input bounds for the fp16-split mode
     e.fwd_total = o;
 
     o = 0;
@@ -518,6 +610,7 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     e.tmp = o; o += align64((long)kRowsSumGroups * 3 * kC);
     e.small = o; o += align64(5L * 3 * kC);
     e.conv0 = o; o += align64(cpc_conv0_backward_scratch_floats(B, Lw));
+    e.bamax = o; o += 64;                   // [i] = max|dx_i| (i = 1..4), [8 + i] = bound of layer i's input
     e.bwd_total = o;
     return true;
 }
@@ -525,27 +618,35 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
 template <int BM>
 static void launch_conv_fwd(const RowMap& am, const float* wp, int K, const float* bias,
                             const float* nw, const float* nb, float* y, float* xhat, float* rstd,
-                            hipStream_t st) {
-    if (g_mfma_mode == 1 && K % 32 == 0)
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, true>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, true>::Tile::NTHREADS),
-                           0, st, am, wp, K, bias, nw, nb, y, xhat, rstd);
+                            const float* x_amax, const float* w_amax, hipStream_t st) {
+    if (g_mfma_mode == 2 && K % 32 == 0)
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 2>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, 2>::Tile::NTHREADS),
+                           0, st, am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax);
+    else if (g_mfma_mode != 0 && K % 32 == 0)
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 1>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, 1>::Tile::NTHREADS),
+                           0, st, am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax);
     else
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, false>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, false>::Tile::NTHREADS),
-                           0, st, am, wp, K, bias, nw, nb, y, xhat, rstd);
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 0>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, 0>::Tile::NTHREADS),
+                           0, st, am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax);
 }
 
 template <int BM, bool FUSE>
 static void launch_conv_dgrad(const RowMap& am, const float* wd, int s, int p, int Lin,
                               const float* xhat_prev, const float* y_prev, const float* rstd_prev,
-                              const float* nw_prev, float* dprev, float* colpart, hipStream_t st) {
-    if (g_mfma_mode == 1)
-        hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE, true>), dim3(cdiv(am.M, BM), s),
-                           dim3(ConvCfg<BM, true>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
-                           rstd_prev, nw_prev, dprev, colpart);
+                              const float* nw_prev, float* dprev, float* colpart, const float* dx_amax,
+                              const float* w_amax, float* prev_amax, hipStream_t st) {
+    if (g_mfma_mode == 2)
+        hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE, 2>), dim3(cdiv(am.M, BM), s),
+                           dim3(ConvCfg<BM, 2>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
+                           rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, prev_amax);
+    else if (g_mfma_mode == 1)
+        hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE, 1>), dim3(cdiv(am.M, BM), s),
+                           dim3(ConvCfg<BM, 1>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
+                           rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, prev_amax);
     else
-        hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE, false>), dim3(cdiv(am.M, BM), s),
-                           dim3(ConvCfg<BM, false>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
-                           rstd_prev, nw_prev, dprev, colpart);
+        hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE, 0>), dim3(cdiv(am.M, BM), s),
+                           dim3(ConvCfg<BM, 0>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
+                           rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, prev_amax);
 }
 
 }  // namespace cpc
@@ -564,25 +665,42 @@ extern "C" int cpc_conv_weight_relayout(const float* w, float* wp, int k, void* 
     CPC_RETURN_IF(!w || !wp || k <= 0, CPC_ERR_ARG);
     const long nw_elems = (long)kC * k * kC;
     hipLaunchKernelGGL(permute_w_fwd_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, k,
-                       (g_mfma_mode == 1 && ConvCfg<128, true>::kPreSplitW) ? 1 : 0);
+                       (g_mfma_mode == 1 && ConvCfg<128, 1>::kPreSplitW) ? 1 : 0);
+    // max|w| for the fp16-split mode, kept behind the re-laid-out weight
+    if (g_mfma_mode == 2) {
+        float* amax = wp + nw_elems;
+        (void)hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream);
+        hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, nw_elems, amax);
+    }
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// out = max(out, max|x|) (out must be initialised, e.g. to 0): an exact upper bound for scale_for_amax
+extern "C" int cpc_absmax(const float* x, long n, float* out, void* stream) {
+    CPC_RETURN_IF(!x || !out || n <= 0, CPC_ERR_ARG);
+    hipLaunchKernelGGL(absmax_kernel, dim3(std::min<long>(cdiv(n, 4096), 1024)), dim3(256), 0, (hipStream_t)stream, x, n, out);
     CPC_LAUNCH_CHECK();
     return 0;
 }
 
 // The forward GEMM kernel alone, on a weight prepared by cpc_conv_weight_relayout (exactly one
 // kernel launch: this is what bench.py times for the roofline figure).
+// x_amax: device float, an upper bound of max|x| (read in the fp16-split mode only; see cpc_absmax).
 extern "C" int cpc_conv_gemm_forward(const float* x, const float* wp, const float* bias, const float* nw,
-                                     const float* nb, float* y, float* xhat, float* rstd, int B, int Lin,
-                                     int k, int s, int p, void* stream) {
+                                     const float* nb, float* y, float* xhat, float* rstd, const float* x_amax,
+                                     int B, int Lin, int k, int s, int p, void* stream) {
     CPC_RETURN_IF(B <= 0 || Lin <= 0 || k != 2 * s || Lin + 2 * p < k, CPC_ERR_SHAPE);
+    CPC_RETURN_IF(g_mfma_mode == 2 && !x_amax, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     const int Lout = conv_out_len(Lin, k, s, p);
     const RowMap am = conv_rows(x, B, Lin, Lout, s, p);
     const int K = k * kC;
+    const float* w_amax = wp + (long)kC * k * kC;
     switch (pick_bm(am.M)) {
-        case 128: launch_conv_fwd<128>(am, wp, K, bias, nw, nb, y, xhat, rstd, st); break;
-        case 64: launch_conv_fwd<64>(am, wp, K, bias, nw, nb, y, xhat, rstd, st); break;
-        default: launch_conv_fwd<32>(am, wp, K, bias, nw, nb, y, xhat, rstd, st); break;
+        case 128: launch_conv_fwd<128>(am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, st); break;
+        case 64: launch_conv_fwd<64>(am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, st); break;
+        default: launch_conv_fwd<32>(am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, st); break;
     }
     CPC_LAUNCH_CHECK();
     return 0;
@@ -597,19 +715,24 @@ extern "C" int cpc_conv_layer_forward(const float* x, const float* w, const floa
     CPC_RETURN_IF(B <= 0 || Lin <= 0 || k != 2 * s || Lin + 2 * p < k, CPC_ERR_SHAPE);
     int rc = cpc_conv_weight_relayout(w, wp, k, stream);
     if (rc) return rc;
-    return cpc_conv_gemm_forward(x, wp, bias, nw, nb, y, xhat, rstd, B, Lin, k, s, p, stream);
+    float* x_amax = wp + (long)kC * k * kC + 1;          // second spare slot behind the weight
+    (void)hipMemsetAsync(x_amax, 0, sizeof(float), (hipStream_t)stream);
+    rc = cpc_absmax(x, (long)B * Lin * kC, x_amax, stream);
+    if (rc) return rc;
+    return cpc_conv_gemm_forward(x, wp, bias, nw, nb, y, xhat, rstd, x_amax, B, Lin, k, s, p, stream);
 }
 
 // ReLU'/ChannelNorm backward of a whole (M,256) activation: dy -> dx, plus
 // small3 = [d norm.weight | d norm.bias | d conv.bias] (3*256 floats).
 // colpart: cdiv(M,32)*768 floats, tmp: kRowsSumGroups*768 floats.
+// dx_amax (may be NULL): device float that receives max(*dx_amax, max|dx|) -- initialise it to 0.
 extern "C" int cpc_norm_backward(const float* dy, const float* xhat, const float* y,
                                  const float* rstd, const float* nw, float* dx, float* colpart,
-                                 float* tmp, float* small3, int M, void* stream) {
+                                 float* tmp, float* small3, float* dx_amax, int M, void* stream) {
     CPC_RETURN_IF(M <= 0, CPC_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     const int nblk = cdiv(M, NB_ROWS);
-    hipLaunchKernelGGL(norm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, xhat, y, rstd, nw, dx, colpart, M);
+    hipLaunchKernelGGL(norm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, xhat, y, rstd, nw, dx, colpart, M, dx_amax);
     CPC_LAUNCH_CHECK();
     return rows_sum(colpart, nblk, 3 * kC, tmp, small3, st);
 }
@@ -618,17 +741,28 @@ extern "C" int cpc_norm_backward(const float* dy, const float* xhat, const float
 // fuse != 0: also applies the previous layer's ReLU'/ChannelNorm backward and writes that
 //   layer's pre-norm gradient to dprev (B,Lin,C) and its small3 gradients;
 // fuse == 0: writes the gradient w.r.t. the previous layer's OUTPUT to dprev.
+// dx_amax: device float, upper bound of max|dx| (mode 2 only; NULL = computed here with an extra pass over dx);
+// dprev_amax (fuse only, may be NULL): receives max(*dprev_amax, max|dprev|).
 extern "C" int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, int fuse,
                                     const float* xhat_prev, const float* y_prev,
                                     const float* rstd_prev, const float* nw_prev, float* dprev,
-                                    float* colpart, float* tmp, float* small3, int B, int Lin, int k,
-                                    int s, int p, void* stream) {
+                                    float* colpart, float* tmp, float* small3, const float* dx_amax,
+                                    float* dprev_amax, int B, int Lin, int k, int s, int p, void* stream) {
     CPC_RETURN_IF(B <= 0 || Lin <= 0 || k != 2 * s || Lin + 2 * p < k, CPC_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     const int Lout = conv_out_len(Lin, k, s, p);
     const long nw_elems = (long)kC * k * kC;
     hipLaunchKernelGGL(permute_w_dgrad_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wd, s,
-                       (g_mfma_mode == 1 && ConvCfg<128, true>::kPreSplitW) ? 1 : 0);
+                       (g_mfma_mode == 1 && ConvCfg<128, 1>::kPreSplitW) ? 1 : 0);
+    float* w_amax = wd + nw_elems;                    // spare floats behind the re-laid-out weight
+    if (g_mfma_mode == 2) {
+        (void)hipMemsetAsync(w_amax, 0, 2 * sizeof(float), st);
+        hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, st, w, nw_elems, w_amax);
+        if (!dx_amax) {
+            hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, dx, (long)B * Lout * kC, w_amax + 1);
+            dx_amax = w_amax + 1;
+        }
+    }
     // 2-row windows [q-1, q] over dx, q in [0, Lout]
     RowMap am;
     am.base = dx; am.R = Lout + 1; am.bstride = (long)Lout * kC; am.rstride = kC; am.off = -kC;
@@ -637,17 +771,17 @@ extern "C" int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, 
     const int nblk = cdiv(am.M, bm) * s;
     if (fuse) {
         switch (bm) {
-            case 128: launch_conv_dgrad<128, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, st); break;
-            case 64: launch_conv_dgrad<64, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, st); break;
-            default: launch_conv_dgrad<32, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, st); break;
+            case 128: launch_conv_dgrad<128, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, dprev_amax, st); break;
+            case 64: launch_conv_dgrad<64, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, dprev_amax, st); break;
+            default: launch_conv_dgrad<32, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, dprev_amax, st); break;
         }
         CPC_LAUNCH_CHECK();
         return rows_sum(colpart, nblk, 3 * kC, tmp, small3, st);
     }
     switch (bm) {
-        case 128: launch_conv_dgrad<128, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, st); break;
-        case 64: launch_conv_dgrad<64, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, st); break;
-        default: launch_conv_dgrad<32, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, st); break;
+        case 128: launch_conv_dgrad<128, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, nullptr, st); break;
+        case 64: launch_conv_dgrad<64, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, nullptr, st); break;
+        default: launch_conv_dgrad<32, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, nullptr, st); break;
     }
     CPC_LAUNCH_CHECK();
     return 0;
@@ -655,7 +789,9 @@ extern "C" int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, 
 
 // wgrad of one conv layer: dW (256,256,k) = sum over rows of dx (B,Lout,C) (x) im2col(x).
 // part: splits*256*k*256 floats of scratch.
-extern "C" int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part, float* dW, int B,
+// dx_amax, x_amax: device floats bounding max|dx| and max|x| (mode 2 only).
+extern "C" int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part, float* dW,
+                                    const float* dx_amax, const float* x_amax, int B,
                                     int Lin, int k, int s, int p, int splits, int rows_per_split,
                                     void* stream) {
     CPC_RETURN_IF(B <= 0 || Lin <= 0 || Lin + 2 * p < k || splits <= 0 || rows_per_split <= 0, CPC_ERR_SHAPE);
@@ -666,10 +802,13 @@ extern "C" int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part
     const RowMap im = conv_rows(x, B, Lin, Lout, s, p);
     CPC_RETURN_IF((long)splits * rows_per_split < dxm.M, CPC_ERR_SHAPE);
     const dim3 grid(8 * 2 * (K / 128) * cdiv(splits, 8));
-    if (g_mfma_mode == 1)
-        hipLaunchKernelGGL((conv_wgrad_kernel<true>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part);
+    CPC_RETURN_IF(g_mfma_mode == 2 && (!dx_amax || !x_amax), CPC_ERR_ARG);
+    if (g_mfma_mode == 2)
+        hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
+    else if (g_mfma_mode == 1)
+        hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<false>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part);
+        hipLaunchKernelGGL((conv_wgrad_kernel<0>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
     const long total = (long)kC * k * kC;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, part, splits, k, dW);
     CPC_LAUNCH_CHECK();
@@ -703,9 +842,16 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
     if (rc) return rc;
     for (int i = 1; i < 5; ++i) {
         float* yo = i == 4 ? z : saved + e.y[i];
-        rc = cpc_conv_layer_forward(saved + e.y[i - 1], params[4 * i], params[4 * i + 1], params[4 * i + 2],
-                                    params[4 * i + 3], scratch + e.wp[i], yo, saved + e.xhat[i],
-                                    saved + e.rstd[i], B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, stream);
+        float* wp = scratch + e.wp[i];
+        float* x_amax = scratch + e.famax + i;
+        rc = cpc_conv_weight_relayout(params[4 * i], wp, kGeom[i].k, stream);
+        if (rc) return rc;
+        if (g_mfma_mode == 2)     // the input is the previous layer's ChannelNorm + ReLU output: bounded by its affine
+            hipLaunchKernelGGL(norm_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, params[4 * (i - 1) + 2],
+                               params[4 * (i - 1) + 3], x_amax);
+        rc = cpc_conv_gemm_forward(saved + e.y[i - 1], wp, params[4 * i + 1], params[4 * i + 2], params[4 * i + 3], yo,
+                                   saved + e.xhat[i], saved + e.rstd[i], x_amax, B, e.L[i - 1], kGeom[i].k, kGeom[i].s,
+                                   kGeom[i].p, stream);
         if (rc) return rc;
     }
     return 0;
@@ -721,24 +867,32 @@ extern "C" int cpc_encoder_backward(const float* wave, const float* const* param
     float* colpart = scratch + e.colpart;
     float* tmp = scratch + e.tmp;
     float* small = scratch + e.small;          // [5][3][256]
+    // operand bounds of the fp16-split GEMMs: max|dx_i| is accumulated by the kernel that writes dx_i (integer
+    // atomicMax on the float bits: exact, order-independent); a layer's input is bounded by its producer's affine
+    float* amax = scratch + e.bamax;
+    (void)hipMemsetAsync(amax, 0, 64 * sizeof(float), st);
+    if (g_mfma_mode == 2)
+        for (int i = 1; i < 5; ++i)
+            hipLaunchKernelGGL(norm_bound_kernel, dim3(1), dim3(256), 0, st, params[4 * (i - 1) + 2], params[4 * (i - 1) + 3],
+                               amax + 8 + i);
     // top layer: ReLU'/norm backward of dz
     int rc = cpc_norm_backward(dz, saved + e.xhat[4], z, saved + e.rstd[4], params[18], scratch + e.dx[4],
-                               colpart, tmp, small + 4 * 3 * kC, B * e.L[4], stream);
+                               colpart, tmp, small + 4 * 3 * kC, amax + 4, B * e.L[4], stream);
     if (rc) return rc;
     for (int i = 4; i >= 1; --i) {
         const float* xin = saved + e.y[i - 1];
-        rc = cpc_conv_layer_wgrad(scratch + e.dx[i], xin, scratch + e.part, grads[4 * i], B, e.L[i - 1],
-                                  kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], stream);
+        rc = cpc_conv_layer_wgrad(scratch + e.dx[i], xin, scratch + e.part, grads[4 * i], amax + i, amax + 8 + i, B,
+                                  e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], stream);
         if (rc) return rc;
         if (i >= 2) {
             rc = cpc_conv_layer_dgrad(scratch + e.dx[i], params[4 * i], scratch + e.wd[i], 1,
                                       saved + e.xhat[i - 1], xin, saved + e.rstd[i - 1], params[4 * (i - 1) + 2],
-                                      scratch + e.dx[i - 1], colpart, tmp, small + (i - 1) * 3 * kC, B,
-                                      e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, stream);
+                                      scratch + e.dx[i - 1], colpart, tmp, small + (i - 1) * 3 * kC, amax + i,
+                                      amax + i - 1, B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, stream);
         } else {
             rc = cpc_conv_layer_dgrad(scratch + e.dx[1], params[4], scratch + e.wd[1], 0, nullptr, nullptr,
-                                      nullptr, nullptr, scratch + e.dy0, nullptr, nullptr, nullptr, B, e.L[0],
-                                      kGeom[1].k, kGeom[1].s, kGeom[1].p, stream);
+                                      nullptr, nullptr, scratch + e.dy0, nullptr, nullptr, nullptr, amax + 1, nullptr,
+                                      B, e.L[0], kGeom[1].k, kGeom[1].s, kGeom[1].p, stream);
         }
         if (rc) return rc;
     }

@@ -105,7 +105,7 @@ int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, flo
     if (am.M <= 0) return 0;
     if (N % 128 != 0 || K % 16 != 0 || K < 16) return CPC_ERR_SHAPE;
     const bool big = (long)cdiv(am.M, 128) * (N / 128) >= 384;
-    const bool x3 = g_mfma_mode == 1 && K % 32 == 0;
+    const bool x3 = g_mfma_mode != 0 && K % 32 == 0;      // mode 2 (fp16 split) covers the conv layers only
     const dim3 gb(cdiv(am.M, 128), N / 128), gs(cdiv(am.M, 64), N / 64);
     if (big && x3)
         hipLaunchKernelGGL((nt_gemm_kernel<NtBigX3, 128>), gb, dim3(NtBigX3::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
@@ -151,7 +151,7 @@ int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, flo
     int S, rows;
     tn_gemm_plan(am.M, N1, N2, &S, &rows);
     const dim3 grid(8 * (N1 / 128) * (N2 / 128) * cdiv(S, 8));
-    if (g_mfma_mode == 1)
+    if (g_mfma_mode != 0)
         hipLaunchKernelGGL((tn_gemm_kernel<TnGX3>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n);
     else
         hipLaunchKernelGGL((tn_gemm_kernel<TnG>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n);

@@ -285,6 +285,48 @@ __device__ __forceinline__ void split3_pack4(const float4& v, uint2& ph, uint2& 
     pl = make_uint2((l0 >> 16) | l1, (l2 >> 16) | l3);
 }
 
+// ---- two fp16 pieces ("H2"): x*s = h + l with h = fp16(x*s) (round to nearest), l = fp16(x*s - h); the
+// subtraction is exact and |x*s - h - l| <= 2^-22 |x*s|.  A product needs only hh + hl + lh (the dropped l*l
+// term is <= 2^-22 |ab|): fp32-level accuracy at HALF the MFMAs of the three-piece bf16 split, provided the
+// power-of-two scale s keeps |x*s| inside fp16's range -- callers derive it from a bound on max|x| (scale_for_amax).
+__device__ __forceinline__ void split2h_pack4(const float4& v, float s, uint2& ph, uint2& pl) {
+    const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1, h2 = (_Float16)x2, h3 = (_Float16)x3;
+    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+    const _Float16 l2 = (_Float16)(x2 - (float)h2), l3 = (_Float16)(x3 - (float)h3);
+    ph = make_uint2(__builtin_bit_cast(unsigned, f16x2{h0, h1}), __builtin_bit_cast(unsigned, f16x2{h2, h3}));
+    pl = make_uint2(__builtin_bit_cast(unsigned, f16x2{l0, l1}), __builtin_bit_cast(unsigned, f16x2{l2, l3}));
+}
+// power-of-two scale that maps a tensor with max|x| <= amax into [2^13, 2^14) (fp16 max is 65504)
+__device__ __forceinline__ float scale_for_amax(float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+    int e;
+    (void)frexpf(amax, &e);                            // amax = m * 2^e, m in [0.5, 1)
+    e = 14 - e;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return ldexpf(1.0f, e);
+}
+
+template <int NP> struct SplitPlanes;
+template <> struct SplitPlanes<3> {                  // three bf16 pieces, six products, no scaling
+    static constexpr int NPROD = 6;
+    __device__ static __forceinline__ void split(const float4& v, float, uint2 (&p)[3]) { split3_pack4(v, p[0], p[1], p[2]); }
+    __device__ static __forceinline__ int pa(int q) { constexpr int t[6] = {2, 0, 1, 1, 0, 0}; return t[q]; }   // l*h, h*l, m*m,
+    __device__ static __forceinline__ int pb(int q) { constexpr int t[6] = {0, 2, 1, 0, 1, 0}; return t[q]; }   // m*h, h*m, h*h
+    __device__ static __forceinline__ f32x16 mfma(const s16x8& a, const s16x8& b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct SplitPlanes<2> {                  // two fp16 pieces, three products, power-of-two operand scales
+    static constexpr int NPROD = 3;
+    __device__ static __forceinline__ void split(const float4& v, float s, uint2 (&p)[2]) { split2h_pack4(v, s, p[0], p[1]); }
+    __device__ static __forceinline__ int pa(int q) { constexpr int t[3] = {1, 0, 0}; return t[q]; }            // l*h, h*l, h*h
+    __device__ static __forceinline__ int pb(int q) { constexpr int t[3] = {0, 1, 0}; return t[q]; }
+    __device__ static __forceinline__ f32x16 mfma(const s16x8& a, const s16x8& b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
 // One BK-deep chunk of the split-bf16 product from K-major bf16 planes in LDS.
 // planes: [h | m | l], each `plane` halves; rows of LDH halves.  The six partial products of a
 // k-step are issued product-major so that consecutive MFMAs hit different accumulators.
@@ -303,47 +345,51 @@ __device__ __forceinline__ void load_b(BSplitReg& dst, const float*, const unsig
 __device__ __forceinline__ void planes_of(const float4& v, uint2& ph, uint2& pm, uint2& pl) { split3_pack4(v, ph, pm, pl); }
 __device__ __forceinline__ void planes_of(const BSplitReg& v, uint2& ph, uint2& pm, uint2& pl) { ph = v.h; pm = v.m; pl = v.l; }
 
-template <int TM, int TN, int BK, int LDH, bool SWZ = false>
+template <int TM, int TN, int BK, int LDH, bool SWZ = false, int NP = 3>
 __device__ __forceinline__ void x3_compute(f32x16 (&acc)[TM][TN], const unsigned short* As, int planeA,
                                            const unsigned short* Bs, int planeB, int arow, int brow, int kofs) {
     constexpr int SWM = BK / 8 - 1;
+    using SP = SplitPlanes<NP>;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-        bf16x8 af[TM][3], bf[TN][3];
+        s16x8 af[TM][NP], bf[TN][NP];
         const int pair = (ks * 16 + kofs) >> 3;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int row = arow + tm * 32;
             const int ko = SWZ ? ((pair ^ ((row >> 3) & SWM)) << 3) : (ks * 16 + kofs);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                af[tm][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(As + pl * planeA + row * LDH + ko));
+            for (int pl = 0; pl < NP; ++pl)
+                af[tm][pl] = *reinterpret_cast<const s16x8*>(As + pl * planeA + row * LDH + ko);
         }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int row = brow + tn * 32;
             const int ko = SWZ ? ((pair ^ ((row >> 3) & SWM)) << 3) : (ks * 16 + kofs);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                bf[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(Bs + pl * planeB + row * LDH + ko));
+            for (int pl = 0; pl < NP; ++pl)
+                bf[tn][pl] = *reinterpret_cast<const s16x8*>(Bs + pl * planeB + row * LDH + ko);
         }
-        // (A piece, B piece): l*h, h*l, m*m, m*h, h*m, h*h  -- small terms first
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+        // small terms first; consecutive MFMAs hit different accumulators
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = 0; q < SP::NPROD; ++q)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][PA[q]], bf[tn][PB[q]], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = SP::mfma(af[tm][SP::pa(q)], bf[tn][SP::pb(q)], acc[tm][tn]);
     }
 }
 
 // BSPLIT: the B operand (weights) is already stored as three bf16 planes [3][N][ldb] (written once per
 // step by the weight re-layout kernels), so only the A operand is split while staging.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1, bool SKEW = false, bool BSPLIT = false>
+// NP: 3 = three bf16 pieces / six products (no operand scaling), 2 = two fp16 pieces / three products (operands
+// pre-multiplied by the power-of-two scales sa, sb given to run(); the caller multiplies the result by 1/(sa*sb)).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1, bool SKEW = false, bool BSPLIT = false,
+          int NP = 3>
 struct NtTileX3 {
+    using SP = SplitPlanes<NP>;
+    static_assert(!BSPLIT || NP == 3, "pre-split B planes exist for the bf16 split only");
     static constexpr int BK = BK_;       // 32 with one LDS stage (default), or 16 double-buffered
     static constexpr int LDH = BK + 8;   // halves per LDS row (80 B / 48 B: 16-byte aligned, conflict-free b128)
     static constexpr int SPR = BK / 4;   // float4 slots per row
@@ -355,7 +401,7 @@ struct NtTileX3 {
     static constexpr int B_PER = (B_SLOTS + NTHREADS - 1) / NTHREADS;
     static constexpr bool A_EXACT = A_SLOTS % NTHREADS == 0, B_EXACT = B_SLOTS % NTHREADS == 0;   // no partial slot
     static constexpr int PLANE_A = BM * LDH, PLANE_B = BN * LDH;          // halves
-    static constexpr int STAGE_H = 3 * (PLANE_A + PLANE_B);               // halves per stage
+    static constexpr int STAGE_H = NP * (PLANE_A + PLANE_B);              // halves per stage
     static constexpr int SMEM_FLOATS = STAGES * STAGE_H / 2;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert(STAGES == 1 || STAGES == 2, "one or two LDS stages");
@@ -371,7 +417,8 @@ struct NtTileX3 {
 
     __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int m0,
                                const float* __restrict__ Bmat, int ldb, int n0, int K,
-                               float* smem_f, long bplane = 0, int bblk = 16, int rot = 0) {     // bblk: see NtTile::run
+                               float* smem_f, long bplane = 0, int bblk = 16, int rot = 0,      // bblk: see NtTile::run
+                               float sa = 1.0f, float sb = 1.0f) {
         // rot (pipelined schedule only): this workgroup walks the K chunks starting at chunk `rot` (mod K/BK).
         // All workgroups of a conv layer otherwise read the same 64-byte channel slice of rows that are a
         // multiple of 1 KB apart at the same moment, i.e. one L2 channel out of 16.
@@ -403,7 +450,7 @@ struct NtTileX3 {
             const long bo = (long)(n0 + r) * ldb + (long)(kv >> 2) * bblk + (kv & 3) * 4;
             bp[i] = Bmat + bo;
             bp16[i] = reinterpret_cast<const unsigned short*>(Bmat) + bo;
-            b_lds[i] = 3 * PLANE_A + r * LDH + kv * 4;
+            b_lds[i] = NP * PLANE_A + r * LDH + kv * 4;
         }
         using BReg = typename std::conditional<BSPLIT, BSplitReg, float4>::type;
         float4 ra[A_PER], ra1[A_PER];
@@ -424,20 +471,19 @@ struct NtTileX3 {
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
                 if (A_EXACT || a_on[i]) {            // exact tilings stay branch-free: one basic block, so the
-                    uint2 ph, pm, pl;                //  split can be scheduled into the MFMA shadow
-                    split3_pack4(ra[i], ph, pm, pl);
-                    *reinterpret_cast<uint2*>(smem + a_lds[i]) = ph;
-                    *reinterpret_cast<uint2*>(smem + PLANE_A + a_lds[i]) = pm;
-                    *reinterpret_cast<uint2*>(smem + 2 * PLANE_A + a_lds[i]) = pl;
+                    uint2 pp[NP];                    //  split can be scheduled into the MFMA shadow
+                    SP::split(ra[i], sa, pp);
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(smem + pl * PLANE_A + a_lds[i]) = pp[pl];
                 }
 #pragma unroll
             for (int i = 0; i < B_PER; ++i)
                 if (B_EXACT || b_on[i]) {
-                    uint2 ph, pm, pl;
-                    planes_of(rb[i], ph, pm, pl);
-                    *reinterpret_cast<uint2*>(smem + b_lds[i]) = ph;
-                    *reinterpret_cast<uint2*>(smem + PLANE_B + b_lds[i]) = pm;
-                    *reinterpret_cast<uint2*>(smem + 2 * PLANE_B + b_lds[i]) = pl;
+                    uint2 pp[NP];
+                    if constexpr (BSPLIT) planes_of(rb[i], pp[0], pp[1], pp[2]);
+                    else SP::split(rb[i], sb, pp);
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(smem + pl * PLANE_B + b_lds[i]) = pp[pl];
                 }
         };
         const int arow = wm * WM + (lane & 31);
@@ -445,7 +491,7 @@ struct NtTileX3 {
         const int kofs = 8 * (lane >> 5);
         auto compute = [&](int st_) __attribute__((always_inline)) {
             const unsigned short* smem = smem0 + st_ * STAGE_H;
-            x3_compute<TM, TN, BK, LDH>(acc, smem, PLANE_A, smem + 3 * PLANE_A, PLANE_B, arow, brow, kofs);
+            x3_compute<TM, TN, BK, LDH, false, NP>(acc, smem, PLANE_A, smem + NP * PLANE_A, PLANE_B, arow, brow, kofs);
         };
 
         auto gload = [&](int kc_) __attribute__((always_inline)) { gload_to(kc_, ra, rb); };
@@ -463,45 +509,43 @@ struct NtTileX3 {
             static_assert(BK == 16, "pipelined schedule is written for one k-step per chunk");
             float4 ra2[A_PER], ra3[A_PER];
             BReg rb2[B_PER], rb3[B_PER];
-            bf16x8 fa[2][TM][3], fb[2][TN][3];
-            auto lfrag = [&](int st_, bf16x8 (&af)[TM][3], bf16x8 (&bf)[TN][3]) __attribute__((always_inline)) {
+            s16x8 fa[2][TM][NP], fb[2][TN][NP];
+            auto lfrag = [&](int st_, s16x8 (&af)[TM][NP], s16x8 (&bf)[TN][NP]) __attribute__((always_inline)) {
                 const unsigned short* As = smem0 + st_ * STAGE_H;
-                const unsigned short* Bs = As + 3 * PLANE_A;
+                const unsigned short* Bs = As + NP * PLANE_A;
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        af[tm][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(
-                                                                     As + pl * PLANE_A + (arow + tm * 32) * LDH + kofs));
+                    for (int pl = 0; pl < NP; ++pl)
+                        af[tm][pl] = *reinterpret_cast<const s16x8*>(As + pl * PLANE_A + (arow + tm * 32) * LDH + kofs);
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        bf[tn][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(
-                                                                     Bs + pl * PLANE_B + (brow + tn * 32) * LDH + kofs));
+                    for (int pl = 0; pl < NP; ++pl)
+                        bf[tn][pl] = *reinterpret_cast<const s16x8*>(Bs + pl * PLANE_B + (brow + tn * 32) * LDH + kofs);
             };
-            auto mfma6 = [&](const bf16x8 (&af)[TM][3], const bf16x8 (&bf)[TN][3]) __attribute__((always_inline)) {
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0};      // (A piece, B piece): l*h, h*l, m*m, m*h, h*m, h*h
-                constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+            auto mfma6 = [&](const s16x8 (&af)[TM][NP], const s16x8 (&bf)[TN][NP]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
+                for (int q = 0; q < SP::NPROD; ++q)
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][PA[q]], bf[tn][PB[q]], acc[tm][tn], 0, 0, 0);
+                            acc[tm][tn] = SP::mfma(af[tm][SP::pa(q)], bf[tn][SP::pb(q)], acc[tm][tn]);
             };
             auto interleave = [&]() __attribute__((always_inline)) {
-                constexpr int NMFMA = TM * TN * 6;
-                constexpr int NRD = 3 * (TM + TN);                         // ds_read_b128 per chunk
-                constexpr int NWR = 3 * (A_PER + B_PER);                   // 8-byte LDS stores per chunk
+                constexpr int NMFMA = TM * TN * SP::NPROD;
+                constexpr int NRD = NP * (TM + TN);                        // ds_read_b128 per chunk
+                constexpr int NWR = NP * (A_PER + B_PER);                  // 8-byte LDS stores per chunk
+                constexpr int VPM = NP == 3 ? 3 : 4;                       // VALU per MFMA slot (fewer MFMAs to hide behind)
+                constexpr int WEVERY = NMFMA / (A_PER + B_PER);            // MFMAs between the stores of two slots
 #pragma unroll
                 for (int q = 0; q < NMFMA; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
                     if (q < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // VALU
-                    if (q % 8 == 7 && q / 8 < NWR / 3) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);   // DS write
-                    if (q % 8 == 3 && q / 8 < A_PER + B_PER) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);   // VALU
+                    if (q % WEVERY == WEVERY - 1) __builtin_amdgcn_sched_group_barrier(0x200, NP, 0);        // DS write
+                    if (q % WEVERY == WEVERY / 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // VMEM read
                 }
             };
             bool va[A_PER], va1[A_PER], va2[A_PER], va3[A_PER];
@@ -726,8 +770,8 @@ RowCursor ca[A_PER], cb[B_PER];
 // one 8-byte LDS store.  LDS then holds the same K-major planes as NtTileX3 ([column][m]) and the
 // compute step is shared.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1>
-struct TnTileX3 {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1, int NP = 3>
+struct TnTileX3 {   // NP: see NtTileX3
     static constexpr int BK = BK_;
     static constexpr int LDH = BK + 8;
     static constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
@@ -737,7 +781,7 @@ struct TnTileX3 {
     static constexpr int A_PER = (A_BLK + NTHREADS - 1) / NTHREADS;
     static constexpr int B_PER = (B_BLK + NTHREADS - 1) / NTHREADS;
     static constexpr int PLANE_A = BM * LDH, PLANE_B = BN * LDH;
-    static constexpr int STAGE_H = 3 * (PLANE_A + PLANE_B);
+    static constexpr int STAGE_H = NP * (PLANE_A + PLANE_B);
     static constexpr int SMEM_FLOATS = STAGES * STAGE_H / 2;
 
     __device__ static __forceinline__ int c_row(int tm, int reg) {
@@ -749,33 +793,55 @@ struct TnTileX3 {
         return (wave % WAVES_N) * WN + tn * 32 + (lane & 31);
     }
 
-    // 4 rows x 4 columns of fp32 -> for each column (x,y,z,w of the float4s) the three planes of its
-    // 4 consecutive-m halves, stored at column-major LDS rows.
+    // 4 rows x 4 columns of fp32 -> for each column (x,y,z,w of the float4s) the NP planes of its
+    // 4 consecutive-m halves, stored at column-major LDS rows.  `scale`: operand scale of the fp16 split.
     __device__ static __forceinline__ void store_block(unsigned short* base, int plane, int col0, int mofs,
-                                                       const float4 (&v)[4]) {
-        unsigned h[4][4], m[4][4], l[4][4];      // [row][col]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            split3(v[r].x, h[r][0], m[r][0], l[r][0]);
-            split3(v[r].y, h[r][1], m[r][1], l[r][1]);
-            split3(v[r].z, h[r][2], m[r][2], l[r][2]);
-            split3(v[r].w, h[r][3], m[r][3], l[r][3]);
-        }
+                                                       const float4 (&v)[4], float scale) {
         // 4-row block `mofs/4` of column group col0/4 goes to k-slot (mofs/4) ^ 2*((col0/8) & SWM): with the
         // (8 column groups x 2 row blocks) lane order below, a 16-lane group then covers 16 distinct banks.
         constexpr int SWM = BK / 8 - 1;
         const int mphys = (((mofs >> 2) ^ (2 * ((col0 >> 3) & SWM))) << 2);
+        if constexpr (NP == 3) {
+            unsigned h[4][4], m[4][4], l[4][4];      // [row][col]
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            unsigned short* dst = base + (col0 + c) * LDH + mphys;
-            *reinterpret_cast<uint2*>(dst) = make_uint2((h[0][c] >> 16) | h[1][c], (h[2][c] >> 16) | h[3][c]);
-            *reinterpret_cast<uint2*>(dst + plane) = make_uint2((m[0][c] >> 16) | m[1][c], (m[2][c] >> 16) | m[3][c]);
-            *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2((l[0][c] >> 16) | l[1][c], (l[2][c] >> 16) | l[3][c]);
+            for (int r = 0; r < 4; ++r) {
+                split3(v[r].x, h[r][0], m[r][0], l[r][0]);
+                split3(v[r].y, h[r][1], m[r][1], l[r][1]);
+                split3(v[r].z, h[r][2], m[r][2], l[r][2]);
+                split3(v[r].w, h[r][3], m[r][3], l[r][3]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned short* dst = base + (col0 + c) * LDH + mphys;
+                *reinterpret_cast<uint2*>(dst) = make_uint2((h[0][c] >> 16) | h[1][c], (h[2][c] >> 16) | h[3][c]);
+                *reinterpret_cast<uint2*>(dst + plane) = make_uint2((m[0][c] >> 16) | m[1][c], (m[2][c] >> 16) | m[3][c]);
+                *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2((l[0][c] >> 16) | l[1][c], (l[2][c] >> 16) | l[3][c]);
+            }
+        } else {
+            _Float16 h[4][4], l[4][4];               // [row][col]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x[4] = {v[r].x * scale, v[r].y * scale, v[r].z * scale, v[r].w * scale};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    h[r][c] = (_Float16)x[c];
+                    l[r][c] = (_Float16)(x[c] - (float)h[r][c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned short* dst = base + (col0 + c) * LDH + mphys;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, f16x2{h[0][c], h[1][c]}),
+                                                            __builtin_bit_cast(unsigned, f16x2{h[2][c], h[3][c]}));
+                *reinterpret_cast<uint2*>(dst + plane) = make_uint2(__builtin_bit_cast(unsigned, f16x2{l[0][c], l[1][c]}),
+                                                                    __builtin_bit_cast(unsigned, f16x2{l[2][c], l[3][c]}));
+            }
         }
     }
 
     __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int c0,
-                               const RowMap& bm, int n0, int mbeg, int mend, float* smem_f) {
+                               const RowMap& bm, int n0, int mbeg, int mend, float* smem_f,
+                               float sa = 1.0f, float sb = 1.0f) {
         unsigned short* smem0 = reinterpret_cast<unsigned short*>(smem_f);
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -835,17 +901,17 @@ struct TnTileX3 {
             unsigned short* smem = smem0 + st_ * STAGE_H;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
-                if (a_on[i]) store_block(smem, PLANE_A, a_c[i], a_m[i], ra[i]);
+                if (a_on[i]) store_block(smem, PLANE_A, a_c[i], a_m[i], ra[i], sa);
 #pragma unroll
             for (int i = 0; i < B_PER; ++i)
-                if (b_on[i]) store_block(smem + 3 * PLANE_A, PLANE_B, b_c[i], b_m[i], rb[i]);
+                if (b_on[i]) store_block(smem + NP * PLANE_A, PLANE_B, b_c[i], b_m[i], rb[i], sb);
         };
         const int arow = wm * WM + (lane & 31);
         const int brow = wn * WN + (lane & 31);
         const int kofs = 8 * (lane >> 5);
         auto compute = [&](int st_) __attribute__((always_inline)) {
             const unsigned short* smem = smem0 + st_ * STAGE_H;
-            x3_compute<TM, TN, BK, LDH, true>(acc, smem, PLANE_A, smem + 3 * PLANE_A, PLANE_B, arow, brow, kofs);
+            x3_compute<TM, TN, BK, LDH, true, NP>(acc, smem, PLANE_A, smem + NP * PLANE_A, PLANE_B, arow, brow, kofs);
         };
         gload(0);
         sstore(0);

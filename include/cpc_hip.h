@@ -28,9 +28,14 @@ extern "C" {
 int cpc_abi_version(void);
 
 /* Arithmetic of the NT GEMMs (conv forward/dgrad, projections, heads):
- *   1 (default) bf16 matrix pipe, fp32 operands split by truncation into three bf16 pieces, six
+ *   1 bf16 matrix pipe, fp32 operands split by truncation into three bf16 pieces, six
  *     bf16 MFMAs per product, fp32 accumulate: error <= 2^-23 per product (fp32 level), 2.67x the rate;
- *   0 exact-f32 MFMA (v_mfma_f32_32x32x2_f32). */
+ *   0 exact-f32 MFMA (v_mfma_f32_32x32x2_f32);
+ *   2 (default) fp16 matrix pipe for the 128-row conv tiles, operands scaled by a power of two (from a bound on their max|.|) and split into two
+ *     fp16 pieces, three fp16 MFMAs per product (hh + hl + lh), fp32 accumulate: error <= 2^-21 per product,
+ *     half the MFMAs of mode 1.  Applies to the conv layers (forward, dgrad, wgrad), whose operand bounds
+ *     come for free (ChannelNorm affine; max|gradient| accumulated by the producing kernel); the small generic
+ *     GEMMs (projections, heads, weight gradients of the AR / criterion) run as in mode 1. */
 int cpc_set_mfma_mode(int mode);
 
 /* ---------------------------------------------------------------- encoder ----
@@ -61,20 +66,31 @@ int cpc_conv_layer_forward(const float* x, const float* w, const float* bias, co
  * split-bf16 mode.  wp: 256*k*256*3/2 floats. */
 int cpc_conv_weight_relayout(const float* w, float* wp, int k, void* stream);
 /* The forward GEMM kernel alone on a weight prepared by cpc_conv_weight_relayout (one launch). */
+/* x_amax: device float holding an upper bound of max|x| (cpc_absmax, or the bound of the producing ChannelNorm);
+ * read in mode 2 only, may be NULL otherwise. */
 int cpc_conv_gemm_forward(const float* x, const float* wp, const float* bias, const float* nw,
-                          const float* nb, float* y, float* xhat, float* rstd, int B, int Lin, int k,
-                          int s, int p, void* stream);
+                          const float* nb, float* y, float* xhat, float* rstd, const float* x_amax, int B,
+                          int Lin, int k, int s, int p, void* stream);
+/* *out = max(*out, max_i |x_i|), exact and order-independent (*out must be initialised, e.g. 0). */
+int cpc_absmax(const float* x, long n, float* out, void* stream);
 /* ReLU' + ChannelNorm backward over M rows; small3 = [d norm.w | d norm.b | d conv.bias]. */
+/* dx_amax (may be NULL): device float that receives max(*dx_amax, max|dx|) (initialise to 0); it is the operand
+ * bound the mode-2 dgrad / wgrad of this layer read. */
 int cpc_norm_backward(const float* dy, const float* xhat, const float* y, const float* rstd,
-                      const float* nw, float* dx, float* colpart, float* tmp, float* small3, int M,
-                      void* stream);
+                      const float* nw, float* dx, float* colpart, float* tmp, float* small3,
+                      float* dx_amax, int M, void* stream);
 /* wd: 256*k*256*3/2 floats of scratch (per-phase re-laid-out weight). */
+/* dx_amax: device float bounding max|dx| (mode 2; NULL = computed with an extra pass over dx);
+ * dprev_amax (fuse only, may be NULL): receives max(*dprev_amax, max|dprev|). */
 int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, int fuse,
                          const float* xhat_prev, const float* y_prev, const float* rstd_prev,
                          const float* nw_prev, float* dprev, float* colpart, float* tmp,
-                         float* small3, int B, int Lin, int k, int s, int p, void* stream);
-int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part, float* dW, int B, int Lin,
-                         int k, int s, int p, int splits, int rows_per_split, void* stream);
+                         float* small3, const float* dx_amax, float* dprev_amax, int B, int Lin, int k,
+                         int s, int p, void* stream);
+/* dx_amax, x_amax: device floats bounding max|dx| and max|x| (read in mode 2 only). */
+int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part, float* dW, const float* dx_amax,
+                         const float* x_amax, int B, int Lin, int k, int s, int p, int splits,
+                         int rows_per_split, void* stream);
 
 /* 1 (default): the two-layer recurrence runs as one persistent launch whenever all of its workgroups can
  * be resident at once (gru.hip); 0: one launch per time step.  Both give bit-identical results. */

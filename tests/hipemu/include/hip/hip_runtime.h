@@ -216,6 +216,29 @@ inline f32x16 mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int
     return c;
 }
 
+// v_mfma_f32_32x32x16_f16: same operand layout with IEEE half elements
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+inline f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c, int, int, int) {
+    WaveBuf& w = my_wave();
+    int ph = w.phase, l = lane_id();
+    memcpy(w.va[ph][l], &a, 16);
+    memcpy(w.vb[ph][l], &b, 16);
+    wave_sync();
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            _Float16 x, y;
+            memcpy(&x, &w.va[ph][row + 32 * (k >> 3)][k & 7], 2);
+            memcpy(&y, &w.vb[ph][col + 32 * (k >> 3)][k & 7], 2);
+            acc = fmaf((float)x, (float)y, acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur->tid)
@@ -265,6 +288,11 @@ static inline float atomicAdd(float* p, float v) {
 }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicMax(unsigned* p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 static inline void unsafeAtomicAdd(float* p, float v) { (void)atomicAdd(p, v); }
 
 static inline int min(int a, int b) { return a < b ? a : b; }
@@ -277,6 +305,7 @@ static inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu::mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu::mfma_f32_32x32x16_bf16
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu::mfma_f32_32x32x16_f16
 static inline unsigned __float_as_uint(float x) { return hipemu::bits(x); }
 static inline float __uint_as_float(unsigned u) { return hipemu::unbits<float>(u); }
 #define __builtin_amdgcn_readfirstlane(x) (x)

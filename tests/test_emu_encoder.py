@@ -6,6 +6,11 @@ import ctypes
 import pytest
 import torch
 
+
+def _lib_default_mode():
+    from cpc_audio_amd._lib import DEFAULT_MFMA_MODE
+    return DEFAULT_MFMA_MODE
+
 from emu_util import P, emu, rel_err
 from oracle import cpc_oracle as O
 
@@ -25,9 +30,10 @@ def _oracle_encoder(p, wave, dz, relu_override=None):
 
 
 @pytest.mark.parametrize("B,L,bm,mode", [(2, 1280, 0, 1), (1, 1370, 64, 1), (1, 1600, 128, 1), (3, 1290, 128, 0),
-                                          (2, 1280, 0, 0)])
+                                          (2, 1280, 0, 0), (1, 1600, 128, 2), (2, 1280, 0, 2), (1, 1370, 64, 2)])
 def test_encoder_forward_backward_emulated(B, L, bm, mode):
-    """mode 1: NT GEMMs on the bf16 pipe with 3-piece split operands; mode 0: exact-f32 MFMA."""
+    """mode 1: NT GEMMs on the bf16 pipe with 3-piece split operands; mode 0: exact-f32 MFMA; mode 2: fp16 pipe with
+    scaled 2-piece split operands."""
     lib = emu()
     assert lib.cpc_set_conv_tile(bm) == 0
     assert lib.cpc_set_mfma_mode(mode) == 0
@@ -72,4 +78,4 @@ def test_encoder_forward_backward_emulated(B, L, bm, mode):
         assert not bad, bad
     finally:
         lib.cpc_set_conv_tile(0)
-        lib.cpc_set_mfma_mode(1)
+        lib.cpc_set_mfma_mode(_lib_default_mode())

@@ -4,6 +4,11 @@ import ctypes
 import pytest
 import torch
 
+
+def _lib_default_mode():
+    from cpc_audio_amd._lib import DEFAULT_MFMA_MODE
+    return DEFAULT_MFMA_MODE
+
 from emu_util import P, emu, rel_err
 from oracle import cpc_oracle as O
 
@@ -15,7 +20,7 @@ def test_gemm_nt_tn_emulated(mode):
     try:
         _gemm_checks(lib)
     finally:
-        lib.cpc_set_mfma_mode(1)
+        lib.cpc_set_mfma_mode(_lib_default_mode())
 
 
 def _gemm_checks(lib):

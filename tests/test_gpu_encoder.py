@@ -4,6 +4,11 @@ import ctypes
 import pytest
 import torch
 
+
+def _lib_default_mode():
+    from cpc_audio_amd._lib import DEFAULT_MFMA_MODE
+    return DEFAULT_MFMA_MODE
+
 from oracle import cpc_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -47,7 +52,7 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1):
               "encoder_backward")
     torch.cuda.synchronize()
     lib.cpc_set_conv_tile(0)
-    lib.cpc_set_mfma_mode(1)
+    lib.cpc_set_mfma_mode(_lib_default_mode())
     # oracle
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("gEncoder")}
     acts = []
@@ -61,9 +66,11 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1):
 
 
 @pytest.mark.parametrize("B,L,bm,mode", [(2, 20480, 0, 1), (3, 20480, 128, 1), (1, 4330, 64, 1), (8, 20480, 0, 1),
-                                          (3, 20480, 0, 0), (2, 10240, 32, 0)])
+                                          (3, 20480, 0, 0), (2, 10240, 32, 0), (8, 20480, 0, 2), (3, 20480, 128, 2),
+                                          (1, 4330, 64, 2), (2, 10240, 32, 2)])
 def test_encoder_matches_oracle(B, L, bm, mode):
-    """mode 1 = bf16 pipe with 3-piece split operands (default), mode 0 = exact-f32 MFMA."""
+    """mode 1 = bf16 pipe with 3-piece split operands, mode 0 = exact-f32 MFMA, mode 2 = fp16 pipe with scaled
+    2-piece split operands."""
     dev = _dev()
     from cpc_audio_amd import _lib
     lib = _lib.get()

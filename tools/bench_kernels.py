@@ -7,6 +7,11 @@ import sys
 
 import torch
 
+
+def _lib_default_mode():
+    from cpc_audio_amd._lib import DEFAULT_MFMA_MODE
+    return DEFAULT_MFMA_MODE
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cpc_audio_amd import _lib           # noqa: E402
 from cpc_audio_amd._lib import ptr as P  # noqa: E402
@@ -89,7 +94,7 @@ def main():
             out[f"conv{i}_fwd_bm{bm}_mode{mode}_ms"] = round(t, 4)
             out[f"conv{i}_fwd_bm{bm}_mode{mode}_TFLOPs"] = round(2 * macs[i] * B / t / 1e9, 1)
     lib.cpc_set_conv_tile(0)
-    lib.cpc_set_mfma_mode(1)
+    lib.cpc_set_mfma_mode(_lib_default_mode())
     print(json.dumps(out, indent=1))
 
 

@@ -14,8 +14,11 @@ lib.check(lib.cpc_conv_weight_relayout(P(w), P(wp), k, st))
 L = 20480
 wave = torch.randn(B, L, device=dev) * 0.1; w0 = torch.randn(256, 10, device=dev) * 0.3
 y0 = torch.empty(B, 4096, 256, device=dev); m0 = torch.empty(B * 4096, device=dev); r0 = torch.empty(B * 4096, device=dev)
+xamax = torch.zeros(1, device=dev)
+lib.check(lib.cpc_conv0_forward(P(wave), P(w0), P(bias), P(nw), P(nb), P(y0), P(m0), P(r0), B, L, st))
+lib.check(lib.cpc_absmax(P(y0), y0.numel(), P(xamax), st))
 for _ in range(5):      # layer 1 runs on the activations conv0 produces, as inside the train step (and as bench.py's probe)
     lib.check(lib.cpc_conv0_forward(P(wave), P(w0), P(bias), P(nw), P(nb), P(y0), P(m0), P(r0), B, L, st))
-    lib.check(lib.cpc_conv_gemm_forward(P(y0), P(wp), P(bias), P(nw), P(nb), P(y), P(xh), P(rs), B, Lin, k, s, p, st))
+    lib.check(lib.cpc_conv_gemm_forward(P(y0), P(wp), P(bias), P(nw), P(nb), P(y), P(xh), P(rs), P(xamax), B, Lin, k, s, p, st))
 torch.cuda.synchronize()
 print("done")
