@@ -552,6 +552,7 @@ struct EncLayout {
 };
 
 static int g_force_bm = 0;   // 0 = choose by problem size; 32/64/128 = tuning / test override
+static constexpr int g_unfuse_big = 1;   // 128-row dgrad runs unfused + streaming norm backward (5.13 vs 5.16 ms/step)
 static int pick_bm(int M) {
     if (g_force_bm) return g_force_bm;
     // measured on MI355X (tools/bench_kernels.py): 128-row tiles win as soon as they give ~256 blocks
@@ -604,7 +605,7 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
             col_max = std::max(col_max, (long)cdiv(Md, pick_bm(Md)) * kGeom[i].s);
         }
     }
-    col_max = std::max(col_max, (long)cdiv(B * e.L[4], NB_ROWS));
+    for (int i = 1; i < 5; ++i) col_max = std::max(col_max, (long)cdiv(B * e.L[i], NB_ROWS));   // stand-alone norm backward
     e.part = o; o += align64(part_max);
     e.colpart = o; o += align64(col_max * 3 * kC);
     e.tmp = o; o += align64((long)kRowsSumGroups * 3 * kC);
@@ -884,7 +885,18 @@ extern "C" int cpc_encoder_backward(const float* wave, const float* const* param
         rc = cpc_conv_layer_wgrad(scratch + e.dx[i], xin, scratch + e.part, grads[4 * i], amax + i, amax + 8 + i, B,
                                   e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], stream);
         if (rc) return rc;
-        if (i >= 2) {
+        if (i >= 2 && g_unfuse_big && pick_bm(B * (e.L[i] + 1)) == 128) {
+            // 128-row tiles: the fused ReLU'/ChannelNorm-backward epilogue is latency-bound there; a plain dgrad into a
+            // temporary (dy0 is free until layer 1's dgrad) followed by the streaming norm backward is faster
+            float* tmpd = scratch + e.dy0;
+            rc = cpc_conv_layer_dgrad(scratch + e.dx[i], params[4 * i], scratch + e.wd[i], 0, nullptr, nullptr, nullptr,
+                                      nullptr, tmpd, nullptr, nullptr, nullptr, amax + i, nullptr, B, e.L[i - 1],
+                                      kGeom[i].k, kGeom[i].s, kGeom[i].p, stream);
+            if (rc) return rc;
+            rc = cpc_norm_backward(tmpd, saved + e.xhat[i - 1], xin, saved + e.rstd[i - 1], params[4 * (i - 1) + 2],
+                                   scratch + e.dx[i - 1], colpart, tmp, small + (i - 1) * 3 * kC, amax + i - 1,
+                                   B * e.L[i - 1], stream);
+        } else if (i >= 2) {
             rc = cpc_conv_layer_dgrad(scratch + e.dx[i], params[4 * i], scratch + e.wd[i], 1,
                                       saved + e.xhat[i - 1], xin, saved + e.rstd[i - 1], params[4 * (i - 1) + 2],
                                       scratch + e.dx[i - 1], colpart, tmp, small + (i - 1) * 3 * kC, amax + i,
