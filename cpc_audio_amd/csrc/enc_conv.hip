@@ -34,8 +34,17 @@ namespace cpc {
 // B tile of one 16-k chunk (256 rows x 64 B) is ONE contiguous 16 KB block instead of 256 half cache lines
 // 8 KB apart (all CUs walk k in lockstep and would hammer the same few L2 channels).
 // split != 0: Wp is written as three bf16 planes [3][total] (the pre-split B operand of NtTileX3).
+// split == 2: fp16 two-piece slots [h0..h3 | l0..l3] of w * scale_for_amax(*amax) in place of each 4-float slot.
+__device__ __forceinline__ void store_h2(float* base, long dst, float v, float scale) {
+    const float x = v * scale;
+    const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+    _Float16* o = reinterpret_cast<_Float16*>(base) + ((dst & ~3L) << 1) + (dst & 3);
+    o[0] = h;
+    o[4] = l;
+}
 __global__ __launch_bounds__(256) void permute_w_fwd_kernel(const float* __restrict__ w,
-                                                            float* __restrict__ wp, int k, int split) {
+                                                            float* __restrict__ wp, int k, int split,
+                                                            const float* __restrict__ amax) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)kC * k * kC;
     if (idx >= total) return;
@@ -44,7 +53,9 @@ __global__ __launch_bounds__(256) void permute_w_fwd_kernel(const float* __restr
     const int kk = rem >> kCLog2, ci = rem & (kC - 1);
     const float v = w[((long)co * kC + ci) * k + kk];
     const long dst = ((long)(rem >> 4) * kC + co) * 16 + (rem & 15);
-    if (split) {
+    if (split == 2) {
+        store_h2(wp, dst, v, scale_for_amax(*amax));
+    } else if (split) {
         unsigned h, m, l;
         split3(v, h, m, l);
         unsigned short* o = reinterpret_cast<unsigned short*>(wp);
@@ -59,7 +70,8 @@ __global__ __launch_bounds__(256) void permute_w_fwd_kernel(const float* __restr
 // (O,I,W) -> Wd[r](ci, kg = j*C + co) = W[co][ci][r + (1-j)*s],  r < s, j in {0,1}; each phase r k-blocked
 // like Wp: [kg/16][ci][kg%16]
 __global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __restrict__ w,
-                                                              float* __restrict__ wd, int s, int split) {
+                                                              float* __restrict__ wd, int s, int split,
+                                                              const float* __restrict__ amax) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)s * kC * 2 * kC;
     if (idx >= total) return;
@@ -71,7 +83,9 @@ __global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __res
     const int j = jc >> kCLog2, co = jc & (kC - 1);
     const float v = w[((long)co * kC + ci) * k + r + (1 - j) * s];
     const long dst = (long)r * kC * 2 * kC + ((long)(jc >> 4) * kC + ci) * 16 + (jc & 15);
-    if (split) {
+    if (split == 2) {
+        store_h2(wd, dst, v, scale_for_amax(*amax));
+    } else if (split) {
         unsigned h, m, l;
         split3(v, h, m, l);
         unsigned short* o = reinterpret_cast<unsigned short*>(wd);
@@ -122,15 +136,15 @@ __global__ __launch_bounds__(256) void norm_bound_kernel(const float* __restrict
 template <int BM, int MODE>
 struct ConvCfg {
     static constexpr bool X3 = MODE != 0;
-    // the fp16 split pays where the tile is MFMA-bound (128 rows); the 32/64-row tiles of the short layers are
-    // bound by staging the 256-column weight tile and keep the bf16 split (measured: 108 vs 76 us on layer 3)
-    static constexpr int NP = (MODE == 2 && BM == 128) ? 2 : 3;
+    static constexpr int NP = MODE == 2 ? 2 : 3;
     static constexpr bool H2 = NP == 2;
     static constexpr int WAVES_M = BM >= 128 ? 2 : 1;
     // 128-row tiles: two LDS stages of 16 k with the skewed (store-first / MFMA-first) wave schedule
     // (pre-split weight planes, BSPLIT = true, measured slower: 162 vs 176 TF on layer 1 -- three 8-byte loads per
     //  slot instead of one 16-byte load cost more than the VALU they save)
-    static constexpr bool kPreSplitW = false;
+    // mode 2: the weight re-layout kernels also split (same 4 bytes per weight, no VALU left for B in the main loop --
+    // what made the 32-row tiles of the short layers slower with on-the-fly fp16 conversion: 108 vs 76 us)
+    static constexpr bool kPreSplitW = MODE == 2;
     using X3Tile = typename std::conditional<BM == 128, NtTileX3<BM, kC, WAVES_M, 4, 16, 2, true, kPreSplitW, NP>,
                                              NtTileX3<BM, kC, WAVES_M, 4, 32, 1, false, kPreSplitW, NP>>::type;
     using Tile = typename std::conditional<X3, X3Tile, NtTile<BM, kC, WAVES_M, 4>>::type;
@@ -665,14 +679,14 @@ extern "C" int cpc_set_conv_tile(int bm) {
 extern "C" int cpc_conv_weight_relayout(const float* w, float* wp, int k, void* stream) {
     CPC_RETURN_IF(!w || !wp || k <= 0, CPC_ERR_ARG);
     const long nw_elems = (long)kC * k * kC;
-    hipLaunchKernelGGL(permute_w_fwd_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, k,
-                       (g_mfma_mode == 1 && ConvCfg<128, 1>::kPreSplitW) ? 1 : 0);
-    // max|w| for the fp16-split mode, kept behind the re-laid-out weight
+    hipStream_t st = (hipStream_t)stream;
+    float* amax = wp + nw_elems;                     // spare floats behind the re-laid-out weight
     if (g_mfma_mode == 2) {
-        float* amax = wp + nw_elems;
-        (void)hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream);
-        hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, nw_elems, amax);
+        (void)hipMemsetAsync(amax, 0, sizeof(float), st);
+        hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, st, w, nw_elems, amax);
     }
+    hipLaunchKernelGGL(permute_w_fwd_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wp, k,
+                       g_mfma_mode == 2 ? 2 : ((g_mfma_mode == 1 && ConvCfg<128, 1>::kPreSplitW) ? 1 : 0), amax);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -753,12 +767,14 @@ extern "C" int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, 
     hipStream_t st = (hipStream_t)stream;
     const int Lout = conv_out_len(Lin, k, s, p);
     const long nw_elems = (long)kC * k * kC;
-    hipLaunchKernelGGL(permute_w_dgrad_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wd, s,
-                       (g_mfma_mode == 1 && ConvCfg<128, 1>::kPreSplitW) ? 1 : 0);
     float* w_amax = wd + nw_elems;                    // spare floats behind the re-laid-out weight
     if (g_mfma_mode == 2) {
         (void)hipMemsetAsync(w_amax, 0, 2 * sizeof(float), st);
         hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, st, w, nw_elems, w_amax);
+    }
+    hipLaunchKernelGGL(permute_w_dgrad_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wd, s,
+                       g_mfma_mode == 2 ? 2 : ((g_mfma_mode == 1 && ConvCfg<128, 1>::kPreSplitW) ? 1 : 0), w_amax);
+    if (g_mfma_mode == 2) {
         if (!dx_amax) {
             hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, dx, (long)B * Lout * kC, w_amax + 1);
             dx_amax = w_amax + 1;

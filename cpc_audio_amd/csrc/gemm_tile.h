@@ -342,6 +342,12 @@ __device__ __forceinline__ void load_b(BSplitReg& dst, const float*, const unsig
     dst.m = *reinterpret_cast<const uint2*>(p16 + plane + k0);
     dst.l = *reinterpret_cast<const uint2*>(p16 + 2 * plane + k0);
 }
+// pre-split fp16 operand: the 16 bytes of a 4-k slot hold [h0 h1 h2 h3 | l0 l1 l2 l3] (same bytes and the same
+// addresses as the fp32 slot, so it is fetched by the same single 16-byte load)
+struct BSplitH2 { uint4 v; };
+__device__ __forceinline__ void load_b(BSplitH2& dst, const float* p32, const unsigned short*, long k0, long) {
+    dst.v = *reinterpret_cast<const uint4*>(p32 + k0);
+}
 __device__ __forceinline__ void planes_of(const float4& v, uint2& ph, uint2& pm, uint2& pl) { split3_pack4(v, ph, pm, pl); }
 __device__ __forceinline__ void planes_of(const BSplitReg& v, uint2& ph, uint2& pm, uint2& pl) { ph = v.h; pm = v.m; pl = v.l; }
 
@@ -389,7 +395,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1
           int NP = 3>
 struct NtTileX3 {
     using SP = SplitPlanes<NP>;
-    static_assert(!BSPLIT || NP == 3, "pre-split B planes exist for the bf16 split only");
+    // BSPLIT: the B operand is stored pre-split (NP == 3: three bf16 planes; NP == 2: interleaved fp16 slots, BSplitH2)
     static constexpr int BK = BK_;       // 32 with one LDS stage (default), or 16 double-buffered
     static constexpr int LDH = BK + 8;   // halves per LDS row (80 B / 48 B: 16-byte aligned, conflict-free b128)
     static constexpr int SPR = BK / 4;   // float4 slots per row
@@ -452,7 +458,7 @@ struct NtTileX3 {
             bp16[i] = reinterpret_cast<const unsigned short*>(Bmat) + bo;
             b_lds[i] = NP * PLANE_A + r * LDH + kv * 4;
         }
-        using BReg = typename std::conditional<BSPLIT, BSplitReg, float4>::type;
+        using BReg = typename std::conditional<BSPLIT, typename std::conditional<NP == 3, BSplitReg, BSplitH2>::type, float4>::type;
         float4 ra[A_PER], ra1[A_PER];
         BReg rb[B_PER], rb1[B_PER];                // second register set for the deep-prefetch schedule
         const int nk = K / BK;
@@ -480,7 +486,8 @@ struct NtTileX3 {
             for (int i = 0; i < B_PER; ++i)
                 if (B_EXACT || b_on[i]) {
                     uint2 pp[NP];
-                    if constexpr (BSPLIT) planes_of(rb[i], pp[0], pp[1], pp[2]);
+                    if constexpr (BSPLIT && NP == 3) planes_of(rb[i], pp[0], pp[1], pp[2]);
+                    else if constexpr (BSPLIT) { pp[0] = make_uint2(rb[i].v.x, rb[i].v.y); pp[1] = make_uint2(rb[i].v.z, rb[i].v.w); }
                     else SP::split(rb[i], sb, pp);
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(smem + pl * PLANE_B + b_lds[i]) = pp[pl];
