@@ -80,3 +80,33 @@ def test_chunked_feature_extraction_matches_oracle():
     fz = H.FeatureModule(model, get_encoded=True).eval()
     zf = H.build_feature(fz, seq, strict=True, max_size_seq=64000)
     assert zf.shape == (1, 400 + 400 + 77, 256)
+
+
+def test_device_resident_dataset_feeds_the_train_loop(tmp_path):
+    """AudioBatchData.to(cuda): the packed waveform lives in HBM and batches are gathered there (dataset.py);
+    two epochs over a small synthetic corpus through the harness's train loop."""
+    dev = _dev()
+    import wave
+    from cpc_audio_amd import harness as H
+    from cpc_audio_amd.dataset import AudioBatchData, findAllSeqs
+    from cpc_audio_amd.train import build_criterion, build_model
+    rng = np.random.default_rng(0)
+    for spk in range(3):
+        for utt in range(2):
+            d = tmp_path / "db" / f"s{spk}" / "c0"
+            d.mkdir(parents=True, exist_ok=True)
+            pcm = (rng.standard_normal(20480 * 3 + 100 * utt) * 3000).astype("<i2")
+            with wave.open(str(d / f"s{spk}-c0-{utt}.wav"), "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000); f.writeframes(pcm.tobytes())
+    seqs, speakers = findAllSeqs(str(tmp_path / "db"), extension=".wav")
+    data = AudioBatchData(tmp_path / "db", 20480, seqs, None, len(speakers)).to(dev)
+    assert data.data.is_cuda
+    loader = data.getDataLoader(4, "uniform", True)
+    batch, labels = next(iter(loader))
+    assert batch.is_cuda and batch.shape == (4, 1, 20480) and labels.is_cuda
+    torch.manual_seed(0)
+    model, crit = build_model().to(dev), build_criterion().to(dev)
+    opt = torch.optim.Adam(list(crit.parameters()) + list(model.parameters()), lr=2e-4)
+    logs = [H.train_epoch(data.getDataLoader(4, "samespeaker", True), model, crit, opt) for _ in range(2)]
+    for lg in logs:
+        assert np.isfinite(np.array(lg["locLoss_train"])).all() and len(lg["locLoss_train"]) == 12
