@@ -424,20 +424,25 @@ static int nce_scores_forward(const NceLayout& n, const float* pred, const float
     return 0;
 }
 
-// dPred and dz from the upstream per-head gradients
+// dPred and dz from the upstream per-head gradients.  The dz path (candidate gradient rows + destination-sorted
+// gather, ~half of the criterion's backward, HBM-bound) does not depend on dPred: it may be given its own stream
+// `st_dz` so that it runs next to whatever consumes dPred / dc (the auto-regressive network's backward, which is
+// latency-bound and leaves most of the chip idle).  Ordering across the two streams is the caller's business.
 static int nce_scores_backward(const NceLayout& n, const float* pred, const float* z, const int* ext, const int* perm,
                                const int* row_ptr, const float* saved, const float* gloss, float* scratch,
-                               float* dpred, float* dz, int B, int S, int K, int N, hipStream_t st) {
+                               float* dpred, float* dz, int B, int S, int K, int N, hipStream_t st, hipStream_t st_dz) {
     const float* logits = saved + n.logits, *lse = saved + n.lse;
     float* gscale = scratch + n.gscale;
-    hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale, K,
-                       1.0f / ((float)n.BW * (float)kC));
+    float* gscale_dz = st_dz == st ? gscale : gscale + 32;        // own copy: no cross-stream dependency
+    const float gs = 1.0f / ((float)n.BW * (float)kC);
+    hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale, K, gs);
     const dim3 grid(cdiv(n.BW, 4));
     hipLaunchKernelGGL(nce_bwd_dpred_kernel, grid, dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
                        n.W, S, K, N);
-    hipLaunchKernelGGL(nce_bwd_dz_rows_kernel, grid, dim3(256), 0, st, pred, logits, lse, gscale, scratch + n.V,
+    if (st_dz != st) hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st_dz, gloss, gscale_dz, K, gs);
+    hipLaunchKernelGGL(nce_bwd_dz_rows_kernel, grid, dim3(256), 0, st_dz, pred, logits, lse, gscale_dz, scratch + n.V,
                        n.BW, K, N);
-    hipLaunchKernelGGL(nce_gather_rows_kernel, dim3(B * S), dim3(64), 0, st, scratch + n.V, perm, row_ptr, dz, B * S);
+    hipLaunchKernelGGL(nce_gather_rows_kernel, dim3(B * S), dim3(64), 0, st_dz, scratch + n.V, perm, row_ptr, dz, B * S);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -510,7 +515,7 @@ extern "C" int cpc_nce_scores_backward(const float* pred, const float* z, const 
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!pred || !z || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dpred || !dz, CPC_ERR_ARG);
     return nce_scores_backward(n, pred, z, ext, perm, row_ptr, saved, gloss, scratch, dpred, dz, B, S, K, N,
-                               (hipStream_t)stream);
+                               (hipStream_t)stream, (hipStream_t)stream);
 }
 
 // gloss: K upstream gradients dL/dloss_k (device).  Outputs (overwritten): dc, dz (B,S,256), dwall (K*256,256).
@@ -521,13 +526,25 @@ extern "C" int cpc_nce_backward(const float* c, const float* z, const float* wal
                                 const int* perm, const int* row_ptr, const float* saved, const float* gloss,
                                 float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K, int N,
                                 void* stream) {
+    return cpc_nce_backward_streams(c, z, wall, ext, perm, row_ptr, saved, gloss, scratch, dc, dz, dwall, B, S, K, N,
+                                    stream, stream);
+}
+
+// As cpc_nce_backward, with the dz path (which needs only saved / gloss / perm / row_ptr and writes only dz and its own
+// part of scratch) launched on `dz_stream`.  No cross-stream synchronisation is done here: the caller makes
+// dz_stream wait until gloss is ready, and makes every consumer of dz wait for dz_stream.
+extern "C" int cpc_nce_backward_streams(const float* c, const float* z, const float* wall, const int* ext,
+                                        const int* perm, const int* row_ptr, const float* saved, const float* gloss,
+                                        float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K,
+                                        int N, void* stream, void* dz_stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc || !dz || !dwall, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     float* dpred = scratch + n.dpred, *wallT = scratch + n.wallT;
     (void)hipMemsetAsync(dc, 0, sizeof(float) * (size_t)B * S * kC, st);
-    int rc = nce_scores_backward(n, saved + n.pred, z, ext, perm, row_ptr, saved, gloss, scratch, dpred, dz, B, S, K, N, st);
+    int rc = nce_scores_backward(n, saved + n.pred, z, ext, perm, row_ptr, saved, gloss, scratch, dpred, dz, B, S, K, N, st,
+                                 (hipStream_t)dz_stream);
     if (rc) return rc;
     // dc[:, :W] = dPred . Wall  (NT against Wall^T [256][K*256])
     rc = transpose(wall, wallT, K * kC, kC, st);

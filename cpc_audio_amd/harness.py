@@ -31,6 +31,8 @@ from copy import deepcopy
 import numpy as np
 import torch
 
+from . import ops
+
 from .dist import FlatGradAllReduce
 
 
@@ -110,7 +112,10 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
         n_ex += batch.size(0)
         c_feature, encoded, label = model(batch, label)
         all_losses, all_acc = criterion(c_feature, encoded, label)
+        ops.OVERLAP_DZ = True                             # no foreign consumer of dz in this graph (ops.py)
         all_losses.sum().backward()                       # train.py:85-87
+        ops.wait_side_stream()
+        ops.OVERLAP_DZ = False
         if allreduce is not None:
             allreduce()
         optimizer.step()

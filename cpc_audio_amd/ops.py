@@ -34,6 +34,30 @@ def _ptrs(ts):
 
 _layout_cache = {}
 
+# ---- side stream for the criterion's dz path (InfoNCEFunction.backward) -------------------------------------------
+# The candidate-row + sorted-gather half of the criterion's backward depends only on the upstream loss gradients, and
+# the network that consumes dc (the persistent GRU backward: 128 workgroups, latency-bound) leaves most of the chip
+# idle.  With OVERLAP_DZ the dz path is launched on a side stream; every Function of this package that can be the
+# next consumer of dz waits for it (wait_side_stream) before returning / starting.  It is switched on by the package's
+# own train loops (train.Trainer, harness.train_epoch), whose autograd graph has no foreign op between the criterion
+# and the encoder; code that reads dz on the current stream through other ops must leave it off (the default).
+OVERLAP_DZ = False
+_side_streams = {}
+_side_events = []
+
+
+def _side_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def wait_side_stream():
+    """Make the current stream wait for everything this package has launched on its side stream."""
+    while _side_events:
+        torch.cuda.current_stream().wait_event(_side_events.pop())
+
 # Parity tests set KEEP_DEBUG = True to look at the encoder's saved activations (the ReLU
 # masks of the device path, see oracle/cpc_oracle._ReluTieAware).  Never used by the product.
 KEEP_DEBUG = False
@@ -79,6 +103,7 @@ class EncoderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         lib = _lib.get()
+        wait_side_stream()                     # dz may carry the criterion's side-stream part
         wave, saved, z, *params = ctx.saved_tensors
         B, L, nscr = ctx.dims
         dz = dz.contiguous()
@@ -130,6 +155,7 @@ class GruFunction(torch.autograd.Function):
             grads = [torch.empty_like(p) for p in params]
             lib.check(lib.cpc_gru_backward(_p(x), _p(ctx.h0), _ptrs(params), _p(saved), _p(y), _p(dy),
                                            _p(scratch), _p(dx), _ptrs(grads), B, S, nl, _stream()), "gru_backward")
+        wait_side_stream()      # autograd adds dx to the criterion's dz next: that part must have landed
         return (dx, None, *grads)
 
 
@@ -202,9 +228,21 @@ class InfoNCEFunction(torch.autograd.Function):
         with torch.cuda.device(c.device):
             scratch = torch.empty(nscr, device=c.device, dtype=torch.float32)
             dc, dz, dwall = torch.empty_like(c), torch.empty_like(z), torch.empty_like(wall)
-            lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
-                                           _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
-                                           _stream()), "nce_backward")
+            if OVERLAP_DZ:
+                main, side = torch.cuda.current_stream(), _side_stream(c.device)
+                side.wait_stream(main)                            # gloss, and the allocations above, are ready
+                lib.check(lib.cpc_nce_backward_streams(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
+                                                       _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
+                                                       main.cuda_stream, side.cuda_stream), "nce_backward")
+                for t in (dz, scratch, saved, gloss, perm, row_ptr):
+                    t.record_stream(side)                         # the allocator must not recycle them early
+                ev = torch.cuda.Event()
+                ev.record(side)
+                _side_events.append(ev)
+            else:
+                lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
+                                               _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
+                                               _stream()), "nce_backward")
         return dc, dz, dwall, None, None, None
 
 
@@ -294,4 +332,5 @@ class TransformerLayerFunction(torch.autograd.Function):
             grads = [None if p is None else torch.empty_like(p) for p in params]
             lib.check(lib.cpc_transformer_layer_backward(_p(x), _ptrs(params), _p(saved), _p(dy), _p(scratch), _p(dx),
                                                          _ptrs(grads), B, S, _stream()), "transformer_layer_backward")
+        wait_side_stream()
         return (dx, *grads)

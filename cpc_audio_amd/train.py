@@ -45,10 +45,14 @@ class Trainer:
         self.allreduce = FlatGradAllReduce(params)
 
     def step(self, batchData, label, negatives=None):
+        from . import ops
+        ops.OVERLAP_DZ = True        # this loop's graph has no foreign consumer of dz between criterion and encoder
         c_feature, encoded_data, label = self.model(batchData, label)
         allLosses, allAcc = self.criterion(c_feature, encoded_data, label, negatives=negatives)
         totLoss = allLosses.sum()
         totLoss.backward()
+        ops.wait_side_stream()
+        ops.OVERLAP_DZ = False
         self.allreduce()
         self.optimizer.step()
         self.optimizer.zero_grad()

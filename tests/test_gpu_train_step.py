@@ -92,3 +92,28 @@ def test_train_step_is_bit_reproducible():
     assert torch.equal(a["dz"], b["dz"]) and torch.equal(a["dc"], b["dc"])
     for k in a["grads"]:
         assert torch.equal(a["grads"][k], b["grads"][k]), k
+
+
+def test_side_stream_dz_path_gives_identical_results():
+    """ops.OVERLAP_DZ launches the criterion's dz half of the backward on a side stream next to the GRU backward;
+    same kernels, same order of arithmetic: every gradient must be bit-identical to the single-stream run."""
+    dev = _dev()
+    from cpc_audio_amd import ops
+    B = 6
+    p = O.make_params(seed=12, head_scale=64.0)
+    wave = O.make_waveform(B, 20480, seed=22)
+    g = torch.Generator().manual_seed(6)
+    bidx, sidx = O.draw_negative_indices(B, 128, 116, 128, generator=g)
+    a = _hip_step(p, wave, bidx, sidx, dev)
+    outs = []
+    for _ in range(3):
+        ops.OVERLAP_DZ = True
+        try:
+            outs.append(_hip_step(p, wave, bidx, sidx, dev))
+            ops.wait_side_stream()
+        finally:
+            ops.OVERLAP_DZ = False
+    for b in outs:
+        assert torch.equal(a["dz"], b["dz"]) and torch.equal(a["dc"], b["dc"])
+        for k in a["grads"]:
+            assert torch.equal(a["grads"][k], b["grads"][k]), k
