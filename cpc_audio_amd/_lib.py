@@ -52,6 +52,7 @@ SIGNATURES = {
     "cpc_nce_forward": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward": (_I, [_P] * 12 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward_streams": (_I, [_P] * 12 + [_I, _I, _I, _I, _P, _P]),
+    "cpc_nce_backward_dz": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
 }
 
 

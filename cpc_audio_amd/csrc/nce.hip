@@ -424,13 +424,28 @@ static int nce_scores_forward(const NceLayout& n, const float* pred, const float
     return 0;
 }
 
+// dz = scatter of the per-candidate gradient rows, as candidate rows V + destination-sorted gather
+static int nce_dz_path(const NceLayout& n, const float* pred, const float* saved, const float* gloss, const int* perm,
+                       const int* row_ptr, float* scratch, float* gscale_dz, float* dz, int B, int S, int K, int N,
+                       hipStream_t st, bool own_gscale) {
+    const float* logits = saved + n.logits, *lse = saved + n.lse;
+    if (own_gscale)
+        hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale_dz, K, 1.0f / ((float)n.BW * (float)kC));
+    hipLaunchKernelGGL(nce_bwd_dz_rows_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, logits, lse, gscale_dz,
+                       scratch + n.V, n.BW, K, N);
+    hipLaunchKernelGGL(nce_gather_rows_kernel, dim3(B * S), dim3(64), 0, st, scratch + n.V, perm, row_ptr, dz, B * S);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
 // dPred and dz from the upstream per-head gradients.  The dz path (candidate gradient rows + destination-sorted
 // gather, ~half of the criterion's backward, HBM-bound) does not depend on dPred: it may be given its own stream
 // `st_dz` so that it runs next to whatever consumes dPred / dc (the auto-regressive network's backward, which is
 // latency-bound and leaves most of the chip idle).  Ordering across the two streams is the caller's business.
 static int nce_scores_backward(const NceLayout& n, const float* pred, const float* z, const int* ext, const int* perm,
                                const int* row_ptr, const float* saved, const float* gloss, float* scratch,
-                               float* dpred, float* dz, int B, int S, int K, int N, hipStream_t st, hipStream_t st_dz) {
+                               float* dpred, float* dz, int B, int S, int K, int N, hipStream_t st, hipStream_t st_dz,
+                               bool do_dz = true) {
     const float* logits = saved + n.logits, *lse = saved + n.lse;
     float* gscale = scratch + n.gscale;
     float* gscale_dz = st_dz == st ? gscale : gscale + 32;        // own copy: no cross-stream dependency
@@ -439,12 +454,9 @@ static int nce_scores_backward(const NceLayout& n, const float* pred, const floa
     const dim3 grid(cdiv(n.BW, 4));
     hipLaunchKernelGGL(nce_bwd_dpred_kernel, grid, dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
                        n.W, S, K, N);
-    if (st_dz != st) hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st_dz, gloss, gscale_dz, K, gs);
-    hipLaunchKernelGGL(nce_bwd_dz_rows_kernel, grid, dim3(256), 0, st_dz, pred, logits, lse, gscale_dz, scratch + n.V,
-                       n.BW, K, N);
-    hipLaunchKernelGGL(nce_gather_rows_kernel, dim3(B * S), dim3(64), 0, st_dz, scratch + n.V, perm, row_ptr, dz, B * S);
     CPC_LAUNCH_CHECK();
-    return 0;
+    if (!do_dz) return 0;                                          // dz path launched separately (cpc_nce_backward_dz)
+    return nce_dz_path(n, pred, saved, gloss, perm, row_ptr, scratch, gscale_dz, dz, B, S, K, N, st_dz, st_dz != st);
 }
 
 }  // namespace cpc
@@ -530,21 +542,33 @@ extern "C" int cpc_nce_backward(const float* c, const float* z, const float* wal
                                     stream, stream);
 }
 
+// The dz path alone (linear-head criterion; pred is taken from `saved`), for callers that launch it separately.
+extern "C" int cpc_nce_backward_dz(const float* z, const int* ext, const int* perm, const int* row_ptr,
+                                   const float* saved, const float* gloss, float* scratch, float* dz, int B, int S,
+                                   int K, int N, void* stream) {
+    NceLayout n;
+    CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!z || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dz, CPC_ERR_ARG);
+    return nce_dz_path(n, saved + n.pred, saved, gloss, perm, row_ptr, scratch, scratch + n.gscale + 32, dz, B, S, K, N,
+                       (hipStream_t)stream, true);
+}
+
 // As cpc_nce_backward, with the dz path (which needs only saved / gloss / perm / row_ptr and writes only dz and its own
-// part of scratch) launched on `dz_stream`.  No cross-stream synchronisation is done here: the caller makes
-// dz_stream wait until gloss is ready, and makes every consumer of dz wait for dz_stream.
+// part of scratch) launched on `dz_stream`; dz == NULL leaves the dz path out altogether (cpc_nce_backward_dz runs it
+// later).  No cross-stream synchronisation is done here: the caller makes dz_stream wait until gloss is ready, and
+// makes every consumer of dz wait for dz_stream.
 extern "C" int cpc_nce_backward_streams(const float* c, const float* z, const float* wall, const int* ext,
                                         const int* perm, const int* row_ptr, const float* saved, const float* gloss,
                                         float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K,
                                         int N, void* stream, void* dz_stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
-    CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc || !dz || !dwall, CPC_ERR_ARG);
+    CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc || !dwall, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     float* dpred = scratch + n.dpred, *wallT = scratch + n.wallT;
     (void)hipMemsetAsync(dc, 0, sizeof(float) * (size_t)B * S * kC, st);
     int rc = nce_scores_backward(n, saved + n.pred, z, ext, perm, row_ptr, saved, gloss, scratch, dpred, dz, B, S, K, N, st,
-                                 (hipStream_t)dz_stream);
+                                 (hipStream_t)dz_stream, dz != nullptr);
     if (rc) return rc;
     // dc[:, :W] = dPred . Wall  (NT against Wall^T [256][K*256])
     rc = transpose(wall, wallT, K * kC, kC, st);

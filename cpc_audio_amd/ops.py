@@ -44,6 +44,8 @@ _layout_cache = {}
 OVERLAP_DZ = False
 _side_streams = {}
 _side_events = []
+_deferred = []          # side-stream launches held back until the AR backward is in flight (it needs whole CUs: its
+                        # 768-thread workgroups cannot squeeze in beside a chip full of gather blocks)
 
 
 def _side_stream(device):
@@ -53,8 +55,14 @@ def _side_stream(device):
     return st
 
 
+def launch_deferred():
+    while _deferred:
+        _deferred.pop(0)()
+
+
 def wait_side_stream():
-    """Make the current stream wait for everything this package has launched on its side stream."""
+    """Make the current stream wait for everything this package has launched (or still holds) for its side stream."""
+    launch_deferred()
     while _side_events:
         torch.cuda.current_stream().wait_event(_side_events.pop())
 
@@ -155,7 +163,8 @@ class GruFunction(torch.autograd.Function):
             grads = [torch.empty_like(p) for p in params]
             lib.check(lib.cpc_gru_backward(_p(x), _p(ctx.h0), _ptrs(params), _p(saved), _p(y), _p(dy),
                                            _p(scratch), _p(dx), _ptrs(grads), B, S, nl, _stream()), "gru_backward")
-        wait_side_stream()      # autograd adds dx to the criterion's dz next: that part must have landed
+        wait_side_stream()      # starts the criterion's deferred dz path beside the recurrence just launched, and makes
+        #                         this stream wait for it: autograd adds dx to that dz next
         return (dx, None, *grads)
 
 
@@ -230,15 +239,23 @@ class InfoNCEFunction(torch.autograd.Function):
             dc, dz, dwall = torch.empty_like(c), torch.empty_like(z), torch.empty_like(wall)
             if OVERLAP_DZ:
                 main, side = torch.cuda.current_stream(), _side_stream(c.device)
-                side.wait_stream(main)                            # gloss, and the allocations above, are ready
+                ready = torch.cuda.Event()
+                # dc / dwall now, on this stream (dz = NULL leaves the dz path out) ...
                 lib.check(lib.cpc_nce_backward_streams(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
-                                                       _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
-                                                       main.cuda_stream, side.cuda_stream), "nce_backward")
-                for t in (dz, scratch, saved, gloss, perm, row_ptr):
-                    t.record_stream(side)                         # the allocator must not recycle them early
-                ev = torch.cuda.Event()
-                ev.record(side)
-                _side_events.append(ev)
+                                                       _p(gloss), _p(scratch), _p(dc), None, _p(dwall), B, S, K, N,
+                                                       main.cuda_stream, main.cuda_stream), "nce_backward")
+                ready.record(main)
+
+                def dz_path():            # ... dz later, on the side stream, once the AR backward has been launched
+                    side.wait_event(ready)
+                    lib.check(lib.cpc_nce_backward_dz(_p(z), _p(ext), _p(perm), _p(row_ptr), _p(saved), _p(gloss),
+                                                      _p(scratch), _p(dz), B, S, K, N, side.cuda_stream), "nce_backward_dz")
+                    for t in (dz, scratch, saved, gloss, perm, row_ptr, z, ext):
+                        t.record_stream(side)                     # the allocator must not recycle them early
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    _side_events.append(ev)
+                _deferred.append(dz_path)
             else:
                 lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
                                                _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,

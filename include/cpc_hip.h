@@ -180,12 +180,17 @@ int cpc_nce_backward(const float* c, const float* z, const float* wall, const in
                      void* stream);
 
 /* As cpc_nce_backward with the dz path (candidate rows + sorted gather; independent of dpred / dc / dwall) launched on
- * dz_stream, so that it can run beside the auto-regressive network's backward.  No cross-stream synchronisation inside:
- * dz_stream must already wait for gloss, and every consumer of dz must wait for dz_stream. */
+ * dz_stream, so that it can run beside the auto-regressive network's backward; dz == NULL leaves the dz path out
+ * (run it later with cpc_nce_backward_dz, same scratch).  No cross-stream synchronisation inside: dz_stream must
+ * already wait for gloss, and every consumer of dz must wait for dz_stream. */
 int cpc_nce_backward_streams(const float* c, const float* z, const float* wall, const int* ext,
                              const int* perm, const int* row_ptr, const float* saved, const float* gloss,
                              float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K, int N,
                              void* stream, void* dz_stream);
+
+int cpc_nce_backward_dz(const float* z, const int* ext, const int* perm, const int* row_ptr,
+                        const float* saved, const float* gloss, float* scratch, float* dz, int B, int S, int K,
+                        int N, void* stream);
 
 /* The same criterion for predictions formed by the caller -- any prediction network of
  * cpc/criterion/criterion.py:44-118, e.g. K transformer layers (--rnnMode transformer, :82-88):
