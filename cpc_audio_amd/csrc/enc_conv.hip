@@ -566,7 +566,8 @@ struct EncLayout {
 };
 
 static int g_force_bm = 0;   // 0 = choose by problem size; 32/64/128 = tuning / test override
-static constexpr int g_unfuse_big = 1;   // 128-row dgrad runs unfused + streaming norm backward (5.13 vs 5.16 ms/step)
+static constexpr int g_unfuse_big = 2;   // 2: every dgrad runs unfused + streaming norm backward, 1: only the 128-row tiles,
+                                         // 0: fused epilogue (cpc_conv_layer_dgrad fuse=1).  Measured 4.69 / 4.76 / 4.79 ms per step
 static int pick_bm(int M) {
     if (g_force_bm) return g_force_bm;
     // measured on MI355X (tools/bench_kernels.py): 128-row tiles win as soon as they give ~256 blocks
@@ -901,9 +902,9 @@ extern "C" int cpc_encoder_backward(const float* wave, const float* const* param
         rc = cpc_conv_layer_wgrad(scratch + e.dx[i], xin, scratch + e.part, grads[4 * i], amax + i, amax + 8 + i, B,
                                   e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], stream);
         if (rc) return rc;
-        if (i >= 2 && g_unfuse_big && pick_bm(B * (e.L[i] + 1)) == 128) {
-            // 128-row tiles: the fused ReLU'/ChannelNorm-backward epilogue is latency-bound there; a plain dgrad into a
-            // temporary (dy0 is free until layer 1's dgrad) followed by the streaming norm backward is faster
+        if (i >= 2 && g_unfuse_big && (g_unfuse_big == 2 || pick_bm(B * (e.L[i] + 1)) == 128)) {
+            // the fused ReLU'/ChannelNorm-backward epilogue is latency-bound (row-by-row reductions between the loads); a
+            // plain dgrad into a temporary (dy0 is free until layer 1's dgrad) + the streaming norm backward is faster
             float* tmpd = scratch + e.dy0;
             rc = cpc_conv_layer_dgrad(scratch + e.dx[i], params[4 * i], scratch + e.wd[i], 0, nullptr, nullptr, nullptr,
                                       nullptr, tmpd, nullptr, nullptr, nullptr, amax + i, nullptr, B, e.L[i - 1],
