@@ -79,3 +79,42 @@ def test_encoder_forward_backward_emulated(B, L, bm, mode):
     finally:
         lib.cpc_set_conv_tile(0)
         lib.cpc_set_mfma_mode(_lib_default_mode())
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_and_unfused_dgrad_agree_emulated(mode):
+    """cpc_conv_layer_dgrad(fuse=1) (ReLU'/ChannelNorm backward in the GEMM epilogue) against the path the encoder
+    uses (plain dgrad + cpc_norm_backward): same dprev and the same three small gradients."""
+    lib = emu()
+    assert lib.cpc_set_mfma_mode(mode) == 0
+    try:
+        torch.manual_seed(3)
+        B, Lin, k, s, p = 2, 40, 4, 2, 1
+        Lout = (Lin + 2 * p - k) // s + 1
+        dx = torch.randn(B, Lout, 256) * 0.01
+        w = torch.randn(256, 256, k) / 32.0
+        xhat = torch.randn(B, Lin, 256)
+        nw = 1.0 + 0.1 * torch.randn(256)
+        y = (xhat * nw + 0.1 * torch.randn(256)).relu()
+        rstd = torch.rand(B * Lin) + 0.5
+        wd = torch.zeros(256 * k * 256 * 3 // 2)
+        nblk = (B * (Lout + 1) + 31) // 32 * s + (B * Lin + 31) // 32 + 8
+        colpart = torch.zeros(nblk * 768); tmp = torch.zeros(128 * 768)
+        outs = []
+        for fuse in (1, 0):
+            dprev = torch.full((B, Lin, 256), float("nan")); small = torch.full((768,), float("nan"))
+            amax = torch.zeros(2)
+            if fuse:
+                assert lib.cpc_conv_layer_dgrad(P(dx), P(w), P(wd), 1, P(xhat), P(y), P(rstd), P(nw), P(dprev), P(colpart),
+                                                P(tmp), P(small), None, amax.data_ptr(), B, Lin, k, s, p, None) == 0
+            else:
+                raw = torch.full((B, Lin, 256), float("nan"))
+                assert lib.cpc_conv_layer_dgrad(P(dx), P(w), P(wd), 0, None, None, None, None, P(raw), None, None, None,
+                                                None, None, B, Lin, k, s, p, None) == 0
+                assert lib.cpc_norm_backward(P(raw), P(xhat), P(y), P(rstd), P(nw), P(dprev), P(colpart), P(tmp), P(small),
+                                             amax.data_ptr(), B * Lin, None) == 0
+            outs.append((dprev, small, amax[0].item()))
+        assert rel_err(outs[0][0], outs[1][0]) < 1e-6 and rel_err(outs[0][1], outs[1][1]) < 1e-5
+        assert abs(outs[0][2] - outs[1][2]) <= 1e-6 * outs[1][2] and outs[1][2] == outs[1][0].abs().max().item()
+    finally:
+        lib.cpc_set_mfma_mode(_lib_default_mode())
