@@ -131,10 +131,23 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             cFeature = torch.flip(cFeature, [1])
         batchSize, seqSize, _ = cFeature.size()
         windowSize = seqSize - self.nPredicts
-        if negatives is None:
-            negatives = self.drawNegatives(batchSize, seqSize, windowSize, cFeature.device)
-        ext, perm, row_ptr = prepare_negatives(negatives[0], negatives[1], batchSize, seqSize, self.nPredicts,
-                                               self.negativeSamplingExt)
+        from . import ops
+        if negatives is None and ops.OVERLAP_DZ and cFeature.is_cuda:
+            # the draws and their index preparation depend on nothing the GPU is still computing (encoder, AR): issued
+            # on the side stream they run beside the latency-bound recurrence instead of after it
+            main, side = torch.cuda.current_stream(), ops._side_stream(cFeature.device)
+            with torch.cuda.stream(side):
+                negatives = self.drawNegatives(batchSize, seqSize, windowSize, cFeature.device)
+                ext, perm, row_ptr = prepare_negatives(negatives[0], negatives[1], batchSize, seqSize, self.nPredicts,
+                                                       self.negativeSamplingExt)
+            main.wait_stream(side)
+            for t in (ext, perm, row_ptr):
+                t.record_stream(main)
+        else:
+            if negatives is None:
+                negatives = self.drawNegatives(batchSize, seqSize, windowSize, cFeature.device)
+            ext, perm, row_ptr = prepare_negatives(negatives[0], negatives[1], batchSize, seqSize, self.nPredicts,
+                                                   self.negativeSamplingExt)
         if self.wPrediction.rnnMode == "transformer":
             pred = self.wPrediction.predictions(cFeature[:, :windowSize].contiguous())
             losses, acc = InfoNCEScoresFunction.apply(pred, encodedData, ext, perm, row_ptr)

@@ -110,9 +110,9 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
     for step, (batch, label) in enumerate(loader):
         batch, label = _to_device(batch, device), _to_device(label, device)
         n_ex += batch.size(0)
+        ops.OVERLAP_DZ = True                             # no foreign consumer of dz in this graph (ops.py)
         c_feature, encoded, label = model(batch, label)
         all_losses, all_acc = criterion(c_feature, encoded, label)
-        ops.OVERLAP_DZ = True                             # no foreign consumer of dz in this graph (ops.py)
         all_losses.sum().backward()                       # train.py:85-87
         ops.wait_side_stream()
         ops.OVERLAP_DZ = False
