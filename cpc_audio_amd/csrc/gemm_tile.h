@@ -303,8 +303,8 @@ __device__ __forceinline__ float scale_for_amax(float amax) {
     int e;
     (void)frexpf(amax, &e);                            // amax = m * 2^e, m in [0.5, 1)
     e = 14 - e;
-    e = e > 100 ? 100 : (e < -100 ? -100 : e);
-    return ldexpf(1.0f, e);
+    e = e > 60 ? 60 : (e < -60 ? -60 : e);             // |log2 s| <= 60: 1/(sa*sb) stays far inside fp32's range; an
+    return ldexpf(1.0f, e);                            // operand with amax < 2^-46 is scaled as far as that allows
 }
 
 template <int NP> struct SplitPlanes;

@@ -118,3 +118,30 @@ def test_fused_and_unfused_dgrad_agree_emulated(mode):
         assert abs(outs[0][2] - outs[1][2]) <= 1e-6 * outs[1][2] and outs[1][2] == outs[1][0].abs().max().item()
     finally:
         lib.cpc_set_mfma_mode(_lib_default_mode())
+
+
+@pytest.mark.parametrize("xs,ws", [(1e-12, 1e-9), (3e7, 2e4), (1.0, 1e-30)])
+def test_fp16_split_scaling_extremes_emulated(xs, ws):
+    """Mode 2 maps every operand into fp16's range with a power-of-two scale taken from its exact max|.|: operands of
+    any magnitude must give the same normalised output as the exact-f32 MFMA path."""
+    lib = emu()
+    torch.manual_seed(5)
+    B, Lin, k, s, p = 1, 64, 4, 2, 1
+    Lout = (Lin + 2 * p - k) // s + 1
+    x = (torch.randn(B, Lin, 256).relu() * xs).contiguous()
+    w = (torch.randn(256, 256, k) * ws).contiguous()
+    bias = torch.zeros(256); nw = torch.ones(256); nb = torch.zeros(256)
+    outs = []
+    for mode in (0, 2):
+        assert lib.cpc_set_mfma_mode(mode) == 0
+        try:
+            wp = torch.zeros(256 * k * 256 * 3 // 2)
+            y = torch.full((B, Lout, 256), float("nan")); xh = torch.full_like(y, float("nan")); rs = torch.zeros(B * Lout)
+            assert lib.cpc_conv_layer_forward(P(x), P(w), P(bias), P(nw), P(nb), P(wp), P(y), P(xh), P(rs), B, Lin, k, s, p,
+                                              None) == 0
+            outs.append(xh)
+        finally:
+            lib.cpc_set_mfma_mode(_lib_default_mode())
+    assert torch.isfinite(outs[1]).all()
+    if xs * ws > 1e-25:        # below that the conv output itself underflows against the norm's epsilon in BOTH modes
+        assert (outs[0] - outs[1]).abs().max().item() < 2e-5
