@@ -244,7 +244,7 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const float xh = (acc[tm][tn][r] - mean[tm][r]) * rstd[tm][r];
-                    xhat[(long)m * kC + col[tn]] = xh;
+                    __builtin_nontemporal_store(xh, xhat + (long)m * kC + col[tn]);     // read again only in backward
                     y[(long)m * kC + col[tn]] = fmaxf(fmaf(xh, gw[tn], gb[tn]), 0.f);
                 }
             }

@@ -238,7 +238,9 @@ __global__ __launch_bounds__(256) void nce_bwd_dz_rows_kernel(
             for (int u = 0; u < 4; ++u) {
                 float4 o;
                 o.x = acc[u * 4 + 0][r]; o.y = acc[u * 4 + 1][r]; o.z = acc[u * 4 + 2][r]; o.w = acc[u * 4 + 3][r];
-                *reinterpret_cast<float4*>(dst + 64 * u) = o;
+                // streamed: 1 GB written once and read once by the gather (non-temporal: 4.62 vs 4.66 ms per step)
+                __builtin_nontemporal_store(o.x, dst + 64 * u); __builtin_nontemporal_store(o.y, dst + 64 * u + 1);
+                __builtin_nontemporal_store(o.z, dst + 64 * u + 2); __builtin_nontemporal_store(o.w, dst + 64 * u + 3);
             }
         }
     }
@@ -289,18 +291,22 @@ __global__ __launch_bounds__(64) void nce_gather_rows_kernel(const float* __rest
     const int* list = do_sort ? sorted : perm + beg;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
     int p = 0;
+    auto ldv = [&](const float* q) __attribute__((always_inline)) {      // V is read exactly once: non-temporal (4.61 vs 4.66 ms)
+        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
+        return make_float4(t.x, t.y, t.z, t.w);
+    };
     for (; p + 4 <= len; p += 4) {
-        const float4 v0 = ld4(V + (long)list[p] * kC + 4 * lane);
-        const float4 v1 = ld4(V + (long)list[p + 1] * kC + 4 * lane);
-        const float4 v2 = ld4(V + (long)list[p + 2] * kC + 4 * lane);
-        const float4 v3 = ld4(V + (long)list[p + 3] * kC + 4 * lane);
+        const float4 v0 = ldv(V + (long)list[p] * kC + 4 * lane);
+        const float4 v1 = ldv(V + (long)list[p + 1] * kC + 4 * lane);
+        const float4 v2 = ldv(V + (long)list[p + 2] * kC + 4 * lane);
+        const float4 v3 = ldv(V + (long)list[p + 3] * kC + 4 * lane);
         a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
         a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
         a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
         a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
     }
     for (; p < len; ++p) {
-        const float4 v0 = ld4(V + (long)list[p] * kC + 4 * lane);
+        const float4 v0 = ldv(V + (long)list[p] * kC + 4 * lane);
         a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
     }
     float4 o;
