@@ -749,10 +749,12 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
         float* gi = p.dGi[LAYER] + bt * kG;
         float* gh = p.dGh[LAYER] + bt * kG;
         const float dar = dh * cr, daz = dh * cz;
-        gi[j] = dar;            gh[j] = dar;
-        gi[kH + j] = daz;       gh[kH + j] = daz;
-        gi[2 * kH + j] = dh * cni;   gh[2 * kH + j] = dh * cnh;
-        p.DH[LAYER][bt * kH + j] = dh;
+        // 200 MB of gate gradients for the weight-gradient GEMMs that follow: streamed past the caches the polling
+        // traffic lives in (non-temporal: 0.834 vs 0.853 ms for the whole backward)
+        __builtin_nontemporal_store(dar, gi + j); __builtin_nontemporal_store(dar, gh + j);
+        __builtin_nontemporal_store(daz, gi + kH + j); __builtin_nontemporal_store(daz, gh + kH + j);
+        __builtin_nontemporal_store(dh * cni, gi + 2 * kH + j); __builtin_nontemporal_store(dh * cnh, gh + 2 * kH + j);
+        __builtin_nontemporal_store(dh, p.DH[LAYER] + bt * kH + j);
         dh_next = dh;
         z_next = z;
         if (t > 0) fetch(t - 1);                                  // a step ahead: memory latency off the chain
