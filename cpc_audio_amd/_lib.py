@@ -53,6 +53,7 @@ SIGNATURES = {
     "cpc_nce_backward": (_I, [_P] * 12 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward_streams": (_I, [_P] * 12 + [_I, _I, _I, _I, _P, _P]),
     "cpc_nce_backward_dz": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
+    "cpc_nce_backward_dwall": (_I, [_P] * 3 + [_I, _I, _I, _I, _P]),
 }
 
 

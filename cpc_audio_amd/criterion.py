@@ -152,6 +152,7 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             pred = self.wPrediction.predictions(cFeature[:, :windowSize].contiguous())
             losses, acc = InfoNCEScoresFunction.apply(pred, encodedData, ext, perm, row_ptr)
         else:
+            heads = [p.weight for p in self.wPrediction.predictors]
             losses, acc = InfoNCEFunction.apply(cFeature, encodedData, self.wPrediction.stacked_weight(), ext, perm,
-                                                row_ptr)
+                                                row_ptr, heads)
         return losses.view(1, -1), acc.view(1, -1)

@@ -569,7 +569,7 @@ extern "C" int cpc_nce_backward_streams(const float* c, const float* z, const fl
                                         int N, void* stream, void* dz_stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
-    CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc || !dwall, CPC_ERR_ARG);
+    CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     float* dpred = scratch + n.dpred, *wallT = scratch + n.wallT;
     (void)hipMemsetAsync(dc, 0, sizeof(float) * (size_t)B * S * kC, st);
@@ -581,8 +581,19 @@ extern "C" int cpc_nce_backward_streams(const float* c, const float* z, const fl
     if (rc) return rc;
     rc = nt_gemm(plain_rows(dpred, n.BW, K * kC), wallT, K * kC, nullptr, dc, kC, kC, K * kC, st, n.W,
                  (long)S * kC);
-    if (rc) return rc;
+    if (rc || !dwall) return rc;
     // dW_k = dPred_k^T . c[:, :W]
     return tn_gemm(plain_rows(dpred, n.BW, K * kC), K * kC, window_rows(c, B, S, n.W), kC, scratch + n.part,
                    dwall, 0, st);
+}
+
+// The head-weight gradient alone, from the dPred that cpc_nce_backward_streams(dwall = NULL) left in `scratch`:
+// nothing on the way to the encoder depends on it, so the caller may run it on any stream that waits for that call.
+extern "C" int cpc_nce_backward_dwall(const float* c, float* scratch, float* dwall, int B, int S, int K, int N,
+                                      void* stream) {
+    NceLayout n;
+    CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!c || !scratch || !dwall, CPC_ERR_ARG);
+    return tn_gemm(plain_rows(scratch + n.dpred, n.BW, K * kC), K * kC, window_rows(c, B, S, n.W), kC,
+                   scratch + n.part, dwall, 0, (hipStream_t)stream);
 }

@@ -43,7 +43,8 @@ _layout_cache = {}
 # and the encoder; code that reads dz on the current stream through other ops must leave it off (the default).
 OVERLAP_DZ = False
 _side_streams = {}
-_side_events = []
+_side_events = []       # work the next backward op depends on (dz)
+_late_events = []       # work only the optimiser reads (the prediction heads' weight gradient)
 _deferred = []          # side-stream launches held back until the AR backward is in flight (it needs whole CUs: its
                         # 768-thread workgroups cannot squeeze in beside a chip full of gather blocks)
 
@@ -60,11 +61,15 @@ def launch_deferred():
         _deferred.pop(0)()
 
 
-def wait_side_stream():
-    """Make the current stream wait for everything this package has launched (or still holds) for its side stream."""
+def wait_side_stream(final=True):
+    """Make the current stream wait for everything this package has launched (or still holds) for its side stream.
+    ``final=False`` (used between the backward ops) leaves out what only the optimiser reads; whoever switches
+    OVERLAP_DZ on calls this with final=True after backward() and before touching any ``.grad``."""
     launch_deferred()
     while _side_events:
         torch.cuda.current_stream().wait_event(_side_events.pop())
+    while final and _late_events:
+        torch.cuda.current_stream().wait_event(_late_events.pop())
 
 # Parity tests set KEEP_DEBUG = True to look at the encoder's saved activations (the ReLU
 # masks of the device path, see oracle/cpc_oracle._ReluTieAware).  Never used by the product.
@@ -111,7 +116,7 @@ class EncoderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         lib = _lib.get()
-        wait_side_stream()                     # dz may carry the criterion's side-stream part
+        wait_side_stream(final=False)          # dz may carry the criterion's side-stream part
         wave, saved, z, *params = ctx.saved_tensors
         B, L, nscr = ctx.dims
         dz = dz.contiguous()
@@ -120,6 +125,7 @@ class EncoderFunction(torch.autograd.Function):
             grads = [torch.empty_like(p) for p in params]
             lib.check(lib.cpc_encoder_backward(_p(wave), _ptrs(params), _p(saved), _p(z), _p(dz), _p(scratch),
                                                _ptrs(grads), B, L, _stream()), "encoder_backward")
+        wait_side_stream()                     # the last backward op: everything on the side stream is due now
         return (None, *grads)
 
 
@@ -163,7 +169,7 @@ class GruFunction(torch.autograd.Function):
             grads = [torch.empty_like(p) for p in params]
             lib.check(lib.cpc_gru_backward(_p(x), _p(ctx.h0), _ptrs(params), _p(saved), _p(y), _p(dy),
                                            _p(scratch), _p(dx), _ptrs(grads), B, S, nl, _stream()), "gru_backward")
-        wait_side_stream()      # starts the criterion's deferred dz path beside the recurrence just launched, and makes
+        wait_side_stream(final=False)  # starts the criterion's deferred dz path beside the recurrence just launched, and makes
         #                         this stream wait for it: autograd adds dx to that dz next
         return (dx, None, *grads)
 
@@ -203,10 +209,13 @@ def prepare_negatives(batchIdx, seqIdx, B, S, K, N):
 
 
 class InfoNCEFunction(torch.autograd.Function):
-    """c, z (B,S,256), wall (K*256,256), ext (B,W,N) int32, perm, row_ptr -> losses (K), acc (K)."""
+    """c, z (B,S,256), wall (K*256,256), ext (B,W,N) int32, perm, row_ptr -> losses (K), acc (K).
+    ``heads``: optionally the K leaf parameters (256,256) that ``wall`` is the row-wise concatenation of.  With
+    OVERLAP_DZ their gradient is then formed on the side stream as well and accumulated into ``.grad`` directly
+    (bit-identical values; ``wall`` itself receives no gradient), which takes that GEMM off the path to the encoder."""
 
     @staticmethod
-    def forward(ctx, c, z, wall, ext, perm, row_ptr):
+    def forward(ctx, c, z, wall, ext, perm, row_ptr, heads=None):
         _require_cuda(c, "InfoNCEFunction")
         lib = _lib.get()
         B, S, H = c.shape
@@ -225,6 +234,9 @@ class InfoNCEFunction(torch.autograd.Function):
                                           _p(acc), B, S, K, N, _stream()), "nce_forward")
         ctx.save_for_backward(c, z, wall, ext, saved, perm, row_ptr)
         ctx.dims = (B, S, K, N, sizes[2])
+        ctx.heads = list(heads) if heads is not None else None
+        if ctx.heads is not None and (len(ctx.heads) != K or any(h.shape != (_HID, _HID) for h in ctx.heads)):
+            raise ValueError("InfoNCEFunction: heads must be the K (256,256) weights stacked in wall")
         ctx.mark_non_differentiable(acc)
         return losses, acc
 
@@ -240,9 +252,11 @@ class InfoNCEFunction(torch.autograd.Function):
             if OVERLAP_DZ:
                 main, side = torch.cuda.current_stream(), _side_stream(c.device)
                 ready = torch.cuda.Event()
-                # dc / dwall now, on this stream (dz = NULL leaves the dz path out) ...
+                heads = ctx.heads if ctx.heads is not None and any(h.requires_grad for h in ctx.heads) else None
+                # dc (and dwall, unless the leaf weights are known) now, on this stream; dz = NULL leaves the dz path out
                 lib.check(lib.cpc_nce_backward_streams(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
-                                                       _p(gloss), _p(scratch), _p(dc), None, _p(dwall), B, S, K, N,
+                                                       _p(gloss), _p(scratch), _p(dc), None,
+                                                       None if heads else _p(dwall), B, S, K, N,
                                                        main.cuda_stream, main.cuda_stream), "nce_backward")
                 ready.record(main)
 
@@ -256,11 +270,34 @@ class InfoNCEFunction(torch.autograd.Function):
                     ev.record(side)
                     _side_events.append(ev)
                 _deferred.append(dz_path)
+                if heads:
+                    dheads = dwall
+                    def dwall_path():     # ... and the head-weight gradient after it: only the optimiser reads it
+                        with torch.cuda.stream(side):
+                            lib.check(lib.cpc_nce_backward_dwall(_p(c), _p(scratch), _p(dheads), B, S, K, N,
+                                                                 side.cuda_stream), "nce_backward_dwall")
+                            with torch.no_grad():
+                                for k, h in enumerate(heads):
+                                    if not h.requires_grad:
+                                        continue
+                                    g = dheads[k * _HID:(k + 1) * _HID]
+                                    if h.grad is None:
+                                        h.grad = g
+                                    else:
+                                        h.grad.add_(g)
+                                        h.grad.record_stream(side)
+                        for t in (c, scratch, dheads):
+                            t.record_stream(side)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        _late_events.append(ev)
+                    _deferred.append(dwall_path)
+                    dwall = None
             else:
                 lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
                                                _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
                                                _stream()), "nce_backward")
-        return dc, dz, dwall, None, None, None
+        return dc, dz, dwall, None, None, None, None
 
 
 class InfoNCEScoresFunction(torch.autograd.Function):
@@ -349,5 +386,5 @@ class TransformerLayerFunction(torch.autograd.Function):
             grads = [None if p is None else torch.empty_like(p) for p in params]
             lib.check(lib.cpc_transformer_layer_backward(_p(x), _ptrs(params), _p(saved), _p(dy), _p(scratch), _p(dx),
                                                          _ptrs(grads), B, S, _stream()), "transformer_layer_backward")
-        wait_side_stream()
+        wait_side_stream(final=False)
         return (dx, *grads)

@@ -192,6 +192,11 @@ int cpc_nce_backward_dz(const float* z, const int* ext, const int* perm, const i
                         const float* saved, const float* gloss, float* scratch, float* dz, int B, int S, int K,
                         int N, void* stream);
 
+/* cpc_nce_backward_streams also accepts dwall == NULL: the head-weight gradient (criterion.py:44-50, the K
+ * nn.Linear weights) is then left out and formed later by this call from the dPred kept in `scratch`; nothing on
+ * the way to the encoder depends on it.  `stream` must wait for the cpc_nce_backward_streams call. */
+int cpc_nce_backward_dwall(const float* c, float* scratch, float* dwall, int B, int S, int K, int N, void* stream);
+
 /* The same criterion for predictions formed by the caller -- any prediction network of
  * cpc/criterion/criterion.py:44-118, e.g. K transformer layers (--rnnMode transformer, :82-88):
  * pred (B*W, K*256), row (b,t), head k at columns k*256..; implements :115-116 (mean over 256 of pred * candidate)

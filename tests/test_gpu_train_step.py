@@ -117,3 +117,35 @@ def test_side_stream_dz_path_gives_identical_results():
         assert torch.equal(a["dz"], b["dz"]) and torch.equal(a["dc"], b["dc"])
         for k in a["grads"]:
             assert torch.equal(a["grads"][k], b["grads"][k]), k
+
+
+def test_side_stream_head_gradient_accumulates_like_autograd():
+    """With OVERLAP_DZ the prediction heads' weight gradient is written into .grad by the side-stream job instead of
+    by autograd; a second backward without zero_grad must add to it exactly as AccumulateGrad would."""
+    dev = _dev()
+    from cpc_audio_amd import ops
+    from cpc_audio_amd.train import build_criterion, build_model, load_flat_params
+    B = 4
+    p = O.make_params(seed=13, head_scale=64.0)
+    wave = O.make_waveform(B, 20480, seed=23).to(dev)
+    g = torch.Generator().manual_seed(7)
+    bidx, sidx = O.draw_negative_indices(B, 128, 116, 128, generator=g)
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    res = []
+    for overlap in (False, True):
+        model, crit = build_model().to(dev), build_criterion().to(dev)
+        load_flat_params(model, crit, p)
+        for _ in range(2):
+            ops.OVERLAP_DZ = overlap
+            try:
+                c, z, _ = model(wave, label)
+                losses, _ = crit(c, z, None, negatives=(bidx.to(dev), sidx.to(dev)))
+                losses.sum().backward()
+                ops.wait_side_stream()
+            finally:
+                ops.OVERLAP_DZ = False
+        torch.cuda.synchronize()
+        res.append({k: v.grad.cpu() for k, v in list(model.state_dict(keep_vars=True).items())
+                    + list(crit.state_dict(keep_vars=True).items())})
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
