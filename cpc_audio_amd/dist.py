@@ -1,4 +1,4 @@
-"""Data-parallel gradient exchange: one process per GPU, ONE flat RCCL all-reduce per step.
+"""Data-parallel gradient exchange: one process per GPU, a flat RCCL SUM all-reduce per step in two buckets.
 
 The reference wraps model and criterion in torch.nn.DataParallel (cpc/train.py:372-375):
 every step it broadcasts all parameters, gathers c and z to GPU 0, re-scatters them into
@@ -8,36 +8,102 @@ here each rank runs the whole step on its own sub-batch and the only collective 
 all-reduce of the 2,893,056 gradient values (11.57 MB) over xGMI.  SUM, not mean: the
 reference sums the per-replica losses (train.py:85, ``allLosses.sum()`` over the gathered
 (nGPU, K) tensor), see SURVEY.md T8.
+
+Two buckets of one persistent flat buffer, because the backward pass ends with the encoder (about a third of the
+step) and everything else -- prediction heads and auto-regressive network, 55 % of the values -- is final before it
+starts: ``begin()`` (hooked to the start of the encoder's backward by the package's train loops, ops.
+pre_encoder_backward) sends that ``early`` bucket off on the side stream while the encoder's backward runs, and
+the call after backward() sends the rest, waits for both and writes the sums back.  Every rank issues the two
+collectives in the same order; without ``begin()`` the call reduces the whole buffer at once.
 """
 import torch
 import torch.distributed as dist
 
 
 class FlatGradAllReduce:
-    """Flattens the gradients of ``params`` into one persistent buffer and all-reduces it."""
+    """Flattens the gradients of ``params`` into one persistent buffer and all-reduces it (SUM).
+    ``early``: the subset of ``params`` whose gradients are complete when ``begin()`` is called."""
 
-    def __init__(self, params, group=None):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, early=None, group=None):
+        params = [p for p in params if p.requires_grad]
+        ids = {id(p) for p in (early or [])}
+        self.early = [p for p in params if id(p) in ids]
+        self.late = [p for p in params if id(p) not in ids]
+        self.params = self.early + self.late                 # buffer order: early bucket first
+        self.n_early = sum(p.numel() for p in self.early)
         self.group = group
         self.numel = sum(p.numel() for p in self.params)
         self.buf = None
+        self.views = None
+        self._pending = None                                  # work handle of the early bucket
+        self.single_rank_too = False                          # tests: run the collectives in a 1-rank group as well
 
-    def __call__(self):
-        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
-            return
+    def _active(self):
+        return (dist.is_available() and dist.is_initialized()
+                and (dist.get_world_size(self.group) > 1 or self.single_rank_too))
+
+    def _views(self, params):
         ref = self.params[0]
         if self.buf is None or self.buf.device != ref.device:
             self.buf = torch.empty(self.numel, device=ref.device, dtype=ref.dtype)
-        views, off = [], 0
-        for p in self.params:
-            n = p.numel()
-            views.append(self.buf[off:off + n].view_as(p))
-            off += n
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        torch._foreach_copy_(views, grads)
-        dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+            self.views, off = {}, 0
+            for p in self.params:
+                n = p.numel()
+                self.views[id(p)] = self.buf[off:off + n].view_as(p)
+                off += n
+        return [self.views[id(p)] for p in params]
+
+    def _pack(self, params):
+        views = self._views(params)
+        have = [(v, p.grad) for v, p in zip(views, params) if p.grad is not None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(views, params):
+            if p.grad is None:
+                v.zero_()
+
+    def begin(self):
+        """Start reducing the ``early`` bucket.  On a GPU the packing and the collective are ordered after everything
+        the side stream (ops.py) holds -- the heads' gradient is formed there -- and after the current stream's work
+        up to now; the current stream does not wait for them."""
+        if not self._active() or not self.early or self._pending is not None:
+            return
+        ref = self.early[0]
+        bucket = None
+        if ref.is_cuda:
+            from . import ops
+            main, side = torch.cuda.current_stream(ref.device), ops._side_stream(ref.device)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                self._pack(self.early)
+                bucket = self.buf[:self.n_early]
+                self._pending = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            for p in self.early:
+                if p.grad is not None:
+                    p.grad.record_stream(side)
+        else:
+            self._pack(self.early)
+            bucket = self.buf[:self.n_early]
+            self._pending = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def __call__(self):
+        if not self._active():
+            return
+        if self._pending is None:                             # begin() was not called: one collective
+            self._pack(self.params)
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            if self.late:
+                self._pack(self.late)
+                dist.all_reduce(self.buf[self.n_early:], op=dist.ReduceOp.SUM, group=self.group)
+            self._pending.wait()                              # current stream waits for the early bucket
+            self._pending = None
+        views = self._views(self.params)
+        have = [(p.grad, v) for p, v in zip(self.params, views) if p.grad is not None]
+        if have:
+            torch._foreach_copy_([g for g, _ in have], [v for _, v in have])
         for p, v in zip(self.params, views):
             if p.grad is None:
                 p.grad = v.clone()
-            else:
-                p.grad.copy_(v)

@@ -111,11 +111,17 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
         batch, label = _to_device(batch, device), _to_device(label, device)
         n_ex += batch.size(0)
         ops.OVERLAP_DZ = True                             # no foreign consumer of dz in this graph (ops.py)
-        c_feature, encoded, label = model(batch, label)
-        all_losses, all_acc = criterion(c_feature, encoded, label)
-        all_losses.sum().backward()                       # train.py:85-87
-        ops.wait_side_stream()
-        ops.OVERLAP_DZ = False
+        if allreduce is not None:
+            ops.pre_encoder_backward.append(allreduce.begin)
+        try:
+            c_feature, encoded, label = model(batch, label)
+            all_losses, all_acc = criterion(c_feature, encoded, label)
+            all_losses.sum().backward()                   # train.py:85-87
+            ops.wait_side_stream()
+        finally:
+            ops.OVERLAP_DZ = False
+            if allreduce is not None:
+                ops.pre_encoder_backward.remove(allreduce.begin)
         if allreduce is not None:
             allreduce()
         optimizer.step()
@@ -215,7 +221,9 @@ def run(train_loader_fn, val_loader_fn, model, criterion, n_epoch, path_checkpoi
     logs.setdefault("epoch", [])
     start_epoch = len(logs["epoch"])
     best_acc, best_state = 0.0, None
-    allreduce = FlatGradAllReduce(list(criterion.parameters()) + list(model.parameters()))
+    enc = {id(p) for p in model.gEncoder.parameters()} if hasattr(model, "gEncoder") else set()
+    every = list(criterion.parameters()) + list(model.parameters())
+    allreduce = FlatGradAllReduce(every, early=[p for p in every if id(p) not in enc] if enc else None)
     if path_checkpoint is not None and args is not None:
         os.makedirs(os.path.dirname(path_checkpoint) or ".", exist_ok=True)
         with open(os.path.join(os.path.dirname(path_checkpoint) or ".", "checkpoint_args.json"), "w") as f:

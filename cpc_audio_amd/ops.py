@@ -49,6 +49,10 @@ _deferred = []          # side-stream launches held back until the AR backward i
                         # 768-thread workgroups cannot squeeze in beside a chip full of gather blocks)
 
 
+pre_encoder_backward = []   # callables run when the encoder's backward starts: every other gradient of the step is
+                            # final (or queued on the side stream) by then -- dist.FlatGradAllReduce.begin hooks here
+
+
 def _side_stream(device):
     st = _side_streams.get(device)
     if st is None:
@@ -117,6 +121,8 @@ class EncoderFunction(torch.autograd.Function):
     def backward(ctx, dz):
         lib = _lib.get()
         wait_side_stream(final=False)          # dz may carry the criterion's side-stream part
+        for hook in pre_encoder_backward:
+            hook()
         wave, saved, z, *params = ctx.saved_tensors
         B, L, nscr = ctx.dims
         dz = dz.contiguous()

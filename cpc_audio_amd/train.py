@@ -42,17 +42,22 @@ class Trainer:
         params = list(criterion.parameters()) + list(model.parameters())      # train.py:332
         fused = all(p.is_cuda for p in params)     # one fused multi-tensor kernel on the GPU
         self.optimizer = torch.optim.Adam(params, lr=lr, betas=betas, eps=eps, fused=fused)  # train.py:335-337
-        self.allreduce = FlatGradAllReduce(params)
+        enc = {id(p) for p in model.gEncoder.parameters()} if hasattr(model, "gEncoder") else set()
+        self.allreduce = FlatGradAllReduce(params, early=[p for p in params if id(p) not in enc] if enc else None)
 
     def step(self, batchData, label, negatives=None):
         from . import ops
         ops.OVERLAP_DZ = True        # this loop's graph has no foreign consumer of dz between criterion and encoder
-        c_feature, encoded_data, label = self.model(batchData, label)
-        allLosses, allAcc = self.criterion(c_feature, encoded_data, label, negatives=negatives)
-        totLoss = allLosses.sum()
-        totLoss.backward()
-        ops.wait_side_stream()
-        ops.OVERLAP_DZ = False
+        ops.pre_encoder_backward.append(self.allreduce.begin)
+        try:
+            c_feature, encoded_data, label = self.model(batchData, label)
+            allLosses, allAcc = self.criterion(c_feature, encoded_data, label, negatives=negatives)
+            totLoss = allLosses.sum()
+            totLoss.backward()
+            ops.wait_side_stream()
+        finally:
+            ops.OVERLAP_DZ = False
+            ops.pre_encoder_backward.remove(self.allreduce.begin)
         self.allreduce()
         self.optimizer.step()
         self.optimizer.zero_grad()

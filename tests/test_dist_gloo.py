@@ -34,6 +34,23 @@ def _worker(rank, world, port, out):
         p.grad.fill_(float(rank))
     ar()
     ok = ok and all(torch.equal(p.grad, torch.full_like(p, 1.0)) for p in params)
+    # two buckets: the early one is sent off by begin(), the rest by the call; a parameter without gradient counts 0
+    early = [params[2], params[0]]
+    ar2 = FlatGradAllReduce(params, early=early)
+    for rep in range(2):
+        for i, p in enumerate(params):
+            p.grad = torch.full_like(p, float((rank + 1) * (i + 1) + rep))
+        if rank == 1:
+            params[0].grad = None
+        ar2.begin()
+        ar2()
+        want = [1.0 + rep, 6.0 + 2 * rep, 9.0 + 2 * rep]
+        ok = ok and all(torch.equal(p.grad, torch.full_like(p, w)) for p, w in zip(params, want))
+    # ... and without begin() the same object falls back to one collective
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + i))
+    ar2()
+    ok = ok and all(torch.equal(p.grad, torch.full_like(p, float(1 + 2 * i))) for i, p in enumerate(params))
     # sharding: each rank draws its own sequences; no overlap, identical parameters
     g = torch.Generator().manual_seed(1234 + rank)
     wave = (0.1 * torch.randn(2, 1, 64, generator=g)).clamp_(-1, 1)
