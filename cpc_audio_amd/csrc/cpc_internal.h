@@ -9,6 +9,10 @@ namespace cpc {
 // tmp must hold kRowsSumGroups*n floats.
 constexpr int kRowsSumGroups = 128;
 int rows_sum(const float* part, int nrows, int n, float* tmp, float* out, hipStream_t stream);
+// several independent reductions (each with its own tmp) in two launches; bit-identical with rows_sum per job
+constexpr int kRowsSumMaxJobs = 8;
+struct RowsSumJob { const float* part; int nrows; int n; float* tmp; float* out; };
+int rows_sum_multi(const RowsSumJob* jobs, int njobs, hipStream_t stream);
 
 // C[M,N] = A . B[N,K]^T (+ bias);  N % 128 == 0, K % 16 == 0
 int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc, int N,
@@ -20,6 +24,8 @@ int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, flo
             hipStream_t st);
 // out[Cn][R] = in[R][Cn]^T
 int transpose(const float* in, float* out, int R, int Cn, hipStream_t st);
+// n <= 4 matrices of one shape in one launch
+int transpose_batch(const float* const* in, float* const* out, int n, int R, int Cn, hipStream_t st);
 
 // 1 (default): NT GEMMs run on the bf16 matrix pipe with 3-piece split operands (NtTileX3, fp32-level
 // accuracy); 0: exact-f32 MFMA (NtTile).  Set through cpc_set_mfma_mode().

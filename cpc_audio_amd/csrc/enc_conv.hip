@@ -42,19 +42,16 @@ __device__ __forceinline__ void store_h2(float* base, long dst, float v, float s
     o[0] = h;
     o[4] = l;
 }
-__global__ __launch_bounds__(256) void permute_w_fwd_kernel(const float* __restrict__ w,
-                                                            float* __restrict__ wp, int k, int split,
-                                                            const float* __restrict__ amax) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void permute_w_fwd_elem(const float* __restrict__ w, float* __restrict__ wp, int k,
+                                                   int split, float amax, long idx) {
     const long total = (long)kC * k * kC;
-    if (idx >= total) return;
     const int co = (int)(idx / (k * kC));
     const int rem = (int)(idx - (long)co * k * kC);
     const int kk = rem >> kCLog2, ci = rem & (kC - 1);
     const float v = w[((long)co * kC + ci) * k + kk];
     const long dst = ((long)(rem >> 4) * kC + co) * 16 + (rem & 15);
     if (split == 2) {
-        store_h2(wp, dst, v, scale_for_amax(*amax));
+        store_h2(wp, dst, v, scale_for_amax(amax));
     } else if (split) {
         unsigned h, m, l;
         split3(v, h, m, l);
@@ -66,15 +63,18 @@ __global__ __launch_bounds__(256) void permute_w_fwd_kernel(const float* __restr
         wp[dst] = v;
     }
 }
+__global__ __launch_bounds__(256) void permute_w_fwd_kernel(const float* __restrict__ w,
+                                                            float* __restrict__ wp, int k, int split,
+                                                            const float* __restrict__ amax) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < (long)kC * k * kC) permute_w_fwd_elem(w, wp, k, split, split == 2 ? *amax : 0.f, idx);
+}
 
 // (O,I,W) -> Wd[r](ci, kg = j*C + co) = W[co][ci][r + (1-j)*s],  r < s, j in {0,1}; each phase r k-blocked
 // like Wp: [kg/16][ci][kg%16]
-__global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __restrict__ w,
-                                                              float* __restrict__ wd, int s, int split,
-                                                              const float* __restrict__ amax) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void permute_w_dgrad_elem(const float* __restrict__ w, float* __restrict__ wd, int s,
+                                                     int split, float amax, long idx) {
     const long total = (long)s * kC * 2 * kC;
-    if (idx >= total) return;
     const int k = 2 * s;
     const int r = (int)(idx / (kC * 2 * kC));
     const int rem = (int)(idx - (long)r * kC * 2 * kC);
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __res
     const float v = w[((long)co * kC + ci) * k + r + (1 - j) * s];
     const long dst = (long)r * kC * 2 * kC + ((long)(jc >> 4) * kC + ci) * 16 + (jc & 15);
     if (split == 2) {
-        store_h2(wd, dst, v, scale_for_amax(*amax));
+        store_h2(wd, dst, v, scale_for_amax(amax));
     } else if (split) {
         unsigned h, m, l;
         split3(v, h, m, l);
@@ -96,29 +96,39 @@ __global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __res
         wd[dst] = v;
     }
 }
+__global__ __launch_bounds__(256) void permute_w_dgrad_kernel(const float* __restrict__ w,
+                                                              float* __restrict__ wd, int s, int split,
+                                                              const float* __restrict__ amax) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < (long)s * kC * 2 * kC) permute_w_dgrad_elem(w, wd, s, split, split == 2 ? *amax : 0.f, idx);
+}
 
 // ------------------------------------------------------------------ operand bounds for the fp16-split mode
 // out = max(out, max_i |x_i|): |x| as uint bits is monotone, so an integer atomicMax gives an order-independent,
 // exact result.
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+// max|x| over the slice this workgroup (`blk` of `nblk`) walks; the result is valid in thread 0
+__device__ __forceinline__ float block_absmax(const float* __restrict__ x, long n, int blk, int nblk) {
     __shared__ float red[4];
     float m = 0.f;
     const long n4 = n >> 2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    for (long i = (long)blk * 256 + threadIdx.x; i < n4; i += (long)nblk * 256) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
-    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    for (long i = (n4 << 2) + (long)blk * 256 + threadIdx.x; i < n; i += (long)nblk * 256) m = fmaxf(m, fabsf(x[i]));
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0)
-        atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    const float m = block_absmax(x, n, blockIdx.x, gridDim.x);
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
 }
 // Bound of a ChannelNorm output (cpc/model.py:50-58): |xhat| <= sqrt(C-1) (unbiased variance), so
 // |y| <= sqrt(C-1) * max|w| + max|b|; ReLU only shrinks it.  One workgroup of 256 threads.
-__global__ __launch_bounds__(256) void norm_bound_kernel(const float* __restrict__ nw, const float* __restrict__ nb,
-                                                         float* __restrict__ out) {
+__device__ __forceinline__ void norm_bound_block(const float* __restrict__ nw, const float* __restrict__ nb,
+                                                 float* __restrict__ out) {
     __shared__ float red[2][4];
     const float w = wave_max(fabsf(nw[threadIdx.x])), b = wave_max(fabsf(nb[threadIdx.x]));
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = w; red[1][threadIdx.x >> 6] = b; }
@@ -128,6 +138,55 @@ __global__ __launch_bounds__(256) void norm_bound_kernel(const float* __restrict
         const float mb = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
         *out = 15.968719f * mw + mb;                             // sqrt(255)
     }
+}
+__global__ __launch_bounds__(256) void norm_bound_kernel(const float* __restrict__ nw, const float* __restrict__ nb,
+                                                         float* __restrict__ out) {
+    norm_bound_block(nw, nb, out);
+}
+
+// ---- all per-step weight preparation of layers 1..4 in two launches (the composite encoder; the per-layer entry
+// points keep their own).  The weights change once per optimiser step, and as separate launches the 4 x (bound,
+// max|w|, forward layout, dgrad layout) are ~30 kernels of ~5 us each: more than a whole conv layer.
+//   enc_prep_amax_kernel    grid (kPrepParts, 5): rows 0..3 = partial max|w| of layer y+1 (plain stores, no atomics, no
+//                           zero fill), row 4 = the ChannelNorm bounds of the four layers' inputs
+//   enc_prep_permute_kernel one thread per (layer, layout, element); every workgroup folds its layer's kPrepParts
+//                           partials itself (a max is order-independent)
+constexpr int kPrepParts = 32;
+struct PrepArgs {
+    const float* w[4];      // conv{1..4}.weight
+    float* wp[4];           // forward layouts   (+ max|w| behind them in the fp16-split mode)
+    float* wd[4];           // dgrad layouts     (same)
+    const float* nw[4];     // batchNorm{0..3}.weight / .bias: the producers of the four inputs
+    const float* nb[4];
+    float* bound;           // [4]
+    float* partial;         // [4][kPrepParts]
+    int k[4];
+    int blk0[9];            // first workgroup of segment 2*layer + layout
+    int split;
+};
+__global__ __launch_bounds__(256) void enc_prep_amax_kernel(PrepArgs a) {
+    const int y = blockIdx.y;
+    if (y == 4) {
+        if (blockIdx.x < 4) norm_bound_block(a.nw[blockIdx.x], a.nb[blockIdx.x], a.bound + blockIdx.x);
+        return;
+    }
+    const float m = block_absmax(a.w[y], (long)kC * a.k[y] * kC, blockIdx.x, kPrepParts);
+    if (threadIdx.x == 0) a.partial[y * kPrepParts + blockIdx.x] = m;
+}
+__global__ __launch_bounds__(256) void enc_prep_permute_kernel(PrepArgs a) {
+    const int b = blockIdx.x;
+    int seg = 0;
+    while (seg < 7 && b >= a.blk0[seg + 1]) ++seg;            // block-uniform
+    const int layer = seg >> 1, k = a.k[layer];
+    const long total = (long)kC * k * kC;
+    static_assert(kPrepParts == 32, "one partial per half-wave lane");
+    const float amax = wave_max(a.partial[layer * kPrepParts + (threadIdx.x & 31)]);
+    float* dst = (seg & 1) ? a.wd[layer] : a.wp[layer];
+    const long idx = (long)(b - a.blk0[seg]) * 256 + threadIdx.x;
+    if (a.split == 2 && idx == 0) dst[total] = amax;          // where the GEMM kernels read max|w|
+    if (idx >= total) return;
+    if (seg & 1) permute_w_dgrad_elem(a.w[layer], dst, k / 2, a.split, amax, idx);
+    else permute_w_fwd_elem(a.w[layer], dst, k, a.split, amax, idx);
 }
 
 // ------------------------------------------------------------------ forward
@@ -556,11 +615,13 @@ static inline long align64(long v) { return (v + 63) & ~63L; }
 struct EncLayout {
     int L[5];
     long y[4], xhat[5], rstd[5], mean0;    // offsets (floats) into the saved workspace
+    long swd[5], sbound;                   // ... dgrad weight layouts (1..4) and input bounds, prepared by the forward
     long saved_total;
     long wp[5];                            // forward scratch: permuted weights (1..4)
-    long famax, fwd_total;
+    long famax, fwd_total;                 // famax: kPrepParts partial max|w| per layer
     // backward scratch
-    long wd[5], dx[5], dy0, part, colpart, tmp, small, conv0, bamax;
+    long dx[5], dy0, part, colpart, tmp, small, conv0, bamax;
+    long colp[5], tmpq[5];                 // per-layer partials of the stand-alone norm backwards (summed in one batch)
     long bwd_total;
     int wg_splits[5], wg_rows[5];
 };
@@ -589,18 +650,19 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     for (int i = 1; i < 5; ++i) { e.xhat[i] = o; o += align64((long)B * e.L[i] * kC); }
     for (int i = 0; i < 5; ++i) { e.rstd[i] = o; o += align64((long)B * e.L[i]); }
     e.mean0 = o; o += align64((long)B * e.L[0]);
+    e.swd[0] = -1;
+    for (int i = 1; i < 5; ++i) { e.swd[i] = o; o += align64((long)kC * kGeom[i].k * kC * 3 / 2); }
+    e.sbound = o; o += 64;                 // [i] = bound of layer i's input (fp16-split mode), i = 1..4
     e.saved_total = o;
 
     o = 0;
     e.wp[0] = -1;
     // 1.5x: in split-bf16 mode the re-laid-out weight is three bf16 planes (6 bytes per weight)
     for (int i = 1; i < 5; ++i) { e.wp[i] = o; o += align64((long)kC * kGeom[i].k * kC * 3 / 2); }
-    e.famax = o; o += 64;                  // per-layer input bounds for the fp16-split mode
+    e.famax = o; o += align64(4 * kPrepParts);
     e.fwd_total = o;
 
     o = 0;
-    e.wd[0] = -1;
-    for (int i = 1; i < 5; ++i) { e.wd[i] = o; o += align64((long)kC * kGeom[i].k * kC * 3 / 2); }
     e.dx[0] = -1;
     for (int i = 1; i < 5; ++i) { e.dx[i] = o; o += align64((long)B * e.L[i] * kC); }
     e.dy0 = o; o += align64((long)B * e.L[0] * kC);
@@ -625,8 +687,13 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     e.colpart = o; o += align64(col_max * 3 * kC);
     e.tmp = o; o += align64((long)kRowsSumGroups * 3 * kC);
     e.small = o; o += align64(5L * 3 * kC);
+    e.colp[0] = e.tmpq[0] = -1;
+    for (int i = 1; i < 5; ++i) {
+        e.colp[i] = o; o += align64((long)cdiv(B * e.L[i], NB_ROWS) * 3 * kC);
+        e.tmpq[i] = o; o += align64((long)kRowsSumGroups * 3 * kC);
+    }
     e.conv0 = o; o += align64(cpc_conv0_backward_scratch_floats(B, Lw));
-    e.bamax = o; o += 64;                   // [i] = max|dx_i| (i = 1..4), [8 + i] = bound of layer i's input
+    e.bamax = o; o += 64;                   // [i] = max|dx_i| (i = 1..4)
     e.bwd_total = o;
     return true;
 }
@@ -669,6 +736,14 @@ static void launch_conv_dgrad(const RowMap& am, const float* wd, int s, int p, i
 
 using namespace cpc;
 
+static int weight_split() {
+    return g_mfma_mode == 2 ? 2 : ((g_mfma_mode == 1 && ConvCfg<128, 1>::kPreSplitW) ? 1 : 0);
+}
+static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const float* xhat_prev, const float* y_prev,
+                           const float* rstd_prev, const float* nw_prev, float* dprev, float* colpart, float* tmp,
+                           float* small3, const float* dx_amax, float* dprev_amax, int B, int Lin, int k, int s, int p,
+                           hipStream_t st);
+
 extern "C" int cpc_set_conv_tile(int bm) {
     CPC_RETURN_IF(bm != 0 && bm != 32 && bm != 64 && bm != 128, CPC_ERR_ARG);
     g_force_bm = bm;
@@ -686,8 +761,7 @@ extern "C" int cpc_conv_weight_relayout(const float* w, float* wp, int k, void* 
         (void)hipMemsetAsync(amax, 0, sizeof(float), st);
         hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, st, w, nw_elems, amax);
     }
-    hipLaunchKernelGGL(permute_w_fwd_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wp, k,
-                       g_mfma_mode == 2 ? 2 : ((g_mfma_mode == 1 && ConvCfg<128, 1>::kPreSplitW) ? 1 : 0), amax);
+    hipLaunchKernelGGL(permute_w_fwd_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wp, k, weight_split(), amax);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -773,14 +847,25 @@ extern "C" int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, 
         (void)hipMemsetAsync(w_amax, 0, 2 * sizeof(float), st);
         hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, st, w, nw_elems, w_amax);
     }
-    hipLaunchKernelGGL(permute_w_dgrad_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wd, s,
-                       g_mfma_mode == 2 ? 2 : ((g_mfma_mode == 1 && ConvCfg<128, 1>::kPreSplitW) ? 1 : 0), w_amax);
+    hipLaunchKernelGGL(permute_w_dgrad_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wd, s, weight_split(),
+                       w_amax);
     if (g_mfma_mode == 2) {
         if (!dx_amax) {
             hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, dx, (long)B * Lout * kC, w_amax + 1);
             dx_amax = w_amax + 1;
         }
     }
+    return conv_dgrad_core(dx, wd, fuse, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, tmp, small3, dx_amax,
+                           dprev_amax, B, Lin, k, s, p, st);
+}
+
+// The dgrad GEMM on a weight already in the dgrad layout (max|w| behind it in the fp16-split mode).
+static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const float* xhat_prev, const float* y_prev,
+                           const float* rstd_prev, const float* nw_prev, float* dprev, float* colpart, float* tmp,
+                           float* small3, const float* dx_amax, float* dprev_amax, int B, int Lin, int k, int s, int p,
+                           hipStream_t st) {
+    const int Lout = conv_out_len(Lin, k, s, p);
+    const float* w_amax = wd + (long)kC * k * kC;
     // 2-row windows [q-1, q] over dx, q in [0, Lout]
     RowMap am;
     am.base = dx; am.R = Lout + 1; am.bstride = (long)Lout * kC; am.rstride = kC; am.off = -kC;
@@ -858,18 +943,34 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
     int rc = cpc_conv0_forward(wave, params[0], params[1], params[2], params[3], saved + e.y[0],
                                saved + e.mean0, saved + e.rstd[0], B, L, stream);
     if (rc) return rc;
+    // every weight-only quantity of layers 1..4 -- both GEMM layouts, max|w|, the bounds of the layers' inputs (the
+    // previous layer's ChannelNorm + ReLU output is bounded by its affine) -- in two launches; the backward finds the
+    // dgrad layouts and the bounds in `saved`
+    PrepArgs a;
+    int nblk = 0;
+    for (int i = 1; i < 5; ++i) {
+        a.w[i - 1] = params[4 * i];
+        a.wp[i - 1] = scratch + e.wp[i];
+        a.wd[i - 1] = saved + e.swd[i];
+        a.nw[i - 1] = params[4 * (i - 1) + 2];
+        a.nb[i - 1] = params[4 * (i - 1) + 3];
+        a.k[i - 1] = kGeom[i].k;
+        const int per = cdiv((long)kC * kGeom[i].k * kC, 256);
+        a.blk0[2 * (i - 1)] = nblk; nblk += per;
+        a.blk0[2 * (i - 1) + 1] = nblk; nblk += per;
+    }
+    a.blk0[8] = nblk;
+    a.bound = saved + e.sbound + 1;
+    a.partial = scratch + e.famax;
+    a.split = weight_split();
+    hipLaunchKernelGGL(enc_prep_amax_kernel, dim3(kPrepParts, 5), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(enc_prep_permute_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    CPC_LAUNCH_CHECK();
     for (int i = 1; i < 5; ++i) {
         float* yo = i == 4 ? z : saved + e.y[i];
-        float* wp = scratch + e.wp[i];
-        float* x_amax = scratch + e.famax + i;
-        rc = cpc_conv_weight_relayout(params[4 * i], wp, kGeom[i].k, stream);
-        if (rc) return rc;
-        if (g_mfma_mode == 2)     // the input is the previous layer's ChannelNorm + ReLU output: bounded by its affine
-            hipLaunchKernelGGL(norm_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, params[4 * (i - 1) + 2],
-                               params[4 * (i - 1) + 3], x_amax);
-        rc = cpc_conv_gemm_forward(saved + e.y[i - 1], wp, params[4 * i + 1], params[4 * i + 2], params[4 * i + 3], yo,
-                                   saved + e.xhat[i], saved + e.rstd[i], x_amax, B, e.L[i - 1], kGeom[i].k, kGeom[i].s,
-                                   kGeom[i].p, stream);
+        rc = cpc_conv_gemm_forward(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2],
+                                   params[4 * i + 3], yo, saved + e.xhat[i], saved + e.rstd[i], saved + e.sbound + i, B,
+                                   e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, stream);
         if (rc) return rc;
     }
     return 0;
@@ -886,48 +987,54 @@ extern "C" int cpc_encoder_backward(const float* wave, const float* const* param
     float* tmp = scratch + e.tmp;
     float* small = scratch + e.small;          // [5][3][256]
     // operand bounds of the fp16-split GEMMs: max|dx_i| is accumulated by the kernel that writes dx_i (integer
-    // atomicMax on the float bits: exact, order-independent); a layer's input is bounded by its producer's affine
+    // atomicMax on the float bits: exact, order-independent); the bounds of the layers' inputs and the dgrad weight
+    // layouts come from the forward (saved)
     float* amax = scratch + e.bamax;
+    const float* xbound = saved + e.sbound;
     (void)hipMemsetAsync(amax, 0, 64 * sizeof(float), st);
-    if (g_mfma_mode == 2)
-        for (int i = 1; i < 5; ++i)
-            hipLaunchKernelGGL(norm_bound_kernel, dim3(1), dim3(256), 0, st, params[4 * (i - 1) + 2], params[4 * (i - 1) + 3],
-                               amax + 8 + i);
     // top layer: ReLU'/norm backward of dz
-    int rc = cpc_norm_backward(dz, saved + e.xhat[4], z, saved + e.rstd[4], params[18], scratch + e.dx[4],
-                               colpart, tmp, small + 4 * 3 * kC, amax + 4, B * e.L[4], stream);
-    if (rc) return rc;
+    // the four stand-alone norm backwards leave their per-workgroup column partials in their own buffers; one batched
+    // reduction at the end replaces eight small launches on the way
+    RowsSumJob jobs[4];
+    int njobs = 0;
+    auto norm_bwd = [&](int layer, const float* dy, const float* yl, float* dxl) {
+        const int M = B * e.L[layer], nblk = cdiv(M, NB_ROWS);
+        hipLaunchKernelGGL(norm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
+                           saved + e.rstd[layer], params[4 * layer + 2], dxl, scratch + e.colp[layer], M, amax + layer);
+        jobs[njobs++] = RowsSumJob{scratch + e.colp[layer], nblk, 3 * kC, scratch + e.tmpq[layer], small + layer * 3 * kC};
+    };
+    int rc = 0;
+    norm_bwd(4, dz, z, scratch + e.dx[4]);
     for (int i = 4; i >= 1; --i) {
         const float* xin = saved + e.y[i - 1];
-        rc = cpc_conv_layer_wgrad(scratch + e.dx[i], xin, scratch + e.part, grads[4 * i], amax + i, amax + 8 + i, B,
+        rc = cpc_conv_layer_wgrad(scratch + e.dx[i], xin, scratch + e.part, grads[4 * i], amax + i, xbound + i, B,
                                   e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], stream);
         if (rc) return rc;
         if (i >= 2 && g_unfuse_big && (g_unfuse_big == 2 || pick_bm(B * (e.L[i] + 1)) == 128)) {
             // the fused ReLU'/ChannelNorm-backward epilogue is latency-bound (row-by-row reductions between the loads); a
             // plain dgrad into a temporary (dy0 is free until layer 1's dgrad) + the streaming norm backward is faster
             float* tmpd = scratch + e.dy0;
-            rc = cpc_conv_layer_dgrad(scratch + e.dx[i], params[4 * i], scratch + e.wd[i], 0, nullptr, nullptr, nullptr,
-                                      nullptr, tmpd, nullptr, nullptr, nullptr, amax + i, nullptr, B, e.L[i - 1],
-                                      kGeom[i].k, kGeom[i].s, kGeom[i].p, stream);
+            rc = conv_dgrad_core(scratch + e.dx[i], saved + e.swd[i], 0, nullptr, nullptr, nullptr, nullptr, tmpd, nullptr,
+                                 nullptr, nullptr, amax + i, nullptr, B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, st);
             if (rc) return rc;
-            rc = cpc_norm_backward(tmpd, saved + e.xhat[i - 1], xin, saved + e.rstd[i - 1], params[4 * (i - 1) + 2],
-                                   scratch + e.dx[i - 1], colpart, tmp, small + (i - 1) * 3 * kC, amax + i - 1,
-                                   B * e.L[i - 1], stream);
+            norm_bwd(i - 1, tmpd, xin, scratch + e.dx[i - 1]);
         } else if (i >= 2) {
-            rc = cpc_conv_layer_dgrad(scratch + e.dx[i], params[4 * i], scratch + e.wd[i], 1,
-                                      saved + e.xhat[i - 1], xin, saved + e.rstd[i - 1], params[4 * (i - 1) + 2],
-                                      scratch + e.dx[i - 1], colpart, tmp, small + (i - 1) * 3 * kC, amax + i,
-                                      amax + i - 1, B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, stream);
+            rc = conv_dgrad_core(scratch + e.dx[i], saved + e.swd[i], 1, saved + e.xhat[i - 1], xin,
+                                 saved + e.rstd[i - 1], params[4 * (i - 1) + 2], scratch + e.dx[i - 1], colpart, tmp,
+                                 small + (i - 1) * 3 * kC, amax + i, amax + i - 1, B, e.L[i - 1], kGeom[i].k, kGeom[i].s,
+                                 kGeom[i].p, st);
         } else {
-            rc = cpc_conv_layer_dgrad(scratch + e.dx[1], params[4], scratch + e.wd[1], 0, nullptr, nullptr,
-                                      nullptr, nullptr, scratch + e.dy0, nullptr, nullptr, nullptr, amax + 1, nullptr,
-                                      B, e.L[0], kGeom[1].k, kGeom[1].s, kGeom[1].p, stream);
+            rc = conv_dgrad_core(scratch + e.dx[1], saved + e.swd[1], 0, nullptr, nullptr, nullptr, nullptr,
+                                 scratch + e.dy0, nullptr, nullptr, nullptr, amax + 1, nullptr, B, e.L[0], kGeom[1].k,
+                                 kGeom[1].s, kGeom[1].p, st);
         }
         if (rc) return rc;
     }
     rc = cpc_conv0_backward(wave, params[0], params[1], params[2], params[3], saved + e.mean0,
                             saved + e.rstd[0], scratch + e.dy0, scratch + e.conv0, grads[0], grads[1],
                             grads[2], grads[3], B, L, stream);
+    if (rc) return rc;
+    rc = rows_sum_multi(jobs, njobs, st);
     if (rc) return rc;
     // layers 1..4: small[i] = [d norm.weight | d norm.bias | d conv.bias]
     GradPtrs gp;

@@ -241,6 +241,44 @@ __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__
     }
 }
 
+// The same for up to kRowsSumMaxJobs independent reductions per launch (blockIdx.z = job): stage 0 sums each job's row
+// groups into its tmp (or straight into out when there is one group), stage 1 folds the groups.
+struct RowsSumBatch {
+    RowsSumJob j[kRowsSumMaxJobs];
+    int groups[kRowsSumMaxJobs], rpg[kRowsSumMaxJobs];
+};
+__global__ __launch_bounds__(256) void rows_sum_multi_kernel(RowsSumBatch b, int stage) {
+    __shared__ float red[8][33];
+    const RowsSumJob& jb = b.j[blockIdx.z];
+    const int groups = b.groups[blockIdx.z], n = jb.n;
+    if ((int)blockIdx.y >= (stage == 0 ? groups : 1) || (stage == 1 && groups == 1) || (int)blockIdx.x * 32 >= n) return;
+    const float* part = stage == 0 ? jb.part : jb.tmp;
+    float* out = (stage == 1 || groups == 1) ? jb.out : jb.tmp;
+    const int nrows = stage == 0 ? jb.nrows : groups;
+    const int rpg = stage == 0 ? b.rpg[blockIdx.z] : groups;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + tx;
+    const int r0 = blockIdx.y * rpg;
+    const int r1 = min(nrows, r0 + rpg);
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int r = r0 + ty;
+        for (; r + 8 < r1; r += 16) {
+            s0 += part[(long)r * n + i];
+            s1 += part[(long)(r + 8) * n + i];
+        }
+        if (r < r1) s0 += part[(long)r * n + i];
+    }
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += red[q][tx];
+        out[(long)blockIdx.y * n + i] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void conv0_scatter_kernel(const float* __restrict__ sum,
                                                             float* __restrict__ dW0,
                                                             float* __restrict__ dB0,
@@ -266,6 +304,29 @@ int rows_sum(const float* part, int nrows, int n, float* tmp, float* out, hipStr
         hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 32), groups), dim3(256), 0, stream, part, nrows, n, rpg, tmp);
         hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 32), 1), dim3(256), 0, stream, tmp, groups, n, groups, out);
     }
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// Same arithmetic and summation order as rows_sum for every job (so results do not depend on which one ran).
+int rows_sum_multi(const RowsSumJob* jobs, int njobs, hipStream_t stream) {
+    if (njobs <= 0) return 0;
+    if (njobs > kRowsSumMaxJobs) return CPC_ERR_ARG;
+    RowsSumBatch b;
+    int gmax = 1, nmax = 0;
+    bool two = false;
+    for (int q = 0; q < njobs; ++q) {
+        b.j[q] = jobs[q];
+        if (jobs[q].nrows <= 0 || jobs[q].n <= 0) return CPC_ERR_SHAPE;
+        int groups = jobs[q].nrows > 64 ? kRowsSumGroups : 1;
+        const int rpg = cdiv(jobs[q].nrows, groups);
+        groups = cdiv(jobs[q].nrows, rpg);
+        b.groups[q] = groups; b.rpg[q] = rpg;
+        gmax = std::max(gmax, groups); nmax = std::max(nmax, jobs[q].n);
+        two = two || groups > 1;
+    }
+    hipLaunchKernelGGL(rows_sum_multi_kernel, dim3(cdiv(nmax, 32), gmax, njobs), dim3(256), 0, stream, b, 0);
+    if (two) hipLaunchKernelGGL(rows_sum_multi_kernel, dim3(cdiv(nmax, 32), 1, njobs), dim3(256), 0, stream, b, 1);
     CPC_LAUNCH_CHECK();
     return 0;
 }

@@ -100,6 +100,25 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// the same for up to 4 equally shaped matrices in one launch (blockIdx.z picks the pair)
+struct TransposeBatch { const float* in[4]; float* out[4]; };
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch b, int R, int Cn) {
+    __shared__ float tile[32][33];
+    const float* __restrict__ in = b.in[blockIdx.z];
+    float* __restrict__ out = b.out[blockIdx.z];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cn) ? in[(long)r * Cn + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < Cn && r < R) out[(long)c * R + r] = tile[tx][i];
+    }
+}
+
 int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc,
             int N, int K, hipStream_t st, int c_R, long c_bstride) {
     if (am.M <= 0) return 0;
@@ -162,6 +181,15 @@ int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, flo
 
 int transpose(const float* in, float* out, int R, int Cn, hipStream_t st) {
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cn, 32), cdiv(R, 32)), dim3(256), 0, st, in, out, R, Cn);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+int transpose_batch(const float* const* in, float* const* out, int n, int R, int Cn, hipStream_t st) {
+    if (n <= 0 || n > 4) return CPC_ERR_ARG;
+    TransposeBatch b;
+    for (int i = 0; i < 4; ++i) { b.in[i] = in[i < n ? i : 0]; b.out[i] = out[i < n ? i : 0]; }
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3(cdiv(Cn, 32), cdiv(R, 32), n), dim3(256), 0, st, b, R, Cn);
     CPC_LAUNCH_CHECK();
     return 0;
 }

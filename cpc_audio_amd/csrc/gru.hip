@@ -807,7 +807,7 @@ static bool gru_layout(int B, int S, int nl, GruLayout& g) {
     g.mid[0] = o; o += bsh;
     g.mid[1] = o; o += bsh;
     g.part = o; o += align64l(tn_gemm_part_floats(B * S, kG, kH));
-    g.tmp = o; o += align64l((long)kRowsSumGroups * kG);
+    g.tmp = o; o += 4 * align64l((long)kRowsSumGroups * kG);      // one per bias reduction of the batched sum
     g.whhT2 = o; o += (long)kH * kG;
     g.wihT2 = o; o += (long)kH * kG;
     g.dGi2 = o; o += align64l((long)B * S * kG);
@@ -933,11 +933,13 @@ extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* co
         const float* yl[2] = {saved + g.Y[0], y};
         const float* h0l[2] = {h0, h0 ? h0 + (long)B * kH : nullptr};
         int rc = 0;
+        {   // (3H,H) -> (H,3H), the four weight matrices in one launch
+            const float* tin[4] = {params[1], params[0], params[5], params[4]};
+            float* tout[4] = {whhT_[0], wihT_[0], whhT_[1], wihT_[1]};
+            rc = transpose_batch(tin, tout, 4, kG, kH, st);
+            if (rc) return rc;
+        }
         for (int l = 0; l < 2; ++l) {
-            rc = transpose(params[4 * l + 1], whhT_[l], kG, kH, st);
-            if (rc) return rc;
-            rc = transpose(params[4 * l], wihT_[l], kG, kH, st);
-            if (rc) return rc;
             p.whhT[l] = whhT_[l];
             p.Z[l] = saved + g.Z[l];
             p.dGi[l] = dGi_[l]; p.dGh[l] = dGh_[l]; p.DH[l] = DH_[l];
@@ -958,6 +960,11 @@ extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* co
             for (int s = 0; s <= S; ++s) hipLaunchKernelGGL(gru2_bwd_kernel, grid, dim3(512), 0, st, p, s);
         }
         CPC_LAUNCH_CHECK();
+        const long tmp1 = align64l((long)kRowsSumGroups * kG);
+        const RowsSumJob jobs[4] = {{dGi_[0], M, kG, scratch + g.tmp, grads[2]},
+                                    {dGh_[0], M, kG, scratch + g.tmp + tmp1, grads[3]},
+                                    {dGi_[1], M, kG, scratch + g.tmp + 2 * tmp1, grads[6]},
+                                    {dGh_[1], M, kG, scratch + g.tmp + 3 * tmp1, grads[7]}};
         for (int l = 0; l < 2; ++l) {
             const float* in = l == 0 ? x : saved + g.Y[0];
             const float* out = yl[l];
@@ -976,11 +983,9 @@ extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* co
                 rc = tn_gemm(g0, kG, plain_rows(h0l[l], B, kH), kH, scratch + g.part, grads[4 * l + 1], 1, st);
                 if (rc) return rc;
             }
-            rc = rows_sum(dGi_[l], M, kG, scratch + g.tmp, grads[4 * l + 2], st);
-            if (rc) return rc;
-            rc = rows_sum(dGh_[l], M, kG, scratch + g.tmp, grads[4 * l + 3], st);
-            if (rc) return rc;
         }
+        rc = rows_sum_multi(jobs, 4, st);                // the four bias gradients in two launches
+        if (rc) return rc;
         // dx = dGi0 . W_ih0
         return nt_gemm(plain_rows(dGi_[0], M, kG), wihT_[0], kG, nullptr, dx, kH, kH, kG, st);
     }

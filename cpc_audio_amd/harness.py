@@ -107,6 +107,7 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
     device = next(model.parameters()).device
     sum_loss = sum_acc = None
     n_iter, t0, n_ex = 0, time.perf_counter(), 0
+    ones = None
     for step, (batch, label) in enumerate(loader):
         batch, label = _to_device(batch, device), _to_device(label, device)
         n_ex += batch.size(0)
@@ -116,7 +117,9 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
         try:
             c_feature, encoded, label = model(batch, label)
             all_losses, all_acc = criterion(c_feature, encoded, label)
-            all_losses.sum().backward()                   # train.py:85-87
+            if ones is None or ones.shape != all_losses.shape or ones.device != all_losses.device:
+                ones = torch.ones_like(all_losses)
+            torch.autograd.backward([all_losses], [ones])  # = all_losses.sum().backward() (train.py:85-87), 3 kernels less
             ops.wait_side_stream()
         finally:
             ops.OVERLAP_DZ = False

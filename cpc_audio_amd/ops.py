@@ -161,6 +161,7 @@ class GruFunction(torch.autograd.Function):
         ctx.h0 = h0c
         ctx.dims = (B, S, nl, sizes[2])
         ctx.mark_non_differentiable(hN)
+        ctx.set_materialize_grads(False)       # no zero-filled gradient for hN on every step
         return y, hN
 
     @staticmethod
@@ -168,7 +169,7 @@ class GruFunction(torch.autograd.Function):
         lib = _lib.get()
         x, saved, y, *params = ctx.saved_tensors
         B, S, nl, nscr = ctx.dims
-        dy = dy.contiguous()
+        dy = torch.zeros_like(y) if dy is None else dy.contiguous()
         with torch.cuda.device(x.device):
             scratch = torch.empty(nscr, device=x.device, dtype=torch.float32)
             dx = torch.empty_like(x)
@@ -240,6 +241,7 @@ class InfoNCEFunction(torch.autograd.Function):
                                           _p(acc), B, S, K, N, _stream()), "nce_forward")
         ctx.save_for_backward(c, z, wall, ext, saved, perm, row_ptr)
         ctx.dims = (B, S, K, N, sizes[2])
+        ctx.set_materialize_grads(False)       # no zero-filled gradient for the accuracies
         ctx.heads = list(heads) if heads is not None else None
         if ctx.heads is not None and (len(ctx.heads) != K or any(h.shape != (_HID, _HID) for h in ctx.heads)):
             raise ValueError("InfoNCEFunction: heads must be the K (256,256) weights stacked in wall")
@@ -251,7 +253,7 @@ class InfoNCEFunction(torch.autograd.Function):
         lib = _lib.get()
         c, z, wall, ext, saved, perm, row_ptr = ctx.saved_tensors
         B, S, K, N, nscr = ctx.dims
-        gloss = gloss.contiguous()
+        gloss = torch.zeros(K, device=c.device) if gloss is None else gloss.contiguous()
         with torch.cuda.device(c.device):
             scratch = torch.empty(nscr, device=c.device, dtype=torch.float32)
             dc, dz, dwall = torch.empty_like(c), torch.empty_like(z), torch.empty_like(wall)
@@ -329,6 +331,7 @@ class InfoNCEScoresFunction(torch.autograd.Function):
                                                  B, S, K, N, _stream()), "nce_scores_forward")
         ctx.save_for_backward(pred, z, ext, saved, perm, row_ptr)
         ctx.dims = (B, S, K, N, sizes[2])
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(acc)
         return losses, acc
 
@@ -337,7 +340,7 @@ class InfoNCEScoresFunction(torch.autograd.Function):
         lib = _lib.get()
         pred, z, ext, saved, perm, row_ptr = ctx.saved_tensors
         B, S, K, N, nscr = ctx.dims
-        gloss = gloss.contiguous()
+        gloss = torch.zeros(K, device=z.device) if gloss is None else gloss.contiguous()
         with torch.cuda.device(z.device):
             scratch = torch.empty(nscr, device=z.device, dtype=torch.float32)
             dpred, dz = torch.empty_like(pred), torch.empty_like(z)

@@ -45,6 +45,12 @@ class Trainer:
         enc = {id(p) for p in model.gEncoder.parameters()} if hasattr(model, "gEncoder") else set()
         self.allreduce = FlatGradAllReduce(params, early=[p for p in params if id(p) not in enc] if enc else None)
 
+    def _ones_like(self, t):
+        o = getattr(self, "_ones", None)
+        if o is None or o.shape != t.shape or o.device != t.device or o.dtype != t.dtype:
+            o = self._ones = torch.ones_like(t)
+        return o
+
     def step(self, batchData, label, negatives=None):
         from . import ops
         ops.OVERLAP_DZ = True        # this loop's graph has no foreign consumer of dz between criterion and encoder
@@ -52,8 +58,8 @@ class Trainer:
         try:
             c_feature, encoded_data, label = self.model(batchData, label)
             allLosses, allAcc = self.criterion(c_feature, encoded_data, label, negatives=negatives)
-            totLoss = allLosses.sum()
-            totLoss.backward()
+            # allLosses.sum().backward() (train.py:85-87) without the sum / fill / expand kernels: d sum / d loss_k = 1
+            torch.autograd.backward([allLosses], [self._ones_like(allLosses)])
             ops.wait_side_stream()
         finally:
             ops.OVERLAP_DZ = False
