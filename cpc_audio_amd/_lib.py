@@ -54,6 +54,7 @@ SIGNATURES = {
     "cpc_nce_backward_streams": (_I, [_P] * 12 + [_I, _I, _I, _I, _P, _P]),
     "cpc_nce_backward_dz": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward_dwall": (_I, [_P] * 3 + [_I, _I, _I, _I, _P]),
+    "cpc_adam_step": (_I, [_P] * 5 + [_I] + [ctypes.c_double] * 6 + [_P]),
 }
 
 

@@ -8,6 +8,7 @@ import torch
 from .criterion import CPCUnsupersivedCriterion
 from .dist import FlatGradAllReduce
 from .model import CPCAR, CPCEncoder, CPCModel
+from .optim import Adam
 
 
 def build_model(hiddenEncoder=256, hiddenGar=256, nLevelsGRU=2, keepHidden=False, reverse=False, arMode="GRU",
@@ -40,8 +41,7 @@ class Trainer:
     def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8):
         self.model, self.criterion = model, criterion
         params = list(criterion.parameters()) + list(model.parameters())      # train.py:332
-        fused = all(p.is_cuda for p in params)     # one fused multi-tensor kernel on the GPU
-        self.optimizer = torch.optim.Adam(params, lr=lr, betas=betas, eps=eps, fused=fused)  # train.py:335-337
+        self.optimizer = Adam(params, lr=lr, betas=betas, eps=eps)      # train.py:335-337; one launch per step on the GPU
         enc = {id(p) for p in model.gEncoder.parameters()} if hasattr(model, "gEncoder") else set()
         self.allreduce = FlatGradAllReduce(params, early=[p for p in params if id(p) not in enc] if enc else None)
 

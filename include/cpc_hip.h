@@ -208,6 +208,16 @@ int cpc_nce_scores_backward(const float* pred, const float* z, const int* ext, c
                             const int* row_ptr, const float* saved, const float* gloss, float* scratch,
                             float* dpred, float* dz, int B, int S, int K, int N, void* stream);
 
+/* ---- optimiser -------------------------------------------------------------------------------------------------
+ * One Adam step (cpc/train.py:335-337: torch.optim.Adam(params, lr, betas, eps); :88-89 optimizer.step()) on n dense
+ * fp32 tensors in one launch: exp_avg <- lerp(exp_avg, grad, 1 - beta1), exp_avg_sq <- beta2 exp_avg_sq + (1 - beta2)
+ * grad^2, param <- param - (lr / bias_correction1) exp_avg / (sqrt(exp_avg_sq) / bias_correction2_sqrt + eps), all in
+ * place.  bias_correction1 = 1 - beta1^step, bias_correction2_sqrt = sqrt(1 - beta2^step), step counted from 1.
+ * No weight decay / amsgrad / maximize (the reference uses none). */
+int cpc_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                  const long* numel, int n, double lr, double beta1, double beta2, double eps, double bias_correction1,
+                  double bias_correction2_sqrt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,85 @@
+"""cpc_adam_step behind cpc_audio_amd.optim.Adam against torch.optim.Adam (the reference's optimiser,
+cpc/train.py:335-337) on the same gradients: same update rule, fp32; tolerance 2e-6 relative to lr-sized steps."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    return torch.device("cuda:0")
+
+
+def _params(dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(256, 256, 8), (256,), (3, 5, 7), (1,), (768, 256), (4099,), (256, 1, 10)]
+    return [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in shapes]
+
+
+def test_adam_matches_torch_adam_over_steps():
+    dev = _dev()
+    from cpc_audio_amd.optim import Adam
+    a, b = _params(dev, 3), _params(dev, 3)
+    oa = Adam(a, lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+    ob = torch.optim.Adam(b, lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+    g = torch.Generator().manual_seed(9)
+    for step in range(12):
+        for pa, pb in zip(a, b):
+            # gradients of very different scale, some exactly zero
+            gr = torch.randn(pa.shape, generator=g) * (10.0 ** ((step % 5) - 3))
+            gr[gr.abs() < 1e-4 * gr.abs().max()] = 0.0
+            pa.grad = gr.to(dev)
+            pb.grad = gr.to(dev).clone()
+        oa.step()
+        ob.step()
+    for pa, pb in zip(a, b):
+        # roundings of p itself (ulp of |p|) dominate: the update is lr-sized
+        assert (pa - pb).abs().max().item() <= 2.5e-7 * max(1.0, pb.abs().max().item())
+        sa, sb = oa.state[pa], ob.state[pb]
+        assert float(sa["step"]) == float(sb["step"]) == 12
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-6 * sb["exp_avg"].abs().max().item())
+        assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-6 * sb["exp_avg_sq"].abs().max().item())
+
+
+def test_adam_state_dict_round_trips_with_torch_adam():
+    dev = _dev()
+    from cpc_audio_amd.optim import Adam
+    a, b = _params(dev, 4), _params(dev, 4)
+    oa = Adam(a, lr=1e-3)
+    for p in a:
+        p.grad = torch.ones_like(p)
+    oa.step()
+    ob = torch.optim.Adam(b, lr=1e-3)
+    ob.load_state_dict(copy.deepcopy(oa.state_dict()))     # ours -> torch (load_state_dict keeps the tensors it is given)
+    oc = Adam(_params(dev, 4), lr=1e-3)
+    oc.load_state_dict(copy.deepcopy(ob.state_dict()))     # torch -> ours
+    for pa, pc in zip(a, oc.param_groups[0]["params"]):
+        pc.data.copy_(pa.data)
+        pa.grad = torch.full_like(pa, 0.5)
+        pc.grad = torch.full_like(pc, 0.5)
+    oa.step()
+    oc.step()
+    for pa, pc in zip(a, oc.param_groups[0]["params"]):
+        assert torch.equal(pa, pc)
+        assert float(oc.state[pc]["step"]) == 2
+
+
+def test_adam_skips_parameters_without_gradient_and_other_groups_use_torch():
+    dev = _dev()
+    from cpc_audio_amd.optim import Adam
+    p1, p2, p3 = (torch.nn.Parameter(torch.ones(10, device=dev)) for _ in range(3))
+    opt = Adam([{"params": [p1, p2]}, {"params": [p3], "weight_decay": 0.1}], lr=1e-2)
+    p1.grad = torch.ones_like(p1)
+    p3.grad = torch.ones_like(p3)
+    opt.step()
+    assert torch.equal(p2, torch.ones_like(p2)) and len(opt.state[p2]) == 0
+    assert (p1 - 0.99).abs().max().item() < 1e-6
+    q = torch.nn.Parameter(torch.ones(10, device=dev))
+    ref = torch.optim.Adam([q], lr=1e-2, weight_decay=0.1)
+    q.grad = torch.ones_like(q)
+    ref.step()
+    assert torch.allclose(p3, q)
