@@ -22,6 +22,10 @@ void tn_gemm_plan(int M, int N1, int N2, int* splits, int* rows);
 long tn_gemm_part_floats(int M, int N1, int N2);
 int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, float* C, int accumulate,
             hipStream_t st);
+// nprob <= 4 TN problems with equal M, N1, N2 in one GEMM launch + one reduction; part: tn_gemm_batch_part_floats
+long tn_gemm_batch_part_floats(int nprob, int M, int N1, int N2);
+int tn_gemm_batch(int nprob, const RowMap* am, int N1, const RowMap* bm, int N2, float* part, float* const* C,
+                  int accumulate, hipStream_t st);
 // out[Cn][R] = in[R][Cn]^T
 int transpose(const float* in, float* out, int R, int Cn, hipStream_t st);
 // n <= 4 matrices of one shape in one launch

@@ -83,6 +83,49 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restri
     C[idx] = s;
 }
 
+// Up to 4 TN problems of one shape (same M, N1, N2) in one launch: the four weight gradients of a two-layer GRU are
+// 3.2 GFLOP each -- alone, each needs 32 row splits to fill the chip and spends its time in prologues and in its
+// own split reduction.  Together 8 splits do, with 4x the rows per workgroup.
+struct TnBatch { RowMap a[4], b[4]; float* out[4]; };
+template <class TnG>
+__global__ __launch_bounds__(256) void tn_gemm_batch_kernel(TnBatch bt, int N1, int N2, int rows_per_split, int S,
+                                                            float* __restrict__ part, long zstride) {
+    __shared__ float smem[TnG::SMEM_FLOATS];
+    const int tn2 = N2 / 128, T = (N1 / 128) * tn2;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = slot % T, z = (slot / T) * 8 + xcd;
+    if (z >= S) return;                                  // block-uniform
+    const int q = blockIdx.y;
+    const RowMap& am = bt.a[q];
+    const RowMap& bm = bt.b[q];
+    const int n0 = (tile % tn2) * 128, c0 = (tile / tn2) * 128;
+    const int mbeg = z * rows_per_split;
+    const int mend = min(am.M, mbeg + rows_per_split);
+    f32x16 acc[TnG::TM][TnG::TN];
+    zero_acc(acc);
+    TnG::run(acc, am, c0, bm, n0, mbeg, mend, smem);
+    float* out = part + ((long)q * S + z) * zstride;
+#pragma unroll
+    for (int tm = 0; tm < TnG::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = c0 + TnG::c_row(tm, r);
+#pragma unroll
+            for (int tn = 0; tn < TnG::TN; ++tn)
+                out[(long)row * N2 + n0 + TnG::c_col(tn)] = acc[tm][tn][r];
+        }
+}
+__global__ __launch_bounds__(256) void split_reduce_batch_kernel(const float* __restrict__ part, int S, long n,
+                                                                 TnBatch bt, int accumulate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    float* __restrict__ C = bt.out[blockIdx.y];
+    const float* __restrict__ p = part + (long)blockIdx.y * S * n;
+    float s = accumulate ? C[idx] : 0.f;
+    for (int z = 0; z < S; ++z) s += p[(long)z * n + idx];
+    C[idx] = s;
+}
+
 // out[c][r] = in[r][c]
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         int R, int Cn) {
@@ -175,6 +218,46 @@ int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, flo
     else
         hipLaunchKernelGGL((tn_gemm_kernel<TnG>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n);
     hipLaunchKernelGGL(split_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, S, n, C, accumulate);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// Splits of the batched plan: aim at ~768 workgroups over all problems, at least 256 rows each.
+void tn_gemm_batch_plan(int nprob, int M, int N1, int N2, int* splits, int* rows) {
+    const int tiles = nprob * (N1 / 128) * (N2 / 128);
+    int S = cdiv(768, tiles > 0 ? tiles : 1);
+    int r = cdiv(cdiv(M, S), 32) * 32;
+    if (r < 256) r = 256;
+    S = cdiv(M, r);
+    if (S < 1) S = 1;
+    *splits = S;
+    *rows = r;
+}
+
+long tn_gemm_batch_part_floats(int nprob, int M, int N1, int N2) {
+    int S, rows;
+    tn_gemm_batch_plan(nprob, M, N1, N2, &S, &rows);
+    return (long)nprob * S * N1 * N2;
+}
+
+int tn_gemm_batch(int nprob, const RowMap* am, int N1, const RowMap* bm, int N2, float* part, float* const* C,
+                  int accumulate, hipStream_t st) {
+    if (nprob <= 0 || nprob > 4 || N1 % 128 != 0 || N2 % 128 != 0) return CPC_ERR_SHAPE;
+    const int M = am[0].M;
+    for (int q = 0; q < nprob; ++q)
+        if (am[q].M != M || bm[q].M != M) return CPC_ERR_SHAPE;
+    if (M <= 0) return CPC_ERR_SHAPE;
+    const long n = (long)N1 * N2;
+    TnBatch bt;
+    for (int q = 0; q < 4; ++q) { const int u = q < nprob ? q : 0; bt.a[q] = am[u]; bt.b[q] = bm[u]; bt.out[q] = C[u]; }
+    int S, rows;
+    tn_gemm_batch_plan(nprob, M, N1, N2, &S, &rows);
+    const dim3 grid(8 * (N1 / 128) * (N2 / 128) * cdiv(S, 8), nprob);
+    if (g_mfma_mode != 0)
+        hipLaunchKernelGGL((tn_gemm_batch_kernel<TnGX3>), grid, dim3(256), 0, st, bt, N1, N2, rows, S, part, n);
+    else
+        hipLaunchKernelGGL((tn_gemm_batch_kernel<TnG>), grid, dim3(256), 0, st, bt, N1, N2, rows, S, part, n);
+    hipLaunchKernelGGL(split_reduce_batch_kernel, dim3(cdiv(n, 256), nprob), dim3(256), 0, st, part, S, n, bt, accumulate);
     CPC_LAUNCH_CHECK();
     return 0;
 }

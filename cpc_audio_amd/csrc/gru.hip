@@ -806,7 +806,7 @@ static bool gru_layout(int B, int S, int nl, GruLayout& g) {
     g.DH = o; o += bsh;
     g.mid[0] = o; o += bsh;
     g.mid[1] = o; o += bsh;
-    g.part = o; o += align64l(tn_gemm_part_floats(B * S, kG, kH));
+    g.part = o; o += align64l(std::max(tn_gemm_part_floats(B * S, kG, kH), tn_gemm_batch_part_floats(4, B * S, kG, kH)));
     g.tmp = o; o += 4 * align64l((long)kRowsSumGroups * kG);      // one per bias reduction of the batched sum
     g.whhT2 = o; o += (long)kH * kG;
     g.wihT2 = o; o += (long)kH * kG;
@@ -912,9 +912,50 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
 
 // dy (B,S,256) -> dx (B,S,256) and grads[4*nl] (same order as params; overwritten).
 // h0 receives no gradient (the reference detaches the carried state, cpc/model.py:194-198).
+// Floats of the coefficient arrays of the two-layer backward (0 when nl != 2), see cpc_gru_backward_coef.
+extern "C" long cpc_gru_coef_floats(int B, int S, int nl) {
+    GruLayout g;
+    if (nl != 2 || !gru_layout(B, S, nl, g)) return 0;
+    return 8 * g.frag_floats;
+}
+
+static void launch_gru_coef(const GruLayout& g, const float* h0, const float* saved, const float* y, float* coef,
+                            int B, int S, hipStream_t st) {
+    const float* yl[2] = {saved + g.Y[0], y};
+    const float* h0l[2] = {h0, h0 ? h0 + (long)B * kH : nullptr};
+    for (int l = 0; l < 2; ++l) {
+        float* c = coef + 4 * l * g.frag_floats;
+        hipLaunchKernelGGL(gru_bwd_coef_kernel, dim3(cdiv((long)cdiv(B, 16) * 16 * S * 64, 256)), dim3(256), 0, st,
+                           saved + g.R[l], saved + g.Z[l], saved + g.N[l], saved + g.GHN[l], yl[l], h0l[l], c,
+                           c + g.frag_floats, c + 2 * g.frag_floats, c + 3 * g.frag_floats, B, S);
+    }
+}
+
+// Everything in the two-layer backward that depends on the forward pass only (gru_bwd_coef_kernel), into `coef`
+// (cpc_gru_coef_floats floats): a caller may run this any time after the forward, on any stream, and hand the result
+// to cpc_gru_backward_with_coef -- it takes 47 us of HBM streaming off the path between the criterion and the
+// recurrence.
+extern "C" int cpc_gru_backward_coef(const float* h0, const float* saved, const float* y, float* coef, int B, int S,
+                                     int nl, void* stream) {
+    GruLayout g;
+    CPC_RETURN_IF(nl != 2 || !gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!saved || !y || !coef, CPC_ERR_ARG);
+    launch_gru_coef(g, h0, saved, y, coef, B, S, (hipStream_t)stream);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* const* params,
                                 const float* saved, const float* y, const float* dy, float* scratch,
                                 float* dx, float* const* grads, int B, int S, int nl, void* stream) {
+    return cpc_gru_backward_with_coef(x, h0, params, saved, y, dy, nullptr, scratch, dx, grads, B, S, nl, stream);
+}
+
+// coef: NULL (computed here) or the output of cpc_gru_backward_coef for the same forward pass (nl == 2 only).
+extern "C" int cpc_gru_backward_with_coef(const float* x, const float* h0, const float* const* params,
+                                          const float* saved, const float* y, const float* dy, const float* coef,
+                                          float* scratch, float* dx, float* const* grads, int B, int S, int nl,
+                                          void* stream) {
     GruLayout g;
     CPC_RETURN_IF(!gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!x || !params || !saved || !scratch || !y || !dy || !dx || !grads, CPC_ERR_ARG);
@@ -943,13 +984,11 @@ extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* co
             p.whhT[l] = whhT_[l];
             p.Z[l] = saved + g.Z[l];
             p.dGi[l] = dGi_[l]; p.dGh[l] = dGh_[l]; p.DH[l] = DH_[l];
-            float* c = scratch + g.coef + 4 * l * g.frag_floats;
+            const float* c = (coef ? coef : scratch + g.coef) + 4 * l * g.frag_floats;
             p.cr[l] = c; p.cz[l] = c + g.frag_floats; p.cnh[l] = c + 2 * g.frag_floats; p.cni[l] = c + 3 * g.frag_floats;
             p.xdh[l] = scratch + g.xdh + l * g.frag_floats;
-            hipLaunchKernelGGL(gru_bwd_coef_kernel, dim3(cdiv((long)cdiv(B, 16) * 16 * S * 64, 256)), dim3(256), 0, st, saved + g.R[l],
-                               saved + g.Z[l], saved + g.N[l], saved + g.GHN[l], yl[l], h0l[l], c, c + g.frag_floats,
-                               c + 2 * g.frag_floats, c + 3 * g.frag_floats, B, S);
         }
+        if (!coef) launch_gru_coef(g, h0, saved, y, scratch + g.coef, B, S, st);
         p.wih1T = wihT_[1];
         const int nblocks = 32 * cdiv(B, 16);
         if (g_gru_mode == 1 && fits_resident(gru2_persist_bwd_kernel, nblocks)) {
@@ -965,18 +1004,26 @@ extern "C" int cpc_gru_backward(const float* x, const float* h0, const float* co
                                     {dGh_[0], M, kG, scratch + g.tmp + tmp1, grads[3]},
                                     {dGi_[1], M, kG, scratch + g.tmp + 2 * tmp1, grads[6]},
                                     {dGh_[1], M, kG, scratch + g.tmp + 3 * tmp1, grads[7]}};
+        {   // the four weight gradients dW_ih^l = dGi_l^T . in_l, dW_hh^l = dGh_l^T . h^l_{t-1} as one batched GEMM
+            RowMap am[4], bm[4];
+            float* Cq[4];
+            for (int l = 0; l < 2; ++l) {
+                const float* in = l == 0 ? x : saved + g.Y[0];
+                am[2 * l] = plain_rows(dGi_[l], M, kG);
+                bm[2 * l] = plain_rows(in, M, kH);
+                Cq[2 * l] = grads[4 * l];
+                RowMap hm;                             // h_{t-1} rows: y[b, t-1] (zero row at t = 0; h0 term below)
+                hm.base = yl[l]; hm.R = S; hm.bstride = (long)S * kH; hm.rstride = kH; hm.off = -kH;
+                hm.tmul = 1; hm.tadd = -1; hm.Lin = S; hm.M = M;
+                am[2 * l + 1] = plain_rows(dGh_[l], M, kG);
+                bm[2 * l + 1] = hm;
+                Cq[2 * l + 1] = grads[4 * l + 1];
+            }
+            rc = tn_gemm_batch(4, am, kG, bm, kH, scratch + g.part, Cq, 0, st);
+            if (rc) return rc;
+        }
         for (int l = 0; l < 2; ++l) {
-            const float* in = l == 0 ? x : saved + g.Y[0];
-            const float* out = yl[l];
-            const RowMap gim = plain_rows(dGi_[l], M, kG), ghm = plain_rows(dGh_[l], M, kG);
-            rc = tn_gemm(gim, kG, plain_rows(in, M, kH), kH, scratch + g.part, grads[4 * l], 0, st);
-            if (rc) return rc;
-            RowMap hm;
-            hm.base = out; hm.R = S; hm.bstride = (long)S * kH; hm.rstride = kH; hm.off = -kH;
-            hm.tmul = 1; hm.tadd = -1; hm.Lin = S; hm.M = M;
-            rc = tn_gemm(ghm, kG, hm, kH, scratch + g.part, grads[4 * l + 1], 0, st);
-            if (rc) return rc;
-            if (h0l[l]) {
+            if (h0l[l]) {                              // + dGh[:,0,:]^T . h0
                 RowMap g0;
                 g0.base = dGh_[l]; g0.R = 1; g0.bstride = (long)S * kG; g0.rstride = 0; g0.off = 0;
                 g0.tmul = 0; g0.tadd = 0; g0.Lin = 0x7fffffff; g0.M = B;

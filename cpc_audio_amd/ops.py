@@ -53,10 +53,12 @@ pre_encoder_backward = []   # callables run when the encoder's backward starts: 
                             # final (or queued on the side stream) by then -- dist.FlatGradAllReduce.begin hooks here
 
 
-def _side_stream(device):
-    st = _side_streams.get(device)
+def _side_stream(device, which=0):
+    """which = 0: the criterion's stream (negative draws, dz path, head gradient, early all-reduce bucket);
+    1: forward-only preparation of the recurrence's backward (it must not queue in front of the negative draws)."""
+    st = _side_streams.get((device, which))
     if st is None:
-        st = _side_streams[device] = torch.cuda.Stream(device=device)
+        st = _side_streams[(device, which)] = torch.cuda.Stream(device=device)
     return st
 
 
@@ -157,6 +159,24 @@ class GruFunction(torch.autograd.Function):
             hN = torch.empty(nl, B, _HID, device=x.device, dtype=torch.float32)
             lib.check(lib.cpc_gru_forward(_p(x), _p(h0c), _ptrs(params), _p(saved), _p(scratch), _p(y), _p(hN),
                                           B, S, nl, _stream()), "gru_forward")
+            # train loops (OVERLAP_DZ): the forward-only part of the two-layer backward runs now, on the side stream,
+            # beside the criterion's forward, instead of between the criterion's backward and the recurrence
+            coef = None
+            if OVERLAP_DZ and nl == 2 and any(ctx.needs_input_grad):
+                ncoef = lib.cpc_gru_coef_floats(B, S, nl)
+                if ncoef > 0:
+                    coef = torch.empty(ncoef, device=x.device, dtype=torch.float32)
+                    main, side = torch.cuda.current_stream(), _side_stream(x.device, 1)
+                    done = torch.cuda.Event()
+                    done.record(main)
+                    side.wait_event(done)
+                    lib.check(lib.cpc_gru_backward_coef(_p(h0c), _p(saved), _p(y), _p(coef), B, S, nl,
+                                                        side.cuda_stream), "gru_backward_coef")
+                    for t in (coef, saved, y) + (() if h0c is None else (h0c,)):
+                        t.record_stream(side)
+                    ctx.coef_ready = torch.cuda.Event()
+                    ctx.coef_ready.record(side)
+        ctx.coef = coef
         ctx.save_for_backward(x, saved, y, *params)
         ctx.h0 = h0c
         ctx.dims = (B, S, nl, sizes[2])
@@ -174,8 +194,11 @@ class GruFunction(torch.autograd.Function):
             scratch = torch.empty(nscr, device=x.device, dtype=torch.float32)
             dx = torch.empty_like(x)
             grads = [torch.empty_like(p) for p in params]
-            lib.check(lib.cpc_gru_backward(_p(x), _p(ctx.h0), _ptrs(params), _p(saved), _p(y), _p(dy),
-                                           _p(scratch), _p(dx), _ptrs(grads), B, S, nl, _stream()), "gru_backward")
+            if ctx.coef is not None:
+                torch.cuda.current_stream().wait_event(ctx.coef_ready)
+            lib.check(lib.cpc_gru_backward_with_coef(_p(x), _p(ctx.h0), _ptrs(params), _p(saved), _p(y), _p(dy),
+                                                     _p(ctx.coef), _p(scratch), _p(dx), _ptrs(grads), B, S, nl,
+                                                     _stream()), "gru_backward")
         wait_side_stream(final=False)  # starts the criterion's deferred dz path beside the recurrence just launched, and makes
         #                         this stream wait for it: autograd adds dx to that dz next
         return (dx, None, *grads)

@@ -133,6 +133,17 @@ int cpc_gru_backward(const float* x, const float* h0, const float* const* params
                      const float* saved, const float* y, const float* dy, float* scratch, float* dx,
                      float* const* grads, int B, int S, int nl, void* stream);
 
+/* The part of the two-layer backward that depends on the forward pass only (per-step gate-derivative coefficients,
+ * cpc_gru_coef_floats(B,S,nl) floats; 0 unless nl == 2).  cpc_gru_backward_coef may run any time after the forward
+ * on any stream; cpc_gru_backward_with_coef(coef != NULL) then skips that work (coef == NULL: same as
+ * cpc_gru_backward). */
+long cpc_gru_coef_floats(int B, int S, int nl);
+int cpc_gru_backward_coef(const float* h0, const float* saved, const float* y, float* coef, int B, int S, int nl,
+                          void* stream);
+int cpc_gru_backward_with_coef(const float* x, const float* h0, const float* const* params, const float* saved,
+                               const float* y, const float* dy, const float* coef, float* scratch, float* dx,
+                               float* const* grads, int B, int S, int nl, void* stream);
+
 /* ---------------------------------------------------------------- transformer layer ----
  * One TransformerLayer of cpc/transformers.py:103-111 (buildTransformerAR, :130-139), d_model 256, 8 heads,
  * d_ff 2048, sequence S <= 128, dropout not applied.  Used as the auto-regressive network (--arMode
