@@ -136,6 +136,8 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             # the draws and their index preparation depend on nothing the GPU is still computing (encoder, AR): issued
             # on the side stream they run beside the latency-bound recurrence instead of after it
             main, side = torch.cuda.current_stream(), ops._side_stream(cFeature.device)
+            # (holding them back until the recurrence starts was measured: 4.187 vs 4.162 ms/step -- they disturb its
+            # hand-over polling more than they cost beside the first conv layers, where the host-side lead puts them)
             with torch.cuda.stream(side):
                 negatives = self.drawNegatives(batchSize, seqSize, windowSize, cFeature.device)
                 ext, perm, row_ptr = prepare_negatives(negatives[0], negatives[1], batchSize, seqSize, self.nPredicts,
