@@ -522,6 +522,53 @@ __device__ __forceinline__ void mfma_gates(f32x4 (&acc)[3], const float4 (&a)[NI
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii], jj), f4c(bw[g][ii], jj), acc[g], 0, 0, 0);
 }
 
+// The same products on the 16-bit matrix pipe: both operands as two fp16 pieces of x * s (s a power of two, see
+// gemm_tile.h), three v_mfma_f32_16x16x32_f16 per product (hh + hl + lh; the dropped ll term is <= 2^-22 of the
+// product) instead of eight exact-f32 16x16x4 issues per 8 k.  |h| < 1 for every recurrent operand (a convex
+// combination of tanh outputs when h0 is absent), so sa is a constant; sb comes from the wave's own weight slice.
+// Slot e of the 8-k operand is element (e & 3) of fragment (e >> 2), for A and B alike.
+struct H2Frag { f16x8 h, l; };
+__device__ __forceinline__ H2Frag split2h_8(const float4& u, const float4& v, float s) {
+    const float x[8] = {u.x * s, u.y * s, u.z * s, u.w * s, v.x * s, v.y * s, v.z * s, v.w * s};
+    H2Frag f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 hi = (_Float16)x[e];
+        f.h[e] = hi;
+        f.l[e] = (_Float16)(x[e] - (float)hi);
+    }
+    return f;
+}
+template <int NII>
+__device__ __forceinline__ float split_gate_weights(const float4 (&bw)[3][NII], H2Frag (&bh)[3][NII / 2]) {
+    float m = 0.f;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ii = 0; ii < NII; ++ii)
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(bw[g][ii].x), fabsf(bw[g][ii].y))), fmaxf(fabsf(bw[g][ii].z), fabsf(bw[g][ii].w)));
+    const float sb = scale_for_amax(wave_max(m));
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int pr = 0; pr < NII / 2; ++pr) bh[g][pr] = split2h_8(bw[g][2 * pr], bw[g][2 * pr + 1], sb);
+    return sb;
+}
+template <int NII>
+__device__ __forceinline__ void mfma_gates_h2(f32x4 (&acc)[3], const float4 (&a)[NII], const H2Frag (&bh)[3][NII / 2],
+                                              float sa) {
+#pragma unroll
+    for (int pr = 0; pr < NII / 2; ++pr) {
+        const H2Frag af = split2h_8(a[2 * pr], a[2 * pr + 1], sa);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af.h, bh[g][pr].h, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af.h, bh[g][pr].l, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af.l, bh[g][pr].h, acc[g], 0, 0, 0);
+    }
+}
+
 struct PersistIds {
     int layer, j0, b0, tile, ntiles;
     __device__ PersistIds() {
@@ -542,7 +589,7 @@ struct PersistIds {
 constexpr int kPersistThreads = 768;
 constexpr int kMfmaWaves = 8;
 
-template <int LAYER>
+template <int LAYER, bool H2>
 __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8][3][256], const PersistIds& id) {
     const int j0 = id.j0, b0 = id.b0;
     constexpr int NII = LAYER == 0 ? 2 : 4;
@@ -557,6 +604,12 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
         const int koff = LAYER == 0 ? 32 * w + 4 * kq : 64 * (w & 3) + 4 * kq;
         float4 bw[3][NII];
         load_gate_weights<NII>(bw, recurrent ? p.whh[LAYER] : p.wih1, j0 + i, koff);
+        H2Frag bh[3][NII / 2];
+        float sa = 1.f, inv = 1.f;
+        if constexpr (H2) {
+            sa = scale_for_amax(1.0f);
+            inv = 1.0f / (sa * split_gate_weights<NII>(bw, bh));      // powers of two: exact
+        }
         const float* __restrict__ xsrc = (recurrent ? p.xh[LAYER] : p.xh[0]) + xpos(i, koff);
         int budget = kSpinLimit;
         for (int t = 0; t < S; ++t) {
@@ -571,7 +624,13 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
             f32x4 acc[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            mfma_gates<NII>(acc, a, bw);
+            if constexpr (H2) {
+                mfma_gates_h2<NII>(acc, a, bh, sa);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] *= inv;
+            } else {
+                mfma_gates<NII>(acc, a, bw);
+            }
             float (&pt)[8][3][256] = part[t & 1];
 #pragma unroll
             for (int g = 0; g < 3; ++g)
@@ -641,8 +700,15 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
 __global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_kernel(Gru2Fwd p) {
     __shared__ float part[2][8][3][256];
     const PersistIds id;
-    if (id.layer == 0) persist_fwd<0>(p, part, id);
-    else persist_fwd<1>(p, part, id);
+    if (id.layer == 0) persist_fwd<0, false>(p, part, id);
+    else persist_fwd<1, false>(p, part, id);
+}
+// the same with the recurrent products on the fp16 pipe (two-piece split operands); h0 must be absent (|h| < 1)
+__global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_h2_kernel(Gru2Fwd p) {
+    __shared__ float part[2][8][3][256];
+    const PersistIds id;
+    if (id.layer == 0) persist_fwd<0, true>(p, part, id);
+    else persist_fwd<1, true>(p, part, id);
 }
 
 template <int NU>
@@ -661,6 +727,9 @@ __device__ __forceinline__ void load_coef(float4 (&cf)[NU][3], const float* __re
 // Backward hand-over carries dh (256 values per row), not the 768 gate gradients: the MFMA waves rebuild
 // their operand fragments as dh * coefficient (the very products the gate threads store to dGi / dGh),
 // which cuts the polled volume -- the cost that sets the step time -- to a third.
+// (The fp16-split products of the forward, mfma_gates_h2, were tried here too -- with a per-wave, per-step power-of-two
+// scale taken from the operand's own max, since gate gradients have no a-priori bound: parity was fine, but the extra
+// VALU work (max, scale, 48 conversions per lane and step) and 23 spilled registers made the step 0.23 ms slower.)
 template <int LAYER>
 __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8][256], const PersistIds& id) {
     constexpr int NU = LAYER == 1 ? 2 : 4;           // unit fragments per lane (x 3 gates = MFMA fragments)
@@ -825,7 +894,9 @@ static bool gru_layout(int B, int S, int nl, GruLayout& g) {
 using namespace cpc;
 
 namespace {
-int g_gru_mode = 1;        // 1: persistent two-layer recurrence when the grid fits the device, 0: per-step launches
+int g_gru_mode = 2;        // 0: per-step launches; 1: persistent two-layer recurrence when the grid fits the device, exact-f32
+                           // MFMAs; 2 (default): the same with the forward's recurrent products on the fp16 pipe (two-piece
+                           // split, 3 MFMAs per product; exact-f32 when the caller supplies h0, whose size is unknown)
 
 // true if `nblocks` workgroups of `kernel` (kPersistThreads each) can all be resident at the same time
 template <class K>
@@ -839,7 +910,7 @@ bool fits_resident(K kernel, int nblocks) {
 }  // namespace
 
 extern "C" int cpc_set_gru_mode(int mode) {
-    if (mode != 0 && mode != 1) return CPC_ERR_ARG;
+    if (mode != 0 && mode != 1 && mode != 2) return CPC_ERR_ARG;
     g_gru_mode = mode;
     return 0;
 }
@@ -878,10 +949,13 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
         p.hN = hN; p.B = B; p.S = S;
         p.xh[0] = p.xh[1] = nullptr;
         const int nblocks = 32 * cdiv(B, 16);
-        if (g_gru_mode == 1 && fits_resident(gru2_persist_fwd_kernel, nblocks)) {
+        const bool h2 = g_gru_mode == 2 && !h0;
+        if (g_gru_mode >= 1 && (h2 ? fits_resident(gru2_persist_fwd_h2_kernel, nblocks)
+                                   : fits_resident(gru2_persist_fwd_kernel, nblocks))) {
             p.xh[0] = scratch + g.xh; p.xh[1] = scratch + g.xh + g.xh_floats;
             if (hipMemsetAsync(p.xh[0], 0xFF, 2 * g.xh_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
-            hipLaunchKernelGGL(gru2_persist_fwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+            if (h2) hipLaunchKernelGGL(gru2_persist_fwd_h2_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+            else hipLaunchKernelGGL(gru2_persist_fwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
             CPC_LAUNCH_CHECK();
             return 0;
         }
@@ -991,7 +1065,7 @@ extern "C" int cpc_gru_backward_with_coef(const float* x, const float* h0, const
         if (!coef) launch_gru_coef(g, h0, saved, y, scratch + g.coef, B, S, st);
         p.wih1T = wihT_[1];
         const int nblocks = 32 * cdiv(B, 16);
-        if (g_gru_mode == 1 && fits_resident(gru2_persist_bwd_kernel, nblocks)) {
+        if (g_gru_mode >= 1 && fits_resident(gru2_persist_bwd_kernel, nblocks)) {
             if (hipMemsetAsync(p.xdh[0], 0xFF, 2 * g.frag_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
             hipLaunchKernelGGL(gru2_persist_bwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
         } else {

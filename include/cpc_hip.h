@@ -92,8 +92,10 @@ int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part, float* dW
                          const float* x_amax, int B, int Lin, int k, int s, int p, int splits,
                          int rows_per_split, void* stream);
 
-/* 1 (default): the two-layer recurrence runs as one persistent launch whenever all of its workgroups can
- * be resident at once (gru.hip); 0: one launch per time step.  Both give bit-identical results. */
+/* 0: one launch per time step; 1: the two-layer recurrence runs as one persistent launch whenever all of its
+ * workgroups can be resident at once (gru.hip) -- bit-identical with 0; 2 (default): as 1, with the forward's
+ * recurrent products on the fp16 matrix pipe (operands split into two fp16 pieces, three MFMAs per product, fp32
+ * accumulate: differences at the 1e-7 level; exact-f32 products whenever the caller supplies h0). */
 int cpc_set_gru_mode(int mode);
 
 /* Tuning / test knob: rows per block of the conv GEMM tiles (0 = auto, 32, 64, 128). */

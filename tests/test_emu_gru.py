@@ -5,6 +5,11 @@ import pytest
 import torch
 
 
+def _lib_default_gru_mode():
+    from cpc_audio_amd._lib import DEFAULT_GRU_MODE
+    return DEFAULT_GRU_MODE
+
+
 def _lib_default_mode():
     from cpc_audio_amd._lib import DEFAULT_MFMA_MODE
     return DEFAULT_MFMA_MODE
@@ -52,7 +57,7 @@ def test_gru_persistent_equals_stepwise_emulated(B, S, use_h0):
         try:
             outs.append(_run_gru(lib, B, S, 2, use_h0, check=(mode == 1)))
         finally:
-            lib.cpc_set_gru_mode(1)
+            lib.cpc_set_gru_mode(_lib_default_gru_mode())
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
 
@@ -94,3 +99,28 @@ def _run_gru(lib, B, S, nl, use_h0, check=True):
         bad = {n: rel_err(g, leaves[n].grad) for n, g in zip(names, grads) if not rel_err(g, leaves[n].grad) < 1e-5}
         assert not bad, bad
     return [y, hN, dx] + grads
+
+
+@pytest.mark.parametrize("B,S", [(3, 6), (20, 5)])
+def test_gru_fp16_split_forward_emulated(B, S):
+    """cpc_set_gru_mode(2): the recurrent products of the persistent forward on the fp16 pipe (two-piece split
+    operands, three MFMAs per product).  Same tolerance against the oracle as the exact-f32 path (_run_gru: 1e-5 on y
+    and hN, 1e-5 relative on every gradient), and within 2e-6 of the f32 path itself."""
+    lib = emu()
+    outs = []
+    for mode in (1, 2):
+        assert lib.cpc_set_gru_mode(mode) == 0
+        try:
+            outs.append(_run_gru(lib, B, S, 2, False))
+        finally:
+            lib.cpc_set_gru_mode(_lib_default_gru_mode())
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 2e-6
+    assert not torch.equal(outs[0][0], outs[1][0])          # the mode did switch the arithmetic
+    # with a caller-supplied h0 (|h| not bounded by 1) mode 2 keeps the exact-f32 products
+    assert lib.cpc_set_gru_mode(2) == 0
+    try:
+        a = _run_gru(lib, B, S, 2, True)
+    finally:
+        lib.cpc_set_gru_mode(_lib_default_gru_mode())
+    b = _run_gru(lib, B, S, 2, True)
+    assert torch.equal(a[0], b[0])

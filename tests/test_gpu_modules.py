@@ -9,6 +9,11 @@ from oracle import cpc_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def _lib_default_gru_mode():
+    from cpc_audio_amd._lib import DEFAULT_GRU_MODE
+    return DEFAULT_GRU_MODE
+
+
 def _dev():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -155,7 +160,31 @@ def test_gru_persistent_launch_equals_stepwise(B, S):
             torch.cuda.synchronize()
             outs.append([y.detach().clone(), xd.grad.clone()] + [q.grad.clone() for q in ar.parameters()])
         finally:
-            lib.cpc_set_gru_mode(1)
+            lib.cpc_set_gru_mode(_lib_default_gru_mode())
     assert all(torch.isfinite(t).all() for t in outs[1])
     for a, b, c in zip(*outs):
         assert torch.equal(a, b) and torch.equal(b, c)
+
+
+def test_gru_fp16_split_forward_is_within_fp32_rounding_of_exact_products():
+    """cpc_set_gru_mode(2) (default) against mode 1 (exact-f32 MFMAs) over the full 128-step recurrence at B = 64:
+    the two-piece fp16 split keeps 22 mantissa bits per operand; tolerance 2e-6 absolute on |y| < 1."""
+    dev = _dev()
+    from cpc_audio_amd import _lib
+    from cpc_audio_amd.model import CPCAR
+    lib = _lib.get()
+    p = O.make_params(seed=4)
+    ar = CPCAR(256, 256, False, 2, mode="GRU").to(dev)
+    ar.load_state_dict({k[len("gAR."):]: v for k, v in p.items() if k.startswith("gAR.")})
+    x = torch.randn(64, 128, 256, generator=torch.Generator().manual_seed(3)).to(dev)
+    ys = []
+    for mode in (1, 2):
+        assert lib.cpc_set_gru_mode(mode) == 0
+        try:
+            with torch.no_grad():
+                ys.append(ar(x).clone())
+            torch.cuda.synchronize()
+        finally:
+            lib.cpc_set_gru_mode(_lib_default_gru_mode())
+    d = (ys[0] - ys[1]).abs().max().item()
+    assert 0.0 < d < 2e-6, d

@@ -12,6 +12,11 @@ from cpc_audio_amd import _lib           # noqa: E402
 from cpc_audio_amd._lib import ptr as P  # noqa: E402
 
 
+def _lib_default_gru_mode():
+    from cpc_audio_amd._lib import DEFAULT_GRU_MODE
+    return DEFAULT_GRU_MODE
+
+
 def timeit(fn, iters=20, warm=3):
     for _ in range(warm):
         fn()
@@ -66,7 +71,7 @@ def main():
         else:
             out["bit_identical"] = all(torch.equal(a, b) for a, b in zip(ref, cur))
             out["finite"] = all(bool(torch.isfinite(a).all()) for a in cur)
-    lib.cpc_set_gru_mode(1)
+    lib.cpc_set_gru_mode(_lib_default_gru_mode())
     print(json.dumps(out))
 
 
