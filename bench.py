@@ -200,8 +200,9 @@ def main():
             "metric": "audio-seconds/sec (train step)", "value": round(value, 1), "unit": "audio-s/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * el / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (conv GEMMs: fp32 operands scaled and split into 2 fp16 pieces, 3 fp16 MFMAs per product; other "
-                     "GEMMs: 3 bf16 pieces, 6 bf16 MFMAs per product; fp32 accumulate; fp32-level accuracy)",
+            "dtype": "f32 (conv GEMMs and the GRU forward recurrence: fp32 operands scaled and split into 2 fp16 pieces, "
+                     "3 fp16 MFMAs per product; GRU backward recurrence and InfoNCE scores: f32 MFMAs; other GEMMs: 3 bf16 "
+                     "pieces, 6 bf16 MFMAs per product; fp32 accumulate; fp32-level accuracy)",
             "data": "synthetic white noise 0.1*N(0,1) clamped to [-1,1], resident in HBM; random-init weights",
             "config": {"workload": "default CPC train step (conv encoder + 2-layer GRU + K=12 InfoNCE, 128 negatives), "
                                    f"{world}x{B}x20480 fp32 (BASELINE.json configs[1] at fp32)",
