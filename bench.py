@@ -120,6 +120,42 @@ def roofline_probe(B, dev):
     return roof, hbm
 
 
+def scoring_probe(B, dev):
+    """The contrastive score matrix (north star: 'MFMA only for the dense z_{t+k}.W_k.c_t score matrix'):
+    cpc_nce_scores_forward = nce_fwd_kernel (one wavefront per window: P[16x256] . Cand^T[256 x (N+K)] on
+    v_mfma_f32_16x16x4_f32 with the candidate rows gathered from L2, online log-softmax) + its three small reduction
+    launches.  Algorithmic work: 2 * 256 * K * (N + 1) FLOP per window (the K = 12 real heads, N negatives + 1
+    positive each); peak = the exact-f32 MFMA rate the kernel issues at."""
+    import ctypes
+    from cpc_audio_amd import _lib
+    from cpc_audio_amd._lib import ptr as P
+    lib = _lib.get()
+    S, K, N = 128, 12, 128
+    W = S - K
+    sizes = (ctypes.c_long * 6)()
+    lib.check(lib.cpc_nce_layout(B, S, K, N, sizes))
+    pred = torch.randn(B, W, K * 256, device=dev)
+    z = torch.randn(B, S, 256, device=dev)
+    ext = torch.randint(0, B * S, (B, W, N), device=dev, dtype=torch.int32)
+    saved = torch.empty(sizes[0], device=dev)
+    scratch = torch.empty(sizes[1], device=dev)
+    losses, acc = torch.empty(K, device=dev), torch.empty(K, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def f():
+        lib.check(lib.cpc_nce_scores_forward(P(pred), P(z), P(ext), P(saved), P(scratch), P(losses), P(acc),
+                                             B, S, K, N, st))
+
+    ms = hip_event_time(f, iters=20)
+    flops = 2.0 * 256 * K * (N + 1) * B * W
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "nce_fwd_kernel (score matrix on exact-f32 MFMAs, gathered candidate rows, online "
+                                       "log-softmax) + 3 reduction launches (cpc_nce_scores_forward)",
+            "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "ms_per_launch": round(ms, 4),
+            "flop_per_launch": flops}
+
+
 def cpu_baseline():
     """The oracle (CPU port of the reference path) timed on this host: forward + backward + Adam at
     B = 8 (BASELINE.json configs[0]), bounded to ~10-30 s of CPU work."""
@@ -214,6 +250,7 @@ def main():
                 roof, hbm = roofline_probe(B, dev)
                 out["roofline"] = roof
                 out["roofline_hbm_layer"] = hbm
+                out["roofline_scoring"] = scoring_probe(B, dev)
             except Exception as e:       # never lose the bench line over the probe
                 out["roofline"] = {"error": repr(e)}
             if not a.no_cpu_baseline:
