@@ -35,6 +35,7 @@ SIGNATURES = {
     "cpc_encoder_layout": (_I, [_I, _I, _P]),
     "cpc_encoder_forward": (_I, [_P] * 5 + [_I, _I, _P]),
     "cpc_encoder_backward": (_I, [_P] * 7 + [_I, _I, _P]),
+    "cpc_encoder_backward_streams": (_I, [_P] * 7 + [_I, _I, _P, _P]),
     "cpc_set_conv_tile": (_I, [_I]),
     "cpc_set_gru_mode": (_I, [_I]),
     "cpc_gemm_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),

@@ -977,12 +977,54 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
 }
 
 // grads: 20 output pointers in the same order as params (each overwritten).
+// Events that order the weight-gradient stream of cpc_encoder_backward_streams against the main one (timing disabled;
+// created once per device and reused: a wait captures the record that precedes it, so re-recording later is harmless).
+namespace {
+constexpr int kEncEvents = 6;
+hipEvent_t* enc_events() {
+    static hipEvent_t ev[16][kEncEvents];
+    static bool made[16] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!made[dev]) {
+        for (int i = 0; i < kEncEvents; ++i)
+            if (hipEventCreateWithFlags(&ev[dev][i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        made[dev] = true;
+    }
+    return ev[dev];
+}
+}  // namespace
+
+static int encoder_backward_impl(const float* wave, const float* const* params, const float* saved, const float* z,
+                                 const float* dz, float* scratch, float* const* grads, int B, int L, hipStream_t st,
+                                 hipStream_t wst);
+
 extern "C" int cpc_encoder_backward(const float* wave, const float* const* params,
                                     const float* saved, const float* z, const float* dz,
                                     float* scratch, float* const* grads, int B, int L, void* stream) {
+    return encoder_backward_impl(wave, params, saved, z, dz, scratch, grads, B, L, (hipStream_t)stream,
+                                 (hipStream_t)stream);
+}
+
+// The same with the four weight-gradient GEMMs (and their split reductions) on `wgrad_stream`: they are not on the
+// dx chain (norm backward -> dgrad -> norm backward ...), whose streaming norm backwards and VALU-bound conv0
+// backward leave the matrix pipes idle.  Ordering is internal (events); on return `stream` waits for `wgrad_stream`,
+// so every output is safe to use on `stream` -- no host synchronisation.
+extern "C" int cpc_encoder_backward_streams(const float* wave, const float* const* params, const float* saved,
+                                            const float* z, const float* dz, float* scratch, float* const* grads,
+                                            int B, int L, void* stream, void* wgrad_stream) {
+    return encoder_backward_impl(wave, params, saved, z, dz, scratch, grads, B, L, (hipStream_t)stream,
+                                 (hipStream_t)wgrad_stream);
+}
+
+static int encoder_backward_impl(const float* wave, const float* const* params, const float* saved, const float* z,
+                                 const float* dz, float* scratch, float* const* grads, int B, int L, hipStream_t st,
+                                 hipStream_t wst) {
     EncLayout e;
     CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
-    hipStream_t st = (hipStream_t)stream;
+    void* stream = (void*)st;
+    hipEvent_t* ev = wst != st ? enc_events() : nullptr;
+    CPC_RETURN_IF(wst != st && !ev, CPC_ERR_ARG);
     float* colpart = scratch + e.colpart;
     float* tmp = scratch + e.tmp;
     float* small = scratch + e.small;          // [5][3][256]
@@ -1007,8 +1049,12 @@ extern "C" int cpc_encoder_backward(const float* wave, const float* const* param
     norm_bwd(4, dz, z, scratch + e.dx[4]);
     for (int i = 4; i >= 1; --i) {
         const float* xin = saved + e.y[i - 1];
+        if (ev) {                                        // dx_i and its bound are final: the weight gradient may start
+            if (hipEventRecord(ev[i], st) != hipSuccess || hipStreamWaitEvent(wst, ev[i], 0) != hipSuccess)
+                return CPC_ERR_ARG;
+        }
         rc = cpc_conv_layer_wgrad(scratch + e.dx[i], xin, scratch + e.part, grads[4 * i], amax + i, xbound + i, B,
-                                  e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], stream);
+                                  e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], (void*)wst);
         if (rc) return rc;
         if (i >= 2 && g_unfuse_big && (g_unfuse_big == 2 || pick_bm(B * (e.L[i] + 1)) == 128)) {
             // the fused ReLU'/ChannelNorm-backward epilogue is latency-bound (row-by-row reductions between the loads); a
@@ -1029,6 +1075,16 @@ extern "C" int cpc_encoder_backward(const float* wave, const float* const* param
                                  kGeom[1].s, kGeom[1].p, st);
         }
         if (rc) return rc;
+    }
+    if (ev) {
+        // Join BEFORE conv0's backward: conv0_bwd_kernel must not share the chip with the 16-bit-MFMA GEMM kernels.
+        // Measured on MI355X (tools/probe_corun.py): beside conv_wgrad_kernel<1|2> or conv_dgrad_kernel<128,.,2> about a
+        // fifth of its workgroups return partial sums that differ from the solo run (single accumulators off by
+        // ~1e-3 relative, i.e. single LDS-broadcast operands of a time step read wrong), run after run; beside the
+        // exact-f32 wgrad, a rocBLAS GEMM or copies it is bit-exact, and the GEMM kernels themselves are bit-exact
+        // beside each other.  Not understood; avoided.
+        if (hipEventRecord(ev[0], wst) != hipSuccess || hipStreamWaitEvent(st, ev[0], 0) != hipSuccess)
+            return CPC_ERR_ARG;
     }
     rc = cpc_conv0_backward(wave, params[0], params[1], params[2], params[3], saved + e.mean0,
                             saved + e.rstd[0], scratch + e.dy0, scratch + e.conv0, grads[0], grads[1],

@@ -42,6 +42,7 @@ _layout_cache = {}
 # own train loops (train.Trainer, harness.train_epoch), whose autograd graph has no foreign op between the criterion
 # and the encoder; code that reads dz on the current stream through other ops must leave it off (the default).
 OVERLAP_DZ = False
+WGRAD_STREAM = True     # with OVERLAP_DZ: the encoder's weight-gradient GEMMs on their own stream (ops.EncoderFunction.backward)
 _side_streams = {}
 _side_events = []       # work the next backward op depends on (dz)
 _late_events = []       # work only the optimiser reads (the prediction heads' weight gradient)
@@ -122,7 +123,10 @@ class EncoderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         lib = _lib.get()
-        wait_side_stream(final=False)          # dz may carry the criterion's side-stream part
+        # dz may carry the criterion's side-stream part.  The head-gradient GEMM queued behind it is waited for as well
+        # (it has normally finished inside the recurrence's window): conv0's backward at the end of this call must not
+        # run beside a 16-bit-MFMA GEMM kernel (tools/probe_corun.py)
+        wait_side_stream()
         for hook in pre_encoder_backward:
             hook()
         wave, saved, z, *params = ctx.saved_tensors
@@ -131,8 +135,15 @@ class EncoderFunction(torch.autograd.Function):
         with torch.cuda.device(wave.device):
             scratch = torch.empty(nscr, device=wave.device, dtype=torch.float32)
             grads = [torch.empty_like(p) for p in params]
-            lib.check(lib.cpc_encoder_backward(_p(wave), _ptrs(params), _p(saved), _p(z), _p(dz), _p(scratch),
-                                               _ptrs(grads), B, L, _stream()), "encoder_backward")
+            if OVERLAP_DZ and WGRAD_STREAM:
+                # the weight-gradient GEMMs beside the dx chain (its norm backwards stream, conv0's backward is
+                # VALU-bound: both leave the matrix pipes idle); the call joins the two streams before it returns
+                lib.check(lib.cpc_encoder_backward_streams(_p(wave), _ptrs(params), _p(saved), _p(z), _p(dz), _p(scratch),
+                                                           _ptrs(grads), B, L, _stream(),
+                                                           _side_stream(wave.device, 2).cuda_stream), "encoder_backward")
+            else:
+                lib.check(lib.cpc_encoder_backward(_p(wave), _ptrs(params), _p(saved), _p(z), _p(dz), _p(scratch),
+                                                   _ptrs(grads), B, L, _stream()), "encoder_backward")
         wait_side_stream()                     # the last backward op: everything on the side stream is due now
         return (None, *grads)
 

@@ -112,6 +112,13 @@ int cpc_encoder_backward(const float* wave, const float* const* params, const fl
                          const float* z, const float* dz, float* scratch, float* const* grads,
                          int B, int L, void* stream);
 
+/* The same with the four conv weight-gradient GEMMs on `wgrad_stream` (they are not on the dx chain); ordering
+ * between the two streams is internal (hip events, no host synchronisation) and `stream` waits for `wgrad_stream`
+ * before the call returns control of the outputs.  wgrad_stream == stream: identical to cpc_encoder_backward. */
+int cpc_encoder_backward_streams(const float* wave, const float* const* params, const float* saved,
+                                 const float* z, const float* dz, float* scratch, float* const* grads, int B,
+                                 int L, void* stream, void* wgrad_stream);
+
 /* ------------------------------------------------------------ plain GEMMs ----
  * C[M,N] = A[M,K] . B[N,K]^T + bias[N]   (N % 128 == 0, K % 16 == 0; bias may be NULL).
  * This is torch.nn.Linear's arithmetic (criterion.py:90-91,108; the GRU projections). */

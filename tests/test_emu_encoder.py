@@ -76,6 +76,16 @@ def test_encoder_forward_backward_emulated(B, L, bm, mode):
             if not e < 2e-5:
                 bad[n] = e
         assert not bad, bad
+        # the two-stream entry point (weight gradients on their own stream) runs the same kernels: identical results
+        bscr2 = torch.full((sizes[2],), float("nan"))
+        grads2 = [torch.full_like(t, float("nan")) for t in plist]
+        garr2 = (ctypes.c_void_p * 20)(*[P(t) for t in grads2])
+        other = ctypes.c_void_p(0x10)                      # any handle != stream: the emulator ignores streams
+        rc = lib.cpc_encoder_backward_streams(P(wave), parr, P(saved), P(z), P(dz.contiguous()), P(bscr2), garr2,
+                                              B, L, None, other)
+        assert rc == 0
+        for a, b in zip(grads, grads2):
+            assert torch.equal(a, b)
     finally:
         lib.cpc_set_conv_tile(0)
         lib.cpc_set_mfma_mode(_lib_default_mode())
