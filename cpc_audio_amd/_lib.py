@@ -52,6 +52,7 @@ SIGNATURES = {
     "cpc_gru_coef_floats": (_L, [_I, _I, _I]),
     "cpc_gru_backward_coef": (_I, [_P] * 4 + [_I, _I, _I, _P]),
     "cpc_gru_backward_with_coef": (_I, [_P] * 10 + [_I, _I, _I, _P]),
+    "cpc_gru_backward_streams": (_I, [_P] * 10 + [_I, _I, _I, _P, _P]),
     "cpc_nce_layout": (_I, [_I, _I, _I, _I, _P]),
     "cpc_nce_prepare": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
     "cpc_nce_forward": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),

@@ -977,24 +977,6 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
 }
 
 // grads: 20 output pointers in the same order as params (each overwritten).
-// Events that order the weight-gradient stream of cpc_encoder_backward_streams against the main one (timing disabled;
-// created once per device and reused: a wait captures the record that precedes it, so re-recording later is harmless).
-namespace {
-constexpr int kEncEvents = 6;
-hipEvent_t* enc_events() {
-    static hipEvent_t ev[16][kEncEvents];
-    static bool made[16] = {false};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!made[dev]) {
-        for (int i = 0; i < kEncEvents; ++i)
-            if (hipEventCreateWithFlags(&ev[dev][i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        made[dev] = true;
-    }
-    return ev[dev];
-}
-}  // namespace
-
 static int encoder_backward_impl(const float* wave, const float* const* params, const float* saved, const float* z,
                                  const float* dz, float* scratch, float* const* grads, int B, int L, hipStream_t st,
                                  hipStream_t wst);
@@ -1023,7 +1005,7 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     EncLayout e;
     CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
     void* stream = (void*)st;
-    hipEvent_t* ev = wst != st ? enc_events() : nullptr;
+    hipEvent_t* ev = wst != st ? stream_events() : nullptr;      // [0..4] used here
     CPC_RETURN_IF(wst != st && !ev, CPC_ERR_ARG);
     float* colpart = scratch + e.colpart;
     float* tmp = scratch + e.tmp;

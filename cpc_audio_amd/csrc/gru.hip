@@ -1030,10 +1030,22 @@ extern "C" int cpc_gru_backward_with_coef(const float* x, const float* h0, const
                                           const float* saved, const float* y, const float* dy, const float* coef,
                                           float* scratch, float* dx, float* const* grads, int B, int S, int nl,
                                           void* stream) {
+    return cpc_gru_backward_streams(x, h0, params, saved, y, dy, coef, scratch, dx, grads, B, S, nl, stream, stream);
+}
+
+// As cpc_gru_backward_with_coef, with everything that only the optimiser reads -- the four weight gradients (one
+// batched TN GEMM) and the four bias gradients -- on `wgrad_stream`, released by an event behind the recurrence; dx
+// (what the encoder's backward waits for) stays on `stream`.  NO join: the caller orders every consumer of `grads`
+// after `wgrad_stream`, and keeps `scratch` alive until then.  nl == 2 only; other depths run on `stream` alone.
+extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const float* const* params,
+                                        const float* saved, const float* y, const float* dy, const float* coef,
+                                        float* scratch, float* dx, float* const* grads, int B, int S, int nl,
+                                        void* stream, void* wgrad_stream) {
     GruLayout g;
     CPC_RETURN_IF(!gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!x || !params || !saved || !scratch || !y || !dy || !dx || !grads, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
+    hipStream_t wst = nl == 2 ? (hipStream_t)wgrad_stream : st;
     float* whhT = scratch + g.whhT, *wihT = scratch + g.wihT;
     float* dGi = scratch + g.dGi, *dGh = scratch + g.dGh, *DH = scratch + g.DH;
     const int M = B * S;
@@ -1073,6 +1085,14 @@ extern "C" int cpc_gru_backward_with_coef(const float* x, const float* h0, const
             for (int s = 0; s <= S; ++s) hipLaunchKernelGGL(gru2_bwd_kernel, grid, dim3(512), 0, st, p, s);
         }
         CPC_LAUNCH_CHECK();
+        // dx = dGi0 . W_ih0 first: it is what the rest of the backward pass waits for
+        rc = nt_gemm(plain_rows(dGi_[0], M, kG), wihT_[0], kG, nullptr, dx, kH, kH, kG, st);
+        if (rc) return rc;
+        if (wst != st) {
+            hipEvent_t* ev = stream_events();
+            CPC_RETURN_IF(!ev, CPC_ERR_ARG);
+            if (hipEventRecord(ev[8], st) != hipSuccess || hipStreamWaitEvent(wst, ev[8], 0) != hipSuccess) return CPC_ERR_ARG;
+        }
         const long tmp1 = align64l((long)kRowsSumGroups * kG);
         const RowsSumJob jobs[4] = {{dGi_[0], M, kG, scratch + g.tmp, grads[2]},
                                     {dGh_[0], M, kG, scratch + g.tmp + tmp1, grads[3]},
@@ -1093,7 +1113,7 @@ extern "C" int cpc_gru_backward_with_coef(const float* x, const float* h0, const
                 bm[2 * l + 1] = hm;
                 Cq[2 * l + 1] = grads[4 * l + 1];
             }
-            rc = tn_gemm_batch(4, am, kG, bm, kH, scratch + g.part, Cq, 0, st);
+            rc = tn_gemm_batch(4, am, kG, bm, kH, scratch + g.part, Cq, 0, wst);
             if (rc) return rc;
         }
         for (int l = 0; l < 2; ++l) {
@@ -1101,14 +1121,12 @@ extern "C" int cpc_gru_backward_with_coef(const float* x, const float* h0, const
                 RowMap g0;
                 g0.base = dGh_[l]; g0.R = 1; g0.bstride = (long)S * kG; g0.rstride = 0; g0.off = 0;
                 g0.tmul = 0; g0.tadd = 0; g0.Lin = 0x7fffffff; g0.M = B;
-                rc = tn_gemm(g0, kG, plain_rows(h0l[l], B, kH), kH, scratch + g.part, grads[4 * l + 1], 1, st);
+                rc = tn_gemm(g0, kG, plain_rows(h0l[l], B, kH), kH, scratch + g.part, grads[4 * l + 1], 1, wst);
                 if (rc) return rc;
             }
         }
-        rc = rows_sum_multi(jobs, 4, st);                // the four bias gradients in two launches
-        if (rc) return rc;
-        // dx = dGi0 . W_ih0
-        return nt_gemm(plain_rows(dGi_[0], M, kG), wihT_[0], kG, nullptr, dx, kH, kH, kG, st);
+        rc = rows_sum_multi(jobs, 4, wst);               // the four bias gradients in two launches
+        return rc;
     }
     const float* dYl = dy;
     for (int l = nl - 1; l >= 0; --l) {

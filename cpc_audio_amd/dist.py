@@ -76,6 +76,8 @@ class FlatGradAllReduce:
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
+            for e in ops._wgrad_events:              # the recurrence's gradients are formed on the weight-gradient stream
+                side.wait_event(e)
             with torch.cuda.stream(side):
                 self._pack(self.early)
                 bucket = self.buf[:self.n_early]

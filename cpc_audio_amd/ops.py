@@ -46,6 +46,7 @@ WGRAD_STREAM = True     # with OVERLAP_DZ: the encoder's weight-gradient GEMMs o
 _side_streams = {}
 _side_events = []       # work the next backward op depends on (dz)
 _late_events = []       # work only the optimiser reads (the prediction heads' weight gradient)
+_wgrad_events = []      # the same on the weight-gradient stream (stream 2: the recurrence's weight / bias gradients)
 _deferred = []          # side-stream launches held back until the AR backward is in flight (it needs whole CUs: its
                         # 768-thread workgroups cannot squeeze in beside a chip full of gather blocks)
 
@@ -68,15 +69,18 @@ def launch_deferred():
         _deferred.pop(0)()
 
 
-def wait_side_stream(final=True):
-    """Make the current stream wait for everything this package has launched (or still holds) for its side stream.
+def wait_side_stream(final=True, wgrad=None):
+    """Make the current stream wait for everything this package has launched (or still holds) for its side streams.
     ``final=False`` (used between the backward ops) leaves out what only the optimiser reads; whoever switches
-    OVERLAP_DZ on calls this with final=True after backward() and before touching any ``.grad``."""
+    OVERLAP_DZ on calls this with final=True after backward() and before touching any ``.grad``.
+    ``wgrad`` (default: same as ``final``): also wait for the weight-gradient stream."""
     launch_deferred()
     while _side_events:
         torch.cuda.current_stream().wait_event(_side_events.pop())
     while final and _late_events:
         torch.cuda.current_stream().wait_event(_late_events.pop())
+    while (final if wgrad is None else wgrad) and _wgrad_events:
+        torch.cuda.current_stream().wait_event(_wgrad_events.pop())
 
 # Parity tests set KEEP_DEBUG = True to look at the encoder's saved activations (the ReLU
 # masks of the device path, see oracle/cpc_oracle._ReluTieAware).  Never used by the product.
@@ -125,8 +129,9 @@ class EncoderFunction(torch.autograd.Function):
         lib = _lib.get()
         # dz may carry the criterion's side-stream part.  The head-gradient GEMM queued behind it is waited for as well
         # (it has normally finished inside the recurrence's window): conv0's backward at the end of this call must not
-        # run beside a 16-bit-MFMA GEMM kernel (tools/probe_corun.py)
-        wait_side_stream()
+        # run beside a 16-bit-MFMA GEMM kernel (tools/probe_corun.py).  The weight-gradient stream is not waited for here:
+        # the call below runs its own GEMMs there and joins it before conv0's backward.
+        wait_side_stream(final=True, wgrad=False)
         for hook in pre_encoder_backward:
             hook()
         wave, saved, z, *params = ctx.saved_tensors
@@ -157,6 +162,7 @@ class GruFunction(torch.autograd.Function):
         lib = _lib.get()
         B, S, D = x.shape
         nl = len(params) // 4
+        leaves = params                           # the tensors autograd knows (normally the module's Parameters)
         if D != _HID or params[1].shape != (3 * _HID, _HID):
             raise NotImplementedError("the HIP GRU is built for dimEncoded == dimOutput == 256")
         x = x.contiguous()
@@ -188,6 +194,7 @@ class GruFunction(torch.autograd.Function):
                     ctx.coef_ready = torch.cuda.Event()
                     ctx.coef_ready.record(side)
         ctx.coef = coef
+        ctx.leaves = list(leaves) if all(isinstance(q, torch.Tensor) and q.is_leaf for q in leaves) else None
         ctx.save_for_backward(x, saved, y, *params)
         ctx.h0 = h0c
         ctx.dims = (B, S, nl, sizes[2])
@@ -207,9 +214,34 @@ class GruFunction(torch.autograd.Function):
             grads = [torch.empty_like(p) for p in params]
             if ctx.coef is not None:
                 torch.cuda.current_stream().wait_event(ctx.coef_ready)
-            lib.check(lib.cpc_gru_backward_with_coef(_p(x), _p(ctx.h0), _ptrs(params), _p(saved), _p(y), _p(dy),
-                                                     _p(ctx.coef), _p(scratch), _p(dx), _ptrs(grads), B, S, nl,
-                                                     _stream()), "gru_backward")
+            split = OVERLAP_DZ and WGRAD_STREAM and nl == 2 and ctx.leaves is not None
+            if split:
+                # dx on this stream; the weight / bias gradients -- read by nobody before the optimiser -- on the
+                # weight-gradient stream, beside the start of the encoder's backward.  They are added to .grad there
+                # (autograd gets None for them: it would accumulate on this stream, before they exist).
+                wst = _side_stream(x.device, 2)
+                lib.check(lib.cpc_gru_backward_streams(_p(x), _p(ctx.h0), _ptrs(params), _p(saved), _p(y), _p(dy),
+                                                       _p(ctx.coef), _p(scratch), _p(dx), _ptrs(grads), B, S, nl,
+                                                       _stream(), wst.cuda_stream), "gru_backward")
+                with torch.cuda.stream(wst), torch.no_grad():
+                    for leaf, g in zip(ctx.leaves, grads):
+                        if not leaf.requires_grad:
+                            continue
+                        if leaf.grad is None:
+                            leaf.grad = g.view_as(leaf)
+                        else:
+                            leaf.grad.add_(g.view_as(leaf))
+                            leaf.grad.record_stream(wst)
+                for t in [scratch, saved, x, y, dy] + grads + ([] if ctx.coef is None else [ctx.coef]):
+                    t.record_stream(wst)
+                ev = torch.cuda.Event()
+                ev.record(wst)
+                _wgrad_events.append(ev)
+                grads = [None] * len(grads)
+            else:
+                lib.check(lib.cpc_gru_backward_with_coef(_p(x), _p(ctx.h0), _ptrs(params), _p(saved), _p(y), _p(dy),
+                                                         _p(ctx.coef), _p(scratch), _p(dx), _ptrs(grads), B, S, nl,
+                                                         _stream()), "gru_backward")
         wait_side_stream(final=False)  # starts the criterion's deferred dz path beside the recurrence just launched, and makes
         #                         this stream wait for it: autograd adds dx to that dz next
         return (dx, None, *grads)

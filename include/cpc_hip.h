@@ -153,6 +153,14 @@ int cpc_gru_backward_with_coef(const float* x, const float* h0, const float* con
                                const float* y, const float* dy, const float* coef, float* scratch, float* dx,
                                float* const* grads, int B, int S, int nl, void* stream);
 
+/* As cpc_gru_backward_with_coef, with the weight and bias gradients (what only the optimiser reads) on
+ * `wgrad_stream`, released by an event behind the recurrence; dx stays on `stream`.  There is NO join: the caller
+ * orders every consumer of `grads` after `wgrad_stream` and keeps `scratch` alive until then.  (nl == 2; other depths
+ * run on `stream` alone.) */
+int cpc_gru_backward_streams(const float* x, const float* h0, const float* const* params, const float* saved,
+                             const float* y, const float* dy, const float* coef, float* scratch, float* dx,
+                             float* const* grads, int B, int S, int nl, void* stream, void* wgrad_stream);
+
 /* ---------------------------------------------------------------- transformer layer ----
  * One TransformerLayer of cpc/transformers.py:103-111 (buildTransformerAR, :130-139), d_model 256, 8 heads,
  * d_ff 2048, sequence S <= 128, dropout not applied.  Used as the auto-regressive network (--arMode
