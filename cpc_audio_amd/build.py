@@ -20,6 +20,13 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
          "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
+# Per-file flags.  enc_conv0.hip: no SLP vectorisation, i.e. no compiler-formed v_pk_fma_f32 in conv0_bwd_kernel -- with
+# them the kernel returns wrong partial sums whenever a 16-bit-MFMA GEMM kernel shares the chip with it (measured,
+# tools/probe_corun.py; same speed without them: the kernel is bound by VALU issue either way).  conv0_fwd_kernel keeps its
+# explicit f32x2 arithmetic and never runs beside such a kernel.
+FILE_FLAGS = {"enc_conv0.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -37,7 +44,7 @@ def _deps_mtime():
 
 
 def _compile(src, obj, extra):
-    cmd = [_hipcc(), *FLAGS, *extra, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), *extra, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

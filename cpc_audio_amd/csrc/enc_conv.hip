@@ -1031,10 +1031,14 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     norm_bwd(4, dz, z, scratch + e.dx[4]);
     for (int i = 4; i >= 1; --i) {
         const float* xin = saved + e.y[i - 1];
-        if (ev) {                                        // dx_i and its bound are final: the weight gradient may start
+        // dx_i and its bound are final: the weight gradient may start -- except layer 1's, which is as long as its
+        // dgrad and only slows it down when both fight for the matrix pipes (0.66 + 0.44 ms together vs 0.29 + 0.30 alone);
+        // it is released behind that dgrad and runs beside conv0's VALU-bound backward instead
+        if (ev && i > 1) {
             if (hipEventRecord(ev[i], st) != hipSuccess || hipStreamWaitEvent(wst, ev[i], 0) != hipSuccess)
                 return CPC_ERR_ARG;
         }
+        if (!(ev && i == 1))
         rc = cpc_conv_layer_wgrad(scratch + e.dx[i], xin, scratch + e.part, grads[4 * i], amax + i, xbound + i, B,
                                   e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], (void*)wst);
         if (rc) return rc;
@@ -1057,16 +1061,12 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                                  kGeom[1].s, kGeom[1].p, st);
         }
         if (rc) return rc;
-    }
-    if (ev) {
-        // Join BEFORE conv0's backward: conv0_bwd_kernel must not share the chip with the 16-bit-MFMA GEMM kernels.
-        // Measured on MI355X (tools/probe_corun.py): beside conv_wgrad_kernel<1|2> or conv_dgrad_kernel<128,.,2> about a
-        // fifth of its workgroups return partial sums that differ from the solo run (single accumulators off by
-        // ~1e-3 relative, i.e. single LDS-broadcast operands of a time step read wrong), run after run; beside the
-        // exact-f32 wgrad, a rocBLAS GEMM or copies it is bit-exact, and the GEMM kernels themselves are bit-exact
-        // beside each other.  Not understood; avoided.
-        if (hipEventRecord(ev[0], wst) != hipSuccess || hipStreamWaitEvent(st, ev[0], 0) != hipSuccess)
-            return CPC_ERR_ARG;
+        if (ev && i == 1) {
+            if (hipEventRecord(ev[1], st) != hipSuccess || hipStreamWaitEvent(wst, ev[1], 0) != hipSuccess) return CPC_ERR_ARG;
+            rc = cpc_conv_layer_wgrad(scratch + e.dx[1], xin, scratch + e.part, grads[4], amax + 1, xbound + 1, B, e.L[0],
+                                      kGeom[1].k, kGeom[1].s, kGeom[1].p, e.wg_splits[1], e.wg_rows[1], (void*)wst);
+        }
+        if (rc) return rc;
     }
     rc = cpc_conv0_backward(wave, params[0], params[1], params[2], params[3], saved + e.mean0,
                             saved + e.rstd[0], scratch + e.dy0, scratch + e.conv0, grads[0], grads[1],
@@ -1083,5 +1083,9 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     }
     hipLaunchKernelGGL(small_to_grads_kernel, dim3(12), dim3(256), 0, st, small, gp);
     CPC_LAUNCH_CHECK();
+    if (ev) {                                            // join: everything written on the weight-gradient stream
+        if (hipEventRecord(ev[0], wst) != hipSuccess || hipStreamWaitEvent(st, ev[0], 0) != hipSuccess)
+            return CPC_ERR_ARG;
+    }
     return 0;
 }

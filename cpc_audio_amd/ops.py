@@ -127,11 +127,9 @@ class EncoderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         lib = _lib.get()
-        # dz may carry the criterion's side-stream part.  The head-gradient GEMM queued behind it is waited for as well
-        # (it has normally finished inside the recurrence's window): conv0's backward at the end of this call must not
-        # run beside a 16-bit-MFMA GEMM kernel (tools/probe_corun.py).  The weight-gradient stream is not waited for here:
-        # the call below runs its own GEMMs there and joins it before conv0's backward.
-        wait_side_stream(final=True, wgrad=False)
+        # dz may carry the criterion's side-stream part.  The weight-gradient stream is not waited for here: the call
+        # below runs its own GEMMs there and joins it before it returns.
+        wait_side_stream(final=False)
         for hook in pre_encoder_backward:
             hook()
         wave, saved, z, *params = ctx.saved_tensors

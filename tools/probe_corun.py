@@ -1,12 +1,11 @@
 """Co-residency probe: does a kernel give bit-identical results when another kernel of this library runs beside it on a
-second stream?  (It must: the kernels share no memory.)  Written while moving the conv weight-gradient GEMMs onto their
-own stream (cpc_encoder_backward_streams).  Findings on MI355X, ROCm 7.2, run after run:
-  * conv_dgrad_kernel<128,false,2> beside conv_wgrad_kernel<2>: both bit-exact            -> the overlap the library uses
-  * conv0_bwd_kernel beside conv_wgrad_kernel<1|2> or conv_dgrad_kernel<128,false,2> (16-bit MFMA kernels): ~20 % of
-    its workgroups return partial sums that differ from the solo run by ~1e-3 relative (single accumulators: single
-    LDS-broadcast operands of a time step); beside the exact-f32 wgrad (mode 0), a rocBLAS GEMM or device copies: exact
-  * not understood (no shared memory, LDS indices of both kernels checked in range, no scratch, DPP vs ds_bpermute
-    reductions make no difference); cpc_encoder_backward_streams therefore joins the streams BEFORE conv0's backward.
+second stream?  (It must: the kernels share no memory.)  Written while moving the weight-gradient GEMMs onto their own
+stream.  Findings on MI355X, ROCm 7.2, run after run:
+  * conv_dgrad_kernel<128,false,2> beside conv_wgrad_kernel<2>: both bit-exact
+  * conv0_bwd_kernel built with the default flags (SLP vectoriser -> v_pk_fma_f32 with op_sel on ds_read2_b32 pairs)
+    beside conv_wgrad_kernel<1|2> or conv_dgrad_kernel<128,false,2> (16-bit MFMA kernels): ~20 % of its workgroups
+    returned partial sums off by ~1e-3 relative; beside the exact-f32 wgrad, a rocBLAS GEMM or device copies: exact
+  * the same kernel built with -fno-slp-vectorize (no packed fp32; what build.py does now): exact beside all of them
 Usage (GPU): python tools/probe_corun.py"""
 import sys
 
