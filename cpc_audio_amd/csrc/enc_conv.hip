@@ -226,7 +226,9 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
     zero_acc(acc);
     if constexpr (ConvCfg<BM, MODE>::H2) {
         const float sa = scale_for_amax(*x_amax), sb = scale_for_amax(*w_amax);
-        Tile::run(acc, am, m0, wp, 16, 0, K, smem, 0, kC * 16, (int)((blockIdx.x * 4u) % (unsigned)(K / Tile::BK)), sa, sb);
+        Tile::run(acc, am, m0, wp, 16, 0, K, smem, 0, kC * 16, (int)((blockIdx.x * 4u) % (unsigned)(K / Tile::BK)), sa, sb,
+                  ((K >> kCLog2) & ((K >> kCLog2) - 1)) == 0 ? 31 - __builtin_clz(K >> kCLog2) : 0);   // tap-fastest K walk
+                                                                                                      // (power-of-two tap counts)
         const float inv = 1.0f / (sa * sb);                      // powers of two: exact
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -405,7 +407,7 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
     zero_acc(acc);
     if constexpr (ConvCfg<BM, MODE>::H2) {
         const float sa = scale_for_amax(*dx_amax), sb = scale_for_amax(*w_amax);
-        Tile::run(acc, am, m0, wd + (long)ph * kC * 2 * kC, 16, 0, 2 * kC, smem, 0, kC * 16, 0, sa, sb);
+        Tile::run(acc, am, m0, wd + (long)ph * kC * 2 * kC, 16, 0, 2 * kC, smem, 0, kC * 16, 0, sa, sb, 1);     // two 256-wide segments
         const float inv = 1.0f / (sa * sb);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)

@@ -424,7 +424,11 @@ struct NtTileX3 {
     __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int m0,
                                const float* __restrict__ Bmat, int ldb, int n0, int K,
                                float* smem_f, long bplane = 0, int bblk = 16, int rot = 0,      // bblk: see NtTile::run
-                               float sa = 1.0f, float sb = 1.0f) {
+                               float sa = 1.0f, float sb = 1.0f, int tshift = 0) {
+        // tshift: K consists of 2^tshift equal segments (conv taps) whose rows overlap in memory: tap j of output row t
+        // and tap j - s of row t + 1 are the same input row.  Walking the chunks tap-fastest (all taps of one channel
+        // block, then the next block) brings the two reads of every input segment a few chunks apart instead of half
+        // the K walk, i.e. inside L2's reach: the plain order fetched layer 1's activation 2.4 times from HBM (PMC).
         // rot (pipelined schedule only): this workgroup walks the K chunks starting at chunk `rot` (mod K/BK).
         // All workgroups of a conv layer otherwise read the same 64-byte channel slice of rows that are a
         // multiple of 1 KB apart at the same moment, i.e. one L2 channel out of 16.
@@ -466,6 +470,7 @@ struct NtTileX3 {
         auto gload_to = [&](int kc0_, float4 (&ra_)[A_PER], BReg (&rb_)[B_PER]) __attribute__((always_inline)) {
             int kc_ = kc0_ + rot;
             kc_ = kc_ >= nk ? kc_ - nk : kc_;
+            kc_ = (kc_ & ((1 << tshift) - 1)) * (nk >> tshift) + (kc_ >> tshift);
             const int k0 = kc_ * BK;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) ra_[i] = load_row4(ar[i], k0 + a_k[i], am.Lin, am.base);
@@ -559,6 +564,7 @@ struct NtTileX3 {
             auto gload_raw = [&](int kc0_, float4 (&ra_)[A_PER], BReg (&rb_)[B_PER], bool (&ok_)[A_PER]) __attribute__((always_inline)) {
                 int kc_ = kc0_ + rot;
                 kc_ = kc_ >= nk ? kc_ - nk : kc_;
+                kc_ = (kc_ & ((1 << tshift) - 1)) * (nk >> tshift) + (kc_ >> tshift);
                 const int k0 = kc_ * BK;
 #pragma unroll
                 for (int i = 0; i < A_PER; ++i) ra_[i] = load_row4_raw(ar[i], k0 + a_k[i], am.Lin, am.base, ok_[i]);
