@@ -28,7 +28,9 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (same guide)
 X3_PRODUCTS = 3                   # fp16 MFMAs issued per fp32 product in the split-fp16 conv tiles (gemm_tile.h; bf16 split: 6)
 HBM_PEAK_GBPS = 8000.0
 # HBM bytes per launch at B = 64 from the PMC counters (profiles/r1_pmc_roofline_kernels.md)
-PMC_TRAFFIC_B64 = {"conv1_fwd": 805.9e6, "conv0_fwd": 276.5e6}
+# conv1 (tap-fastest K walk, profiles/r1_pmc_counters_v19.csv): 430.8 MB fetched + 134.5 MB written, against 405 MB
+# algorithmic; the plain K walk fetched 671.4 MB (805.9 MB in total).
+PMC_TRAFFIC_B64 = {"conv1_fwd": 565.3e6, "conv0_fwd": 276.5e6}
 
 
 def parse():
