@@ -121,6 +121,9 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
                 ones = torch.ones_like(all_losses)
             torch.autograd.backward([all_losses], [ones])  # = all_losses.sum().backward() (train.py:85-87), 3 kernels less
             ops.wait_side_stream()
+        except BaseException:
+            ops.abandon_side_work()
+            raise
         finally:
             ops.OVERLAP_DZ = False
             if allreduce is not None:

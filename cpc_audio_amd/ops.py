@@ -64,6 +64,15 @@ def _side_stream(device, which=0):
     return st
 
 
+def abandon_side_work():
+    """After an exception inside an overlapped step: forget the launches still held back and the events not yet waited
+    for (what was already enqueued simply completes), so that the next step does not start from stale state."""
+    del _deferred[:]
+    del _side_events[:]
+    del _late_events[:]
+    del _wgrad_events[:]
+
+
 def launch_deferred():
     while _deferred:
         _deferred.pop(0)()

@@ -61,6 +61,9 @@ class Trainer:
             # allLosses.sum().backward() (train.py:85-87) without the sum / fill / expand kernels: d sum / d loss_k = 1
             torch.autograd.backward([allLosses], [self._ones_like(allLosses)])
             ops.wait_side_stream()
+        except BaseException:
+            ops.abandon_side_work()
+            raise
         finally:
             ops.OVERLAP_DZ = False
             ops.pre_encoder_backward.remove(self.allreduce.begin)
