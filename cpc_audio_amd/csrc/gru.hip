@@ -986,11 +986,12 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
 
 // dy (B,S,256) -> dx (B,S,256) and grads[4*nl] (same order as params; overwritten).
 // h0 receives no gradient (the reference detaches the carried state, cpc/model.py:194-198).
-// Floats of the coefficient arrays of the two-layer backward (0 when nl != 2), see cpc_gru_backward_coef.
+// Floats of the buffer cpc_gru_backward_coef fills (0 when nl != 2): the coefficient arrays of the two-layer backward
+// and its hand-over buffers.  A buffer serves ONE backward call (the hand-over buffers are consumed by it).
 extern "C" long cpc_gru_coef_floats(int B, int S, int nl) {
     GruLayout g;
     if (nl != 2 || !gru_layout(B, S, nl, g)) return 0;
-    return 8 * g.frag_floats;
+    return 10 * g.frag_floats;       // 8 coefficient arrays + the two hand-over buffers of the persistent backward
 }
 
 static void launch_gru_coef(const GruLayout& g, const float* h0, const float* saved, const float* y, float* coef,
@@ -1015,6 +1016,9 @@ extern "C" int cpc_gru_backward_coef(const float* h0, const float* saved, const 
     CPC_RETURN_IF(nl != 2 || !gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!saved || !y || !coef, CPC_ERR_ARG);
     launch_gru_coef(g, h0, saved, y, coef, B, S, (hipStream_t)stream);
+    // ... and the hand-over buffers of the persistent backward, pre-filled with the "not written yet" pattern
+    if (hipMemsetAsync(coef + 8 * g.frag_floats, 0xFF, 2 * g.frag_floats * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        return CPC_ERR_ARG;
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -1072,13 +1076,13 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
             p.dGi[l] = dGi_[l]; p.dGh[l] = dGh_[l]; p.DH[l] = DH_[l];
             const float* c = (coef ? coef : scratch + g.coef) + 4 * l * g.frag_floats;
             p.cr[l] = c; p.cz[l] = c + g.frag_floats; p.cnh[l] = c + 2 * g.frag_floats; p.cni[l] = c + 3 * g.frag_floats;
-            p.xdh[l] = scratch + g.xdh + l * g.frag_floats;
+            p.xdh[l] = (coef ? const_cast<float*>(coef) + 8 * g.frag_floats : scratch + g.xdh) + l * g.frag_floats;
         }
         if (!coef) launch_gru_coef(g, h0, saved, y, scratch + g.coef, B, S, st);
         p.wih1T = wihT_[1];
         const int nblocks = 32 * cdiv(B, 16);
         if (g_gru_mode >= 1 && fits_resident(gru2_persist_bwd_kernel, nblocks)) {
-            if (hipMemsetAsync(p.xdh[0], 0xFF, 2 * g.frag_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+            if (!coef && hipMemsetAsync(p.xdh[0], 0xFF, 2 * g.frag_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
             hipLaunchKernelGGL(gru2_persist_bwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
         } else {
             const dim3 grid(kH / 16, cdiv(B, 16), 2);

@@ -249,6 +249,7 @@ class GruFunction(torch.autograd.Function):
                 lib.check(lib.cpc_gru_backward_with_coef(_p(x), _p(ctx.h0), _ptrs(params), _p(saved), _p(y), _p(dy),
                                                          _p(ctx.coef), _p(scratch), _p(dx), _ptrs(grads), B, S, nl,
                                                          _stream()), "gru_backward")
+        ctx.coef = None                # its hand-over buffers are consumed: a second backward through this node recomputes
         wait_side_stream(final=False)  # starts the criterion's deferred dz path beside the recurrence just launched, and makes
         #                         this stream wait for it: autograd adds dx to that dz next
         return (dx, None, *grads)

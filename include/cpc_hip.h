@@ -142,8 +142,9 @@ int cpc_gru_backward(const float* x, const float* h0, const float* const* params
                      const float* saved, const float* y, const float* dy, float* scratch, float* dx,
                      float* const* grads, int B, int S, int nl, void* stream);
 
-/* The part of the two-layer backward that depends on the forward pass only (per-step gate-derivative coefficients,
- * cpc_gru_coef_floats(B,S,nl) floats; 0 unless nl == 2).  cpc_gru_backward_coef may run any time after the forward
+/* The part of the two-layer backward that depends on the forward pass only (per-step gate-derivative coefficients
+ * and the pre-filled hand-over buffers of the persistent launch: cpc_gru_coef_floats(B,S,nl) floats; 0 unless
+ * nl == 2; one buffer serves one backward call).  cpc_gru_backward_coef may run any time after the forward
  * on any stream; cpc_gru_backward_with_coef(coef != NULL) then skips that work (coef == NULL: same as
  * cpc_gru_backward). */
 long cpc_gru_coef_floats(int B, int S, int nl);

@@ -124,3 +124,50 @@ def test_gru_fp16_split_forward_emulated(B, S):
         lib.cpc_set_gru_mode(_lib_default_gru_mode())
     b = _run_gru(lib, B, S, 2, True)
     assert torch.equal(a[0], b[0])
+
+
+def test_gru_backward_with_early_coefficients_emulated():
+    """cpc_gru_backward_coef (forward-only part + pre-filled hand-over buffers, run ahead of time by the overlapped train
+    loops) + cpc_gru_backward_with_coef / _streams give bit-identical results to the one-call backward."""
+    lib = emu()
+    B, S, nl = 5, 6, 2
+    torch.manual_seed(2)
+    p = O.make_params(seed=3, n_levels_gru=nl)
+    names = [f"gAR.baseNet.{w}_l{l}" for l in range(nl) for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    plist = [p[n].contiguous() for n in names]
+    x = torch.randn(B, S, 256)
+    sizes = (ctypes.c_long * 3)()
+    assert lib.cpc_gru_layout(B, S, nl, sizes) == 0
+    saved = torch.full((sizes[0],), float("nan"))
+    fscr = torch.full((sizes[1],), float("nan"))
+    y = torch.full((B, S, 256), float("nan"))
+    hN = torch.full((nl, B, 256), float("nan"))
+    parr = (ctypes.c_void_p * (4 * nl))(*[P(t) for t in plist])
+    assert lib.cpc_gru_forward(P(x), None, parr, P(saved), P(fscr), P(y), P(hN), B, S, nl, None) == 0
+    dy = torch.randn(B, S, 256)
+
+    def backward(kind):
+        bscr = torch.full((sizes[2],), float("nan"))
+        dx = torch.full((B, S, 256), float("nan"))
+        grads = [torch.full_like(t, float("nan")) for t in plist]
+        garr = (ctypes.c_void_p * (4 * nl))(*[P(t) for t in grads])
+        if kind == "plain":
+            rc = lib.cpc_gru_backward(P(x), None, parr, P(saved), P(y), P(dy), P(bscr), P(dx), garr, B, S, nl, None)
+        else:
+            n = lib.cpc_gru_coef_floats(B, S, nl)
+            assert n > 0
+            coef = torch.full((n,), float("nan"))
+            assert lib.cpc_gru_backward_coef(None, P(saved), P(y), P(coef), B, S, nl, None) == 0
+            if kind == "coef":
+                rc = lib.cpc_gru_backward_with_coef(P(x), None, parr, P(saved), P(y), P(dy), P(coef), P(bscr), P(dx), garr,
+                                                    B, S, nl, None)
+            else:
+                rc = lib.cpc_gru_backward_streams(P(x), None, parr, P(saved), P(y), P(dy), P(coef), P(bscr), P(dx), garr,
+                                                  B, S, nl, None, ctypes.c_void_p(0x10))
+        assert rc == 0
+        return [dx] + grads
+
+    ref = backward("plain")
+    for kind in ("coef", "streams"):
+        for a, b in zip(ref, backward(kind)):
+            assert torch.equal(a, b), kind
