@@ -22,6 +22,7 @@ _F = ctypes.c_float
 SIGNATURES = {
     "cpc_abi_version": (_I, []),
     "cpc_set_mfma_mode": (_I, [_I]),
+    "cpc_device_error_flags": (_I, [_I]),
     "cpc_conv0_forward": (_I, [_P] * 8 + [_I, _I, _P]),
     "cpc_conv0_backward_scratch_floats": (_L, [_I, _I]),
     "cpc_conv0_backward": (_I, [_P] * 13 + [_I, _I, _P]),
@@ -38,6 +39,7 @@ SIGNATURES = {
     "cpc_encoder_backward_streams": (_I, [_P] * 7 + [_I, _I, _P, _P]),
     "cpc_set_conv_tile": (_I, [_I]),
     "cpc_set_gru_mode": (_I, [_I]),
+    "cpc_set_gru_spin_limit": (_I, [_I]),
     "cpc_gemm_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "cpc_gemm_tn_scratch_floats": (_L, [_I, _I, _I]),
     "cpc_gemm_tn": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),

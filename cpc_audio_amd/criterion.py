@@ -132,10 +132,11 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         batchSize, seqSize, _ = cFeature.size()
         windowSize = seqSize - self.nPredicts
         from . import ops
-        if negatives is None and ops.OVERLAP_DZ and cFeature.is_cuda:
+        step = ops.current()
+        if negatives is None and step is not None and step.overlap and cFeature.is_cuda:
             # the draws and their index preparation depend on nothing the GPU is still computing (encoder, AR): issued
             # on the side stream they run beside the latency-bound recurrence instead of after it
-            main, side = torch.cuda.current_stream(), ops._side_stream(cFeature.device)
+            main, side = torch.cuda.current_stream(), step.side_stream(cFeature.device)
             # (holding them back until the recurrence starts was measured: 4.187 vs 4.162 ms/step -- they disturb its
             # hand-over polling more than they cost beside the first conv layers, where the host-side lead puts them)
             with torch.cuda.stream(side):
@@ -155,6 +156,9 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             losses, acc = InfoNCEScoresFunction.apply(pred, encodedData, ext, perm, row_ptr)
         else:
             heads = [p.weight for p in self.wPrediction.predictors]
+            # dz may be filled late (on the side stream) only if nobody outside this package can read it first: not in
+            # mode 'reverse' (the flip above sits between the criterion and the encoder), not behind a foreign network
+            defer = step is not None and step.overlap and ops.dz_may_be_deferred(cFeature, encodedData)
             losses, acc = InfoNCEFunction.apply(cFeature, encodedData, self.wPrediction.stacked_weight(), ext, perm,
-                                                row_ptr, heads)
+                                                row_ptr, heads, defer)
         return losses.view(1, -1), acc.view(1, -1)

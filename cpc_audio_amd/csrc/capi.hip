@@ -2,26 +2,51 @@
 #include "cpc_common.h"
 #include "cpc_internal.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace cpc {
 int g_mfma_mode = 2;
 
 // Events that order a second stream against the caller's inside the *_streams entry points (timing disabled; created
-// once per device and reused: a wait captures the record that precedes it, so re-recording later is harmless).
-hipEvent_t* stream_events() {
-    static hipEvent_t ev[16][kStreamEvents];
-    static bool made[16] = {false};
+// once per (device, caller stream) and reused: a wait captures the record that precedes it, so re-recording later is
+// harmless).  The pool is keyed by the caller's stream and guarded by a mutex: two host threads driving two streams of
+// one device (nn.DataParallel-style replicas) each get their own events -- with a shared pool one thread's wait could
+// capture the other's record.  Two threads enqueueing on the SAME stream at once is a caller error, as everywhere in HIP.
+hipEvent_t* stream_events(hipStream_t st) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, hipEvent_t*> pools;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!made[dev]) {
-        for (int i = 0; i < kStreamEvents; ++i)
-            if (hipEventCreateWithFlags(&ev[dev][i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        made[dev] = true;
-    }
-    return ev[dev];
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = pools.find({dev, st});
+    if (it != pools.end()) return it->second;
+    hipEvent_t* ev = new hipEvent_t[kStreamEvents];
+    for (int i = 0; i < kStreamEvents; ++i)
+        if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipEventDestroy(ev[j]);
+            delete[] ev;
+            return nullptr;
+        }
+    pools[{dev, st}] = ev;
+    return ev;
 }
 }  // namespace cpc
 
-extern "C" int cpc_abi_version(void) { return 5; }
+extern "C" int cpc_abi_version(void) { return 6; }
+
+// Device-side error flags of the current device, accumulated since they were last cleared:
+//   bit 0  CPC_DEVERR_GRU_POLL_TIMEOUT   a workgroup of the persistent recurrence gave up waiting for another one (its
+//                                        outputs carry NaN from there on)
+//   bit 1  CPC_DEVERR_NEGATIVE_INDEX     cpc_nce_prepare was given a draw outside [0,B) x [0,S) (clamped)
+// Synchronises with the device (two 4-byte reads): for logging points and tests, not for the step path.
+// Returns the mask (>= 0), or a negative number if it cannot be read.
+extern "C" int cpc_device_error_flags(int clear) {
+    unsigned a = 0, b = 0;
+    if (cpc::gru_error_flag_fetch(clear, &a) != 0 || cpc::nce_error_flag_fetch(clear, &b) != 0) return -1;
+    return (int)((a ? 1u : 0u) | (b ? 2u : 0u));
+}
 
 extern "C" int cpc_set_mfma_mode(int mode) {
     CPC_RETURN_IF(mode != 0 && mode != 1 && mode != 2, CPC_ERR_ARG);

@@ -35,9 +35,13 @@ int transpose_batch(const float* const* in, float* const* out, int n, int R, int
 // accuracy); 0: exact-f32 MFMA (NtTile).  Set through cpc_set_mfma_mode().
 extern int g_mfma_mode;
 
-// per-device pool of events for the two-stream entry points: [0..4] encoder backward, [8] GRU backward
+// per-(device, caller stream) pool of events for the two-stream entry points: [0..4] encoder backward, [8] GRU backward
 constexpr int kStreamEvents = 12;
-hipEvent_t* stream_events();
+hipEvent_t* stream_events(hipStream_t caller_stream);
+
+// device-side error words of the translation units that own them (cpc_device_error_flags)
+int gru_error_flag_fetch(int clear, unsigned* out);
+int nce_error_flag_fetch(int clear, unsigned* out);
 
 static inline long align64l(long v) { return (v + 63) & ~63L; }
 

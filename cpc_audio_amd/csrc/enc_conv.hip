@@ -1007,7 +1007,7 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     EncLayout e;
     CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
     void* stream = (void*)st;
-    hipEvent_t* ev = wst != st ? stream_events() : nullptr;      // [0..4] used here
+    hipEvent_t* ev = wst != st ? stream_events(st) : nullptr;      // [0..4] used here
     CPC_RETURN_IF(wst != st && !ev, CPC_ERR_ARG);
     float* colpart = scratch + e.colpart;
     float* tmp = scratch + e.tmp;

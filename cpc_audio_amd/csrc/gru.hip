@@ -184,6 +184,7 @@ struct Gru2Fwd {
     float* hN;                 // (2,B,H)
     float* xh[2];              // persistent launch only: hand-over copies of y[l] (see xtile)
     int B, S;
+    int spin_limit;            // persistent launch only: polling budget of a wave (cpc_set_gru_spin_limit)
 };
 
 __device__ __forceinline__ void mfma_slice(f32x4 (&acc)[3], const float* __restrict__ arow, bool ok,
@@ -302,6 +303,7 @@ struct Gru2Bwd {
     float* dGi[2]; float* dGh[2]; float* DH[2];
     float* xdh[2];             // persistent launch only: hand-over copies of DH[l] (fragment order)
     int B, S;
+    int spin_limit;            // persistent launch only: polling budget of a wave (cpc_set_gru_spin_limit)
 };
 
 // Everything in the gate derivatives that does not depend on dh, for all (b, t, j) at once and in fragment
@@ -454,6 +456,10 @@ __global__ __launch_bounds__(512) void gru2_bwd_kernel(Gru2Bwd p, int s) {
 // pattern -- a NaN -- propagate into the outputs and the loss, and the launch still terminates.
 constexpr unsigned kNotReady = 0xFFFFFFFFu;
 constexpr int kSpinLimit = 1 << 20;
+// Set (bit 0) by a wave that gave up polling: the NaN it lets through reaches the loss, and this says why.  Read and
+// cleared by cpc_device_error_flags() (capi.hip) -- a synchronising call, made by the train loops at their logging
+// points and by the tests, never on the step path.
+static __device__ unsigned g_gru_poll_timeout = 0;
 
 __device__ __forceinline__ float4 load4_coherent(const float* p) {
     const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
@@ -489,6 +495,7 @@ __device__ __forceinline__ void poll_row(const float* __restrict__ row, bool ok,
         for (int ii = 0; ii < NII; ++ii)                          // re-read only what was incomplete
             if (ok && !ready4(a[ii])) a[ii] = load4_coherent(row + kXStride * ii);
     }
+    if (budget <= 0) atomicOr(&g_gru_poll_timeout, 1u);
     if (!ok) {
 #pragma unroll
         for (int ii = 0; ii < NII; ++ii) a[ii] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -611,7 +618,7 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
             inv = 1.0f / (sa * split_gate_weights<NII>(bw, bh));      // powers of two: exact
         }
         const float* __restrict__ xsrc = (recurrent ? p.xh[LAYER] : p.xh[0]) + xpos(i, koff);
-        int budget = kSpinLimit;
+        int budget = p.spin_limit;
         for (int t = 0; t < S; ++t) {
             float4 a[NII];
             if (recurrent) {
@@ -759,7 +766,7 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
         const float* __restrict__ xsrc = p.xdh[sl] + lane_off;
         float4 cf[NU][3];
         if (!recurrent) load_coef<NU>(cf, c0, c1, c2, xtile(S - 1, id.tile, id.ntiles, kH) + lane_off);
-        int budget = kSpinLimit;
+        int budget = p.spin_limit;
         for (int t = S - 1; t >= 0; --t) {
             const int ts = recurrent ? t + 1 : t;                 // step whose gate gradients are this wave's operand
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -894,6 +901,7 @@ static bool gru_layout(int B, int S, int nl, GruLayout& g) {
 using namespace cpc;
 
 namespace {
+int g_gru_spin_limit = kSpinLimit;
 int g_gru_mode = 2;        // 0: per-step launches; 1: persistent two-layer recurrence when the grid fits the device, exact-f32
                            // MFMAs; 2 (default): the same with the forward's recurrent products on the fp16 pipe (two-piece
                            // split, 3 MFMAs per product; exact-f32 when the caller supplies h0, whose size is unknown)
@@ -908,6 +916,28 @@ bool fits_resident(K kernel, int nblocks) {
     return (long)nblocks <= (long)cus * occ;
 }
 }  // namespace
+
+namespace cpc {
+// bit 0 of cpc_device_error_flags(): a persistent-recurrence wave ran out of its polling budget
+int gru_error_flag_fetch(int clear, unsigned* out) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_gru_poll_timeout), sizeof(v)) != hipSuccess) return CPC_ERR_ARG;
+    if (clear && v) {
+        const unsigned zero = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_gru_poll_timeout), &zero, sizeof(zero)) != hipSuccess) return CPC_ERR_ARG;
+    }
+    *out = v;
+    return 0;
+}
+}  // namespace cpc
+
+// Polling budget of the persistent recurrence (re-reads per wave over the whole launch, ~1 us each) before it gives up,
+// flags CPC_DEVERR_GRU_POLL_TIMEOUT and lets NaN through.  limit < 0 restores the default (2^20, about a second -- far
+// beyond any co-scheduled side-stream kernel of the train step).  Tests use 0 to drive the error path.
+extern "C" int cpc_set_gru_spin_limit(int limit) {
+    g_gru_spin_limit = limit < 0 ? kSpinLimit : limit;
+    return 0;
+}
 
 extern "C" int cpc_set_gru_mode(int mode) {
     if (mode != 0 && mode != 1 && mode != 2) return CPC_ERR_ARG;
@@ -946,7 +976,7 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
         }
         p.wih1 = params[4]; p.bih1 = params[6];
         p.y[0] = saved + g.Y[0]; p.y[1] = y;
-        p.hN = hN; p.B = B; p.S = S;
+        p.hN = hN; p.B = B; p.S = S; p.spin_limit = g_gru_spin_limit;
         p.xh[0] = p.xh[1] = nullptr;
         const int nblocks = 32 * cdiv(B, 16);
         const bool h2 = g_gru_mode == 2 && !h0;
@@ -1060,7 +1090,7 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
         float* dGh_[2] = {scratch + g.dGh, scratch + g.dGh2};
         float* DH_[2] = {scratch + g.DH, scratch + g.DH2};
         Gru2Bwd p;
-        p.dy = dy; p.B = B; p.S = S;
+        p.dy = dy; p.B = B; p.S = S; p.spin_limit = g_gru_spin_limit;
         const float* yl[2] = {saved + g.Y[0], y};
         const float* h0l[2] = {h0, h0 ? h0 + (long)B * kH : nullptr};
         int rc = 0;
@@ -1093,7 +1123,7 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
         rc = nt_gemm(plain_rows(dGi_[0], M, kG), wihT_[0], kG, nullptr, dx, kH, kH, kG, st);
         if (rc) return rc;
         if (wst != st) {
-            hipEvent_t* ev = stream_events();
+            hipEvent_t* ev = stream_events(st);
             CPC_RETURN_IF(!ev, CPC_ERR_ARG);
             if (hipEventRecord(ev[8], st) != hipSuccess || hipStreamWaitEvent(wst, ev[8], 0) != hipSuccess) return CPC_ERR_ARG;
         }

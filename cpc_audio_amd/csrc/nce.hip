@@ -321,6 +321,10 @@ __global__ __launch_bounds__(64) void nce_gather_rows_kernel(const float* __rest
 // Turns the two draws of sampleClean (criterion.py:181-189; int64, flat (b,n,t) order) into what the
 // kernels consume: ext[(b*W+t)*N + n] = ((seqIdx + t) mod S) + batchIdx*S (criterion.py:191-199), and the
 // destination-sorted candidate slot list (perm, row_ptr) used by the backward gather.
+// Set (bit 0) when a caller-supplied draw is outside its range (batchIdx in [0,B), seqIdx in [0,S)); the offending index
+// is clamped so that nothing is read or counted out of bounds.  Read through cpc_device_error_flags() (capi.hip).
+static __device__ unsigned g_nce_bad_index = 0;
+
 __global__ __launch_bounds__(256) void nce_index_kernel(const long* __restrict__ batchIdx,
                                                         const long* __restrict__ seqIdx,
                                                         int* __restrict__ ext, int* __restrict__ dest,
@@ -334,7 +338,13 @@ __global__ __launch_bounds__(256) void nce_index_kernel(const long* __restrict__
     int d;
     if (j < N) {
         const long flat = ((long)b * N + j) * W + t;
-        d = (int)((seqIdx[flat] + t) % S) + (int)batchIdx[flat] * S;
+        long si = seqIdx[flat], bi = batchIdx[flat];
+        if (si < 0 || si >= S || bi < 0 || bi >= B) {
+            atomicOr(&g_nce_bad_index, 1u);
+            si = si < 0 ? 0 : (si >= S ? S - 1 : si);
+            bi = bi < 0 ? 0 : (bi >= B ? B - 1 : bi);
+        }
+        d = (int)((si + t) % S) + (int)bi * S;
         ext[(long)bt * N + j] = d;
     } else {
         d = b * S + t + (j - N) + 1;                    // positive of head j-N (criterion.py:210-215)
@@ -463,6 +473,18 @@ static int nce_scores_backward(const NceLayout& n, const float* pred, const floa
     CPC_LAUNCH_CHECK();
     if (!do_dz) return 0;                                          // dz path launched separately (cpc_nce_backward_dz)
     return nce_dz_path(n, pred, saved, gloss, perm, row_ptr, scratch, gscale_dz, dz, B, S, K, N, st_dz, st_dz != st);
+}
+
+// bit 1 of cpc_device_error_flags(): cpc_nce_prepare saw an out-of-range negative index
+int nce_error_flag_fetch(int clear, unsigned* out) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_nce_bad_index), sizeof(v)) != hipSuccess) return CPC_ERR_ARG;
+    if (clear && v) {
+        const unsigned zero = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_nce_bad_index), &zero, sizeof(zero)) != hipSuccess) return CPC_ERR_ARG;
+    }
+    *out = v;
+    return 0;
 }
 
 }  // namespace cpc

@@ -13,7 +13,7 @@ Two buckets of one persistent flat buffer, because the backward pass ends with t
 step) and everything else -- prediction heads and auto-regressive network, 55 % of the values -- is final before it
 starts: ``begin()`` (hooked to the start of the encoder's backward by the package's train loops, ops.
 pre_encoder_backward) sends that ``early`` bucket off on the side stream while the encoder's backward runs, and
-the call after backward() sends the rest, waits for both and writes the sums back.  Every rank issues the two
+the call after backward() sends the rest, waits for both and writes the sums back (``abort()`` after a failed step).  Every rank issues the two
 collectives in the same order; without ``begin()`` the call reduces the whole buffer at once.
 """
 import torch
@@ -62,21 +62,21 @@ class FlatGradAllReduce:
             if p.grad is None:
                 v.zero_()
 
-    def begin(self):
-        """Start reducing the ``early`` bucket.  On a GPU the packing and the collective are ordered after everything
-        the side stream (ops.py) holds -- the heads' gradient is formed there -- and after the current stream's work
-        up to now; the current stream does not wait for them."""
+    def begin(self, step=None):
+        """Start reducing the ``early`` bucket.  ``step``: the ops.StepContext of the train loop (this is hooked to its
+        ``pre_encoder_backward``).  On a GPU the packing and the collective are ordered after everything the context's
+        side stream holds -- the heads' gradient is formed there -- and after the current stream's work up to now; the
+        current stream does not wait for them."""
         if not self._active() or not self.early or self._pending is not None:
             return
         ref = self.early[0]
         bucket = None
-        if ref.is_cuda:
-            from . import ops
-            main, side = torch.cuda.current_stream(ref.device), ops._side_stream(ref.device)
+        if ref.is_cuda and step is not None:
+            main, side = torch.cuda.current_stream(ref.device), step.side_stream(ref.device)
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
-            for e in ops._wgrad_events:              # the recurrence's gradients are formed on the weight-gradient stream
+            for e in step.wgrad_events:              # the recurrence's gradients are formed on the weight-gradient stream
                 side.wait_event(e)
             with torch.cuda.stream(side):
                 self._pack(self.early)
@@ -89,6 +89,16 @@ class FlatGradAllReduce:
             self._pack(self.early)
             bucket = self.buf[:self.n_early]
             self._pending = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def abort(self):
+        """A step raised after begin(): let the early bucket's collective finish (every rank issued it; dropping the
+        handle would leave the next step waiting on a stale one and copying last step's sums into .grad) and forget it."""
+        pending, self._pending = self._pending, None
+        if pending is not None:
+            try:
+                pending.wait()
+            except Exception:                                  # the group may be the thing that failed
+                pass
 
     def __call__(self):
         if not self._active():

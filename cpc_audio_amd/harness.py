@@ -108,26 +108,24 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
     sum_loss = sum_acc = None
     n_iter, t0, n_ex = 0, time.perf_counter(), 0
     ones = None
+    step_ctx = ops.StepContext(overlap=True)
+    if allreduce is not None:
+        step_ctx.pre_encoder_backward.append(allreduce.begin)
     for step, (batch, label) in enumerate(loader):
         batch, label = _to_device(batch, device), _to_device(label, device)
         n_ex += batch.size(0)
-        ops.OVERLAP_DZ = True                             # no foreign consumer of dz in this graph (ops.py)
-        if allreduce is not None:
-            ops.pre_encoder_backward.append(allreduce.begin)
         try:
-            c_feature, encoded, label = model(batch, label)
-            all_losses, all_acc = criterion(c_feature, encoded, label)
-            if ones is None or ones.shape != all_losses.shape or ones.device != all_losses.device:
-                ones = torch.ones_like(all_losses)
-            torch.autograd.backward([all_losses], [ones])  # = all_losses.sum().backward() (train.py:85-87), 3 kernels less
-            ops.wait_side_stream()
+            with step_ctx as sc:                          # side streams for the dz path / weight gradients (ops.StepContext)
+                c_feature, encoded, label = model(batch, label)
+                all_losses, all_acc = criterion(c_feature, encoded, label)
+                if ones is None or ones.shape != all_losses.shape or ones.device != all_losses.device:
+                    ones = torch.ones_like(all_losses)
+                torch.autograd.backward([all_losses], [ones])  # = all_losses.sum().backward() (train.py:85-87), 3 kernels less
+                sc.wait()
         except BaseException:
-            ops.abandon_side_work()
-            raise
-        finally:
-            ops.OVERLAP_DZ = False
             if allreduce is not None:
-                ops.pre_encoder_backward.remove(allreduce.begin)
+                allreduce.abort()
+            raise
         if allreduce is not None:
             allreduce()
         optimizer.step()
@@ -146,6 +144,9 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
         scheduler.step()
     if n_iter == 0:
         return {"iter": 0}
+    if device.type == "cuda":
+        with torch.cuda.device(device):
+            ops.check_device_errors()       # the averages below synchronise anyway: the place to look at the device flags
     return {"locLoss_train": (sum_loss / n_iter).cpu().numpy(), "locAcc_train": (sum_acc / n_iter).cpu().numpy(),
             "iter": n_iter}
 

@@ -34,62 +34,135 @@ def _ptrs(ts):
 
 _layout_cache = {}
 
-# ---- side stream for the criterion's dz path (InfoNCEFunction.backward) -------------------------------------------
+
+def check_device_errors(clear=True):
+    """Raise if a kernel of this library flagged an error on the current device since the last check (include/cpc_hip.h,
+    cpc_device_error_flags): a persistent-recurrence workgroup that gave up polling, a negative index out of range.
+    Synchronises with the device -- the train loops call it where they already synchronise (logging, epoch end)."""
+    mask = _lib.get().cpc_device_error_flags(1 if clear else 0)
+    if mask < 0:
+        raise _lib.CpcHipError("cpc_device_error_flags could not read the device flags")
+    what = []
+    if mask & 1:
+        what.append("a workgroup of the persistent GRU recurrence timed out waiting for its neighbours "
+                    "(outputs contain NaN from that step on)")
+    if mask & 2:
+        what.append("cpc_nce_prepare received negative-sample indices outside [0,B) x [0,S) (they were clamped)")
+    if what:
+        raise _lib.CpcHipError("device-side error: " + "; ".join(what))
+
+# ---- stream-level overlap inside one train step ---------------------------------------------------------------------
 # The candidate-row + sorted-gather half of the criterion's backward depends only on the upstream loss gradients, and
 # the network that consumes dc (the persistent GRU backward: 128 workgroups, latency-bound) leaves most of the chip
-# idle.  With OVERLAP_DZ the dz path is launched on a side stream; every Function of this package that can be the
-# next consumer of dz waits for it (wait_side_stream) before returning / starting.  It is switched on by the package's
-# own train loops (train.Trainer, harness.train_epoch), whose autograd graph has no foreign op between the criterion
-# and the encoder; code that reads dz on the current stream through other ops must leave it off (the default).
-OVERLAP_DZ = False
-WGRAD_STREAM = True     # with OVERLAP_DZ: the encoder's weight-gradient GEMMs on their own stream (ops.EncoderFunction.backward)
-_side_streams = {}
-_side_events = []       # work the next backward op depends on (dz)
-_late_events = []       # work only the optimiser reads (the prediction heads' weight gradient)
-_wgrad_events = []      # the same on the weight-gradient stream (stream 2: the recurrence's weight / bias gradients)
-_deferred = []          # side-stream launches held back until the AR backward is in flight (it needs whole CUs: its
-                        # 768-thread workgroups cannot squeeze in beside a chip full of gather blocks)
+# idle; the weight-gradient GEMMs hang off the dx chain.  A train loop that wants them on side streams owns a
+# StepContext and runs forward + backward inside ``with ctx:``.  All overlap state (streams, events, launches held back)
+# lives on that object -- nothing is module-global -- so two loops on two threads / devices (nn.DataParallel-style
+# replicas, SURVEY.md section 8b) do not see each other.  The Functions pick the context up in forward (on the caller's
+# thread) and carry it to backward on their autograd ctx: autograd runs backward on its own worker thread.
+# Without an active context every Function is single-stream.
+import threading
+
+_tls = threading.local()
 
 
-pre_encoder_backward = []   # callables run when the encoder's backward starts: every other gradient of the step is
-                            # final (or queued on the side stream) by then -- dist.FlatGradAllReduce.begin hooks here
+class StepContext:
+    """Overlap state of one train loop.  ``overlap``: the criterion's dz path and head gradient on a side stream;
+    ``wgrad_stream`` (with overlap): the encoder's / recurrence's weight-gradient GEMMs on their own stream."""
+
+    def __init__(self, overlap=True, wgrad_stream=True):
+        self.overlap = bool(overlap)
+        self.wgrad_stream = bool(wgrad_stream)
+        self._streams = {}
+        self.side_events = []       # work the next backward op depends on (dz)
+        self.late_events = []       # work only the optimiser reads (the prediction heads' weight gradient)
+        self.wgrad_events = []      # the same on the weight-gradient stream (the recurrence's weight / bias gradients)
+        self.deferred = []          # side-stream launches held back until the AR backward is in flight (it needs whole
+        #                             CUs: its 768-thread workgroups cannot squeeze in beside a chip full of gather blocks)
+        self.pre_encoder_backward = []   # callables(ctx) run when the encoder's backward starts: every other gradient
+        #                             of the step is final (or queued on the side stream) by then -- FlatGradAllReduce.begin
+
+    def side_stream(self, device, which=0):
+        """which = 0: the criterion's stream (negative draws, dz path, head gradient, early all-reduce bucket);
+        1: forward-only preparation of the recurrence's backward (it must not queue in front of the negative draws);
+        2: weight gradients."""
+        key = (torch.device(device).index, which)
+        st = self._streams.get(key)
+        if st is None:
+            st = self._streams[key] = torch.cuda.Stream(device=device)
+        return st
+
+    def abandon(self):
+        """After an exception inside an overlapped step: forget the launches still held back and the events not yet
+        waited for (what was already enqueued simply completes), so that the next step does not start from stale state."""
+        del self.deferred[:]
+        del self.side_events[:]
+        del self.late_events[:]
+        del self.wgrad_events[:]
+
+    def launch_deferred(self):
+        while self.deferred:
+            self.deferred.pop(0)()
+
+    def wait(self, final=True, wgrad=None):
+        """Make the current stream wait for everything launched (or still held) for the side streams.  ``final=False``
+        (used between the backward ops) leaves out what only the optimiser reads; the owner calls this with
+        final=True after backward() and before touching any ``.grad``.  ``wgrad`` (default: same as ``final``): also
+        wait for the weight-gradient stream."""
+        self.launch_deferred()
+        cur = torch.cuda.current_stream()
+        while self.side_events:
+            cur.wait_event(self.side_events.pop())
+        while final and self.late_events:
+            cur.wait_event(self.late_events.pop())
+        while (final if wgrad is None else wgrad) and self.wgrad_events:
+            cur.wait_event(self.wgrad_events.pop())
+
+    def __enter__(self):
+        self._prev = getattr(_tls, "ctx", None)
+        _tls.ctx = self
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _tls.ctx = self._prev
+        if et is not None:
+            self.abandon()
+        return False
 
 
-def _side_stream(device, which=0):
-    """which = 0: the criterion's stream (negative draws, dz path, head gradient, early all-reduce bucket);
-    1: forward-only preparation of the recurrence's backward (it must not queue in front of the negative draws)."""
-    st = _side_streams.get((device, which))
-    if st is None:
-        st = _side_streams[(device, which)] = torch.cuda.Stream(device=device)
-    return st
+def current():
+    """The StepContext active on this thread (None: single-stream)."""
+    return getattr(_tls, "ctx", None)
 
 
-def abandon_side_work():
-    """After an exception inside an overlapped step: forget the launches still held back and the events not yet waited
-    for (what was already enqueued simply completes), so that the next step does not start from stale state."""
-    del _deferred[:]
-    del _side_events[:]
-    del _late_events[:]
-    del _wgrad_events[:]
+def _overlap(step):
+    return step is not None and step.overlap
 
 
-def launch_deferred():
-    while _deferred:
-        _deferred.pop(0)()
+def _wait(step, **kw):
+    if step is not None:
+        step.wait(**kw)
 
 
-def wait_side_stream(final=True, wgrad=None):
-    """Make the current stream wait for everything this package has launched (or still holds) for its side streams.
-    ``final=False`` (used between the backward ops) leaves out what only the optimiser reads; whoever switches
-    OVERLAP_DZ on calls this with final=True after backward() and before touching any ``.grad``.
-    ``wgrad`` (default: same as ``final``): also wait for the weight-gradient stream."""
-    launch_deferred()
-    while _side_events:
-        torch.cuda.current_stream().wait_event(_side_events.pop())
-    while final and _late_events:
-        torch.cuda.current_stream().wait_event(_late_events.pop())
-    while (final if wgrad is None else wgrad) and _wgrad_events:
-        torch.cuda.current_stream().wait_event(_wgrad_events.pop())
+_VIEW_NODES = ("PermuteBackward0", "TransposeBackward0", "ViewBackward0", "UnsafeViewBackward0", "AliasBackward0")
+_OWN_WAITING_NODES = ("GruFunctionBackward", "TransformerLayerFunctionBackward")
+
+
+def dz_may_be_deferred(c, z):
+    """Whether InfoNCEFunction.backward may hand autograd a dz that is filled later, on the side stream.  True only
+    when this package can prove nobody reads it earlier: z reaches EncoderFunction through pure views (its backward
+    waits first), and the other consumer of z -- the network that made c -- ends in one of this package's Functions
+    (their backward waits before returning dx, which autograd then adds to dz).  Anything else -- criterion mode
+    'reverse' puts a torch.flip between the criterion and the encoder, a foreign autoregressor -- gets dz on the
+    current stream right away."""
+    fn = z.grad_fn
+    while fn is not None and type(fn).__name__ in _VIEW_NODES:
+        fn = fn.next_functions[0][0]
+    if fn is not None and type(fn).__name__ != "EncoderFunctionBackward":
+        return False
+    fn = c.grad_fn
+    while fn is not None and type(fn).__name__ in _VIEW_NODES + ("FlipBackward0", "SliceBackward0"):
+        fn = fn.next_functions[0][0]
+    return fn is None or type(fn).__name__ in _OWN_WAITING_NODES
 
 # Parity tests set KEEP_DEBUG = True to look at the encoder's saved activations (the ReLU
 # masks of the device path, see oracle/cpc_oracle._ReluTieAware).  Never used by the product.
@@ -129,6 +202,7 @@ class EncoderFunction(torch.autograd.Function):
                                               _stream()), "encoder_forward")
         ctx.save_for_backward(wave, saved, z, *params)
         ctx.dims = (B, L, sizes[2])
+        ctx.step = current()
         if KEEP_DEBUG:
             debug_last["encoder"] = (saved, sizes, z)
         return z
@@ -138,25 +212,27 @@ class EncoderFunction(torch.autograd.Function):
         lib = _lib.get()
         # dz may carry the criterion's side-stream part.  The weight-gradient stream is not waited for here: the call
         # below runs its own GEMMs there and joins it before it returns.
-        wait_side_stream(final=False)
-        for hook in pre_encoder_backward:
-            hook()
+        step = ctx.step
+        _wait(step, final=False)
+        if step is not None:
+            for hook in step.pre_encoder_backward:
+                hook(step)
         wave, saved, z, *params = ctx.saved_tensors
         B, L, nscr = ctx.dims
         dz = dz.contiguous()
         with torch.cuda.device(wave.device):
             scratch = torch.empty(nscr, device=wave.device, dtype=torch.float32)
             grads = [torch.empty_like(p) for p in params]
-            if OVERLAP_DZ and WGRAD_STREAM:
+            if _overlap(step) and step.wgrad_stream:
                 # the weight-gradient GEMMs beside the dx chain (its norm backwards stream, conv0's backward is
                 # VALU-bound: both leave the matrix pipes idle); the call joins the two streams before it returns
                 lib.check(lib.cpc_encoder_backward_streams(_p(wave), _ptrs(params), _p(saved), _p(z), _p(dz), _p(scratch),
                                                            _ptrs(grads), B, L, _stream(),
-                                                           _side_stream(wave.device, 2).cuda_stream), "encoder_backward")
+                                                           step.side_stream(wave.device, 2).cuda_stream), "encoder_backward")
             else:
                 lib.check(lib.cpc_encoder_backward(_p(wave), _ptrs(params), _p(saved), _p(z), _p(dz), _p(scratch),
                                                    _ptrs(grads), B, L, _stream()), "encoder_backward")
-        wait_side_stream()                     # the last backward op: everything on the side stream is due now
+        _wait(step)                            # the last backward op: everything on the side stream is due now
         return (None, *grads)
 
 
@@ -183,14 +259,15 @@ class GruFunction(torch.autograd.Function):
             hN = torch.empty(nl, B, _HID, device=x.device, dtype=torch.float32)
             lib.check(lib.cpc_gru_forward(_p(x), _p(h0c), _ptrs(params), _p(saved), _p(scratch), _p(y), _p(hN),
                                           B, S, nl, _stream()), "gru_forward")
-            # train loops (OVERLAP_DZ): the forward-only part of the two-layer backward runs now, on the side stream,
+            # train loops (an overlapping StepContext): the forward-only part of the two-layer backward runs now, on the side stream,
             # beside the criterion's forward, instead of between the criterion's backward and the recurrence
             coef = None
-            if OVERLAP_DZ and nl == 2 and any(ctx.needs_input_grad):
+            step = ctx.step = current()
+            if _overlap(step) and nl == 2 and any(ctx.needs_input_grad):
                 ncoef = lib.cpc_gru_coef_floats(B, S, nl)
                 if ncoef > 0:
                     coef = torch.empty(ncoef, device=x.device, dtype=torch.float32)
-                    main, side = torch.cuda.current_stream(), _side_stream(x.device, 1)
+                    main, side = torch.cuda.current_stream(), step.side_stream(x.device, 1)
                     done = torch.cuda.Event()
                     done.record(main)
                     side.wait_event(done)
@@ -221,12 +298,13 @@ class GruFunction(torch.autograd.Function):
             grads = [torch.empty_like(p) for p in params]
             if ctx.coef is not None:
                 torch.cuda.current_stream().wait_event(ctx.coef_ready)
-            split = OVERLAP_DZ and WGRAD_STREAM and nl == 2 and ctx.leaves is not None
+            step = ctx.step
+            split = _overlap(step) and step.wgrad_stream and nl == 2 and ctx.leaves is not None
             if split:
                 # dx on this stream; the weight / bias gradients -- read by nobody before the optimiser -- on the
                 # weight-gradient stream, beside the start of the encoder's backward.  They are added to .grad there
                 # (autograd gets None for them: it would accumulate on this stream, before they exist).
-                wst = _side_stream(x.device, 2)
+                wst = step.side_stream(x.device, 2)
                 lib.check(lib.cpc_gru_backward_streams(_p(x), _p(ctx.h0), _ptrs(params), _p(saved), _p(y), _p(dy),
                                                        _p(ctx.coef), _p(scratch), _p(dx), _ptrs(grads), B, S, nl,
                                                        _stream(), wst.cuda_stream), "gru_backward")
@@ -243,14 +321,14 @@ class GruFunction(torch.autograd.Function):
                     t.record_stream(wst)
                 ev = torch.cuda.Event()
                 ev.record(wst)
-                _wgrad_events.append(ev)
+                step.wgrad_events.append(ev)
                 grads = [None] * len(grads)
             else:
                 lib.check(lib.cpc_gru_backward_with_coef(_p(x), _p(ctx.h0), _ptrs(params), _p(saved), _p(y), _p(dy),
                                                          _p(ctx.coef), _p(scratch), _p(dx), _ptrs(grads), B, S, nl,
                                                          _stream()), "gru_backward")
         ctx.coef = None                # its hand-over buffers are consumed: a second backward through this node recomputes
-        wait_side_stream(final=False)  # starts the criterion's deferred dz path beside the recurrence just launched, and makes
+        _wait(ctx.step, final=False)   # starts the criterion's deferred dz path beside the recurrence just launched, and makes
         #                         this stream wait for it: autograd adds dx to that dz next
         return (dx, None, *grads)
 
@@ -292,11 +370,11 @@ def prepare_negatives(batchIdx, seqIdx, B, S, K, N):
 class InfoNCEFunction(torch.autograd.Function):
     """c, z (B,S,256), wall (K*256,256), ext (B,W,N) int32, perm, row_ptr -> losses (K), acc (K).
     ``heads``: optionally the K leaf parameters (256,256) that ``wall`` is the row-wise concatenation of.  With
-    OVERLAP_DZ their gradient is then formed on the side stream as well and accumulated into ``.grad`` directly
+    an overlapping StepContext their gradient is then formed on the side stream as well and accumulated into ``.grad`` directly
     (bit-identical values; ``wall`` itself receives no gradient), which takes that GEMM off the path to the encoder."""
 
     @staticmethod
-    def forward(ctx, c, z, wall, ext, perm, row_ptr, heads=None):
+    def forward(ctx, c, z, wall, ext, perm, row_ptr, heads=None, defer_dz=False):
         _require_cuda(c, "InfoNCEFunction")
         lib = _lib.get()
         B, S, H = c.shape
@@ -317,6 +395,8 @@ class InfoNCEFunction(torch.autograd.Function):
         ctx.dims = (B, S, K, N, sizes[2])
         ctx.set_materialize_grads(False)       # no zero-filled gradient for the accuracies
         ctx.heads = list(heads) if heads is not None else None
+        ctx.step = current()
+        ctx.defer_dz = bool(defer_dz)          # the caller's proof that nobody reads dz early (dz_may_be_deferred)
         if ctx.heads is not None and (len(ctx.heads) != K or any(h.shape != (_HID, _HID) for h in ctx.heads)):
             raise ValueError("InfoNCEFunction: heads must be the K (256,256) weights stacked in wall")
         ctx.mark_non_differentiable(acc)
@@ -331,8 +411,9 @@ class InfoNCEFunction(torch.autograd.Function):
         with torch.cuda.device(c.device):
             scratch = torch.empty(nscr, device=c.device, dtype=torch.float32)
             dc, dz, dwall = torch.empty_like(c), torch.empty_like(z), torch.empty_like(wall)
-            if OVERLAP_DZ:
-                main, side = torch.cuda.current_stream(), _side_stream(c.device)
+            step = ctx.step
+            if _overlap(step):
+                main, side = torch.cuda.current_stream(), step.side_stream(c.device)
                 ready = torch.cuda.Event()
                 heads = ctx.heads if ctx.heads is not None and any(h.requires_grad for h in ctx.heads) else None
                 # dc (and dwall, unless the leaf weights are known) now, on this stream; dz = NULL leaves the dz path out
@@ -350,11 +431,19 @@ class InfoNCEFunction(torch.autograd.Function):
                         t.record_stream(side)                     # the allocator must not recycle them early
                     ev = torch.cuda.Event()
                     ev.record(side)
-                    _side_events.append(ev)
-                _deferred.append(dz_path)
+                    step.side_events.append(ev)
+                if ctx.defer_dz:
+                    step.deferred.append(dz_path)
+                else:
+                    # somebody this package does not know may read dz as soon as this backward returns (criterion mode
+                    # 'reverse': a torch.flip; a foreign autoregressor): it is formed now, on this stream
+                    lib.check(lib.cpc_nce_backward_dz(_p(z), _p(ext), _p(perm), _p(row_ptr), _p(saved), _p(gloss),
+                                                      _p(scratch), _p(dz), B, S, K, N, main.cuda_stream), "nce_backward_dz")
+                    ready.record(main)         # the head gradient on the side stream reads the same scratch
                 if heads:
                     dheads = dwall
                     def dwall_path():     # ... and the head-weight gradient after it: only the optimiser reads it
+                        side.wait_event(ready)
                         with torch.cuda.stream(side):
                             lib.check(lib.cpc_nce_backward_dwall(_p(c), _p(scratch), _p(dheads), B, S, K, N,
                                                                  side.cuda_stream), "nce_backward_dwall")
@@ -372,14 +461,14 @@ class InfoNCEFunction(torch.autograd.Function):
                             t.record_stream(side)
                         ev = torch.cuda.Event()
                         ev.record(side)
-                        _late_events.append(ev)
-                    _deferred.append(dwall_path)
+                        step.late_events.append(ev)
+                    step.deferred.append(dwall_path)
                     dwall = None
             else:
                 lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
                                                _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
                                                _stream()), "nce_backward")
-        return dc, dz, dwall, None, None, None, None
+        return dc, dz, dwall, None, None, None, None, None
 
 
 class InfoNCEScoresFunction(torch.autograd.Function):
@@ -452,6 +541,7 @@ class TransformerLayerFunction(torch.autograd.Function):
         if KEEP_DEBUG:                      # parity tests read the FFN's ReLU mask (oracle _ReluTieAware)
             debug_last.setdefault("transformer", []).append((saved, sizes))
         ctx.has_rel = params[4] is not None
+        ctx.step = current()
         ctx.save_for_backward(x, saved, *[p for p in params if p is not None])
         ctx.dims = (B, S, sizes[2])
         return out
@@ -469,5 +559,5 @@ class TransformerLayerFunction(torch.autograd.Function):
             grads = [None if p is None else torch.empty_like(p) for p in params]
             lib.check(lib.cpc_transformer_layer_backward(_p(x), _ptrs(params), _p(saved), _p(dy), _p(scratch), _p(dx),
                                                          _ptrs(grads), B, S, _stream()), "transformer_layer_backward")
-        wait_side_stream(final=False)
+        _wait(ctx.step, final=False)
         return (dx, *grads)

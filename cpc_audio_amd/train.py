@@ -44,6 +44,9 @@ class Trainer:
         self.optimizer = Adam(params, lr=lr, betas=betas, eps=eps)      # train.py:335-337; one launch per step on the GPU
         enc = {id(p) for p in model.gEncoder.parameters()} if hasattr(model, "gEncoder") else set()
         self.allreduce = FlatGradAllReduce(params, early=[p for p in params if id(p) not in enc] if enc else None)
+        from . import ops
+        self.ctx = ops.StepContext(overlap=True)
+        self.ctx.pre_encoder_backward.append(self.allreduce.begin)
 
     def _ones_like(self, t):
         o = getattr(self, "_ones", None)
@@ -52,21 +55,18 @@ class Trainer:
         return o
 
     def step(self, batchData, label, negatives=None):
-        from . import ops
-        ops.OVERLAP_DZ = True        # this loop's graph has no foreign consumer of dz between criterion and encoder
-        ops.pre_encoder_backward.append(self.allreduce.begin)
+        # the overlap state (side streams, events, launches held back) lives on this Trainer's StepContext: two Trainers
+        # on two threads / devices do not share any
         try:
-            c_feature, encoded_data, label = self.model(batchData, label)
-            allLosses, allAcc = self.criterion(c_feature, encoded_data, label, negatives=negatives)
-            # allLosses.sum().backward() (train.py:85-87) without the sum / fill / expand kernels: d sum / d loss_k = 1
-            torch.autograd.backward([allLosses], [self._ones_like(allLosses)])
-            ops.wait_side_stream()
+            with self.ctx as step:
+                c_feature, encoded_data, label = self.model(batchData, label)
+                allLosses, allAcc = self.criterion(c_feature, encoded_data, label, negatives=negatives)
+                # allLosses.sum().backward() (train.py:85-87) without the sum / fill / expand kernels: d sum / d loss_k = 1
+                torch.autograd.backward([allLosses], [self._ones_like(allLosses)])
+                step.wait()
         except BaseException:
-            ops.abandon_side_work()
+            self.allreduce.abort()
             raise
-        finally:
-            ops.OVERLAP_DZ = False
-            ops.pre_encoder_backward.remove(self.allreduce.begin)
         self.allreduce()
         self.optimizer.step()
         self.optimizer.zero_grad()

@@ -38,6 +38,18 @@ int cpc_abi_version(void);
  *     GEMMs (projections, heads, weight gradients of the AR / criterion) run as in mode 1. */
 int cpc_set_mfma_mode(int mode);
 
+/* Device-side error flags of the current device, accumulated since they were last cleared (clear != 0 clears them):
+ *   CPC_DEVERR_GRU_POLL_TIMEOUT  a workgroup of the persistent recurrence (cpc_gru_forward / _backward) gave up
+ *                                waiting for another one; its outputs carry NaN from that step on
+ *   CPC_DEVERR_NEGATIVE_INDEX    cpc_nce_prepare was handed a draw outside batchIdx in [0,B) / seqIdx in [0,S)
+ *                                (criterion.py:181-189 draws [0,B) and [1,S)); the index was clamped
+ * The reference raises Python exceptions for such things; kernels cannot, so the wrapper (ops.check_device_errors) turns
+ * the mask into a RuntimeError.  The call synchronises with the device: logging points and tests, not the step path.
+ * Returns the mask (>= 0) or a negative number if the flags cannot be read. */
+#define CPC_DEVERR_GRU_POLL_TIMEOUT 1
+#define CPC_DEVERR_NEGATIVE_INDEX 2
+int cpc_device_error_flags(int clear);
+
 /* ---------------------------------------------------------------- encoder ----
  * CPCEncoder.forward, cpc/model.py:99-105:  5 x relu(ChannelNorm(conv_i(x))).
  * ChannelNorm: cpc/model.py:50-58 (mean / UNBIASED variance over channels, eps 1e-5).
@@ -97,6 +109,9 @@ int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part, float* dW
  * recurrent products on the fp16 matrix pipe (operands split into two fp16 pieces, three MFMAs per product, fp32
  * accumulate: differences at the 1e-7 level; exact-f32 products whenever the caller supplies h0). */
 int cpc_set_gru_mode(int mode);
+/* Polling budget of one wave of the persistent recurrence (re-reads over the whole launch) before it gives up and
+ * flags CPC_DEVERR_GRU_POLL_TIMEOUT; limit < 0 restores the default (2^20).  Tests use 0 to drive the error path. */
+int cpc_set_gru_spin_limit(int limit);
 
 /* Tuning / test knob: rows per block of the conv GEMM tiles (0 = auto, 32, 64, 128). */
 int cpc_set_conv_tile(int bm);

@@ -205,12 +205,30 @@ def gru_forward(p: Dict[str, Tensor], x: Tensor, n_levels: int = 2,
     return inp, torch.stack(h_last, dim=0)
 
 
+def gru_forward_fused(p: Dict[str, Tensor], x: Tensor, n_levels: int = 2,
+                      h0: Optional[Tensor] = None, prefix: str = "gAR.baseNet."
+                      ) -> Tuple[Tensor, Tensor]:
+    """Same function as gru_forward through the fused aten GRU that the reference's nn.GRU module calls
+    (cpc/model.py:175-176,193): used by the timed CPU baseline only, so that the baseline is not handicapped by a
+    Python loop over the 128 steps.  tests/test_oracle_golden.py checks it against the explicit recurrence above."""
+    B = x.shape[0]
+    flat = []
+    for l in range(n_levels):
+        flat += [p[f"{prefix}weight_ih_l{l}"], p[f"{prefix}weight_hh_l{l}"],
+                 p[f"{prefix}bias_ih_l{l}"], p[f"{prefix}bias_hh_l{l}"]]
+    H = flat[1].shape[1]
+    hx = x.new_zeros(n_levels, B, H) if h0 is None else h0
+    y, hN = torch._VF.gru(x, hx, flat, True, n_levels, 0.0, True, False, True)
+    return y, hN
+
+
 def model_forward(p: Dict[str, Tensor], wave: Tensor, n_levels: int = 2,
                   h0: Optional[Tensor] = None,
-                  relu_override: Optional[Sequence[Tensor]] = None) -> Tuple[Tensor, Tensor, Tensor]:
+                  relu_override: Optional[Sequence[Tensor]] = None,
+                  fused_gru: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
     """CPCModel.forward -- model.py:286-289.  Returns (c (B,S,H), z (B,S,C), hN)."""
     z = encoder_forward(p, wave, relu_override=relu_override).permute(0, 2, 1)
-    c, hN = gru_forward(p, z, n_levels=n_levels, h0=h0)
+    c, hN = (gru_forward_fused if fused_gru else gru_forward)(p, z, n_levels=n_levels, h0=h0)
     return c, z, hN
 
 
@@ -306,13 +324,14 @@ class CpuTrainer:
     step as cpc/train.py:83-91 with torch.optim.Adam(lr=2e-4, betas=(0.9,0.999),
     eps=1e-8) (train.py:335-337, cpc_default_config.py:25-40)."""
 
-    def __init__(self, p: Dict[str, Tensor], n_predicts=12, n_neg=128, n_levels=2):
+    def __init__(self, p: Dict[str, Tensor], n_predicts=12, n_neg=128, n_levels=2, fused_gru=False):
+        self.fused_gru = fused_gru
         self.p = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
         self.opt = torch.optim.Adam(list(self.p.values()), lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
         self.n_predicts, self.n_neg, self.n_levels = n_predicts, n_neg, n_levels
 
     def step(self, wave: Tensor) -> Tensor:
-        c, z, _ = model_forward(self.p, wave, n_levels=self.n_levels)
+        c, z, _ = model_forward(self.p, wave, n_levels=self.n_levels, fused_gru=self.fused_gru)
         B, S, _ = z.shape
         W = S - self.n_predicts
         bi, si = draw_negative_indices(B, S, W, self.n_neg)

@@ -60,3 +60,35 @@ def test_nce_forward_backward_emulated(B, S, K, N, scale):
     assert rel_err(dz, zr.grad) < 1e-5
     ref_dw = torch.cat([leaves[f"wPrediction.predictors.{k}.weight"].grad for k in range(K)], dim=0)
     assert rel_err(dwall, ref_dw) < 1e-5
+
+
+def test_out_of_range_negative_indices_are_clamped_and_flagged():
+    """cpc_nce_prepare validates caller-supplied draws (criterion.py:181-189 draws batchIdx in [0,B), seqIdx in [1,S)):
+    an index outside the batch would otherwise count and gather out of bounds.  The device flag is read through
+    cpc_device_error_flags (bit CPC_DEVERR_NEGATIVE_INDEX = 2)."""
+    lib = emu()
+    B, S, K, N = 2, 20, 12, 16
+    W = S - K
+    g = torch.Generator().manual_seed(1)
+    bi, si = O.draw_negative_indices(B, S, W, N, generator=g)
+
+    def prepare(bi, si):
+        ext = torch.full((B, W, N), -1, dtype=torch.int32)
+        perm = torch.full((B * W * (N + K),), -1, dtype=torch.int32)
+        row_ptr = torch.full((B * S + 1,), -1, dtype=torch.int32)
+        work = torch.zeros(B * W * (N + K) + 2 * B * S + 2, dtype=torch.int32)
+        assert lib.cpc_nce_prepare(P(bi), P(si), P(ext), P(perm), P(row_ptr), P(work), B, S, K, N, None) == 0
+        return ext, row_ptr
+
+    lib.cpc_device_error_flags(1)
+    ext, row_ptr = prepare(bi, si)
+    assert lib.cpc_device_error_flags(0) == 0
+    bad_b, bad_s = bi.clone(), si.clone()
+    bad_b[5] = B + 3
+    bad_s[11] = -7
+    ext, row_ptr = prepare(bad_b, bad_s)
+    assert lib.cpc_device_error_flags(0) & 2
+    assert lib.cpc_device_error_flags(1) & 2            # read + clear
+    assert lib.cpc_device_error_flags(0) == 0
+    assert int(ext.min()) >= 0 and int(ext.max()) < B * S
+    assert int(row_ptr[-1]) == B * W * (N + K)

@@ -188,3 +188,49 @@ def test_gru_fp16_split_forward_is_within_fp32_rounding_of_exact_products():
             lib.cpc_set_gru_mode(_lib_default_gru_mode())
     d = (ys[0] - ys[1]).abs().max().item()
     assert 0.0 < d < 2e-6, d
+
+
+def test_device_error_flags_negative_index_and_recurrence_timeout():
+    """The two things a kernel can notice but not raise (include/cpc_hip.h, cpc_device_error_flags):
+    * cpc_nce_prepare handed an index outside the batch -> clamped, flagged, ops.check_device_errors raises;
+    * a wave of the persistent recurrence that runs out of its polling budget -> flagged (and NaN in the outputs, which
+      is what reaches the loss).  Driven here by a budget of zero re-reads (cpc_set_gru_spin_limit(0)): every hand-over
+      that is not complete at the first look counts as a timeout."""
+    dev = _dev()
+    from cpc_audio_amd import _lib, ops
+    from cpc_audio_amd._lib import CpcHipError
+    from cpc_audio_amd.model import CPCAR
+    lib = _lib.get()
+    lib.cpc_device_error_flags(1)
+    B, S, K, N = 4, 128, 12, 128
+    g = torch.Generator().manual_seed(0)
+    bi, si = O.draw_negative_indices(B, S, S - K, N, generator=g)
+    ops.prepare_negatives(bi.to(dev), si.to(dev), B, S, K, N)
+    ops.check_device_errors()                               # clean draws: nothing flagged
+    bi[17] = B
+    ext, perm, row_ptr = ops.prepare_negatives(bi.to(dev), si.to(dev), B, S, K, N)
+    with pytest.raises(CpcHipError, match="negative-sample indices"):
+        ops.check_device_errors()
+    ops.check_device_errors()                               # cleared by the raising call
+    assert int(ext.max()) < B * S and int(row_ptr[-1]) == B * (S - K) * (N + K)
+
+    p = O.make_params(seed=4)
+    ar = CPCAR(256, 256, False, 2, mode="GRU").to(dev)
+    ar.load_state_dict({k[len("gAR."):]: v for k, v in p.items() if k.startswith("gAR.")})
+    x = torch.randn(64, 128, 256, generator=g).to(dev)
+    assert lib.cpc_set_gru_spin_limit(0) == 0
+    try:
+        with torch.no_grad():
+            y = ar(x)
+        torch.cuda.synchronize()
+    finally:
+        lib.cpc_set_gru_spin_limit(-1)
+    assert lib.cpc_device_error_flags(0) & 1
+    assert not torch.isfinite(y).all()                      # the fill pattern (a NaN) went through, the launch ended
+    with pytest.raises(CpcHipError, match="recurrence timed out"):
+        ops.check_device_errors()
+    with torch.no_grad():
+        y = ar(x)                                           # default budget: fine again
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    ops.check_device_errors()

@@ -27,14 +27,11 @@ def main():
     def step(overlap):
         for p in params:
             p.grad = None
-        ops.OVERLAP_DZ = overlap
-        try:
+        with ops.StepContext(overlap=overlap) as sc:
             c, z, _ = model(wave, label)
             losses, _ = crit(c, z, None, negatives=negs)
             torch.autograd.backward([losses], [torch.ones_like(losses)])
-            ops.wait_side_stream()
-        finally:
-            ops.OVERLAP_DZ = False
+            sc.wait()
         torch.cuda.synchronize()
         return [p.grad.clone() for p in params], losses.detach().clone()
 
