@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcpc_hip.so")
 DEFAULT_GRU_MODE = 2       # cpc_set_gru_mode: persistent recurrence, forward products on the fp16 split
-DEFAULT_MFMA_MODE = 2      # what libcpc_hip starts in (cpc_set_mfma_mode): conv layers on the fp16 split, GEMMs on the bf16 split
+DEFAULT_MFMA_MODE = 3      # what libcpc_hip starts in (cpc_set_mfma_mode): conv layers on the fp16 split, GEMMs on the bf16 split
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -24,6 +24,15 @@ SIGNATURES = {
     "cpc_set_mfma_mode": (_I, [_I]),
     "cpc_device_error_flags": (_I, [_I]),
     "cpc_conv0_forward": (_I, [_P] * 8 + [_I, _I, _P]),
+    "cpc_conv0_forward_h2": (_I, [_P] * 9 + [_I, _I, _P]),
+    "cpc_h2_encode": (_I, [_P, _P, _L, _P, _P]),
+    "cpc_h2_decode": (_I, [_P, _P, _L, _P, _P]),
+    "cpc_conv_weight_relayout_h2": (_I, [_P, _P, _I, _P]),
+    "cpc_conv_gemm_forward_h2": (_I, [_P] * 11 + [_I] * 6 + [_P]),
+    "cpc_set_dma_tile": (_I, [_I]),
+    "cpc_set_h2_layers": (_I, [_I]),
+    "cpc_set_dma_rotation": (_I, [_I]),
+    "cpc_set_dma_pipeline": (_I, [_I]),
     "cpc_conv0_backward_scratch_floats": (_L, [_I, _I]),
     "cpc_conv0_backward": (_I, [_P] * 13 + [_I, _I, _P]),
     "cpc_conv_layer_forward": (_I, [_P] * 9 + [_I] * 5 + [_P]),
@@ -34,6 +43,7 @@ SIGNATURES = {
     "cpc_conv_layer_dgrad": (_I, [_P] * 3 + [_I] + [_P] * 10 + [_I] * 5 + [_P]),
     "cpc_conv_layer_wgrad": (_I, [_P] * 6 + [_I] * 7 + [_P]),
     "cpc_encoder_layout": (_I, [_I, _I, _P]),
+    "cpc_encoder_saved_activation": (_I, [_P, _I, _P, _I, _I, _P]),
     "cpc_encoder_forward": (_I, [_P] * 5 + [_I, _I, _P]),
     "cpc_encoder_backward": (_I, [_P] * 7 + [_I, _I, _P]),
     "cpc_encoder_backward_streams": (_I, [_P] * 7 + [_I, _I, _P, _P]),

@@ -7,7 +7,7 @@
 #include <utility>
 
 namespace cpc {
-int g_mfma_mode = 2;
+int g_mfma_mode = 3;
 
 // Events that order a second stream against the caller's inside the *_streams entry points (timing disabled; created
 // once per (device, caller stream) and reused: a wait captures the record that precedes it, so re-recording later is
@@ -49,7 +49,7 @@ extern "C" int cpc_device_error_flags(int clear) {
 }
 
 extern "C" int cpc_set_mfma_mode(int mode) {
-    CPC_RETURN_IF(mode != 0 && mode != 1 && mode != 2, CPC_ERR_ARG);
+    CPC_RETURN_IF(mode < 0 || mode > 3, CPC_ERR_ARG);
     cpc::g_mfma_mode = mode;
     return 0;
 }

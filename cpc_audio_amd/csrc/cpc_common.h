@@ -74,6 +74,71 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- "H2" storage of an fp32 tensor (encoder activations that feed the fp16 matrix pipe) -----------------------------
+// The value x is kept as two fp16 pieces of x*s (s a power of two chosen from an a-priori bound on max|x|,
+// scale_for_amax in gemm_tile.h):  h = fp16(x*s), l = fp16(x*s - h), x = (h + l) / s up to 2^-22 |x| -- exactly the
+// pieces the 3-product GEMM tiles form when they stage an fp32 operand.  The layout makes the 16 bytes ONE lane feeds to
+// ONE 16-bit MFMA (8 consecutive contraction indices of one piece) contiguous: per group of 8 channels
+//     bytes [32 g, 32 g + 16) = h[8]      bytes [32 g + 16, 32 g + 32) = l[8]
+// i.e. the same 4 bytes per element as fp32 and the same 1 KB rows, so such a tensor goes global -> LDS by DMA
+// (global_load_lds_dwordx4) with no VGPR staging and no VALU, and is written once by the producing epilogue.
+__device__ __forceinline__ long h2_byte_of(int c) { return ((long)(c >> 3) << 5) + ((c & 7) << 1); }   // h of channel c; l at +16
+__device__ __forceinline__ void h2_split(float x, float s, _Float16& h, _Float16& l) {
+    const float xs = x * s;
+    h = (_Float16)xs;
+    l = (_Float16)(xs - (float)h);
+}
+// channels c .. c+3 (c % 4 == 0) of the row starting at `row`
+__device__ __forceinline__ void h2_store4(void* row, int c, float v0, float v1, float v2, float v3, float s) {
+    _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
+    h2_split(v0, s, h0, l0); h2_split(v1, s, h1, l1); h2_split(v2, s, h2, l2); h2_split(v3, s, h3, l3);
+    unsigned char* p = reinterpret_cast<unsigned char*>(row) + h2_byte_of(c);
+    *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_bit_cast(unsigned, f16x2{h0, h1}), __builtin_bit_cast(unsigned, f16x2{h2, h3}));
+    *reinterpret_cast<uint2*>(p + 16) = make_uint2(__builtin_bit_cast(unsigned, f16x2{l0, l1}), __builtin_bit_cast(unsigned, f16x2{l2, l3}));
+}
+// A whole 256-channel row held 4 channels per lane (lane l: channels 4l .. 4l+3), streamed out once: neighbouring lanes
+// swap halves so that the even lane owns the 8 h pieces of its 8-channel group and the odd lane the 8 l pieces, and every
+// lane stores 16 contiguous bytes at row + 16 l -- one full 1 KB line per wave instruction.  (Two 8-byte stores per lane
+// would leave 16-byte holes in every instruction: 0.084 vs 0.060 ms for conv0 at B = 64.)  Convergent: all 64 lanes call it.
+__device__ __forceinline__ void h2_store_row_nt(void* row, float v0, float v1, float v2, float v3, float s) {
+    _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
+    h2_split(v0, s, h0, l0); h2_split(v1, s, h1, l1); h2_split(v2, s, h2, l2); h2_split(v3, s, h3, l3);
+    const unsigned hw0 = __builtin_bit_cast(unsigned, f16x2{h0, h1}), hw1 = __builtin_bit_cast(unsigned, f16x2{h2, h3});
+    const unsigned lw0 = __builtin_bit_cast(unsigned, f16x2{l0, l1}), lw1 = __builtin_bit_cast(unsigned, f16x2{l2, l3});
+    const int lane = threadIdx.x & 63;
+    const bool odd = lane & 1;
+    // quad_perm [1,0,3,2]: the even lane receives the odd lane's h pieces, the odd lane the even lane's l pieces
+    const unsigned r0 = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, odd ? hw0 : lw0)));
+    const unsigned r1 = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, odd ? hw1 : lw1)));
+    f32x4 o;
+    o.x = __builtin_bit_cast(float, odd ? r0 : hw0);
+    o.y = __builtin_bit_cast(float, odd ? r1 : hw1);
+    o.z = __builtin_bit_cast(float, odd ? lw0 : r0);
+    o.w = __builtin_bit_cast(float, odd ? lw1 : r1);
+    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(row) + 16 * lane));
+}
+// raw pieces of channels c .. c+3: hp = {h0 h1 | h2 h3}, lp likewise
+__device__ __forceinline__ void h2_load4_raw(const void* row, int c, uint2& hp, uint2& lp) {
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(row) + h2_byte_of(c);
+    hp = *reinterpret_cast<const uint2*>(p);
+    lp = *reinterpret_cast<const uint2*>(p + 16);
+}
+__device__ __forceinline__ float h2_join(unsigned short hb, unsigned short lb, float inv_s) {
+    return ((float)__builtin_bit_cast(_Float16, hb) + (float)__builtin_bit_cast(_Float16, lb)) * inv_s;
+}
+
+// One 16-byte piece per lane, global -> LDS, no VGPR in between (global_load_lds_dwordx4): lane l's 16 bytes land at
+// lds_wave_base + 16 l (the LDS side is wave-uniform base + lane * size; only the global address is per lane).
+// Completion is counted on vmcnt like any load; nothing orders a later ds_read behind it except that wait (+ a barrier
+// for the other waves' reads), MI355X_MICROARCH.md.
+__device__ __forceinline__ void dma16_to_lds(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// s_waitcnt vmcnt(n) alone (expcnt / lgkmcnt left at their maxima): gfx9 encoding vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14
+#define CPC_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt((((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14)))
+#define CPC_WAIT_LGKMCNT0() __builtin_amdgcn_s_waitcnt((15 | (7 << 4) | (0 << 8) | (3 << 14)))
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // output length of a strided conv (cpc/model.py:83-92 geometry)

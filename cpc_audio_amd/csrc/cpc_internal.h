@@ -39,6 +39,12 @@ extern int g_mfma_mode;
 constexpr int kStreamEvents = 12;
 hipEvent_t* stream_events(hipStream_t caller_stream);
 
+// conv_dma.hip: forward conv layer with both operands DMA'd into LDS (H2 storage, cpc_common.h)
+int conv_fwd_dma(const float* x_h2, const float* wq, const float* bias, const float* nw, const float* nb, float* y,
+                 int y_h2, float* xhat, float* rstd, const float* x_amax, const float* y_amax, const float* zeros, int B,
+                 int Lin, int k, int s, int p, int bm, hipStream_t st);
+int permute_w_h2(const float* w, float* wq, int k, const float* amax, hipStream_t st);
+
 // device-side error words of the translation units that own them (cpc_device_error_flags)
 int gru_error_flag_fetch(int clear, unsigned* out);
 int nce_error_flag_fetch(int clear, unsigned* out);

@@ -163,6 +163,7 @@ struct PrepArgs {
     int k[4];
     int blk0[9];            // first workgroup of segment 2*layer + layout
     int split;
+    int fwd_h2[4];          // forward layout of layer y+1 in K-tile-major H2 rows (the DMA kernel's, conv_dma.hip)
 };
 __global__ __launch_bounds__(256) void enc_prep_amax_kernel(PrepArgs a) {
     const int y = blockIdx.y;
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(256) void enc_prep_permute_kernel(PrepArgs a) {
     if (a.split == 2 && idx == 0) dst[total] = amax;          // where the GEMM kernels read max|w|
     if (idx >= total) return;
     if (seg & 1) permute_w_dgrad_elem(a.w[layer], dst, k / 2, a.split, amax, idx);
+    else if (a.fwd_h2[layer]) permute_w_h2_elem(a.w[layer], reinterpret_cast<unsigned char*>(dst), k, amax, idx);
     else permute_w_fwd_elem(a.w[layer], dst, k, a.split, amax, idx);
 }
 
@@ -321,6 +323,8 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
 // stand-alone version for the top layer (its dy comes from autograd, not from a dgrad GEMM)
 constexpr int NB_ROWS = 32;   // rows per block (8 per wave)
 // dx_amax (may be NULL): max|dx| is accumulated into it for the fp16-split GEMMs that consume dx
+// YH2: y is in H2 storage (cpc_common.h); only its sign is needed here, and that of the h piece is the value's
+template <bool YH2>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ y,
     const float* __restrict__ rstd, const float* __restrict__ nw, float* __restrict__ dx,
@@ -341,10 +345,18 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
         if (m >= M) break;                     // wave-uniform
         const float4 g4 = *reinterpret_cast<const float4*>(dy + (long)m * kC + c);
         const float4 x4 = *reinterpret_cast<const float4*>(xhat + (long)m * kC + c);
-        const float4 y4 = *reinterpret_cast<const float4*>(y + (long)m * kC + c);
+        float yv[4];
+        if constexpr (YH2) {
+            uint2 hp, lp;
+            h2_load4_raw(y + (long)m * kC, c, hp, lp);
+            yv[0] = (float)(short)(hp.x & 0xFFFFu); yv[1] = (float)(short)(hp.x >> 16);      // > 0 iff the fp16 piece is
+            yv[2] = (float)(short)(hp.y & 0xFFFFu); yv[3] = (float)(short)(hp.y >> 16);
+        } else {
+            const float4 y4 = *reinterpret_cast<const float4*>(y + (long)m * kC + c);
+            yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
+        }
         const float g[4] = {g4.x, g4.y, g4.z, g4.w};
         const float xh[4] = {x4.x, x4.y, x4.z, x4.w};
-        const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
         const float rs = rstd[m];
         float dxh[4], s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -542,9 +554,10 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
 }
 
 // ------------------------------------------------------------------ wgrad
+// MODE 3: as 2 with the activation operand (x) in H2 storage
 template <int MODE>
 struct WgCfg {
-    using Tile = typename std::conditional<MODE != 0, TnTileX3<128, 128, 2, 2, 32, 1, MODE == 2 ? 2 : 3>,
+    using Tile = typename std::conditional<MODE != 0, TnTileX3<128, 128, 2, 2, 32, 1, MODE >= 2 ? 2 : 3, MODE == 3>,
                                            TnTile<128, 128, 2, 2>>::type;
 };
 // 1-D grid of 8 * T * ceil(S/8) blocks, T = 2*K/128 output tiles; part[z][co][K].
@@ -568,7 +581,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     f32x16 acc[WgTile::TM][WgTile::TN];
     zero_acc(acc);
     float inv = 1.0f;
-    if constexpr (MODE == 2) {
+    if constexpr (MODE >= 2) {
         const float sa = scale_for_amax(*dx_amax), sb = scale_for_amax(*x_amax);
         WgTile::run(acc, dxm, c0, im, n0, mbeg, mend, smem, sa, sb);
         inv = 1.0f / (sa * sb);
@@ -583,7 +596,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
             const int row = c0 + WgTile::c_row(tm, r);
 #pragma unroll
             for (int tn = 0; tn < WgTile::TN; ++tn)
-                out[(long)row * K + n0 + WgTile::c_col(tn)] = MODE == 2 ? acc[tm][tn][r] * inv : acc[tm][tn][r];
+                out[(long)row * K + n0 + WgTile::c_col(tn)] = MODE >= 2 ? acc[tm][tn][r] * inv : acc[tm][tn][r];
         }
 }
 
@@ -617,7 +630,7 @@ static inline long align64(long v) { return (v + 63) & ~63L; }
 struct EncLayout {
     int L[5];
     long y[4], xhat[5], rstd[5], mean0;    // offsets (floats) into the saved workspace
-    long swd[5], sbound;                   // ... dgrad weight layouts (1..4) and input bounds, prepared by the forward
+    long swd[5], sbound, szero;            // ... dgrad weight layouts (1..4) and input bounds, prepared by the forward
     long saved_total;
     long wp[5];                            // forward scratch: permuted weights (1..4)
     long famax, fwd_total;                 // famax: kPrepParts partial max|w| per layer
@@ -626,8 +639,16 @@ struct EncLayout {
     long colp[5], tmpq[5];                 // per-layer partials of the stand-alone norm backwards (summed in one batch)
     long bwd_total;
     int wg_splits[5], wg_rows[5];
+    bool h2[4];                            // output of layer i kept in H2 storage (cpc_common.h) -- see act_h2 below
 };
+#define act_h2(layer) (e.h2[layer])
 
+// Mode 3: the output of layer 0 (conv1's input; conv1 is 70 % of the stack's FLOPs) lives in H2 storage and conv1 runs on
+// the DMA kernel (conv_dma.hip); so does conv2 (a further 17 %) once its 256-row tiles fill the chip (B >= ~100: at B = 64
+// its 128-row DMA tiles measured 0.070 ms against 0.067 for the register-staged kernel).  Layers 3 and 4 keep fp32
+// activations and the register-staged kernels, whose 32/64-row tiles fill the chip at their small row counts.
+static int g_dma_bm = 0;     // 0 = by problem size; 128 / 256 = tuning override of the DMA kernel's rows per workgroup
+static int g_h2_layers = 0;  // 0 = by problem size; 1 / 2 = tuning / test override: how many layers (conv1, conv2) read H2 input
 static int g_force_bm = 0;   // 0 = choose by problem size; 32/64/128 = tuning / test override
 static constexpr int g_unfuse_big = 2;   // 2: every dgrad runs unfused + streaming norm backward, 1: only the 128-row tiles,
                                          // 0: fused epilogue (cpc_conv_layer_dgrad fuse=1).  Measured 4.69 / 4.76 / 4.79 ms per step
@@ -646,6 +667,8 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
         if (e.L[i] <= 0) return false;
         lin = e.L[i];
     }
+    const int nh2 = g_mfma_mode != 3 ? 0 : (g_h2_layers ? g_h2_layers : ((long)B * e.L[2] >= 256L * 200 ? 2 : 1));
+    for (int i = 0; i < 4; ++i) e.h2[i] = i < nh2;
     long o = 0;
     for (int i = 0; i < 4; ++i) { e.y[i] = o; o += align64((long)B * e.L[i] * kC); }
     e.xhat[0] = -1;
@@ -655,6 +678,7 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     e.swd[0] = -1;
     for (int i = 1; i < 5; ++i) { e.swd[i] = o; o += align64((long)kC * kGeom[i].k * kC * 3 / 2); }
     e.sbound = o; o += 64;                 // [i] = bound of layer i's input (fp16-split mode), i = 1..4
+    e.szero = o; o += 64;                  // zeros: what the DMA kernel reads for the conv's padding rows
     e.saved_total = o;
 
     o = 0;
@@ -704,7 +728,7 @@ template <int BM>
 static void launch_conv_fwd(const RowMap& am, const float* wp, int K, const float* bias,
                             const float* nw, const float* nb, float* y, float* xhat, float* rstd,
                             const float* x_amax, const float* w_amax, hipStream_t st) {
-    if (g_mfma_mode == 2 && K % 32 == 0)
+    if (g_mfma_mode >= 2 && K % 32 == 0)
         hipLaunchKernelGGL((conv_fwd_kernel<BM, 2>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, 2>::Tile::NTHREADS),
                            0, st, am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax);
     else if (g_mfma_mode != 0 && K % 32 == 0)
@@ -720,7 +744,7 @@ static void launch_conv_dgrad(const RowMap& am, const float* wd, int s, int p, i
                               const float* xhat_prev, const float* y_prev, const float* rstd_prev,
                               const float* nw_prev, float* dprev, float* colpart, const float* dx_amax,
                               const float* w_amax, float* prev_amax, hipStream_t st) {
-    if (g_mfma_mode == 2)
+    if (g_mfma_mode >= 2)
         hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE, 2>), dim3(cdiv(am.M, BM), s),
                            dim3(ConvCfg<BM, 2>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
                            rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, prev_amax);
@@ -739,7 +763,7 @@ static void launch_conv_dgrad(const RowMap& am, const float* wd, int s, int p, i
 using namespace cpc;
 
 static int weight_split() {
-    return g_mfma_mode == 2 ? 2 : ((g_mfma_mode == 1 && ConvCfg<128, 1>::kPreSplitW) ? 1 : 0);
+    return g_mfma_mode >= 2 ? 2 : ((g_mfma_mode == 1 && ConvCfg<128, 1>::kPreSplitW) ? 1 : 0);
 }
 static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const float* xhat_prev, const float* y_prev,
                            const float* rstd_prev, const float* nw_prev, float* dprev, float* colpart, float* tmp,
@@ -751,6 +775,16 @@ extern "C" int cpc_set_conv_tile(int bm) {
     g_force_bm = bm;
     return 0;
 }
+extern "C" int cpc_set_dma_tile(int bm) {
+    CPC_RETURN_IF(bm != 0 && bm != 128 && bm != 256, CPC_ERR_ARG);
+    g_dma_bm = bm;
+    return 0;
+}
+extern "C" int cpc_set_h2_layers(int n) {
+    CPC_RETURN_IF(n < 0 || n > 2, CPC_ERR_ARG);
+    g_h2_layers = n;
+    return 0;
+}
 
 // Weight re-layout for the forward GEMM: PyTorch (O,I,W) -> K-major rows wp[co][kk*C+ci]; in the default
 // split-bf16 mode wp holds three bf16 planes.  wp must have room for 256*k*256*3/2 floats.
@@ -759,7 +793,7 @@ extern "C" int cpc_conv_weight_relayout(const float* w, float* wp, int k, void* 
     const long nw_elems = (long)kC * k * kC;
     hipStream_t st = (hipStream_t)stream;
     float* amax = wp + nw_elems;                     // spare floats behind the re-laid-out weight
-    if (g_mfma_mode == 2) {
+    if (g_mfma_mode >= 2) {
         (void)hipMemsetAsync(amax, 0, sizeof(float), st);
         hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, st, w, nw_elems, amax);
     }
@@ -783,7 +817,7 @@ extern "C" int cpc_conv_gemm_forward(const float* x, const float* wp, const floa
                                      const float* nb, float* y, float* xhat, float* rstd, const float* x_amax,
                                      int B, int Lin, int k, int s, int p, void* stream) {
     CPC_RETURN_IF(B <= 0 || Lin <= 0 || k != 2 * s || Lin + 2 * p < k, CPC_ERR_SHAPE);
-    CPC_RETURN_IF(g_mfma_mode == 2 && !x_amax, CPC_ERR_ARG);
+    CPC_RETURN_IF(g_mfma_mode >= 2 && !x_amax, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     const int Lout = conv_out_len(Lin, k, s, p);
     const RowMap am = conv_rows(x, B, Lin, Lout, s, p);
@@ -824,7 +858,7 @@ extern "C" int cpc_norm_backward(const float* dy, const float* xhat, const float
     CPC_RETURN_IF(M <= 0, CPC_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     const int nblk = cdiv(M, NB_ROWS);
-    hipLaunchKernelGGL(norm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, xhat, y, rstd, nw, dx, colpart, M, dx_amax);
+    hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(nblk), dim3(256), 0, st, dy, xhat, y, rstd, nw, dx, colpart, M, dx_amax);
     CPC_LAUNCH_CHECK();
     return rows_sum(colpart, nblk, 3 * kC, tmp, small3, st);
 }
@@ -845,13 +879,13 @@ extern "C" int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, 
     const int Lout = conv_out_len(Lin, k, s, p);
     const long nw_elems = (long)kC * k * kC;
     float* w_amax = wd + nw_elems;                    // spare floats behind the re-laid-out weight
-    if (g_mfma_mode == 2) {
+    if (g_mfma_mode >= 2) {
         (void)hipMemsetAsync(w_amax, 0, 2 * sizeof(float), st);
         hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, st, w, nw_elems, w_amax);
     }
     hipLaunchKernelGGL(permute_w_dgrad_kernel, dim3(cdiv(nw_elems, 256)), dim3(256), 0, st, w, wd, s, weight_split(),
                        w_amax);
-    if (g_mfma_mode == 2) {
+    if (g_mfma_mode >= 2) {
         if (!dx_amax) {
             hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, dx, (long)B * Lout * kC, w_amax + 1);
             dx_amax = w_amax + 1;
@@ -895,10 +929,20 @@ static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const flo
 // wgrad of one conv layer: dW (256,256,k) = sum over rows of dx (B,Lout,C) (x) im2col(x).
 // part: splits*256*k*256 floats of scratch.
 // dx_amax, x_amax: device floats bounding max|dx| and max|x| (mode 2 only).
+static int conv_layer_wgrad(const float* dx, const float* x, int x_h2, float* part, float* dW, const float* dx_amax,
+                            const float* x_amax, int B, int Lin, int k, int s, int p, int splits, int rows_per_split,
+                            void* stream);
 extern "C" int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part, float* dW,
                                     const float* dx_amax, const float* x_amax, int B,
                                     int Lin, int k, int s, int p, int splits, int rows_per_split,
                                     void* stream) {
+    return conv_layer_wgrad(dx, x, 0, part, dW, dx_amax, x_amax, B, Lin, k, s, p, splits, rows_per_split, stream);
+}
+// x_h2: the layer's input activation is in H2 storage scaled by scale_for_amax(*x_amax) (fp16-split modes only)
+static int conv_layer_wgrad(const float* dx, const float* x, int x_h2, float* part, float* dW, const float* dx_amax,
+                            const float* x_amax, int B, int Lin, int k, int s, int p, int splits, int rows_per_split,
+                            void* stream) {
+    CPC_RETURN_IF(x_h2 && g_mfma_mode < 2, CPC_ERR_ARG);
     CPC_RETURN_IF(B <= 0 || Lin <= 0 || Lin + 2 * p < k || splits <= 0 || rows_per_split <= 0, CPC_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     const int Lout = conv_out_len(Lin, k, s, p);
@@ -907,8 +951,10 @@ extern "C" int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part
     const RowMap im = conv_rows(x, B, Lin, Lout, s, p);
     CPC_RETURN_IF((long)splits * rows_per_split < dxm.M, CPC_ERR_SHAPE);
     const dim3 grid(8 * 2 * (K / 128) * cdiv(splits, 8));
-    CPC_RETURN_IF(g_mfma_mode == 2 && (!dx_amax || !x_amax), CPC_ERR_ARG);
-    if (g_mfma_mode == 2)
+    CPC_RETURN_IF(g_mfma_mode >= 2 && (!dx_amax || !x_amax), CPC_ERR_ARG);
+    if (g_mfma_mode >= 2 && x_h2)
+        hipLaunchKernelGGL((conv_wgrad_kernel<3>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
+    else if (g_mfma_mode >= 2)
         hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
     else if (g_mfma_mode == 1)
         hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
@@ -936,18 +982,29 @@ extern "C" int cpc_encoder_layout(int B, int L, long* sizes) {
     return 0;
 }
 
+// fp32 copy of the saved output of encoder layer `layer` (0..3), whatever its storage (mode 3 keeps layers 0 and 1 in H2
+// form): dst (B, L_layer, 256).  For tests and debugging; call it in the mode the forward ran in.
+extern "C" int cpc_encoder_saved_activation(const float* saved, int layer, float* dst, int B, int L, void* stream) {
+    EncLayout e;
+    CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!saved || !dst || layer < 0 || layer > 3, CPC_ERR_ARG);
+    const long rows = (long)B * e.L[layer];
+    if (act_h2(layer)) return cpc_h2_decode(saved + e.y[layer], dst, rows, saved + e.sbound + layer + 1, stream);
+    if (hipMemcpyAsync(dst, saved + e.y[layer], rows * kC * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return CPC_ERR_ARG;
+    return 0;
+}
+
 // params: 20 pointers in the reference's state-dict order
 //   conv{i}.weight, conv{i}.bias, batchNorm{i}.weight, batchNorm{i}.bias  for i = 0..4
 extern "C" int cpc_encoder_forward(const float* wave, const float* const* params, float* saved,
                                    float* scratch, float* z, int B, int L, void* stream) {
     EncLayout e;
     CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
-    int rc = cpc_conv0_forward(wave, params[0], params[1], params[2], params[3], saved + e.y[0],
-                               saved + e.mean0, saved + e.rstd[0], B, L, stream);
-    if (rc) return rc;
     // every weight-only quantity of layers 1..4 -- both GEMM layouts, max|w|, the bounds of the layers' inputs (the
     // previous layer's ChannelNorm + ReLU output is bounded by its affine) -- in two launches; the backward finds the
-    // dgrad layouts and the bounds in `saved`
+    // dgrad layouts and the bounds in `saved`.  First, because in mode 3 conv0 already writes its output scaled by the
+    // bound of layer 1's input.
     PrepArgs a;
     int nblk = 0;
     for (int i = 1; i < 5; ++i) {
@@ -957,6 +1014,7 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
         a.nw[i - 1] = params[4 * (i - 1) + 2];
         a.nb[i - 1] = params[4 * (i - 1) + 3];
         a.k[i - 1] = kGeom[i].k;
+        a.fwd_h2[i - 1] = act_h2(i - 1);               // layer i consumes an H2 activation: DMA kernel, DMA weight layout
         const int per = cdiv((long)kC * kGeom[i].k * kC, 256);
         a.blk0[2 * (i - 1)] = nblk; nblk += per;
         a.blk0[2 * (i - 1) + 1] = nblk; nblk += per;
@@ -965,14 +1023,27 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
     a.bound = saved + e.sbound + 1;
     a.partial = scratch + e.famax;
     a.split = weight_split();
-    hipLaunchKernelGGL(enc_prep_amax_kernel, dim3(kPrepParts, 5), dim3(256), 0, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(enc_prep_permute_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(enc_prep_amax_kernel, dim3(kPrepParts, 5), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(enc_prep_permute_kernel, dim3(nblk), dim3(256), 0, st, a);
     CPC_LAUNCH_CHECK();
+    if (g_mfma_mode == 3 && hipMemsetAsync(saved + e.szero, 0, 64 * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+    int rc = cpc_conv0_forward_h2(wave, params[0], params[1], params[2], params[3], saved + e.y[0], saved + e.mean0,
+                                  saved + e.rstd[0], act_h2(0) ? saved + e.sbound + 1 : nullptr, B, L, stream);
+    if (rc) return rc;
     for (int i = 1; i < 5; ++i) {
         float* yo = i == 4 ? z : saved + e.y[i];
-        rc = cpc_conv_gemm_forward(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2],
-                                   params[4 * i + 3], yo, saved + e.xhat[i], saved + e.rstd[i], saved + e.sbound + i, B,
-                                   e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, stream);
+        if (act_h2(i - 1)) {
+            const long M = (long)B * e.L[i];
+            rc = conv_fwd_dma(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2], params[4 * i + 3],
+                              yo, i < 4 && act_h2(i), saved + e.xhat[i], saved + e.rstd[i], saved + e.sbound + i,
+                              saved + e.sbound + i + 1, saved + e.szero, B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p,
+                              g_dma_bm ? g_dma_bm : (M >= 256L * 200 ? 256 : 128), st);
+        } else {
+            rc = cpc_conv_gemm_forward(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2],
+                                       params[4 * i + 3], yo, saved + e.xhat[i], saved + e.rstd[i], saved + e.sbound + i, B,
+                                       e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, stream);
+        }
         if (rc) return rc;
     }
     return 0;
@@ -1025,7 +1096,11 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     int njobs = 0;
     auto norm_bwd = [&](int layer, const float* dy, const float* yl, float* dxl) {
         const int M = B * e.L[layer], nblk = cdiv(M, NB_ROWS);
-        hipLaunchKernelGGL(norm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
+        if (act_h2(layer))
+            hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
+                               saved + e.rstd[layer], params[4 * layer + 2], dxl, scratch + e.colp[layer], M, amax + layer);
+        else
+        hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
                            saved + e.rstd[layer], params[4 * layer + 2], dxl, scratch + e.colp[layer], M, amax + layer);
         jobs[njobs++] = RowsSumJob{scratch + e.colp[layer], nblk, 3 * kC, scratch + e.tmpq[layer], small + layer * 3 * kC};
     };
@@ -1041,8 +1116,8 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                 return CPC_ERR_ARG;
         }
         if (!(ev && i == 1))
-        rc = cpc_conv_layer_wgrad(scratch + e.dx[i], xin, scratch + e.part, grads[4 * i], amax + i, xbound + i, B,
-                                  e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], (void*)wst);
+        rc = conv_layer_wgrad(scratch + e.dx[i], xin, act_h2(i - 1), scratch + e.part, grads[4 * i], amax + i, xbound + i, B,
+                              e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], (void*)wst);
         if (rc) return rc;
         if (i >= 2 && g_unfuse_big && (g_unfuse_big == 2 || pick_bm(B * (e.L[i] + 1)) == 128)) {
             // the fused ReLU'/ChannelNorm-backward epilogue is latency-bound (row-by-row reductions between the loads); a
@@ -1065,8 +1140,8 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
         if (rc) return rc;
         if (ev && i == 1) {
             if (hipEventRecord(ev[1], st) != hipSuccess || hipStreamWaitEvent(wst, ev[1], 0) != hipSuccess) return CPC_ERR_ARG;
-            rc = cpc_conv_layer_wgrad(scratch + e.dx[1], xin, scratch + e.part, grads[4], amax + 1, xbound + 1, B, e.L[0],
-                                      kGeom[1].k, kGeom[1].s, kGeom[1].p, e.wg_splits[1], e.wg_rows[1], (void*)wst);
+            rc = conv_layer_wgrad(scratch + e.dx[1], xin, act_h2(0), scratch + e.part, grads[4], amax + 1, xbound + 1, B, e.L[0],
+                                  kGeom[1].k, kGeom[1].s, kGeom[1].p, e.wg_splits[1], e.wg_rows[1], (void*)wst);
         }
         if (rc) return rc;
     }

@@ -18,6 +18,7 @@
 // packed math, and non-temporal stores are used for the streamed output.
 #include "cpc_common.h"
 #include "cpc_internal.h"
+#include "gemm_tile.h"
 
 namespace cpc {
 
@@ -25,10 +26,12 @@ constexpr int K0 = 10, S0 = 5, P0 = 3;     // conv0 geometry, cpc/model.py:83
 constexpr int C0_TT = 128;                 // time steps per block (32 per wave, two at a time)
 constexpr int C0_NS = S0 * C0_TT + (K0 - S0);   // staged samples per block
 
+template <bool YH2>
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(
     const float* __restrict__ wave, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
-    float* __restrict__ mean_out, float* __restrict__ rstd_out, int L, int L0) {
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, int L, int L0, const float* __restrict__ y_amax) {
+    // YH2: y is written in H2 storage (cpc_common.h) scaled by scale_for_amax(*y_amax), the form conv1's DMA kernel reads
     __shared__ float smp[C0_NS];
     __shared__ float wT[K0][kC];                 // conv0.weight transposed: coalesced global read, float4 LDS reads
     const int b = blockIdx.y;
@@ -61,6 +64,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(
         n01 = f32x2{n4.x, n4.y}; n23 = f32x2{n4.z, n4.w};
     }
     const f32x2 zero2 = f32x2{0.f, 0.f};
+    const float sy = YH2 ? scale_for_amax(*y_amax) : 1.0f;
     // two time steps per iteration: their reduction chains are independent and interleave
     for (int tt = wv; tt < C0_TT; tt += 8) {
         const int ta = t0 + tt, tb = ta + 4;
@@ -91,10 +95,14 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(
             float* yo = y + row * kC + c;       // streamed once, 268 MB per launch at B = 64 (>> L2): non-temporal
             const f32x2 o01 = __builtin_elementwise_max(__builtin_elementwise_fma(da01 * f32x2{rsa, rsa}, g01, n01), zero2);
             const f32x2 o23 = __builtin_elementwise_max(__builtin_elementwise_fma(da23 * f32x2{rsa, rsa}, g23, n23), zero2);
-            __builtin_nontemporal_store(o01.x, yo);
-            __builtin_nontemporal_store(o01.y, yo + 1);
-            __builtin_nontemporal_store(o23.x, yo + 2);
-            __builtin_nontemporal_store(o23.y, yo + 3);
+            if constexpr (YH2) {
+                h2_store_row_nt(y + row * kC, o01.x, o01.y, o23.x, o23.y, sy);
+            } else {
+                __builtin_nontemporal_store(o01.x, yo);
+                __builtin_nontemporal_store(o01.y, yo + 1);
+                __builtin_nontemporal_store(o23.x, yo + 2);
+                __builtin_nontemporal_store(o23.y, yo + 3);
+            }
             if (lane == 0) { mean_out[row] = mua; rstd_out[row] = rsa; }
         }
         if (has_b) {
@@ -102,10 +110,14 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(
             float* yo = y + row * kC + c;
             const f32x2 o01 = __builtin_elementwise_max(__builtin_elementwise_fma(db01 * f32x2{rsb, rsb}, g01, n01), zero2);
             const f32x2 o23 = __builtin_elementwise_max(__builtin_elementwise_fma(db23 * f32x2{rsb, rsb}, g23, n23), zero2);
-            __builtin_nontemporal_store(o01.x, yo);
-            __builtin_nontemporal_store(o01.y, yo + 1);
-            __builtin_nontemporal_store(o23.x, yo + 2);
-            __builtin_nontemporal_store(o23.y, yo + 3);
+            if constexpr (YH2) {
+                h2_store_row_nt(y + row * kC, o01.x, o01.y, o23.x, o23.y, sy);
+            } else {
+                __builtin_nontemporal_store(o01.x, yo);
+                __builtin_nontemporal_store(o01.y, yo + 1);
+                __builtin_nontemporal_store(o23.x, yo + 2);
+                __builtin_nontemporal_store(o23.y, yo + 3);
+            }
             if (lane == 0) { mean_out[row] = mub; rstd_out[row] = rsb; }
         }
     }
@@ -338,10 +350,22 @@ using namespace cpc;
 extern "C" int cpc_conv0_forward(const float* wave, const float* w, const float* bias,
                                  const float* nw, const float* nb, float* y, float* mean,
                                  float* rstd, int B, int L, void* stream) {
+    return cpc_conv0_forward_h2(wave, w, bias, nw, nb, y, mean, rstd, nullptr, B, L, stream);
+}
+
+// y_amax != NULL: y is written in H2 storage (two fp16 pieces per element, cpc_common.h) scaled by
+// scale_for_amax(*y_amax); *y_amax must bound |y| (the ChannelNorm bound, norm_bound_kernel).  NULL: fp32.
+extern "C" int cpc_conv0_forward_h2(const float* wave, const float* w, const float* bias, const float* nw,
+                                    const float* nb, void* y, float* mean, float* rstd, const float* y_amax, int B,
+                                    int L, void* stream) {
     CPC_RETURN_IF(B <= 0 || L < K0 - 2 * P0, CPC_ERR_SHAPE);
     const int L0 = conv_out_len(L, K0, S0, P0);
-    hipLaunchKernelGGL(conv0_fwd_kernel, dim3(cdiv(L0, C0_TT), B), dim3(256), 0, (hipStream_t)stream,
-                       wave, w, bias, nw, nb, y, mean, rstd, L, L0);
+    if (y_amax)
+        hipLaunchKernelGGL(conv0_fwd_kernel<true>, dim3(cdiv(L0, C0_TT), B), dim3(256), 0, (hipStream_t)stream,
+                           wave, w, bias, nw, nb, reinterpret_cast<float*>(y), mean, rstd, L, L0, y_amax);
+    else
+        hipLaunchKernelGGL(conv0_fwd_kernel<false>, dim3(cdiv(L0, C0_TT), B), dim3(256), 0, (hipStream_t)stream,
+                           wave, w, bias, nw, nb, reinterpret_cast<float*>(y), mean, rstd, L, L0, y_amax);
     CPC_LAUNCH_CHECK();
     return 0;
 }

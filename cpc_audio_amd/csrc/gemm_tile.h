@@ -307,6 +307,22 @@ __device__ __forceinline__ float scale_for_amax(float amax) {
     return ldexpf(1.0f, e);                            // operand with amax < 2^-46 is scaled as far as that allows
 }
 
+// (O,I,W) conv weight -> K-tile-major H2 rows for the DMA kernels (conv_dma.hip): element (co, kg = kk*C + ci) of
+// w * scale_for_amax(amax) goes to row (kg / 32) * 256 + co, a 128-byte row of four 8-element groups [h x 8 | l x 8].
+__device__ __forceinline__ void permute_w_h2_elem(const float* __restrict__ w, unsigned char* __restrict__ wq, int k,
+                                                  float amax, long idx) {
+    const int co = (int)(idx / (k * kC));
+    const int rem = (int)(idx - (long)co * k * kC);
+    const int kk = rem >> kCLog2, ci = rem & (kC - 1);
+    const float v = w[((long)co * kC + ci) * k + kk];
+    _Float16 h, l;
+    h2_split(v, scale_for_amax(amax), h, l);
+    unsigned char* row = wq + ((long)(rem >> 5) * kC + co) * 128;
+    _Float16* p = reinterpret_cast<_Float16*>(row + h2_byte_of(rem & 31));
+    p[0] = h;
+    p[8] = l;
+}
+
 template <int NP> struct SplitPlanes;
 template <> struct SplitPlanes<3> {                  // three bf16 pieces, six products, no scaling
     static constexpr int NPROD = 6;
@@ -783,7 +799,9 @@ RowCursor ca[A_PER], cb[B_PER];
 // one 8-byte LDS store.  LDS then holds the same K-major planes as NtTileX3 ([column][m]) and the
 // compute step is shared.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1, int NP = 3>
+// BH2 (NP == 2 only): the B operand is stored in H2 form (cpc_common.h: two fp16 pieces per element, already scaled by sb):
+// the loader fetches the pieces and transposes them, no split VALU.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1, int NP = 3, bool BH2 = false>
 struct TnTileX3 {   // NP: see NtTileX3
     static constexpr int BK = BK_;
     static constexpr int LDH = BK + 8;
@@ -852,9 +870,43 @@ struct TnTileX3 {   // NP: see NtTileX3
         }
     }
 
+    // the same for a block that arrives as H2 pieces: v[r] = {h0h1, h2h3, l0l1, l2l3} (bit patterns) of row r
+    __device__ static __forceinline__ void store_block_h2(unsigned short* base, int plane, int col0, int mofs,
+                                                          const float4 (&v)[4]) {
+        constexpr int SWM = BK / 8 - 1;
+        const int mphys = (((mofs >> 2) ^ (2 * ((col0 >> 3) & SWM))) << 2);
+        unsigned h[4][4], l[4][4];               // [row][col], 16-bit values
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned hx = __float_as_uint(v[r].x), hy = __float_as_uint(v[r].y);
+            const unsigned lx = __float_as_uint(v[r].z), ly = __float_as_uint(v[r].w);
+            h[r][0] = hx & 0xFFFFu; h[r][1] = hx >> 16; h[r][2] = hy & 0xFFFFu; h[r][3] = hy >> 16;
+            l[r][0] = lx & 0xFFFFu; l[r][1] = lx >> 16; l[r][2] = ly & 0xFFFFu; l[r][3] = ly >> 16;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned short* dst = base + (col0 + c) * LDH + mphys;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(h[0][c] | (h[1][c] << 16), h[2][c] | (h[3][c] << 16));
+            *reinterpret_cast<uint2*>(dst + plane) = make_uint2(l[0][c] | (l[1][c] << 16), l[2][c] | (l[3][c] << 16));
+        }
+    }
+    // H2 pieces of elements k .. k+3 (k % 4 == 0) of an im2col row: tap k >> 8, channel k & 255 of a 1 KB H2 row
+    __device__ static __forceinline__ float4 load_row4_h2(const RowRef& r, int k, int Lin, const float* safe) {
+        const int tau = r.tau0 + (k >> kCLog2);
+        const bool ok = (unsigned)tau < (unsigned)Lin;
+        const unsigned char* p = ok ? reinterpret_cast<const unsigned char*>(r.ptr + (k & ~(kC - 1))) + h2_byte_of(k & (kC - 1))
+                                    : reinterpret_cast<const unsigned char*>(safe);
+        const uint2 hp = *reinterpret_cast<const uint2*>(p), lp = *reinterpret_cast<const uint2*>(p + 16);
+        float4 v;
+        v.x = ok ? __uint_as_float(hp.x) : 0.f; v.y = ok ? __uint_as_float(hp.y) : 0.f;
+        v.z = ok ? __uint_as_float(lp.x) : 0.f; v.w = ok ? __uint_as_float(lp.y) : 0.f;
+        return v;
+    }
+
     __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int c0,
                                const RowMap& bm, int n0, int mbeg, int mend, float* smem_f,
                                float sa = 1.0f, float sb = 1.0f) {
+        static_assert(!BH2 || NP == 2, "H2 operands are two fp16 pieces");
         unsigned short* smem0 = reinterpret_cast<unsigned short*>(smem_f);
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -905,7 +957,8 @@ struct TnTileX3 {   // NP: see NtTileX3
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const RowRef rr = cursor_ref(bm, cursor_plus(bm, cb[i], r), b_on[i] && (mm + b_m[i] + r) < mend);
-                    rb[i][r] = load_row4(rr, n0 + b_c[i], bm.Lin, bm.base);
+                    if constexpr (BH2) rb[i][r] = load_row4_h2(rr, n0 + b_c[i], bm.Lin, bm.base);
+                    else rb[i][r] = load_row4(rr, n0 + b_c[i], bm.Lin, bm.base);
                 }
                 cb[i] = cursor_plus(bm, cb[i], BK);
             }
@@ -917,7 +970,10 @@ struct TnTileX3 {   // NP: see NtTileX3
                 if (a_on[i]) store_block(smem, PLANE_A, a_c[i], a_m[i], ra[i], sa);
 #pragma unroll
             for (int i = 0; i < B_PER; ++i)
-                if (b_on[i]) store_block(smem + NP * PLANE_A, PLANE_B, b_c[i], b_m[i], rb[i], sb);
+                if (b_on[i]) {
+                    if constexpr (BH2) store_block_h2(smem + NP * PLANE_A, PLANE_B, b_c[i], b_m[i], rb[i]);
+                    else store_block(smem + NP * PLANE_A, PLANE_B, b_c[i], b_m[i], rb[i], sb);
+                }
         };
         const int arow = wm * WM + (lane & 31);
         const int brow = wn * WN + (lane & 31);

@@ -7,6 +7,7 @@ scratch) comes from torch's caching allocator; kernels are enqueued on torch's c
 stream of the input's device.  There is no CPU implementation: CPU tensors raise.
 """
 import ctypes
+from contextlib import nullcontext as _nullcontext
 
 import torch
 
@@ -179,6 +180,21 @@ def _layout(kind, fn, n, *args):
         v = tuple(sizes)
         _layout_cache[key] = v
     return v
+
+
+def saved_encoder_activations(saved, B, L):
+    """fp32 copies (B, L_i, 256) of the four intermediate activations y0..y3 an EncoderFunction forward left in ``saved``
+    (layers 0 and 1 are kept as two fp16 pieces per element in the default mode).  Parity tests only."""
+    lib = _lib.get()
+    with torch.cuda.device(saved.device) if saved.is_cuda else _nullcontext():
+        sizes = _layout("encoder_layout", lib.cpc_encoder_layout, 22, B, L)
+        out = []
+        for i in range(4):
+            y = torch.empty(B, sizes[3 + i], _HID, device=saved.device, dtype=torch.float32)
+            lib.check(lib.cpc_encoder_saved_activation(_p(saved), i, _p(y), B, L, _stream() if saved.is_cuda else None),
+                      "encoder_saved_activation")
+            out.append(y)
+    return out
 
 
 class EncoderFunction(torch.autograd.Function):

@@ -35,7 +35,10 @@ int cpc_abi_version(void);
  *     fp16 pieces, three fp16 MFMAs per product (hh + hl + lh), fp32 accumulate: error <= 2^-21 per product,
  *     half the MFMAs of mode 1.  Applies to the conv layers (forward, dgrad, wgrad), whose operand bounds
  *     come for free (ChannelNorm affine; max|gradient| accumulated by the producing kernel); the small generic
- *     GEMMs (projections, heads, weight gradients of the AR / criterion) run as in mode 1. */
+ *     GEMMs (projections, heads, weight gradients of the AR / criterion) run as in mode 1.  *   3 (default) as 2, and the encoder (cpc_encoder_forward / _backward) keeps the output of layer 0 -- at B >= ~100 also
+ *     of layer 1 -- in H2 storage (below): conv1 (conv2), 70 % (87 %) of the conv stack's FLOPs, read both GEMM operands
+ *     global -> LDS by DMA (csrc/conv_dma.hip, 256- / 128-row tiles); their weight gradients read the pieces as stored.  The
+ *     per-layer entry points (cpc_conv_layer_*, cpc_conv_gemm_forward, cpc_norm_backward) behave as in mode 2. */
 int cpc_set_mfma_mode(int mode);
 
 /* Device-side error flags of the current device, accumulated since they were last cleared (clear != 0 clears them):
@@ -60,6 +63,31 @@ int cpc_device_error_flags(int clear);
 int cpc_conv0_forward(const float* wave, const float* w, const float* bias, const float* nw,
                       const float* nb, float* y, float* mean, float* rstd, int B, int L,
                       void* stream);
+/* "H2" activation storage (csrc/cpc_common.h): an fp32 tensor of 256-channel rows kept as two fp16 pieces per element,
+ * x * s = h + l with s = the power of two that maps a bound *amax >= max|x| into fp16's range -- exactly the two operand
+ * pieces of the 3-product fp16 GEMM tiles -- laid out per 8 channels as [h x 8 | l x 8] (32 bytes; 1 KB per row, as fp32).
+ * In mode 3 (cpc_set_mfma_mode) the encoder keeps the outputs of layers 0 and 1 in this form: conv1 / conv2 then read both
+ * GEMM operands global -> LDS by DMA.  The entry points below expose the pieces (tests, benchmarks, other callers). */
+/* conv0 writing y in H2 storage scaled by scale(*y_amax) (y_amax == NULL: plain fp32, = cpc_conv0_forward) */
+int cpc_conv0_forward_h2(const float* wave, const float* w, const float* bias, const float* nw, const float* nb,
+                         void* y, float* mean, float* rstd, const float* y_amax, int B, int L, void* stream);
+/* fp32 (n_rows,256) <-> H2 with the scale of *amax */
+int cpc_h2_encode(const float* src, void* dst, long n_rows, const float* amax, void* stream);
+int cpc_h2_decode(const void* src, float* dst, long n_rows, const float* amax, void* stream);
+/* conv weight (256,256,k) -> the DMA kernel's K-tile-major H2 rows; wq: 256*k*256 + 64 floats (max|w| behind the tiles) */
+int cpc_conv_weight_relayout_h2(const float* w, float* wq, int k, void* stream);
+/* One conv layer (k = 2s) + bias + ChannelNorm + ReLU on the DMA kernel (conv_dma.hip, one launch): x in H2 storage scaled
+ * by scale(*x_amax); y in H2 storage scaled by scale(*y_amax) (which must bound |y|), or fp32 when y_amax == NULL; xhat,
+ * rstd fp32.  zeros: 32 floats of zeros (padding rows).  bm: rows per workgroup, 128 / 256 (0: by problem size). */
+int cpc_conv_gemm_forward_h2(const void* x_h2, const float* wq, const float* bias, const float* nw, const float* nb,
+                             void* y, float* xhat, float* rstd, const float* x_amax, const float* y_amax,
+                             const float* zeros, int B, int Lin, int k, int s, int p, int bm, void* stream);
+/* tuning knobs of the DMA kernel inside the composite encoder: rows per workgroup (0 / 128 / 256) and the K-walk
+ * rotation step between neighbouring workgroups (0: lockstep) */
+int cpc_set_dma_tile(int bm);
+int cpc_set_h2_layers(int n);            /* mode 3: 1 = only conv1, 2 = conv1 and conv2 read H2 input; 0 = by problem size */
+int cpc_set_dma_rotation(int step);
+int cpc_set_dma_pipeline(int variant);   /* 0 (default): four 16-k LDS stages, three in flight; 1: two 32-k stages */
 long cpc_conv0_backward_scratch_floats(int B, int L);
 /* Backward of layer 0 (no dgrad: the waveform needs no gradient, train.py:81-87).
  * dy = gradient w.r.t. y.  Outputs dW0 (256,1,10), dB0, dNW0, dNB0 (256) are overwritten. */
@@ -121,6 +149,9 @@ int cpc_set_conv_tile(int bm);
  * cpc_encoder_layout fills sizes[0..21]: [0] saved floats, [1] fwd scratch floats,
  * [2] bwd scratch floats, [3..7] L0..L4, then offsets into `saved` (see enc_conv.hip). */
 int cpc_encoder_layout(int B, int L, long* sizes);
+/* fp32 copy of the saved output of layer `layer` (0..3) of a cpc_encoder_forward, whatever its storage: dst (B,L_layer,256).
+ * Tests / debugging; call it in the mode the forward ran in. */
+int cpc_encoder_saved_activation(const float* saved, int layer, float* dst, int B, int L, void* stream);
 int cpc_encoder_forward(const float* wave, const float* const* params, float* saved,
                         float* scratch, float* z, int B, int L, void* stream);
 int cpc_encoder_backward(const float* wave, const float* const* params, const float* saved,

@@ -372,6 +372,16 @@ static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+// LDS DMA: lane l's `size` bytes land at (wave-uniform) lds base + l * size, synchronously in the emulator
+namespace hipemu {
+static inline void global_load_lds(const void* g, void* lds_base, unsigned size, int offset) {
+    memcpy(reinterpret_cast<char*>(lds_base) + offset + (size_t)(threadIdx.x & 63) * size, g, size);
+}
+}  // namespace hipemu
+#define __builtin_amdgcn_global_load_lds(g, l, size, offset, aux) \
+    hipemu::global_load_lds((const void*)(g), (void*)(l), (size), (offset))
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() hipemu::block_sync()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 

@@ -29,14 +29,31 @@ def _oracle_encoder(p, wave, dz, relu_override=None):
     return z.detach(), [a.detach().permute(0, 2, 1).contiguous() for a in acts], leaves
 
 
+def _saved_acts(lib, saved, B, L, Ls):
+    """fp32 copies of y0..y3 whatever their storage (mode 3 keeps y0, y1 as fp16 piece pairs)"""
+    out = []
+    for i in range(4):
+        y = torch.full((B, Ls[i], 256), float("nan"))
+        assert lib.cpc_encoder_saved_activation(P(saved), i, P(y), B, L, None) == 0
+        out.append(y)
+    return out
+
+
 @pytest.mark.parametrize("B,L,bm,mode", [(2, 1280, 0, 1), (1, 1370, 64, 1), (1, 1600, 128, 1), (3, 1290, 128, 0),
-                                          (2, 1280, 0, 0), (1, 1600, 128, 2), (2, 1280, 0, 2), (1, 1370, 64, 2)])
+                                          (2, 1280, 0, 0), (1, 1600, 128, 2), (2, 1280, 0, 2), (1, 1370, 64, 2),
+                                          (2, 1280, 0, 3), (1, 1370, 64, 3), (3, 1290, 128, 3), (2, 1280, 0, 32),
+                                          (1, 1370, 0, 132)])
 def test_encoder_forward_backward_emulated(B, L, bm, mode):
     """mode 1: NT GEMMs on the bf16 pipe with 3-piece split operands; mode 0: exact-f32 MFMA; mode 2: fp16 pipe with
-    scaled 2-piece split operands."""
+    scaled 2-piece split operands; mode 3 (default): mode 2 + layers 1, 2 on the DMA kernel reading H2 activations
+    (ragged lengths: partial 128-row tiles, padding rows from the zero buffer)."""
     lib = emu()
+    # mode 32: mode 3 with conv2 on the DMA kernel as well (what B >= ~100 selects); 132: that with two 32-k LDS stages
+    h2_layers, pipe = (2, mode // 100) if mode >= 32 else (0, 0)
+    mode = 3 if mode >= 32 else mode
     assert lib.cpc_set_conv_tile(bm) == 0
     assert lib.cpc_set_mfma_mode(mode) == 0
+    assert lib.cpc_set_h2_layers(h2_layers) == 0 and lib.cpc_set_dma_pipeline(pipe) == 0
     try:
         torch.manual_seed(0)
         p, plist = _params()
@@ -52,13 +69,12 @@ def test_encoder_forward_backward_emulated(B, L, bm, mode):
         assert rc == 0
         dz = torch.randn(B, Ls[4], 256)
         # ReLU derivative of numerically tied pre-activations follows the device path (see oracle)
-        ys = [saved[sizes[8 + i]: sizes[8 + i] + B * Ls[i] * 256].view(B, Ls[i], 256) for i in range(4)] + [z]
+        ys = _saved_acts(lib, saved, B, L, Ls) + [z]
         z_ref, acts, leaves = _oracle_encoder(p, wave, dz, [(y > 0).permute(0, 2, 1) for y in ys])
         assert z_ref.shape == z.shape
         # intermediate activations y0..y3 live in the saved workspace
         for i in range(4):
-            yi = saved[sizes[8 + i]: sizes[8 + i] + B * Ls[i] * 256].view(B, Ls[i], 256)
-            assert (yi - acts[i]).abs().max().item() < 2e-5, f"layer {i}"
+            assert (ys[i] - acts[i]).abs().max().item() < 2e-5, f"layer {i}"
         assert (z - z_ref).abs().max().item() < 2e-5
 
         bscr = torch.full((sizes[2],), float("nan"))
@@ -89,6 +105,8 @@ def test_encoder_forward_backward_emulated(B, L, bm, mode):
     finally:
         lib.cpc_set_conv_tile(0)
         lib.cpc_set_mfma_mode(_lib_default_mode())
+        lib.cpc_set_h2_layers(0)
+        lib.cpc_set_dma_pipeline(0)
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -155,3 +173,50 @@ def test_fp16_split_scaling_extremes_emulated(xs, ws):
     assert torch.isfinite(outs[1]).all()
     if xs * ws > 1e-25:        # below that the conv output itself underflows against the norm's epsilon in BOTH modes
         assert (outs[0] - outs[1]).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,Lin,k,s,p,bm,y_h2,pipe", [(1, 300, 8, 4, 2, 128, True, 0), (2, 131, 4, 2, 1, 256, False, 0),
+                                                    (1, 70, 8, 4, 2, 256, True, 1), (1, 300, 4, 2, 1, 128, False, 1)])
+def test_dma_conv_kernel_matches_the_register_staged_kernel_emulated(B, Lin, k, s, p, bm, y_h2, pipe):
+    """cpc_conv_gemm_forward_h2 (both operands DMA'd into XOR-swizzled LDS rows, H2 storage) against
+    cpc_conv_layer_forward in mode 2 on the same fp32 data: same pieces, same products, same ChannelNorm -- results agree
+    to fp32 summation-order noise.  Covers padding rows (zero buffer), ragged last tiles, both tile heights, both output
+    storages, and the H2 encode / decode round trip."""
+    lib = emu()
+    torch.manual_seed(7)
+    Lout = (Lin + 2 * p - k) // s + 1
+    x = torch.randn(B, Lin, 256).relu().contiguous()
+    w = (torch.randn(256, 256, k) / (16.0 * k ** 0.5)).contiguous()
+    bias = 0.1 * torch.randn(256); nw = 1 + 0.1 * torch.randn(256); nb = 0.1 * torch.randn(256)
+    assert lib.cpc_set_mfma_mode(2) == 0
+    try:
+        wp = torch.zeros(256 * k * 256 * 3 // 2)
+        y_ref = torch.full((B, Lout, 256), float("nan")); xh_ref = torch.full_like(y_ref, float("nan")); rs_ref = torch.zeros(B * Lout)
+        assert lib.cpc_conv_layer_forward(P(x), P(w), P(bias), P(nw), P(nb), P(wp), P(y_ref), P(xh_ref), P(rs_ref), B, Lin, k,
+                                          s, p, None) == 0
+    finally:
+        lib.cpc_set_mfma_mode(_lib_default_mode())
+    xamax = x.abs().max().view(1).clone() * 1.7                 # any bound works
+    x_h2 = torch.zeros(B, Lin, 256)
+    assert lib.cpc_h2_encode(P(x), P(x_h2), B * Lin, P(xamax), None) == 0
+    back = torch.full_like(x, float("nan"))
+    assert lib.cpc_h2_decode(P(x_h2), P(back), B * Lin, P(xamax), None) == 0
+    assert (back - x).abs().max().item() <= 2.0 ** -21 * x.abs().max().item()
+    wq = torch.zeros(256 * k * 256 + 64)
+    assert lib.cpc_conv_weight_relayout_h2(P(w), P(wq), k, None) == 0
+    zeros = torch.zeros(32)
+    yamax = (15.968719 * nw.abs().max() + nb.abs().max()).view(1).clone()
+    y = torch.full((B, Lout, 256), float("nan")); xh = torch.full_like(y, float("nan")); rs = torch.zeros(B * Lout)
+    assert lib.cpc_set_dma_pipeline(pipe) == 0           # 0: four 16-k LDS stages, 1: two 32-k stages
+    try:
+        assert lib.cpc_conv_gemm_forward_h2(P(x_h2), P(wq), P(bias), P(nw), P(nb), P(y), P(xh), P(rs), P(xamax),
+                                            P(yamax) if y_h2 else None, P(zeros), B, Lin, k, s, p, bm, None) == 0
+    finally:
+        lib.cpc_set_dma_pipeline(0)
+    if y_h2:
+        dec = torch.full_like(y, float("nan"))
+        assert lib.cpc_h2_decode(P(y), P(dec), B * Lout, P(yamax), None) == 0
+        y = dec
+    assert (xh - xh_ref).abs().max().item() < 2e-5
+    assert (rs - rs_ref).abs().max().item() < 2e-5 * rs_ref.abs().max().item()
+    assert (y - y_ref).abs().max().item() < 2e-5

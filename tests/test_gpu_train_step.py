@@ -27,6 +27,7 @@ def _hip_step(p, wave, bidx, sidx, dev):
     ops.KEEP_DEBUG = True
     c, z, _ = model(wave.to(dev), torch.zeros(wave.shape[0], dtype=torch.long, device=dev))
     saved, sizes, zz = ops.debug_last["encoder"]
+    acts_dev = ops.saved_encoder_activations(saved, wave.shape[0], wave.shape[2])
     ops.KEEP_DEBUG = False
     z.retain_grad(); c.retain_grad()
     losses, acc = crit(c, z, None, negatives=(bidx.to(dev), sidx.to(dev)))
@@ -44,7 +45,7 @@ def _hip_step(p, wave, bidx, sidx, dev):
     _lib.get().check(_lib.get().cpc_nce_layout(B, 128, 12, 128, lay))
     logits = nce_saved[lay[4]: lay[4] + B * 116 * 12 * 129].view(B, 116, 12, 129).cpu()
     Ls = [sizes[3 + i] for i in range(5)]
-    ys = [saved[sizes[8 + i]: sizes[8 + i] + B * Ls[i] * 256].view(B, Ls[i], 256).cpu() for i in range(4)] + [zz.cpu()]
+    ys = [t.cpu() for t in acts_dev] + [zz.cpu()]
     grads = {}
     for k, v in model.state_dict(keep_vars=True).items():
         grads[k] = v.grad.cpu()
