@@ -323,63 +323,90 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
 // stand-alone version for the top layer (its dy comes from autograd, not from a dgrad GEMM)
 constexpr int NB_ROWS = 32;   // rows per block (8 per wave)
 // dx_amax (may be NULL): max|dx| is accumulated into it for the fp16-split GEMMs that consume dx
-// YH2: y is in H2 storage (cpc_common.h); only its sign is needed here, and that of the h piece is the value's
-template <bool YH2>
+// MASK: where [y > 0] comes from.  0: y in fp32; 1: y in H2 storage (cpc_common.h; the sign of the h piece is the value's);
+// 2: recomputed as fmaf(xhat, w, b) > 0 -- the very expression the forward kernels rectify, on the very xhat they stored,
+// so the mask is bit-identical and the 4 bytes per element of y are not read at all (the composite encoder's choice).
+// The kernel streams 12-16 bytes per element and is latency-bound per row (two dependent wave reductions), so a wave
+// keeps the loads of four rows in flight and interleaves their reduction chains (0.25 -> ... ms per step for the four layers).
+constexpr int NBW = 4;        // rows a wave works on at a time
+template <int MASK>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ y,
-    const float* __restrict__ rstd, const float* __restrict__ nw, float* __restrict__ dx,
+    const float* __restrict__ rstd, const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ dx,
     float* __restrict__ colpart, int M, float* __restrict__ dx_amax) {
     __shared__ float red[4][3][kC];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = lane * 4;
     const float4 w4 = *reinterpret_cast<const float4*>(nw + c);
     const float gw[4] = {w4.x, w4.y, w4.z, w4.w};
+    float gb[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MASK == 2) {
+        const float4 b4 = *reinterpret_cast<const float4*>(nb + c);
+        gb[0] = b4.x; gb[1] = b4.y; gb[2] = b4.z; gb[3] = b4.w;
+    }
     float cs[3][4];
     float amax = 0.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int q = 0; q < 4; ++q) cs[a][q] = 0.f;
-    for (int rr = wv; rr < NB_ROWS; rr += 4) {
-        const int m = blockIdx.x * NB_ROWS + rr;
-        if (m >= M) break;                     // wave-uniform
-        const float4 g4 = *reinterpret_cast<const float4*>(dy + (long)m * kC + c);
-        const float4 x4 = *reinterpret_cast<const float4*>(xhat + (long)m * kC + c);
-        float yv[4];
-        if constexpr (YH2) {
-            uint2 hp, lp;
-            h2_load4_raw(y + (long)m * kC, c, hp, lp);
-            yv[0] = (float)(short)(hp.x & 0xFFFFu); yv[1] = (float)(short)(hp.x >> 16);      // > 0 iff the fp16 piece is
-            yv[2] = (float)(short)(hp.y & 0xFFFFu); yv[3] = (float)(short)(hp.y >> 16);
-        } else {
-            const float4 y4 = *reinterpret_cast<const float4*>(y + (long)m * kC + c);
-            yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
-        }
-        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
-        const float xh[4] = {x4.x, x4.y, x4.z, x4.w};
-        const float rs = rstd[m];
-        float dxh[4], s1 = 0.f, s2 = 0.f;
+    static_assert(NB_ROWS % (4 * NBW) == 0, "whole batches of rows per wave");
+    for (int r0 = wv; r0 < NB_ROWS; r0 += 4 * NBW) {
+        // rows r0, r0 + 4, ... of this block (the four waves interleave); out-of-range rows read row 0 and are dropped
+        int m[NBW];
+        bool live[NBW];
+        f32x4 g4[NBW], x4[NBW];
+        float yv[NBW][4], rs[NBW];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float dyh = yv[q] > 0.f ? g[q] : 0.f;
-            cs[0][q] = fmaf(dyh, xh[q], cs[0][q]);
-            cs[1][q] += dyh;
-            dxh[q] = dyh * gw[q];
-            s1 += dxh[q];
-            s2 = fmaf(dxh[q], xh[q], s2);
+        for (int j = 0; j < NBW; ++j) {
+            m[j] = blockIdx.x * NB_ROWS + r0 + 4 * j;
+            live[j] = m[j] < M;
+            const long row = live[j] ? m[j] : 0;
+            g4[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dy + row * kC + c));     // read once
+            x4[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xhat + row * kC + c));
+            rs[j] = rstd[row];
+            if constexpr (MASK == 1) {
+                uint2 hp, lp;
+                h2_load4_raw(y + row * kC, c, hp, lp);
+                yv[j][0] = (float)(short)(hp.x & 0xFFFFu); yv[j][1] = (float)(short)(hp.x >> 16);   // > 0 iff the fp16 piece is
+                yv[j][2] = (float)(short)(hp.y & 0xFFFFu); yv[j][3] = (float)(short)(hp.y >> 16);
+            } else if constexpr (MASK == 0) {
+                const float4 y4 = *reinterpret_cast<const float4*>(y + row * kC + c);
+                yv[j][0] = y4.x; yv[j][1] = y4.y; yv[j][2] = y4.z; yv[j][3] = y4.w;
+            }
         }
-        s1 = wave_sum(s1) * (1.0f / kC);
-        s2 = wave_sum(s2) * (1.0f / (kC - 1));
-        float4 o;
-        float ov[4];
+        float dxh[NBW][4], s1[NBW], s2[NBW];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ov[q] = rs * (dxh[q] - s1 - xh[q] * s2);
-            cs[2][q] += ov[q];
-            amax = fmaxf(amax, fabsf(ov[q]));
+        for (int j = 0; j < NBW; ++j) {
+            s1[j] = 0.f; s2[j] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float yq = MASK == 2 ? fmaf(x4[j][q], gw[q], gb[q]) : yv[j][q];
+                const float dyh = (live[j] && yq > 0.f) ? g4[j][q] : 0.f;
+                cs[0][q] = fmaf(dyh, x4[j][q], cs[0][q]);
+                cs[1][q] += dyh;
+                dxh[j][q] = dyh * gw[q];
+                s1[j] += dxh[j][q];
+                s2[j] = fmaf(dxh[j][q], x4[j][q], s2[j]);
+            }
         }
-        o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
-        *reinterpret_cast<float4*>(dx + (long)m * kC + c) = o;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {          // independent chains: the DPP steps of the rows interleave
+            s1[j] = wave_sum(s1[j]) * (1.0f / kC);
+            s2[j] = wave_sum(s2[j]) * (1.0f / (kC - 1));
+        }
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = live[j] ? rs[j] * (dxh[j][q] - s1[j] - x4[j][q] * s2[j]) : 0.f;
+                o[q] = v;
+                cs[2][q] += v;
+                amax = fmaxf(amax, fabsf(v));
+            }
+            if (live[j]) *reinterpret_cast<f32x4*>(dx + (long)m[j] * kC + c) = o;
+        }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -858,7 +885,7 @@ extern "C" int cpc_norm_backward(const float* dy, const float* xhat, const float
     CPC_RETURN_IF(M <= 0, CPC_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     const int nblk = cdiv(M, NB_ROWS);
-    hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(nblk), dim3(256), 0, st, dy, xhat, y, rstd, nw, dx, colpart, M, dx_amax);
+    hipLaunchKernelGGL(norm_bwd_kernel<0>, dim3(nblk), dim3(256), 0, st, dy, xhat, y, rstd, nw, nullptr, dx, colpart, M, dx_amax);
     CPC_LAUNCH_CHECK();
     return rows_sum(colpart, nblk, 3 * kC, tmp, small3, st);
 }
@@ -1096,12 +1123,10 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     int njobs = 0;
     auto norm_bwd = [&](int layer, const float* dy, const float* yl, float* dxl) {
         const int M = B * e.L[layer], nblk = cdiv(M, NB_ROWS);
-        if (act_h2(layer))
-            hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
-                               saved + e.rstd[layer], params[4 * layer + 2], dxl, scratch + e.colp[layer], M, amax + layer);
-        else
-        hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
-                           saved + e.rstd[layer], params[4 * layer + 2], dxl, scratch + e.colp[layer], M, amax + layer);
+        // the ReLU mask is recomputed from xhat and the affine (bit-identical to the forward's): y is not read
+        hipLaunchKernelGGL(norm_bwd_kernel<2>, dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
+                           saved + e.rstd[layer], params[4 * layer + 2], params[4 * layer + 3], dxl, scratch + e.colp[layer], M,
+                           amax + layer);
         jobs[njobs++] = RowsSumJob{scratch + e.colp[layer], nblk, 3 * kC, scratch + e.tmpq[layer], small + layer * 3 * kC};
     };
     int rc = 0;

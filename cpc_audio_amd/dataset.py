@@ -28,7 +28,7 @@ from pathlib import Path
 
 import numpy as np
 import torch
-from torch.utils.data import Dataset, Sampler
+from torch.utils.data import Dataset
 
 # ----------------------------------------------------------------------------------------------- file readers
 _READERS = {}
@@ -268,6 +268,7 @@ class AudioBatchData(Dataset):
             return batch, speaker, torch.zeros(len(idx), 1, device=self.device)
         return batch, speaker
 
+    # -- counts (names as in cpc/dataset.py:203-213)
     def getNSpeakers(self):
         return len(self.speakers)
 
@@ -275,126 +276,176 @@ class AudioBatchData(Dataset):
         return len(self.seqLabel) - 1
 
     def getNLoadsPerEpoch(self):
-        return len(self.packageIndex)
+        return self.getNPacks()
+
+    # -- window plans
+    def window_plan(self, type, batchSize, offset, generator=None):
+        """All window starts of the pack that is loaded now, for one pass, as ONE tensor on the pack's device (WindowPlan)."""
+        n = len(self.data)
+        if type == "samespeaker":
+            return WindowPlan.grouped(self._bounds_tensor(self.speakerLabel), self.sizeWindow, batchSize, offset,
+                                      self.device, generator)
+        if type == "samesequence":
+            return WindowPlan.grouped(self._bounds_tensor(self.seqLabel), self.sizeWindow, batchSize, offset, self.device,
+                                      generator)
+        if type == "sequential":
+            return WindowPlan.sequential(n, self.sizeWindow, batchSize, offset, self.device)
+        return WindowPlan.uniform(n, self.sizeWindow, batchSize, offset, self.device, generator)
+
+    def _bounds_tensor(self, bounds):
+        return torch.as_tensor(bounds, dtype=torch.long, device=self.device)
 
     def getBaseSampler(self, type, batchSize, offset):
-        if type == "samespeaker":
-            return SameSpeakerSampler(batchSize, self.speakerLabel, self.sizeWindow, offset)
-        if type == "samesequence":
-            return SameSpeakerSampler(batchSize, self.seqLabel, self.sizeWindow, offset)
-        if type == "sequential":
-            return SequentialSampler(len(self.data), self.sizeWindow, offset, batchSize)
-        sampler = UniformAudioSampler(len(self.data), self.sizeWindow, offset)
-        return torch.utils.data.BatchSampler(sampler, batchSize, True)
+        """cpc/dataset.py:215-229's name for window_plan: an iterable of index batches with a length."""
+        return self.window_plan(type, batchSize, offset)
 
     def getDataLoader(self, batchSize, type, randomOffset, numWorkers=0, onLoop=-1):
-        """cpc/dataset.py:218-246.  ``numWorkers`` is accepted and ignored (batches are gathered in one shot)."""
-        nLoops = len(self.packageIndex)
-        totSize = self.totSize // (self.sizeWindow * batchSize)
+        """cpc/dataset.py:231-258: one pass over every pack (or over pack ``onLoop`` only), a fresh plan -- and a fresh
+        random offset in [0, sizeWindow/2] -- per pack.  ``numWorkers`` is accepted and ignored: a batch is one gather."""
+        packs = self.getNPacks()
         if onLoop >= 0:
             self.currentPack = onLoop - 1
             self.loadNextPack()
-            nLoops = 1
-
-        def samplerCall():
-            offset = random.randint(0, self.sizeWindow // 2) if randomOffset else 0
-            return self.getBaseSampler(type, batchSize, offset)
-
-        return AudioLoader(self, samplerCall, nLoops, self.loadNextPack, totSize, numWorkers)
+            packs = 1
+        return AudioLoader(self, type, batchSize, randomOffset, packs)
 
 
-class AudioLoader(object):
-    """cpc/dataset.py:261-316: iterate every pack once, one batch sampler per pack."""
+class WindowPlan:
+    """The window starts of one pass over a pack, for every sampling type of cpc/dataset.py:318-408, built with tensor
+    ops on the device the pack lives on (no Python loop over windows, no host round trip per batch):
 
-    def __init__(self, dataset, samplerCall, nLoop, updateCall, size, numWorkers):
-        self.samplerCall = samplerCall
-        self.updateCall = updateCall
-        self.nLoop = nLoop
-        self.size = size
-        self.dataset = dataset
-        self.numWorkers = numWorkers
+      ``starts``  (n_windows,) int64   the windows in the order they are served
+      ``ptr``     (n_batches + 1,)     batch j is starts[ptr[j] : ptr[j + 1]]  (the grouped types have short last batches)
+      ``order``   (n_batches,)         the order in which the batches are served
+
+    Iterating yields the index tensor of each batch (AudioBatchData.get_batch gathers it in one shot)."""
+
+    def __init__(self, starts, ptr, order):
+        self.starts, self.ptr, self.order = starts, ptr, order
+        self._ptr_host = ptr.tolist()                    # one transfer per pack: slicing needs host integers
+        self._order_host = order.tolist()
+
+    def __len__(self):
+        return len(self._order_host)
+
+    def __iter__(self):
+        for j in self._order_host:
+            yield self.starts[self._ptr_host[j]:self._ptr_host[j + 1]]
+
+    def batches(self):
+        """The plan as Python lists (tests, debugging)."""
+        return [b.tolist() for b in self]
+
+    @staticmethod
+    def _n_windows(span, sizeWindow, offset):
+        """Windows that fit in ``span`` samples (an int, or a tensor of interval lengths) once the first ``offset`` are
+        skipped; with an offset the reference gives up one window instead of computing (span - offset) // sizeWindow
+        (cpc/dataset.py:324-325,347-348,382-383)."""
+        n = torch.as_tensor(span) // sizeWindow
+        n = (n - (1 if offset > 0 else 0)).clamp(min=0)
+        return n if torch.is_tensor(span) else int(n)
+
+    @classmethod
+    def uniform(cls, dataSize, sizeWindow, batchSize, offset, device, generator=None):
+        """Every window once, in random order, whole batches only (BatchSampler(..., drop_last=True), dataset.py:229)."""
+        n = cls._n_windows(dataSize, sizeWindow, offset)
+        nb = n // batchSize
+        perm = torch.randperm(n, device=device, generator=generator)[:nb * batchSize]
+        return cls(offset + sizeWindow * perm, torch.arange(nb + 1, device=device) * batchSize,
+                   torch.arange(nb, device=device))
+
+    @classmethod
+    def sequential(cls, dataSize, sizeWindow, batchSize, offset, device):
+        """Batch item b walks its own contiguous dataSize // batchSize samples, window after window, so that a recurrent
+        state carried from batch to batch (CPCAR.keepHidden) always continues the audio it has seen (dataset.py:339-358)."""
+        n = max(0, (dataSize // sizeWindow) // batchSize - (1 if offset > 0 else 0))    # one whole step less with an offset
+        step = torch.arange(n, device=device).view(n, 1) * sizeWindow
+        lane = torch.arange(batchSize, device=device).view(1, batchSize) * (dataSize // batchSize)
+        return cls((offset + step + lane).reshape(-1), torch.arange(n + 1, device=device) * batchSize,
+                   torch.arange(n, device=device))
+
+    @classmethod
+    def grouped(cls, bounds, sizeWindow, batchSize, offset, device, generator=None):
+        """'samespeaker' / 'samesequence': every batch comes from ONE interval [bounds[i], bounds[i+1]) (a speaker, a
+        sequence); inside an interval every window once in random order, cut into batches of at most batchSize; the
+        batches of all intervals are served in random order (dataset.py:361-408)."""
+        if int(bounds[0]) != 0:
+            raise AttributeError("Sampling intervals should start at zero")
+        bounds = bounds.to(device)
+        count = cls._n_windows(bounds[1:] - bounds[:-1], sizeWindow, offset)           # windows per interval
+        first = torch.cumsum(count, 0) - count                                         # first slot of each interval
+        total = int(count.sum())
+        interval = torch.repeat_interleave(torch.arange(count.numel(), device=device), count)
+        slot = torch.arange(total, device=device) - first[interval]                    # position inside its interval
+        # a random order inside each interval: sort by (interval, uniform key) -- the integer part keeps intervals apart
+        key = interval.double() + torch.rand(total, device=device, dtype=torch.float64, generator=generator)
+        window = slot[torch.argsort(key)]                                              # which window sits at each slot
+        starts = offset + window * sizeWindow + bounds[interval]
+        nb = (count + batchSize - 1) // batchSize                                      # batches per interval
+        batch_of = (torch.cumsum(nb, 0) - nb)[interval] + slot // batchSize            # batch each slot belongs to
+        n_batches = int(nb.sum())
+        sizes = torch.bincount(batch_of, minlength=n_batches)
+        ptr = torch.cat([sizes.new_zeros(1), torch.cumsum(sizes, 0)])
+        return cls(starts, ptr, torch.randperm(n_batches, device=device, generator=generator))
+
+
+# The reference's sampler classes (cpc/dataset.py:318-408), kept by name and constructor for callers that build them
+# directly; each is a WindowPlan of the matching kind on the CPU.  The first two iterate single indices / index lists as
+# the reference's do (UniformAudioSampler is wrapped in a BatchSampler there).
+class UniformAudioSampler(WindowPlan):
+    def __init__(self, dataSize, sizeWindow, offset):
+        p = WindowPlan.uniform(dataSize, sizeWindow, 1, offset, torch.device("cpu"))
+        super().__init__(p.starts, p.ptr, p.order)
+
+    def __iter__(self):
+        return iter(self.starts.tolist())
+
+
+class SequentialSampler(WindowPlan):
+    def __init__(self, dataSize, sizeWindow, offset, batchSize):
+        p = WindowPlan.sequential(dataSize, sizeWindow, batchSize, offset, torch.device("cpu"))
+        super().__init__(p.starts, p.ptr, p.order)
+
+    def __iter__(self):
+        return iter(self.batches_as_lists())
+
+    def batches_as_lists(self):
+        return [b.tolist() for b in WindowPlan.__iter__(self)]
+
+
+class SameSpeakerSampler(WindowPlan):
+    def __init__(self, batchSize, samplingIntervals, sizeWindow, offset):
+        p = WindowPlan.grouped(torch.as_tensor(samplingIntervals, dtype=torch.long), sizeWindow, batchSize, offset,
+                               torch.device("cpu"))
+        super().__init__(p.starts, p.ptr, p.order)
+
+    def __iter__(self):
+        return iter([b.tolist() for b in WindowPlan.__iter__(self)])
+
+
+class AudioLoader:
+    """One pass over the data set: for every pack a fresh WindowPlan, every batch one device-side gather
+    (AudioBatchData.get_batch); the next pack -- prefetched in the background while this one was served -- is swapped in
+    between.  len() is the reference's estimate, total windows // batchSize (cpc/dataset.py:233,298-299)."""
+
+    def __init__(self, dataset, samplingType, batchSize, randomOffset, nPacks):
+        self.dataset, self.samplingType, self.batchSize = dataset, samplingType, batchSize
+        self.randomOffset, self.nPacks = randomOffset, nPacks
+        self.size = dataset.totSize // (dataset.sizeWindow * batchSize)
 
     def __len__(self):
         return self.size
 
-    def __iter__(self):
-        for i in range(self.nLoop):
-            for starts in self.samplerCall():
-                yield self.dataset.get_batch(starts)
-            if i < self.nLoop - 1:
-                self.updateCall()
-
-
-# ----------------------------------------------------------------------------------------------- samplers
-class UniformAudioSampler(Sampler):
-    """cpc/dataset.py:318-336: every window of the pack once, in random order."""
-
-    def __init__(self, dataSize, sizeWindow, offset):
-        self.len = dataSize // sizeWindow
-        self.sizeWindow = sizeWindow
-        self.offset = offset
-        if self.offset > 0:
-            self.len -= 1
+    def plan(self):
+        offset = random.randint(0, self.dataset.sizeWindow // 2) if self.randomOffset else 0
+        return self.dataset.window_plan(self.samplingType, self.batchSize, offset)
 
     def __iter__(self):
-        return iter((self.offset + self.sizeWindow * torch.randperm(self.len)).tolist())
-
-    def __len__(self):
-        return self.len
-
-
-class SequentialSampler(Sampler):
-    """cpc/dataset.py:339-358: batch item b walks its own contiguous 1/batchSize of the pack (hidden-state carry)."""
-
-    def __init__(self, dataSize, sizeWindow, offset, batchSize):
-        self.len = (dataSize // sizeWindow) // batchSize
-        self.sizeWindow = sizeWindow
-        self.offset = offset
-        self.startBatches = [x * (dataSize // batchSize) for x in range(batchSize)]
-        self.batchSize = batchSize
-        if self.offset > 0:
-            self.len -= 1
-
-    def __iter__(self):
-        for idx in range(self.len):
-            yield [self.offset + self.sizeWindow * idx + start for start in self.startBatches]
-
-    def __len__(self):
-        return self.len
-
-
-class SameSpeakerSampler(Sampler):
-    """cpc/dataset.py:361-408: every batch is drawn from ONE interval (speaker or sequence) of the pack."""
-
-    def __init__(self, batchSize, samplingIntervals, sizeWindow, offset):
-        self.samplingIntervals = samplingIntervals
-        self.sizeWindow = sizeWindow
-        self.batchSize = batchSize
-        self.offset = offset
-        if self.samplingIntervals[0] != 0:
-            raise AttributeError("Sampling intervals should start at zero")
-        nIntervals = len(self.samplingIntervals) - 1
-        self.sizeSamplers = [(self.samplingIntervals[i + 1] - self.samplingIntervals[i]) // self.sizeWindow
-                             for i in range(nIntervals)]
-        if self.offset > 0:
-            self.sizeSamplers = [max(0, x - 1) for x in self.sizeSamplers]
-        self.batches = []
-        for interval, n in enumerate(self.sizeSamplers):
-            if n <= 0:
-                continue
-            order = torch.randperm(n).tolist()
-            for first in range(0, n, self.batchSize):
-                self.batches.append([self.getIndex(x, interval) for x in order[first:first + self.batchSize]])
-
-    def __len__(self):
-        return len(self.batches)
-
-    def getIndex(self, x, iInterval):
-        return self.offset + x * self.sizeWindow + self.samplingIntervals[iInterval]
-
-    def __iter__(self):
-        random.shuffle(self.batches)
-        return iter(self.batches)
+        for pack in range(self.nPacks):
+            if pack:
+                self.dataset.loadNextPack()
+            for index in self.plan():
+                yield self.dataset.get_batch(index)
 
 
 # ----------------------------------------------------------------------------------------------- helpers

@@ -24,7 +24,9 @@ def emu():
         import build_emu
         from cpc_audio_amd import _lib
         try:
-            path = build_emu.build()
+            # CPC_EMU_SANITIZE=1 (tests/test_emu_sanitized.py runs a subset that way, with clang's ASan runtime preloaded):
+            # the AddressSanitizer + UBSan build of the same sources
+            path = build_emu.build(sanitize=os.environ.get("CPC_EMU_SANITIZE") == "1")
         except FileNotFoundError as e:  # no host clang: cannot emulate (a compile ERROR still fails the test)
             pytest.skip(f"emulator build unavailable: {e}")
         _emu = _lib.bind(path)

@@ -20,7 +20,25 @@ def _cxx():
     raise FileNotFoundError("clang++ not found")
 
 
-def build(force=False):
+def asan_runtime():
+    """clang's shared ASan runtime (to LD_PRELOAD into the python that loads the sanitized library), or None."""
+    hits = glob.glob(os.path.join(os.path.dirname(os.path.dirname(_cxx())), "lib", "clang", "*", "lib", "linux",
+                                  "libclang_rt.asan-x86_64.so"))
+    return hits[0] if hits else None
+
+
+def build(force=False, sanitize=False):
+    """sanitize: AddressSanitizer + UndefinedBehaviorSanitizer build of the same sources (libcpc_emu_san.so): every C entry
+    point, its host logic and the kernels' index arithmetic run under the sanitizers in tests/test_emu_sanitized.py."""
+    global OUT, LIB
+    if sanitize:
+        out_dir, lib = os.path.join(HERE, "_build", "san"), os.path.join(HERE, "_build", "san", "libcpc_emu_san.so")
+        return _build(force, out_dir, lib, ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                                            "-fno-omit-frame-pointer", "-shared-libasan", "-g1"])
+    return _build(force, OUT, LIB, [])
+
+
+def _build(force, OUT, LIB, extra):
     os.makedirs(OUT, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(HERE, "hipemu.cpp")]
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + \
@@ -28,7 +46,7 @@ def build(force=False):
     hdr_m = max(os.path.getmtime(h) for h in hdrs)
     flags = ["-O2", "-std=c++17", "-fPIC", "-x", "c++", "-I", os.path.join(HERE, "include"),
              "-ffp-contract=off", "-Wno-unused-value", "-Wno-unknown-pragmas", "-Wno-pass-failed",
-             "-Wno-unused-variable"]
+             "-Wno-unused-variable", *extra]
     jobs, objs = [], []
     for s in srcs:
         o = os.path.join(OUT, os.path.basename(s) + ".o")
@@ -46,7 +64,7 @@ def build(force=False):
         with cf.ThreadPoolExecutor(max_workers=8) as ex:
             list(ex.map(cc, jobs))
     if jobs or not os.path.exists(LIB):
-        r = subprocess.run([_cxx(), "-shared", "-fPIC", *objs, "-o", LIB, "-lpthread"], capture_output=True, text=True)
+        r = subprocess.run([_cxx(), "-shared", "-fPIC", *extra, *objs, "-o", LIB, "-lpthread"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"emu link failed:\n{r.stderr[-4000:]}")
     return LIB

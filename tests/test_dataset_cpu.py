@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from cpc_audio_amd.dataset import (AudioBatchData, SameSpeakerSampler, SequentialSampler, UniformAudioSampler,
+from cpc_audio_amd.dataset import (AudioBatchData, SameSpeakerSampler, SequentialSampler, UniformAudioSampler, WindowPlan,
                                    filterSeqs, findAllSeqs, parseSeqLabels)
 
 ALL = ["2911/12359/2911-12359-0007", "4051/11218/4051-11218-0044", "4397/15668/4397-15668-0003",
@@ -131,3 +131,62 @@ def test_phone_labels(db):
     data.doubleLabels = True
     _, spk, ph = data.get_batch([0, len(data.data) - 700])
     assert spk.tolist() == [0, 1] and ph.shape == (2, 4)
+
+
+@pytest.mark.parametrize("offset", [0, 1234])
+def test_window_plans_serve_every_window_once_and_respect_their_grouping(offset):
+    """The four sampling types of cpc/dataset.py:318-408 as tensor-built plans (WindowPlan): what each type promises."""
+    g = torch.Generator().manual_seed(3)
+    dev = torch.device("cpu")
+    n, B = 37 * W + 99, 4
+    cut = 1 if offset else 0
+    # uniform: every window of the pack once, whole batches only
+    u = WindowPlan.uniform(n, W, B, offset, dev, g)
+    flat = [x for b in u.batches() for x in b]
+    assert len(u) == (37 - cut) // B and all(len(b) == B for b in u.batches())
+    assert len(set(flat)) == len(flat) and set(flat) <= {offset + W * i for i in range(37 - cut)}
+    # sequential: item b of consecutive batches walks contiguous audio inside its own 1/B of the pack
+    q = WindowPlan.sequential(n, W, B, offset, dev).batches()
+    assert len(q) == 37 // B - cut
+    for i, b in enumerate(q):
+        assert b == [offset + W * i + lane * (n // B) for lane in range(B)]
+    assert all(x + W <= n for x in q[-1])
+    # grouped: one interval per batch, every window of every interval once, short last batches kept
+    bounds = [0, 5 * W + 17, 5 * W + 17, 6 * W, 19 * W + 3, n]   # an empty interval and one shorter than a window (with offset)
+    p = WindowPlan.grouped(torch.tensor(bounds), W, B, offset, dev, g)
+    seen = []
+    for b in p.batches():
+        which = {max(i for i in range(len(bounds) - 1) if bounds[i] <= x) for x in b}
+        assert len(which) == 1 and 1 <= len(b) <= B
+        i = which.pop()
+        assert all((x - offset - bounds[i]) % W == 0 and x + W <= bounds[i + 1] + (W if offset else 0) for x in b)
+        seen += b
+    expect = sum(max(0, (bounds[i + 1] - bounds[i]) // W - cut) for i in range(len(bounds) - 1))
+    assert len(seen) == len(set(seen)) == expect
+    assert len(p) == sum(-(-max(0, (bounds[i + 1] - bounds[i]) // W - cut) // B) for i in range(len(bounds) - 1))
+    # two plans from one generator state differ (the order is random), the same seed reproduces
+    a1 = WindowPlan.grouped(torch.tensor(bounds), W, B, offset, dev, torch.Generator().manual_seed(5)).batches()
+    a2 = WindowPlan.grouped(torch.tensor(bounds), W, B, offset, dev, torch.Generator().manual_seed(5)).batches()
+    assert a1 == a2 and a1 != p.batches()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "sequential", "samespeaker", "samesequence"])
+def test_loader_batches_equal_per_item_getitem(db, kind):
+    """Every batch the loader serves is what __getitem__ (the reference's per-item path, cpc/dataset.py:185-202) returns
+    for the plan's indices, stacked."""
+    root, _ = db
+    random.seed(2)
+    torch.manual_seed(2)
+    seq_names, speakers = findAllSeqs(str(root / "test_db"), extension=".wav")
+    data = AudioBatchData(root / "test_db", W, seq_names, None, len(speakers))
+    plan = data.getBaseSampler(kind, 3, 500)
+    assert len(plan) > 0
+    for index in plan:
+        batch, labels = data.get_batch(index)
+        for row, sidx in enumerate(index.tolist()):
+            x, lab = data[sidx]
+            assert torch.equal(batch[row], x) and int(labels[row]) == int(lab)
+        if kind == "samespeaker":
+            assert len(set(labels.tolist())) == 1
+    n = sum(1 for _ in data.getDataLoader(3, kind, True))
+    assert n > 0

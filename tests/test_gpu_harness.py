@@ -110,3 +110,64 @@ def test_device_resident_dataset_feeds_the_train_loop(tmp_path):
     logs = [H.train_epoch(data.getDataLoader(4, "samespeaker", True), model, crit, opt) for _ in range(2)]
     for lg in logs:
         assert np.isfinite(np.array(lg["locLoss_train"])).all() and len(lg["locLoss_train"]) == 12
+
+
+@pytest.mark.parametrize("kind", ["uniform", "sequential", "samespeaker", "samesequence"])
+def test_device_side_window_plans_against_the_per_item_path(tmp_path, kind):
+    """The four sampling types of cpc/dataset.py:318-408 with the pack resident in HBM: the plan (all window starts of the
+    pass) is built on the device, every batch is one device-side gather -- and equals, item by item, what the reference's
+    per-item path (__getitem__ on a CPU copy of the same pack) returns for the same indices.  'sequential' additionally
+    feeds the hidden-state carry it exists for (keepHidden): item b of consecutive batches is contiguous audio."""
+    dev = _dev()
+    import wave
+    from cpc_audio_amd.dataset import AudioBatchData, findAllSeqs
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model
+    W = 20480
+    rng = np.random.default_rng(1)
+    for spk in range(3):
+        for utt in range(3):
+            d = tmp_path / "db" / f"s{spk}" / "c0"
+            d.mkdir(parents=True, exist_ok=True)
+            pcm = (rng.standard_normal(W * (3 + utt) + 321 * spk) * 3000).astype("<i2")
+            with wave.open(str(d / f"s{spk}-c0-{utt}.wav"), "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000); f.writeframes(pcm.tobytes())
+    seqs, speakers = findAllSeqs(str(tmp_path / "db"), extension=".wav")
+    random_state = __import__("random").getstate()
+    __import__("random").seed(4)
+    data = AudioBatchData(tmp_path / "db", W, seqs, None, len(speakers)).to(dev)
+    __import__("random").setstate(random_state)
+    host = {"data": data.data.cpu(), "bounds": list(data.speakerLabel), "seq": list(data.seqLabel)}
+    B = 4
+    plan = data.window_plan(kind, B, 777)
+    assert plan.starts.is_cuda and len(plan) > 0
+    served = []
+    for index in plan:
+        assert index.is_cuda
+        batch, labels = data.get_batch(index)
+        assert batch.is_cuda and batch.shape[1:] == (1, W)
+        for row, sidx in enumerate(index.tolist()):
+            assert torch.equal(batch[row, 0].cpu(), host["data"][sidx:sidx + W])
+            spk = next(i for i, b in enumerate(host["bounds"]) if b > sidx) - 1          # cpc/dataset.py:181-183
+            assert int(labels[row]) == spk
+        served.append(index.tolist())
+    flat = [x for b in served for x in b]
+    assert len(flat) == len(set(flat))                                                   # no window twice in a pass
+    if kind == "uniform":
+        assert all(len(b) == B for b in served)
+    if kind in ("samespeaker", "samesequence"):
+        bounds = host["bounds"] if kind == "samespeaker" else host["seq"]
+        for b in served:
+            assert len({next(i for i, e in enumerate(bounds) if e > x) for x in b}) == 1
+    if kind == "sequential":
+        for prev, cur in zip(served, served[1:]):
+            assert [c - p for p, c in zip(prev, cur)] == [W] * B
+        # ... which is what lets the GRU state of batch i seed batch i+1 (feature_loader.py:149, model.py:193-198)
+        torch.manual_seed(0)
+        model, crit = build_model(keepHidden=True).to(dev), build_criterion().to(dev)
+        tr = Trainer(model, crit)
+        n = 0
+        for batch, labels in data.getDataLoader(B, "sequential", False):
+            losses, _ = tr.step(batch, labels)
+            assert torch.isfinite(losses).all() and model.gAR.hidden is not None
+            n += 1
+        assert n == len(data.window_plan("sequential", B, 0)) >= 2

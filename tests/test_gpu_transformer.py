@@ -100,13 +100,13 @@ def test_config4_transformer_ar_and_predictors_train_step():
     ops.KEEP_DEBUG = True
     c, z, _ = model(wave.to(dev), torch.zeros(B, dtype=torch.long, device=dev))
     saved, sizes, zz = ops.debug_last["encoder"]
+    acts_dev = ops.saved_encoder_activations(saved, B, 20480)      # fp32 copies whatever the storage (y0 is kept as fp16 pieces)
     losses, acc = crit(c, z, None, negatives=(bidx.to(dev), sidx.to(dev)))
     ops.KEEP_DEBUG = False
     tmasks = _ffn_masks(ops, [(B, 128)] + [(B, 116)] * K)       # call order: the AR layer, then predictors 0..K-1
     losses.sum().backward()
     torch.cuda.synchronize()
-    Ls = [sizes[3 + i] for i in range(5)]
-    ys = [saved[sizes[8 + i]: sizes[8 + i] + B * Ls[i] * 256].view(B, Ls[i], 256).cpu() for i in range(4)] + [zz.cpu()]
+    ys = [t.cpu() for t in acts_dev] + [zz.cpu()]
     masks = [(y > 0).permute(0, 2, 1) for y in ys]
 
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}

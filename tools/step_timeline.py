@@ -12,6 +12,18 @@ def main():
     last = [i for i, r in enumerate(rows) if "adam_kernel" in r[0] or "multi_tensor_apply" in r[0]]
     end = last[-1]
     begin = max(i for i in first if i < end)
+    if "--period" in sys.argv:
+        # distance between the optimiser kernels of consecutive steps = the true step period, idle gaps included
+        ad = [rows[i][1] for i in last]
+        d = [(b - a) / 1e3 for a, b in zip(ad, ad[1:])]
+        tail = d[-8:]
+        print(f"step period over the last {len(tail)} steps: mean {sum(tail) / len(tail):.1f} us, min {min(tail):.1f}, max {max(tail):.1f}")
+        # what runs between the optimiser kernel and the next conv0 forward
+        prev_end = max(i for i in last if i < begin)
+        for i in range(prev_end, begin + 1):
+            n, s0, e0, st, *_ = rows[i]
+            print(f"  s{st} t={(s0 - rows[prev_end][1]) / 1e3:8.1f} dur={(e0 - s0) / 1e3:7.1f} {n[:70]}")
+        return
     if "--stats" in sys.argv:
         tot = {}
         for n, s, e, *_ in rows[begin:end + 1]:
