@@ -49,7 +49,7 @@ extern "C" int cpc_device_error_flags(int clear) {
 }
 
 extern "C" int cpc_set_mfma_mode(int mode) {
-    CPC_RETURN_IF(mode < 0 || mode > 3, CPC_ERR_ARG);
+    CPC_RETURN_IF(mode < 0 || mode > 4, CPC_ERR_ARG);
     cpc::g_mfma_mode = mode;
     return 0;
 }

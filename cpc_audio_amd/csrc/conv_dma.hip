@@ -30,14 +30,16 @@
 
 namespace cpc {
 
-// BKE: contraction elements per LDS stage (16 or 32), NST: LDS stages.  NST - 1 stages are in flight or being read at
-// any time; what sets the speed of this kernel is the per-CU global -> LDS rate (~10 B/clk measured: latency-bound, far
-// below L2's bandwidth), so the number of bytes kept in flight matters more than the size of a stage.
-template <int BM, int BKE_ = 16, int NST_ = 4>
+// BKE: contraction elements per LDS stage, NST: LDS stages, NP: storage of the operands -- 2 = H2 (two fp16 pieces per
+// element, 4 bytes, three MFMAs per product: the fp32-accurate path), 1 = bf16 (2 bytes, one MFMA per product: the
+// bf16-storage variant, cpc_set_mfma_mode(4)).  Rows of a stage are ROWB = 64 or 128 bytes in either storage.
+template <int BM, int BKE_, int NST_, int NP_>
 struct DmaCfg {
     static constexpr int BN = kC;
-    static constexpr int BKE = BKE_, NST = NST_;
-    static constexpr int ROWB = BKE * 4;               // bytes per row and stage (h + l pieces)
+    static constexpr int BKE = BKE_, NST = NST_, NP = NP_;
+    static constexpr int ESZ = 2 * NP;                 // bytes per element
+    static constexpr int ROWB = BKE * ESZ;             // bytes per row and stage
+    static constexpr int KPR = 128 / ESZ;              // contraction elements per 128-byte global weight row
     static constexpr int PPR = ROWB / 16;              // 16-byte pieces per row (4 or 8)
     static constexpr int RPP = 1024 / ROWB;            // rows per 1 KB DMA piece (16 or 8)
     static constexpr int SWSH = PPR == 8 ? 1 : 2;      // swizzle: piece ^= (row >> SWSH) & (PPR - 1)
@@ -49,7 +51,8 @@ struct DmaCfg {
     static constexpr int A_PER = (BM / RPP) / NW, B_PER = (BN / RPP) / NW;    // 1 KB DMA pieces per wave and stage
     static constexpr int NPS = A_PER + B_PER;          // DMA instructions per wave and stage (vmcnt bookkeeping)
     static constexpr int SMEM_BYTES = NST * STAGE;
-    static_assert(BKE == 16 || BKE == 32, "one or two MFMA k-steps per stage");
+    static_assert(NP == 1 || NP == 2, "bf16 or two fp16 pieces");
+    static_assert(ROWB == 64 || ROWB == 128, "rows of 4 or 8 pieces");
     static_assert(NST >= 2 && NST <= 4, "2..4 stages");
     static_assert((BM / RPP) % NW == 0 && (BN / RPP) % NW == 0, "whole pieces per wave");
     static_assert(SMEM_BYTES >= BM * 2 * 4 * 2, "the row-statistics exchange reuses the stage buffers");
@@ -57,37 +60,27 @@ struct DmaCfg {
 };
 
 // row of the C tile held in accumulator register `reg` of tile tm / column held by this lane for tile tn
-template <int BM>
 __device__ __forceinline__ int dma_c_row(int tm, int reg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    return (wave / DmaCfg<BM>::WAVES_N) * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    return (wave >> 1) * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
 }
-template <int BM>
 __device__ __forceinline__ int dma_c_col(int tn) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    return (wave % DmaCfg<BM>::WAVES_N) * 128 + tn * 32 + (lane & 31);
+    return (wave & 1) * 128 + tn * 32 + (lane & 31);
 }
 
-// am: im2col rows of the H2 activation (element strides; an element is 4 bytes in either storage).
-// wq: weight in K-tile-major H2 rows [K/32][256][128 B] (permute_w_h2), max|w| behind it.
-// y_h2 != 0: y is written in H2 storage scaled by scale_for_amax(*y_amax) (the next layer's operand); else fp32.
-// zeros: >= 128 bytes of zeros (the rows of the conv's zero padding and of the ragged last tile read them).
-template <int BM, int BKE, int NST>
-__global__ __launch_bounds__((DmaCfg<BM, BKE, NST>::NTHREADS)) void conv_fwd_dma_kernel(
-    RowMap am, const unsigned char* __restrict__ wq, int K, const float* __restrict__ bias,
-    const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y, int y_h2,
-    float* __restrict__ xhat, float* __restrict__ rstd_out, const float* __restrict__ x_amax,
-    const float* __restrict__ w_amax, const float* __restrict__ y_amax, const unsigned char* __restrict__ zeros,
-    int rot_step) {
-    using C = DmaCfg<BM, BKE, NST>;
+// acc[64 x 128 per wave] += A[m0.., 0:K] . B[0:256, 0:K]^T with both operands DMA'd global -> LDS.
+// am: rows of the A operand in ELEMENTS of C::ESZ bytes (im2col windows: element k of a row is real iff the position
+// tau0 + (k >> 8) is inside [0, Lin), otherwise it reads `zeros`); wq: weight rows of 128 bytes, [K / KPR][256][128 B].
+template <class C>
+__device__ __forceinline__ void dma_gemm(f32x16 (&acc)[C::TM][C::TN], const RowMap& am, int m0,
+                                         const unsigned char* __restrict__ wq, int K, const unsigned char* __restrict__ zeros,
+                                         int rot_step, unsigned char* smem) {
     constexpr int TM = C::TM, TN = C::TN;
-    // ONE LDS object: a second one makes the compiler drain the DMA queue (vmcnt(0)) before every ds_read of the loop
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
-    const int m0 = blockIdx.x * BM;
     const int nkt = K / C::BKE;
-    const int taps = K >> kCLog2;                                  // power of two for every caller (8, 4)
+    const int taps = K >> kCLog2;                                  // power of two for every caller (8, 4, 2)
     const int tshift = 31 - __builtin_clz(taps);
     const int rot = (int)((blockIdx.x * (unsigned)rot_step) % (unsigned)nkt);
 
@@ -100,25 +93,37 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST>::NTHREADS)) void conv_fwd_dma
     for (int i = 0; i < C::A_PER; ++i) {
         const int row = (wave * C::A_PER + i) * C::RPP + lane / C::PPR;
         const int piece = (lane % C::PPR) ^ ((row >> C::SWSH) & (C::PPR - 1));
-        const RowRef rr = resolve_row(am, m0 + row, am.M);
-        a_src[i] = reinterpret_cast<const unsigned char*>(rr.ptr) + piece * 16;
-        a_tau0[i] = rr.tau0;
+        const int m = m0 + row;
+        if (m < am.M) {
+            const int b = m / am.R, t = m - b * am.R;
+            a_src[i] = reinterpret_cast<const unsigned char*>(am.base) +
+                       ((long)b * am.bstride + (long)t * am.rstride + am.off) * C::ESZ + piece * 16;
+            a_tau0[i] = t * am.tmul + am.tadd;
+        } else {
+            a_src[i] = zeros;
+            a_tau0[i] = -(1 << 30);
+        }
     }
 #pragma unroll
     for (int i = 0; i < C::B_PER; ++i) {
         const int row = (wave * C::B_PER + i) * C::RPP + lane / C::PPR;
         const int piece = (lane % C::PPR) ^ ((row >> C::SWSH) & (C::PPR - 1));
-        b_src[i] = wq + (long)row * 128 + piece * 16;       // global weight rows are 128 B (32 k) whatever the stage depth
+        b_src[i] = wq + (long)row * 128 + piece * 16;       // global weight rows are 128 B whatever the stage depth
     }
     const unsigned char* zsrc = zeros + (lane % C::PPR) * 16;
     auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
         int q = kt + rot;
         q = q >= nkt ? q - nkt : q;
-        q = (q & (taps - 1)) * (nkt >> tshift) + (q >> tshift);            // tap-fastest walk (gemm_tile.h, tshift)
-        const int tap = (q * C::BKE) >> kCLog2;
+        // tap-fastest walk (gemm_tile.h, tshift), the taps in the order 0, s, 1, s+1, ...: tap j of output row t and tap
+        // j + s of row t - 1 are the same input row, so the two reads of every input row are ONE stage apart and the second
+        // one hits L2 (in plain tap order they are s stages = 4 x 32 KB per CU apart: 671 MB fetched for a 268 MB
+        // activation on layer 1, PMC)
+        const int ti = q & (taps - 1);
+        q = ((ti >> 1) + (taps >> 1) * (ti & 1)) * (nkt >> tshift) + (q >> tshift);
         const int k0 = q * C::BKE;
-        const long koff = (long)k0 * 4;                                    // bytes into an A row
-        const long boff = (long)(k0 >> 5) * (C::BN * 128) + (k0 & 31) * 4; // weight: [k / 32][256 rows][128 B]
+        const int tap = k0 >> kCLog2;
+        const long koff = (long)k0 * C::ESZ;                               // bytes into an A row
+        const long boff = (long)(k0 / C::KPR) * (C::BN * 128) + (k0 % C::KPR) * C::ESZ;
         unsigned char* as = smem + stage * C::STAGE + (wave * C::A_PER) * 1024;
         unsigned char* bs = smem + stage * C::STAGE + C::A_BYTES + (wave * C::B_PER) * 1024;
 #pragma unroll
@@ -130,7 +135,6 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST>::NTHREADS)) void conv_fwd_dma
         for (int i = 0; i < C::B_PER; ++i) dma16_to_lds(b_src[i] + boff, bs + i * 1024);
     };
 
-    f32x16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -140,7 +144,6 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST>::NTHREADS)) void conv_fwd_dma
 
     const int sw = ((lane & 31) >> C::SWSH) & (C::PPR - 1), kg = lane >> 5;
     const int a_row0 = (wm * 64 + (lane & 31)) * C::ROWB, b_row0 = (wn * 128 + (lane & 31)) * C::ROWB;
-    using SP = SplitPlanes<2>;
 
     // NST - 1 stages ahead: at the top of iteration kt the stages kt .. kt + NST - 2 have been issued; stage kt must have
     // landed (vmcnt leaves the NST - 2 younger ones in flight), the barrier publishes it to the other waves and retires
@@ -164,38 +167,80 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST>::NTHREADS)) void conv_fwd_dma
         const unsigned char* Bs = As + C::A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
-            s16x8 af[TM][2], bf[TN][2];
+            if constexpr (C::NP == 2) {
+                using SP = SplitPlanes<2>;
+                s16x8 af[TM][2], bf[TN][2];
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                const int off = ((4 * ks + 2 * kg + pl) ^ sw) * 16;
+                for (int pl = 0; pl < 2; ++pl) {
+                    const int off = ((4 * ks + 2 * kg + pl) ^ sw) * 16;
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        af[tm][pl] = *reinterpret_cast<const s16x8*>(As + a_row0 + tm * 32 * C::ROWB + off);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        bf[tn][pl] = *reinterpret_cast<const s16x8*>(Bs + b_row0 + tn * 32 * C::ROWB + off);
+                }
+#pragma unroll
+                for (int q = 0; q < SP::NPROD; ++q)                     // small terms first (l*h, h*l, h*h)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = SP::mfma(af[tm][SP::pa(q)], bf[tn][SP::pb(q)], acc[tm][tn]);
+            } else {
+                s16x8 af[TM], bf[TN];
+                const int off = ((2 * ks + kg) ^ sw) * 16;
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
-                    af[tm][pl] = *reinterpret_cast<const s16x8*>(As + a_row0 + tm * 32 * C::ROWB + off);
+                    af[tm] = *reinterpret_cast<const s16x8*>(As + a_row0 + tm * 32 * C::ROWB + off);
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    bf[tn][pl] = *reinterpret_cast<const s16x8*>(Bs + b_row0 + tn * 32 * C::ROWB + off);
-            }
-#pragma unroll
-            for (int q = 0; q < SP::NPROD; ++q)                     // small terms first (l*h, h*l, h*h)
+                    bf[tn] = *reinterpret_cast<const s16x8*>(Bs + b_row0 + tn * 32 * C::ROWB + off);
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = SP::mfma(af[tm][SP::pa(q)], bf[tn][SP::pb(q)], acc[tm][tn]);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[tm]),
+                                                                              __builtin_bit_cast(bf16x8, bf[tn]), acc[tm][tn], 0, 0, 0);
+            }
         }
         stage = stage + 1 == C::NST ? 0 : stage + 1;
     }
-    __syncthreads();                            // the stage buffers are free: reused for the row statistics below
+    __syncthreads();                            // the stage buffers are free (the epilogues reuse them)
+}
+
+// Storage of an epilogue's outputs
+constexpr int kStoreF32 = 0, kStoreH2 = 1, kStoreBf16 = 2;
+
+// Forward conv layer.  am: im2col rows of the input activation (H2 for NP = 2, bf16 for NP = 1); wq: weight in K-tile-major
+// rows (permute_w_h2 / permute_w_bf16), for NP = 2 max|w| behind it.  y is written as `ykind` says (H2: scaled by
+// scale_for_amax(*y_amax)), xhat as `xkind` (fp32 or bf16), rstd fp32.
+// zeros: >= 128 bytes of zeros (the rows of the conv's zero padding and of the ragged last tile read them).
+template <int BM, int BKE, int NST, int NP>
+__global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd_dma_kernel(
+    RowMap am, const unsigned char* __restrict__ wq, int K, const float* __restrict__ bias,
+    const float* __restrict__ nw, const float* __restrict__ nb, void* __restrict__ y, int ykind,
+    void* __restrict__ xhat, int xkind, float* __restrict__ rstd_out, const float* __restrict__ x_amax,
+    const float* __restrict__ w_amax, const float* __restrict__ y_amax, const unsigned char* __restrict__ zeros,
+    int rot_step) {
+    using C = DmaCfg<BM, BKE, NST, NP>;
+    constexpr int TM = C::TM, TN = C::TN;
+    // ONE LDS object: a second one makes the compiler drain the DMA queue (vmcnt(0)) before every ds_read of the loop
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES];
+    const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) % C::WAVES_N;
+    const int m0 = blockIdx.x * BM;
+    f32x16 acc[TM][TN];
+    dma_gemm<C>(acc, am, m0, wq, K, zeros, rot_step, smem);
 
     // ---- epilogue: undo the operand scales, bias, ChannelNorm (two passes over the accumulators), ReLU
-    const float sa = scale_for_amax(*x_amax), sb = scale_for_amax(*w_amax);
-    const float inv = 1.0f / (sa * sb);                             // powers of two: exact
+    float inv = 1.0f;
+    if constexpr (NP == 2) inv = 1.0f / (scale_for_amax(*x_amax) * scale_for_amax(*w_amax));      // powers of two: exact
     float (*red)[2] = reinterpret_cast<float (*)[2]>(smem);         // [BM][2]: one partial per column half (wave wn)
     int col[TN];
     float gw[TN], gb[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        col[tn] = dma_c_col<BM>(tn);
+        col[tn] = dma_c_col(tn);
         const float bc = bias[col[tn]];
         gw[tn] = nw[col[tn]];
         gb[tn] = nb[col[tn]];
@@ -211,14 +256,14 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST>::NTHREADS)) void conv_fwd_dma
         for (int r = 0; r < 16; ++r) {
             float v = (acc[tm][0][r] + acc[tm][1][r]) + (acc[tm][2][r] + acc[tm][3][r]);
             v = half_wave_sum(v);
-            if ((lane & 31) == 0) red[dma_c_row<BM>(tm, r)][wn] = v;
+            if ((lane & 31) == 0) red[dma_c_row(tm, r)][wn] = v;
         }
     __syncthreads();
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = dma_c_row<BM>(tm, r);
+            const int row = dma_c_row(tm, r);
             mean[tm][r] = (red[row][0] + red[row][1]) * (1.0f / kC);
         }
     __syncthreads();
@@ -233,16 +278,19 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST>::NTHREADS)) void conv_fwd_dma
                 v = fmaf(d, d, v);
             }
             v = half_wave_sum(v);
-            if ((lane & 31) == 0) red[dma_c_row<BM>(tm, r)][wn] = v;
+            if ((lane & 31) == 0) red[dma_c_row(tm, r)][wn] = v;
         }
     __syncthreads();
-    const float sy = y_h2 ? scale_for_amax(*y_amax) : 1.0f;
+    const float sy = ykind == kStoreH2 ? scale_for_amax(*y_amax) : 1.0f;
     const bool odd = lane & 1;
+    auto swap1 = [](unsigned v) __attribute__((always_inline)) {     // the neighbouring lane's value (quad_perm [1,0,3,2])
+        return __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, v)));
+    };
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = dma_c_row<BM>(tm, r);
+            const int row = dma_c_row(tm, r);
             const float var = (red[row][0] + red[row][1]) * (1.0f / (kC - 1));
             const float rs = 1.0f / sqrtf(var + kNormEps);
             const int m = m0 + row;
@@ -252,23 +300,76 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST>::NTHREADS)) void conv_fwd_dma
             for (int tn = 0; tn < TN; ++tn) {
                 const float xh = (acc[tm][tn][r] - mean[tm][r]) * rs;
                 const float yv = fmaxf(fmaf(xh, gw[tn], gb[tn]), 0.f);
-                if (live) __builtin_nontemporal_store(xh, xhat + (long)m * kC + col[tn]);   // read again only in backward
-                if (!y_h2) {
-                    if (live) y[(long)m * kC + col[tn]] = yv;
-                } else {
-                    // H2: neighbouring lanes hold neighbouring channels; the even lane stores the pair's h pieces, the
-                    // odd lane the l pieces (one dword store per lane, as for fp32).  The exchange is unconditional.
+                const int c0 = col[tn] & ~1;
+                // Neighbouring lanes hold neighbouring channels.  16-bit storages are written as one dword per lane pair
+                // and tensor: the exchanges are unconditional (convergent), the stores are guarded.
+                if (xkind == kStoreF32) {
+                    if (live) __builtin_nontemporal_store(xh, reinterpret_cast<float*>(xhat) + (long)m * kC + col[tn]);
+                }
+                if (ykind == kStoreF32) {
+                    if (live) reinterpret_cast<float*>(y)[(long)m * kC + col[tn]] = yv;
+                }
+                if (ykind == kStoreH2) {
+                    // the even lane stores the pair's h pieces, the odd lane the l pieces
                     _Float16 h, l;
                     h2_split(yv, sy, h, l);
                     const unsigned mine_h = __builtin_bit_cast(unsigned short, h), mine_l = __builtin_bit_cast(unsigned short, l);
-                    const unsigned got = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, odd ? mine_h : mine_l)));
+                    const unsigned got = swap1(odd ? mine_h : mine_l);
                     const unsigned word = odd ? (got | (mine_l << 16)) : (mine_h | (got << 16));
+                    if (live)
+                        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(y) + (long)m * (kC * 4) + h2_byte_of(c0) +
+                                                     (odd ? 16 : 0)) = word;
+                }
+                if (ykind == kStoreBf16 || xkind == kStoreBf16) {
+                    // both 16-bit: the even lane stores the pair's y, the odd lane the pair's xhat; only xhat 16-bit (the
+                    // last layer, whose y = z stays fp32): the odd lane stores it
+                    const unsigned yb = bf16_rne(yv), xb = bf16_rne(xh);
+                    const unsigned got = swap1(odd ? yb : xb);       // even gets the odd lane's y, odd the even lane's xhat
                     if (live) {
-                        const int c0 = col[tn] & ~1;
-                        unsigned char* dst = reinterpret_cast<unsigned char*>(y + (long)m * kC) + h2_byte_of(c0) + (odd ? 16 : 0);
-                        *reinterpret_cast<unsigned*>(dst) = word;
+                        if (!odd && ykind == kStoreBf16)
+                            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(y) + (long)m * kC + c0) = yb | (got << 16);
+                        if (odd && xkind == kStoreBf16)
+                            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(xhat) + (long)m * kC + c0) = got | (xb << 16);
                     }
                 }
+            }
+        }
+}
+
+// Data gradient of a conv layer (k = 2s) as `s` phase GEMMs with K = 512 (enc_conv.hip, conv_dgrad_kernel): phase r of
+// input step tau = q*s + r - p receives dx[q-1] . W[:,:,r+s] + dx[q] . W[:,:,r], a contiguous 2-row window of the
+// (B, Lout, 256) gradient.  am: those windows (rows q = 0..Lout of every batch item); wd: the phase's weight in K-tile-major
+// rows, phases 256*512*ESZ bytes apart; dprev (B, Lin, 256): gradient w.r.t. the previous layer's output, bf16 (NP = 1).
+template <int BM, int BKE, int NST, int NP>
+__global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_dgrad_dma_kernel(
+    RowMap am, const unsigned char* __restrict__ wd, int s, int p, int Lin, void* __restrict__ dprev,
+    const unsigned char* __restrict__ zeros, int rot_step) {
+    using C = DmaCfg<BM, BKE, NST, NP>;
+    constexpr int TM = C::TM, TN = C::TN;
+    static_assert(NP == 1, "the H2 gradient path is not built: its scale is not known when dx is written");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int m0 = blockIdx.x * BM, ph = blockIdx.y;
+    f32x16 acc[TM][TN];
+    dma_gemm<C>(acc, am, m0, wd + (long)ph * (kC * 2 * kC * C::ESZ), 2 * kC, zeros, rot_step, smem);
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + dma_c_row(tm, r);
+            long o = -1;
+            if (m < am.M) {
+                const int b = m / am.R, q = m - b * am.R;
+                const int tau = q * s + ph - p;
+                if ((unsigned)tau < (unsigned)Lin) o = (long)b * Lin + tau;
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const unsigned mine = bf16_rne(acc[tm][tn][r]);
+                const unsigned got = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, mine)));
+                if (o >= 0 && !odd)
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(dprev) + o * kC + (dma_c_col(tn) & ~1)) = mine | (got << 16);
             }
         }
 }
@@ -324,14 +425,80 @@ int conv_fwd_dma(const float* x_h2, const float* wq, const float* bias, const fl
     const unsigned char* wqb = reinterpret_cast<const unsigned char*>(wq);
     const float* w_amax = wq + (long)kC * k * kC;
     const unsigned char* zb = reinterpret_cast<const unsigned char*>(zeros);
+    const int ykind = y_h2 ? kStoreH2 : kStoreF32;
 #define CPC_LAUNCH_DMA(BM_, BKE_, NST_)                                                                                       \
-    hipLaunchKernelGGL((conv_fwd_dma_kernel<BM_, BKE_, NST_>), dim3(cdiv(am.M, BM_)), dim3(DmaCfg<BM_, BKE_, NST_>::NTHREADS), 0, \
-                       st, am, wqb, K, bias, nw, nb, y, y_h2, xhat, rstd, x_amax, w_amax, y_amax, zb, g_dma_rot)
+    hipLaunchKernelGGL((conv_fwd_dma_kernel<BM_, BKE_, NST_, 2>), dim3(cdiv(am.M, BM_)), dim3(DmaCfg<BM_, BKE_, NST_, 2>::NTHREADS), \
+                       0, st, am, wqb, K, bias, nw, nb, (void*)y, ykind, (void*)xhat, kStoreF32, rstd, x_amax, w_amax, y_amax, zb,   \
+                       g_dma_rot)
     if (bm == 256 && g_dma_pipe == 0) CPC_LAUNCH_DMA(256, 16, 4);
     else if (bm == 256) CPC_LAUNCH_DMA(256, 32, 2);
     else if (g_dma_pipe == 0) CPC_LAUNCH_DMA(128, 16, 4);
     else CPC_LAUNCH_DMA(128, 32, 2);
 #undef CPC_LAUNCH_DMA
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- bf16-storage variant (cpc_set_mfma_mode(4)): activations, saved xhat and gradients as bf16, weights rounded to bf16
+// by the re-layout, one v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate and fp32 ChannelNorm statistics.
+// rows per workgroup: 256 when that still gives ~one workgroup per CU, else 128, else 64
+static int bf16_bm(long M) { return M >= 256L * 200 ? 256 : (M >= 128L * 200 ? 128 : 64); }
+
+// x, y (y_f32 == 0), xhat: bf16 (B, L, 256); y_f32 != 0: y is the fp32 encoder output z.  wq: permute_w_bf16(..., dgrad = 0).
+int conv_fwd_dma_bf16(const void* x, const void* wq, const float* bias, const float* nw, const float* nb, void* y, int y_f32,
+                      void* xhat, float* rstd, const float* zeros, int B, int Lin, int k, int s, int p, hipStream_t st) {
+    const int Lout = conv_out_len(Lin, k, s, p);
+    const RowMap am = conv_rows(reinterpret_cast<const float*>(x), B, Lin, Lout, s, p);    // strides in elements
+    const int K = k * kC;
+    const int taps = K >> kCLog2;
+    if (K % 128 != 0 || (taps & (taps - 1)) != 0) return CPC_ERR_SHAPE;
+    const unsigned char* wqb = reinterpret_cast<const unsigned char*>(wq);
+    const unsigned char* zb = reinterpret_cast<const unsigned char*>(zeros);
+    const int ykind = y_f32 ? kStoreF32 : kStoreBf16;
+#define CPC_LAUNCH_DMA(BM_)                                                                                                    \
+    hipLaunchKernelGGL((conv_fwd_dma_kernel<BM_, 64, 2, 1>), dim3(cdiv(am.M, BM_)), dim3(DmaCfg<BM_, 64, 2, 1>::NTHREADS), 0, st,  \
+                       am, wqb, K, bias, nw, nb, y, ykind, xhat, kStoreBf16, rstd, (const float*)nullptr, (const float*)nullptr, \
+                       (const float*)nullptr, zb, g_dma_rot)
+    switch (bf16_bm(am.M)) {
+        case 256: CPC_LAUNCH_DMA(256); break;
+        case 128: CPC_LAUNCH_DMA(128); break;
+        default: CPC_LAUNCH_DMA(64); break;
+    }
+#undef CPC_LAUNCH_DMA
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx (B, Lout, 256) bf16 -> dprev (B, Lin, 256) bf16: gradient w.r.t. the previous layer's output.  wd: permute_w_bf16(..., dgrad = 1).
+int conv_dgrad_dma_bf16(const void* dx, const void* wd, void* dprev, const float* zeros, int B, int Lin, int k, int s, int p,
+                        hipStream_t st) {
+    if (k != 2 * s) return CPC_ERR_SHAPE;
+    const int Lout = conv_out_len(Lin, k, s, p);
+    RowMap am;                                           // 2-row windows [q-1, q] over dx, q in [0, Lout] (enc_conv.hip)
+    am.base = reinterpret_cast<const float*>(dx); am.R = Lout + 1; am.bstride = (long)Lout * kC; am.rstride = kC; am.off = -kC;
+    am.tmul = 1; am.tadd = -1; am.Lin = Lout; am.M = B * (Lout + 1);
+    const unsigned char* wdb = reinterpret_cast<const unsigned char*>(wd);
+    const unsigned char* zb = reinterpret_cast<const unsigned char*>(zeros);
+#define CPC_LAUNCH_DMA(BM_)                                                                                                    \
+    hipLaunchKernelGGL((conv_dgrad_dma_kernel<BM_, 64, 2, 1>), dim3(cdiv(am.M, BM_), s), dim3(DmaCfg<BM_, 64, 2, 1>::NTHREADS), 0, \
+                       st, am, wdb, s, p, Lin, dprev, zb, 0)
+    switch (bf16_bm((long)am.M * s)) {
+        case 256: CPC_LAUNCH_DMA(256); break;
+        case 128: CPC_LAUNCH_DMA(128); break;
+        default: CPC_LAUNCH_DMA(64); break;
+    }
+#undef CPC_LAUNCH_DMA
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// bf16 <-> fp32 rows of 256 channels (tests, debugging)
+__global__ __launch_bounds__(256) void bf16_decode_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = bf16_val(src[i]);
+}
+int bf16_decode(const void* src, float* dst, long n, hipStream_t st) {
+    hipLaunchKernelGGL(bf16_decode_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, reinterpret_cast<const unsigned short*>(src), dst, n);
     CPC_LAUNCH_CHECK();
     return 0;
 }

@@ -44,6 +44,17 @@ int conv_fwd_dma(const float* x_h2, const float* wq, const float* bias, const fl
                  int y_h2, float* xhat, float* rstd, const float* x_amax, const float* y_amax, const float* zeros, int B,
                  int Lin, int k, int s, int p, int bm, hipStream_t st);
 int permute_w_h2(const float* w, float* wq, int k, const float* amax, hipStream_t st);
+// bf16-storage variant (mode 4): forward / data-gradient conv layers on bf16 tensors, bf16 -> fp32 copy
+int conv_fwd_dma_bf16(const void* x, const void* wq, const float* bias, const float* nw, const float* nb, void* y, int y_f32,
+                      void* xhat, float* rstd, const float* zeros, int B, int Lin, int k, int s, int p, hipStream_t st);
+int conv_dgrad_dma_bf16(const void* dx, const void* wd, void* dprev, const float* zeros, int B, int Lin, int k, int s, int p,
+                        hipStream_t st);
+int bf16_decode(const void* src, float* dst, long n, hipStream_t st);
+int conv0_forward_bf16(const float* wave, const float* w, const float* bias, const float* nw, const float* nb, void* y,
+                       float* mean, float* rstd, int B, int L, hipStream_t st);
+int conv0_backward(const float* wave, const float* w, const float* bias, const float* nw, const float* nb,
+                   const float* mean, const float* rstd, const void* dy, int dy_bf16, float* scratch, float* dW0, float* dB0,
+                   float* dNW0, float* dNB0, int B, int L, hipStream_t stream);
 
 // device-side error words of the translation units that own them (cpc_device_error_flags)
 int gru_error_flag_fetch(int clear, unsigned* out);

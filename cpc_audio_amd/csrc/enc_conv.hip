@@ -163,7 +163,8 @@ struct PrepArgs {
     int k[4];
     int blk0[9];            // first workgroup of segment 2*layer + layout
     int split;
-    int fwd_h2[4];          // forward layout of layer y+1 in K-tile-major H2 rows (the DMA kernel's, conv_dma.hip)
+    int fwd_h2[4];          // 1: forward layout of layer y+1 in K-tile-major H2 rows (the DMA kernel's, conv_dma.hip);
+                            // 2: forward AND dgrad layouts in K-tile-major bf16 rows (mode 4)
 };
 __global__ __launch_bounds__(256) void enc_prep_amax_kernel(PrepArgs a) {
     const int y = blockIdx.y;
@@ -186,7 +187,9 @@ __global__ __launch_bounds__(256) void enc_prep_permute_kernel(PrepArgs a) {
     const long idx = (long)(b - a.blk0[seg]) * 256 + threadIdx.x;
     if (a.split == 2 && idx == 0) dst[total] = amax;          // where the GEMM kernels read max|w|
     if (idx >= total) return;
-    if (seg & 1) permute_w_dgrad_elem(a.w[layer], dst, k / 2, a.split, amax, idx);
+    if ((seg & 1) && a.fwd_h2[layer] == 2) permute_w_dgrad_bf16_elem(a.w[layer], reinterpret_cast<unsigned short*>(dst), k / 2, idx);
+    else if (seg & 1) permute_w_dgrad_elem(a.w[layer], dst, k / 2, a.split, amax, idx);
+    else if (a.fwd_h2[layer] == 2) permute_w_fwd_bf16_elem(a.w[layer], reinterpret_cast<unsigned short*>(dst), k, idx);
     else if (a.fwd_h2[layer]) permute_w_h2_elem(a.w[layer], reinterpret_cast<unsigned char*>(dst), k, amax, idx);
     else permute_w_fwd_elem(a.w[layer], dst, k, a.split, amax, idx);
 }
@@ -328,8 +331,17 @@ constexpr int NB_ROWS = 32;   // rows per block (8 per wave)
 // so the mask is bit-identical and the 4 bytes per element of y are not read at all (the composite encoder's choice).
 // The kernel streams 12-16 bytes per element and is latency-bound per row (two dependent wave reductions), so a wave
 // keeps the loads of four rows in flight and interleaves their reduction chains (0.25 -> ... ms per step for the four layers).
+// DYB / XB: dy / (xhat and the output dx) are bf16 tensors (the bf16-storage variant, mode 4) instead of fp32.
 constexpr int NBW = 4;        // rows a wave works on at a time
-template <int MASK>
+__device__ __forceinline__ f32x4 load4_as_f32(const float* base, long elem, bool bf16) {
+    if (bf16) {
+        const uint2 d = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+        return f32x4{bf16_val((unsigned short)(d.x & 0xFFFFu)), bf16_val((unsigned short)(d.x >> 16)),
+                     bf16_val((unsigned short)(d.y & 0xFFFFu)), bf16_val((unsigned short)(d.y >> 16))};
+    }
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + elem));       // read once
+}
+template <int MASK, bool DYB = false, bool XB = false>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ y,
     const float* __restrict__ rstd, const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ dx,
@@ -362,8 +374,8 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
             m[j] = blockIdx.x * NB_ROWS + r0 + 4 * j;
             live[j] = m[j] < M;
             const long row = live[j] ? m[j] : 0;
-            g4[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dy + row * kC + c));     // read once
-            x4[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xhat + row * kC + c));
+            g4[j] = load4_as_f32(dy, row * kC + c, DYB);
+            x4[j] = load4_as_f32(xhat, row * kC + c, XB);
             rs[j] = rstd[row];
             if constexpr (MASK == 1) {
                 uint2 hp, lp;
@@ -405,7 +417,13 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
                 cs[2][q] += v;
                 amax = fmaxf(amax, fabsf(v));
             }
-            if (live[j]) *reinterpret_cast<f32x4*>(dx + (long)m[j] * kC + c) = o;
+            if (live[j]) {
+                if constexpr (XB)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dx) + (long)m[j] * kC + c) =
+                        make_uint2(bf16_rne(o[0]) | ((unsigned)bf16_rne(o[1]) << 16), bf16_rne(o[2]) | ((unsigned)bf16_rne(o[3]) << 16));
+                else
+                    *reinterpret_cast<f32x4*>(dx + (long)m[j] * kC + c) = o;
+            }
         }
     }
 #pragma unroll
@@ -581,11 +599,12 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
 }
 
 // ------------------------------------------------------------------ wgrad
-// MODE 3: as 2 with the activation operand (x) in H2 storage
+// MODE 3: as 2 with the activation operand (x) in H2 storage; MODE 4: both operands are bf16 tensors, one product
 template <int MODE>
 struct WgCfg {
-    using Tile = typename std::conditional<MODE != 0, TnTileX3<128, 128, 2, 2, 32, 1, MODE >= 2 ? 2 : 3, MODE == 3>,
-                                           TnTile<128, 128, 2, 2>>::type;
+    using Tile = typename std::conditional<MODE == 4, TnTileX3<128, 128, 2, 2, 32, 1, 1, false, true>,      // bf16 tensors
+                 typename std::conditional<MODE != 0, TnTileX3<128, 128, 2, 2, 32, 1, MODE >= 2 ? 2 : 3, MODE == 3>,
+                                           TnTile<128, 128, 2, 2>>::type>::type;
 };
 // 1-D grid of 8 * T * ceil(S/8) blocks, T = 2*K/128 output tiles; part[z][co][K].
 // XCD-aware mapping: the dispatcher places block b on XCD b % 8 (observed, speed only), and every
@@ -608,7 +627,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     f32x16 acc[WgTile::TM][WgTile::TN];
     zero_acc(acc);
     float inv = 1.0f;
-    if constexpr (MODE >= 2) {
+    if constexpr (MODE == 4) {
+        WgTile::run(acc, dxm, c0, im, n0, mbeg, mend, smem);
+    } else if constexpr (MODE >= 2) {
         const float sa = scale_for_amax(*dx_amax), sb = scale_for_amax(*x_amax);
         WgTile::run(acc, dxm, c0, im, n0, mbeg, mend, smem, sa, sb);
         inv = 1.0f / (sa * sb);
@@ -623,7 +644,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
             const int row = c0 + WgTile::c_row(tm, r);
 #pragma unroll
             for (int tn = 0; tn < WgTile::TN; ++tn)
-                out[(long)row * K + n0 + WgTile::c_col(tn)] = MODE >= 2 ? acc[tm][tn][r] * inv : acc[tm][tn][r];
+                out[(long)row * K + n0 + WgTile::c_col(tn)] = (MODE == 2 || MODE == 3) ? acc[tm][tn][r] * inv : acc[tm][tn][r];
         }
 }
 
@@ -667,6 +688,7 @@ struct EncLayout {
     long bwd_total;
     int wg_splits[5], wg_rows[5];
     bool h2[4];                            // output of layer i kept in H2 storage (cpc_common.h) -- see act_h2 below
+    bool bf16;                             // mode 4
 };
 #define act_h2(layer) (e.h2[layer])
 
@@ -694,6 +716,7 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
         if (e.L[i] <= 0) return false;
         lin = e.L[i];
     }
+    e.bf16 = g_mfma_mode == 4;             // bf16-storage variant: y0..y3, xhat1..4 and every gradient tensor as bf16
     const int nh2 = g_mfma_mode != 3 ? 0 : (g_h2_layers ? g_h2_layers : ((long)B * e.L[2] >= 256L * 200 ? 2 : 1));
     for (int i = 0; i < 4; ++i) e.h2[i] = i < nh2;
     long o = 0;
@@ -965,11 +988,12 @@ extern "C" int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part
                                     void* stream) {
     return conv_layer_wgrad(dx, x, 0, part, dW, dx_amax, x_amax, B, Lin, k, s, p, splits, rows_per_split, stream);
 }
-// x_h2: the layer's input activation is in H2 storage scaled by scale_for_amax(*x_amax) (fp16-split modes only)
+// x_h2: 1 = the layer's input activation is in H2 storage scaled by scale_for_amax(*x_amax) (fp16-split modes only);
+// 2 = dx and x are both bf16 tensors (mode 4)
 static int conv_layer_wgrad(const float* dx, const float* x, int x_h2, float* part, float* dW, const float* dx_amax,
                             const float* x_amax, int B, int Lin, int k, int s, int p, int splits, int rows_per_split,
                             void* stream) {
-    CPC_RETURN_IF(x_h2 && g_mfma_mode < 2, CPC_ERR_ARG);
+    CPC_RETURN_IF(x_h2 == 1 && g_mfma_mode < 2, CPC_ERR_ARG);
     CPC_RETURN_IF(B <= 0 || Lin <= 0 || Lin + 2 * p < k || splits <= 0 || rows_per_split <= 0, CPC_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     const int Lout = conv_out_len(Lin, k, s, p);
@@ -978,8 +1002,10 @@ static int conv_layer_wgrad(const float* dx, const float* x, int x_h2, float* pa
     const RowMap im = conv_rows(x, B, Lin, Lout, s, p);
     CPC_RETURN_IF((long)splits * rows_per_split < dxm.M, CPC_ERR_SHAPE);
     const dim3 grid(8 * 2 * (K / 128) * cdiv(splits, 8));
-    CPC_RETURN_IF(g_mfma_mode >= 2 && (!dx_amax || !x_amax), CPC_ERR_ARG);
-    if (g_mfma_mode >= 2 && x_h2)
+    CPC_RETURN_IF(g_mfma_mode >= 2 && x_h2 != 2 && (!dx_amax || !x_amax), CPC_ERR_ARG);
+    if (x_h2 == 2)
+        hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
+    else if (g_mfma_mode >= 2 && x_h2)
         hipLaunchKernelGGL((conv_wgrad_kernel<3>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
     else if (g_mfma_mode >= 2)
         hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
@@ -1016,6 +1042,7 @@ extern "C" int cpc_encoder_saved_activation(const float* saved, int layer, float
     CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!saved || !dst || layer < 0 || layer > 3, CPC_ERR_ARG);
     const long rows = (long)B * e.L[layer];
+    if (e.bf16) return bf16_decode(saved + e.y[layer], dst, rows * kC, (hipStream_t)stream);
     if (act_h2(layer)) return cpc_h2_decode(saved + e.y[layer], dst, rows, saved + e.sbound + layer + 1, stream);
     if (hipMemcpyAsync(dst, saved + e.y[layer], rows * kC * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
         return CPC_ERR_ARG;
@@ -1041,7 +1068,8 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
         a.nw[i - 1] = params[4 * (i - 1) + 2];
         a.nb[i - 1] = params[4 * (i - 1) + 3];
         a.k[i - 1] = kGeom[i].k;
-        a.fwd_h2[i - 1] = act_h2(i - 1);               // layer i consumes an H2 activation: DMA kernel, DMA weight layout
+        a.fwd_h2[i - 1] = e.bf16 ? 2 : act_h2(i - 1);   // 1: layer i consumes an H2 activation (DMA kernel, DMA weight layout);
+                                                        // 2: bf16 storage (both layouts in bf16 K-tile-major rows)
         const int per = cdiv((long)kC * kGeom[i].k * kC, 256);
         a.blk0[2 * (i - 1)] = nblk; nblk += per;
         a.blk0[2 * (i - 1) + 1] = nblk; nblk += per;
@@ -1054,7 +1082,18 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
     hipLaunchKernelGGL(enc_prep_amax_kernel, dim3(kPrepParts, 5), dim3(256), 0, st, a);
     hipLaunchKernelGGL(enc_prep_permute_kernel, dim3(nblk), dim3(256), 0, st, a);
     CPC_LAUNCH_CHECK();
-    if (g_mfma_mode == 3 && hipMemsetAsync(saved + e.szero, 0, 64 * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+    if (g_mfma_mode >= 3 && hipMemsetAsync(saved + e.szero, 0, 64 * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+    if (e.bf16) {
+        // bf16-storage variant: y0..y3 and xhat1..4 as bf16 (half the activation bytes), weights rounded to bf16 by the
+        // re-layout, one bf16 MFMA per product, fp32 accumulators and ChannelNorm statistics; z stays fp32
+        int rc = conv0_forward_bf16(wave, params[0], params[1], params[2], params[3], saved + e.y[0], saved + e.mean0,
+                                    saved + e.rstd[0], B, L, st);
+        for (int i = 1; i < 5 && !rc; ++i)
+            rc = conv_fwd_dma_bf16(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2], params[4 * i + 3],
+                                   i == 4 ? z : saved + e.y[i], i == 4, saved + e.xhat[i], saved + e.rstd[i], saved + e.szero,
+                                   B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, st);
+        return rc;
+    }
     int rc = cpc_conv0_forward_h2(wave, params[0], params[1], params[2], params[3], saved + e.y[0], saved + e.mean0,
                                   saved + e.rstd[0], act_h2(0) ? saved + e.sbound + 1 : nullptr, B, L, stream);
     if (rc) return rc;
@@ -1124,6 +1163,15 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     auto norm_bwd = [&](int layer, const float* dy, const float* yl, float* dxl) {
         const int M = B * e.L[layer], nblk = cdiv(M, NB_ROWS);
         // the ReLU mask is recomputed from xhat and the affine (bit-identical to the forward's): y is not read
+        if (e.bf16 && layer == 4)         // bf16 storage: xhat and dx are bf16; the top layer's dy is autograd's fp32 dz
+            hipLaunchKernelGGL((norm_bwd_kernel<2, false, true>), dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
+                               saved + e.rstd[layer], params[4 * layer + 2], params[4 * layer + 3], dxl, scratch + e.colp[layer],
+                               M, (float*)nullptr);
+        else if (e.bf16)
+            hipLaunchKernelGGL((norm_bwd_kernel<2, true, true>), dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
+                               saved + e.rstd[layer], params[4 * layer + 2], params[4 * layer + 3], dxl, scratch + e.colp[layer],
+                               M, (float*)nullptr);
+        else
         hipLaunchKernelGGL(norm_bwd_kernel<2>, dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
                            saved + e.rstd[layer], params[4 * layer + 2], params[4 * layer + 3], dxl, scratch + e.colp[layer], M,
                            amax + layer);
@@ -1141,10 +1189,17 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                 return CPC_ERR_ARG;
         }
         if (!(ev && i == 1))
-        rc = conv_layer_wgrad(scratch + e.dx[i], xin, act_h2(i - 1), scratch + e.part, grads[4 * i], amax + i, xbound + i, B,
+        rc = conv_layer_wgrad(scratch + e.dx[i], xin, e.bf16 ? 2 : act_h2(i - 1), scratch + e.part, grads[4 * i], amax + i, xbound + i, B,
                               e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], (void*)wst);
         if (rc) return rc;
-        if (i >= 2 && g_unfuse_big && (g_unfuse_big == 2 || pick_bm(B * (e.L[i] + 1)) == 128)) {
+        if (e.bf16) {
+            // bf16 storage: DMA'd bf16 dgrad into a bf16 temporary (layer 1: straight into conv0's dy), then the norm backward
+            float* tmpd = scratch + e.dy0;
+            rc = conv_dgrad_dma_bf16(scratch + e.dx[i], saved + e.swd[i], tmpd, saved + e.szero, B, e.L[i - 1], kGeom[i].k,
+                                     kGeom[i].s, kGeom[i].p, st);
+            if (rc) return rc;
+            if (i >= 2) norm_bwd(i - 1, tmpd, xin, scratch + e.dx[i - 1]);
+        } else if (i >= 2 && g_unfuse_big && (g_unfuse_big == 2 || pick_bm(B * (e.L[i] + 1)) == 128)) {
             // the fused ReLU'/ChannelNorm-backward epilogue is latency-bound (row-by-row reductions between the loads); a
             // plain dgrad into a temporary (dy0 is free until layer 1's dgrad) + the streaming norm backward is faster
             float* tmpd = scratch + e.dy0;
@@ -1165,14 +1220,13 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
         if (rc) return rc;
         if (ev && i == 1) {
             if (hipEventRecord(ev[1], st) != hipSuccess || hipStreamWaitEvent(wst, ev[1], 0) != hipSuccess) return CPC_ERR_ARG;
-            rc = conv_layer_wgrad(scratch + e.dx[1], xin, act_h2(0), scratch + e.part, grads[4], amax + 1, xbound + 1, B, e.L[0],
+            rc = conv_layer_wgrad(scratch + e.dx[1], xin, e.bf16 ? 2 : act_h2(0), scratch + e.part, grads[4], amax + 1, xbound + 1, B, e.L[0],
                                   kGeom[1].k, kGeom[1].s, kGeom[1].p, e.wg_splits[1], e.wg_rows[1], (void*)wst);
         }
         if (rc) return rc;
     }
-    rc = cpc_conv0_backward(wave, params[0], params[1], params[2], params[3], saved + e.mean0,
-                            saved + e.rstd[0], scratch + e.dy0, scratch + e.conv0, grads[0], grads[1],
-                            grads[2], grads[3], B, L, stream);
+    rc = conv0_backward(wave, params[0], params[1], params[2], params[3], saved + e.mean0, saved + e.rstd[0],
+                        scratch + e.dy0, e.bf16, scratch + e.conv0, grads[0], grads[1], grads[2], grads[3], B, L, st);
     if (rc) return rc;
     rc = rows_sum_multi(jobs, njobs, st);
     if (rc) return rc;

@@ -26,12 +26,12 @@ constexpr int K0 = 10, S0 = 5, P0 = 3;     // conv0 geometry, cpc/model.py:83
 constexpr int C0_TT = 128;                 // time steps per block (32 per wave, two at a time)
 constexpr int C0_NS = S0 * C0_TT + (K0 - S0);   // staged samples per block
 
-template <bool YH2>
+// YK: storage of y -- 0 fp32, 1 H2 (two fp16 pieces scaled by scale_for_amax(*y_amax), cpc_common.h), 2 bf16
+template <int YK>
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(
     const float* __restrict__ wave, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, int L, int L0, const float* __restrict__ y_amax) {
-    // YH2: y is written in H2 storage (cpc_common.h) scaled by scale_for_amax(*y_amax), the form conv1's DMA kernel reads
     __shared__ float smp[C0_NS];
     __shared__ float wT[K0][kC];                 // conv0.weight transposed: coalesced global read, float4 LDS reads
     const int b = blockIdx.y;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(
         n01 = f32x2{n4.x, n4.y}; n23 = f32x2{n4.z, n4.w};
     }
     const f32x2 zero2 = f32x2{0.f, 0.f};
-    const float sy = YH2 ? scale_for_amax(*y_amax) : 1.0f;
+    const float sy = YK == 1 ? scale_for_amax(*y_amax) : 1.0f;
     // two time steps per iteration: their reduction chains are independent and interleave
     for (int tt = wv; tt < C0_TT; tt += 8) {
         const int ta = t0 + tt, tb = ta + 4;
@@ -95,8 +95,12 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(
             float* yo = y + row * kC + c;       // streamed once, 268 MB per launch at B = 64 (>> L2): non-temporal
             const f32x2 o01 = __builtin_elementwise_max(__builtin_elementwise_fma(da01 * f32x2{rsa, rsa}, g01, n01), zero2);
             const f32x2 o23 = __builtin_elementwise_max(__builtin_elementwise_fma(da23 * f32x2{rsa, rsa}, g23, n23), zero2);
-            if constexpr (YH2) {
+            if constexpr (YK == 1) {
                 h2_store_row_nt(y + row * kC, o01.x, o01.y, o23.x, o23.y, sy);
+            } else if constexpr (YK == 2) {
+                const unsigned long long w = (unsigned long long)(bf16_rne(o01.x) | ((unsigned)bf16_rne(o01.y) << 16)) |
+                                             ((unsigned long long)(bf16_rne(o23.x) | ((unsigned)bf16_rne(o23.y) << 16)) << 32);
+                __builtin_nontemporal_store(w, reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(y) + row * kC + c));
             } else {
                 __builtin_nontemporal_store(o01.x, yo);
                 __builtin_nontemporal_store(o01.y, yo + 1);
@@ -110,8 +114,12 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(
             float* yo = y + row * kC + c;
             const f32x2 o01 = __builtin_elementwise_max(__builtin_elementwise_fma(db01 * f32x2{rsb, rsb}, g01, n01), zero2);
             const f32x2 o23 = __builtin_elementwise_max(__builtin_elementwise_fma(db23 * f32x2{rsb, rsb}, g23, n23), zero2);
-            if constexpr (YH2) {
+            if constexpr (YK == 1) {
                 h2_store_row_nt(y + row * kC, o01.x, o01.y, o23.x, o23.y, sy);
+            } else if constexpr (YK == 2) {
+                const unsigned long long w = (unsigned long long)(bf16_rne(o01.x) | ((unsigned)bf16_rne(o01.y) << 16)) |
+                                             ((unsigned long long)(bf16_rne(o23.x) | ((unsigned)bf16_rne(o23.y) << 16)) << 32);
+                __builtin_nontemporal_store(w, reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(y) + row * kC + c));
             } else {
                 __builtin_nontemporal_store(o01.x, yo);
                 __builtin_nontemporal_store(o01.y, yo + 1);
@@ -135,6 +143,8 @@ constexpr int C0B_TT = 64;                 // time steps per block in backward (
 constexpr int C0B_NS = S0 * C0B_TT + (K0 - S0);
 constexpr int C0_NACC = K0 + 3;            // 10 weight taps, conv bias, norm weight, norm bias
 
+// DYB: dy arrives as bf16 (the bf16-storage variant) instead of fp32
+template <bool DYB>
 __global__ __launch_bounds__(256) void conv0_bwd_kernel(
     const float* __restrict__ wave, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, const float* __restrict__ mean_in,
@@ -181,8 +191,15 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(
         const int t = t0 + tt;
         if (t >= L0) break;                      // wave-uniform
         const long row = (long)b * L0 + t;
-        const float4 g4 = *reinterpret_cast<const float4*>(dy + row * kC + c);
-        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float g[4];
+        if constexpr (DYB) {
+            const uint2 gb = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dy) + row * kC + c);
+            g[0] = bf16_val((unsigned short)(gb.x & 0xFFFFu)); g[1] = bf16_val((unsigned short)(gb.x >> 16));
+            g[2] = bf16_val((unsigned short)(gb.y & 0xFFFFu)); g[3] = bf16_val((unsigned short)(gb.y >> 16));
+        } else {
+            const float4 g4 = *reinterpret_cast<const float4*>(dy + row * kC + c);
+            g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+        }
         const float mu = mean_in[row], rstd = rstd_in[row];
         float sv[K0];
 #pragma unroll
@@ -361,14 +378,27 @@ extern "C" int cpc_conv0_forward_h2(const float* wave, const float* w, const flo
     CPC_RETURN_IF(B <= 0 || L < K0 - 2 * P0, CPC_ERR_SHAPE);
     const int L0 = conv_out_len(L, K0, S0, P0);
     if (y_amax)
-        hipLaunchKernelGGL(conv0_fwd_kernel<true>, dim3(cdiv(L0, C0_TT), B), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(conv0_fwd_kernel<1>, dim3(cdiv(L0, C0_TT), B), dim3(256), 0, (hipStream_t)stream,
                            wave, w, bias, nw, nb, reinterpret_cast<float*>(y), mean, rstd, L, L0, y_amax);
     else
-        hipLaunchKernelGGL(conv0_fwd_kernel<false>, dim3(cdiv(L0, C0_TT), B), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(conv0_fwd_kernel<0>, dim3(cdiv(L0, C0_TT), B), dim3(256), 0, (hipStream_t)stream,
                            wave, w, bias, nw, nb, reinterpret_cast<float*>(y), mean, rstd, L, L0, y_amax);
     CPC_LAUNCH_CHECK();
     return 0;
 }
+
+namespace cpc {
+// bf16-storage variant (mode 4): y as bf16 (B, L0, 256)
+int conv0_forward_bf16(const float* wave, const float* w, const float* bias, const float* nw, const float* nb, void* y,
+                       float* mean, float* rstd, int B, int L, hipStream_t st) {
+    CPC_RETURN_IF(B <= 0 || L < K0 - 2 * P0, CPC_ERR_SHAPE);
+    const int L0 = conv_out_len(L, K0, S0, P0);
+    hipLaunchKernelGGL(conv0_fwd_kernel<2>, dim3(cdiv(L0, C0_TT), B), dim3(256), 0, st, wave, w, bias, nw, nb,
+                       reinterpret_cast<float*>(y), mean, rstd, L, L0, (const float*)nullptr);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace cpc
 
 extern "C" long cpc_conv0_backward_scratch_floats(int B, int L) {
     const int L0 = conv_out_len(L, K0, S0, P0);
@@ -380,6 +410,14 @@ extern "C" int cpc_conv0_backward(const float* wave, const float* w, const float
                                   const float* nw, const float* nb, const float* mean,
                                   const float* rstd, const float* dy, float* scratch, float* dW0,
                                   float* dB0, float* dNW0, float* dNB0, int B, int L, void* stream) {
+    return cpc::conv0_backward(wave, w, bias, nw, nb, mean, rstd, dy, 0, scratch, dW0, dB0, dNW0, dNB0, B, L, (hipStream_t)stream);
+}
+
+// dy_bf16: dy is a bf16 tensor (the bf16-storage variant, mode 4)
+int cpc::conv0_backward(const float* wave, const float* w, const float* bias, const float* nw, const float* nb,
+                        const float* mean, const float* rstd, const void* dy_any, int dy_bf16, float* scratch, float* dW0,
+                        float* dB0, float* dNW0, float* dNB0, int B, int L, hipStream_t stream) {
+    const float* dy = reinterpret_cast<const float*>(dy_any);
     CPC_RETURN_IF(B <= 0 || L < K0 - 2 * P0, CPC_ERR_SHAPE);
     const int L0 = conv_out_len(L, K0, S0, P0);
     const int nblk = cdiv(L0, C0B_TT) * B;
@@ -388,7 +426,11 @@ extern "C" int cpc_conv0_backward(const float* wave, const float* w, const float
     float* tmp = scratch + (long)nblk * n;        // rows for the first reduction level
     float* sum = tmp + (long)kRowsSumGroups * n;  // final [13][256]
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv0_bwd_kernel, dim3(cdiv(L0, C0B_TT), B), dim3(256), 0, st, wave, w, bias,
+    if (dy_bf16)
+        hipLaunchKernelGGL(conv0_bwd_kernel<true>, dim3(cdiv(L0, C0B_TT), B), dim3(256), 0, st, wave, w, bias,
+                           nw, nb, mean, rstd, dy, part, L, L0);
+    else
+    hipLaunchKernelGGL(conv0_bwd_kernel<false>, dim3(cdiv(L0, C0B_TT), B), dim3(256), 0, st, wave, w, bias,
                        nw, nb, mean, rstd, dy, part, L, L0);
     CPC_LAUNCH_CHECK();
     int rc = rows_sum(part, nblk, n, tmp, sum, st);

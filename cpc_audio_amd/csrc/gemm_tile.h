@@ -323,12 +323,46 @@ __device__ __forceinline__ void permute_w_h2_elem(const float* __restrict__ w, u
     p[8] = l;
 }
 
+// bf16 storage (mode 4): round to nearest even
+__device__ __forceinline__ unsigned short bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_val(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+// (O,I,W) conv weight -> bf16 K-tile-major rows for the DMA kernels: forward [kg / 64][co][64], kg = kk*C + ci
+__device__ __forceinline__ void permute_w_fwd_bf16_elem(const float* __restrict__ w, unsigned short* __restrict__ wq, int k,
+                                                        long idx) {
+    const int co = (int)(idx / (k * kC));
+    const int rem = (int)(idx - (long)co * k * kC);
+    const int kk = rem >> kCLog2, ci = rem & (kC - 1);
+    wq[((long)(rem >> 6) * kC + co) * 64 + (rem & 63)] = bf16_rne(w[((long)co * kC + ci) * k + kk]);
+}
+// ... data gradient: phase r < s, rows ci, contraction kg = j*C + co (j in {0,1}): Wd[r][kg / 64][ci][64] = W[co][ci][r + (1-j)*s]
+__device__ __forceinline__ void permute_w_dgrad_bf16_elem(const float* __restrict__ w, unsigned short* __restrict__ wd, int s,
+                                                          long idx) {
+    const int k = 2 * s;
+    const int r = (int)(idx / (kC * 2 * kC));
+    const int rem = (int)(idx - (long)r * kC * 2 * kC);
+    const int ci = rem / (2 * kC);
+    const int jc = rem - ci * 2 * kC;
+    const int j = jc >> kCLog2, co = jc & (kC - 1);
+    wd[(long)r * kC * 2 * kC + ((long)(jc >> 6) * kC + ci) * 64 + (jc & 63)] = bf16_rne(w[((long)co * kC + ci) * k + r + (1 - j) * s]);
+}
+
 template <int NP> struct SplitPlanes;
 template <> struct SplitPlanes<3> {                  // three bf16 pieces, six products, no scaling
     static constexpr int NPROD = 6;
     __device__ static __forceinline__ void split(const float4& v, float, uint2 (&p)[3]) { split3_pack4(v, p[0], p[1], p[2]); }
     __device__ static __forceinline__ int pa(int q) { constexpr int t[6] = {2, 0, 1, 1, 0, 0}; return t[q]; }   // l*h, h*l, m*m,
     __device__ static __forceinline__ int pb(int q) { constexpr int t[6] = {0, 2, 1, 0, 1, 0}; return t[q]; }   // m*h, h*m, h*h
+    __device__ static __forceinline__ f32x16 mfma(const s16x8& a, const s16x8& b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct SplitPlanes<1> {                  // one bf16 piece, one product: the bf16-storage variant (operands arrive as bf16)
+    static constexpr int NPROD = 1;
+    __device__ static __forceinline__ int pa(int) { return 0; }
+    __device__ static __forceinline__ int pb(int) { return 0; }
     __device__ static __forceinline__ f32x16 mfma(const s16x8& a, const s16x8& b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
@@ -801,7 +835,8 @@ RowCursor ca[A_PER], cb[B_PER];
 // ---------------------------------------------------------------------------
 // BH2 (NP == 2 only): the B operand is stored in H2 form (cpc_common.h: two fp16 pieces per element, already scaled by sb):
 // the loader fetches the pieces and transposes them, no split VALU.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1, int NP = 3, bool BH2 = false>
+// BF16IN (NP == 1 only): both operands are bf16 tensors (the bf16-storage variant): fetched as stored, transposed, one product.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1, int NP = 3, bool BH2 = false, bool BF16IN = false>
 struct TnTileX3 {   // NP: see NtTileX3
     static constexpr int BK = BK_;
     static constexpr int LDH = BK + 8;
@@ -890,6 +925,31 @@ struct TnTileX3 {   // NP: see NtTileX3
             *reinterpret_cast<uint2*>(dst + plane) = make_uint2(l[0][c] | (l[1][c] << 16), l[2][c] | (l[3][c] << 16));
         }
     }
+    // a block of bf16 values: v[r].x, v[r].y = the four 16-bit elements of row r
+    __device__ static __forceinline__ void store_block_bf16(unsigned short* base, int col0, int mofs, const float4 (&v)[4]) {
+        constexpr int SWM = BK / 8 - 1;
+        const int mphys = (((mofs >> 2) ^ (2 * ((col0 >> 3) & SWM))) << 2);
+        unsigned e[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned x = __float_as_uint(v[r].x), y = __float_as_uint(v[r].y);
+            e[r][0] = x & 0xFFFFu; e[r][1] = x >> 16; e[r][2] = y & 0xFFFFu; e[r][3] = y >> 16;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<uint2*>(base + (col0 + c) * LDH + mphys) = make_uint2(e[0][c] | (e[1][c] << 16), e[2][c] | (e[3][c] << 16));
+    }
+    // elements k .. k+3 of a row of a bf16 tensor (row strides of the RowMap are in elements)
+    __device__ static __forceinline__ float4 load_row4_bf16(const RowMap& rm, const RowCursor& cur, bool valid, int k) {
+        const int tau = cur.t * rm.tmul + rm.tadd + (k >> kCLog2);
+        const bool ok = valid && (unsigned)tau < (unsigned)rm.Lin;
+        const unsigned short* base = reinterpret_cast<const unsigned short*>(rm.base);
+        const unsigned short* p = ok ? base + (long)cur.b * rm.bstride + (long)cur.t * rm.rstride + rm.off + k : base;
+        const uint2 d = *reinterpret_cast<const uint2*>(p);
+        float4 v;
+        v.x = ok ? __uint_as_float(d.x) : 0.f; v.y = ok ? __uint_as_float(d.y) : 0.f; v.z = 0.f; v.w = 0.f;
+        return v;
+    }
     // H2 pieces of elements k .. k+3 (k % 4 == 0) of an im2col row: tap k >> 8, channel k & 255 of a 1 KB H2 row
     __device__ static __forceinline__ float4 load_row4_h2(const RowRef& r, int k, int Lin, const float* safe) {
         const int tau = r.tau0 + (k >> kCLog2);
@@ -907,6 +967,7 @@ struct TnTileX3 {   // NP: see NtTileX3
                                const RowMap& bm, int n0, int mbeg, int mend, float* smem_f,
                                float sa = 1.0f, float sb = 1.0f) {
         static_assert(!BH2 || NP == 2, "H2 operands are two fp16 pieces");
+        static_assert(BF16IN == (NP == 1), "one piece <=> bf16 tensors");
         unsigned short* smem0 = reinterpret_cast<unsigned short*>(smem_f);
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -947,6 +1008,10 @@ struct TnTileX3 {   // NP: see NtTileX3
             for (int i = 0; i < A_PER; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if constexpr (BF16IN) {
+                        ra[i][r] = load_row4_bf16(am, cursor_plus(am, ca[i], r), a_on[i] && (mm + a_m[i] + r) < mend, c0 + a_c[i]);
+                        continue;
+                    }
                     const RowRef rr = cursor_ref(am, cursor_plus(am, ca[i], r), a_on[i] && (mm + a_m[i] + r) < mend);
                     ra[i][r] = load_row4(rr, c0 + a_c[i], am.Lin, am.base);
                 }
@@ -956,6 +1021,10 @@ struct TnTileX3 {   // NP: see NtTileX3
             for (int i = 0; i < B_PER; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if constexpr (BF16IN) {
+                        rb[i][r] = load_row4_bf16(bm, cursor_plus(bm, cb[i], r), b_on[i] && (mm + b_m[i] + r) < mend, n0 + b_c[i]);
+                        continue;
+                    }
                     const RowRef rr = cursor_ref(bm, cursor_plus(bm, cb[i], r), b_on[i] && (mm + b_m[i] + r) < mend);
                     if constexpr (BH2) rb[i][r] = load_row4_h2(rr, n0 + b_c[i], bm.Lin, bm.base);
                     else rb[i][r] = load_row4(rr, n0 + b_c[i], bm.Lin, bm.base);
@@ -967,11 +1036,15 @@ struct TnTileX3 {   // NP: see NtTileX3
             unsigned short* smem = smem0 + st_ * STAGE_H;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
-                if (a_on[i]) store_block(smem, PLANE_A, a_c[i], a_m[i], ra[i], sa);
+                if (a_on[i]) {
+                    if constexpr (BF16IN) store_block_bf16(smem, a_c[i], a_m[i], ra[i]);
+                    else store_block(smem, PLANE_A, a_c[i], a_m[i], ra[i], sa);
+                }
 #pragma unroll
             for (int i = 0; i < B_PER; ++i)
                 if (b_on[i]) {
-                    if constexpr (BH2) store_block_h2(smem + NP * PLANE_A, PLANE_B, b_c[i], b_m[i], rb[i]);
+                    if constexpr (BF16IN) store_block_bf16(smem + NP * PLANE_A, b_c[i], b_m[i], rb[i]);
+                    else if constexpr (BH2) store_block_h2(smem + NP * PLANE_A, PLANE_B, b_c[i], b_m[i], rb[i]);
                     else store_block(smem + NP * PLANE_A, PLANE_B, b_c[i], b_m[i], rb[i], sb);
                 }
         };
