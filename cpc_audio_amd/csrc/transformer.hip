@@ -55,11 +55,38 @@ __device__ __forceinline__ void stage_relpos(float* dst, const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------ dropout (cpc/transformers.py:18,50 and :93,100)
+// The reference applies nn.Dropout(0.1) to the attention probabilities and to the feed-forward hidden layer in training
+// mode.  Here the keep decision of an element is a pure function of (seed, site, element index) -- Philox4x32-10, the
+// counter-based generator torch uses on GPUs -- so the backward regenerates it instead of reading a saved mask, and a test
+// can ask for exactly the mask a layer call used (cpc_dropout_keep_mask).
+//   site 0: attention probability (b*8 + head, i, j) at flat index ((b*8 + head)*S + i)*S + j
+//   site 1: hidden activation (row, col) at flat index row*2048 + col; one Philox call serves 4 consecutive columns
+struct Philox4 { unsigned x, y, z, w; };
+__device__ __forceinline__ unsigned mulhi32(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsigned site, unsigned long long ctr) {
+    Philox4 c{(unsigned)ctr, (unsigned)(ctr >> 32), site, 0u};
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = Philox4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+// an element is dropped iff its 32 random bits fall below p * 2^32
+__device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)((double)p * 4294967296.0); }
+
 // ------------------------------------------------------------------ attention forward
 // grid = B * 8, 256 threads; wave w owns query rows 32w .. 32w+31.
 // qkv (B*S, 768) = [q | k | v]; P = Krelpos (32, S) or NULL; o (B*S, 256); A (B*8, S, S) saved for backward.
+// drop_p > 0 (training): the probabilities that multiply V are A * keep / (1 - p); A itself (pre-dropout) is what is saved.
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
-                                                       float* __restrict__ o, float* __restrict__ A, int S) {
+                                                       float* __restrict__ o, float* __restrict__ A, int S, float drop_p,
+                                                       unsigned long long seed) {
     __shared__ float lds[3 * kSmax * kLdH + kDk * kLdS + 4 * 32 * kLdS];     // 133 KB of the CU's 160 KB
     float* Qs = lds;
     float* Ks = Qs + kSmax * kLdH;
@@ -141,7 +168,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         for (int ct = 0; ct < 4; ++ct) {
             const float a = p[ct] * inv;
             const int j = ct * 32 + l31;
-            Ww[il * kLdS + j] = a;
+            float kept = a;
+            if (drop_p > 0.f && i < S && j <= i)
+                kept = philox4x32_10(seed, 0u, ((unsigned long long)bh * S + i) * S + j).x >= drop_threshold(drop_p)
+                           ? a * (1.0f / (1.0f - drop_p)) : 0.f;
+            Ww[il * kLdS + j] = kept;
             if (i < S && j < S) A[((long)bh * S + i) * S + j] = a;
         }
     }
@@ -167,7 +198,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                        const float* __restrict__ o, const float* __restrict__ A,
                                                        const float* __restrict__ dO, float* __restrict__ dqkv,
-                                                       float* __restrict__ dPpart, int S) {
+                                                       float* __restrict__ dPpart, int S, float drop_p,
+                                                       unsigned long long seed) {
     __shared__ float lds[4 * kSmax * kLdH + kDk * kLdS + kSmax * kLdS];      // 150 KB
     float* Qs = lds;
     float* Ks = Qs + kSmax * kLdH;
@@ -220,7 +252,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             for (int r = 0; r < 16; ++r) {
                 const int i = 32 * w + c_row(r, lane), j = ct * 32 + l31;
                 float ds = 0.f;
-                if (ct <= w && i < S && j <= i) ds = Abh[(long)i * S + j] * (acc[r] - rdot[i]) * scale;
+                if (ct <= w && i < S && j <= i) {
+                    // through the dropout: dA_ij = (dO_i . v_j) * keep_ij / (1 - p); rowdot_i = dO_i . o_i holds as it is
+                    float da = acc[r];
+                    if (drop_p > 0.f)
+                        da = philox4x32_10(seed, 0u, ((unsigned long long)bh * S + i) * S + j).x >= drop_threshold(drop_p)
+                                 ? da * (1.0f / (1.0f - drop_p)) : 0.f;
+                    ds = Abh[(long)i * S + j] * (da - rdot[i]) * scale;
+                }
                 Ds[i * kLdS + j] = ds;
             }
         }
@@ -261,7 +300,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         for (int kk = 16 * w; kk < kSmax / 2; ++kk) {
             const int i = 2 * kk + khalf;
             ak = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[i * kLdS + jl], Qs[i * kLdH + l31], ak, 0, 0, 0);
-            const float a = (i < S && jl < S) ? Abh[(long)i * S + jl] : 0.f;
+            float a = (i < S && jl < S) ? Abh[(long)i * S + jl] : 0.f;
+            if (drop_p > 0.f && i < S && jl <= i)            // dv sees the probabilities that multiplied V
+                a = philox4x32_10(seed, 0u, ((unsigned long long)bh * S + i) * S + jl).x >= drop_threshold(drop_p)
+                        ? a * (1.0f / (1.0f - drop_p)) : 0.f;
             av = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Gs[i * kLdH + l31], av, 0, 0, 0);
         }
 #pragma unroll
