@@ -410,21 +410,47 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-__global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, long n4) {
+// x = relu(x), then (drop_p > 0) the hidden layer's dropout: x *= keep / (1 - p)   (transformers.py:93,100)
+__global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, long n4, float drop_p, unsigned long long seed) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     float4 v = reinterpret_cast<float4*>(x)[i];
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    if (drop_p > 0.f) {
+        const Philox4 r = philox4x32_10(seed, 1u, (unsigned long long)i);      // elements 4i .. 4i+3
+        const unsigned th = drop_threshold(drop_p);
+        const float sc = 1.0f / (1.0f - drop_p);
+        v.x = r.x >= th ? v.x * sc : 0.f; v.y = r.y >= th ? v.y * sc : 0.f;
+        v.z = r.z >= th ? v.z * sc : 0.f; v.w = r.w >= th ? v.w * sc : 0.f;
+    }
     reinterpret_cast<float4*>(x)[i] = v;
 }
-// g *= (y > 0)
-__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, long n4) {
+// g *= (y > 0) * scale, y the SAVED hidden layer: it is zero where the ReLU cut or the dropout dropped, so the product of
+// the two derivatives is scale = 1 / (1 - p) exactly where y > 0
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, long n4, float scale) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     float4 v = reinterpret_cast<float4*>(g)[i];
     const float4 a = reinterpret_cast<const float4*>(y)[i];
-    v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+    v.x = a.x > 0.f ? v.x * scale : 0.f; v.y = a.y > 0.f ? v.y * scale : 0.f;
+    v.z = a.z > 0.f ? v.z * scale : 0.f; v.w = a.w > 0.f ? v.w * scale : 0.f;
     reinterpret_cast<float4*>(g)[i] = v;
+}
+// out[i] = keep_i / (1 - p) of site `site` (tests: the mask a layer call with this seed applied)
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long n, int site, float drop_p,
+                                                           unsigned long long seed) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned th = drop_threshold(drop_p);
+    const float sc = 1.0f / (1.0f - drop_p);
+    unsigned bits;
+    if (site == 0) {
+        bits = philox4x32_10(seed, 0u, (unsigned long long)i).x;
+    } else {
+        const Philox4 r = philox4x32_10(seed, 1u, (unsigned long long)(i >> 2));
+        bits = (i & 3) == 0 ? r.x : ((i & 3) == 1 ? r.y : ((i & 3) == 2 ? r.z : r.w));
+    }
+    out[i] = bits >= th ? sc : 0.f;
 }
 __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const float* __restrict__ b, long n4) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -497,6 +523,16 @@ extern "C" int cpc_transformer_layout(int B, int S, long* sizes) {
 // lin2.weight (256,2048)/bias, ln_ffnetwork.weight/bias.   x, out: (B,S,256).
 extern "C" int cpc_transformer_layer_forward(const float* x, const float* const* params, float* saved, float* scratch,
                                              float* out, int B, int S, void* stream) {
+    return cpc_transformer_layer_forward_dropout(x, params, saved, scratch, out, B, S, 0.f, 0ull, stream);
+}
+
+// The same in training mode with dropout probability p on the attention probabilities and on the feed-forward hidden
+// layer (cpc/transformers.py:18,50,93,100; the reference hard-codes p = 0.1).  The masks are a function of `seed`
+// (Philox4x32-10 over the element index, see the kernels): pass the same seed to the backward call.
+extern "C" int cpc_transformer_layer_forward_dropout(const float* x, const float* const* params, float* saved,
+                                                     float* scratch, float* out, int B, int S, float p,
+                                                     unsigned long long seed, void* stream) {
+    CPC_RETURN_IF(!(p >= 0.f && p < 1.f), CPC_ERR_ARG);
     TfLayout t;
     CPC_RETURN_IF(!tf_layout(B, S, t), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!x || !params || !saved || !scratch || !out, CPC_ERR_ARG);
@@ -509,14 +545,14 @@ extern "C" int cpc_transformer_layer_forward(const float* x, const float* const*
     if ((rc = nt_gemm(xm, Wq, kC, nullptr, qkv, 3 * kC, kC, kC, st))) return rc;
     if ((rc = nt_gemm(xm, Wk, kC, nullptr, qkv + kC, 3 * kC, kC, kC, st))) return rc;
     if ((rc = nt_gemm(xm, Wv, kC, nullptr, qkv + 2 * kC, 3 * kC, kC, kC, st))) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * kTH), dim3(256), 0, st, qkv, P, saved + t.o, saved + t.A, S);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * kTH), dim3(256), 0, st, qkv, P, saved + t.o, saved + t.A, S, p, seed);
     CPC_LAUNCH_CHECK();
     float* att = scratch;
     if ((rc = nt_gemm(plain_rows(saved + t.o, M, kC), Wo, kC, nullptr, att, kC, kC, kC, st))) return rc;
     hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, att, params[5], params[6],
                        saved + t.y, saved + t.xhat1, saved + t.rstd1, M);
     if ((rc = nt_gemm(plain_rows(saved + t.y, M, kC), params[7], kC, params[8], saved + t.hid, kDff, kDff, kC, st))) return rc;
-    hipLaunchKernelGGL(relu_kernel, dim3(cdiv((long)M * kDff / 4, 256)), dim3(256), 0, st, saved + t.hid, (long)M * kDff / 4);
+    hipLaunchKernelGGL(relu_kernel, dim3(cdiv((long)M * kDff / 4, 256)), dim3(256), 0, st, saved + t.hid, (long)M * kDff / 4, p, seed);
     float* ff = scratch;
     if ((rc = nt_gemm(plain_rows(saved + t.hid, M, kDff), params[9], kDff, params[10], ff, kC, kC, kDff, st))) return rc;
     hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, saved + t.y, ff, params[11], params[12],
@@ -529,6 +565,14 @@ extern "C" int cpc_transformer_layer_forward(const float* x, const float* const*
 extern "C" int cpc_transformer_layer_backward(const float* x, const float* const* params, const float* saved,
                                               const float* dy, float* scratch, float* dx, float* const* grads,
                                               int B, int S, void* stream) {
+    return cpc_transformer_layer_backward_dropout(x, params, saved, dy, scratch, dx, grads, B, S, 0.f, 0ull, stream);
+}
+
+// Backward of a cpc_transformer_layer_forward_dropout call made with the same p and seed.
+extern "C" int cpc_transformer_layer_backward_dropout(const float* x, const float* const* params, const float* saved,
+                                                      const float* dy, float* scratch, float* dx, float* const* grads,
+                                                      int B, int S, float p, unsigned long long seed, void* stream) {
+    CPC_RETURN_IF(!(p >= 0.f && p < 1.f), CPC_ERR_ARG);
     TfLayout t;
     CPC_RETURN_IF(!tf_layout(B, S, t), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!x || !params || !saved || !dy || !scratch || !dx || !grads, CPC_ERR_ARG);
@@ -555,7 +599,7 @@ extern "C" int cpc_transformer_layer_backward(const float* x, const float* const
     if ((rc = transpose(W2, scratch + t.w2t, kC, kDff, st))) return rc;           // (256,2048) -> (2048,256)
     if ((rc = nt_gemm(ds2m, scratch + t.w2t, kC, nullptr, dhid, kDff, kDff, kC, st))) return rc;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(cdiv((long)M * kDff / 4, 256)), dim3(256), 0, st, dhid, saved + t.hid,
-                       (long)M * kDff / 4);
+                       (long)M * kDff / 4, 1.0f / (1.0f - p));
     // hid = relu(y W1^T + b1)
     const RowMap dhm = plain_rows(dhid, M, kDff), ym = plain_rows(saved + t.y, M, kC);
     if ((rc = tn_gemm(dhm, kDff, ym, kC, part, grads[7], 0, st))) return rc;      // dW1 (2048,256)
@@ -576,7 +620,7 @@ extern "C" int cpc_transformer_layer_backward(const float* x, const float* const
     if ((rc = nt_gemm(ds1m, scratch + t.wot, kC, nullptr, dob, kC, kC, kC, st))) return rc;
     // attention
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * kTH), dim3(256), 0, st, saved + t.qkv, P, saved + t.o,
-                       saved + t.A, dob, dqkv, scratch + t.dppart, S);
+                       saved + t.A, dob, dqkv, scratch + t.dppart, S, p, seed);
     CPC_LAUNCH_CHECK();
     if (P != nullptr && (rc = rows_sum(scratch + t.dppart, B * kTH, kDk * S, tmp, grads[4], st))) return rc;
     // projections
@@ -591,6 +635,16 @@ extern "C" int cpc_transformer_layer_backward(const float* x, const float* const
     if ((rc = transpose(wqkv, scratch + t.wqkvt, 3 * kC, kC, st))) return rc;     // -> (256,768)
     if ((rc = nt_gemm(plain_rows(dqkv, M, 3 * kC), scratch + t.wqkvt, 3 * kC, nullptr, dx, kC, kC, 3 * kC, st))) return rc;
     hipLaunchKernelGGL(add_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dx, ds1, n4);   // + the residual branch
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// Test helper: out[i] = keep_i / (1 - p) for element i of dropout site `site` (0: attention probabilities, flat
+// ((b*8 + head)*S + i)*S + j; 1: feed-forward hidden layer, flat row*2048 + col) under `seed` -- the mask a
+// cpc_transformer_layer_forward_dropout call with that seed applies.
+extern "C" int cpc_dropout_keep_mask(float* out, long n, int site, float p, unsigned long long seed, void* stream) {
+    CPC_RETURN_IF(!out || n <= 0 || (site != 0 && site != 1) || !(p >= 0.f && p < 1.f), CPC_ERR_ARG);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, n, site, p, seed);
     CPC_LAUNCH_CHECK();
     return 0;
 }

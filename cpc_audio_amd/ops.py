@@ -530,11 +530,12 @@ class InfoNCEScoresFunction(torch.autograd.Function):
 
 
 class TransformerLayerFunction(torch.autograd.Function):
-    """x (B,S,256) + the 13 layer parameters (state-dict order, Krelpos possibly None) -> (B,S,256).
-    One TransformerLayer of cpc/transformers.py:103-111 through cpc_transformer_layer_{forward,backward}."""
+    """x (B,S,256), dropout probability, seed + the 13 layer parameters (state-dict order, Krelpos possibly None) -> (B,S,256).
+    One TransformerLayer of cpc/transformers.py:103-111 through cpc_transformer_layer_{forward,backward}_dropout."""
 
     @staticmethod
-    def forward(ctx, x, *params):
+    def forward(ctx, x, drop_p, seed, *params):
+        """drop_p, seed: dropout probability of this call (0: none) and the 64-bit seed its masks derive from."""
         _require_cuda(x, "TransformerLayerFunction")
         lib = _lib.get()
         B, S, D = x.shape
@@ -552,8 +553,10 @@ class TransformerLayerFunction(torch.autograd.Function):
             saved = torch.empty(sizes[0], device=x.device, dtype=torch.float32)
             scratch = torch.empty(sizes[1], device=x.device, dtype=torch.float32)
             out = torch.empty(B, S, _HID, device=x.device, dtype=torch.float32)
-            lib.check(lib.cpc_transformer_layer_forward(_p(x), _ptrs(params), _p(saved), _p(scratch), _p(out), B, S,
-                                                        _stream()), "transformer_layer_forward")
+            lib.check(lib.cpc_transformer_layer_forward_dropout(_p(x), _ptrs(params), _p(saved), _p(scratch), _p(out), B, S,
+                                                                float(drop_p), int(seed), _stream()),
+                      "transformer_layer_forward")
+        ctx.drop = (float(drop_p), int(seed))
         if KEEP_DEBUG:                      # parity tests read the FFN's ReLU mask (oracle _ReluTieAware)
             debug_last.setdefault("transformer", []).append((saved, sizes))
         ctx.has_rel = params[4] is not None
@@ -573,7 +576,8 @@ class TransformerLayerFunction(torch.autograd.Function):
             scratch = torch.empty(nscr, device=x.device, dtype=torch.float32)
             dx = torch.empty_like(x)
             grads = [None if p is None else torch.empty_like(p) for p in params]
-            lib.check(lib.cpc_transformer_layer_backward(_p(x), _ptrs(params), _p(saved), _p(dy), _p(scratch), _p(dx),
-                                                         _ptrs(grads), B, S, _stream()), "transformer_layer_backward")
+            lib.check(lib.cpc_transformer_layer_backward_dropout(_p(x), _ptrs(params), _p(saved), _p(dy), _p(scratch), _p(dx),
+                                                                 _ptrs(grads), B, S, ctx.drop[0], ctx.drop[1], _stream()),
+                      "transformer_layer_backward")
         _wait(ctx.step, final=False)
-        return (dx, *grads)
+        return (dx, None, None, *grads)

@@ -90,29 +90,31 @@ class TransformerLayer(nn.Module):
         self.ln_ffnetwork = nn.LayerNorm(dmodel)
 
     def forward(self, x):
+        # nn.Dropout semantics (transformers.py:18,93): active in training mode only.  The masks of a call derive from one
+        # 64-bit seed drawn from torch's CPU generator (reproducible under torch.manual_seed, no device synchronisation).
+        p, seed = 0.0, 0
         if self.training and self.dropout_p > 0:
-            raise NotImplementedError("TransformerLayer in training mode with dropout > 0: the HIP layer applies no "
-                                      "dropout; build it with dropout=0 (buildTransformerAR(..., dropout=0.0))")
+            p = self.dropout_p
+            seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
         m, f = self.multihead, self.ffnetwork
         krel = m.Att.Krelpos if m.Att.relpos else None
-        return TransformerLayerFunction.apply(x, m.Wo.weight, m.Wk.weight, m.Wq.weight, m.Wv.weight, krel,
+        return TransformerLayerFunction.apply(x, p, seed, m.Wo.weight, m.Wk.weight, m.Wq.weight, m.Wv.weight, krel,
                                               self.ln_multihead.weight, self.ln_multihead.bias, f.lin1.weight,
                                               f.lin1.bias, f.lin2.weight, f.lin2.bias, self.ln_ffnetwork.weight,
                                               self.ln_ffnetwork.bias)
 
 
 class StaticPositionEmbedding(nn.Module):
-    """cpc/transformers.py:113-127."""
+    """cpc/transformers.py:113-127: x + pe, pe[t, i] = sin(t * w_i) for even i, cos(t * w_i) for odd i, with
+    w_i = 10000^(-2 * (i // 2) / dmodel); the table is a (non-trainable) buffer named ``pe`` as in the reference."""
 
     def __init__(self, seqlen, dmodel):
         super().__init__()
-        pos = torch.arange(0., seqlen).unsqueeze(1).repeat(1, dmodel)
-        dim = torch.arange(0., dmodel).unsqueeze(0).repeat(seqlen, 1)
-        div = torch.exp(-math.log(10000) * (2 * (dim // 2) / dmodel))
-        pos *= div
-        pos[:, 0::2] = torch.sin(pos[:, 0::2])
-        pos[:, 1::2] = torch.cos(pos[:, 1::2])
-        self.register_buffer("pe", pos.unsqueeze(0))
+        index = torch.arange(dmodel)
+        freq = torch.exp(-math.log(10000) * (2 * (index // 2).float() / dmodel))
+        angle = torch.arange(0., seqlen).unsqueeze(1) * freq.unsqueeze(0)
+        table = torch.where((index % 2 == 0).unsqueeze(0), torch.sin(angle), torch.cos(angle))
+        self.register_buffer("pe", table.unsqueeze(0))
 
     def forward(self, x):
         return x + self.pe[:, :x.size(1), :]

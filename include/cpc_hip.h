@@ -224,6 +224,17 @@ int cpc_transformer_layer_forward(const float* x, const float* const* params, fl
 int cpc_transformer_layer_backward(const float* x, const float* const* params, const float* saved,
                                    const float* dy, float* scratch, float* dx, float* const* grads,
                                    int B, int S, void* stream);
+/* Training mode with dropout probability p (0 <= p < 1) on the attention probabilities and on the feed-forward hidden
+ * layer (cpc/transformers.py:18,50,93,100; the reference hard-codes 0.1).  Masks are a pure function of `seed` and the
+ * element index (Philox4x32-10): give the backward call the seed of its forward call.  p = 0 is the plain layer. */
+int cpc_transformer_layer_forward_dropout(const float* x, const float* const* params, float* saved, float* scratch,
+                                          float* out, int B, int S, float p, unsigned long long seed, void* stream);
+int cpc_transformer_layer_backward_dropout(const float* x, const float* const* params, const float* saved,
+                                           const float* dy, float* scratch, float* dx, float* const* grads, int B,
+                                           int S, float p, unsigned long long seed, void* stream);
+/* Test helper: out[i] = keep_i / (1 - p) of dropout site 0 (attention probabilities, flat ((b*8 + head)*S + i)*S + j) or
+ * 1 (hidden layer, flat row*2048 + col) under `seed`. */
+int cpc_dropout_keep_mask(float* out, long n, int site, float p, unsigned long long seed, void* stream);
 
 /* ---------------------------------------------------------------- criterion ----
  * CPCUnsupersivedCriterion.forward (criterion.py:225-257) with linear prediction heads

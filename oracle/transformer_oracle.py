@@ -104,10 +104,14 @@ def attention_probabilities(q: Tensor, k: Tensor, krelpos: Optional[Tensor]) -> 
 
 
 def layer_forward(p: Dict[str, Tensor], x: Tensor, prefix: str = "", collect: Optional[dict] = None,
-                  relu_override: Optional[Tensor] = None) -> Tensor:
+                  relu_override: Optional[Tensor] = None, attn_keep: Optional[Tensor] = None,
+                  ffn_keep: Optional[Tensor] = None) -> Tensor:
     """One TransformerLayer, x (B, S, d_model) -> (B, S, d_model).
     ``relu_override``: optional bool (B, S, d_ff) = [hidden_device > 0]; used for the derivative of the
-    feed-forward ReLU at numerically tied pre-activations only (|x| < 1e-5, cpc_oracle._ReluTieAware)."""
+    feed-forward ReLU at numerically tied pre-activations only (|x| < 1e-5, cpc_oracle._ReluTieAware).
+    ``attn_keep`` (B*heads, S, S) / ``ffn_keep`` (B, S, d_ff): the training-mode dropout of transformers.py:18,50 and
+    :93,100 with EXPLICIT masks (entries 0 or 1 / (1 - p), what nn.Dropout multiplies by), so that a device run can be
+    reproduced with the masks it drew."""
     b, s, d = x.shape
     h, dk = N_HEADS, d // N_HEADS
 
@@ -118,6 +122,8 @@ def layer_forward(p: Dict[str, Tensor], x: Tensor, prefix: str = "", collect: Op
     k = heads(x @ p[f"{prefix}multihead.Wk.weight"].t())
     v = heads(x @ p[f"{prefix}multihead.Wv.weight"].t())
     a = attention_probabilities(q, k, p.get(f"{prefix}multihead.Att.Krelpos"))
+    if attn_keep is not None:
+        a = a * attn_keep                                         # self.drop(A), transformers.py:50
     o = torch.bmm(a, v).view(b, h, s, dk).transpose(1, 2).reshape(b, s, d)
     att = o @ p[f"{prefix}multihead.Wo.weight"].t()
     y = F.layer_norm(x + att, (d,), p[f"{prefix}ln_multihead.weight"], p[f"{prefix}ln_multihead.bias"], 1e-5)
@@ -127,6 +133,8 @@ def layer_forward(p: Dict[str, Tensor], x: Tensor, prefix: str = "", collect: Op
         hid = _ReluTieAware.apply(pre, relu_override, 1e-5)
     else:
         hid = torch.relu(pre)
+    if ffn_keep is not None:
+        hid = hid * ffn_keep                                      # self.drop(self.relu(...)), transformers.py:100
     ff = hid @ p[f"{prefix}ffnetwork.lin2.weight"].t() + p[f"{prefix}ffnetwork.lin2.bias"]
     out = F.layer_norm(y + ff, (d,), p[f"{prefix}ln_ffnetwork.weight"], p[f"{prefix}ln_ffnetwork.bias"], 1e-5)
     if collect is not None:

@@ -49,3 +49,55 @@ def test_transformer_layer_forward_backward_emulated(B, S, abspos):
     assert rel_err(dx, xr.grad) < 1e-5
     bad = {k: rel_err(g, leaves[k].grad) for k, g in grads.items() if not rel_err(g, leaves[k].grad) < 1e-5}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("B,S,abspos,p_drop", [(1, 40, False, 0.1), (1, 48, True, 0.3)])
+def test_transformer_layer_training_dropout_emulated(B, S, abspos, p_drop):
+    """Training-mode dropout (cpc/transformers.py:18,50,93,100): the layer run with dropout probability p and a seed must
+    equal the oracle run with the masks that seed generates (cpc_dropout_keep_mask: Philox4x32-10 over the element index),
+    forward and every gradient; the masks keep ~(1 - p) of the elements and the same seed reproduces the call."""
+    lib = emu()
+    prm = T.make_layer_params(seed=9 + S, size_seq=S, abspos=abspos)
+    g = torch.Generator().manual_seed(S + 1)
+    x = torch.randn(B, S, 256, generator=g)
+    dy = torch.randn(B, S, 256, generator=g)
+    seed = 0x1234ABCD5678EF01
+    plist = [prm[k].contiguous() if k in prm else None for k in ORDER]
+    sizes = (ctypes.c_long * 8)()
+    assert lib.cpc_transformer_layout(B, S, sizes) == 0
+    parr = (ctypes.c_void_p * 13)(*[P(t) for t in plist])
+
+    def run(sd, forward_only=False):
+        saved = torch.full((sizes[0],), float("nan")); fscr = torch.full((sizes[1],), float("nan"))
+        bscr = torch.full((sizes[2],), float("nan")); out = torch.full((B, S, 256), float("nan"))
+        assert lib.cpc_transformer_layer_forward_dropout(P(x), parr, P(saved), P(fscr), P(out), B, S, p_drop, sd, None) == 0
+        if forward_only:
+            return out, None, None
+        dx = torch.full((B, S, 256), float("nan"))
+        grads = [torch.full_like(t, float("nan")) if t is not None else None for t in plist]
+        garr = (ctypes.c_void_p * 13)(*[P(t) for t in grads])
+        assert lib.cpc_transformer_layer_backward_dropout(P(x), parr, P(saved), P(dy), P(bscr), P(dx), garr, B, S, p_drop, sd,
+                                                          None) == 0
+        return out, dx, {k: gr for k, gr in zip(ORDER, grads) if gr is not None}
+
+    out, dx, grads = run(seed)
+    attn_keep = torch.full((B * 8, S, S), float("nan"))
+    ffn_keep = torch.full((B, S, 2048), float("nan"))
+    assert lib.cpc_dropout_keep_mask(P(attn_keep), attn_keep.numel(), 0, p_drop, seed, None) == 0
+    assert lib.cpc_dropout_keep_mask(P(ffn_keep), ffn_keep.numel(), 1, p_drop, seed, None) == 0
+    for m in (attn_keep, ffn_keep):
+        assert set(m.unique().tolist()) <= {0.0, float(np.float32(1.0) / (np.float32(1.0) - np.float32(p_drop)))}
+        assert abs((m > 0).float().mean().item() - (1 - p_drop)) < 0.01
+    leaves = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = T.layer_forward(leaves, xr, attn_keep=attn_keep, ffn_keep=ffn_keep)
+    (yr * dy).sum().backward()
+    assert (out - yr).abs().max().item() < 1e-5
+    assert rel_err(dx, xr.grad) < 1e-5
+    bad = {k: rel_err(gr, leaves[k].grad) for k, gr in grads.items() if not rel_err(gr, leaves[k].grad) < 1e-5}
+    assert not bad, bad
+    out2, _, _ = run(seed, forward_only=True)
+    assert torch.equal(out, out2)                                   # the same seed reproduces the call ...
+    other = torch.full_like(ffn_keep, float("nan"))
+    assert lib.cpc_dropout_keep_mask(P(other), other.numel(), 1, p_drop, seed + 1, None) == 0
+    assert not torch.equal(other, ffn_keep)                         # ... another seed draws other masks

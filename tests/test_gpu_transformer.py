@@ -128,3 +128,52 @@ def test_config4_transformer_ar_and_predictors_train_step():
         if not r < 2e-4:
             bad[k] = r
     assert not bad, bad
+
+
+def test_transformer_layer_trains_with_the_references_dropout():
+    """The reference's layers always carry nn.Dropout(0.1) (cpc/transformers.py:18,93,100).  In training mode the HIP layer
+    applies it with in-kernel Philox masks: checked against the oracle run with the masks of the call's seed (forward and
+    gradients at fp32 parity), eval mode stays deterministic, and the default builders (dropout 0.1) train."""
+    dev = _dev()
+    import ctypes
+    from cpc_audio_amd import _lib
+    from cpc_audio_amd._lib import ptr as P
+    from cpc_audio_amd.transformers import buildTransformerAR
+    lib = _lib.get()
+    B, S, p_drop = 3, 128, 0.1
+    prm = T.make_layer_params(77, 256, S, False, prefix="0.")
+    net = buildTransformerAR(256, 1, S, False).to(dev)              # default dropout: 0.1, as the reference
+    net.load_state_dict(prm, strict=False)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, S, 256, generator=g)
+    dy = torch.randn(B, S, 256, generator=g)
+    net.train()
+    torch.manual_seed(123)
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())  # what the layer will draw next under this manual_seed
+    torch.manual_seed(123)
+    xd = x.to(dev).requires_grad_(True)
+    y = net(xd)
+    (y * dy.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    attn_keep = torch.empty(B * 8, S, S, device=dev)
+    ffn_keep = torch.empty(B, S, 2048, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.check(lib.cpc_dropout_keep_mask(P(attn_keep), attn_keep.numel(), 0, p_drop, seed, st), "keep_mask")
+    lib.check(lib.cpc_dropout_keep_mask(P(ffn_keep), ffn_keep.numel(), 1, p_drop, seed, st), "keep_mask")
+    torch.cuda.synchronize()
+    assert abs((ffn_keep > 0).float().mean().item() - 0.9) < 2e-3 and abs((attn_keep > 0).float().mean().item() - 0.9) < 5e-3
+    leaves = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = T.layer_forward(leaves, xr, prefix="0.", attn_keep=attn_keep.cpu(), ffn_keep=ffn_keep.cpu())
+    (yr * dy).sum().backward()
+    assert (y.detach().cpu() - yr).abs().max().item() < 1e-4
+    assert _rel(xd.grad.cpu(), xr.grad) < 1e-4
+    bad = {k: _rel(v.grad.cpu(), leaves[k].grad) for k, v in net.named_parameters()}
+    bad = {k: v for k, v in bad.items() if not v < 1e-4}
+    assert not bad, bad
+    # eval mode: no dropout, deterministic, equal to the p = 0 oracle
+    net.eval()
+    with torch.no_grad():
+        e1, e2 = net(x.to(dev)), net(x.to(dev))
+    assert torch.equal(e1, e2)
+    assert (e1.cpu() - T.layer_forward(prm, x, prefix="0.")).abs().max().item() < 1e-4
