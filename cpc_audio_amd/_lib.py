@@ -76,6 +76,7 @@ SIGNATURES = {
     "cpc_nce_backward_dz": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward_dwall": (_I, [_P] * 3 + [_I, _I, _I, _I, _P]),
     "cpc_adam_step": (_I, [_P] * 5 + [_I] + [ctypes.c_double] * 6 + [_P]),
+    "cpc_adam_step_capturable": (_I, [_P] * 5 + [_I] + [ctypes.c_double] * 4 + [_P, _P, _P]),
 }
 
 

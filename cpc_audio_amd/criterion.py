@@ -139,6 +139,8 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             main, side = torch.cuda.current_stream(), step.side_stream(cFeature.device)
             # (holding them back until the recurrence starts was measured: 4.187 vs 4.162 ms/step -- they disturb its
             # hand-over polling more than they cost beside the first conv layers, where the host-side lead puts them)
+            if step.begin is not None:
+                side.wait_event(step.begin)           # fork from the start of the step (ops.StepContext.__enter__)
             with torch.cuda.stream(side):
                 negatives = self.drawNegatives(batchSize, seqSize, windowSize, cFeature.device)
                 ext, perm, row_ptr = prepare_negatives(negatives[0], negatives[1], batchSize, seqSize, self.nPredicts,

@@ -34,7 +34,26 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p - c.step_size * m / denom;
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamBatch b, AdamCoef c) {
+// Capturable form (the whole train step replayed as one HIP graph: kernel arguments are frozen at capture, so nothing
+// that changes from step to step may be a host scalar): the step counter lives on the device, this one-thread kernel
+// advances it and forms the step's coefficients -- in double, as the host path and torch do -- for adam_kernel_dev.
+__global__ void adam_coef_kernel(double* __restrict__ step, AdamCoef* __restrict__ out, double lr, double beta1, double beta2,
+                                 double eps) {
+    const double t = *step + 1.0;
+    *step = t;
+    const double bc1 = 1.0 - pow(beta1, t), bc2s = sqrt(1.0 - pow(beta2, t));
+    AdamCoef c;
+    c.b1c = (float)(1. - beta1); c.b2 = (float)beta2; c.b2c = (float)(1. - beta2);
+    c.step_size = (float)(lr / bc1); c.inv_bc2_sqrt = (float)(1. / bc2s); c.eps = (float)eps;
+    *out = c;
+}
+
+__device__ __forceinline__ void adam_body(const AdamBatch& b, const AdamCoef& c);
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamBatch b, AdamCoef c) { adam_body(b, c); }
+__global__ __launch_bounds__(256) void adam_kernel_dev(AdamBatch b, const AdamCoef* __restrict__ cp) { adam_body(b, *cp); }
+
+__device__ __forceinline__ void adam_body(const AdamBatch& b, const AdamCoef& c) {
     int t = 0;
     while (t + 1 < b.count && (int)blockIdx.x >= b.blk0[t + 1]) ++t;       // block-uniform
     const int n = b.n[t];
@@ -75,6 +94,9 @@ using namespace cpc;
 // One Adam step on n tensors (fp32, dense).  params / exp_avg / exp_avg_sq are updated in place; bias_correction1 =
 // 1 - beta1^step and bias_correction2_sqrt = sqrt(1 - beta2^step) come from the caller; the scalars are doubles so that
 // 1 - beta and lr / bias_correction1 are rounded to fp32 once, as in torch.
+static int adam_launch(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                       const long* numel, int n, const AdamCoef* host_coef, const AdamCoef* dev_coef, void* stream);
+
 extern "C" int cpc_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
                              float* const* exp_avg_sq, const long* numel, int n, double lr, double beta1, double beta2,
                              double eps, double bias_correction1, double bias_correction2_sqrt, void* stream) {
@@ -83,6 +105,25 @@ extern "C" int cpc_adam_step(float* const* params, const float* const* grads, fl
     AdamCoef c;      // formed in double like torch does (1 - 0.999f would already be off by 1.3e-5 relative)
     c.b1c = (float)(1. - beta1); c.b2 = (float)beta2; c.b2c = (float)(1. - beta2);
     c.step_size = (float)(lr / bias_correction1); c.inv_bc2_sqrt = (float)(1. / bias_correction2_sqrt); c.eps = (float)eps;
+    return adam_launch(params, grads, exp_avg, exp_avg_sq, numel, n, &c, nullptr, stream);
+}
+
+// The same update with the step counter on the device (graph-capturable: no per-step host scalar).  step: one device
+// double, the number of updates done so far (incremented here); coef: 8 device floats of scratch that stay valid until
+// the launch has run.  lr / betas / eps are frozen into a captured graph (the reference's schedule changes lr per epoch:
+// re-capture, or run eagerly, when it changes).
+extern "C" int cpc_adam_step_capturable(float* const* params, const float* const* grads, float* const* exp_avg,
+                                        float* const* exp_avg_sq, const long* numel, int n, double lr, double beta1,
+                                        double beta2, double eps, double* step, float* coef, void* stream) {
+    CPC_RETURN_IF(n < 0 || (n > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)) || !step || !coef, CPC_ERR_ARG);
+    AdamCoef* cd = reinterpret_cast<AdamCoef*>(coef);
+    hipLaunchKernelGGL(adam_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, cd, lr, beta1, beta2, eps);
+    CPC_LAUNCH_CHECK();
+    return adam_launch(params, grads, exp_avg, exp_avg_sq, numel, n, nullptr, cd, stream);
+}
+
+static int adam_launch(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                       const long* numel, int n, const AdamCoef* host_coef, const AdamCoef* dev_coef, void* stream) {
     int i = 0;
     while (i < n) {
         AdamBatch b;
@@ -103,7 +144,8 @@ extern "C" int cpc_adam_step(float* const* params, const float* const* grads, fl
             b.p[q] = nullptr; b.g[q] = nullptr; b.m[q] = nullptr; b.v[q] = nullptr; b.n[q] = 0; b.blk0[q + 1] = nblk;
         }
         b.count = cnt;
-        hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, b, c);
+        if (dev_coef) hipLaunchKernelGGL(adam_kernel_dev, dim3(nblk), dim3(256), 0, (hipStream_t)stream, b, dev_coef);
+        else hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, b, *host_coef);
         CPC_LAUNCH_CHECK();
     }
     return 0;

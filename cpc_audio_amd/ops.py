@@ -121,6 +121,13 @@ class StepContext:
     def __enter__(self):
         self._prev = getattr(_tls, "ctx", None)
         _tls.ctx = self
+        # where the step starts on the caller's stream: side-stream work that depends on nothing of the step (the negative
+        # draws) forks from HERE -- early enough to run beside the encoder, and an explicit fork, which a stream capture
+        # (train.Trainer(graph=True)) needs to see the side stream's work as part of the step
+        self.begin = None
+        if self.overlap and torch.cuda.is_available():
+            self.begin = torch.cuda.Event()
+            self.begin.record()
         return self
 
     def __exit__(self, et, ev, tb):

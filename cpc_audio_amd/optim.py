@@ -19,6 +19,68 @@ from . import _lib
 class Adam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
+        self._device_step = None          # graph-capturable mode (device_step_counter()): the step count lives on the GPU
+
+    def device_step_counter(self, enable=True):
+        """Graph-capturable mode: ``step()`` makes no per-step host decision (no ``.item()``, no host-side bias correction),
+        the step count lives in one device double advanced by the kernel (cpc_adam_step_capturable), so a whole train step
+        can be captured once and replayed as a HIP graph (train.Trainer(graph=True)).  ``state[p]["step"]`` is brought up to
+        date by ``sync_step_state()`` (state_dict() calls it).  Requires every group to satisfy ``_hip_ok`` and one shared
+        step count, which is how the reference's single-group optimiser behaves."""
+        if not enable:
+            if self._device_step is not None:
+                self.sync_step_state()
+            self._device_step = None
+            return self
+        params = [p for g in self.param_groups for p in g["params"]]
+        counts = {int(self.state[p]["step"].item()) for p in params if len(self.state[p])}
+        if len(counts) > 1:
+            raise ValueError("device_step_counter() needs one shared step count")
+        dev = params[0].device
+        self._device_step = torch.tensor([float(counts.pop()) if counts else 0.0], dtype=torch.float64, device=dev)
+        self._device_coef = torch.zeros(8, dtype=torch.float32, device=dev)
+        for p in params:                                   # state tensors must exist before a capture
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return self
+
+    def sync_step_state(self):
+        if self._device_step is not None:
+            k = float(self._device_step.item())
+            for g in self.param_groups:
+                for p in g["params"]:
+                    if len(self.state[p]):
+                        self.state[p]["step"] = torch.tensor(k, dtype=torch.float32)
+
+    def state_dict(self):
+        self.sync_step_state()
+        return super().state_dict()
+
+    def _step_on_device(self):
+        lib = _lib.get()
+        for group in self.param_groups:
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            if not self._hip_ok(group, params):
+                raise RuntimeError("device_step_counter(): a parameter group cannot run on the one-launch HIP update")
+            n = len(params)
+            arr = ctypes.c_void_p * n
+            ps = arr(*[p.data_ptr() for p in params])
+            gs = arr(*[p.grad.data_ptr() for p in params])
+            ms = arr(*[self.state[p]["exp_avg"].data_ptr() for p in params])
+            vs = arr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in params])
+            ns = (ctypes.c_long * n)(*[p.numel() for p in params])
+            beta1, beta2 = group["betas"]
+            dev = params[0].device
+            with torch.cuda.device(dev):
+                lib.check(lib.cpc_adam_step_capturable(ps, gs, ms, vs, ns, n, float(group["lr"]), beta1, beta2,
+                                                       float(group["eps"]), self._device_step.data_ptr(),
+                                                       self._device_coef.data_ptr(),
+                                                       torch.cuda.current_stream(dev).cuda_stream), "adam_step_capturable")
 
     @staticmethod
     def _hip_ok(group, params):
@@ -41,6 +103,9 @@ class Adam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self._device_step is not None:
+            self._step_on_device()
+            return loss
         rest = []
         for group in self.param_groups:
             params = [p for p in group["params"] if p.grad is not None]

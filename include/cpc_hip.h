@@ -303,6 +303,12 @@ int cpc_nce_scores_backward(const float* pred, const float* z, const int* ext, c
 int cpc_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                   const long* numel, int n, double lr, double beta1, double beta2, double eps, double bias_correction1,
                   double bias_correction2_sqrt, void* stream);
+/* The same with the step counter on the device: nothing changes from call to call on the host side, so the launch can be
+ * part of a captured HIP graph.  step: one device double = updates done so far (incremented by the call); coef: 8 device
+ * floats of scratch. */
+int cpc_adam_step_capturable(float* const* params, const float* const* grads, float* const* exp_avg,
+                             float* const* exp_avg_sq, const long* numel, int n, double lr, double beta1, double beta2,
+                             double eps, double* step, float* coef, void* stream);
 
 #ifdef __cplusplus
 }

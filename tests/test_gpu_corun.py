@@ -138,7 +138,8 @@ def test_norm_backward_is_bit_exact_beside_the_fp16_gemm_kernels():
     amax = torch.zeros(1, device=dev)
 
     def victim(st):
-        amax.zero_()
+        with torch.cuda.stream(st):
+            amax.zero_()                                   # on the victim's stream: the kernel accumulates into it
         lib.check(lib.cpc_norm_backward(P(dy), P(xhat), P(y), P(rstd), P(nw), P(dx), P(colpart), P(tmp), P(small3),
                                         P(amax), M, st.cuda_stream))
     _check_beside(victim, [dx, small3, amax], co)

@@ -83,3 +83,44 @@ def test_adam_skips_parameters_without_gradient_and_other_groups_use_torch():
     q.grad = torch.ones_like(q)
     ref.step()
     assert torch.allclose(p3, q)
+
+
+def test_graph_replayed_step_equals_the_eager_step():
+    """Trainer(graph=True): the whole step (forward, backward on all streams, Adam with a device-side step counter,
+    zero_grad) captured once as a HIP graph and replayed.  Given the same parameters and the same generator state the
+    replayed step must leave the parameters the eager step leaves (same kernels, same order per stream), over several steps
+    -- including Adam's bias correction, which a frozen host scalar would get wrong from the second replay on -- and the
+    optimiser's state dict must report the true step count."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
+    from oracle import cpc_oracle as O
+    dev = torch.device("cuda:0")
+    B, n_steps = 4, 4
+    p = O.make_params(seed=15, head_scale=64.0)
+    waves = [O.make_waveform(B, 20480, seed=60 + i).to(dev) for i in range(n_steps)]
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    finals, losses = [], []
+    for graph in (False, True):
+        model, crit = build_model().to(dev), build_criterion().to(dev)
+        load_flat_params(model, crit, p)
+        model.train(); crit.train()
+        tr = Trainer(model, crit, graph=graph)
+        if graph:
+            tr.capture(waves[0], label)                    # warm-up + capture first, so that the generator can be aligned
+            assert tr._captured is not None
+        torch.manual_seed(4242)
+        ls = []
+        for i in range(n_steps):
+            l, _ = tr.step(waves[i], label)
+            ls.append(l.clone())
+        torch.cuda.synchronize()
+        assert (tr._captured is not None) == graph
+        finals.append({k: v.detach().cpu() for k, v in list(model.state_dict().items()) + list(crit.state_dict().items())})
+        losses.append(torch.stack(ls).cpu())
+        sd = tr.optimizer.state_dict()
+        assert {int(s["step"]) for s in sd["state"].values()} == {n_steps}
+    assert torch.isfinite(losses[1]).all()
+    assert torch.equal(losses[0], losses[1]), (losses[0] - losses[1]).abs().max()
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
