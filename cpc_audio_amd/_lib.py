@@ -22,6 +22,7 @@ _F = ctypes.c_float
 SIGNATURES = {
     "cpc_abi_version": (_I, []),
     "cpc_set_mfma_mode": (_I, [_I]),
+    "cpc_get_mfma_mode": (_I, []),
     "cpc_device_error_flags": (_I, [_I]),
     "cpc_conv0_forward": (_I, [_P] * 8 + [_I, _I, _P]),
     "cpc_conv0_forward_h2": (_I, [_P] * 9 + [_I, _I, _P]),

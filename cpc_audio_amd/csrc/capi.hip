@@ -48,6 +48,8 @@ extern "C" int cpc_device_error_flags(int clear) {
     return (int)((a ? 1u : 0u) | (b ? 2u : 0u));
 }
 
+extern "C" int cpc_get_mfma_mode(void) { return cpc::g_mfma_mode; }
+
 extern "C" int cpc_set_mfma_mode(int mode) {
     CPC_RETURN_IF(mode < 0 || mode > 4, CPC_ERR_ARG);
     cpc::g_mfma_mode = mode;

@@ -89,7 +89,9 @@ class Trainer:
 
     def _graph_key(self, batchData):
         lrs = tuple(float(g["lr"]) for g in self.optimizer.param_groups)
-        return (tuple(batchData.shape), batchData.device, self.model.training, lrs)
+        from . import _lib
+        # ... and the library's arithmetic / storage mode: its kernels are frozen into the graph
+        return (tuple(batchData.shape), batchData.device, self.model.training, lrs, _lib.get().cpc_get_mfma_mode())
 
     def _graph_safe(self):
         """What a replayed graph cannot express: a recurrent state carried from step to step on the Python side

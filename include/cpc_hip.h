@@ -40,6 +40,7 @@ int cpc_abi_version(void);
  *     global -> LDS by DMA (csrc/conv_dma.hip, 256- / 128-row tiles); their weight gradients read the pieces as stored.  The
  *     per-layer entry points (cpc_conv_layer_*, cpc_conv_gemm_forward, cpc_norm_backward) behave as in mode 2. */
 int cpc_set_mfma_mode(int mode);
+int cpc_get_mfma_mode(void);
 
 /* Device-side error flags of the current device, accumulated since they were last cleared (clear != 0 clears them):
  *   CPC_DEVERR_GRU_POLL_TIMEOUT  a workgroup of the persistent recurrence (cpc_gru_forward / _backward) gave up
