@@ -194,6 +194,17 @@ __global__ __launch_bounds__(256) void enc_prep_permute_kernel(PrepArgs a) {
     else permute_w_fwd_elem(a.w[layer], dst, k, a.split, amax, idx);
 }
 
+// max|dx| of a layer as its consumers read it.  The kernel that writes dx accumulates it with integer atomicMax on the float
+// bits; 8192 waves hammering ONE address serialise at L2 (measured: the largest norm backward spent ~0.12 ms, as long as its
+// 200 MB of traffic should take twice over), so the composite encoder spreads them over kAmaxSlots addresses by workgroup
+// and the consuming GEMM kernels fold the slots (a max is order-independent: still exact and deterministic).
+constexpr int kAmaxSlots = 64;
+__device__ __forceinline__ float fold_amax(const float* __restrict__ p, int slots) {
+    if (slots <= 1) return *p;
+    const int lane = threadIdx.x & 63;
+    return wave_max(lane < slots ? p[lane] : 0.f);
+}
+
 // ------------------------------------------------------------------ forward
 // MODE: 0 = exact-f32 MFMA, 1 = three bf16 pieces (6 MFMAs per product), 2 = two fp16 pieces (3 MFMAs per
 // product; operands scaled by powers of two derived from bounds on their max|.|, see gemm_tile.h)
@@ -345,8 +356,9 @@ template <int MASK, bool DYB = false, bool XB = false>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ y,
     const float* __restrict__ rstd, const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ dx,
-    float* __restrict__ colpart, int M, float* __restrict__ dx_amax) {
+    float* __restrict__ colpart, int M, float* __restrict__ dx_amax, int amax_slots) {
     __shared__ float red[4][3][kC];
+    __shared__ float wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = lane * 4;
     const float4 w4 = *reinterpret_cast<const float4*>(nw + c);
@@ -436,9 +448,13 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
         const int a = i >> kCLog2, cc = i & (kC - 1);
         prow[i] = (red[0][a][cc] + red[1][a][cc]) + (red[2][a][cc] + red[3][a][cc]);
     }
-    if (dx_amax != nullptr) {
+    if (dx_amax != nullptr) {                  // one atomic per workgroup, spread over amax_slots addresses (fold_amax)
         amax = wave_max(amax);
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(dx_amax), __float_as_uint(amax));
+        if (lane == 0) wmax[wv] = amax;
+        __syncthreads();
+        if (tid == 0)
+            atomicMax(reinterpret_cast<unsigned*>(dx_amax + (int)(blockIdx.x % (unsigned)amax_slots)),
+                      __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
     }
 }
 
@@ -451,7 +467,7 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
     const float* __restrict__ xhat_prev, const float* __restrict__ y_prev,
     const float* __restrict__ rstd_prev, const float* __restrict__ nw_prev,
     float* __restrict__ dprev, float* __restrict__ colpart, const float* __restrict__ dx_amax,
-    const float* __restrict__ w_amax, float* __restrict__ prev_amax) {
+    const float* __restrict__ w_amax, float* __restrict__ prev_amax, int amax_slots) {
     using Tile = typename ConvCfg<BM, MODE>::Tile;
     constexpr bool X3 = MODE != 0;
     constexpr int TM = Tile::TM, TN = Tile::TN, WAVES_M = ConvCfg<BM, MODE>::WAVES_M;
@@ -463,7 +479,7 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
     f32x16 acc[TM][TN];
     zero_acc(acc);
     if constexpr (ConvCfg<BM, MODE>::H2) {
-        const float sa = scale_for_amax(*dx_amax), sb = scale_for_amax(*w_amax);
+        const float sa = scale_for_amax(fold_amax(dx_amax, amax_slots)), sb = scale_for_amax(*w_amax);
         Tile::run(acc, am, m0, wd + (long)ph * kC * 2 * kC, 16, 0, 2 * kC, smem, 0, kC * 16, 0, sa, sb, 1);     // two 256-wide segments
         const float inv = 1.0f / (sa * sb);
 #pragma unroll
@@ -594,7 +610,7 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
     for (int i = threadIdx.x; i < 3 * kC; i += Tile::NTHREADS) prow[i] = (&colsum[0][0])[i];
     if (prev_amax != nullptr) {
         amax = wave_max(amax);
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(prev_amax), __float_as_uint(amax));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(prev_amax + (int)(blockIdx.x % (unsigned)amax_slots)), __float_as_uint(amax));
     }
 }
 
@@ -614,7 +630,7 @@ struct WgCfg {
 template <int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     RowMap dxm, RowMap im, int K, int rows_per_split, int S, float* __restrict__ part,
-    const float* __restrict__ dx_amax, const float* __restrict__ x_amax) {
+    const float* __restrict__ dx_amax, const float* __restrict__ x_amax, int amax_slots) {
     using WgTile = typename WgCfg<MODE>::Tile;
     __shared__ float smem[WgTile::SMEM_FLOATS];
     const int T = 2 * (K / 128);
@@ -630,7 +646,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     if constexpr (MODE == 4) {
         WgTile::run(acc, dxm, c0, im, n0, mbeg, mend, smem);
     } else if constexpr (MODE >= 2) {
-        const float sa = scale_for_amax(*dx_amax), sb = scale_for_amax(*x_amax);
+        const float sa = scale_for_amax(fold_amax(dx_amax, amax_slots)), sb = scale_for_amax(*x_amax);
         WgTile::run(acc, dxm, c0, im, n0, mbeg, mend, smem, sa, sb);
         inv = 1.0f / (sa * sb);
     } else {
@@ -769,7 +785,7 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
         e.tmpq[i] = o; o += align64((long)kRowsSumGroups * 3 * kC);
     }
     e.conv0 = o; o += align64(cpc_conv0_backward_scratch_floats(B, Lw));
-    e.bamax = o; o += 64;                   // [i] = max|dx_i| (i = 1..4)
+    e.bamax = o; o += 5 * kAmaxSlots;       // [i][slot] = partial max|dx_i| (i = 1..4), folded by the consumers (fold_amax)
     e.bwd_total = o;
     return true;
 }
@@ -793,19 +809,19 @@ template <int BM, bool FUSE>
 static void launch_conv_dgrad(const RowMap& am, const float* wd, int s, int p, int Lin,
                               const float* xhat_prev, const float* y_prev, const float* rstd_prev,
                               const float* nw_prev, float* dprev, float* colpart, const float* dx_amax,
-                              const float* w_amax, float* prev_amax, hipStream_t st) {
+                              const float* w_amax, float* prev_amax, int amax_slots, hipStream_t st) {
     if (g_mfma_mode >= 2)
         hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE, 2>), dim3(cdiv(am.M, BM), s),
                            dim3(ConvCfg<BM, 2>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
-                           rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, prev_amax);
+                           rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, prev_amax, amax_slots);
     else if (g_mfma_mode == 1)
         hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE, 1>), dim3(cdiv(am.M, BM), s),
                            dim3(ConvCfg<BM, 1>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
-                           rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, prev_amax);
+                           rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, prev_amax, amax_slots);
     else
         hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE, 0>), dim3(cdiv(am.M, BM), s),
                            dim3(ConvCfg<BM, 0>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
-                           rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, prev_amax);
+                           rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, prev_amax, amax_slots);
 }
 
 }  // namespace cpc
@@ -818,7 +834,7 @@ static int weight_split() {
 static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const float* xhat_prev, const float* y_prev,
                            const float* rstd_prev, const float* nw_prev, float* dprev, float* colpart, float* tmp,
                            float* small3, const float* dx_amax, float* dprev_amax, int B, int Lin, int k, int s, int p,
-                           hipStream_t st);
+                           hipStream_t st, int amax_slots = 1);
 
 extern "C" int cpc_set_conv_tile(int bm) {
     CPC_RETURN_IF(bm != 0 && bm != 32 && bm != 64 && bm != 128, CPC_ERR_ARG);
@@ -908,7 +924,7 @@ extern "C" int cpc_norm_backward(const float* dy, const float* xhat, const float
     CPC_RETURN_IF(M <= 0, CPC_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     const int nblk = cdiv(M, NB_ROWS);
-    hipLaunchKernelGGL(norm_bwd_kernel<0>, dim3(nblk), dim3(256), 0, st, dy, xhat, y, rstd, nw, nullptr, dx, colpart, M, dx_amax);
+    hipLaunchKernelGGL(norm_bwd_kernel<0>, dim3(nblk), dim3(256), 0, st, dy, xhat, y, rstd, nw, nullptr, dx, colpart, M, dx_amax, 1);
     CPC_LAUNCH_CHECK();
     return rows_sum(colpart, nblk, 3 * kC, tmp, small3, st);
 }
@@ -949,7 +965,7 @@ extern "C" int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, 
 static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const float* xhat_prev, const float* y_prev,
                            const float* rstd_prev, const float* nw_prev, float* dprev, float* colpart, float* tmp,
                            float* small3, const float* dx_amax, float* dprev_amax, int B, int Lin, int k, int s, int p,
-                           hipStream_t st) {
+                           hipStream_t st, int amax_slots) {
     const int Lout = conv_out_len(Lin, k, s, p);
     const float* w_amax = wd + (long)kC * k * kC;
     // 2-row windows [q-1, q] over dx, q in [0, Lout]
@@ -960,17 +976,17 @@ static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const flo
     const int nblk = cdiv(am.M, bm) * s;
     if (fuse) {
         switch (bm) {
-            case 128: launch_conv_dgrad<128, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, dprev_amax, st); break;
-            case 64: launch_conv_dgrad<64, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, dprev_amax, st); break;
-            default: launch_conv_dgrad<32, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, dprev_amax, st); break;
+            case 128: launch_conv_dgrad<128, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, dprev_amax, amax_slots, st); break;
+            case 64: launch_conv_dgrad<64, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, dprev_amax, amax_slots, st); break;
+            default: launch_conv_dgrad<32, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, dprev_amax, amax_slots, st); break;
         }
         CPC_LAUNCH_CHECK();
         return rows_sum(colpart, nblk, 3 * kC, tmp, small3, st);
     }
     switch (bm) {
-        case 128: launch_conv_dgrad<128, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, nullptr, st); break;
-        case 64: launch_conv_dgrad<64, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, nullptr, st); break;
-        default: launch_conv_dgrad<32, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, nullptr, st); break;
+        case 128: launch_conv_dgrad<128, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, nullptr, amax_slots, st); break;
+        case 64: launch_conv_dgrad<64, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, nullptr, amax_slots, st); break;
+        default: launch_conv_dgrad<32, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, nullptr, amax_slots, st); break;
     }
     CPC_LAUNCH_CHECK();
     return 0;
@@ -981,7 +997,7 @@ static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const flo
 // dx_amax, x_amax: device floats bounding max|dx| and max|x| (mode 2 only).
 static int conv_layer_wgrad(const float* dx, const float* x, int x_h2, float* part, float* dW, const float* dx_amax,
                             const float* x_amax, int B, int Lin, int k, int s, int p, int splits, int rows_per_split,
-                            void* stream);
+                            void* stream, int amax_slots = 1);
 extern "C" int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part, float* dW,
                                     const float* dx_amax, const float* x_amax, int B,
                                     int Lin, int k, int s, int p, int splits, int rows_per_split,
@@ -992,7 +1008,7 @@ extern "C" int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part
 // 2 = dx and x are both bf16 tensors (mode 4)
 static int conv_layer_wgrad(const float* dx, const float* x, int x_h2, float* part, float* dW, const float* dx_amax,
                             const float* x_amax, int B, int Lin, int k, int s, int p, int splits, int rows_per_split,
-                            void* stream) {
+                            void* stream, int amax_slots) {
     CPC_RETURN_IF(x_h2 == 1 && g_mfma_mode < 2, CPC_ERR_ARG);
     CPC_RETURN_IF(B <= 0 || Lin <= 0 || Lin + 2 * p < k || splits <= 0 || rows_per_split <= 0, CPC_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
@@ -1004,15 +1020,15 @@ static int conv_layer_wgrad(const float* dx, const float* x, int x_h2, float* pa
     const dim3 grid(8 * 2 * (K / 128) * cdiv(splits, 8));
     CPC_RETURN_IF(g_mfma_mode >= 2 && x_h2 != 2 && (!dx_amax || !x_amax), CPC_ERR_ARG);
     if (x_h2 == 2)
-        hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
+        hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax, amax_slots);
     else if (g_mfma_mode >= 2 && x_h2)
-        hipLaunchKernelGGL((conv_wgrad_kernel<3>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
+        hipLaunchKernelGGL((conv_wgrad_kernel<3>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax, amax_slots);
     else if (g_mfma_mode >= 2)
-        hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
+        hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax, amax_slots);
     else if (g_mfma_mode == 1)
-        hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
+        hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax, amax_slots);
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<0>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax);
+        hipLaunchKernelGGL((conv_wgrad_kernel<0>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax, amax_slots);
     const long total = (long)kC * k * kC;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, part, splits, k, dW);
     CPC_LAUNCH_CHECK();
@@ -1154,7 +1170,7 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     // layouts come from the forward (saved)
     float* amax = scratch + e.bamax;
     const float* xbound = saved + e.sbound;
-    (void)hipMemsetAsync(amax, 0, 64 * sizeof(float), st);
+    (void)hipMemsetAsync(amax, 0, 5 * kAmaxSlots * sizeof(float), st);
     // top layer: ReLU'/norm backward of dz
     // the four stand-alone norm backwards leave their per-workgroup column partials in their own buffers; one batched
     // reduction at the end replaces eight small launches on the way
@@ -1166,15 +1182,15 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
         if (e.bf16 && layer == 4)         // bf16 storage: xhat and dx are bf16; the top layer's dy is autograd's fp32 dz
             hipLaunchKernelGGL((norm_bwd_kernel<2, false, true>), dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
                                saved + e.rstd[layer], params[4 * layer + 2], params[4 * layer + 3], dxl, scratch + e.colp[layer],
-                               M, (float*)nullptr);
+                               M, (float*)nullptr, 1);
         else if (e.bf16)
             hipLaunchKernelGGL((norm_bwd_kernel<2, true, true>), dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
                                saved + e.rstd[layer], params[4 * layer + 2], params[4 * layer + 3], dxl, scratch + e.colp[layer],
-                               M, (float*)nullptr);
+                               M, (float*)nullptr, 1);
         else
         hipLaunchKernelGGL(norm_bwd_kernel<2>, dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
                            saved + e.rstd[layer], params[4 * layer + 2], params[4 * layer + 3], dxl, scratch + e.colp[layer], M,
-                           amax + layer);
+                           amax + layer * kAmaxSlots, kAmaxSlots);
         jobs[njobs++] = RowsSumJob{scratch + e.colp[layer], nblk, 3 * kC, scratch + e.tmpq[layer], small + layer * 3 * kC};
     };
     int rc = 0;
@@ -1189,8 +1205,8 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                 return CPC_ERR_ARG;
         }
         if (!(ev && i == 1))
-        rc = conv_layer_wgrad(scratch + e.dx[i], xin, e.bf16 ? 2 : act_h2(i - 1), scratch + e.part, grads[4 * i], amax + i, xbound + i, B,
-                              e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], (void*)wst);
+        rc = conv_layer_wgrad(scratch + e.dx[i], xin, e.bf16 ? 2 : act_h2(i - 1), scratch + e.part, grads[4 * i], amax + i * kAmaxSlots, xbound + i, B,
+                              e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], (void*)wst, kAmaxSlots);
         if (rc) return rc;
         if (e.bf16) {
             // bf16 storage: DMA'd bf16 dgrad into a bf16 temporary (layer 1: straight into conv0's dy), then the norm backward
@@ -1204,24 +1220,24 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
             // plain dgrad into a temporary (dy0 is free until layer 1's dgrad) + the streaming norm backward is faster
             float* tmpd = scratch + e.dy0;
             rc = conv_dgrad_core(scratch + e.dx[i], saved + e.swd[i], 0, nullptr, nullptr, nullptr, nullptr, tmpd, nullptr,
-                                 nullptr, nullptr, amax + i, nullptr, B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, st);
+                                 nullptr, nullptr, amax + i * kAmaxSlots, nullptr, B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, st, kAmaxSlots);
             if (rc) return rc;
             norm_bwd(i - 1, tmpd, xin, scratch + e.dx[i - 1]);
         } else if (i >= 2) {
             rc = conv_dgrad_core(scratch + e.dx[i], saved + e.swd[i], 1, saved + e.xhat[i - 1], xin,
                                  saved + e.rstd[i - 1], params[4 * (i - 1) + 2], scratch + e.dx[i - 1], colpart, tmp,
-                                 small + (i - 1) * 3 * kC, amax + i, amax + i - 1, B, e.L[i - 1], kGeom[i].k, kGeom[i].s,
-                                 kGeom[i].p, st);
+                                 small + (i - 1) * 3 * kC, amax + i * kAmaxSlots, amax + (i - 1) * kAmaxSlots, B, e.L[i - 1], kGeom[i].k,
+                                 kGeom[i].s, kGeom[i].p, st, kAmaxSlots);
         } else {
             rc = conv_dgrad_core(scratch + e.dx[1], saved + e.swd[1], 0, nullptr, nullptr, nullptr, nullptr,
-                                 scratch + e.dy0, nullptr, nullptr, nullptr, amax + 1, nullptr, B, e.L[0], kGeom[1].k,
-                                 kGeom[1].s, kGeom[1].p, st);
+                                 scratch + e.dy0, nullptr, nullptr, nullptr, amax + kAmaxSlots, nullptr, B, e.L[0], kGeom[1].k,
+                                 kGeom[1].s, kGeom[1].p, st, kAmaxSlots);
         }
         if (rc) return rc;
         if (ev && i == 1) {
             if (hipEventRecord(ev[1], st) != hipSuccess || hipStreamWaitEvent(wst, ev[1], 0) != hipSuccess) return CPC_ERR_ARG;
-            rc = conv_layer_wgrad(scratch + e.dx[1], xin, e.bf16 ? 2 : act_h2(0), scratch + e.part, grads[4], amax + 1, xbound + 1, B, e.L[0],
-                                  kGeom[1].k, kGeom[1].s, kGeom[1].p, e.wg_splits[1], e.wg_rows[1], (void*)wst);
+            rc = conv_layer_wgrad(scratch + e.dx[1], xin, e.bf16 ? 2 : act_h2(0), scratch + e.part, grads[4], amax + kAmaxSlots, xbound + 1, B, e.L[0],
+                                  kGeom[1].k, kGeom[1].s, kGeom[1].p, e.wg_splits[1], e.wg_rows[1], (void*)wst, kAmaxSlots);
         }
         if (rc) return rc;
     }
