@@ -11,6 +11,24 @@ import torch.nn as nn
 from .ops import InfoNCEFunction, InfoNCEScoresFunction, prepare_negatives
 
 
+class _StackedHeads(torch.autograd.Function):
+    """The buffer the K head weights are views of, as a differentiable function of them (gradient: its K row blocks)."""
+
+    @staticmethod
+    def forward(ctx, flat, *heads):
+        ctx.rows = heads[0].shape[0]
+        ctx.set_materialize_grads(False)
+        return flat.view_as(flat)
+
+    @staticmethod
+    def backward(ctx, g):
+        n = len(ctx.needs_input_grad) - 1
+        if g is None:
+            return (None,) * (n + 1)
+        return (None,) + tuple(g[k * ctx.rows:(k + 1) * ctx.rows] if ctx.needs_input_grad[k + 1] else None
+                               for k in range(n))
+
+
 class PredictionNetwork(nn.Module):
     """cpc/criterion/criterion.py:44-118: K prediction networks.  ``--rnnMode linear`` (the ``else`` branch at
     :89-95, north-star configuration): K bias-free nn.Linear(dimOutputAR, dimOutputEncoder) fused into the
@@ -48,8 +66,21 @@ class PredictionNetwork(nn.Module):
         return torch.cat([p(c) for p in self.predictors], dim=2)
 
     def stacked_weight(self):
-        """(K*256, 256): the K head weights stacked along the output dimension."""
-        return torch.cat([p.weight for p in self.predictors], dim=0)
+        """(K*256, 256): the K head weights stacked along the output dimension -- without a per-step ``torch.cat``: the K
+        parameters are kept as views of one buffer (re-established whenever somebody gave them new storage, e.g.
+        ``.to(device)``; in-place updates -- the optimiser, ``load_state_dict`` -- keep it), and the buffer is tied to
+        them for autograd by _StackedHeads."""
+        ws = [p.weight for p in self.predictors]
+        flat = getattr(self, "_flat_heads", None)
+        rows, step = ws[0].shape[0], ws[0].numel() * ws[0].element_size()
+        if (flat is None or flat.device != ws[0].device or flat.dtype != ws[0].dtype
+                or any(w.data_ptr() != flat.data_ptr() + k * step for k, w in enumerate(ws))):
+            with torch.no_grad():
+                flat = torch.cat([w.detach() for w in ws], dim=0).contiguous()
+                for k, w in enumerate(ws):
+                    w.data = flat[k * rows:(k + 1) * rows]
+            self._flat_heads = flat
+        return _StackedHeads.apply(flat, *ws)
 
     def forward(self, c, candidates):
         """Reference API (criterion.py:97-118) on materialised candidates; kept for callers

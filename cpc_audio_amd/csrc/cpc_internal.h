@@ -14,14 +14,25 @@ constexpr int kRowsSumMaxJobs = 8;
 struct RowsSumJob { const float* part; int nrows; int n; float* tmp; float* out; };
 int rows_sum_multi(const RowsSumJob* jobs, int njobs, hipStream_t stream);
 
+// Device-side upper bounds of max|A| and max|B| (each `slots` <= 64 floats whose maximum is the bound).  Given both -- and in
+// cpc_set_mfma_mode >= 2 -- a GEMM runs on the fp16 pipe with two-piece split operands (3 MFMAs per product) instead of
+// three bf16 pieces (6); the bounds need not be tight (a factor 2^10 costs nothing measurable, gemm_tile.h).
+struct GemmBounds {
+    const float* a = nullptr;
+    const float* b = nullptr;
+    int a_slots = 1, b_slots = 1;
+};
+// max|x| of up to 4 arrays in one launch, as kAmaxSlots partial maxima each (no memset, no atomics): out[j*64 .. j*64+63]
+int absmax_slots(const float* const* x, const long* n, int njobs, float* out, hipStream_t st);
+
 // C[M,N] = A . B[N,K]^T (+ bias);  N % 128 == 0, K % 16 == 0
 int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc, int N,
-            int K, hipStream_t st, int c_R = 0, long c_bstride = 0);
+            int K, hipStream_t st, int c_R = 0, long c_bstride = 0, GemmBounds gb = GemmBounds());
 // C[N1,N2] (+)= sum_m A[m,:N1]^T (x) B[m,:N2];  part: tn_gemm_part_floats(M,N1,N2) floats
 void tn_gemm_plan(int M, int N1, int N2, int* splits, int* rows);
 long tn_gemm_part_floats(int M, int N1, int N2);
 int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, float* C, int accumulate,
-            hipStream_t st);
+            hipStream_t st, GemmBounds gb = GemmBounds());
 // nprob <= 4 TN problems with equal M, N1, N2 in one GEMM launch + one reduction; part: tn_gemm_batch_part_floats
 long tn_gemm_batch_part_floats(int nprob, int M, int N1, int N2);
 int tn_gemm_batch(int nprob, const RowMap* am, int N1, const RowMap* bm, int N2, float* part, float* const* C,

@@ -198,12 +198,7 @@ __global__ __launch_bounds__(256) void enc_prep_permute_kernel(PrepArgs a) {
 // bits; 8192 waves hammering ONE address serialise at L2 (measured: the largest norm backward spent ~0.12 ms, as long as its
 // 200 MB of traffic should take twice over), so the composite encoder spreads them over kAmaxSlots addresses by workgroup
 // and the consuming GEMM kernels fold the slots (a max is order-independent: still exact and deterministic).
-constexpr int kAmaxSlots = 64;
-__device__ __forceinline__ float fold_amax(const float* __restrict__ p, int slots) {
-    if (slots <= 1) return *p;
-    const int lane = threadIdx.x & 63;
-    return wave_max(lane < slots ? p[lane] : 0.f);
-}
+// (kAmaxSlots, fold_amax: gemm_tile.h)
 
 // ------------------------------------------------------------------ forward
 // MODE: 0 = exact-f32 MFMA, 1 = three bf16 pieces (6 MFMAs per product), 2 = two fp16 pieces (3 MFMAs per

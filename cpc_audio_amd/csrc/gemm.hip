@@ -15,19 +15,40 @@ using NtBigX3 = NtTileX3<128, 128, 2, 2>;  // the same on the bf16 pipe with 3-p
 using NtSmallX3 = NtTileX3<64, 64, 2, 2>;
 using TnG = TnTile<128, 128, 2, 2>;
 using TnGX3 = TnTileX3<128, 128, 2, 2>;
+// ... and on the fp16 pipe with 2-piece split operands (3 MFMAs per product instead of 6): needs a bound on max|A| and
+// max|B| for the power-of-two operand scales (GemmBounds; gemm_tile.h scale_for_amax)
+using NtBigH2 = NtTileX3<128, 128, 2, 2, 32, 1, false, false, 2>;
+using NtSmallH2 = NtTileX3<64, 64, 2, 2, 32, 1, false, false, 2>;
+using TnGH2 = TnTileX3<128, 128, 2, 2, 32, 1, 2>;
+
+struct OperandScales { float sa, sb, inv; };
+__device__ __forceinline__ OperandScales operand_scales(const GemmBounds& gb) {
+    OperandScales o;
+    o.sa = scale_for_amax(fold_amax(gb.a, gb.a_slots));
+    o.sb = scale_for_amax(fold_amax(gb.b, gb.b_slots));
+    o.inv = 1.0f / (o.sa * o.sb);                         // powers of two: exact
+    return o;
+}
 
 // Output row m goes to C + m*ldc, or, when c_R > 0, to C + (m / c_R)*c_bstride + (m % c_R)*ldc
 // (a batch-strided view such as dc[:, :W]).
-template <class NtG, int BMN>
+template <class NtG, int BMN, bool H2 = false>
 __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const float* __restrict__ Bmat,
                                                                 int ldb, const float* __restrict__ bias,
                                                                 float* __restrict__ C, long ldc, int K,
-                                                                int c_R, long c_bstride) {
+                                                                int c_R, long c_bstride, GemmBounds gb) {
     __shared__ float smem[NtG::SMEM_FLOATS];
     const int m0 = blockIdx.x * BMN, n0 = blockIdx.y * BMN;
     f32x16 acc[NtG::TM][NtG::TN];
     zero_acc(acc);
-    NtG::run(acc, am, m0, Bmat, ldb, n0, K, smem);
+    float inv = 1.0f;
+    if constexpr (H2) {
+        const OperandScales os = operand_scales(gb);
+        inv = os.inv;
+        NtG::run(acc, am, m0, Bmat, ldb, n0, K, smem, 0, 16, 0, os.sa, os.sb);
+    } else {
+        NtG::run(acc, am, m0, Bmat, ldb, n0, K, smem);
+    }
 #pragma unroll
     for (int tn = 0; tn < NtG::TN; ++tn) {
         const int col = n0 + NtG::c_col(tn);
@@ -40,7 +61,7 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
                 if (m < am.M) {
                     long ro = (long)m * ldc;
                     if (c_R > 0) { const int cb = m / c_R; ro = cb * c_bstride + (long)(m - cb * c_R) * ldc; }
-                    C[ro + col] = acc[tm][tn][r] + bv;
+                    C[ro + col] = H2 ? fmaf(acc[tm][tn][r], inv, bv) : acc[tm][tn][r] + bv;
                 }
             }
     }
@@ -48,9 +69,9 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
 
 // 1-D grid of 8 * T * ceil(S/8) blocks, T = (N1/128)*(N2/128) output tiles; part[z][N1][N2].
 // XCD-aware: all tiles of one row split run on one XCD (see conv_wgrad_kernel).
-template <class TnG>
+template <class TnG, bool H2 = false>
 __global__ __launch_bounds__(256) void tn_gemm_kernel(RowMap am, RowMap bm, int N1, int N2, int rows_per_split,
-                                                      int S, float* __restrict__ part, long zstride) {
+                                                      int S, float* __restrict__ part, long zstride, GemmBounds gb) {
     __shared__ float smem[TnG::SMEM_FLOATS];
     const int tn2 = N2 / 128, T = (N1 / 128) * tn2;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -61,7 +82,14 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(RowMap am, RowMap bm, int 
     const int mend = min(am.M, mbeg + rows_per_split);
     f32x16 acc[TnG::TM][TnG::TN];
     zero_acc(acc);
-    TnG::run(acc, am, c0, bm, n0, mbeg, mend, smem);
+    float inv = 1.0f;
+    if constexpr (H2) {
+        const OperandScales os = operand_scales(gb);
+        inv = os.inv;
+        TnG::run(acc, am, c0, bm, n0, mbeg, mend, smem, os.sa, os.sb);
+    } else {
+        TnG::run(acc, am, c0, bm, n0, mbeg, mend, smem);
+    }
     float* out = part + (long)z * zstride;
 #pragma unroll
     for (int tm = 0; tm < TnG::TM; ++tm)
@@ -70,7 +98,7 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(RowMap am, RowMap bm, int 
             const int row = c0 + TnG::c_row(tm, r);
 #pragma unroll
             for (int tn = 0; tn < TnG::TN; ++tn)
-                out[(long)row * N2 + n0 + TnG::c_col(tn)] = acc[tm][tn][r];
+                out[(long)row * N2 + n0 + TnG::c_col(tn)] = H2 ? acc[tm][tn][r] * inv : acc[tm][tn][r];
         }
 }
 
@@ -162,25 +190,80 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch b, 
     }
 }
 
+// One workgroup of 1024 threads per (array, slot): slot s covers elements [s, s+1) * ceil(n / 64 / 4) * 4 of its array,
+// four 16-byte loads in flight per thread.
+struct AbsmaxJobs { const float* x[4]; long n[4]; };
+__global__ __launch_bounds__(1024) void absmax_slots_kernel(AbsmaxJobs jobs, float* __restrict__ out) {
+    __shared__ float red[16];
+    const float* __restrict__ x = jobs.x[blockIdx.y];
+    const long n = jobs.n[blockIdx.y];
+    const long per = ((n + kAmaxSlots - 1) / kAmaxSlots + 3) & ~3L;
+    const long beg = (long)blockIdx.x * per, end = beg + per < n ? beg + per : n;
+    float m = 0.f;
+    if ((reinterpret_cast<unsigned long>(x) & 15) == 0) {
+        long i = beg + 4L * threadIdx.x;
+        for (; i + 3 * 4096 + 3 < end; i += 4 * 4096) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + i + u * 4096);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+        }
+        for (; i + 3 < end; i += 4096) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        for (; i < end; ++i) m = fmaxf(m, fabsf(x[i]));         // the one thread that holds a partial last group
+    } else {
+        for (long i = beg + threadIdx.x; i < end; i += 1024) m = fmaxf(m, fabsf(x[i]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        m = wave_max(threadIdx.x < 16 ? red[threadIdx.x] : 0.f);
+        if (threadIdx.x == 0) out[blockIdx.y * kAmaxSlots + blockIdx.x] = m;
+    }
+}
+
+int g_gemm_split = 1;      // cpc_set_gemm_split: 0 keeps every plain GEMM on three bf16 pieces, bounds or not
+
+int absmax_slots(const float* const* x, const long* n, int njobs, float* out, hipStream_t st) {
+    if (njobs <= 0 || njobs > 4) return CPC_ERR_ARG;
+    AbsmaxJobs jobs;
+    for (int j = 0; j < 4; ++j) { jobs.x[j] = x[j < njobs ? j : 0]; jobs.n[j] = n[j < njobs ? j : 0]; }
+    hipLaunchKernelGGL(absmax_slots_kernel, dim3(kAmaxSlots, njobs), dim3(1024), 0, st, jobs, out);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
 int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc,
-            int N, int K, hipStream_t st, int c_R, long c_bstride) {
+            int N, int K, hipStream_t st, int c_R, long c_bstride, GemmBounds bounds) {
     if (am.M <= 0) return 0;
     if (N % 128 != 0 || K % 16 != 0 || K < 16) return CPC_ERR_SHAPE;
     const bool big = (long)cdiv(am.M, 128) * (N / 128) >= 384;
-    const bool x3 = g_mfma_mode != 0 && K % 32 == 0;      // mode 2 (fp16 split) covers the conv layers only
+    const bool x3 = g_mfma_mode != 0 && K % 32 == 0;
+    const bool h2 = x3 && g_mfma_mode >= 2 && g_gemm_split && bounds.a && bounds.b;      // operand bounds known: fp16 split
     const dim3 gb(cdiv(am.M, 128), N / 128), gs(cdiv(am.M, 64), N / 64);
-    if (big && x3)
+    if (big && h2)
+        hipLaunchKernelGGL((nt_gemm_kernel<NtBigH2, 128, true>), gb, dim3(NtBigH2::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
+                           ldc, K, c_R, c_bstride, bounds);
+    else if (h2)
+        hipLaunchKernelGGL((nt_gemm_kernel<NtSmallH2, 64, true>), gs, dim3(NtSmallH2::NTHREADS), 0, st, am, Bmat, ldb, bias,
+                           C, ldc, K, c_R, c_bstride, bounds);
+    else if (big && x3)
         hipLaunchKernelGGL((nt_gemm_kernel<NtBigX3, 128>), gb, dim3(NtBigX3::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
-                           ldc, K, c_R, c_bstride);
+                           ldc, K, c_R, c_bstride, bounds);
     else if (big)
         hipLaunchKernelGGL((nt_gemm_kernel<NtBig, 128>), gb, dim3(NtBig::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
-                           ldc, K, c_R, c_bstride);
+                           ldc, K, c_R, c_bstride, bounds);
     else if (x3)
         hipLaunchKernelGGL((nt_gemm_kernel<NtSmallX3, 64>), gs, dim3(NtSmallX3::NTHREADS), 0, st, am, Bmat, ldb, bias,
-                           C, ldc, K, c_R, c_bstride);
+                           C, ldc, K, c_R, c_bstride, bounds);
     else
-        hipLaunchKernelGGL((nt_gemm_kernel<NtSmall, 64>), gs, dim3(NtSmall::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
-                           ldc, K, c_R, c_bstride);
+        hipLaunchKernelGGL((nt_gemm_kernel<NtSmall, 64>), gs, dim3(NtSmall::NTHREADS), 0, st, am, Bmat, ldb, bias,
+                           C, ldc, K, c_R, c_bstride, bounds);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -203,7 +286,7 @@ void tn_gemm_plan(int M, int N1, int N2, int* splits, int* rows) {
 }
 
 int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, float* C, int accumulate,
-            hipStream_t st) {
+            hipStream_t st, GemmBounds bounds) {
     if (N1 % 128 != 0 || N2 % 128 != 0 || am.M != bm.M) return CPC_ERR_SHAPE;
     const long n = (long)N1 * N2;
     if (am.M <= 0) {
@@ -213,10 +296,12 @@ int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, flo
     int S, rows;
     tn_gemm_plan(am.M, N1, N2, &S, &rows);
     const dim3 grid(8 * (N1 / 128) * (N2 / 128) * cdiv(S, 8));
-    if (g_mfma_mode != 0)
-        hipLaunchKernelGGL((tn_gemm_kernel<TnGX3>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n);
+    if (g_mfma_mode >= 2 && g_gemm_split && bounds.a && bounds.b)
+        hipLaunchKernelGGL((tn_gemm_kernel<TnGH2, true>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n, bounds);
+    else if (g_mfma_mode != 0)
+        hipLaunchKernelGGL((tn_gemm_kernel<TnGX3>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n, bounds);
     else
-        hipLaunchKernelGGL((tn_gemm_kernel<TnG>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n);
+        hipLaunchKernelGGL((tn_gemm_kernel<TnG>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n, bounds);
     hipLaunchKernelGGL(split_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, S, n, C, accumulate);
     CPC_LAUNCH_CHECK();
     return 0;
@@ -296,4 +381,11 @@ extern "C" int cpc_gemm_tn(const float* A, int lda, const float* B, int ldb, flo
     CPC_RETURN_IF(!A || !B || !C || !part, CPC_ERR_ARG);
     return tn_gemm(plain_rows(A, M, lda), N1, plain_rows(B, M, ldb), N2, part, C, accumulate,
                    (hipStream_t)stream);
+}
+
+// 1 (default): plain GEMMs whose operand bounds are known run on two fp16 pieces in cpc_set_mfma_mode >= 2; 0: three bf16
+// pieces always (A/B measurements, numerical comparisons)
+extern "C" int cpc_set_gemm_split(int on) {
+    cpc::g_gemm_split = on ? 1 : 0;
+    return 0;
 }

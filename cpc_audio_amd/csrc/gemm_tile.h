@@ -307,6 +307,15 @@ __device__ __forceinline__ float scale_for_amax(float amax) {
     return ldexpf(1.0f, e);                            // operand with amax < 2^-46 is scaled as far as that allows
 }
 
+// A bound kept as `slots` partial maxima (<= 64; written by different workgroups so that no single address takes
+// thousands of atomics, or by a reduction kernel with one workgroup per slot): every wave folds them itself.
+constexpr int kAmaxSlots = 64;
+__device__ __forceinline__ float fold_amax(const float* __restrict__ p, int slots) {
+    if (slots <= 1) return *p;
+    const int lane = threadIdx.x & 63;
+    return wave_max(lane < slots ? p[lane] : 0.f);
+}
+
 // (O,I,W) conv weight -> K-tile-major H2 rows for the DMA kernels (conv_dma.hip): element (co, kg = kk*C + ci) of
 // w * scale_for_amax(amax) goes to row (kg / 32) * 256 + co, a 128-byte row of four 8-element groups [h x 8 | l x 8].
 __device__ __forceinline__ void permute_w_h2_elem(const float* __restrict__ w, unsigned char* __restrict__ wq, int k,

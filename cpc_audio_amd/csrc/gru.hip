@@ -185,6 +185,8 @@ struct Gru2Fwd {
     float* xh[2];              // persistent launch only: hand-over copies of y[l] (see xtile)
     int B, S;
     int spin_limit;            // persistent launch only: polling budget of a wave (cpc_set_gru_spin_limit)
+    int ntiles, xcd_pack;      // persistent launch only: see PersistIds
+    int first_sleep;           // persistent launch only: see PollPace (< 0: self-steering)
 };
 
 __device__ __forceinline__ void mfma_slice(f32x4 (&acc)[3], const float* __restrict__ arow, bool ok,
@@ -304,6 +306,8 @@ struct Gru2Bwd {
     float* xdh[2];             // persistent launch only: hand-over copies of DH[l] (fragment order)
     int B, S;
     int spin_limit;            // persistent launch only: polling budget of a wave (cpc_set_gru_spin_limit)
+    int ntiles, xcd_pack;      // persistent launch only: see PersistIds
+    int first_sleep;           // persistent launch only: see PollPace (< 0: self-steering)
 };
 
 // Everything in the gate derivatives that does not depend on dh, for all (b, t, j) at once and in fragment
@@ -478,23 +482,49 @@ __device__ __forceinline__ void store_coherent(float* p, float v) {
 
 // Fetch NII float4 fragments (k += 16 apart) of this lane's row, re-reading until every lane of the wave
 // has complete data.  Lanes whose row is outside the batch contribute zeros.
+// Pacing.  Every look is a device-scope load that travels to L2 and back whatever it finds, and sixteen workgroups per XCD
+// looking flat out slow one another's hand-over down (measured at B = 64: forward 0.41 -> 0.28 ms, backward 0.77 -> 0.67 ms
+// once the looks that cannot succeed are left out).  The data cannot be there before the producers' gate math is done, so a
+// wave first sleeps `delay` x 64 clocks.  The right delay depends on the kernel, the batch and on what else runs on the
+// chip, so each wave steers its own (PollPace): a look that had to be repeated came too early (delay += 4), four first-time
+// hits in a row may have come late (delay -= 1); the steady state is about one repeated look in twenty steps.
+// fixed >= 0 pins the delay instead (cpc_set_gru_poll_pacing).
+struct PollPace {
+    int delay, streak, fixed;
+    __device__ explicit PollPace(int fixed_) : delay(fixed_ > 0 ? fixed_ : 0), streak(0), fixed(fixed_) {}
+    __device__ __forceinline__ void update(int repeats) {     // wave-uniform
+        if (fixed >= 0) return;
+        if (repeats == 0) {
+            if (++streak >= 4) { streak = 0; delay = delay > 0 ? delay - 1 : 0; }
+        } else {
+            streak = 0;
+            delay = delay + 4 < 96 ? delay + 4 : 96;
+        }
+    }
+};
+
 template <int NII>
-__device__ __forceinline__ void poll_row(const float* __restrict__ row, bool ok, float4 (&a)[NII], int& budget) {
+__device__ __forceinline__ void poll_row(const float* __restrict__ row, bool ok, float4 (&a)[NII], int& budget,
+                                         PollPace& pace) {
+    for (int q = 0; q < pace.delay; ++q) __builtin_amdgcn_s_sleep(1);
     // Unconditional loads (a predicated load costs a branch and a full vmcnt(0) each): rows past the batch
     // are inside the buffer, never written, and masked out below.
 #pragma unroll
     for (int ii = 0; ii < NII; ++ii) a[ii] = load4_coherent(row + kXStride * ii);
+    int repeats = 0;
     for (;;) {
         bool rdy = true;
 #pragma unroll
         for (int ii = 0; ii < NII; ++ii) rdy = rdy && ready4(a[ii]);
         if (__all(rdy || !ok) || budget <= 0) break;
         --budget;
+        ++repeats;
         __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int ii = 0; ii < NII; ++ii)                          // re-read only what was incomplete
             if (ok && !ready4(a[ii])) a[ii] = load4_coherent(row + kXStride * ii);
     }
+    pace.update(repeats);
     if (budget <= 0) atomicOr(&g_gru_poll_timeout, 1u);
     if (!ok) {
 #pragma unroll
@@ -578,11 +608,24 @@ __device__ __forceinline__ void mfma_gates_h2(f32x4 (&acc)[3], const float4 (&a)
 
 struct PersistIds {
     int layer, j0, b0, tile, ntiles;
-    __device__ PersistIds() {
-        const int G = gridDim.x / 32;               // batch tiles; ids of one tile are G apart
-        const int rest = blockIdx.x / G;
+    bool valid;
+    // G batch tiles of 32 workgroups each (2 layers x 16 unit tiles).  pack: workgroup b is dispatched to XCD b % 8, so the
+    // grid is 256 * ceil(G / 8) and tile (slot / 32) * 8 + xcd takes the 32 slots of its XCD -- every hand-over of a tile
+    // then stays inside one L2 instead of crossing the fabric (surplus workgroups exit at once; at B = 64 four XCDs
+    // run the recurrence and four are left to the side-stream kernels).  Otherwise (default, faster): grid = 32 G, ids of one
+    // tile G apart.
+    __device__ PersistIds(int G, int pack) {
+        int rest;
+        if (pack) {
+            const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+            tile = (slot >> 5) * 8 + xcd;
+            rest = slot & 31;
+        } else {
+            tile = blockIdx.x % G;
+            rest = blockIdx.x / G;
+        }
         ntiles = G;
-        tile = blockIdx.x % G;
+        valid = tile < G;
         b0 = tile * 16;
         layer = rest >> 4;
         j0 = (rest & 15) * 16;
@@ -619,14 +662,15 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
         }
         const float* __restrict__ xsrc = (recurrent ? p.xh[LAYER] : p.xh[0]) + xpos(i, koff);
         int budget = p.spin_limit;
+        PollPace pace(p.first_sleep);
         for (int t = 0; t < S; ++t) {
             float4 a[NII];
             if (recurrent) {
                 if (t == 0) load_row_plain<NII>(p.h0[LAYER] ? p.h0[LAYER] + (long)(b0 + i) * kH + koff : nullptr,
                                                 bok && p.h0[LAYER] != nullptr, a);
-                else poll_row<NII>(xsrc + xtile(t - 1, id.tile, id.ntiles, kH), bok, a, budget);
+                else poll_row<NII>(xsrc + xtile(t - 1, id.tile, id.ntiles, kH), bok, a, budget, pace);
             } else {
-                poll_row<NII>(xsrc + xtile(t, id.tile, id.ntiles, kH), bok, a, budget);
+                poll_row<NII>(xsrc + xtile(t, id.tile, id.ntiles, kH), bok, a, budget, pace);
             }
             f32x4 acc[3];
 #pragma unroll
@@ -706,14 +750,16 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
 // grid = 32 * ceil(B/16) workgroups (1-D), 768 threads; xh[0] and xh[1] pre-filled with 0xFF bytes
 __global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_kernel(Gru2Fwd p) {
     __shared__ float part[2][8][3][256];
-    const PersistIds id;
+    const PersistIds id(p.ntiles, p.xcd_pack);
+    if (!id.valid) return;
     if (id.layer == 0) persist_fwd<0, false>(p, part, id);
     else persist_fwd<1, false>(p, part, id);
 }
 // the same with the recurrent products on the fp16 pipe (two-piece split operands); h0 must be absent (|h| < 1)
 __global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_h2_kernel(Gru2Fwd p) {
     __shared__ float part[2][8][3][256];
-    const PersistIds id;
+    const PersistIds id(p.ntiles, p.xcd_pack);
+    if (!id.valid) return;
     if (id.layer == 0) persist_fwd<0, true>(p, part, id);
     else persist_fwd<1, true>(p, part, id);
 }
@@ -767,12 +813,13 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
         float4 cf[NU][3];
         if (!recurrent) load_coef<NU>(cf, c0, c1, c2, xtile(S - 1, id.tile, id.ntiles, kH) + lane_off);
         int budget = p.spin_limit;
+        PollPace pace(p.first_sleep);
         for (int t = S - 1; t >= 0; --t) {
             const int ts = recurrent ? t + 1 : t;                 // step whose gate gradients are this wave's operand
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             if (ts < S) {
                 float4 dh[NU];
-                poll_row<NU>(xsrc + xtile(ts, id.tile, id.ntiles, kH), bok, dh, budget);
+                poll_row<NU>(xsrc + xtile(ts, id.tile, id.ntiles, kH), bok, dh, budget, pace);
                 f32x4 ag[3];
 #pragma unroll
                 for (int g = 0; g < 3; ++g) ag[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -840,7 +887,8 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
 // grid / block as the forward; xdh[0] and xdh[1] pre-filled with 0xFF bytes
 __global__ __launch_bounds__(kPersistThreads) void gru2_persist_bwd_kernel(Gru2Bwd p) {
     __shared__ float part[2][8][256];
-    const PersistIds id;
+    const PersistIds id(p.ntiles, p.xcd_pack);
+    if (!id.valid) return;
     if (id.layer == 0) persist_bwd<1>(p, part, id);               // the top layer leads
     else persist_bwd<0>(p, part, id);
 }
@@ -902,18 +950,33 @@ using namespace cpc;
 
 namespace {
 int g_gru_spin_limit = kSpinLimit;
+int g_gru_first_sleep[2] = {-1, -1};   // forward, backward (cpc_set_gru_poll_pacing); < 0: self-steering
+int g_gru_xcd_pack = 0;    // persistent launches: 0 (default) = tiles interleaved over the XCDs, 1 = one batch tile per XCD where the
+                           // device has 8 (PersistIds; measured slower: B = 64 forward +42 us, backward +70 us -- what a tile gains
+                           // in hand-over distance it loses to 32 instead of 16 polling workgroups on its L2), 2 = packed numbering
+                           // forced (tests on the emulator)
 int g_gru_mode = 2;        // 0: per-step launches; 1: persistent two-layer recurrence when the grid fits the device, exact-f32
                            // MFMAs; 2 (default): the same with the forward's recurrent products on the fp16 pipe (two-piece
                            // split, 3 MFMAs per product; exact-f32 when the caller supplies h0, whose size is unknown)
 
-// true if `nblocks` workgroups of `kernel` (kPersistThreads each) can all be resident at the same time
+// Grid of a persistent launch over G batch tiles (PersistIds), or 0 if its 32 G working workgroups (kPersistThreads each)
+// cannot all be resident at once.  *pack: one tile per XCD -- when asked for (g_gru_xcd_pack 1) and the device is 8 XCDs of
+// cus / 8 CUs each with room for 32 * ceil(G / 8) workgroups per XCD; g_gru_xcd_pack == 2 forces the packed numbering on any
+// device whose dispatcher hands out workgroups in id order as slots free up (the emulator; surplus ids exit at once).
 template <class K>
-bool fits_resident(K kernel, int nblocks) {
+int persist_grid(K kernel, int G, int* pack) {
     int dev = 0, cus = 0, occ = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kPersistThreads, 0) != hipSuccess) return false;
-    return (long)nblocks <= (long)cus * occ;
+    *pack = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kPersistThreads, 0) != hipSuccess) return 0;
+    const long room = (long)cus * occ;
+    if (32L * G > room) return 0;
+    if (g_gru_xcd_pack == 2 || (g_gru_xcd_pack == 1 && cus % 8 == 0 && 32L * cdiv(G, 8) <= (long)(cus / 8) * occ)) {
+        *pack = 1;
+        return 256 * cdiv(G, 8);
+    }
+    return 32 * G;
 }
 }  // namespace
 
@@ -936,6 +999,21 @@ int gru_error_flag_fetch(int clear, unsigned* out) {
 // beyond any co-scheduled side-stream kernel of the train step).  Tests use 0 to drive the error path.
 extern "C" int cpc_set_gru_spin_limit(int limit) {
     g_gru_spin_limit = limit < 0 ? kSpinLimit : limit;
+    return 0;
+}
+
+// Wait before a step's first look at the hand-over buffers in the persistent recurrence (forward / backward kernel), in units
+// of 64 clocks; < 0 (default): every wave steers its own (PollPace).
+extern "C" int cpc_set_gru_poll_pacing(int first_fwd, int first_bwd) {
+    if (first_fwd > 200 || first_bwd > 200) return CPC_ERR_ARG;
+    g_gru_first_sleep[0] = first_fwd < 0 ? -1 : first_fwd;
+    g_gru_first_sleep[1] = first_bwd < 0 ? -1 : first_bwd;
+    return 0;
+}
+
+extern "C" int cpc_set_gru_xcd_pack(int on) {
+    if (on < 0 || on > 2) return CPC_ERR_ARG;
+    g_gru_xcd_pack = on;
     return 0;
 }
 
@@ -977,11 +1055,13 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
         p.wih1 = params[4]; p.bih1 = params[6];
         p.y[0] = saved + g.Y[0]; p.y[1] = y;
         p.hN = hN; p.B = B; p.S = S; p.spin_limit = g_gru_spin_limit;
+        p.first_sleep = g_gru_first_sleep[0];
         p.xh[0] = p.xh[1] = nullptr;
-        const int nblocks = 32 * cdiv(B, 16);
+        p.ntiles = cdiv(B, 16);
         const bool h2 = g_gru_mode == 2 && !h0;
-        if (g_gru_mode >= 1 && (h2 ? fits_resident(gru2_persist_fwd_h2_kernel, nblocks)
-                                   : fits_resident(gru2_persist_fwd_kernel, nblocks))) {
+        const int nblocks = g_gru_mode < 1 ? 0 : h2 ? persist_grid(gru2_persist_fwd_h2_kernel, p.ntiles, &p.xcd_pack)
+                                                    : persist_grid(gru2_persist_fwd_kernel, p.ntiles, &p.xcd_pack);
+        if (nblocks > 0) {
             p.xh[0] = scratch + g.xh; p.xh[1] = scratch + g.xh + g.xh_floats;
             if (hipMemsetAsync(p.xh[0], 0xFF, 2 * g.xh_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
             if (h2) hipLaunchKernelGGL(gru2_persist_fwd_h2_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
@@ -1091,6 +1171,7 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
         float* DH_[2] = {scratch + g.DH, scratch + g.DH2};
         Gru2Bwd p;
         p.dy = dy; p.B = B; p.S = S; p.spin_limit = g_gru_spin_limit;
+        p.first_sleep = g_gru_first_sleep[1];
         const float* yl[2] = {saved + g.Y[0], y};
         const float* h0l[2] = {h0, h0 ? h0 + (long)B * kH : nullptr};
         int rc = 0;
@@ -1110,8 +1191,9 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
         }
         if (!coef) launch_gru_coef(g, h0, saved, y, scratch + g.coef, B, S, st);
         p.wih1T = wihT_[1];
-        const int nblocks = 32 * cdiv(B, 16);
-        if (g_gru_mode >= 1 && fits_resident(gru2_persist_bwd_kernel, nblocks)) {
+        p.ntiles = cdiv(B, 16);
+        const int nblocks = g_gru_mode < 1 ? 0 : persist_grid(gru2_persist_bwd_kernel, p.ntiles, &p.xcd_pack);
+        if (nblocks > 0) {
             if (!coef && hipMemsetAsync(p.xdh[0], 0xFF, 2 * g.frag_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
             hipLaunchKernelGGL(gru2_persist_bwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
         } else {

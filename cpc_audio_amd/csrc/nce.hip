@@ -126,21 +126,31 @@ __global__ __launch_bounds__(64) void nce_finalize_kernel(const float* __restric
 }
 
 // gscale[k] = dL/dloss_k / (B*W) / C
+// fwd_bounds (linear heads; NULL otherwise): the forward's max|c|, max|wall| slots.  Then also gscale[17] = max|c|,
+// gscale[18] = max|wall| (operand bounds of the backward GEMMs, GemmBounds) and the 64 max|dPred| slots at gscale[64..127]
+// are cleared for nce_bwd_dpred_kernel.  (An a-priori bound -- |dPred| <= 2 max|gscale| max|z| -- needs no slots but is far
+// too loose once the softmax is confident: operands 2^-20 of their bound lose the low fp16 piece.)
 __global__ __launch_bounds__(64) void nce_gscale_kernel(const float* __restrict__ gloss, float* __restrict__ gscale,
-                                                        int K, float f) {
+                                                        int K, float f, const float* __restrict__ fwd_bounds) {
     const int k = threadIdx.x;
     if (k < K) gscale[k] = gloss[k] * f;
+    if (fwd_bounds != nullptr) {
+        const float cm = wave_max(fwd_bounds[k]), wm = wave_max(fwd_bounds[kAmaxSlots + k]);
+        if (k == 0) { gscale[17] = cm; gscale[18] = wm; }
+        gscale[64 + k] = 0.f;
+    }
 }
 
 // ------------------------------------------------------------------ backward: dPred
 __global__ __launch_bounds__(256) void nce_bwd_dpred_kernel(
     const float* __restrict__ z, const int* __restrict__ ext, const float* __restrict__ logits,
     const float* __restrict__ lse, const float* __restrict__ gscale, float* __restrict__ dpred, int BW,
-    int W, int S, int K, int N) {
+    int W, int S, int K, int N, float* __restrict__ amax_slots) {
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bt >= BW) return;
     const int b = bt / W, t = bt - b * W;
+    float amax = 0.f;
     const int i = lane & 15, kq = lane >> 4;
     const bool hv = i < K;
     const float gs = hv ? gscale[i] : 0.f;
@@ -182,8 +192,13 @@ __global__ __launch_bounds__(256) void nce_bwd_dpred_kernel(
                 o.z = fmaf(d0, zv.z, acc[u * 4 + 2][r]);
                 o.w = fmaf(d0, zv.w, acc[u * 4 + 3][r]);
                 *reinterpret_cast<float4*>(op + 64 * u) = o;
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             }
         }
+    }
+    if (amax_slots != nullptr) {             // max|dPred| for the GEMMs that read it: one atomic per wave, 64 addresses
+        amax = wave_max(amax);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(amax_slots + (bt & (kAmaxSlots - 1))), __float_as_uint(amax));
     }
 }
 
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(256) void nce_fill_kernel(const int* __restrict__ d
 // ------------------------------------------------------------------ host side
 struct NceLayout {
     int W, BW;
-    long pred, logits, lse, saved_total;
+    long pred, logits, lse, bounds, saved_total;
     long rowstat, tmp, sums, fwd_total;
     long dpred, wallT, part, gscale, V, bwd_total;
 };
@@ -403,6 +418,7 @@ static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     n.pred = o; o += align64l((long)n.BW * K * kC);
     n.logits = o; o += align64l((long)n.BW * K * (N + 1));
     n.lse = o; o += align64l((long)n.BW * K);
+    n.bounds = o; o += 2 * kAmaxSlots;       // max|c|, max|wall| as 64 partial maxima each (linear heads only)
     n.saved_total = o;
     o = 0;
     n.rowstat = o; o += align64l((long)n.BW * 2 * K);
@@ -413,7 +429,7 @@ static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     n.dpred = o; o += align64l((long)n.BW * K * kC);
     n.wallT = o; o += (long)kC * K * kC;
     n.part = o; o += align64l(tn_gemm_part_floats(n.BW, K * kC, kC));
-    n.gscale = o; o += 64;
+    n.gscale = o; o += 128;                  // [0..15] gscale, [17..18] bounds, [32..47] the dz path's copy, [64..127] max|dPred| slots
     n.V = o; o += align64l((long)n.BW * (N + K) * kC);
     n.bwd_total = o;
     return true;
@@ -446,7 +462,8 @@ static int nce_dz_path(const NceLayout& n, const float* pred, const float* saved
                        hipStream_t st, bool own_gscale) {
     const float* logits = saved + n.logits, *lse = saved + n.lse;
     if (own_gscale)
-        hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale_dz, K, 1.0f / ((float)n.BW * (float)kC));
+        hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale_dz, K, 1.0f / ((float)n.BW * (float)kC),
+                           (const float*)nullptr);
     hipLaunchKernelGGL(nce_bwd_dz_rows_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, logits, lse, gscale_dz,
                        scratch + n.V, n.BW, K, N);
     hipLaunchKernelGGL(nce_gather_rows_kernel, dim3(B * S), dim3(64), 0, st, scratch + n.V, perm, row_ptr, dz, B * S);
@@ -461,15 +478,15 @@ static int nce_dz_path(const NceLayout& n, const float* pred, const float* saved
 static int nce_scores_backward(const NceLayout& n, const float* pred, const float* z, const int* ext, const int* perm,
                                const int* row_ptr, const float* saved, const float* gloss, float* scratch,
                                float* dpred, float* dz, int B, int S, int K, int N, hipStream_t st, hipStream_t st_dz,
-                               bool do_dz = true) {
+                               bool do_dz = true, const float* fwd_bounds = nullptr) {
     const float* logits = saved + n.logits, *lse = saved + n.lse;
     float* gscale = scratch + n.gscale;
     float* gscale_dz = st_dz == st ? gscale : gscale + 32;        // own copy: no cross-stream dependency
     const float gs = 1.0f / ((float)n.BW * (float)kC);
-    hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale, K, gs);
+    hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale, K, gs, fwd_bounds);
     const dim3 grid(cdiv(n.BW, 4));
     hipLaunchKernelGGL(nce_bwd_dpred_kernel, grid, dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
-                       n.W, S, K, N);
+                       n.W, S, K, N, fwd_bounds ? gscale + 64 : (float*)nullptr);
     CPC_LAUNCH_CHECK();
     if (!do_dz) return 0;                                          // dz path launched separately (cpc_nce_backward_dz)
     return nce_dz_path(n, pred, saved, gloss, perm, row_ptr, scratch, gscale_dz, dz, B, S, K, N, st_dz, st_dz != st);
@@ -532,7 +549,16 @@ extern "C" int cpc_nce_forward(const float* c, const float* z, const float* wall
     CPC_RETURN_IF(!c || !z || !wall || !ext || !saved || !scratch || !losses || !acc, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     float* pred = saved + n.pred;
-    int rc = nt_gemm(window_rows(c, B, S, n.W), wall, kC, nullptr, pred, (long)K * kC, K * kC, kC, st);
+    // operand bounds for the fp16-split GEMMs of this call and of the backward (one small launch: 11 MB read)
+    // (written in every mode: the backward may run in another one)
+    const float* xs[2] = {c, wall};
+    const long ns[2] = {(long)B * S * kC, (long)K * kC * kC};
+    int rc = absmax_slots(xs, ns, 2, saved + n.bounds, st);
+    if (rc) return rc;
+    GemmBounds gb;
+    gb.a = saved + n.bounds; gb.a_slots = kAmaxSlots;
+    gb.b = saved + n.bounds + kAmaxSlots; gb.b_slots = kAmaxSlots;
+    rc = nt_gemm(window_rows(c, B, S, n.W), wall, kC, nullptr, pred, (long)K * kC, K * kC, kC, st, 0, 0, gb);
     if (rc) return rc;
     return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, st);
 }
@@ -595,18 +621,25 @@ extern "C" int cpc_nce_backward_streams(const float* c, const float* z, const fl
     hipStream_t st = (hipStream_t)stream;
     float* dpred = scratch + n.dpred, *wallT = scratch + n.wallT;
     (void)hipMemsetAsync(dc, 0, sizeof(float) * (size_t)B * S * kC, st);
+    const bool h2 = g_mfma_mode >= 2;        // the forward left the operand bounds in `saved`
     int rc = nce_scores_backward(n, saved + n.pred, z, ext, perm, row_ptr, saved, gloss, scratch, dpred, dz, B, S, K, N, st,
-                                 (hipStream_t)dz_stream, dz != nullptr);
+                                 (hipStream_t)dz_stream, dz != nullptr, h2 ? saved + n.bounds : nullptr);
     if (rc) return rc;
+    const float* bnd = scratch + n.gscale;                        // [17] max|c|, [18] max|wall|, [64..127] max|dPred| slots
+    GemmBounds gdc, gdw;
+    if (h2) {
+        gdc.a = gdw.a = bnd + 64; gdc.a_slots = gdw.a_slots = kAmaxSlots;
+        gdc.b = bnd + 18; gdw.b = bnd + 17;
+    }
     // dc[:, :W] = dPred . Wall  (NT against Wall^T [256][K*256])
     rc = transpose(wall, wallT, K * kC, kC, st);
     if (rc) return rc;
     rc = nt_gemm(plain_rows(dpred, n.BW, K * kC), wallT, K * kC, nullptr, dc, kC, kC, K * kC, st, n.W,
-                 (long)S * kC);
+                 (long)S * kC, gdc);
     if (rc || !dwall) return rc;
     // dW_k = dPred_k^T . c[:, :W]
     return tn_gemm(plain_rows(dpred, n.BW, K * kC), K * kC, window_rows(c, B, S, n.W), kC, scratch + n.part,
-                   dwall, 0, st);
+                   dwall, 0, st, gdw);
 }
 
 // The head-weight gradient alone, from the dPred that cpc_nce_backward_streams(dwall = NULL) left in `scratch`:
@@ -616,6 +649,8 @@ extern "C" int cpc_nce_backward_dwall(const float* c, float* scratch, float* dwa
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!c || !scratch || !dwall, CPC_ERR_ARG);
+    GemmBounds gdw;                                               // left by cpc_nce_backward_streams (nce_gscale_kernel)
+    if (g_mfma_mode >= 2) { gdw.a = scratch + n.gscale + 64; gdw.a_slots = kAmaxSlots; gdw.b = scratch + n.gscale + 17; }
     return tn_gemm(plain_rows(scratch + n.dpred, n.BW, K * kC), K * kC, window_rows(c, B, S, n.W), kC,
-                   scratch + n.part, dwall, 0, (hipStream_t)stream);
+                   scratch + n.part, dwall, 0, (hipStream_t)stream, gdw);
 }

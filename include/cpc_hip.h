@@ -87,6 +87,8 @@ int cpc_conv_gemm_forward_h2(const void* x_h2, const float* wq, const float* bia
  * rotation step between neighbouring workgroups (0: lockstep) */
 int cpc_set_dma_tile(int bm);
 int cpc_set_h2_layers(int n);            /* mode 3: 1 = only conv1, 2 = conv1 and conv2 read H2 input; 0 = by problem size */
+int cpc_set_gemm_split(int on);          /* 1 (default): plain GEMMs with known operand bounds (the criterion's, see cpc_nce_forward) run on two
+                                            fp16 pieces in mode >= 2; 0: three bf16 pieces always */
 int cpc_set_dma_rotation(int step);
 int cpc_set_dma_pipeline(int variant);   /* 0 (default): four 16-k LDS stages, three in flight; 1: two 32-k stages */
 long cpc_conv0_backward_scratch_floats(int B, int L);
@@ -138,6 +140,15 @@ int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part, float* dW
  * recurrent products on the fp16 matrix pipe (operands split into two fp16 pieces, three MFMAs per product, fp32
  * accumulate: differences at the 1e-7 level; exact-f32 products whenever the caller supplies h0). */
 int cpc_set_gru_mode(int mode);
+/* Persistent recurrence: 1 places the 32 workgroups of each 16-sequence batch tile on one XCD (grid of 256 * ceil(tiles / 8)
+ * workgroups, workgroup b on XCD b % 8), so that the step-to-step hand-over stays inside one L2; 0 (default, measured
+ * faster) interleaves the tiles over the XCDs (grid of 32 * tiles); 2 forces the packed numbering whatever the device
+ * reports (tests). */
+int cpc_set_gru_xcd_pack(int on);
+/* Persistent recurrence: the wait before a step's first look at the hand-over buffers (forward / backward kernel), in
+ * units of 64 clocks; < 0 (default): every wave steers its own so that looks that cannot succeed yet are not issued
+ * (they load the L2s the hand-over itself goes through). */
+int cpc_set_gru_poll_pacing(int first_fwd, int first_bwd);
 /* Polling budget of one wave of the persistent recurrence (re-reads over the whole launch) before it gives up and
  * flags CPC_DEVERR_GRU_POLL_TIMEOUT; limit < 0 restores the default (2^20).  Tests use 0 to drive the error path. */
 int cpc_set_gru_spin_limit(int limit);

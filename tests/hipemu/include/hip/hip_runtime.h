@@ -345,6 +345,8 @@ static inline float __fdividef(float a, float b) { return a / b; }
 static inline unsigned __float_as_uint(float x) { return hipemu::bits(x); }
 static inline float __uint_as_float(unsigned u) { return hipemu::unbits<float>(u); }
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_update_dpp hipemu::update_dpp
 #define __builtin_amdgcn_readlane hipemu::readlane
 // ---- inter-workgroup exchange support (persistent kernels): agent-scope atomics are host atomics,

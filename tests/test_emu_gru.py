@@ -126,6 +126,22 @@ def test_gru_fp16_split_forward_emulated(B, S):
     assert torch.equal(a[0], b[0])
 
 
+def test_persistent_recurrence_with_one_batch_tile_per_xcd_emulated():
+    """cpc_set_gru_xcd_pack: the packed workgroup numbering (grid of 256 * ceil(tiles / 8), tile (slot / 32) * 8 + id % 8,
+    surplus workgroups exit) computes exactly what the interleaved numbering computes; 2 forces it on the emulator, which
+    has no XCDs to report.  B = 20: two batch tiles, the second one ragged."""
+    lib = emu()
+    outs = []
+    for pack in (0, 2):
+        assert lib.cpc_set_gru_xcd_pack(pack) == 0
+        try:
+            outs.append(_run_gru(lib, 20, 5, 2, False))
+        finally:
+            lib.cpc_set_gru_xcd_pack(0)
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    assert lib.cpc_set_gru_xcd_pack(3) != 0
+
+
 def test_gru_backward_with_early_coefficients_emulated():
     """cpc_gru_backward_coef (forward-only part + pre-filled hand-over buffers, run ahead of time by the overlapped train
     loops) + cpc_gru_backward_with_coef / _streams give bit-identical results to the one-call backward."""

@@ -4,7 +4,7 @@ alternates two settings of a module-level switch over several rounds and prints 
     python tools/ab_step.py "ops.PIN_NEGATIVES" False True [--rounds 6 --steps 20]
 
 The first argument is an attribute path inside cpc_audio_amd (ops.X, criterion.X ...) or ENV:NAME for an
-environment variable read at call time, or CALL:cpc_set_xxx for a one-int setter of the C ABI; the two values are Python literals."""
+environment variable read at call time, or CALL:cpc_set_xxx for a setter of the C ABI (an int, or a tuple of ints for several arguments); the two values are Python literals."""
 import ast
 import importlib
 import os
@@ -28,7 +28,7 @@ def main():
         elif target.startswith("CALL:"):                  # a setter of the C ABI, e.g. CALL:cpc_set_conv_tile
             from cpc_audio_amd import _lib
             lib = _lib.get()
-            lib.check(getattr(lib, target[5:])(v), target)
+            lib.check(getattr(lib, target[5:])(*(v if isinstance(v, tuple) else (v,))), target)
         else:
             mod, attr = target.rsplit(".", 1)
             setattr(importlib.import_module("cpc_audio_amd." + mod), attr, v)

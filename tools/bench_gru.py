@@ -61,8 +61,10 @@ def main():
 
     out = {"B": B, "S": S}
     ref = None
-    for mode in (0, 1):
+    for mode, pack in ((0, 1), (1, 1), (2, 1), (2, 0), (1, 0)):
         lib.check(lib.cpc_set_gru_mode(mode))
+        lib.check(lib.cpc_set_gru_xcd_pack(pack))
+        mode = f"{mode}_pack{pack}"
         out[f"fwd_ms_mode{mode}"] = round(timeit(fwd), 4)
         out[f"bwd_ms_mode{mode}"] = round(timeit(bwd), 4)
         cur = [y.clone(), dx.clone()] + [g.clone() for g in grads]
@@ -72,6 +74,7 @@ def main():
             out["bit_identical"] = all(torch.equal(a, b) for a, b in zip(ref, cur))
             out["finite"] = all(bool(torch.isfinite(a).all()) for a in cur)
     lib.cpc_set_gru_mode(_lib_default_gru_mode())
+    lib.cpc_set_gru_xcd_pack(0)
     print(json.dumps(out))
 
 
