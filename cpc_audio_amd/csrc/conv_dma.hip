@@ -339,20 +339,26 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd
 // Data gradient of a conv layer (k = 2s) as `s` phase GEMMs with K = 512 (enc_conv.hip, conv_dgrad_kernel): phase r of
 // input step tau = q*s + r - p receives dx[q-1] . W[:,:,r+s] + dx[q] . W[:,:,r], a contiguous 2-row window of the
 // (B, Lout, 256) gradient.  am: those windows (rows q = 0..Lout of every batch item); wd: the phase's weight in K-tile-major
-// rows, phases 256*512*ESZ bytes apart; dprev (B, Lin, 256): gradient w.r.t. the previous layer's output, bf16 (NP = 1).
+// rows, phases 256*512*ESZ bytes apart; dprev (B, Lin, 256): gradient w.r.t. the previous layer's output.
+//   NP = 1: dx, wd and dprev are bf16 (the bf16-storage variant).
+//   NP = 2: dx is H2 storage scaled by scale_for_amax(*dx_bound) (the norm backward that wrote it chose the bound, enc_conv.hip),
+//           wd H2 rows (permute_w_dgrad_h2_elem) with max|w| in *w_amax; dprev is fp32, and amax_out (or NULL) receives
+//           max|dprev| spread over kAmaxSlots addresses (fold_amax).
 template <int BM, int BKE, int NST, int NP>
 __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_dgrad_dma_kernel(
     RowMap am, const unsigned char* __restrict__ wd, int s, int p, int Lin, void* __restrict__ dprev,
-    const unsigned char* __restrict__ zeros, int rot_step) {
+    const unsigned char* __restrict__ zeros, int rot_step, const float* __restrict__ dx_bound,
+    const float* __restrict__ w_amax, float* __restrict__ amax_out) {
     using C = DmaCfg<BM, BKE, NST, NP>;
     constexpr int TM = C::TM, TN = C::TN;
-    static_assert(NP == 1, "the H2 gradient path is not built: its scale is not known when dx is written");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES];
     const int lane = threadIdx.x & 63;
     const int m0 = blockIdx.x * BM, ph = blockIdx.y;
     f32x16 acc[TM][TN];
     dma_gemm<C>(acc, am, m0, wd + (long)ph * (kC * 2 * kC * C::ESZ), 2 * kC, zeros, rot_step, smem);
     const bool odd = lane & 1;
+    float inv = 1.0f, amax = 0.f;
+    if constexpr (NP == 2) inv = 1.0f / (scale_for_amax(*dx_bound) * scale_for_amax(*w_amax));      // powers of two: exact
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -366,12 +372,28 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_dgr
             }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                const unsigned mine = bf16_rne(acc[tm][tn][r]);
-                const unsigned got = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, mine)));
-                if (o >= 0 && !odd)
-                    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(dprev) + o * kC + (dma_c_col(tn) & ~1)) = mine | (got << 16);
+                if constexpr (NP == 2) {
+                    const float v = acc[tm][tn][r] * inv;
+                    if (o >= 0) {
+                        reinterpret_cast<float*>(dprev)[o * kC + dma_c_col(tn)] = v;
+                        amax = fmaxf(amax, fabsf(v));
+                    }
+                } else {
+                    const unsigned mine = bf16_rne(acc[tm][tn][r]);
+                    const unsigned got = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, mine)));
+                    if (o >= 0 && !odd)
+                        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(dprev) + o * kC + (dma_c_col(tn) & ~1)) = mine | (got << 16);
+                }
             }
         }
+    if constexpr (NP == 2) {
+        if (amax_out != nullptr) {
+            amax = wave_max(amax);
+            if (lane == 0)
+                atomicMax(reinterpret_cast<unsigned*>(amax_out + (int)((blockIdx.x + blockIdx.y) % (unsigned)kAmaxSlots)),
+                          __float_as_uint(amax));
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void permute_w_h2_kernel(const float* __restrict__ w, unsigned char* __restrict__ wq,
@@ -481,12 +503,34 @@ int conv_dgrad_dma_bf16(const void* dx, const void* wd, void* dprev, const float
     const unsigned char* zb = reinterpret_cast<const unsigned char*>(zeros);
 #define CPC_LAUNCH_DMA(BM_)                                                                                                    \
     hipLaunchKernelGGL((conv_dgrad_dma_kernel<BM_, 64, 2, 1>), dim3(cdiv(am.M, BM_), s), dim3(DmaCfg<BM_, 64, 2, 1>::NTHREADS), 0, \
-                       st, am, wdb, s, p, Lin, dprev, zb, 0)
+                       st, am, wdb, s, p, Lin, dprev, zb, 0, (const float*)nullptr, (const float*)nullptr, (float*)nullptr)
     switch (bf16_bm((long)am.M * s)) {
         case 256: CPC_LAUNCH_DMA(256); break;
         case 128: CPC_LAUNCH_DMA(128); break;
         default: CPC_LAUNCH_DMA(64); break;
     }
+#undef CPC_LAUNCH_DMA
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// The fp32-accurate data gradient on the DMA kernel: dx (B, Lout, 256) in H2 storage scaled for *dx_bound, wd = s phases of H2
+// weight rows with max|w| behind them (enc_prep_permute_kernel) -> dprev (B, Lin, 256) fp32; amax_out: see the kernel.
+int conv_dgrad_dma_h2(const void* dx_h2, const float* wd, float* dprev, const float* zeros, const float* dx_bound,
+                      float* amax_out, int B, int Lin, int k, int s, int p, hipStream_t st) {
+    if (k != 2 * s) return CPC_ERR_SHAPE;
+    const int Lout = conv_out_len(Lin, k, s, p);
+    RowMap am;                                           // 2-row windows [q-1, q] over dx, q in [0, Lout] (enc_conv.hip)
+    am.base = reinterpret_cast<const float*>(dx_h2); am.R = Lout + 1; am.bstride = (long)Lout * kC; am.rstride = kC; am.off = -kC;
+    am.tmul = 1; am.tadd = -1; am.Lin = Lout; am.M = B * (Lout + 1);
+    const unsigned char* wdb = reinterpret_cast<const unsigned char*>(wd);
+    const float* w_amax = wd + (long)kC * k * kC;
+    const unsigned char* zb = reinterpret_cast<const unsigned char*>(zeros);
+#define CPC_LAUNCH_DMA(BM_)                                                                                                    \
+    hipLaunchKernelGGL((conv_dgrad_dma_kernel<BM_, 32, 2, 2>), dim3(cdiv(am.M, BM_), s), dim3(DmaCfg<BM_, 32, 2, 2>::NTHREADS), 0, \
+                       st, am, wdb, s, p, Lin, (void*)dprev, zb, g_dma_rot, dx_bound, w_amax, amax_out)
+    if ((long)am.M * s >= 256L * 200) CPC_LAUNCH_DMA(256);
+    else CPC_LAUNCH_DMA(128);
 #undef CPC_LAUNCH_DMA
     CPC_LAUNCH_CHECK();
     return 0;

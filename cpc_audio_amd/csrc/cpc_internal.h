@@ -60,6 +60,8 @@ int conv_fwd_dma_bf16(const void* x, const void* wq, const float* bias, const fl
                       void* xhat, float* rstd, const float* zeros, int B, int Lin, int k, int s, int p, hipStream_t st);
 int conv_dgrad_dma_bf16(const void* dx, const void* wd, void* dprev, const float* zeros, int B, int Lin, int k, int s, int p,
                         hipStream_t st);
+int conv_dgrad_dma_h2(const void* dx_h2, const float* wd, float* dprev, const float* zeros, const float* dx_bound,
+                      float* amax_out, int B, int Lin, int k, int s, int p, hipStream_t st);
 int bf16_decode(const void* src, float* dst, long n, hipStream_t st);
 int conv0_forward_bf16(const float* wave, const float* w, const float* bias, const float* nw, const float* nb, void* y,
                        float* mean, float* rstd, int B, int L, hipStream_t st);

@@ -165,6 +165,7 @@ struct PrepArgs {
     int split;
     int fwd_h2[4];          // 1: forward layout of layer y+1 in K-tile-major H2 rows (the DMA kernel's, conv_dma.hip);
                             // 2: forward AND dgrad layouts in K-tile-major bf16 rows (mode 4)
+    int dgrad_h2[4];        // 1: dgrad layout of layer y+1 in K-tile-major H2 rows (conv_dgrad_dma_kernel<.., 2>)
 };
 __global__ __launch_bounds__(256) void enc_prep_amax_kernel(PrepArgs a) {
     const int y = blockIdx.y;
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256) void enc_prep_permute_kernel(PrepArgs a) {
     if (a.split == 2 && idx == 0) dst[total] = amax;          // where the GEMM kernels read max|w|
     if (idx >= total) return;
     if ((seg & 1) && a.fwd_h2[layer] == 2) permute_w_dgrad_bf16_elem(a.w[layer], reinterpret_cast<unsigned short*>(dst), k / 2, idx);
+    else if ((seg & 1) && a.dgrad_h2[layer]) permute_w_dgrad_h2_elem(a.w[layer], reinterpret_cast<unsigned char*>(dst), k / 2, amax, idx);
     else if (seg & 1) permute_w_dgrad_elem(a.w[layer], dst, k / 2, a.split, amax, idx);
     else if (a.fwd_h2[layer] == 2) permute_w_fwd_bf16_elem(a.w[layer], reinterpret_cast<unsigned short*>(dst), k, idx);
     else if (a.fwd_h2[layer]) permute_w_h2_elem(a.w[layer], reinterpret_cast<unsigned char*>(dst), k, amax, idx);
@@ -338,6 +340,14 @@ constexpr int NB_ROWS = 32;   // rows per block (8 per wave)
 // The kernel streams 12-16 bytes per element and is latency-bound per row (two dependent wave reductions), so a wave
 // keeps the loads of four rows in flight and interleaves their reduction chains (0.25 -> ... ms per step for the four layers).
 // DYB / XB: dy / (xhat and the output dx) are bf16 tensors (the bf16-storage variant, mode 4) instead of fp32.
+// DXH2: dx is written in H2 storage (cpc_common.h) for the DMA data-gradient kernel and the weight gradient that read it next.
+// Its scale must be known before the first element is written, so it comes from a bound instead of the measured maximum:
+//   |dx| = rstd |dxh - mean(dxh) - xhat mean'(dxh xhat)| <= rstd max|dxh| (1 + 1 + sqrt(C-1))     (|xhat| <= sqrt(C-1), mean|xhat| <= 1)
+//        <= eps^-1/2 * 17.97 * max|w| * max|dy|
+// with max|dy| measured by the kernel that wrote dy (dy_amax, dy_slots partial maxima).  The bound is loose by the ratio of
+// 316 to the typical rstd and of 18 to ~2, i.e. 2^8..2^11 -- inside the 2^17 that the two-piece storage absorbs without any
+// loss (gemm_tile.h); workgroup 0 leaves it in *dx_bound for the readers.
+constexpr float kNormBwdBound = 316.22777f * 17.968719f;
 constexpr int NBW = 4;        // rows a wave works on at a time
 __device__ __forceinline__ f32x4 load4_as_f32(const float* base, long elem, bool bf16) {
     if (bf16) {
@@ -347,17 +357,25 @@ __device__ __forceinline__ f32x4 load4_as_f32(const float* base, long elem, bool
     }
     return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + elem));       // read once
 }
-template <int MASK, bool DYB = false, bool XB = false>
+template <int MASK, bool DYB = false, bool XB = false, bool DXH2 = false>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ y,
     const float* __restrict__ rstd, const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ dx,
-    float* __restrict__ colpart, int M, float* __restrict__ dx_amax, int amax_slots) {
+    float* __restrict__ colpart, int M, float* __restrict__ dx_amax, int amax_slots,
+    const float* __restrict__ dy_amax = nullptr, int dy_slots = 1, float* __restrict__ dx_bound = nullptr) {
     __shared__ float red[4][3][kC];
     __shared__ float wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = lane * 4;
     const float4 w4 = *reinterpret_cast<const float4*>(nw + c);
     const float gw[4] = {w4.x, w4.y, w4.z, w4.w};
+    float sdx = 1.0f;
+    if constexpr (DXH2) {
+        const float wm = wave_max(fmaxf(fmaxf(fabsf(gw[0]), fabsf(gw[1])), fmaxf(fabsf(gw[2]), fabsf(gw[3]))));
+        const float bound = kNormBwdBound * wm * fold_amax(dy_amax, dy_slots);
+        sdx = scale_for_amax(bound);
+        if (blockIdx.x == 0 && tid == 0) *dx_bound = bound;
+    }
     float gb[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MASK == 2) {
         const float4 b4 = *reinterpret_cast<const float4*>(nb + c);
@@ -425,7 +443,9 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
                 amax = fmaxf(amax, fabsf(v));
             }
             if (live[j]) {
-                if constexpr (XB)
+                if constexpr (DXH2)
+                    h2_store_row_nt(reinterpret_cast<unsigned char*>(dx) + (long)m[j] * (kC * 4), o[0], o[1], o[2], o[3], sdx);
+                else if constexpr (XB)
                     *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dx) + (long)m[j] * kC + c) =
                         make_uint2(bf16_rne(o[0]) | ((unsigned)bf16_rne(o[1]) << 16), bf16_rne(o[2]) | ((unsigned)bf16_rne(o[3]) << 16));
                 else
@@ -513,14 +533,24 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
         }
 
     if (!FUSE) {
+        float amax = 0.f;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (orow[tm][r] >= 0) {
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) dprev[(long)orow[tm][r] * kC + col[tn]] = acc[tm][tn][r];
+                    for (int tn = 0; tn < TN; ++tn) {
+                        dprev[(long)orow[tm][r] * kC + col[tn]] = acc[tm][tn][r];
+                        amax = fmaxf(amax, fabsf(acc[tm][tn][r]));
+                    }
                 }
+        if (prev_amax != nullptr) {          // max|dprev| for a norm backward that writes H2 (norm_bwd_kernel, DXH2)
+            amax = wave_max(amax);
+            if ((threadIdx.x & 63) == 0)
+                atomicMax(reinterpret_cast<unsigned*>(prev_amax + (int)((blockIdx.x + blockIdx.y) % (unsigned)kAmaxSlots)),
+                          __float_as_uint(amax));
+        }
         return;
     }
 
@@ -610,12 +640,14 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
 }
 
 // ------------------------------------------------------------------ wgrad
-// MODE 3: as 2 with the activation operand (x) in H2 storage; MODE 4: both operands are bf16 tensors, one product
+// MODE 3: as 2 with the activation operand (x) in H2 storage; MODE 4: both operands are bf16 tensors, one product;
+// MODE 5: as 3 with dx in H2 storage too (scaled for the bound *dx_amax that the norm backward left, norm_bwd_kernel DXH2)
 template <int MODE>
 struct WgCfg {
     using Tile = typename std::conditional<MODE == 4, TnTileX3<128, 128, 2, 2, 32, 1, 1, false, true>,      // bf16 tensors
+                 typename std::conditional<MODE == 5, TnTileX3<128, 128, 2, 2, 32, 1, 2, true, false, true>,   // dx and x in H2
                  typename std::conditional<MODE != 0, TnTileX3<128, 128, 2, 2, 32, 1, MODE >= 2 ? 2 : 3, MODE == 3>,
-                                           TnTile<128, 128, 2, 2>>::type>::type;
+                                           TnTile<128, 128, 2, 2>>::type>::type>::type;
 };
 // 1-D grid of 8 * T * ceil(S/8) blocks, T = 2*K/128 output tiles; part[z][co][K].
 // XCD-aware mapping: the dispatcher places block b on XCD b % 8 (observed, speed only), and every
@@ -655,7 +687,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
             const int row = c0 + WgTile::c_row(tm, r);
 #pragma unroll
             for (int tn = 0; tn < WgTile::TN; ++tn)
-                out[(long)row * K + n0 + WgTile::c_col(tn)] = (MODE == 2 || MODE == 3) ? acc[tm][tn][r] * inv : acc[tm][tn][r];
+                out[(long)row * K + n0 + WgTile::c_col(tn)] = (MODE == 2 || MODE == 3 || MODE == 5) ? acc[tm][tn][r] * inv : acc[tm][tn][r];
         }
 }
 
@@ -699,6 +731,8 @@ struct EncLayout {
     long bwd_total;
     int wg_splits[5], wg_rows[5];
     bool h2[4];                            // output of layer i kept in H2 storage (cpc_common.h) -- see act_h2 below
+    bool dxh2[5];                          // gradient dx of layer i kept in H2 storage (norm_bwd_kernel DXH2): DMA dgrad, wgrad<5>
+    long dxbound, dyamax;                  // [i] the bound dx_i was scaled for; [i][slot] partial max|dy_i| (dy_i: dgrad output)
     bool bf16;                             // mode 4
 };
 #define act_h2(layer) (e.h2[layer])
@@ -708,6 +742,7 @@ struct EncLayout {
 // its 128-row DMA tiles measured 0.070 ms against 0.067 for the register-staged kernel).  Layers 3 and 4 keep fp32
 // activations and the register-staged kernels, whose 32/64-row tiles fill the chip at their small row counts.
 static int g_dma_bm = 0;     // 0 = by problem size; 128 / 256 = tuning override of the DMA kernel's rows per workgroup
+static int g_h2_dx = 1;      // mode 3: layer 1's gradient dx in H2 storage (DMA data gradient); 0 = fp32 dx, register-staged dgrad
 static int g_h2_layers = 0;  // 0 = by problem size; 1 / 2 = tuning / test override: how many layers (conv1, conv2) read H2 input
 static int g_force_bm = 0;   // 0 = choose by problem size; 32/64/128 = tuning / test override
 static constexpr int g_unfuse_big = 2;   // 2: every dgrad runs unfused + streaming norm backward, 1: only the 128-row tiles,
@@ -730,6 +765,8 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     e.bf16 = g_mfma_mode == 4;             // bf16-storage variant: y0..y3, xhat1..4 and every gradient tensor as bf16
     const int nh2 = g_mfma_mode != 3 ? 0 : (g_h2_layers ? g_h2_layers : ((long)B * e.L[2] >= 256L * 200 ? 2 : 1));
     for (int i = 0; i < 4; ++i) e.h2[i] = i < nh2;
+    // layer 1's gradient in H2 storage: its data gradient (the largest GEMM of the backward) runs on the DMA kernel
+    for (int i = 0; i < 5; ++i) e.dxh2[i] = i == 1 && g_h2_dx && e.h2[0];
     long o = 0;
     for (int i = 0; i < 4; ++i) { e.y[i] = o; o += align64((long)B * e.L[i] * kC); }
     e.xhat[0] = -1;
@@ -781,6 +818,8 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     }
     e.conv0 = o; o += align64(cpc_conv0_backward_scratch_floats(B, Lw));
     e.bamax = o; o += 5 * kAmaxSlots;       // [i][slot] = partial max|dx_i| (i = 1..4), folded by the consumers (fold_amax)
+    e.dyamax = o; o += 5 * kAmaxSlots;      // cleared together with bamax
+    e.dxbound = o; o += 64;
     e.bwd_total = o;
     return true;
 }
@@ -829,7 +868,7 @@ static int weight_split() {
 static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const float* xhat_prev, const float* y_prev,
                            const float* rstd_prev, const float* nw_prev, float* dprev, float* colpart, float* tmp,
                            float* small3, const float* dx_amax, float* dprev_amax, int B, int Lin, int k, int s, int p,
-                           hipStream_t st, int amax_slots = 1);
+                           hipStream_t st, int amax_slots = 1, float* dprev_slots = nullptr);
 
 extern "C" int cpc_set_conv_tile(int bm) {
     CPC_RETURN_IF(bm != 0 && bm != 32 && bm != 64 && bm != 128, CPC_ERR_ARG);
@@ -839,6 +878,10 @@ extern "C" int cpc_set_conv_tile(int bm) {
 extern "C" int cpc_set_dma_tile(int bm) {
     CPC_RETURN_IF(bm != 0 && bm != 128 && bm != 256, CPC_ERR_ARG);
     g_dma_bm = bm;
+    return 0;
+}
+extern "C" int cpc_set_h2_dx(int on) {
+    g_h2_dx = on ? 1 : 0;
     return 0;
 }
 extern "C" int cpc_set_h2_layers(int n) {
@@ -960,7 +1003,8 @@ extern "C" int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, 
 static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const float* xhat_prev, const float* y_prev,
                            const float* rstd_prev, const float* nw_prev, float* dprev, float* colpart, float* tmp,
                            float* small3, const float* dx_amax, float* dprev_amax, int B, int Lin, int k, int s, int p,
-                           hipStream_t st, int amax_slots) {
+                           hipStream_t st, int amax_slots, float* dprev_slots) {
+    // dprev_slots (plain dgrad only, may be NULL): kAmaxSlots floats that receive max|dprev| (atomicMax: zero them first)
     const int Lout = conv_out_len(Lin, k, s, p);
     const float* w_amax = wd + (long)kC * k * kC;
     // 2-row windows [q-1, q] over dx, q in [0, Lout]
@@ -979,9 +1023,9 @@ static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const flo
         return rows_sum(colpart, nblk, 3 * kC, tmp, small3, st);
     }
     switch (bm) {
-        case 128: launch_conv_dgrad<128, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, nullptr, amax_slots, st); break;
-        case 64: launch_conv_dgrad<64, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, nullptr, amax_slots, st); break;
-        default: launch_conv_dgrad<32, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, nullptr, amax_slots, st); break;
+        case 128: launch_conv_dgrad<128, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, dprev_slots, amax_slots, st); break;
+        case 64: launch_conv_dgrad<64, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, dprev_slots, amax_slots, st); break;
+        default: launch_conv_dgrad<32, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, dprev_slots, amax_slots, st); break;
     }
     CPC_LAUNCH_CHECK();
     return 0;
@@ -1004,7 +1048,7 @@ extern "C" int cpc_conv_layer_wgrad(const float* dx, const float* x, float* part
 static int conv_layer_wgrad(const float* dx, const float* x, int x_h2, float* part, float* dW, const float* dx_amax,
                             const float* x_amax, int B, int Lin, int k, int s, int p, int splits, int rows_per_split,
                             void* stream, int amax_slots) {
-    CPC_RETURN_IF(x_h2 == 1 && g_mfma_mode < 2, CPC_ERR_ARG);
+    CPC_RETURN_IF((x_h2 == 1 || x_h2 == 3) && g_mfma_mode < 2, CPC_ERR_ARG);
     CPC_RETURN_IF(B <= 0 || Lin <= 0 || Lin + 2 * p < k || splits <= 0 || rows_per_split <= 0, CPC_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     const int Lout = conv_out_len(Lin, k, s, p);
@@ -1016,6 +1060,8 @@ static int conv_layer_wgrad(const float* dx, const float* x, int x_h2, float* pa
     CPC_RETURN_IF(g_mfma_mode >= 2 && x_h2 != 2 && (!dx_amax || !x_amax), CPC_ERR_ARG);
     if (x_h2 == 2)
         hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax, amax_slots);
+    else if (x_h2 == 3)          // x and dx in H2 storage; dx_amax = the bound dx was scaled for
+        hipLaunchKernelGGL((conv_wgrad_kernel<5>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax, amax_slots);
     else if (g_mfma_mode >= 2 && x_h2)
         hipLaunchKernelGGL((conv_wgrad_kernel<3>), grid, dim3(256), 0, st, dxm, im, K, rows_per_split, splits, part, dx_amax, x_amax, amax_slots);
     else if (g_mfma_mode >= 2)
@@ -1079,6 +1125,7 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
         a.nw[i - 1] = params[4 * (i - 1) + 2];
         a.nb[i - 1] = params[4 * (i - 1) + 3];
         a.k[i - 1] = kGeom[i].k;
+        a.dgrad_h2[i - 1] = e.dxh2[i];
         a.fwd_h2[i - 1] = e.bf16 ? 2 : act_h2(i - 1);   // 1: layer i consumes an H2 activation (DMA kernel, DMA weight layout);
                                                         // 2: bf16 storage (both layouts in bf16 K-tile-major rows)
         const int per = cdiv((long)kC * kGeom[i].k * kC, 256);
@@ -1164,8 +1211,10 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     // atomicMax on the float bits: exact, order-independent); the bounds of the layers' inputs and the dgrad weight
     // layouts come from the forward (saved)
     float* amax = scratch + e.bamax;
+    float* dyamax = scratch + e.dyamax;
+    float* dxbound = scratch + e.dxbound;
     const float* xbound = saved + e.sbound;
-    (void)hipMemsetAsync(amax, 0, 5 * kAmaxSlots * sizeof(float), st);
+    (void)hipMemsetAsync(amax, 0, 2 * 5 * kAmaxSlots * sizeof(float), st);      // bamax and dyamax
     // top layer: ReLU'/norm backward of dz
     // the four stand-alone norm backwards leave their per-workgroup column partials in their own buffers; one batched
     // reduction at the end replaces eight small launches on the way
@@ -1182,11 +1231,22 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
             hipLaunchKernelGGL((norm_bwd_kernel<2, true, true>), dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
                                saved + e.rstd[layer], params[4 * layer + 2], params[4 * layer + 3], dxl, scratch + e.colp[layer],
                                M, (float*)nullptr, 1);
+        else if (e.dxh2[layer])           // dx in H2 storage, scaled for a bound derived from max|dy| (left by the dgrad above it)
+            hipLaunchKernelGGL((norm_bwd_kernel<2, false, false, true>), dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
+                               saved + e.rstd[layer], params[4 * layer + 2], params[4 * layer + 3], dxl, scratch + e.colp[layer],
+                               M, (float*)nullptr, 1, dyamax + layer * kAmaxSlots, kAmaxSlots, dxbound + layer);
         else
         hipLaunchKernelGGL(norm_bwd_kernel<2>, dim3(nblk), dim3(256), 0, st, dy, saved + e.xhat[layer], yl,
                            saved + e.rstd[layer], params[4 * layer + 2], params[4 * layer + 3], dxl, scratch + e.colp[layer], M,
                            amax + layer * kAmaxSlots, kAmaxSlots);
         jobs[njobs++] = RowsSumJob{scratch + e.colp[layer], nblk, 3 * kC, scratch + e.tmpq[layer], small + layer * 3 * kC};
+    };
+    // weight gradient of layer i on the wgrad stream: operand storages as the layout says; a dx in H2 storage comes with the
+    // single bound it was scaled for instead of the kAmaxSlots partial maxima
+    auto wgrad = [&](int i, const float* xin) {
+        return conv_layer_wgrad(scratch + e.dx[i], xin, e.bf16 ? 2 : (e.dxh2[i] ? 3 : act_h2(i - 1)), scratch + e.part, grads[4 * i],
+                                e.dxh2[i] ? dxbound + i : amax + i * kAmaxSlots, xbound + i, B, e.L[i - 1], kGeom[i].k, kGeom[i].s,
+                                kGeom[i].p, e.wg_splits[i], e.wg_rows[i], (void*)wst, e.dxh2[i] ? 1 : kAmaxSlots);
     };
     int rc = 0;
     norm_bwd(4, dz, z, scratch + e.dx[4]);
@@ -1200,8 +1260,7 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                 return CPC_ERR_ARG;
         }
         if (!(ev && i == 1))
-        rc = conv_layer_wgrad(scratch + e.dx[i], xin, e.bf16 ? 2 : act_h2(i - 1), scratch + e.part, grads[4 * i], amax + i * kAmaxSlots, xbound + i, B,
-                              e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, e.wg_splits[i], e.wg_rows[i], (void*)wst, kAmaxSlots);
+        rc = wgrad(i, xin);
         if (rc) return rc;
         if (e.bf16) {
             // bf16 storage: DMA'd bf16 dgrad into a bf16 temporary (layer 1: straight into conv0's dy), then the norm backward
@@ -1210,12 +1269,13 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                                      kGeom[i].s, kGeom[i].p, st);
             if (rc) return rc;
             if (i >= 2) norm_bwd(i - 1, tmpd, xin, scratch + e.dx[i - 1]);
-        } else if (i >= 2 && g_unfuse_big && (g_unfuse_big == 2 || pick_bm(B * (e.L[i] + 1)) == 128)) {
+        } else if (i >= 2 && (e.dxh2[i - 1] || (g_unfuse_big && (g_unfuse_big == 2 || pick_bm(B * (e.L[i] + 1)) == 128)))) {
             // the fused ReLU'/ChannelNorm-backward epilogue is latency-bound (row-by-row reductions between the loads); a
             // plain dgrad into a temporary (dy0 is free until layer 1's dgrad) + the streaming norm backward is faster
             float* tmpd = scratch + e.dy0;
             rc = conv_dgrad_core(scratch + e.dx[i], saved + e.swd[i], 0, nullptr, nullptr, nullptr, nullptr, tmpd, nullptr,
-                                 nullptr, nullptr, amax + i * kAmaxSlots, nullptr, B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, st, kAmaxSlots);
+                                 nullptr, nullptr, amax + i * kAmaxSlots, nullptr, B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, st, kAmaxSlots,
+                                 e.dxh2[i - 1] ? dyamax + (i - 1) * kAmaxSlots : nullptr);
             if (rc) return rc;
             norm_bwd(i - 1, tmpd, xin, scratch + e.dx[i - 1]);
         } else if (i >= 2) {
@@ -1223,6 +1283,9 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                                  saved + e.rstd[i - 1], params[4 * (i - 1) + 2], scratch + e.dx[i - 1], colpart, tmp,
                                  small + (i - 1) * 3 * kC, amax + i * kAmaxSlots, amax + (i - 1) * kAmaxSlots, B, e.L[i - 1], kGeom[i].k,
                                  kGeom[i].s, kGeom[i].p, st, kAmaxSlots);
+        } else if (e.dxh2[1]) {
+            rc = conv_dgrad_dma_h2(scratch + e.dx[1], saved + e.swd[1], scratch + e.dy0, saved + e.szero, dxbound + 1, nullptr, B,
+                                   e.L[0], kGeom[1].k, kGeom[1].s, kGeom[1].p, st);
         } else {
             rc = conv_dgrad_core(scratch + e.dx[1], saved + e.swd[1], 0, nullptr, nullptr, nullptr, nullptr,
                                  scratch + e.dy0, nullptr, nullptr, nullptr, amax + kAmaxSlots, nullptr, B, e.L[0], kGeom[1].k,
@@ -1231,8 +1294,7 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
         if (rc) return rc;
         if (ev && i == 1) {
             if (hipEventRecord(ev[1], st) != hipSuccess || hipStreamWaitEvent(wst, ev[1], 0) != hipSuccess) return CPC_ERR_ARG;
-            rc = conv_layer_wgrad(scratch + e.dx[1], xin, e.bf16 ? 2 : act_h2(0), scratch + e.part, grads[4], amax + kAmaxSlots, xbound + 1, B, e.L[0],
-                                  kGeom[1].k, kGeom[1].s, kGeom[1].p, e.wg_splits[1], e.wg_rows[1], (void*)wst, kAmaxSlots);
+            rc = wgrad(1, xin);
         }
         if (rc) return rc;
     }

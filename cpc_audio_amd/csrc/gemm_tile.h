@@ -332,6 +332,24 @@ __device__ __forceinline__ void permute_w_h2_elem(const float* __restrict__ w, u
     p[8] = l;
 }
 
+// ... data gradient (enc_conv.hip, conv_dgrad_kernel): phase r < s, rows ci, contraction kg = j*C + co (j in {0,1}):
+// element W[co][ci][r + (1-j)*s] * scale goes to phase block r (256 * 512 * 4 bytes), row (kg / 32) * 256 + ci
+__device__ __forceinline__ void permute_w_dgrad_h2_elem(const float* __restrict__ w, unsigned char* __restrict__ wd, int s,
+                                                        float amax, long idx) {
+    const int k = 2 * s;
+    const int r = (int)(idx / (kC * 2 * kC));
+    const int rem = (int)(idx - (long)r * kC * 2 * kC);
+    const int ci = rem / (2 * kC);
+    const int jc = rem - ci * 2 * kC;
+    const int j = jc >> kCLog2, co = jc & (kC - 1);
+    _Float16 h, l;
+    h2_split(w[((long)co * kC + ci) * k + r + (1 - j) * s], scale_for_amax(amax), h, l);
+    unsigned char* row = wd + (long)r * (kC * 2 * kC * 4) + ((long)(jc >> 5) * kC + ci) * 128;
+    _Float16* o = reinterpret_cast<_Float16*>(row + h2_byte_of(jc & 31));
+    o[0] = h;
+    o[8] = l;
+}
+
 // bf16 storage (mode 4): round to nearest even
 __device__ __forceinline__ unsigned short bf16_rne(float x) {
     const unsigned u = __float_as_uint(x);
@@ -845,7 +863,9 @@ RowCursor ca[A_PER], cb[B_PER];
 // BH2 (NP == 2 only): the B operand is stored in H2 form (cpc_common.h: two fp16 pieces per element, already scaled by sb):
 // the loader fetches the pieces and transposes them, no split VALU.
 // BF16IN (NP == 1 only): both operands are bf16 tensors (the bf16-storage variant): fetched as stored, transposed, one product.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1, int NP = 3, bool BH2 = false, bool BF16IN = false>
+// AH2: the same for the A operand.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1, int NP = 3, bool BH2 = false, bool BF16IN = false,
+          bool AH2 = false>
 struct TnTileX3 {   // NP: see NtTileX3
     static constexpr int BK = BK_;
     static constexpr int LDH = BK + 8;
@@ -975,7 +995,7 @@ struct TnTileX3 {   // NP: see NtTileX3
     __device__ static void run(f32x16 (&acc)[TM][TN], const RowMap& am, int c0,
                                const RowMap& bm, int n0, int mbeg, int mend, float* smem_f,
                                float sa = 1.0f, float sb = 1.0f) {
-        static_assert(!BH2 || NP == 2, "H2 operands are two fp16 pieces");
+        static_assert((!BH2 && !AH2) || NP == 2, "H2 operands are two fp16 pieces");
         static_assert(BF16IN == (NP == 1), "one piece <=> bf16 tensors");
         unsigned short* smem0 = reinterpret_cast<unsigned short*>(smem_f);
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1022,7 +1042,8 @@ struct TnTileX3 {   // NP: see NtTileX3
                         continue;
                     }
                     const RowRef rr = cursor_ref(am, cursor_plus(am, ca[i], r), a_on[i] && (mm + a_m[i] + r) < mend);
-                    ra[i][r] = load_row4(rr, c0 + a_c[i], am.Lin, am.base);
+                    if constexpr (AH2) ra[i][r] = load_row4_h2(rr, c0 + a_c[i], am.Lin, am.base);
+                    else ra[i][r] = load_row4(rr, c0 + a_c[i], am.Lin, am.base);
                 }
                 ca[i] = cursor_plus(am, ca[i], BK);
             }
@@ -1047,6 +1068,7 @@ struct TnTileX3 {   // NP: see NtTileX3
             for (int i = 0; i < A_PER; ++i)
                 if (a_on[i]) {
                     if constexpr (BF16IN) store_block_bf16(smem, a_c[i], a_m[i], ra[i]);
+                    else if constexpr (AH2) store_block_h2(smem, PLANE_A, a_c[i], a_m[i], ra[i]);
                     else store_block(smem, PLANE_A, a_c[i], a_m[i], ra[i], sa);
                 }
 #pragma unroll

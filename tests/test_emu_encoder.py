@@ -42,15 +42,18 @@ def _saved_acts(lib, saved, B, L, Ls):
 @pytest.mark.parametrize("B,L,bm,mode", [(2, 1280, 0, 1), (1, 1370, 64, 1), (1, 1600, 128, 1), (3, 1290, 128, 0),
                                           (2, 1280, 0, 0), (1, 1600, 128, 2), (2, 1280, 0, 2), (1, 1370, 64, 2),
                                           (2, 1280, 0, 3), (1, 1370, 64, 3), (3, 1290, 128, 3), (2, 1280, 0, 32),
-                                          (1, 1370, 0, 132)])
+                                          (1, 1370, 0, 132), (2, 1280, 0, 30)])
 def test_encoder_forward_backward_emulated(B, L, bm, mode):
     """mode 1: NT GEMMs on the bf16 pipe with 3-piece split operands; mode 0: exact-f32 MFMA; mode 2: fp16 pipe with
     scaled 2-piece split operands; mode 3 (default): mode 2 + layers 1, 2 on the DMA kernel reading H2 activations
     (ragged lengths: partial 128-row tiles, padding rows from the zero buffer)."""
     lib = emu()
-    # mode 32: mode 3 with conv2 on the DMA kernel as well (what B >= ~100 selects); 132: that with two 32-k LDS stages
+    # mode 32: mode 3 with conv2 on the DMA kernel as well (what B >= ~100 selects); 132: that with two 32-k LDS stages;
+    # mode 30: mode 3 with layer 1's gradient kept fp32 (cpc_set_h2_dx(0): register-staged data gradient) instead of H2 storage
     h2_layers, pipe = (2, mode // 100) if mode >= 32 else (0, 0)
-    mode = 3 if mode >= 32 else mode
+    h2_dx = 0 if mode == 30 else 1
+    mode = 3 if mode >= 30 else mode
+    assert lib.cpc_set_h2_dx(h2_dx) == 0
     assert lib.cpc_set_conv_tile(bm) == 0
     assert lib.cpc_set_mfma_mode(mode) == 0
     assert lib.cpc_set_h2_layers(h2_layers) == 0 and lib.cpc_set_dma_pipeline(pipe) == 0
@@ -107,6 +110,7 @@ def test_encoder_forward_backward_emulated(B, L, bm, mode):
         lib.cpc_set_mfma_mode(_lib_default_mode())
         lib.cpc_set_h2_layers(0)
         lib.cpc_set_dma_pipeline(0)
+        lib.cpc_set_h2_dx(1)
 
 
 @pytest.mark.parametrize("mode", [1, 2])
