@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(
 // no dgrad.  Each block reduces its waves through LDS and writes one partial row
 // [13][256] to `part`; a second tiny kernel sums the partial rows in a fixed order
 // (deterministic, no float atomics).
-constexpr int C0B_TT = 64;                 // time steps per block in backward (16 per wave)
+constexpr int C0B_TT = 256;                // time steps per block in backward (64 per wave); measured alone at B = 64, with
+constexpr int C0B_NBW = 2;                 // C0B_NBW rows in flight per wave: 64/1 174 us, 256/1 138, 256/2 140, 256/4 125 (the
+                                           // last one slower inside the step, beside the layer-1 weight gradient)
 constexpr int C0B_NS = S0 * C0B_TT + (K0 - S0);
 constexpr int C0_NACC = K0 + 3;            // 10 weight taps, conv bias, norm weight, norm bias
 
@@ -187,47 +189,63 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(
 #pragma unroll
         for (int j = 0; j < C0_NACC; ++j) acc[q][j] = 0.f;
     __syncthreads();
-    for (int tt = wv; tt < C0B_TT; tt += 4) {
-        const int t = t0 + tt;
-        if (t >= L0) break;                      // wave-uniform
-        const long row = (long)b * L0 + t;
-        float g[4];
-        if constexpr (DYB) {
-            const uint2 gb = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dy) + row * kC + c);
-            g[0] = bf16_val((unsigned short)(gb.x & 0xFFFFu)); g[1] = bf16_val((unsigned short)(gb.x >> 16));
-            g[2] = bf16_val((unsigned short)(gb.y & 0xFFFFu)); g[3] = bf16_val((unsigned short)(gb.y >> 16));
-        } else {
-            const float4 g4 = *reinterpret_cast<const float4*>(dy + row * kC + c);
-            g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+    // C0B_NBW rows of this wave at a time: their loads, the two wave reductions each needs and the ~130 VALU operations
+    // per row interleave instead of queueing behind one another (one row at a time: 153 us alone at B = 64)
+    for (int tt0 = wv; tt0 < C0B_TT; tt0 += 4 * C0B_NBW) {
+        if (t0 + tt0 >= L0) break;               // wave-uniform
+        float g[C0B_NBW][4], mu[C0B_NBW], rstd[C0B_NBW];
+        bool live[C0B_NBW];
+#pragma unroll
+        for (int u = 0; u < C0B_NBW; ++u) {
+            const int tt = tt0 + 4 * u;
+            live[u] = tt < C0B_TT && t0 + tt < L0;
+            const long row = (long)b * L0 + (live[u] ? t0 + tt : t0 + tt0);
+            if constexpr (DYB) {
+                const uint2 gb = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dy) + row * kC + c);
+                g[u][0] = bf16_val((unsigned short)(gb.x & 0xFFFFu)); g[u][1] = bf16_val((unsigned short)(gb.x >> 16));
+                g[u][2] = bf16_val((unsigned short)(gb.y & 0xFFFFu)); g[u][3] = bf16_val((unsigned short)(gb.y >> 16));
+            } else {
+                const float4 g4 = *reinterpret_cast<const float4*>(dy + row * kC + c);
+                g[u][0] = g4.x; g[u][1] = g4.y; g[u][2] = g4.z; g[u][3] = g4.w;
+            }
+            mu[u] = mean_in[row]; rstd[u] = rstd_in[row];
         }
-        const float mu = mean_in[row], rstd = rstd_in[row];
-        float sv[K0];
+        float sv[C0B_NBW][K0], xh[C0B_NBW][4], dxh[C0B_NBW][4], s1[C0B_NBW], s2[C0B_NBW];
 #pragma unroll
-        for (int j = 0; j < K0; ++j) sv[j] = smp[tt * S0 + j];
-        float xh[4], dxh[4], s1 = 0.f, s2 = 0.f;
+        for (int u = 0; u < C0B_NBW; ++u) {
+            const int tt = live[u] ? tt0 + 4 * u : tt0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float x = br[q];
+            for (int j = 0; j < K0; ++j) sv[u][j] = smp[tt * S0 + j];
+            s1[u] = 0.f; s2[u] = 0.f;
 #pragma unroll
-            for (int j = 0; j < K0; ++j) x = fmaf(wr[q][j], sv[j], x);
-            xh[q] = (x - mu) * rstd;
-            const float yv = fmaf(xh[q], gw[q], gb[q]);
-            const float dyh = yv > 0.f ? g[q] : 0.f;        // relu'
-            acc[q][K0 + 1] = fmaf(dyh, xh[q], acc[q][K0 + 1]);   // d batchNorm0.weight
-            acc[q][K0 + 2] += dyh;                               // d batchNorm0.bias
-            dxh[q] = dyh * gw[q];
-            s1 += dxh[q];
-            s2 = fmaf(dxh[q], xh[q], s2);
+            for (int q = 0; q < 4; ++q) {
+                float x = br[q];
+#pragma unroll
+                for (int j = 0; j < K0; ++j) x = fmaf(wr[q][j], sv[u][j], x);
+                xh[u][q] = (x - mu[u]) * rstd[u];
+                const float yv = fmaf(xh[u][q], gw[q], gb[q]);
+                const float dyh = (live[u] && yv > 0.f) ? g[u][q] : 0.f;   // relu'
+                acc[q][K0 + 1] = fmaf(dyh, xh[u][q], acc[q][K0 + 1]);       // d batchNorm0.weight
+                acc[q][K0 + 2] += dyh;                                      // d batchNorm0.bias
+                dxh[u][q] = dyh * gw[q];
+                s1[u] += dxh[u][q];
+                s2[u] = fmaf(dxh[u][q], xh[u][q], s2[u]);
+            }
         }
-        s1 = wave_sum(s1) * (1.0f / kC);
-        s2 = wave_sum(s2) * (1.0f / (kC - 1));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float dx = rstd * (dxh[q] - s1 - xh[q] * s2);
-            acc[q][K0] += dx;                                    // d conv0.bias
-#pragma unroll
-            for (int j = 0; j < K0; ++j) acc[q][j] = fmaf(dx, sv[j], acc[q][j]);   // d conv0.weight
+        for (int u = 0; u < C0B_NBW; ++u) {
+            s1[u] = wave_sum(s1[u]) * (1.0f / kC);
+            s2[u] = wave_sum(s2[u]) * (1.0f / (kC - 1));
         }
+#pragma unroll
+        for (int u = 0; u < C0B_NBW; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float dx = live[u] ? rstd[u] * (dxh[u][q] - s1[u] - xh[u][q] * s2[u]) : 0.f;
+                acc[q][K0] += dx;                                    // d conv0.bias
+#pragma unroll
+                for (int j = 0; j < K0; ++j) acc[q][j] = fmaf(dx, sv[u][j], acc[q][j]);   // d conv0.weight
+            }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
