@@ -20,6 +20,10 @@ using TnGX3 = TnTileX3<128, 128, 2, 2>;
 using NtBigH2 = NtTileX3<128, 128, 2, 2, 32, 1, false, false, 2>;
 using NtSmallH2 = NtTileX3<64, 64, 2, 2, 32, 1, false, false, 2>;
 using TnGH2 = TnTileX3<128, 128, 2, 2, 32, 1, 2>;
+// 128 x 256 tile, 8 waves, 16-k chunks through two LDS stages with four register sets of global prefetch (the conv layers'
+// tile, gemm_tile.h): for the wide products (N a multiple of 256, K of 64, enough row tiles to fill the chip) -- a third less
+// operand traffic through L2 than 128 x 128, and the load latency of a short K walk stays hidden
+using NtWideH2 = NtTileX3<128, 256, 2, 4, 16, 2, true, false, 2>;
 
 struct OperandScales { float sa, sb, inv; };
 __device__ __forceinline__ OperandScales operand_scales(const GemmBounds& gb) {
@@ -32,13 +36,13 @@ __device__ __forceinline__ OperandScales operand_scales(const GemmBounds& gb) {
 
 // Output row m goes to C + m*ldc, or, when c_R > 0, to C + (m / c_R)*c_bstride + (m % c_R)*ldc
 // (a batch-strided view such as dc[:, :W]).
-template <class NtG, int BMN, bool H2 = false>
+template <class NtG, int BMN, bool H2 = false, int BNN = BMN>
 __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const float* __restrict__ Bmat,
                                                                 int ldb, const float* __restrict__ bias,
                                                                 float* __restrict__ C, long ldc, int K,
                                                                 int c_R, long c_bstride, GemmBounds gb) {
     __shared__ float smem[NtG::SMEM_FLOATS];
-    const int m0 = blockIdx.x * BMN, n0 = blockIdx.y * BMN;
+    const int m0 = blockIdx.x * BMN, n0 = blockIdx.y * BNN;
     f32x16 acc[NtG::TM][NtG::TN];
     zero_acc(acc);
     float inv = 1.0f;
@@ -227,6 +231,7 @@ __global__ __launch_bounds__(1024) void absmax_slots_kernel(AbsmaxJobs jobs, flo
     }
 }
 
+int g_gemm_wide = 1;
 int g_gemm_split = 1;      // cpc_set_gemm_split: 0 keeps every plain GEMM on three bf16 pieces, bounds or not
 
 int absmax_slots(const float* const* x, const long* n, int njobs, float* out, hipStream_t st) {
@@ -246,7 +251,12 @@ int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, flo
     const bool x3 = g_mfma_mode != 0 && K % 32 == 0;
     const bool h2 = x3 && g_mfma_mode >= 2 && g_gemm_split && bounds.a && bounds.b;      // operand bounds known: fp16 split
     const dim3 gb(cdiv(am.M, 128), N / 128), gs(cdiv(am.M, 64), N / 64);
-    if (big && h2)
+    const bool wide = h2 && g_gemm_wide && N % 256 == 0 && K % 64 == 0 &&
+                      (g_gemm_wide == 2 || (long)cdiv(am.M, 128) * (N / 256) >= 256);
+    if (wide)
+        hipLaunchKernelGGL((nt_gemm_kernel<NtWideH2, 128, true, 256>), dim3(cdiv(am.M, 128), N / 256), dim3(NtWideH2::NTHREADS), 0,
+                           st, am, Bmat, ldb, bias, C, ldc, K, c_R, c_bstride, bounds);
+    else if (big && h2)
         hipLaunchKernelGGL((nt_gemm_kernel<NtBigH2, 128, true>), gb, dim3(NtBigH2::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
                            ldc, K, c_R, c_bstride, bounds);
     else if (h2)
@@ -387,5 +397,7 @@ extern "C" int cpc_gemm_tn(const float* A, int lda, const float* B, int ldb, flo
 // pieces always (A/B measurements, numerical comparisons)
 extern "C" int cpc_set_gemm_split(int on) {
     cpc::g_gemm_split = on ? 1 : 0;
+    cpc::g_gemm_wide = on == 2 ? 0 : (on == 3 ? 2 : 1);   // 2: two fp16 pieces, but never the 128 x 256 tile (A/B measurements);
+                                                           // 3: that tile whenever the shape allows, however few workgroups (tests)
     return 0;
 }

@@ -8,9 +8,18 @@ from emu_util import P, emu, rel_err
 from oracle import cpc_oracle as O
 
 
-@pytest.mark.parametrize("B,S,K,N,scale", [(2, 20, 12, 16, 1.0), (3, 19, 5, 32, 40.0)])
-def test_nce_forward_backward_emulated(B, S, K, N, scale):
+@pytest.mark.parametrize("B,S,K,N,scale,wide", [(2, 20, 12, 16, 1.0, 0), (3, 19, 5, 32, 40.0, 0), (2, 20, 12, 16, 1.0, 1)])
+def test_nce_forward_backward_emulated(B, S, K, N, scale, wide):
+    """wide: the prediction GEMM on the 128 x 256 pipelined tile (cpc_set_gemm_split(3) forces it at test sizes)."""
     lib = emu()
+    assert lib.cpc_set_gemm_split(3 if wide else 1) == 0
+    try:
+        _nce_forward_backward(lib, B, S, K, N, scale)
+    finally:
+        lib.cpc_set_gemm_split(1)
+
+
+def _nce_forward_backward(lib, B, S, K, N, scale):
     torch.manual_seed(2)
     W = S - K
     p = O.make_params(seed=4, n_predicts=K, head_scale=scale)
