@@ -11,12 +11,13 @@ import torch.nn as nn
 from .ops import InfoNCEFunction, InfoNCEScoresFunction, prepare_negatives
 
 
-class _StackedHeads(torch.autograd.Function):
-    """The buffer the K head weights are views of, as a differentiable function of them (gradient: its K row blocks)."""
+class _Stacked(torch.autograd.Function):
+    """The buffer K equally shaped parameters are views of (one behind the other), as a differentiable function of them:
+    its gradient is handed to them block by block."""
 
     @staticmethod
-    def forward(ctx, flat, *heads):
-        ctx.rows = heads[0].shape[0]
+    def forward(ctx, flat, *parts):
+        ctx.shape = tuple(parts[0].shape)
         ctx.set_materialize_grads(False)
         return flat.view_as(flat)
 
@@ -25,8 +26,36 @@ class _StackedHeads(torch.autograd.Function):
         n = len(ctx.needs_input_grad) - 1
         if g is None:
             return (None,) * (n + 1)
-        return (None,) + tuple(g[k * ctx.rows:(k + 1) * ctx.rows] if ctx.needs_input_grad[k + 1] else None
-                               for k in range(n))
+        g = g.reshape(n, *ctx.shape)
+        return (None,) + tuple(g[k] if ctx.needs_input_grad[k + 1] else None for k in range(n))
+
+
+def stacked_parameters(owner, key, params, shape=None):
+    """``params``: K equally shaped parameters.  -> one tensor of shape ``shape`` (default (K, *p.shape)) holding them one
+    behind the other, tied to them for autograd, WITHOUT a per-step ``torch.cat``: the parameters are kept as views of one
+    buffer (cached on ``owner`` under ``key``; re-established whenever somebody gave them new storage, e.g. ``.to(device)``;
+    in-place updates -- the optimiser, ``load_state_dict`` -- keep it)."""
+    cache = owner.__dict__.setdefault("_stacked_cache", {})
+    flat = cache.get(key)
+    p0 = params[0]
+    step = p0.numel() * p0.element_size()
+    if (flat is None or flat.device != p0.device or flat.dtype != p0.dtype
+            or any(p.data_ptr() != flat.data_ptr() + k * step for k, p in enumerate(params))):
+        with torch.no_grad():
+            flat = torch.stack([p.detach() for p in params]).contiguous()
+            for k, p in enumerate(params):
+                p.data = flat[k]
+        cache[key] = flat
+    out = flat if shape is None else flat.view(shape)
+    return _Stacked.apply(out, *params)
+
+
+# the 13 parameters of a TransformerLayer in the order of the C ABI (cpc_transformer_layer_forward)
+_LAYER_PARAMS = (lambda l: l.multihead.Wo.weight, lambda l: l.multihead.Wk.weight, lambda l: l.multihead.Wq.weight,
+                 lambda l: l.multihead.Wv.weight, lambda l: l.multihead.Att.Krelpos if l.multihead.Att.relpos else None,
+                 lambda l: l.ln_multihead.weight, lambda l: l.ln_multihead.bias, lambda l: l.ffnetwork.lin1.weight,
+                 lambda l: l.ffnetwork.lin1.bias, lambda l: l.ffnetwork.lin2.weight, lambda l: l.ffnetwork.lin2.bias,
+                 lambda l: l.ln_ffnetwork.weight, lambda l: l.ln_ffnetwork.bias)
 
 
 class PredictionNetwork(nn.Module):
@@ -62,25 +91,30 @@ class PredictionNetwork(nn.Module):
                 self.predictors.append(nn.Linear(dimOutputAR, dimOutputEncoder, bias=False))
 
     def predictions(self, c):
-        """c (B,W,256) -> (B,W,K*256): head k at columns k*256.. (the layout the score kernels read)."""
+        """c (B,W,256) -> (B,W,K*256): head k at columns k*256.. (the layout the score kernels read).  K one-layer transformer
+        predictors (the only kind buildTransformerAR(.., 1, .., False) builds) run in lock-step, one launch per kernel for all
+        of them (ops.TransformerGroupFunction); anything else head by head."""
+        from .transformers import TransformerLayer
+        layers = [p[0] if isinstance(p, nn.Sequential) and len(p) == 1 else None for p in self.predictors]
+        if (self.rnnMode == "transformer" and len(layers) > 1 and all(isinstance(l, TransformerLayer) for l in layers)
+                and len({(l.dropout_p, l.training, l.multihead.Att.relpos) for l in layers}) == 1 and c.is_cuda):
+            from .ops import TransformerGroupFunction
+            l0 = layers[0]
+            p, seed = 0.0, 0
+            if l0.training and l0.dropout_p > 0:
+                p = l0.dropout_p
+                seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
+            kinds = []
+            for i, get in enumerate(_LAYER_PARAMS):
+                ps = [get(l) for l in layers]
+                kinds.append(None if ps[0] is None else stacked_parameters(self, f"layer{i}", ps))
+            return TransformerGroupFunction.apply(c, p, seed, len(layers), *kinds)
         return torch.cat([p(c) for p in self.predictors], dim=2)
 
     def stacked_weight(self):
-        """(K*256, 256): the K head weights stacked along the output dimension -- without a per-step ``torch.cat``: the K
-        parameters are kept as views of one buffer (re-established whenever somebody gave them new storage, e.g.
-        ``.to(device)``; in-place updates -- the optimiser, ``load_state_dict`` -- keep it), and the buffer is tied to
-        them for autograd by _StackedHeads."""
+        """(K*256, 256): the K head weights stacked along the output dimension (stacked_parameters: no per-step cat)."""
         ws = [p.weight for p in self.predictors]
-        flat = getattr(self, "_flat_heads", None)
-        rows, step = ws[0].shape[0], ws[0].numel() * ws[0].element_size()
-        if (flat is None or flat.device != ws[0].device or flat.dtype != ws[0].dtype
-                or any(w.data_ptr() != flat.data_ptr() + k * step for k, w in enumerate(ws))):
-            with torch.no_grad():
-                flat = torch.cat([w.detach() for w in ws], dim=0).contiguous()
-                for k, w in enumerate(ws):
-                    w.data = flat[k * rows:(k + 1) * rows]
-            self._flat_heads = flat
-        return _StackedHeads.apply(flat, *ws)
+        return stacked_parameters(self, "heads", ws, (len(ws) * ws[0].shape[0], ws[0].shape[1]))
 
     def forward(self, c, candidates):
         """Reference API (criterion.py:97-118) on materialised candidates; kept for callers

@@ -8,7 +8,9 @@ namespace cpc {
 // out[0:n] = sum over `nrows` rows of `part` (row length n), summed in a fixed order.
 // tmp must hold kRowsSumGroups*n floats.
 constexpr int kRowsSumGroups = 128;
-int rows_sum(const float* part, int nrows, int n, float* tmp, float* out, hipStream_t stream);
+// (G independent reductions: part, tmp, out of problem g at + g * part_gs / tmp_gs / out_gs floats)
+int rows_sum(const float* part, int nrows, int n, float* tmp, float* out, hipStream_t stream, int G = 1, long part_gs = 0,
+             long tmp_gs = 0, long out_gs = 0);
 // several independent reductions (each with its own tmp) in two launches; bit-identical with rows_sum per job
 constexpr int kRowsSumMaxJobs = 8;
 struct RowsSumJob { const float* part; int nrows; int n; float* tmp; float* out; };
@@ -25,20 +27,28 @@ struct GemmBounds {
 // max|x| of up to 4 arrays in one launch, as kAmaxSlots partial maxima each (no memset, no atomics): out[j*64 .. j*64+63]
 int absmax_slots(const float* const* x, const long* n, int njobs, float* out, hipStream_t st);
 
+// G equally shaped problems in one launch (blockIdx.z / .y picks the problem): problem g reads and writes at the given
+// pointers + g * stride (floats).  A stride of 0 shares the operand between the problems.
+struct GemmGroup {
+    int G = 1;
+    long a = 0, b = 0, bias = 0, c = 0;
+    long part = 0;      // tn_gemm: stride of the split partials (0: problem g's S * N1 * N2 floats right behind problem g-1's)
+};
 // C[M,N] = A . B[N,K]^T (+ bias);  N % 128 == 0, K % 16 == 0
 int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc, int N,
-            int K, hipStream_t st, int c_R = 0, long c_bstride = 0, GemmBounds gb = GemmBounds());
+            int K, hipStream_t st, int c_R = 0, long c_bstride = 0, GemmBounds gb = GemmBounds(), GemmGroup grp = GemmGroup());
 // C[N1,N2] (+)= sum_m A[m,:N1]^T (x) B[m,:N2];  part: tn_gemm_part_floats(M,N1,N2) floats
 void tn_gemm_plan(int M, int N1, int N2, int* splits, int* rows);
 long tn_gemm_part_floats(int M, int N1, int N2);
+// (grouped: part holds grp.G * tn_gemm_part_floats floats; grp.c strides C)
 int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, float* C, int accumulate,
-            hipStream_t st, GemmBounds gb = GemmBounds());
+            hipStream_t st, GemmBounds gb = GemmBounds(), GemmGroup grp = GemmGroup());
 // nprob <= 4 TN problems with equal M, N1, N2 in one GEMM launch + one reduction; part: tn_gemm_batch_part_floats
 long tn_gemm_batch_part_floats(int nprob, int M, int N1, int N2);
 int tn_gemm_batch(int nprob, const RowMap* am, int N1, const RowMap* bm, int N2, float* part, float* const* C,
                   int accumulate, hipStream_t st);
-// out[Cn][R] = in[R][Cn]^T
-int transpose(const float* in, float* out, int R, int Cn, hipStream_t st);
+// out[Cn][R] = in[R][Cn]^T  (G matrices in_gs / out_gs floats apart)
+int transpose(const float* in, float* out, int R, int Cn, hipStream_t st, int G = 1, long in_gs = 0, long out_gs = 0);
 // n <= 4 matrices of one shape in one launch
 int transpose_batch(const float* const* in, float* const* out, int n, int R, int Cn, hipStream_t st);
 

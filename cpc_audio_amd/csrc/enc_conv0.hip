@@ -263,8 +263,10 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(
 // Block = 32 columns x 8 row lanes; fixed summation order (deterministic).
 __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ part, int nrows,
                                                        int n, int rows_per_group,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, long part_gs, long out_gs) {
     __shared__ float red[8][33];
+    part += (long)blockIdx.z * part_gs;                  // blockIdx.z: problem of a group of equally shaped reductions
+    out += (long)blockIdx.z * out_gs;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + tx;
     const int r0 = blockIdx.y * rows_per_group;
@@ -340,16 +342,20 @@ __global__ __launch_bounds__(256) void conv0_scatter_kernel(const float* __restr
 }
 
 // sums `nrows` rows of length n in `part` into out[0:n]; `tmp` holds >= kRowsSumGroups*n floats.
-int rows_sum(const float* part, int nrows, int n, float* tmp, float* out, hipStream_t stream) {
-    if (nrows <= 0) { (void)hipMemsetAsync(out, 0, sizeof(float) * n, stream); return 0; }
+int rows_sum(const float* part, int nrows, int n, float* tmp, float* out, hipStream_t stream, int G, long part_gs, long tmp_gs,
+             long out_gs) {
+    if (nrows <= 0) {
+        for (int g = 0; g < G; ++g) (void)hipMemsetAsync(out + g * out_gs, 0, sizeof(float) * n, stream);
+        return 0;
+    }
     int groups = nrows > 64 ? kRowsSumGroups : 1;
     const int rpg = cdiv(nrows, groups);
     groups = cdiv(nrows, rpg);
     if (groups == 1) {
-        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 32), 1), dim3(256), 0, stream, part, nrows, n, nrows, out);
+        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 32), 1, G), dim3(256), 0, stream, part, nrows, n, nrows, out, part_gs, out_gs);
     } else {
-        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 32), groups), dim3(256), 0, stream, part, nrows, n, rpg, tmp);
-        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 32), 1), dim3(256), 0, stream, tmp, groups, n, groups, out);
+        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 32), groups, G), dim3(256), 0, stream, part, nrows, n, rpg, tmp, part_gs, tmp_gs);
+        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(n, 32), 1, G), dim3(256), 0, stream, tmp, groups, n, groups, out, tmp_gs, out_gs);
     }
     CPC_LAUNCH_CHECK();
     return 0;

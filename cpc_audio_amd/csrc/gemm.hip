@@ -24,6 +24,7 @@ using TnGH2 = TnTileX3<128, 128, 2, 2, 32, 1, 2>;
 // tile, gemm_tile.h): for the wide products (N a multiple of 256, K of 64, enough row tiles to fill the chip) -- a third less
 // operand traffic through L2 than 128 x 128, and the load latency of a short K walk stays hidden
 using NtWideH2 = NtTileX3<128, 256, 2, 4, 16, 2, true, false, 2>;
+using NtWideX3 = NtTileX3<128, 256, 2, 4, 16, 2, true, false, 3>;     // the same without operand bounds: three bf16 pieces
 
 struct OperandScales { float sa, sb, inv; };
 __device__ __forceinline__ OperandScales operand_scales(const GemmBounds& gb) {
@@ -40,9 +41,14 @@ template <class NtG, int BMN, bool H2 = false, int BNN = BMN>
 __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const float* __restrict__ Bmat,
                                                                 int ldb, const float* __restrict__ bias,
                                                                 float* __restrict__ C, long ldc, int K,
-                                                                int c_R, long c_bstride, GemmBounds gb) {
+                                                                int c_R, long c_bstride, GemmBounds gb, GemmGroup grp) {
     __shared__ float smem[NtG::SMEM_FLOATS];
     const int m0 = blockIdx.x * BMN, n0 = blockIdx.y * BNN;
+    if (grp.G > 1) {                                     // problem blockIdx.z of a group (cpc_internal.h, GemmGroup)
+        const long g = blockIdx.z;
+        am.base += g * grp.a; Bmat += g * grp.b; C += g * grp.c;
+        if (bias) bias += g * grp.bias;
+    }
     f32x16 acc[NtG::TM][NtG::TN];
     zero_acc(acc);
     float inv = 1.0f;
@@ -75,8 +81,13 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
 // XCD-aware: all tiles of one row split run on one XCD (see conv_wgrad_kernel).
 template <class TnG, bool H2 = false>
 __global__ __launch_bounds__(256) void tn_gemm_kernel(RowMap am, RowMap bm, int N1, int N2, int rows_per_split,
-                                                      int S, float* __restrict__ part, long zstride, GemmBounds gb) {
+                                                      int S, float* __restrict__ part, long zstride, GemmBounds gb,
+                                                      GemmGroup grp) {
     __shared__ float smem[TnG::SMEM_FLOATS];
+    if (grp.G > 1) {                                     // problem blockIdx.y of a group; its partials behind the previous one's
+        const long g = blockIdx.y;
+        am.base += g * grp.a; bm.base += g * grp.b; part += grp.part ? g * grp.part : g * S * zstride;
+    }
     const int tn2 = N2 / 128, T = (N1 / 128) * tn2;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int tile = slot % T, z = (slot / T) * 8 + xcd;
@@ -107,9 +118,12 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(RowMap am, RowMap bm, int 
 }
 
 __global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restrict__ part, int S,
-                                                           long n, float* __restrict__ C, int accumulate) {
+                                                           long n, float* __restrict__ C, int accumulate, long c_gs,
+                                                           long part_gs) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
+    part += part_gs ? (long)blockIdx.y * part_gs : (long)blockIdx.y * S * n;      // blockIdx.y: problem of a group
+    C += (long)blockIdx.y * c_gs;
     float s = accumulate ? C[idx] : 0.f;
     for (int z = 0; z < S; ++z) s += part[(long)z * n + idx];
     C[idx] = s;
@@ -160,8 +174,10 @@ __global__ __launch_bounds__(256) void split_reduce_batch_kernel(const float* __
 
 // out[c][r] = in[r][c]
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                        int R, int Cn) {
+                                                        int R, int Cn, long in_gs, long out_gs) {
     __shared__ float tile[32][33];
+    in += (long)blockIdx.z * in_gs;                      // blockIdx.z: matrix of a group
+    out += (long)blockIdx.z * out_gs;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     for (int i = ty; i < 32; i += 8) {
@@ -244,36 +260,39 @@ int absmax_slots(const float* const* x, const long* n, int njobs, float* out, hi
 }
 
 int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc,
-            int N, int K, hipStream_t st, int c_R, long c_bstride, GemmBounds bounds) {
+            int N, int K, hipStream_t st, int c_R, long c_bstride, GemmBounds bounds, GemmGroup grp) {
     if (am.M <= 0) return 0;
     if (N % 128 != 0 || K % 16 != 0 || K < 16) return CPC_ERR_SHAPE;
-    const bool big = (long)cdiv(am.M, 128) * (N / 128) >= 384;
+    const bool big = (long)cdiv(am.M, 128) * (N / 128) * grp.G >= 384;
     const bool x3 = g_mfma_mode != 0 && K % 32 == 0;
     const bool h2 = x3 && g_mfma_mode >= 2 && g_gemm_split && bounds.a && bounds.b;      // operand bounds known: fp16 split
-    const dim3 gb(cdiv(am.M, 128), N / 128), gs(cdiv(am.M, 64), N / 64);
-    const bool wide = h2 && g_gemm_wide && N % 256 == 0 && K % 64 == 0 &&
-                      (g_gemm_wide == 2 || (long)cdiv(am.M, 128) * (N / 256) >= 256);
-    if (wide)
-        hipLaunchKernelGGL((nt_gemm_kernel<NtWideH2, 128, true, 256>), dim3(cdiv(am.M, 128), N / 256), dim3(NtWideH2::NTHREADS), 0,
-                           st, am, Bmat, ldb, bias, C, ldc, K, c_R, c_bstride, bounds);
+    const dim3 gb(cdiv(am.M, 128), N / 128, grp.G), gs(cdiv(am.M, 64), N / 64, grp.G);
+    const bool wide = x3 && g_gemm_wide && N % 256 == 0 && K % 64 == 0 &&
+                      (g_gemm_wide == 2 || (long)cdiv(am.M, 128) * (N / 256) * grp.G >= 256);
+    if (wide && h2)
+        hipLaunchKernelGGL((nt_gemm_kernel<NtWideH2, 128, true, 256>), dim3(cdiv(am.M, 128), N / 256, grp.G), dim3(NtWideH2::NTHREADS), 0,
+                           st, am, Bmat, ldb, bias, C, ldc, K, c_R, c_bstride, bounds, grp);
+    else if (wide)
+        hipLaunchKernelGGL((nt_gemm_kernel<NtWideX3, 128, false, 256>), dim3(cdiv(am.M, 128), N / 256, grp.G), dim3(NtWideX3::NTHREADS), 0,
+                           st, am, Bmat, ldb, bias, C, ldc, K, c_R, c_bstride, bounds, grp);
     else if (big && h2)
         hipLaunchKernelGGL((nt_gemm_kernel<NtBigH2, 128, true>), gb, dim3(NtBigH2::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
-                           ldc, K, c_R, c_bstride, bounds);
+                           ldc, K, c_R, c_bstride, bounds, grp);
     else if (h2)
         hipLaunchKernelGGL((nt_gemm_kernel<NtSmallH2, 64, true>), gs, dim3(NtSmallH2::NTHREADS), 0, st, am, Bmat, ldb, bias,
-                           C, ldc, K, c_R, c_bstride, bounds);
+                           C, ldc, K, c_R, c_bstride, bounds, grp);
     else if (big && x3)
         hipLaunchKernelGGL((nt_gemm_kernel<NtBigX3, 128>), gb, dim3(NtBigX3::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
-                           ldc, K, c_R, c_bstride, bounds);
+                           ldc, K, c_R, c_bstride, bounds, grp);
     else if (big)
         hipLaunchKernelGGL((nt_gemm_kernel<NtBig, 128>), gb, dim3(NtBig::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
-                           ldc, K, c_R, c_bstride, bounds);
+                           ldc, K, c_R, c_bstride, bounds, grp);
     else if (x3)
         hipLaunchKernelGGL((nt_gemm_kernel<NtSmallX3, 64>), gs, dim3(NtSmallX3::NTHREADS), 0, st, am, Bmat, ldb, bias,
-                           C, ldc, K, c_R, c_bstride, bounds);
+                           C, ldc, K, c_R, c_bstride, bounds, grp);
     else
         hipLaunchKernelGGL((nt_gemm_kernel<NtSmall, 64>), gs, dim3(NtSmall::NTHREADS), 0, st, am, Bmat, ldb, bias,
-                           C, ldc, K, c_R, c_bstride, bounds);
+                           C, ldc, K, c_R, c_bstride, bounds, grp);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -296,7 +315,7 @@ void tn_gemm_plan(int M, int N1, int N2, int* splits, int* rows) {
 }
 
 int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, float* C, int accumulate,
-            hipStream_t st, GemmBounds bounds) {
+            hipStream_t st, GemmBounds bounds, GemmGroup grp) {
     if (N1 % 128 != 0 || N2 % 128 != 0 || am.M != bm.M) return CPC_ERR_SHAPE;
     const long n = (long)N1 * N2;
     if (am.M <= 0) {
@@ -305,14 +324,23 @@ int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, flo
     }
     int S, rows;
     tn_gemm_plan(am.M, N1, N2, &S, &rows);
-    const dim3 grid(8 * (N1 / 128) * (N2 / 128) * cdiv(S, 8));
+    if (grp.G > 1) {                      // the group fills the chip together: fewer row splits per problem (never more than
+        const int tiles = grp.G * (N1 / 128) * (N2 / 128);        // the single-problem plan, which sizes `part`)
+        int Sg = cdiv(768, tiles);
+        if (Sg < 8) Sg = 8;               // the kernel gives split z to XCD z % 8: fewer than 8 splits leave XCDs idle
+        int r = cdiv(cdiv(am.M, Sg), 32) * 32;
+        if (r < rows) r = rows;
+        rows = r;
+        S = cdiv(am.M, rows);
+    }
+    const dim3 grid(8 * (N1 / 128) * (N2 / 128) * cdiv(S, 8), grp.G);
     if (g_mfma_mode >= 2 && g_gemm_split && bounds.a && bounds.b)
-        hipLaunchKernelGGL((tn_gemm_kernel<TnGH2, true>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n, bounds);
+        hipLaunchKernelGGL((tn_gemm_kernel<TnGH2, true>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n, bounds, grp);
     else if (g_mfma_mode != 0)
-        hipLaunchKernelGGL((tn_gemm_kernel<TnGX3>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n, bounds);
+        hipLaunchKernelGGL((tn_gemm_kernel<TnGX3>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n, bounds, grp);
     else
-        hipLaunchKernelGGL((tn_gemm_kernel<TnG>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n, bounds);
-    hipLaunchKernelGGL(split_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, S, n, C, accumulate);
+        hipLaunchKernelGGL((tn_gemm_kernel<TnG>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n, bounds, grp);
+    hipLaunchKernelGGL(split_reduce_kernel, dim3(cdiv(n, 256), grp.G), dim3(256), 0, st, part, S, n, C, accumulate, grp.c, grp.part);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -357,8 +385,8 @@ int tn_gemm_batch(int nprob, const RowMap* am, int N1, const RowMap* bm, int N2,
     return 0;
 }
 
-int transpose(const float* in, float* out, int R, int Cn, hipStream_t st) {
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cn, 32), cdiv(R, 32)), dim3(256), 0, st, in, out, R, Cn);
+int transpose(const float* in, float* out, int R, int Cn, hipStream_t st, int G, long in_gs, long out_gs) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cn, 32), cdiv(R, 32), G), dim3(256), 0, st, in, out, R, Cn, in_gs, out_gs);
     CPC_LAUNCH_CHECK();
     return 0;
 }

@@ -55,6 +55,15 @@ __device__ __forceinline__ void stage_relpos(float* dst, const float* __restrict
     }
 }
 
+// G layers of one shape run in lock-step, one launch per kernel for all of them (blockIdx.y / .z = layer): the K transformer
+// predictors of the criterion (cpc/criterion/criterion.py:82-88) are K such layers on the same input.  Layer g works at the
+// given pointers + g * stride (floats): `saved` / `scratch` are G workspaces of tf_layout's sizes back to back, parameters and
+// their gradients are stacked per kind (par[i]: stride of params[i] and grads[i]; 0 when G == 1).
+struct TfStrides {
+    long saved = 0, scratch = 0;
+    long par[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+};
+
 // ------------------------------------------------------------------ dropout (cpc/transformers.py:18,50 and :93,100)
 // The reference applies nn.Dropout(0.1) to the attention probabilities and to the feed-forward hidden layer in training
 // mode.  Here the keep decision of an element is a pure function of (seed, site, element index) -- Philox4x32-10, the
@@ -86,8 +95,14 @@ __device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)(
 // drop_p > 0 (training): the probabilities that multiply V are A * keep / (1 - p); A itself (pre-dropout) is what is saved.
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                        float* __restrict__ o, float* __restrict__ A, int S, float drop_p,
-                                                       unsigned long long seed) {
+                                                       unsigned long long seed, TfStrides gs) {
     __shared__ float lds[3 * kSmax * kLdH + kDk * kLdS + 4 * 32 * kLdS];     // 133 KB of the CU's 160 KB
+    {                                                 // layer blockIdx.y of a group (TfStrides); its dropout stream: seed + layer
+        const long g = blockIdx.y;
+        qkv += g * gs.saved; o += g * gs.saved; A += g * gs.saved;
+        if (P != nullptr) P += g * gs.par[4];
+        seed += (unsigned long long)g;
+    }
     float* Qs = lds;
     float* Ks = Qs + kSmax * kLdH;
     float* Vs = Ks + kSmax * kLdH;
@@ -199,8 +214,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ o, const float* __restrict__ A,
                                                        const float* __restrict__ dO, float* __restrict__ dqkv,
                                                        float* __restrict__ dPpart, int S, float drop_p,
-                                                       unsigned long long seed) {
+                                                       unsigned long long seed, TfStrides gs) {
     __shared__ float lds[4 * kSmax * kLdH + kDk * kLdS + kSmax * kLdS];      // 150 KB
+    {
+        const long g = blockIdx.y;
+        qkv += g * gs.saved; o += g * gs.saved; A += g * gs.saved;
+        dO += g * gs.scratch; dqkv += g * gs.scratch; dPpart += g * gs.scratch;
+        if (P != nullptr) P += g * gs.par[4];
+        seed += (unsigned long long)g;
+    }
     float* Qs = lds;
     float* Ks = Qs + kSmax * kLdH;
     float* Vs = Ks + kSmax * kLdH;
@@ -339,10 +361,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ out, float* __restrict__ xhat,
-                                                         float* __restrict__ rstd, int M) {
+                                                         float* __restrict__ rstd, int M, long a_gs, long b_gs, long w_gs,
+                                                         long out_gs, int out_ld, long xh_gs) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
+    {                                                 // layer blockIdx.y of a group: rows of `out` are out_ld floats apart
+        const long g = blockIdx.y;
+        a += g * a_gs; b += g * b_gs; w += g * w_gs; bias += g * w_gs; out += g * out_gs; xhat += g * xh_gs; rstd += g * xh_gs;
+    }
     const float4 va = *reinterpret_cast<const float4*>(a + row * kC + 4 * lane);
     const float4 vb = *reinterpret_cast<const float4*>(b + row * kC + 4 * lane);
     float x[4] = {va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w};
@@ -358,7 +385,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
     xh.x = d[0] * rs; xh.y = d[1] * rs; xh.z = d[2] * rs; xh.w = d[3] * rs;
     y.x = xh.x * vw.x + vbi.x; y.y = xh.y * vw.y + vbi.y; y.z = xh.z * vw.z + vbi.z; y.w = xh.w * vw.w + vbi.w;
     *reinterpret_cast<float4*>(xhat + row * kC + 4 * lane) = xh;
-    *reinterpret_cast<float4*>(out + row * kC + 4 * lane) = y;
+    *reinterpret_cast<float4*>(out + row * out_ld + 4 * lane) = y;
     if (lane == 0) rstd[row] = rs;
 }
 
@@ -369,15 +396,21 @@ constexpr int kLnRowsPerBlock = 32;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                      const float* __restrict__ rstd, const float* __restrict__ w,
                                                      const float* __restrict__ add, float* __restrict__ dx,
-                                                     float* __restrict__ part, int M) {
+                                                     float* __restrict__ part, int M, long dy_gs, int dy_ld, long xh_gs,
+                                                     long w_gs, long dx_gs, long part_gs) {
     __shared__ float red[4][2][kC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    {                                                 // layer blockIdx.y of a group: rows of dy are dy_ld floats apart
+        const long g = blockIdx.y;
+        dy += g * dy_gs; xhat += g * xh_gs; rstd += g * xh_gs; w += g * w_gs; dx += g * dx_gs; part += g * part_gs;
+        if (add != nullptr) add += g * dx_gs;
+    }
     const float4 vw = *reinterpret_cast<const float4*>(w + 4 * lane);
     float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < kLnRowsPerBlock / 4; ++it) {
         const long row = (long)blockIdx.x * kLnRowsPerBlock + it * 4 + wv;
         if (row >= M) break;                                       // wave-uniform
-        const float4 g4 = *reinterpret_cast<const float4*>(dy + row * kC + 4 * lane);
+        const float4 g4 = *reinterpret_cast<const float4*>(dy + row * dy_ld + 4 * lane);
         const float4 x4 = *reinterpret_cast<const float4*>(xhat + row * kC + 4 * lane);
         const float gy[4] = {g4.x, g4.y, g4.z, g4.w}, xh[4] = {x4.x, x4.y, x4.z, x4.w};
         const float ww[4] = {vw.x, vw.y, vw.z, vw.w};
@@ -411,9 +444,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // x = relu(x), then (drop_p > 0) the hidden layer's dropout: x *= keep / (1 - p)   (transformers.py:93,100)
-__global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, long n4, float drop_p, unsigned long long seed) {
+__global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, long n4, float drop_p, unsigned long long seed,
+                                                   long x_gs) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
+    x += (long)blockIdx.y * x_gs;                     // layer blockIdx.y of a group, dropout stream seed + layer
+    seed += (unsigned long long)blockIdx.y;
     float4 v = reinterpret_cast<float4*>(x)[i];
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     if (drop_p > 0.f) {
@@ -427,9 +463,12 @@ __global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, long n
 }
 // g *= (y > 0) * scale, y the SAVED hidden layer: it is zero where the ReLU cut or the dropout dropped, so the product of
 // the two derivatives is scale = 1 / (1 - p) exactly where y > 0
-__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, long n4, float scale) {
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, long n4, float scale,
+                                                       long g_gs, long y_gs) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
+    g += (long)blockIdx.y * g_gs;
+    y += (long)blockIdx.y * y_gs;
     float4 v = reinterpret_cast<float4*>(g)[i];
     const float4 a = reinterpret_cast<const float4*>(y)[i];
     v.x = a.x > 0.f ? v.x * scale : 0.f; v.y = a.y > 0.f ? v.y * scale : 0.f;
@@ -452,9 +491,31 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ o
     }
     out[i] = bits >= th ? sc : 0.f;
 }
-__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const float* __restrict__ b, long n4) {
+// dst[0:n] = src[0:n] for G (dst, src) pairs dst_gs / src_gs floats apart (blockIdx.y)
+__global__ __launch_bounds__(256) void gcopy_kernel(float* __restrict__ dst, const float* __restrict__ src, long n, long dst_gs,
+                                                    long src_gs) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[(long)blockIdx.y * dst_gs + i] = src[(long)blockIdx.y * src_gs + i];
+}
+static void gcopy(float* dst, const float* src, long n, int G, long dst_gs, long src_gs, hipStream_t st) {
+    hipLaunchKernelGGL(gcopy_kernel, dim3(cdiv(n, 256), G), dim3(256), 0, st, dst, src, n, dst_gs, src_gs);
+}
+// out[0:n4*4] = sum_g a[g * a_gs + .]: the gradients of G layers that shared one input
+__global__ __launch_bounds__(256) void gsum_kernel(float* __restrict__ out, const float* __restrict__ a, long n4, int G, long a_gs) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
+    float4 v = reinterpret_cast<const float4*>(a)[i];
+    for (int g = 1; g < G; ++g) {
+        const float4 u = reinterpret_cast<const float4*>(a + (long)g * a_gs)[i];
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = v;
+}
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const float* __restrict__ b, long n4, long a_gs, long b_gs) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    a += (long)blockIdx.y * a_gs;
+    b += (long)blockIdx.y * b_gs;
     float4 v = reinterpret_cast<float4*>(a)[i];
     const float4 u = reinterpret_cast<const float4*>(b)[i];
     v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
@@ -504,6 +565,139 @@ static bool tf_layout(int B, int S, TfLayout& t) {
     return true;
 }
 
+// Host-side description of a group call: the strides the kernels need (TfStrides) + those of the tensors the caller owns.
+struct TfGroup {
+    int G = 1;
+    TfStrides ks;                 // saved / scratch / parameter strides
+    long x = 0;                   // input of layer g at x + g * x (0: all layers read the same input)
+    long out = 0; int out_ld = kC;   // forward output of layer g at out + g * out, rows out_ld floats apart
+    long dy = 0; int dy_ld = kC;     // backward input, same addressing
+    long dx = 0;                  // backward output of layer g at dx + g * dx (dense (M,256))
+};
+
+// strides of a group of G stacked layers (cpc_transformer_group_*)
+static TfGroup tf_group(const TfLayout& t, int G, int S) {
+    TfGroup tg;
+    tg.G = G;
+    tg.ks.saved = t.saved_total;
+    tg.ks.scratch = 0;                   // set by the caller's direction: forward / backward workspaces differ in size
+    const long numel[13] = {(long)kC * kC, (long)kC * kC, (long)kC * kC, (long)kC * kC, (long)kDk * S, kC, kC,
+                            (long)kDff * kC, kDff, (long)kC * kDff, kC, kC, kC};
+    for (int i = 0; i < 13; ++i) tg.ks.par[i] = numel[i];
+    return tg;
+}
+
+static int tf_forward(const TfGroup& tg, const float* x, const float* const* params, float* saved, float* scratch, float* out,
+                      int B, int S, float p, unsigned long long seed, hipStream_t st) {
+    TfLayout t;
+    if (!tf_layout(B, S, t)) return CPC_ERR_SHAPE;
+    const int M = B * S, G = tg.G;
+    const long sv = tg.ks.saved, sc = tg.ks.scratch;
+    const long* ps = tg.ks.par;
+    const float *Wo = params[0], *Wk = params[1], *Wq = params[2], *Wv = params[3], *P = params[4];
+    float* qkv = saved + t.qkv;
+    const RowMap xm = plain_rows(x, M, kC);
+    auto grp = [&](long a, long b, long bias, long c) { GemmGroup g; g.G = G; g.a = a; g.b = b; g.bias = bias; g.c = c; return g; };
+    int rc;
+    if ((rc = nt_gemm(xm, Wq, kC, nullptr, qkv, 3 * kC, kC, kC, st, 0, 0, GemmBounds(), grp(tg.x, ps[2], 0, sv)))) return rc;
+    if ((rc = nt_gemm(xm, Wk, kC, nullptr, qkv + kC, 3 * kC, kC, kC, st, 0, 0, GemmBounds(), grp(tg.x, ps[1], 0, sv)))) return rc;
+    if ((rc = nt_gemm(xm, Wv, kC, nullptr, qkv + 2 * kC, 3 * kC, kC, kC, st, 0, 0, GemmBounds(), grp(tg.x, ps[3], 0, sv)))) return rc;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * kTH, G), dim3(256), 0, st, qkv, P, saved + t.o, saved + t.A, S, p, seed, tg.ks);
+    CPC_LAUNCH_CHECK();
+    float* att = scratch;
+    if ((rc = nt_gemm(plain_rows(saved + t.o, M, kC), Wo, kC, nullptr, att, kC, kC, kC, st, 0, 0, GemmBounds(), grp(sv, ps[0], 0, sc))))
+        return rc;
+    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, 4), G), dim3(256), 0, st, x, att, params[5], params[6],
+                       saved + t.y, saved + t.xhat1, saved + t.rstd1, M, tg.x, sc, ps[5], sv, kC, sv);
+    if ((rc = nt_gemm(plain_rows(saved + t.y, M, kC), params[7], kC, params[8], saved + t.hid, kDff, kDff, kC, st, 0, 0,
+                      GemmBounds(), grp(sv, ps[7], ps[8], sv)))) return rc;
+    hipLaunchKernelGGL(relu_kernel, dim3(cdiv((long)M * kDff / 4, 256), G), dim3(256), 0, st, saved + t.hid, (long)M * kDff / 4, p,
+                       seed, sv);
+    float* ff = scratch;
+    if ((rc = nt_gemm(plain_rows(saved + t.hid, M, kDff), params[9], kDff, params[10], ff, kC, kC, kDff, st, 0, 0, GemmBounds(),
+                      grp(sv, ps[9], ps[10], sc)))) return rc;
+    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, 4), G), dim3(256), 0, st, saved + t.y, ff, params[11], params[12],
+                       out, saved + t.xhat2, saved + t.rstd2, M, sv, sc, ps[11], tg.out, tg.out_ld, sv);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+static int tf_backward(const TfGroup& tg, const float* x, const float* const* params, const float* saved, const float* dy,
+                       float* scratch, float* dx, float* const* grads, int B, int S, float p, unsigned long long seed,
+                       hipStream_t st) {
+    TfLayout t;
+    if (!tf_layout(B, S, t)) return CPC_ERR_SHAPE;
+    const int M = B * S, G = tg.G;
+    const long sv = tg.ks.saved, sc = tg.ks.scratch;
+    const long* ps = tg.ks.par;
+    const long n4 = (long)M * kC / 4;
+    const int nblk = cdiv(M, kLnRowsPerBlock);
+    const float *Wo = params[0], *Wk = params[1], *Wq = params[2], *Wv = params[3], *P = params[4];
+    const float *W1 = params[7], *W2 = params[9];
+    float *ds2 = scratch + t.ds2, *dhid = scratch + t.dhid, *dyb = scratch + t.dyb, *ds1 = scratch + t.ds1;
+    float *dob = scratch + t.dob, *dqkv = scratch + t.dqkv, *part = scratch + t.part, *lnpart = scratch + t.lnpart;
+    float *tmp = scratch + t.tmp;
+    auto grp = [&](long a, long b, long c) { GemmGroup g; g.G = G; g.a = a; g.b = b; g.c = c; g.part = sc; return g; };
+    int rc;
+    // out = LN2(y + ff)
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk, G), dim3(256), 0, st, dy, saved + t.xhat2, saved + t.rstd2, params[11],
+                       (const float*)nullptr, ds2, lnpart, M, tg.dy, tg.dy_ld, sv, ps[11], sc, sc);
+    if ((rc = rows_sum(lnpart, nblk, 2 * kC, tmp, dhid, st, G, sc, sc, sc))) return rc;          // dhid as a 512-float staging area
+    gcopy(grads[11], dhid, kC, G, ps[11], sc, st);
+    gcopy(grads[12], dhid + kC, kC, G, ps[12], sc, st);
+    // ff = hid W2^T + b2
+    const RowMap ds2m = plain_rows(ds2, M, kC), hidm = plain_rows(saved + t.hid, M, kDff);
+    if ((rc = tn_gemm(ds2m, kC, hidm, kDff, part, grads[9], 0, st, GemmBounds(), grp(sc, sv, ps[9])))) return rc;   // dW2 (256,2048)
+    if ((rc = rows_sum(ds2, M, kC, tmp, grads[10], st, G, sc, sc, ps[10]))) return rc;
+    if ((rc = transpose(W2, scratch + t.w2t, kC, kDff, st, G, ps[9], sc))) return rc;           // (256,2048) -> (2048,256)
+    if ((rc = nt_gemm(ds2m, scratch + t.w2t, kC, nullptr, dhid, kDff, kDff, kC, st, 0, 0, GemmBounds(), grp(sc, sc, sc)))) return rc;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(cdiv((long)M * kDff / 4, 256), G), dim3(256), 0, st, dhid, saved + t.hid,
+                       (long)M * kDff / 4, 1.0f / (1.0f - p), sc, sv);
+    // hid = relu(y W1^T + b1)
+    const RowMap dhm = plain_rows(dhid, M, kDff), ym = plain_rows(saved + t.y, M, kC);
+    if ((rc = tn_gemm(dhm, kDff, ym, kC, part, grads[7], 0, st, GemmBounds(), grp(sc, sv, ps[7])))) return rc;      // dW1 (2048,256)
+    if ((rc = rows_sum(dhid, M, kDff, tmp, grads[8], st, G, sc, sc, ps[8]))) return rc;
+    if ((rc = transpose(W1, scratch + t.w1t, kDff, kC, st, G, ps[7], sc))) return rc;           // (2048,256) -> (256,2048)
+    if ((rc = nt_gemm(dhm, scratch + t.w1t, kDff, nullptr, dyb, kC, kC, kDff, st, 0, 0, GemmBounds(), grp(sc, sc, sc)))) return rc;
+    hipLaunchKernelGGL(add_kernel, dim3(cdiv(n4, 256), G), dim3(256), 0, st, dyb, ds2, n4, sc, sc);   // dy_total = ds2 + dhid W1
+    // y = LN1(x + att)
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk, G), dim3(256), 0, st, dyb, saved + t.xhat1, saved + t.rstd1, params[5],
+                       (const float*)nullptr, ds1, lnpart, M, sc, kC, sv, ps[5], sc, sc);
+    if ((rc = rows_sum(lnpart, nblk, 2 * kC, tmp, dhid, st, G, sc, sc, sc))) return rc;
+    gcopy(grads[5], dhid, kC, G, ps[5], sc, st);
+    gcopy(grads[6], dhid + kC, kC, G, ps[6], sc, st);
+    // att = o Wo^T
+    const RowMap ds1m = plain_rows(ds1, M, kC);
+    if ((rc = tn_gemm(ds1m, kC, plain_rows(saved + t.o, M, kC), kC, part, grads[0], 0, st, GemmBounds(), grp(sc, sv, ps[0])))) return rc;
+    if ((rc = transpose(Wo, scratch + t.wot, kC, kC, st, G, ps[0], sc))) return rc;
+    if ((rc = nt_gemm(ds1m, scratch + t.wot, kC, nullptr, dob, kC, kC, kC, st, 0, 0, GemmBounds(), grp(sc, sc, sc)))) return rc;
+    // attention
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * kTH, G), dim3(256), 0, st, saved + t.qkv, P, saved + t.o,
+                       saved + t.A, dob, dqkv, scratch + t.dppart, S, p, seed, tg.ks);
+    CPC_LAUNCH_CHECK();
+    if (P != nullptr && (rc = rows_sum(scratch + t.dppart, B * kTH, kDk * S, tmp, grads[4], st, G, sc, sc, ps[4]))) return rc;
+    // projections
+    const RowMap xm = plain_rows(x, M, kC);
+    if ((rc = tn_gemm(plain_rows(dqkv, M, 3 * kC), kC, xm, kC, part, grads[2], 0, st, GemmBounds(), grp(sc, tg.x, ps[2])))) return rc;            // dWq
+    if ((rc = tn_gemm(plain_rows(dqkv + kC, M, 3 * kC), kC, xm, kC, part, grads[1], 0, st, GemmBounds(), grp(sc, tg.x, ps[1])))) return rc;       // dWk
+    if ((rc = tn_gemm(plain_rows(dqkv + 2 * kC, M, 3 * kC), kC, xm, kC, part, grads[3], 0, st, GemmBounds(), grp(sc, tg.x, ps[3])))) return rc;   // dWv
+    float* wqkv = scratch + t.wqkv;                                               // [Wq; Wk; Wv] (768,256)
+    gcopy(wqkv, Wq, (long)kC * kC, G, sc, ps[2], st);
+    gcopy(wqkv + kC * kC, Wk, (long)kC * kC, G, sc, ps[1], st);
+    gcopy(wqkv + 2 * kC * kC, Wv, (long)kC * kC, G, sc, ps[3], st);
+    if ((rc = transpose(wqkv, scratch + t.wqkvt, 3 * kC, kC, st, G, sc, sc))) return rc;     // -> (256,768)
+    // dx of layer g: into the caller's buffer when every layer has its own, else into ds2 (free by now) for the sum below
+    float* dxg = (G > 1 && tg.dx == 0) ? ds2 : dx;
+    const long dxg_gs = (G > 1 && tg.dx == 0) ? sc : tg.dx;
+    if ((rc = nt_gemm(plain_rows(dqkv, M, 3 * kC), scratch + t.wqkvt, 3 * kC, nullptr, dxg, kC, kC, 3 * kC, st, 0, 0, GemmBounds(),
+                      grp(sc, sc, dxg_gs)))) return rc;
+    hipLaunchKernelGGL(add_kernel, dim3(cdiv(n4, 256), G), dim3(256), 0, st, dxg, ds1, n4, dxg_gs, sc);   // + the residual branch
+    if (dxg != dx)                                                                // layers that shared x: dx = sum over them
+        hipLaunchKernelGGL(gsum_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dx, dxg, n4, G, dxg_gs);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace cpc
 
 using namespace cpc;
@@ -533,32 +727,8 @@ extern "C" int cpc_transformer_layer_forward_dropout(const float* x, const float
                                                      float* scratch, float* out, int B, int S, float p,
                                                      unsigned long long seed, void* stream) {
     CPC_RETURN_IF(!(p >= 0.f && p < 1.f), CPC_ERR_ARG);
-    TfLayout t;
-    CPC_RETURN_IF(!tf_layout(B, S, t), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!x || !params || !saved || !scratch || !out, CPC_ERR_ARG);
-    hipStream_t st = (hipStream_t)stream;
-    const int M = B * S;
-    const float *Wo = params[0], *Wk = params[1], *Wq = params[2], *Wv = params[3], *P = params[4];
-    float* qkv = saved + t.qkv;
-    const RowMap xm = plain_rows(x, M, kC);
-    int rc;
-    if ((rc = nt_gemm(xm, Wq, kC, nullptr, qkv, 3 * kC, kC, kC, st))) return rc;
-    if ((rc = nt_gemm(xm, Wk, kC, nullptr, qkv + kC, 3 * kC, kC, kC, st))) return rc;
-    if ((rc = nt_gemm(xm, Wv, kC, nullptr, qkv + 2 * kC, 3 * kC, kC, kC, st))) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * kTH), dim3(256), 0, st, qkv, P, saved + t.o, saved + t.A, S, p, seed);
-    CPC_LAUNCH_CHECK();
-    float* att = scratch;
-    if ((rc = nt_gemm(plain_rows(saved + t.o, M, kC), Wo, kC, nullptr, att, kC, kC, kC, st))) return rc;
-    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, att, params[5], params[6],
-                       saved + t.y, saved + t.xhat1, saved + t.rstd1, M);
-    if ((rc = nt_gemm(plain_rows(saved + t.y, M, kC), params[7], kC, params[8], saved + t.hid, kDff, kDff, kC, st))) return rc;
-    hipLaunchKernelGGL(relu_kernel, dim3(cdiv((long)M * kDff / 4, 256)), dim3(256), 0, st, saved + t.hid, (long)M * kDff / 4, p, seed);
-    float* ff = scratch;
-    if ((rc = nt_gemm(plain_rows(saved + t.hid, M, kDff), params[9], kDff, params[10], ff, kC, kC, kDff, st))) return rc;
-    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, saved + t.y, ff, params[11], params[12],
-                       out, saved + t.xhat2, saved + t.rstd2, M);
-    CPC_LAUNCH_CHECK();
-    return 0;
+    return tf_forward(TfGroup(), x, params, saved, scratch, out, B, S, p, seed, (hipStream_t)stream);
 }
 
 // dy (B,S,256) -> dx (B,S,256) and grads[13] (same order as params; grads[4] ignored when params[4] is NULL).
@@ -573,70 +743,40 @@ extern "C" int cpc_transformer_layer_backward_dropout(const float* x, const floa
                                                       const float* dy, float* scratch, float* dx, float* const* grads,
                                                       int B, int S, float p, unsigned long long seed, void* stream) {
     CPC_RETURN_IF(!(p >= 0.f && p < 1.f), CPC_ERR_ARG);
+    CPC_RETURN_IF(!x || !params || !saved || !dy || !scratch || !dx || !grads, CPC_ERR_ARG);
+    return tf_backward(TfGroup(), x, params, saved, dy, scratch, dx, grads, B, S, p, seed, (hipStream_t)stream);
+}
+
+// G transformer layers of one shape on ONE input x (B,S,256) in lock-step -- the K predictors of the criterion in
+// --rnnMode transformer (cpc/criterion/criterion.py:82-88, :97-118): every kernel of the layer is launched once for all of
+// them instead of G times (G = 12 at B = 64: 17 -> 8 ms per train step, mostly because a 7424-row GEMM alone cannot fill the
+// chip).  params[i] / grads[i]: the G tensors of kind i stacked (layer g at + g * numel); saved / scratch: G workspaces of
+// cpc_transformer_layout's sizes back to back.  out / dy: (B*S, G*256), layer g at columns g*256.. (the layout the score
+// kernels read); dx (B,S,256) = the SUM of the layers' input gradients.  Layer g's dropout masks are those of a single-layer
+// call with seed + g.
+extern "C" int cpc_transformer_group_forward(const float* x, const float* const* params, float* saved, float* scratch,
+                                             float* out, int B, int S, int G, float p, unsigned long long seed, void* stream) {
+    CPC_RETURN_IF(!(p >= 0.f && p < 1.f) || G <= 0 || G > 64, CPC_ERR_ARG);
+    CPC_RETURN_IF(!x || !params || !saved || !scratch || !out, CPC_ERR_ARG);
     TfLayout t;
     CPC_RETURN_IF(!tf_layout(B, S, t), CPC_ERR_SHAPE);
+    TfGroup tg = tf_group(t, G, S);
+    tg.ks.scratch = t.fwd_total;
+    tg.out = kC; tg.out_ld = G * kC;
+    return tf_forward(tg, x, params, saved, scratch, out, B, S, p, seed, (hipStream_t)stream);
+}
+
+extern "C" int cpc_transformer_group_backward(const float* x, const float* const* params, const float* saved, const float* dy,
+                                              float* scratch, float* dx, float* const* grads, int B, int S, int G, float p,
+                                              unsigned long long seed, void* stream) {
+    CPC_RETURN_IF(!(p >= 0.f && p < 1.f) || G <= 0 || G > 64, CPC_ERR_ARG);
     CPC_RETURN_IF(!x || !params || !saved || !dy || !scratch || !dx || !grads, CPC_ERR_ARG);
-    hipStream_t st = (hipStream_t)stream;
-    const int M = B * S;
-    const long n4 = (long)M * kC / 4;
-    const int nblk = cdiv(M, kLnRowsPerBlock);
-    const float *Wo = params[0], *Wk = params[1], *Wq = params[2], *Wv = params[3], *P = params[4];
-    const float *W1 = params[7], *W2 = params[9];
-    float *ds2 = scratch + t.ds2, *dhid = scratch + t.dhid, *dyb = scratch + t.dyb, *ds1 = scratch + t.ds1;
-    float *dob = scratch + t.dob, *dqkv = scratch + t.dqkv, *part = scratch + t.part, *lnpart = scratch + t.lnpart;
-    float *tmp = scratch + t.tmp;
-    int rc;
-    // out = LN2(y + ff)
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, saved + t.xhat2, saved + t.rstd2, params[11],
-                       (const float*)nullptr, ds2, lnpart, M);
-    if ((rc = rows_sum(lnpart, nblk, 2 * kC, tmp, dhid, st))) return rc;          // dhid as a 512-float staging area
-    (void)hipMemcpyAsync(grads[11], dhid, kC * sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(grads[12], dhid + kC, kC * sizeof(float), hipMemcpyDeviceToDevice, st);
-    // ff = hid W2^T + b2
-    const RowMap ds2m = plain_rows(ds2, M, kC), hidm = plain_rows(saved + t.hid, M, kDff);
-    if ((rc = tn_gemm(ds2m, kC, hidm, kDff, part, grads[9], 0, st))) return rc;   // dW2 (256,2048)
-    if ((rc = rows_sum(ds2, M, kC, tmp, grads[10], st))) return rc;
-    if ((rc = transpose(W2, scratch + t.w2t, kC, kDff, st))) return rc;           // (256,2048) -> (2048,256)
-    if ((rc = nt_gemm(ds2m, scratch + t.w2t, kC, nullptr, dhid, kDff, kDff, kC, st))) return rc;
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(cdiv((long)M * kDff / 4, 256)), dim3(256), 0, st, dhid, saved + t.hid,
-                       (long)M * kDff / 4, 1.0f / (1.0f - p));
-    // hid = relu(y W1^T + b1)
-    const RowMap dhm = plain_rows(dhid, M, kDff), ym = plain_rows(saved + t.y, M, kC);
-    if ((rc = tn_gemm(dhm, kDff, ym, kC, part, grads[7], 0, st))) return rc;      // dW1 (2048,256)
-    if ((rc = rows_sum(dhid, M, kDff, tmp, grads[8], st))) return rc;
-    if ((rc = transpose(W1, scratch + t.w1t, kDff, kC, st))) return rc;           // (2048,256) -> (256,2048)
-    if ((rc = nt_gemm(dhm, scratch + t.w1t, kDff, nullptr, dyb, kC, kC, kDff, st))) return rc;
-    hipLaunchKernelGGL(add_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dyb, ds2, n4);   // dy_total = ds2 + dhid W1
-    // y = LN1(x + att)
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, st, dyb, saved + t.xhat1, saved + t.rstd1, params[5],
-                       (const float*)nullptr, ds1, lnpart, M);
-    if ((rc = rows_sum(lnpart, nblk, 2 * kC, tmp, dhid, st))) return rc;
-    (void)hipMemcpyAsync(grads[5], dhid, kC * sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(grads[6], dhid + kC, kC * sizeof(float), hipMemcpyDeviceToDevice, st);
-    // att = o Wo^T
-    const RowMap ds1m = plain_rows(ds1, M, kC);
-    if ((rc = tn_gemm(ds1m, kC, plain_rows(saved + t.o, M, kC), kC, part, grads[0], 0, st))) return rc;
-    if ((rc = transpose(Wo, scratch + t.wot, kC, kC, st))) return rc;
-    if ((rc = nt_gemm(ds1m, scratch + t.wot, kC, nullptr, dob, kC, kC, kC, st))) return rc;
-    // attention
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * kTH), dim3(256), 0, st, saved + t.qkv, P, saved + t.o,
-                       saved + t.A, dob, dqkv, scratch + t.dppart, S, p, seed);
-    CPC_LAUNCH_CHECK();
-    if (P != nullptr && (rc = rows_sum(scratch + t.dppart, B * kTH, kDk * S, tmp, grads[4], st))) return rc;
-    // projections
-    const RowMap xm = plain_rows(x, M, kC);
-    if ((rc = tn_gemm(plain_rows(dqkv, M, 3 * kC), kC, xm, kC, part, grads[2], 0, st))) return rc;            // dWq
-    if ((rc = tn_gemm(plain_rows(dqkv + kC, M, 3 * kC), kC, xm, kC, part, grads[1], 0, st))) return rc;       // dWk
-    if ((rc = tn_gemm(plain_rows(dqkv + 2 * kC, M, 3 * kC), kC, xm, kC, part, grads[3], 0, st))) return rc;   // dWv
-    float* wqkv = scratch + t.wqkv;                                               // [Wq; Wk; Wv] (768,256)
-    (void)hipMemcpyAsync(wqkv, Wq, (size_t)kC * kC * sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(wqkv + kC * kC, Wk, (size_t)kC * kC * sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(wqkv + 2 * kC * kC, Wv, (size_t)kC * kC * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if ((rc = transpose(wqkv, scratch + t.wqkvt, 3 * kC, kC, st))) return rc;     // -> (256,768)
-    if ((rc = nt_gemm(plain_rows(dqkv, M, 3 * kC), scratch + t.wqkvt, 3 * kC, nullptr, dx, kC, kC, 3 * kC, st))) return rc;
-    hipLaunchKernelGGL(add_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dx, ds1, n4);   // + the residual branch
-    CPC_LAUNCH_CHECK();
-    return 0;
+    TfLayout t;
+    CPC_RETURN_IF(!tf_layout(B, S, t), CPC_ERR_SHAPE);
+    TfGroup tg = tf_group(t, G, S);
+    tg.ks.scratch = t.bwd_total;
+    tg.dy = kC; tg.dy_ld = G * kC;
+    return tf_backward(tg, x, params, saved, dy, scratch, dx, grads, B, S, p, seed, (hipStream_t)stream);
 }
 
 // Test helper: out[i] = keep_i / (1 - p) for element i of dropout site `site` (0: attention probabilities, flat

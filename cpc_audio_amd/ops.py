@@ -536,6 +536,63 @@ class InfoNCEScoresFunction(torch.autograd.Function):
         return dpred, dz, None, None, None
 
 
+class TransformerGroupFunction(torch.autograd.Function):
+    """x (B,S,256), dropout probability, seed, G + the 13 parameter kinds of G TransformerLayers, each stacked (G, ...)
+    (Krelpos possibly None) -> (B,S,G*256), layer g at columns g*256..: the K transformer predictors of the criterion on the
+    same input, every kernel launched once for all of them (cpc_transformer_group_{forward,backward}).  Layer g's dropout
+    masks are those of a single-layer call with seed + g."""
+
+    @staticmethod
+    def forward(ctx, x, drop_p, seed, G, *params):
+        _require_cuda(x, "TransformerGroupFunction")
+        lib = _lib.get()
+        B, S, D = x.shape
+        if D != _HID:
+            raise NotImplementedError("the HIP transformer layer is built for d_model == 256")
+        if S > 128:
+            raise NotImplementedError("the HIP attention kernels hold sequences of at most 128 steps")
+        x = x.contiguous()
+        params = [None if p is None else p.detach().contiguous() for p in params]
+        if any(p is not None and p.shape[0] != G for p in params):
+            raise ValueError("TransformerGroupFunction: every parameter kind must be stacked (G, ...)")
+        if params[4] is not None and tuple(params[4].shape[1:]) != (32, S):
+            raise ValueError(f"Krelpos is {tuple(params[4].shape[1:])}; the layers were built for sequences of "
+                             f"{params[4].shape[2]} steps, got {S} (cpc/transformers.py:22-24)")
+        with torch.cuda.device(x.device):
+            sizes = _layout("transformer_layout", lib.cpc_transformer_layout, 8, B, S)
+            saved = torch.empty(G * sizes[0], device=x.device, dtype=torch.float32)
+            scratch = torch.empty(G * sizes[1], device=x.device, dtype=torch.float32)
+            out = torch.empty(B, S, G * _HID, device=x.device, dtype=torch.float32)
+            lib.check(lib.cpc_transformer_group_forward(_p(x), _ptrs(params), _p(saved), _p(scratch), _p(out), B, S, G,
+                                                        float(drop_p), int(seed), _stream()), "transformer_group_forward")
+        ctx.drop = (float(drop_p), int(seed))
+        if KEEP_DEBUG:                      # one entry per layer, as G single-layer calls would leave
+            for g in range(G):
+                debug_last.setdefault("transformer", []).append((saved[g * sizes[0]:(g + 1) * sizes[0]], sizes))
+        ctx.has_rel = params[4] is not None
+        ctx.step = current()
+        ctx.save_for_backward(x, saved, *[p for p in params if p is not None])
+        ctx.dims = (B, S, G, sizes[2])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.get()
+        x, saved, *ps = ctx.saved_tensors
+        params = ps if ctx.has_rel else ps[:4] + [None] + ps[4:]
+        B, S, G, nscr = ctx.dims
+        dy = dy.contiguous()
+        with torch.cuda.device(x.device):
+            scratch = torch.empty(G * nscr, device=x.device, dtype=torch.float32)
+            dx = torch.empty_like(x)
+            grads = [None if p is None else torch.empty_like(p) for p in params]
+            lib.check(lib.cpc_transformer_group_backward(_p(x), _ptrs(params), _p(saved), _p(dy), _p(scratch), _p(dx),
+                                                         _ptrs(grads), B, S, G, ctx.drop[0], ctx.drop[1], _stream()),
+                      "transformer_group_backward")
+        _wait(ctx.step, final=False)
+        return (dx, None, None, None, *grads)
+
+
 class TransformerLayerFunction(torch.autograd.Function):
     """x (B,S,256), dropout probability, seed + the 13 layer parameters (state-dict order, Krelpos possibly None) -> (B,S,256).
     One TransformerLayer of cpc/transformers.py:103-111 through cpc_transformer_layer_{forward,backward}_dropout."""

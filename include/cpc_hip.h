@@ -246,6 +246,16 @@ int cpc_transformer_layer_forward_dropout(const float* x, const float* const* pa
 int cpc_transformer_layer_backward_dropout(const float* x, const float* const* params, const float* saved,
                                            const float* dy, float* scratch, float* dx, float* const* grads, int B,
                                            int S, float p, unsigned long long seed, void* stream);
+/* G transformer layers of one shape on ONE input x (B,S,256), every kernel launched once for all of them: the K predictors
+ * of the criterion in --rnnMode transformer (cpc/criterion/criterion.py:82-88, :97-118).  params[i] / grads[i]: the G
+ * tensors of kind i stacked, layer g at + g * numel; saved / scratch: G workspaces of cpc_transformer_layout's sizes back
+ * to back; out / dy: (B*S, G*256) with layer g at columns g*256..; dx (B,S,256): the SUM of the layers' input gradients.
+ * Dropout masks of layer g: those of a single-layer call with seed + g. */
+int cpc_transformer_group_forward(const float* x, const float* const* params, float* saved, float* scratch, float* out,
+                                  int B, int S, int G, float p, unsigned long long seed, void* stream);
+int cpc_transformer_group_backward(const float* x, const float* const* params, const float* saved, const float* dy,
+                                   float* scratch, float* dx, float* const* grads, int B, int S, int G, float p,
+                                   unsigned long long seed, void* stream);
 /* Test helper: out[i] = keep_i / (1 - p) of dropout site 0 (attention probabilities, flat ((b*8 + head)*S + i)*S + j) or
  * 1 (hidden layer, flat row*2048 + col) under `seed`. */
 int cpc_dropout_keep_mask(float* out, long n, int site, float p, unsigned long long seed, void* stream);

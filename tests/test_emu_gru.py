@@ -46,6 +46,23 @@ def _gemm_checks(lib):
     assert rel_err(C, 2 * C0) < 1e-6
 
 
+def test_gemm_nt_wide_tile_emulated():
+    """The 128 x 256 pipelined tile of the plain NT GEMM on three bf16 pieces (taken for N % 256 == 0, K % 64 == 0 once the
+    grid fills the chip; cpc_set_gemm_split(3) forces it at test sizes): ragged M, two column tiles, bias."""
+    lib = emu()
+    assert lib.cpc_set_mfma_mode(1) == 0 and lib.cpc_set_gemm_split(3) == 0
+    try:
+        torch.manual_seed(1)
+        M, N, K = 200, 512, 128
+        A = torch.randn(M, K); Bm = torch.randn(N, K); bias = torch.randn(N)
+        C = torch.full((M, N), float("nan"))
+        assert lib.cpc_gemm_nt(P(A), K, P(Bm), K, P(bias), P(C), N, M, N, K, None) == 0
+        assert rel_err(C, A @ Bm.t() + bias) < 1e-6
+    finally:
+        lib.cpc_set_mfma_mode(_lib_default_mode())
+        lib.cpc_set_gemm_split(1)
+
+
 @pytest.mark.parametrize("B,S,use_h0", [(3, 6, False), (20, 5, True)])
 def test_gru_persistent_equals_stepwise_emulated(B, S, use_h0):
     """The single-launch recurrence (polling hand-over between co-resident workgroups) and the

@@ -101,3 +101,48 @@ def test_transformer_layer_training_dropout_emulated(B, S, abspos, p_drop):
     other = torch.full_like(ffn_keep, float("nan"))
     assert lib.cpc_dropout_keep_mask(P(other), other.numel(), 1, p_drop, seed + 1, None) == 0
     assert not torch.equal(other, ffn_keep)                         # ... another seed draws other masks
+
+
+@pytest.mark.parametrize("abspos,p_drop", [(False, 0.0), (False, 0.2), (True, 0.0)])
+def test_group_of_layers_equals_single_layer_calls_emulated(abspos, p_drop):
+    """cpc_transformer_group_forward / _backward (the K transformer predictors of the criterion run in lock-step, one launch
+    per kernel): layer g of the group == a single-layer call on the same input with layer g's parameters (and seed + g),
+    bit for bit -- outputs interleaved as (B*S, G*256), dx = the sum of the layers' input gradients."""
+    lib = emu()
+    B, S, G = 1, 40, 3
+    prms = [T.make_layer_params(seed=20 + q, size_seq=S, abspos=abspos) for q in range(G)]
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, S, 256, generator=g)
+    dy = torch.randn(B * S, G * 256, generator=g)
+    seed = 0x0123456789ABCDE
+    sizes = (ctypes.c_long * 8)()
+    assert lib.cpc_transformer_layout(B, S, sizes) == 0
+    kinds = [k for k in ORDER if k in prms[0]]
+    stacked = {k: torch.stack([p[k] for p in prms]).contiguous() for k in kinds}
+    parr = (ctypes.c_void_p * 13)(*[P(stacked[k]) if k in stacked else None for k in ORDER])
+    saved = torch.full((G * sizes[0],), float("nan")); fscr = torch.full((G * sizes[1],), float("nan"))
+    bscr = torch.full((G * sizes[2],), float("nan")); out = torch.full((B * S, G * 256), float("nan"))
+    assert lib.cpc_transformer_group_forward(P(x), parr, P(saved), P(fscr), P(out), B, S, G, p_drop, seed, None) == 0
+    dx = torch.full((B, S, 256), float("nan"))
+    sgrads = {k: torch.full_like(v, float("nan")) for k, v in stacked.items()}
+    garr = (ctypes.c_void_p * 13)(*[P(sgrads[k]) if k in sgrads else None for k in ORDER])
+    assert lib.cpc_transformer_group_backward(P(x), parr, P(saved), P(dy), P(bscr), P(dx), garr, B, S, G, p_drop, seed, None) == 0
+    dx_sum = torch.zeros(B, S, 256)
+    for q in range(G):
+        plist = [prms[q][k].contiguous() if k in prms[q] else None for k in ORDER]
+        pq = (ctypes.c_void_p * 13)(*[P(t) for t in plist])
+        sv = torch.full((sizes[0],), float("nan")); fs = torch.full((sizes[1],), float("nan"))
+        bs = torch.full((sizes[2],), float("nan")); o1 = torch.full((B, S, 256), float("nan"))
+        assert lib.cpc_transformer_layer_forward_dropout(P(x), pq, P(sv), P(fs), P(o1), B, S, p_drop, seed + q, None) == 0
+        assert torch.equal(out[:, q * 256:(q + 1) * 256], o1.view(B * S, 256)), q
+        d1 = torch.full((B, S, 256), float("nan"))
+        g1 = [torch.full_like(t, float("nan")) if t is not None else None for t in plist]
+        gq = (ctypes.c_void_p * 13)(*[P(t) for t in g1])
+        dyq = dy[:, q * 256:(q + 1) * 256].contiguous()
+        assert lib.cpc_transformer_layer_backward_dropout(P(x), pq, P(sv), P(dyq), P(bs), P(d1), gq, B, S, p_drop, seed + q,
+                                                          None) == 0
+        for k, t in zip(ORDER, g1):
+            if t is not None:
+                assert torch.equal(sgrads[k][q], t), (q, k)
+        dx_sum += d1
+    assert (dx - dx_sum).abs().max().item() <= 1e-6 * dx_sum.abs().max().item()
