@@ -765,8 +765,9 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     e.bf16 = g_mfma_mode == 4;             // bf16-storage variant: y0..y3, xhat1..4 and every gradient tensor as bf16
     const int nh2 = g_mfma_mode != 3 ? 0 : (g_h2_layers ? g_h2_layers : ((long)B * e.L[2] >= 256L * 200 ? 2 : 1));
     for (int i = 0; i < 4; ++i) e.h2[i] = i < nh2;
-    // layer 1's gradient in H2 storage: its data gradient (the largest GEMM of the backward) runs on the DMA kernel
-    for (int i = 0; i < 5; ++i) e.dxh2[i] = i == 1 && g_h2_dx && e.h2[0];
+    // the gradient of a layer whose input is kept in H2 storage is kept so too: its data gradient runs on the DMA kernel, its
+    // weight gradient reads both operands as pieces (layer 1 always in mode 3, layer 2 where conv2 reads H2 input)
+    for (int i = 0; i < 5; ++i) e.dxh2[i] = (i == 1 || i == 2) && g_h2_dx && e.h2[i - 1];
     long o = 0;
     for (int i = 0; i < 4; ++i) { e.y[i] = o; o += align64((long)B * e.L[i] * kC); }
     e.xhat[0] = -1;
@@ -1269,13 +1270,19 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                                      kGeom[i].s, kGeom[i].p, st);
             if (rc) return rc;
             if (i >= 2) norm_bwd(i - 1, tmpd, xin, scratch + e.dx[i - 1]);
-        } else if (i >= 2 && (e.dxh2[i - 1] || (g_unfuse_big && (g_unfuse_big == 2 || pick_bm(B * (e.L[i] + 1)) == 128)))) {
+        } else if (i >= 2 && (e.dxh2[i] || e.dxh2[i - 1] || (g_unfuse_big && (g_unfuse_big == 2 || pick_bm(B * (e.L[i] + 1)) == 128)))) {
             // the fused ReLU'/ChannelNorm-backward epilogue is latency-bound (row-by-row reductions between the loads); a
-            // plain dgrad into a temporary (dy0 is free until layer 1's dgrad) + the streaming norm backward is faster
+            // plain dgrad into a temporary (dy0 is free until layer 1's dgrad) + the streaming norm backward is faster.
+            // A layer below that keeps its gradient in H2 storage needs max|dy| from this kernel (slots).
             float* tmpd = scratch + e.dy0;
-            rc = conv_dgrad_core(scratch + e.dx[i], saved + e.swd[i], 0, nullptr, nullptr, nullptr, nullptr, tmpd, nullptr,
-                                 nullptr, nullptr, amax + i * kAmaxSlots, nullptr, B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, st, kAmaxSlots,
-                                 e.dxh2[i - 1] ? dyamax + (i - 1) * kAmaxSlots : nullptr);
+            float* slots = e.dxh2[i - 1] ? dyamax + (i - 1) * kAmaxSlots : nullptr;
+            if (e.dxh2[i])
+                rc = conv_dgrad_dma_h2(scratch + e.dx[i], saved + e.swd[i], tmpd, saved + e.szero, dxbound + i, slots, B,
+                                       e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, st);
+            else
+                rc = conv_dgrad_core(scratch + e.dx[i], saved + e.swd[i], 0, nullptr, nullptr, nullptr, nullptr, tmpd, nullptr,
+                                     nullptr, nullptr, amax + i * kAmaxSlots, nullptr, B, e.L[i - 1], kGeom[i].k, kGeom[i].s,
+                                     kGeom[i].p, st, kAmaxSlots, slots);
             if (rc) return rc;
             norm_bwd(i - 1, tmpd, xin, scratch + e.dx[i - 1]);
         } else if (i >= 2) {
