@@ -353,7 +353,13 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_dgr
     constexpr int TM = C::TM, TN = C::TN;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES];
     const int lane = threadIdx.x & 63;
-    const int m0 = blockIdx.x * BM, ph = blockIdx.y;
+    // 1-D grid of 8 * s * ceil(tiles / 8): workgroup b runs on XCD b % 8, and the s phases of one row tile read the same
+    // rows of dx -- they are given to ONE XCD, 8 ids apart (adjacent in dispatch order), so that its L2 fetches those rows
+    // once instead of s times (PMC, layer 1: 589 MB per launch with the phases on blockIdx.y, of which 4 x 67 MB dx)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ph = slot % s, tile = (slot / s) * 8 + xcd;
+    const int m0 = tile * BM;
+    if (m0 >= am.M) return;                                        // block-uniform
     f32x16 acc[TM][TN];
     dma_gemm<C>(acc, am, m0, wd + (long)ph * (kC * 2 * kC * C::ESZ), 2 * kC, zeros, rot_step, smem);
     const bool odd = lane & 1;
@@ -390,7 +396,7 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_dgr
         if (amax_out != nullptr) {
             amax = wave_max(amax);
             if (lane == 0)
-                atomicMax(reinterpret_cast<unsigned*>(amax_out + (int)((blockIdx.x + blockIdx.y) % (unsigned)kAmaxSlots)),
+                atomicMax(reinterpret_cast<unsigned*>(amax_out + (int)(blockIdx.x % (unsigned)kAmaxSlots)),
                           __float_as_uint(amax));
         }
     }
@@ -502,7 +508,7 @@ int conv_dgrad_dma_bf16(const void* dx, const void* wd, void* dprev, const float
     const unsigned char* wdb = reinterpret_cast<const unsigned char*>(wd);
     const unsigned char* zb = reinterpret_cast<const unsigned char*>(zeros);
 #define CPC_LAUNCH_DMA(BM_)                                                                                                    \
-    hipLaunchKernelGGL((conv_dgrad_dma_kernel<BM_, 64, 2, 1>), dim3(cdiv(am.M, BM_), s), dim3(DmaCfg<BM_, 64, 2, 1>::NTHREADS), 0, \
+    hipLaunchKernelGGL((conv_dgrad_dma_kernel<BM_, 64, 2, 1>), dim3(8 * s * cdiv(cdiv(am.M, BM_), 8)), dim3(DmaCfg<BM_, 64, 2, 1>::NTHREADS), 0, \
                        st, am, wdb, s, p, Lin, dprev, zb, 0, (const float*)nullptr, (const float*)nullptr, (float*)nullptr)
     switch (bf16_bm((long)am.M * s)) {
         case 256: CPC_LAUNCH_DMA(256); break;
@@ -527,7 +533,7 @@ int conv_dgrad_dma_h2(const void* dx_h2, const float* wd, float* dprev, const fl
     const float* w_amax = wd + (long)kC * k * kC;
     const unsigned char* zb = reinterpret_cast<const unsigned char*>(zeros);
 #define CPC_LAUNCH_DMA(BM_)                                                                                                    \
-    hipLaunchKernelGGL((conv_dgrad_dma_kernel<BM_, 32, 2, 2>), dim3(cdiv(am.M, BM_), s), dim3(DmaCfg<BM_, 32, 2, 2>::NTHREADS), 0, \
+    hipLaunchKernelGGL((conv_dgrad_dma_kernel<BM_, 32, 2, 2>), dim3(8 * s * cdiv(cdiv(am.M, BM_), 8)), dim3(DmaCfg<BM_, 32, 2, 2>::NTHREADS), 0, \
                        st, am, wdb, s, p, Lin, (void*)dprev, zb, g_dma_rot, dx_bound, w_amax, amax_out)
     if ((long)am.M * s >= 256L * 200) CPC_LAUNCH_DMA(256);
     else CPC_LAUNCH_DMA(128);
