@@ -402,6 +402,147 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_dgr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a conv layer whose gradient dx AND input x are kept in H2 storage (enc_conv.hip, EncLayout::dxh2):
+//   dW[co][tap*256 + ci] = sum_m dx[m][co] * x[b, t*s + tap - p][ci]        (m = (b, t), zero outside [0, Lin))
+// The contraction runs over ROWS of both operands, so an MFMA fragment wants 8 consecutive rows of one channel -- the
+// transpose of how the tensors lie in memory.  conv_wgrad_kernel (TnTileX3) transposes while it stages through registers;
+// here both operands go global -> LDS by DMA exactly as they lie (one 1 KB row per wave instruction, 32 rows of dx and the 32
+// matching rows of x per stage, two stages) and the fragments are fetched with ds_read_b64_tr_b16, the LDS read that hands
+// each lane of a 16-lane group one COLUMN of a 4 x 16 block of halves (semantics measured in tools/probe_tr16.hip): lane p of
+// a group points at row p >> 2, channels 4 (p & 3).. of the group's 16 channels, and receives four consecutive rows of its
+// own channel; two such reads make the 8-row operand of v_mfma_f32_32x32x16_f16.  No VGPR staging, no VALU, no ds_write.
+//   * workgroup = 512 threads = 8 waves (4 x 2), tile 256 co x 256 ci (one tap), wave tile 64 x 128 (8 accumulator tiles);
+//   * 1-D grid of 8 * k * ceil(S / 8): all k taps of a row split z run on XCD z % 8 (they read the same dx rows and
+//     overlapping x rows); part[z][co][K] partials are summed by wgrad_reduce_kernel in a fixed order;
+//   * LDS rows are 1024 + 64 bytes apart: the four rows a 16-lane group reads then start 16 banks apart.
+// Arithmetic: hh + hl + lh of the fp16 pieces, fp32 accumulators, the two power-of-two scales undone exactly.
+constexpr int kWgPitch = 1024 + 64;
+constexpr int kWgRows = 32;
+constexpr int kWgStage = 2 * kWgRows * kWgPitch;
+__global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(
+    const unsigned char* __restrict__ dx, const unsigned char* __restrict__ x, int B, int Lin, int Lout, int k, int s, int p,
+    int rows_per_split, int S, float* __restrict__ part, const float* __restrict__ dx_bound, const float* __restrict__ x_bound,
+    const unsigned char* __restrict__ zeros) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * kWgStage];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tap = slot % k, z = (slot / k) * 8 + xcd;
+    if (z >= S) return;                                            // block-uniform
+    const int M = B * Lout, K = k * kC;
+    const int mbeg = z * rows_per_split;
+    const int mend = min(M, mbeg + rows_per_split);
+    const int nch = (mend - mbeg + kWgRows - 1) / kWgRows;
+    const unsigned char* zsrc = zeros + (lane & 7) * 16;
+
+    auto issue = [&](int ch, int stage) __attribute__((always_inline)) {
+        unsigned char* as = smem + stage * kWgStage;
+        unsigned char* bs = as + kWgRows * kWgPitch;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave + r;
+            const int m = mbeg + kWgRows * ch + row;               // wave-uniform
+            const unsigned char* a_src = zsrc;
+            const unsigned char* b_src = zsrc;
+            if (m < mend) {
+                a_src = dx + (long)m * (kC * 4) + 16 * lane;
+                const int b = m / Lout, t = m - b * Lout;
+                const int pos = t * s + tap - p;
+                if ((unsigned)pos < (unsigned)Lin) b_src = x + ((long)b * Lin + pos) * (kC * 4) + 16 * lane;
+            }
+            dma16_to_lds(a_src, as + row * kWgPitch);
+            dma16_to_lds(b_src, bs + row * kWgPitch);
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    // this lane inside its 16-lane group: source row (p >> 2), channel quad (p & 3) of the group's 16 channels
+    const int G = lane >> 4, pq = lane & 15, q = pq & 3;
+    const int lane_off = (pq >> 2) * kWgPitch + (2 * (G & 1) + (q >> 1)) * 32 + (q & 1) * 8 + 8 * (G >> 1) * kWgPitch;
+    const int a_off = lane_off + wm * 64 * 4, b_off = lane_off + kWgRows * kWgPitch + wn * 128 * 4;
+
+    if (nch > 0) issue(0, 0);
+    for (int ch = 0; ch < nch; ++ch) {
+        CPC_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();          // stage ch has landed for everybody; everybody is done with stage ch - 1
+        if (ch + 1 < nch) issue(ch + 1, (ch + 1) & 1);
+        const unsigned char* st = smem + (ch & 1) * kWgStage;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            using SP = SplitPlanes<2>;
+            s16x8 af[2][2], bf[4][2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const unsigned char* ra = st + a_off + 16 * ks * kWgPitch + 16 * pl;
+                const unsigned char* rb = st + b_off + 16 * ks * kWgPitch + 16 * pl;
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ra + tm * 128));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ra + tm * 128 + 4 * kWgPitch));
+                    af[tm][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(rb + tn * 128));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(rb + tn * 128 + 4 * kWgPitch));
+                    bf[tn][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < SP::NPROD; ++qq)                  // small terms first (l*h, h*l, h*h)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc[tm][tn] = SP::mfma(af[tm][SP::pa(qq)], bf[tn][SP::pb(qq)], acc[tm][tn]);
+        }
+    }
+    const float inv = 1.0f / (scale_for_amax(*dx_bound) * scale_for_amax(*x_bound));      // powers of two: exact
+    float* out = part + (long)z * kC * K + tap * kC;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) out[(long)co * K + wn * 128 + tn * 32 + (lane & 31)] = acc[tm][tn][r] * inv;
+        }
+}
+
+// row splits of the DMA weight gradient: >= 512 workgroups over the k taps, a multiple of 8 splits (one XCD each), whole
+// 32-row stages
+void conv_wgrad_dma_plan(int M, int k, int* splits, int* rows) {
+    int S = cdiv(512, k);
+    S = cdiv(S, 8) * 8;
+    int r = cdiv(cdiv(M, S), kWgRows) * kWgRows;
+    if (r < 4 * kWgRows) r = 4 * kWgRows;
+    *rows = r;
+    *splits = cdiv(M, r);
+}
+
+// dx (B*Lout, 256) and x (B, Lin, 256) in H2 storage scaled for *dx_bound / *x_bound; part: splits * 256 * k * 256 floats
+// (conv_wgrad_dma_plan); the caller reduces the partials (wgrad_reduce_kernel).
+int conv_wgrad_dma(const void* dx_h2, const void* x_h2, float* part, const float* dx_bound, const float* x_bound,
+                   const float* zeros, int B, int Lin, int k, int s, int p, int* splits_out, hipStream_t st) {
+    const int Lout = conv_out_len(Lin, k, s, p);
+    int S, rows;
+    conv_wgrad_dma_plan(B * Lout, k, &S, &rows);
+    hipLaunchKernelGGL(conv_wgrad_dma_kernel, dim3(8 * k * cdiv(S, 8)), dim3(512), 0, st,
+                       reinterpret_cast<const unsigned char*>(dx_h2), reinterpret_cast<const unsigned char*>(x_h2), B, Lin, Lout,
+                       k, s, p, rows, S, part, dx_bound, x_bound, reinterpret_cast<const unsigned char*>(zeros));
+    CPC_LAUNCH_CHECK();
+    *splits_out = S;
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void permute_w_h2_kernel(const float* __restrict__ w, unsigned char* __restrict__ wq,
                                                            int k, const float* __restrict__ amax) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;

@@ -742,6 +742,8 @@ struct EncLayout {
 // its 128-row DMA tiles measured 0.070 ms against 0.067 for the register-staged kernel).  Layers 3 and 4 keep fp32
 // activations and the register-staged kernels, whose 32/64-row tiles fill the chip at their small row counts.
 static int g_dma_bm = 0;     // 0 = by problem size; 128 / 256 = tuning override of the DMA kernel's rows per workgroup
+static int g_wgrad_dma = 1;  // weight gradient of a layer with dx and x in H2 storage: 1 = DMA + transposing LDS reads (conv_dma.hip),
+                             // 0 = the register-staged TN tile (conv_wgrad_kernel<5>)
 static int g_h2_dx = 1;      // mode 3: layer 1's gradient dx in H2 storage (DMA data gradient); 0 = fp32 dx, register-staged dgrad
 static int g_h2_layers = 0;  // 0 = by problem size; 1 / 2 = tuning / test override: how many layers (conv1, conv2) read H2 input
 static int g_force_bm = 0;   // 0 = choose by problem size; 32/64/128 = tuning / test override
@@ -801,6 +803,11 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
         S = cdiv(M, rows);
         e.wg_splits[i] = S; e.wg_rows[i] = rows;
         part_max = std::max(part_max, (long)S * kC * K);
+        if (i <= 2) {          // the DMA weight gradient splits the rows finer (conv_wgrad_dma_plan).  Sized for it whatever the
+            int Sd, rd;        // switches say: callers cache the layout per shape (ops._layout), a size must not depend on a knob
+            conv_wgrad_dma_plan(M, kGeom[i].k, &Sd, &rd);
+            part_max = std::max(part_max, (long)Sd * kC * K);
+        }
         // dgrad of layer i (i >= 2) writes colpart of layer i-1; norm_bwd writes layer 4's
         if (i >= 2) {
             const int Md = B * (e.L[i] + 1);
@@ -883,6 +890,7 @@ extern "C" int cpc_set_dma_tile(int bm) {
 }
 extern "C" int cpc_set_h2_dx(int on) {
     g_h2_dx = on ? 1 : 0;
+    g_wgrad_dma = on == 2 ? 0 : 1;            // 2: H2 gradient, but its weight gradient on the register-staged TN tile (A/B)
     return 0;
 }
 extern "C" int cpc_set_h2_layers(int n) {
@@ -1245,6 +1253,16 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     // weight gradient of layer i on the wgrad stream: operand storages as the layout says; a dx in H2 storage comes with the
     // single bound it was scaled for instead of the kAmaxSlots partial maxima
     auto wgrad = [&](int i, const float* xin) {
+        if (e.dxh2[i] && g_wgrad_dma) {
+            int S = 0;
+            int rcw = conv_wgrad_dma(scratch + e.dx[i], xin, scratch + e.part, dxbound + i, xbound + i, saved + e.szero, B,
+                                     e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, &S, wst);
+            if (rcw) return rcw;
+            const long total = (long)kC * kGeom[i].k * kC;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, wst, scratch + e.part, S, kGeom[i].k,
+                               grads[4 * i]);
+            return 0;
+        }
         return conv_layer_wgrad(scratch + e.dx[i], xin, e.bf16 ? 2 : (e.dxh2[i] ? 3 : act_h2(i - 1)), scratch + e.part, grads[4 * i],
                                 e.dxh2[i] ? dxbound + i : amax + i * kAmaxSlots, xbound + i, B, e.L[i - 1], kGeom[i].k, kGeom[i].s,
                                 kGeom[i].p, e.wg_splits[i], e.wg_rows[i], (void*)wst, e.dxh2[i] ? 1 : kAmaxSlots);

@@ -262,6 +262,7 @@ auto gload = [&](int kc_) __attribute__((always_inline)) {
 // The double-buffered BK = 16 form (STAGES = 2, 110 KB) measured slower on MI355X (conv1 152 vs 162
 // TFLOP/s-equivalent, conv3 65 vs 107: more LDS per block, twice the barriers per k).
 // ---------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 

@@ -380,6 +380,28 @@ static inline void global_load_lds(const void* g, void* lds_base, unsigned size,
     memcpy(reinterpret_cast<char*>(lds_base) + offset + (size_t)(threadIdx.x & 63) * size, g, size);
 }
 }  // namespace hipemu
+// ds_read_b64_tr_b16 (gfx950): every lane reads 8 bytes at its own address; inside each group of 16 lanes the 16 x 4 halves
+// are handed out transposed -- lane q of the group receives, for j = 0..3, element (q & 3) of source lane 4 j + (q >> 2)
+// (measured on MI355X, tools/probe_tr16.hip: with source lane p pointing at row p >> 2, columns 4 (p & 3).. of a row-major
+// image, lane q gets rows 0..3 of column q)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+namespace hipemu {
+static inline s16x4 ds_read_tr16_b64(const void* lane_addr) {
+    WaveBuf& w = my_wave();
+    const int ph = w.phase, l = lane_id();
+    memcpy(w.va[ph][l], lane_addr, 8);
+    wave_sync();
+    const int g0 = l & ~15, q = l & 15;
+    s16x4 out;
+    for (int j = 0; j < 4; ++j) {
+        short e[4];
+        memcpy(e, w.va[ph][g0 + 4 * j + (q >> 2)], 8);
+        out[j] = e[q & 3];
+    }
+    return out;
+}
+}  // namespace hipemu
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) hipemu::ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_global_load_lds(g, l, size, offset, aux) \
     hipemu::global_load_lds((const void*)(g), (void*)(l), (size), (offset))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
