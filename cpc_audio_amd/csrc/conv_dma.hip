@@ -519,8 +519,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(
 
 // row splits of the DMA weight gradient: >= 512 workgroups over the k taps, a multiple of 8 splits (one XCD each), whole
 // 32-row stages
-void conv_wgrad_dma_plan(int M, int k, int* splits, int* rows) {
-    int S = cdiv(512, k);
+static int g_wgrad_dma_wgs = 256;     // cpc_set_wgrad_dma_groups (<= 512: the partial buffer is sized for 512).  One workgroup per CU
+                                      // (its LDS fills one): measured in the step at B = 64, 512 / 384 / 256 workgroups: 3.44 / 3.49 / 3.42 ms
+void conv_wgrad_dma_plan(int M, int k, int* splits, int* rows, int wgs) {
+    int S = cdiv(wgs > 0 ? wgs : g_wgrad_dma_wgs, k);
     S = cdiv(S, 8) * 8;
     int r = cdiv(cdiv(M, S), kWgRows) * kWgRows;
     if (r < 4 * kWgRows) r = 4 * kWgRows;
@@ -534,7 +536,7 @@ int conv_wgrad_dma(const void* dx_h2, const void* x_h2, float* part, const float
                    const float* zeros, int B, int Lin, int k, int s, int p, int* splits_out, hipStream_t st) {
     const int Lout = conv_out_len(Lin, k, s, p);
     int S, rows;
-    conv_wgrad_dma_plan(B * Lout, k, &S, &rows);
+    conv_wgrad_dma_plan(B * Lout, k, &S, &rows, 0);
     hipLaunchKernelGGL(conv_wgrad_dma_kernel, dim3(8 * k * cdiv(S, 8)), dim3(512), 0, st,
                        reinterpret_cast<const unsigned char*>(dx_h2), reinterpret_cast<const unsigned char*>(x_h2), B, Lin, Lout,
                        k, s, p, rows, S, part, dx_bound, x_bound, reinterpret_cast<const unsigned char*>(zeros));
@@ -705,6 +707,12 @@ int permute_w_h2(const float* w, float* wq, int k, const float* amax, hipStream_
 
 using namespace cpc;
 
+// Workgroups the DMA weight gradient aims at (row splits = this / taps, rounded up to a multiple of 8); 128..512
+extern "C" int cpc_set_wgrad_dma_groups(int wgs) {
+    if (wgs < 64 || wgs > 512) return CPC_ERR_ARG;
+    g_wgrad_dma_wgs = wgs;
+    return 0;
+}
 extern "C" int cpc_set_dma_rotation(int step) {
     CPC_RETURN_IF(step < 0, CPC_ERR_ARG);
     g_dma_rot = step;

@@ -805,7 +805,7 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
         part_max = std::max(part_max, (long)S * kC * K);
         if (i <= 2) {          // the DMA weight gradient splits the rows finer (conv_wgrad_dma_plan).  Sized for it whatever the
             int Sd, rd;        // switches say: callers cache the layout per shape (ops._layout), a size must not depend on a knob
-            conv_wgrad_dma_plan(M, kGeom[i].k, &Sd, &rd);
+            conv_wgrad_dma_plan(M, kGeom[i].k, &Sd, &rd, 512);
             part_max = std::max(part_max, (long)Sd * kC * K);
         }
         // dgrad of layer i (i >= 2) writes colpart of layer i-1; norm_bwd writes layer 4's

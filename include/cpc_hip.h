@@ -87,6 +87,7 @@ int cpc_conv_gemm_forward_h2(const void* x_h2, const float* wq, const float* bia
  * rotation step between neighbouring workgroups (0: lockstep) */
 int cpc_set_dma_tile(int bm);
 int cpc_set_h2_layers(int n);            /* mode 3: 1 = only conv1, 2 = conv1 and conv2 read H2 input; 0 = by problem size */
+int cpc_set_wgrad_dma_groups(int wgs);  /* workgroups the DMA weight gradient aims at (row splits = wgs / taps); 64..512 */
 int cpc_set_h2_dx(int on);               /* mode 3: 1 (default) keeps encoder layer 1's gradient dx in H2 storage (its data gradient runs on
                                             the DMA kernel, its weight gradient reads the pieces); 0: fp32 dx */
 int cpc_set_gemm_split(int on);          /* 1 (default): plain GEMMs with known operand bounds (the criterion's, see cpc_nce_forward) run on two
