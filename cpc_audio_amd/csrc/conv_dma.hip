@@ -517,6 +517,99 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(
         }
 }
 
+// The same for the bf16-storage variant (cpc_set_mfma_mode(4)): dx and x are bf16 tensors (512-byte rows), one
+// v_mfma_f32_32x32x16_bf16 per product.  One DMA instruction moves row m of BOTH operands (lanes 0..31 the 512 bytes of dx,
+// lanes 32..63 those of x) into one 1 KB LDS row [dx | x]; rows 1024 + 64 bytes apart as above.
+constexpr int kWgRowsB = 64;                       // contraction rows per stage (64 KB + padding, as the H2 kernel)
+constexpr int kWgStageB = kWgRowsB * kWgPitch;
+__global__ __launch_bounds__(512) void conv_wgrad_dma_bf16_kernel(
+    const unsigned char* __restrict__ dx, const unsigned char* __restrict__ x, int B, int Lin, int Lout, int k, int s, int p,
+    int rows_per_split, int S, float* __restrict__ part, const unsigned char* __restrict__ zeros) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * kWgStageB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tap = slot % k, z = (slot / k) * 8 + xcd;
+    if (z >= S) return;                                            // block-uniform
+    const int M = B * Lout, K = k * kC;
+    const int mbeg = z * rows_per_split;
+    const int mend = min(M, mbeg + rows_per_split);
+    const int nch = (mend - mbeg + kWgRowsB - 1) / kWgRowsB;
+    const unsigned char* zsrc = zeros + (lane & 7) * 16;
+    const bool xhalf = lane >= 32;                                 // this lane copies x (else dx)
+    const int lbyte = 16 * (lane & 31);
+
+    auto issue = [&](int ch, int stage) __attribute__((always_inline)) {
+        unsigned char* st = smem + stage * kWgStageB;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = 8 * wave + r;
+            const int m = mbeg + kWgRowsB * ch + row;              // wave-uniform
+            const unsigned char* src = zsrc;
+            if (m < mend) {
+                const int b = m / Lout, t = m - b * Lout;
+                const int pos = t * s + tap - p;
+                if (!xhalf) src = dx + (long)m * (kC * 2) + lbyte;
+                else if ((unsigned)pos < (unsigned)Lin) src = x + ((long)b * Lin + pos) * (kC * 2) + lbyte;
+            }
+            dma16_to_lds(src, st + row * kWgPitch);
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int G = lane >> 4, pq = lane & 15;
+    const int lane_off = ((pq >> 2) + 8 * (G >> 1)) * kWgPitch + (16 * (G & 1) + 4 * (pq & 3)) * 2;
+    const int a_off = lane_off + wm * 64 * 2, b_off = lane_off + 512 + wn * 128 * 2;
+
+    if (nch > 0) issue(0, 0);
+    for (int ch = 0; ch < nch; ++ch) {
+        CPC_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (ch + 1 < nch) issue(ch + 1, (ch + 1) & 1);
+        const unsigned char* st = smem + (ch & 1) * kWgStageB;
+#pragma unroll
+        for (int ks = 0; ks < kWgRowsB / 16; ++ks) {
+            s16x8 af[2], bf[4];
+            const unsigned char* ra = st + a_off + 16 * ks * kWgPitch;
+            const unsigned char* rb = st + b_off + 16 * ks * kWgPitch;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ra + tm * 64));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ra + tm * 64 + 4 * kWgPitch));
+                af[tm] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(rb + tn * 64));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(rb + tn * 64 + 4 * kWgPitch));
+                bf[tn] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[tm]),
+                                                                          __builtin_bit_cast(bf16x8, bf[tn]), acc[tm][tn], 0, 0, 0);
+        }
+    }
+    float* out = part + (long)z * kC * K + tap * kC;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) out[(long)co * K + wn * 128 + tn * 32 + (lane & 31)] = acc[tm][tn][r];
+        }
+}
+
 // row splits of the DMA weight gradient: >= 512 workgroups over the k taps, a multiple of 8 splits (one XCD each), whole
 // 32-row stages
 static int g_wgrad_dma_wgs = 256;     // cpc_set_wgrad_dma_groups (<= 512: the partial buffer is sized for 512).  One workgroup per CU
@@ -524,8 +617,8 @@ static int g_wgrad_dma_wgs = 256;     // cpc_set_wgrad_dma_groups (<= 512: the p
 void conv_wgrad_dma_plan(int M, int k, int* splits, int* rows, int wgs) {
     int S = cdiv(wgs > 0 ? wgs : g_wgrad_dma_wgs, k);
     S = cdiv(S, 8) * 8;
-    int r = cdiv(cdiv(M, S), kWgRows) * kWgRows;
-    if (r < 4 * kWgRows) r = 4 * kWgRows;
+    int r = cdiv(cdiv(M, S), kWgRowsB) * kWgRowsB;        // whole stages of either kernel (32 / 64 rows)
+    if (r < 2 * kWgRowsB) r = 2 * kWgRowsB;
     *rows = r;
     *splits = cdiv(M, r);
 }
@@ -540,6 +633,20 @@ int conv_wgrad_dma(const void* dx_h2, const void* x_h2, float* part, const float
     hipLaunchKernelGGL(conv_wgrad_dma_kernel, dim3(8 * k * cdiv(S, 8)), dim3(512), 0, st,
                        reinterpret_cast<const unsigned char*>(dx_h2), reinterpret_cast<const unsigned char*>(x_h2), B, Lin, Lout,
                        k, s, p, rows, S, part, dx_bound, x_bound, reinterpret_cast<const unsigned char*>(zeros));
+    CPC_LAUNCH_CHECK();
+    *splits_out = S;
+    return 0;
+}
+
+// bf16 tensors (mode 4); see conv_wgrad_dma
+int conv_wgrad_dma_bf16(const void* dx, const void* x, float* part, const float* zeros, int B, int Lin, int k, int s, int p,
+                        int* splits_out, hipStream_t st) {
+    const int Lout = conv_out_len(Lin, k, s, p);
+    int S, rows;
+    conv_wgrad_dma_plan(B * Lout, k, &S, &rows, 0);
+    hipLaunchKernelGGL(conv_wgrad_dma_bf16_kernel, dim3(8 * k * cdiv(S, 8)), dim3(512), 0, st,
+                       reinterpret_cast<const unsigned char*>(dx), reinterpret_cast<const unsigned char*>(x), B, Lin, Lout, k, s, p,
+                       rows, S, part, reinterpret_cast<const unsigned char*>(zeros));
     CPC_LAUNCH_CHECK();
     *splits_out = S;
     return 0;

@@ -74,6 +74,8 @@ int conv_dgrad_dma_h2(const void* dx_h2, const float* wd, float* dprev, const fl
                       float* amax_out, int B, int Lin, int k, int s, int p, hipStream_t st);
 // weight gradient with dx and x both in H2 storage: DMA + transposing LDS reads (conv_dma.hip)
 void conv_wgrad_dma_plan(int M, int k, int* splits, int* rows, int wgs = 0);     // wgs: 0 = the current setting, 512 = the largest
+int conv_wgrad_dma_bf16(const void* dx, const void* x, float* part, const float* zeros, int B, int Lin, int k, int s, int p,
+                        int* splits_out, hipStream_t st);
 int conv_wgrad_dma(const void* dx_h2, const void* x_h2, float* part, const float* dx_bound, const float* x_bound,
                    const float* zeros, int B, int Lin, int k, int s, int p, int* splits_out, hipStream_t st);
 int bf16_decode(const void* src, float* dst, long n, hipStream_t st);

@@ -803,7 +803,7 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
         S = cdiv(M, rows);
         e.wg_splits[i] = S; e.wg_rows[i] = rows;
         part_max = std::max(part_max, (long)S * kC * K);
-        if (i <= 2) {          // the DMA weight gradient splits the rows finer (conv_wgrad_dma_plan).  Sized for it whatever the
+        {                      // the DMA weight gradient splits the rows finer (conv_wgrad_dma_plan).  Sized for it whatever the
             int Sd, rd;        // switches say: callers cache the layout per shape (ops._layout), a size must not depend on a knob
             conv_wgrad_dma_plan(M, kGeom[i].k, &Sd, &rd, 512);
             part_max = std::max(part_max, (long)Sd * kC * K);
@@ -1253,10 +1253,12 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     // weight gradient of layer i on the wgrad stream: operand storages as the layout says; a dx in H2 storage comes with the
     // single bound it was scaled for instead of the kAmaxSlots partial maxima
     auto wgrad = [&](int i, const float* xin) {
-        if (e.dxh2[i] && g_wgrad_dma) {
+        if ((e.dxh2[i] || e.bf16) && g_wgrad_dma) {
             int S = 0;
-            int rcw = conv_wgrad_dma(scratch + e.dx[i], xin, scratch + e.part, dxbound + i, xbound + i, saved + e.szero, B,
-                                     e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, &S, wst);
+            int rcw = e.bf16 ? conv_wgrad_dma_bf16(scratch + e.dx[i], xin, scratch + e.part, saved + e.szero, B, e.L[i - 1],
+                                                   kGeom[i].k, kGeom[i].s, kGeom[i].p, &S, wst)
+                             : conv_wgrad_dma(scratch + e.dx[i], xin, scratch + e.part, dxbound + i, xbound + i, saved + e.szero, B,
+                                              e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, &S, wst);
             if (rcw) return rcw;
             const long total = (long)kC * kGeom[i].k * kC;
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, wst, scratch + e.part, S, kGeom[i].k,
