@@ -111,9 +111,12 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
     step_ctx = ops.StepContext(overlap=True)
     if allreduce is not None:
         step_ctx.pre_encoder_backward.append(allreduce.begin)
+    in_flight = []                                        # at most two steps ahead of the GPU (train.Trainer.MAX_IN_FLIGHT)
     for step, (batch, label) in enumerate(loader):
         batch, label = _to_device(batch, device), _to_device(label, device)
         n_ex += batch.size(0)
+        if device.type == "cuda" and len(in_flight) >= 2:
+            in_flight.pop(0).synchronize()
         try:
             with step_ctx as sc:                          # side streams for the dz path / weight gradients (ops.StepContext)
                 c_feature, encoded, label = model(batch, label)
@@ -130,6 +133,9 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
             allreduce()
         optimizer.step()
         optimizer.zero_grad()
+        if device.type == "cuda":
+            in_flight.append(torch.cuda.Event())
+            in_flight[-1].record()
         with torch.no_grad():                             # accumulate on device, no per-step sync
             l, a = all_losses.detach().mean(dim=0), all_acc.mean(dim=0)
             sum_loss = l if sum_loss is None else sum_loss + l
