@@ -88,12 +88,15 @@ int cpc_conv_gemm_forward_h2(const void* x_h2, const float* wq, const float* bia
 int cpc_set_dma_tile(int bm);
 int cpc_set_h2_layers(int n);            /* mode 3: 1 = only conv1, 2 = conv1 and conv2 read H2 input; 0 = by problem size */
 int cpc_set_wgrad_dma_groups(int wgs);  /* workgroups the DMA weight gradient aims at (row splits = wgs / taps); 64..512 */
-int cpc_set_h2_dx(int on);               /* mode 3: 1 (default) keeps encoder layer 1's gradient dx in H2 storage (its data gradient runs on
-                                            the DMA kernel, its weight gradient reads the pieces); 0: fp32 dx */
+int cpc_set_h2_dx(int on);               /* mode 3: 1 (default) keeps the gradient dx of every layer whose input is in H2 storage in H2 storage
+                                            too (layer 1; layer 2 where conv2 reads H2 input): data gradient on the DMA kernel, weight
+                                            gradient on DMA + transposing LDS reads; 2: the same with the weight gradient on the
+                                            register-staged tile (A/B); 0: fp32 dx */
 int cpc_set_gemm_split(int on);          /* 1 (default): plain GEMMs with known operand bounds (the criterion's, see cpc_nce_forward) run on two
-                                            fp16 pieces in mode >= 2; 0: three bf16 pieces always */
+                                            fp16 pieces in mode >= 2, wide products on the 128 x 256 pipelined tile; 0: three bf16 pieces always;
+                                            2: two pieces but never the wide tile; 3: the wide tile whatever the grid size (tests) */
 int cpc_set_dma_rotation(int step);
-int cpc_set_dma_pipeline(int variant);   /* 0 (default): four 16-k LDS stages, three in flight; 1: two 32-k stages */
+int cpc_set_dma_pipeline(int variant);   /* 1 (default): two 32-k LDS stages; 0: four 16-k stages, three in flight */
 long cpc_conv0_backward_scratch_floats(int B, int L);
 /* Backward of layer 0 (no dgrad: the waveform needs no gradient, train.py:81-87).
  * dy = gradient w.r.t. y.  Outputs dW0 (256,1,10), dB0, dNW0, dNB0 (256) are overwritten. */
