@@ -34,9 +34,17 @@ struct GemmGroup {
     long a = 0, b = 0, bias = 0, c = 0;
     long part = 0;      // tn_gemm: stride of the split partials (0: problem g's S * N1 * N2 floats right behind problem g-1's)
 };
+// A scratch buffer a narrow NT product may use to split its K walk over several workgroups per output tile (N = 256 gives
+// M / 128 tiles of the wide kernel -- 58 for the criterion's dc: a quarter of the chip): partial products land in `part`
+// (floats >= splits * M * N, splits <= 8) and one more launch sums them into C in a fixed order.
+struct SplitK {
+    float* part = nullptr;
+    long floats = 0;
+};
 // C[M,N] = A . B[N,K]^T (+ bias);  N % 128 == 0, K % 16 == 0
 int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc, int N,
-            int K, hipStream_t st, int c_R = 0, long c_bstride = 0, GemmBounds gb = GemmBounds(), GemmGroup grp = GemmGroup());
+            int K, hipStream_t st, int c_R = 0, long c_bstride = 0, GemmBounds gb = GemmBounds(), GemmGroup grp = GemmGroup(),
+            SplitK sk = SplitK());
 // C[N1,N2] (+)= sum_m A[m,:N1]^T (x) B[m,:N2];  part: tn_gemm_part_floats(M,N1,N2) floats
 void tn_gemm_plan(int M, int N1, int N2, int* splits, int* rows);
 long tn_gemm_part_floats(int M, int N1, int N2);

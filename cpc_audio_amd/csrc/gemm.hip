@@ -41,9 +41,17 @@ template <class NtG, int BMN, bool H2 = false, int BNN = BMN>
 __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const float* __restrict__ Bmat,
                                                                 int ldb, const float* __restrict__ bias,
                                                                 float* __restrict__ C, long ldc, int K,
-                                                                int c_R, long c_bstride, GemmBounds gb, GemmGroup grp) {
+                                                                int c_R, long c_bstride, GemmBounds gb, GemmGroup grp,
+                                                                int ksplit = 1, float* __restrict__ kpart = nullptr) {
     __shared__ float smem[NtG::SMEM_FLOATS];
     const int m0 = blockIdx.x * BMN, n0 = blockIdx.y * BNN;
+    if (ksplit > 1) {                                    // slice blockIdx.z of the K walk; a dense (M, N) partial per slice
+        const long z = blockIdx.z;
+        K /= ksplit;
+        am.base += z * K; Bmat += z * K;
+        C = kpart + z * (long)am.M * (gridDim.y * BNN);
+        ldc = gridDim.y * BNN; c_R = 0; bias = nullptr;
+    }
     if (grp.G > 1) {                                     // problem blockIdx.z of a group (cpc_internal.h, GemmGroup)
         const long g = blockIdx.z;
         am.base += g * grp.a; Bmat += g * grp.b; C += g * grp.c;
@@ -259,14 +267,54 @@ int absmax_slots(const float* const* x, const long* n, int njobs, float* out, hi
     return 0;
 }
 
+// C (rows mapped as nt_gemm_kernel does) = sum over the `splits` dense (M, N) partials, in order, + bias
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N,
+                                                            const float* __restrict__ bias, float* __restrict__ C, long ldc,
+                                                            int c_R, long c_bstride) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;       // one float4 of a row
+    const int n4 = N / 4;
+    if (i >= (long)M * n4) return;
+    const int m = (int)(i / n4), c = (int)(i - (long)m * n4) * 4;
+    float4 s = *reinterpret_cast<const float4*>(part + (long)m * N + c);
+    for (int z = 1; z < splits; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(part + ((long)z * M + m) * N + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias != nullptr) { s.x += bias[c]; s.y += bias[c + 1]; s.z += bias[c + 2]; s.w += bias[c + 3]; }
+    long ro = (long)m * ldc;
+    if (c_R > 0) { const int cb = m / c_R; ro = cb * c_bstride + (long)(m - cb * c_R) * ldc; }
+    *reinterpret_cast<float4*>(C + ro + c) = s;
+}
+
 int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc,
-            int N, int K, hipStream_t st, int c_R, long c_bstride, GemmBounds bounds, GemmGroup grp) {
+            int N, int K, hipStream_t st, int c_R, long c_bstride, GemmBounds bounds, GemmGroup grp, SplitK sk) {
     if (am.M <= 0) return 0;
     if (N % 128 != 0 || K % 16 != 0 || K < 16) return CPC_ERR_SHAPE;
     const bool big = (long)cdiv(am.M, 128) * (N / 128) * grp.G >= 384;
     const bool x3 = g_mfma_mode != 0 && K % 32 == 0;
     const bool h2 = x3 && g_mfma_mode >= 2 && g_gemm_split && bounds.a && bounds.b;      // operand bounds known: fp16 split
     const dim3 gb(cdiv(am.M, 128), N / 128, grp.G), gs(cdiv(am.M, 64), N / 64, grp.G);
+    // narrow products on the wide tile with the K walk split (see SplitK): the smallest split that gives ~200 workgroups
+    if (x3 && g_gemm_wide >= 1 && grp.G == 1 && sk.part && N % 256 == 0 && am.rstride == K && am.tmul == 0 && ldb == K &&
+        (ldc % 4 == 0) && (long)cdiv(am.M, 128) * (N / 256) < 192) {
+        const long tiles = (long)cdiv(am.M, 128) * (N / 256);
+        int split = 0;
+        for (int q = 2; q <= 8 && !split; ++q)
+            if (K % (64 * q) == 0 && (tiles * q >= 200 || g_gemm_wide == 2) && (long)q * am.M * N <= sk.floats) split = q;
+        if (split) {
+            const dim3 g3(cdiv(am.M, 128), N / 256, split);
+            if (h2)
+                hipLaunchKernelGGL((nt_gemm_kernel<NtWideH2, 128, true, 256>), g3, dim3(NtWideH2::NTHREADS), 0, st, am, Bmat, ldb,
+                                   bias, C, ldc, K, c_R, c_bstride, bounds, grp, split, sk.part);
+            else
+                hipLaunchKernelGGL((nt_gemm_kernel<NtWideX3, 128, false, 256>), g3, dim3(NtWideX3::NTHREADS), 0, st, am, Bmat, ldb,
+                                   bias, C, ldc, K, c_R, c_bstride, bounds, grp, split, sk.part);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((long)am.M * (N / 4), 256)), dim3(256), 0, st, sk.part, split, am.M, N,
+                               bias, C, ldc, c_R, c_bstride);
+            CPC_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const bool wide = x3 && g_gemm_wide && N % 256 == 0 && K % 64 == 0 &&
                       (g_gemm_wide == 2 || (long)cdiv(am.M, 128) * (N / 256) * grp.G >= 256);
     if (wide && h2)

@@ -1202,7 +1202,10 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
         }
         CPC_LAUNCH_CHECK();
         // dx = dGi0 . W_ih0 first: it is what the rest of the backward pass waits for
-        rc = nt_gemm(plain_rows(dGi_[0], M, kG), wihT_[0], kG, nullptr, dx, kH, kH, kG, st);
+        SplitK sk;                       // N = 256: too few tiles for the chip; the partial buffer of the weight gradients is free
+        sk.part = scratch + g.part;      // until they start (behind this GEMM, on either stream)
+        sk.floats = std::max(tn_gemm_part_floats(B * S, kG, kH), tn_gemm_batch_part_floats(4, B * S, kG, kH));
+        rc = nt_gemm(plain_rows(dGi_[0], M, kG), wihT_[0], kG, nullptr, dx, kH, kH, kG, st, 0, 0, GemmBounds(), GemmGroup(), sk);
         if (rc) return rc;
         if (wst != st) {
             hipEvent_t* ev = stream_events(st);

@@ -634,8 +634,11 @@ extern "C" int cpc_nce_backward_streams(const float* c, const float* z, const fl
     // dc[:, :W] = dPred . Wall  (NT against Wall^T [256][K*256])
     rc = transpose(wall, wallT, K * kC, kC, st);
     if (rc) return rc;
+    SplitK sk;                           // N = 256: 58 row tiles at B = 64; the head gradient's partial buffer is free until it
+    sk.part = scratch + n.part;          // starts (behind this GEMM, on either stream)
+    sk.floats = tn_gemm_part_floats(n.BW, K * kC, kC);
     rc = nt_gemm(plain_rows(dpred, n.BW, K * kC), wallT, K * kC, nullptr, dc, kC, kC, K * kC, st, n.W,
-                 (long)S * kC, gdc);
+                 (long)S * kC, gdc, GemmGroup(), sk);
     if (rc || !dwall) return rc;
     // dW_k = dPred_k^T . c[:, :W]
     return tn_gemm(plain_rows(dpred, n.BW, K * kC), K * kC, window_rows(c, B, S, n.W), kC, scratch + n.part,

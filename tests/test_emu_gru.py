@@ -46,6 +46,21 @@ def _gemm_checks(lib):
     assert rel_err(C, 2 * C0) < 1e-6
 
 
+def test_narrow_products_with_split_k_emulated():
+    """N = 256 products (the GRU's dx = dGi . W_ih, the criterion's dc) on the wide tile with the K walk split over several
+    workgroups + one reduction launch (gemm.hip, SplitK): cpc_set_gemm_split(3) forces it at test sizes; same results as
+    the plain tiles to fp32 rounding (the oracle comparison inside _run_gru: 1e-5)."""
+    lib = emu()
+    assert lib.cpc_set_gemm_split(3) == 0
+    try:
+        a = _run_gru(lib, 3, 6, 2, False)
+    finally:
+        lib.cpc_set_gemm_split(1)
+    b = _run_gru(lib, 3, 6, 2, False)
+    assert (a[2] - b[2]).abs().max().item() <= 1e-6 * b[2].abs().max().item()      # dx
+    assert not torch.equal(a[2], b[2])                                              # the path did change
+
+
 def test_gemm_nt_wide_tile_emulated():
     """The 128 x 256 pipelined tile of the plain NT GEMM on three bf16 pieces (taken for N % 256 == 0, K % 64 == 0 once the
     grid fills the chip; cpc_set_gemm_split(3) forces it at test sizes): ragged M, two column tiles, bias."""
