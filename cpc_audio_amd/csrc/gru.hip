@@ -186,6 +186,7 @@ struct Gru2Fwd {
     int B, S;
     int spin_limit;            // persistent launch only: polling budget of a wave (cpc_set_gru_spin_limit)
     int ntiles, xcd_pack;      // persistent launch only: see PersistIds
+    int tile0, total_tiles;    // persistent launch only: this launch covers batch tiles [tile0, tile0 + ntiles) of total_tiles
     int first_sleep;           // persistent launch only: see PollPace (< 0: self-steering)
 };
 
@@ -307,6 +308,7 @@ struct Gru2Bwd {
     int B, S;
     int spin_limit;            // persistent launch only: polling budget of a wave (cpc_set_gru_spin_limit)
     int ntiles, xcd_pack;      // persistent launch only: see PersistIds
+    int tile0, total_tiles;    // persistent launch only: this launch covers batch tiles [tile0, tile0 + ntiles) of total_tiles
     int first_sleep;           // persistent launch only: see PollPace (< 0: self-steering)
 };
 
@@ -614,7 +616,9 @@ struct PersistIds {
     // then stays inside one L2 instead of crossing the fabric (surplus workgroups exit at once; at B = 64 four XCDs
     // run the recurrence and four are left to the side-stream kernels).  Otherwise (default, faster): grid = 32 G, ids of one
     // tile G apart.
-    __device__ PersistIds(int G, int pack) {
+    // A launch may cover only the batch tiles [tile0, tile0 + G) of `total` (a batch too large for one resident grid runs as
+    // several launches one after the other: sequences are independent); everything is addressed by the global tile.
+    __device__ PersistIds(int G, int pack, int tile0, int total) {
         int rest;
         if (pack) {
             const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -624,8 +628,9 @@ struct PersistIds {
             tile = blockIdx.x % G;
             rest = blockIdx.x / G;
         }
-        ntiles = G;
-        valid = tile < G;
+        valid = tile < G && tile0 + tile < total;
+        tile += tile0;
+        ntiles = total;
         b0 = tile * 16;
         layer = rest >> 4;
         j0 = (rest & 15) * 16;
@@ -750,7 +755,7 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
 // grid = 32 * ceil(B/16) workgroups (1-D), 768 threads; xh[0] and xh[1] pre-filled with 0xFF bytes
 __global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_kernel(Gru2Fwd p) {
     __shared__ float part[2][8][3][256];
-    const PersistIds id(p.ntiles, p.xcd_pack);
+    const PersistIds id(p.ntiles, p.xcd_pack, p.tile0, p.total_tiles);
     if (!id.valid) return;
     if (id.layer == 0) persist_fwd<0, false>(p, part, id);
     else persist_fwd<1, false>(p, part, id);
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_kernel(Gru2F
 // the same with the recurrent products on the fp16 pipe (two-piece split operands); h0 must be absent (|h| < 1)
 __global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_h2_kernel(Gru2Fwd p) {
     __shared__ float part[2][8][3][256];
-    const PersistIds id(p.ntiles, p.xcd_pack);
+    const PersistIds id(p.ntiles, p.xcd_pack, p.tile0, p.total_tiles);
     if (!id.valid) return;
     if (id.layer == 0) persist_fwd<0, true>(p, part, id);
     else persist_fwd<1, true>(p, part, id);
@@ -887,7 +892,7 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
 // grid / block as the forward; xdh[0] and xdh[1] pre-filled with 0xFF bytes
 __global__ __launch_bounds__(kPersistThreads) void gru2_persist_bwd_kernel(Gru2Bwd p) {
     __shared__ float part[2][8][256];
-    const PersistIds id(p.ntiles, p.xcd_pack);
+    const PersistIds id(p.ntiles, p.xcd_pack, p.tile0, p.total_tiles);
     if (!id.valid) return;
     if (id.layer == 0) persist_bwd<1>(p, part, id);               // the top layer leads
     else persist_bwd<0>(p, part, id);
@@ -963,6 +968,19 @@ int g_gru_mode = 2;        // 0: per-step launches; 1: persistent two-layer recu
 // cannot all be resident at once.  *pack: one tile per XCD -- when asked for (g_gru_xcd_pack 1) and the device is 8 XCDs of
 // cus / 8 CUs each with room for 32 * ceil(G / 8) workgroups per XCD; g_gru_xcd_pack == 2 forces the packed numbering on any
 // device whose dispatcher hands out workgroups in id order as slots free up (the emulator; surplus ids exit at once).
+// Batch tiles per persistent launch: all of them if their 32 G workgroups can be resident together, else the largest
+// count that can (0: not even one tile).  g_gru_chunk_tiles > 0 caps it (tests: chunking on a device that would not need it).
+int g_gru_chunk_tiles = 0;
+static int persist_chunk(const void* kernel, int G) {
+    int dev = 0, cus = 0, occ = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kPersistThreads, 0) != hipSuccess) return 0;
+    int fit = (int)(((long)cus * occ) / 32);
+    if (g_gru_chunk_tiles > 0 && fit > g_gru_chunk_tiles) fit = g_gru_chunk_tiles;
+    return fit >= G ? G : fit;
+}
+
 template <class K>
 int persist_grid(K kernel, int G, int* pack) {
     int dev = 0, cus = 0, occ = 0;
@@ -1008,6 +1026,14 @@ extern "C" int cpc_set_gru_poll_pacing(int first_fwd, int first_bwd) {
     if (first_fwd > 200 || first_bwd > 200) return CPC_ERR_ARG;
     g_gru_first_sleep[0] = first_fwd < 0 ? -1 : first_fwd;
     g_gru_first_sleep[1] = first_bwd < 0 ? -1 : first_bwd;
+    return 0;
+}
+
+// Cap on the batch tiles (16 sequences each) of one persistent launch; 0 = whatever fits the device.  A larger batch runs as
+// several launches one after the other.
+extern "C" int cpc_set_gru_chunk_tiles(int tiles) {
+    if (tiles < 0) return CPC_ERR_ARG;
+    g_gru_chunk_tiles = tiles;
     return 0;
 }
 
@@ -1057,15 +1083,22 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
         p.hN = hN; p.B = B; p.S = S; p.spin_limit = g_gru_spin_limit;
         p.first_sleep = g_gru_first_sleep[0];
         p.xh[0] = p.xh[1] = nullptr;
-        p.ntiles = cdiv(B, 16);
+        p.total_tiles = cdiv(B, 16);
+        p.tile0 = 0;
         const bool h2 = g_gru_mode == 2 && !h0;
-        const int nblocks = g_gru_mode < 1 ? 0 : h2 ? persist_grid(gru2_persist_fwd_h2_kernel, p.ntiles, &p.xcd_pack)
-                                                    : persist_grid(gru2_persist_fwd_kernel, p.ntiles, &p.xcd_pack);
+        // a batch whose 32 workgroups per tile cannot all be resident at once runs in chunks of tiles, one launch after the
+        // other (B = 256 on 256 CUs: two launches of 8 tiles)
+        p.ntiles = persist_chunk(h2 ? (const void*)gru2_persist_fwd_h2_kernel : (const void*)gru2_persist_fwd_kernel, p.total_tiles);
+        const int nblocks = g_gru_mode < 1 || p.ntiles <= 0 ? 0
+                            : h2 ? persist_grid(gru2_persist_fwd_h2_kernel, p.ntiles, &p.xcd_pack)
+                                 : persist_grid(gru2_persist_fwd_kernel, p.ntiles, &p.xcd_pack);
         if (nblocks > 0) {
             p.xh[0] = scratch + g.xh; p.xh[1] = scratch + g.xh + g.xh_floats;
             if (hipMemsetAsync(p.xh[0], 0xFF, 2 * g.xh_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
-            if (h2) hipLaunchKernelGGL(gru2_persist_fwd_h2_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
-            else hipLaunchKernelGGL(gru2_persist_fwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+            for (p.tile0 = 0; p.tile0 < p.total_tiles; p.tile0 += p.ntiles) {
+                if (h2) hipLaunchKernelGGL(gru2_persist_fwd_h2_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+                else hipLaunchKernelGGL(gru2_persist_fwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+            }
             CPC_LAUNCH_CHECK();
             return 0;
         }
@@ -1191,11 +1224,14 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
         }
         if (!coef) launch_gru_coef(g, h0, saved, y, scratch + g.coef, B, S, st);
         p.wih1T = wihT_[1];
-        p.ntiles = cdiv(B, 16);
-        const int nblocks = g_gru_mode < 1 ? 0 : persist_grid(gru2_persist_bwd_kernel, p.ntiles, &p.xcd_pack);
+        p.total_tiles = cdiv(B, 16);
+        p.tile0 = 0;
+        p.ntiles = persist_chunk((const void*)gru2_persist_bwd_kernel, p.total_tiles);
+        const int nblocks = g_gru_mode < 1 || p.ntiles <= 0 ? 0 : persist_grid(gru2_persist_bwd_kernel, p.ntiles, &p.xcd_pack);
         if (nblocks > 0) {
             if (!coef && hipMemsetAsync(p.xdh[0], 0xFF, 2 * g.frag_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
-            hipLaunchKernelGGL(gru2_persist_bwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+            for (p.tile0 = 0; p.tile0 < p.total_tiles; p.tile0 += p.ntiles)
+                hipLaunchKernelGGL(gru2_persist_bwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
         } else {
             const dim3 grid(kH / 16, cdiv(B, 16), 2);
             for (int s = 0; s <= S; ++s) hipLaunchKernelGGL(gru2_bwd_kernel, grid, dim3(512), 0, st, p, s);

@@ -151,6 +151,9 @@ int cpc_set_gru_mode(int mode);
  * faster) interleaves the tiles over the XCDs (grid of 32 * tiles); 2 forces the packed numbering whatever the device
  * reports (tests). */
 int cpc_set_gru_xcd_pack(int on);
+/* Persistent recurrence: cap on the 16-sequence batch tiles of one launch (0 = whatever fits the device, the default); a
+ * larger batch runs as several launches one after the other (B = 256 on 256 CUs: two launches of 8 tiles). */
+int cpc_set_gru_chunk_tiles(int tiles);
 /* Persistent recurrence: the wait before a step's first look at the hand-over buffers (forward / backward kernel), in
  * units of 64 clocks; < 0 (default): every wave steers its own so that looks that cannot succeed yet are not issued
  * (they load the L2s the hand-over itself goes through). */

@@ -174,6 +174,20 @@ def test_persistent_recurrence_with_one_batch_tile_per_xcd_emulated():
     assert lib.cpc_set_gru_xcd_pack(3) != 0
 
 
+def test_persistent_recurrence_in_chunks_of_batch_tiles_emulated():
+    """A batch whose workgroups cannot all be resident runs as several persistent launches over chunks of 16-sequence tiles
+    (B = 256 on MI355X: two launches of 8 tiles).  cpc_set_gru_chunk_tiles(1) forces one tile per launch: same bits."""
+    lib = emu()
+    outs = []
+    for cap in (0, 1):
+        assert lib.cpc_set_gru_chunk_tiles(cap) == 0
+        try:
+            outs.append(_run_gru(lib, 36, 5, 2, False))          # three tiles, the last one ragged
+        finally:
+            lib.cpc_set_gru_chunk_tiles(0)
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
 def test_gru_backward_with_early_coefficients_emulated():
     """cpc_gru_backward_coef (forward-only part + pre-filled hand-over buffers, run ahead of time by the overlapped train
     loops) + cpc_gru_backward_with_coef / _streams give bit-identical results to the one-call backward."""
