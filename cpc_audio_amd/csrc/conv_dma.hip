@@ -209,6 +209,107 @@ __device__ __forceinline__ void dma_gemm(f32x16 (&acc)[C::TM][C::TN], const RowM
     __syncthreads();                            // the stage buffers are free (the epilogues reuse them)
 }
 
+// ---- the same product with every input row fetched ONCE (forward, k = 2s, H2 operands, 256-row tiles inside one sequence)
+// Tap j of output row t and tap j + s of row t - 1 are the same input row: dma_gemm walks the taps in pairs so that the
+// second fetch hits L2, but it still crosses L2 -> LDS twice, and that bandwidth is what the kernel runs against (1.05 GB per
+// launch on layer 1, half of it activation).  Here a stage is (tap pair (j, j + s), 16 channels): the 257 input rows
+// (t0 + r) s + j - p, r = 0..256, as 64-byte segments + the two taps' weight tiles (2 x 256 x 64 B); tap j multiplies LDS rows
+// r, tap j + s rows r + 1.  49 KB per stage instead of 64 KB for the same 32 k of contraction.  Requires the tile's rows to be
+// consecutive steps of ONE sequence (Lout % 256 == 0), so that "row r + 1" is the next step of the same sequence.
+constexpr int kPairARows = 272;                              // 17 DMA pieces of 16 rows; rows 0..256 are used
+constexpr int kPairA = kPairARows * 64, kPairW = 2 * kC * 64, kPairStage = kPairA + kPairW;
+__device__ __forceinline__ void dma_gemm_pair(f32x16 (&acc)[2][4], const RowMap& am, int m0, const unsigned char* __restrict__ wq,
+                                              int K, const unsigned char* __restrict__ zeros, int rot_step, unsigned char* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int taps = K >> kCLog2, s = taps >> 1;
+    const int nst = s * (kC / 16);                           // stages: (pair, 16-channel chunk)
+    const int rot = (int)((blockIdx.x * (unsigned)rot_step) % (unsigned)nst);
+    const int b = m0 / am.R, t0 = m0 - b * am.R;             // the tile lies inside sequence b
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(am.base) + (long)b * am.bstride * 4;
+    // lane l of a 1 KB piece: row l / 4 of its 16 rows, LDS slot l % 4, which holds global piece (l % 4) ^ ((row >> 2) & 3)
+    const int prow = lane >> 2, pslot = lane & 3;
+    const unsigned char* zsrc = zeros + pslot * 16;
+    int a_tau0[3], a_goff[3];
+    bool a_on[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int piece = wave + 8 * i, row = 16 * piece + prow;
+        a_on[i] = piece < 17;                                // wave-uniform
+        a_tau0[i] = row <= kC ? (t0 + row) * am.tmul + am.tadd : -(1 << 30);
+        a_goff[i] = (pslot ^ ((row >> 2) & 3)) * 16;
+    }
+    const unsigned char* w_src[4];
+    int w_tap[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i, half = piece >> 4, row = 16 * (piece & 15) + prow;
+        w_tap[i] = half;
+        w_src[i] = wq + (long)row * 128 + (pslot ^ ((row >> 2) & 3)) * 16;
+    }
+    auto issue = [&](int st_, int stage) __attribute__((always_inline)) {
+        int q = st_ + rot;
+        q = q >= nst ? q - nst : q;
+        const int j = q % s, c = q / s;                      // tap pair (j, j + s), channels 16 c .. 16 c + 15
+        unsigned char* as = smem + stage * kPairStage;
+        unsigned char* ws = as + kPairA;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (a_on[i]) {
+                const int tau = a_tau0[i] + j;
+                const bool ok = (unsigned)tau < (unsigned)am.Lin;
+                dma16_to_lds(ok ? xb + (long)tau * (kC * 4) + c * 64 + a_goff[i] : zsrc, as + (wave + 8 * i) * 1024);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tap = j + w_tap[i] * s;
+            const long koff = (long)((tap * kC + c * 16) >> 5) * (kC * 128) + (c & 1) * 64;
+            dma16_to_lds(w_src[i] + koff, ws + (wave * 4 + i) * 1024);
+        }
+    };
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int swb = (l31 >> 2) & 3;
+    const int a_row = wm * 64 + l31, b_row = wn * 128 + l31;
+    issue(0, 0);
+    for (int st_ = 0; st_ < nst; ++st_) {
+        CPC_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (st_ + 1 < nst) issue(st_ + 1, (st_ + 1) & 1);
+        const unsigned char* As = smem + (st_ & 1) * kPairStage;
+        const unsigned char* Ws = As + kPairA;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {                     // ks = 0: tap j on rows r; ks = 1: tap j + s on rows r + 1
+            using SP = SplitPlanes<2>;
+            s16x8 af[2][2], bf[4][2];
+            const int swa = ((l31 + ks) >> 2) & 3;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+                    af[tm][pl] = *reinterpret_cast<const s16x8*>(As + (a_row + 32 * tm + ks) * 64 + (((2 * kg + pl) ^ swa) * 16));
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    bf[tn][pl] = *reinterpret_cast<const s16x8*>(Ws + ks * (kC * 64) + (b_row + 32 * tn) * 64 + (((2 * kg + pl) ^ swb) * 16));
+            }
+#pragma unroll
+            for (int q = 0; q < SP::NPROD; ++q)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc[tm][tn] = SP::mfma(af[tm][SP::pa(q)], bf[tn][SP::pb(q)], acc[tm][tn]);
+        }
+    }
+    __syncthreads();                            // the stage buffers are free (the epilogue reuses them)
+}
+
 // Storage of an epilogue's outputs
 constexpr int kStoreF32 = 0, kStoreH2 = 1, kStoreBf16 = 2;
 
@@ -216,7 +317,7 @@ constexpr int kStoreF32 = 0, kStoreH2 = 1, kStoreBf16 = 2;
 // rows (permute_w_h2 / permute_w_bf16), for NP = 2 max|w| behind it.  y is written as `ykind` says (H2: scaled by
 // scale_for_amax(*y_amax)), xhat as `xkind` (fp32 or bf16), rstd fp32.
 // zeros: >= 128 bytes of zeros (the rows of the conv's zero padding and of the ragged last tile read them).
-template <int BM, int BKE, int NST, int NP>
+template <int BM, int BKE, int NST, int NP, bool PAIR = false>
 __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd_dma_kernel(
     RowMap am, const unsigned char* __restrict__ wq, int K, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, void* __restrict__ y, int ykind,
@@ -226,11 +327,13 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd
     using C = DmaCfg<BM, BKE, NST, NP>;
     constexpr int TM = C::TM, TN = C::TN;
     // ONE LDS object: a second one makes the compiler drain the DMA queue (vmcnt(0)) before every ds_read of the loop
+    static_assert(!PAIR || (BM == 256 && NP == 2 && 2 * kPairStage <= C::SMEM_BYTES), "the pair walk is built for 256-row H2 tiles");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES];
     const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) % C::WAVES_N;
     const int m0 = blockIdx.x * BM;
     f32x16 acc[TM][TN];
-    dma_gemm<C>(acc, am, m0, wq, K, zeros, rot_step, smem);
+    if constexpr (PAIR) dma_gemm_pair(acc, am, m0, wq, K, zeros, rot_step, smem);
+    else dma_gemm<C>(acc, am, m0, wq, K, zeros, rot_step, smem);
 
     // ---- epilogue: undo the operand scales, bias, ChannelNorm (two passes over the accumulators), ReLU
     float inv = 1.0f;
@@ -708,7 +811,11 @@ int conv_fwd_dma(const float* x_h2, const float* wq, const float* bias, const fl
     hipLaunchKernelGGL((conv_fwd_dma_kernel<BM_, BKE_, NST_, 2>), dim3(cdiv(am.M, BM_)), dim3(DmaCfg<BM_, BKE_, NST_, 2>::NTHREADS), \
                        0, st, am, wqb, K, bias, nw, nb, (void*)y, ykind, (void*)xhat, kStoreF32, rstd, x_amax, w_amax, y_amax, zb,   \
                        g_dma_rot)
-    if (bm == 256 && g_dma_pipe == 0) CPC_LAUNCH_DMA(256, 16, 4);
+    if (bm == 256 && g_dma_pipe == 2 && k == 2 * s && Lout % 256 == 0)          // every input row once (dma_gemm_pair)
+        hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 32, 2, 2, true>), dim3(cdiv(am.M, 256)), dim3(DmaCfg<256, 32, 2, 2>::NTHREADS), 0,
+                           st, am, wqb, K, bias, nw, nb, (void*)y, ykind, (void*)xhat, kStoreF32, rstd, x_amax, w_amax, y_amax, zb,
+                           g_dma_rot);
+    else if (bm == 256 && g_dma_pipe == 0) CPC_LAUNCH_DMA(256, 16, 4);
     else if (bm == 256) CPC_LAUNCH_DMA(256, 32, 2);
     else if (g_dma_pipe == 0) CPC_LAUNCH_DMA(128, 16, 4);
     else CPC_LAUNCH_DMA(128, 32, 2);
@@ -825,8 +932,8 @@ extern "C" int cpc_set_dma_rotation(int step) {
     g_dma_rot = step;
     return 0;
 }
-extern "C" int cpc_set_dma_pipeline(int variant) {
-    CPC_RETURN_IF(variant != 0 && variant != 1, CPC_ERR_ARG);
+extern "C" int cpc_set_dma_pipeline(int variant) {   // 2: as 1, with the pair walk (dma_gemm_pair) where the shape allows
+    CPC_RETURN_IF(variant < 0 || variant > 2, CPC_ERR_ARG);
     g_dma_pipe = variant;
     return 0;
 }

@@ -180,7 +180,8 @@ def test_fp16_split_scaling_extremes_emulated(xs, ws):
 
 
 @pytest.mark.parametrize("B,Lin,k,s,p,bm,y_h2,pipe", [(1, 300, 8, 4, 2, 128, True, 0), (2, 131, 4, 2, 1, 256, False, 0),
-                                                    (1, 70, 8, 4, 2, 256, True, 1), (1, 300, 4, 2, 1, 128, False, 1)])
+                                                    (1, 70, 8, 4, 2, 256, True, 1), (1, 300, 4, 2, 1, 128, False, 1),
+                                                    (2, 1024, 8, 4, 2, 256, True, 2), (1, 512, 4, 2, 1, 256, False, 2)])
 def test_dma_conv_kernel_matches_the_register_staged_kernel_emulated(B, Lin, k, s, p, bm, y_h2, pipe):
     """cpc_conv_gemm_forward_h2 (both operands DMA'd into XOR-swizzled LDS rows, H2 storage) against
     cpc_conv_layer_forward in mode 2 on the same fp32 data: same pieces, same products, same ChannelNorm -- results agree
@@ -211,7 +212,8 @@ def test_dma_conv_kernel_matches_the_register_staged_kernel_emulated(B, Lin, k, 
     zeros = torch.zeros(32)
     yamax = (15.968719 * nw.abs().max() + nb.abs().max()).view(1).clone()
     y = torch.full((B, Lout, 256), float("nan")); xh = torch.full_like(y, float("nan")); rs = torch.zeros(B * Lout)
-    assert lib.cpc_set_dma_pipeline(pipe) == 0           # 0: four 16-k LDS stages, 1: two 32-k stages
+    # 0: four 16-k LDS stages, 1: two 32-k stages, 2: the pair walk (every input row DMA'd once; 256-row tiles inside one sequence)
+    assert lib.cpc_set_dma_pipeline(pipe) == 0
     try:
         assert lib.cpc_conv_gemm_forward_h2(P(x_h2), P(wq), P(bias), P(nw), P(nb), P(y), P(xh), P(rs), P(xamax),
                                             P(yamax) if y_h2 else None, P(zeros), B, Lin, k, s, p, bm, None) == 0
