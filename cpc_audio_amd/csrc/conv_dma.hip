@@ -211,61 +211,70 @@ __device__ __forceinline__ void dma_gemm(f32x16 (&acc)[C::TM][C::TN], const RowM
 
 // ---- the same product with every input row fetched ONCE (forward, k = 2s, H2 operands, 256-row tiles inside one sequence)
 // Tap j of output row t and tap j + s of row t - 1 are the same input row: dma_gemm walks the taps in pairs so that the
-// second fetch hits L2, but it still crosses L2 -> LDS twice, and that bandwidth is what the kernel runs against (1.05 GB per
-// launch on layer 1, half of it activation).  Here a stage is (tap pair (j, j + s), 16 channels): the 257 input rows
-// (t0 + r) s + j - p, r = 0..256, as 64-byte segments + the two taps' weight tiles (2 x 256 x 64 B); tap j multiplies LDS rows
-// r, tap j + s rows r + 1.  49 KB per stage instead of 64 KB for the same 32 k of contraction.  Requires the tile's rows to be
-// consecutive steps of ONE sequence (Lout % 256 == 0), so that "row r + 1" is the next step of the same sequence.
-constexpr int kPairARows = 272;                              // 17 DMA pieces of 16 rows; rows 0..256 are used
-constexpr int kPairA = kPairARows * 64, kPairW = 2 * kC * 64, kPairStage = kPairA + kPairW;
+// second fetch hits L2, but it still brings the row to LDS twice.  Here the unit is a PAIR (taps j and j + s, 32 channels):
+// the 257 input rows (t0 + r) s + j - p, r = 0..256, as 128-byte rows stay in LDS for two half-stages; half 0 multiplies rows
+// r by tap j's weight tile, half 1 rows r + 1 by tap j + s's.  A and W rotate separately: two A buffers of 264 rows, two W
+// buffers of one tap each (34 + 2 x 32 KB per 64 k instead of 2 x 64 KB).  What this buys is less the bytes than the time the
+// activation rows -- the operand that comes from HBM -- get to arrive: a pair's rows are requested two half-stages before they
+// are needed (dma_gemm: one), the weights (L2 hits) one.  Requires the tile's rows to be consecutive steps of ONE sequence
+// (Lout % 256 == 0), so that "row r + 1" is the next step of the same sequence.
+constexpr int kPairARows = 264;                              // 33 DMA pieces of 8 rows; rows 0..256 are used
+constexpr int kPairA = kPairARows * 128, kPairW = kC * 128, kPairSmem = 2 * kPairA + 2 * kPairW;
 __device__ __forceinline__ void dma_gemm_pair(f32x16 (&acc)[2][4], const RowMap& am, int m0, const unsigned char* __restrict__ wq,
                                               int K, const unsigned char* __restrict__ zeros, int rot_step, unsigned char* smem) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int taps = K >> kCLog2, s = taps >> 1;
-    const int nst = s * (kC / 16);                           // stages: (pair, 16-channel chunk)
-    const int rot = (int)((blockIdx.x * (unsigned)rot_step) % (unsigned)nst);
+    const int npair = s * (kC / 32);                         // (tap pair, 32-channel chunk)
+    const int rot = (int)((blockIdx.x * (unsigned)rot_step) % (unsigned)npair);
     const int b = m0 / am.R, t0 = m0 - b * am.R;             // the tile lies inside sequence b
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(am.base) + (long)b * am.bstride * 4;
-    // lane l of a 1 KB piece: row l / 4 of its 16 rows, LDS slot l % 4, which holds global piece (l % 4) ^ ((row >> 2) & 3)
-    const int prow = lane >> 2, pslot = lane & 3;
+    // lane l of a 1 KB piece: row l / 8 of its 8 rows, LDS slot l % 8, which holds global piece (l % 8) ^ ((row >> 1) & 7)
+    const int prow = lane >> 3, pslot = lane & 7;
     const unsigned char* zsrc = zeros + pslot * 16;
-    int a_tau0[3], a_goff[3];
-    bool a_on[3];
+    // A pieces 0..32: wave w copies w, w + 8, w + 16, w + 24; wave 0 also piece 32 (row 256), FIRST, so that "the four
+    // youngest may be in flight" means the same thing for every wave
+    int a_tau0[5], a_goff[5];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int piece = wave + 8 * i, row = 16 * piece + prow;
-        a_on[i] = piece < 17;                                // wave-uniform
+    for (int i = 0; i < 5; ++i) {
+        const int piece = i == 0 ? 32 : wave + 8 * (i - 1), row = 8 * piece + prow;
         a_tau0[i] = row <= kC ? (t0 + row) * am.tmul + am.tadd : -(1 << 30);
-        a_goff[i] = (pslot ^ ((row >> 2) & 3)) * 16;
+        a_goff[i] = (pslot ^ ((row >> 1) & 7)) * 16;
     }
     const unsigned char* w_src[4];
-    int w_tap[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int piece = wave * 4 + i, half = piece >> 4, row = 16 * (piece & 15) + prow;
-        w_tap[i] = half;
-        w_src[i] = wq + (long)row * 128 + (pslot ^ ((row >> 2) & 3)) * 16;
+        const int row = 8 * (wave * 4 + i) + prow;
+        w_src[i] = wq + (long)row * 128 + (pslot ^ ((row >> 1) & 7)) * 16;
     }
-    auto issue = [&](int st_, int stage) __attribute__((always_inline)) {
-        int q = st_ + rot;
-        q = q >= nst ? q - nst : q;
-        const int j = q % s, c = q / s;                      // tap pair (j, j + s), channels 16 c .. 16 c + 15
-        unsigned char* as = smem + stage * kPairStage;
-        unsigned char* ws = as + kPairA;
+    unsigned char* const a_lds = smem;
+    unsigned char* const w_lds = smem + 2 * kPairA;
+    auto pair_of = [&](int pi, int& j, int& c) __attribute__((always_inline)) {
+        int q = pi + rot;
+        q = q >= npair ? q - npair : q;
+        j = q % s;
+        c = q / s;
+    };
+    auto issue_a = [&](int pi) __attribute__((always_inline)) {
+        int j, c;
+        pair_of(pi, j, c);
+        unsigned char* as = a_lds + (pi & 1) * kPairA;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (a_on[i]) {
+        for (int i = 0; i < 5; ++i)
+            if (i > 0 || wave == 0) {                        // wave-uniform
+                const int piece = i == 0 ? 32 : wave + 8 * (i - 1);
                 const int tau = a_tau0[i] + j;
                 const bool ok = (unsigned)tau < (unsigned)am.Lin;
-                dma16_to_lds(ok ? xb + (long)tau * (kC * 4) + c * 64 + a_goff[i] : zsrc, as + (wave + 8 * i) * 1024);
+                dma16_to_lds(ok ? xb + (long)tau * (kC * 4) + c * 128 + a_goff[i] : zsrc, as + piece * 1024);
             }
+    };
+    auto issue_w = [&](int pi, int half) __attribute__((always_inline)) {
+        int j, c;
+        pair_of(pi, j, c);
+        const long koff = (long)((j + half * s) * (kC / 32) + c) * (kC * 128);
+        unsigned char* ws = w_lds + half * kPairW + wave * 4096;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int tap = j + w_tap[i] * s;
-            const long koff = (long)((tap * kC + c * 16) >> 5) * (kC * 128) + (c & 1) * 64;
-            dma16_to_lds(w_src[i] + koff, ws + (wave * 4 + i) * 1024);
-        }
+        for (int i = 0; i < 4; ++i) dma16_to_lds(w_src[i] + koff, ws + i * 1024);
     };
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -275,28 +284,23 @@ __device__ __forceinline__ void dma_gemm_pair(f32x16 (&acc)[2][4], const RowMap&
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     const int l31 = lane & 31, kg = lane >> 5;
-    const int swb = (l31 >> 2) & 3;
+    const int swb = (l31 >> 1) & 7;
     const int a_row = wm * 64 + l31, b_row = wn * 128 + l31;
-    issue(0, 0);
-    for (int st_ = 0; st_ < nst; ++st_) {
-        CPC_WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-        if (st_ + 1 < nst) issue(st_ + 1, (st_ + 1) & 1);
-        const unsigned char* As = smem + (st_ & 1) * kPairStage;
-        const unsigned char* Ws = As + kPairA;
+    auto multiply = [&](const unsigned char* As, const unsigned char* Ws, int half) __attribute__((always_inline)) {
+        using SP = SplitPlanes<2>;
+        const int swa = ((l31 + half) >> 1) & 7;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {                     // ks = 0: tap j on rows r; ks = 1: tap j + s on rows r + 1
-            using SP = SplitPlanes<2>;
+        for (int ks = 0; ks < 2; ++ks) {
             s16x8 af[2][2], bf[4][2];
-            const int swa = ((l31 + ks) >> 2) & 3;
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
+                const int slot = 4 * ks + 2 * kg + pl;
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)
-                    af[tm][pl] = *reinterpret_cast<const s16x8*>(As + (a_row + 32 * tm + ks) * 64 + (((2 * kg + pl) ^ swa) * 16));
+                    af[tm][pl] = *reinterpret_cast<const s16x8*>(As + (a_row + 32 * tm + half) * 128 + ((slot ^ swa) * 16));
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn)
-                    bf[tn][pl] = *reinterpret_cast<const s16x8*>(Ws + ks * (kC * 64) + (b_row + 32 * tn) * 64 + (((2 * kg + pl) ^ swb) * 16));
+                    bf[tn][pl] = *reinterpret_cast<const s16x8*>(Ws + (b_row + 32 * tn) * 128 + ((slot ^ swb) * 16));
             }
 #pragma unroll
             for (int q = 0; q < SP::NPROD; ++q)
@@ -306,8 +310,24 @@ __device__ __forceinline__ void dma_gemm_pair(f32x16 (&acc)[2][4], const RowMap&
                     for (int tn = 0; tn < 4; ++tn)
                         acc[tm][tn] = SP::mfma(af[tm][SP::pa(q)], bf[tn][SP::pb(q)], acc[tm][tn]);
         }
+    };
+    issue_w(0, 0);
+    issue_a(0);
+    for (int pi = 0; pi < npair; ++pi) {
+        const bool more = pi + 1 < npair;
+        const unsigned char* As = a_lds + (pi & 1) * kPairA;
+        CPC_WAIT_VMCNT(0);                      // this pair's rows (requested two half-stages ago) and tap j's weights
+        __builtin_amdgcn_s_barrier();           // ... of every wave; and everybody is done with the previous pair
+        issue_w(pi, 1);
+        if (more) issue_a(pi + 1);
+        multiply(As, w_lds, 0);
+        if (more) { CPC_WAIT_VMCNT(4); }        // tap j + s's weights; the next pair's rows stay in flight
+        else { CPC_WAIT_VMCNT(0); }
+        __builtin_amdgcn_s_barrier();
+        if (more) issue_w(pi + 1, 0);
+        multiply(As, w_lds + kPairW, 1);
     }
-    __syncthreads();                            // the stage buffers are free (the epilogue reuses them)
+    __syncthreads();                            // the buffers are free (the epilogue reuses them)
 }
 
 // Storage of an epilogue's outputs
@@ -327,8 +347,8 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd
     using C = DmaCfg<BM, BKE, NST, NP>;
     constexpr int TM = C::TM, TN = C::TN;
     // ONE LDS object: a second one makes the compiler drain the DMA queue (vmcnt(0)) before every ds_read of the loop
-    static_assert(!PAIR || (BM == 256 && NP == 2 && 2 * kPairStage <= C::SMEM_BYTES), "the pair walk is built for 256-row H2 tiles");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES];
+    static_assert(!PAIR || (BM == 256 && NP == 2), "the pair walk is built for 256-row H2 tiles");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[PAIR ? kPairSmem : C::SMEM_BYTES];
     const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) % C::WAVES_N;
     const int m0 = blockIdx.x * BM;
     f32x16 acc[TM][TN];

@@ -12,6 +12,7 @@ def _lib_default_mode():
 from oracle import cpc_oracle as O
 
 pytestmark = pytest.mark.gpu
+DMA_PIPELINE_DEFAULT = 1
 
 
 def _dev():
@@ -25,7 +26,7 @@ def _names():
             for n, w in (("conv", "weight"), ("conv", "bias"), ("batchNorm", "weight"), ("batchNorm", "bias"))]
 
 
-def _run(lib, B, L, dev, pseed=0, bm=0, mode=1):
+def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None):
     from cpc_audio_amd._lib import ptr as P
     p = O.make_params(seed=pseed)
     plist = [p[n].contiguous().to(dev) for n in _names()]
@@ -33,6 +34,8 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1):
     sizes = (ctypes.c_long * 22)()
     assert lib.cpc_set_conv_tile(bm) == 0
     assert lib.cpc_set_mfma_mode(mode) == 0
+    if dma is not None:                      # (cpc_set_dma_tile, cpc_set_dma_pipeline)
+        assert lib.cpc_set_dma_tile(dma[0]) == 0 and lib.cpc_set_dma_pipeline(dma[1]) == 0
     assert lib.cpc_encoder_layout(B, L, sizes) == 0
     Ls = [sizes[3 + i] for i in range(5)]
     saved = torch.full((sizes[0],), float("nan"), device=dev)
@@ -58,6 +61,9 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1):
     torch.cuda.synchronize()
     lib.cpc_set_conv_tile(0)
     lib.cpc_set_mfma_mode(_lib_default_mode())
+    if dma is not None:
+        lib.cpc_set_dma_tile(0)
+        lib.cpc_set_dma_pipeline(DMA_PIPELINE_DEFAULT)
     # oracle
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("gEncoder")}
     acts = []
@@ -68,6 +74,20 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1):
     (zr * dz).sum().backward()
     return dict(z=z.cpu(), z_ref=zr.detach(), grads=[g_.cpu() for g_ in grads],
                 ref_grads=[leaves[n].grad for n in _names()], saved=saved, sizes=sizes, Ls=Ls, acts=acts, ys=ys)
+
+
+@pytest.mark.parametrize("pipe", [1, 2])
+def test_encoder_dma_pipelines_match_oracle(pipe):
+    """Layer 1 on 256-row tiles of the DMA kernel at a size the oracle finishes quickly: the two-stage walk (1) and the
+    tap-pair walk (2: every input row brought to LDS once, used by both taps that read it)."""
+    dev = _dev()
+    from cpc_audio_amd import _lib
+    r = _run(_lib.get(), 8, 20480, dev, mode=3, dma=(256, pipe))
+    assert (r["z"] - r["z_ref"]).abs().max().item() < 1e-4
+    for i in range(4):
+        assert (r["ys"][i] - r["acts"][i].permute(0, 2, 1)).abs().max().item() < 1e-4, i
+    for n, g, ref in zip(_names(), r["grads"], r["ref_grads"]):
+        assert ((g.view_as(ref) - ref).norm() / (ref.norm() + 1e-30)).item() < 1e-4, n
 
 
 @pytest.mark.parametrize("B,L,bm,mode", [(2, 20480, 0, 1), (3, 20480, 128, 1), (1, 4330, 64, 1), (8, 20480, 0, 1),
