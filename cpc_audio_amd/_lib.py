@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcpc_hip.so")
 DEFAULT_GRU_MODE = 2       # cpc_set_gru_mode: persistent recurrence, forward products on the fp16 split
 DEFAULT_MFMA_MODE = 3      # what libcpc_hip starts in (cpc_set_mfma_mode): conv layers on the fp16 split, GEMMs on the bf16 split
+DEFAULT_DMA_PIPELINE = 2   # cpc_set_dma_pipeline: the tap-pair walk where the shape allows, two 32-k stages elsewhere
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int

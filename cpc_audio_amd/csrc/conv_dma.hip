@@ -14,10 +14,11 @@
 //   * tiles are BM x 256 x 32(k) with 64 x 128 wave tiles (8 accumulator tiles of 32 x 32 per wave): 12 ds_read_b128
 //     per 24 MFMAs, 62 B/clk of LDS reads per CU at the full MFMA rate (the 64 x 64 wave tiles of the older kernel need
 //     85 + 32 B/clk of the 128 available);
-//   * four LDS stages of (BM + 256) x 64 B (16 k), three of them in flight or landed ahead of the one being multiplied:
-//     what limits this kernel is the per-CU global -> LDS rate, which is latency-bound (~10 B/clk per CU with one 64 KB
-//     stage in flight, far below L2's bandwidth), so the bytes kept in flight are what counts; counted vmcnt (the two
-//     younger stages stay in flight) + one raw s_barrier per stage.  (cpc_set_dma_pipeline(1): two 32-k stages.)
+//   * two LDS stages of (BM + 256) x 128 B (32 k), one in flight while the other is multiplied; counted vmcnt + one raw
+//     s_barrier per stage (cpc_set_dma_pipeline: the other schedules that were measured, and what they showed -- neither
+//     the L2 -> LDS path (27 TB/s chip-wide in tools/probe_dma_bw.hip, the kernel draws 5) nor the bytes in flight limit
+//     this kernel; at the full clock it is the issue structure (a DMA piece costs its wave ~70 clocks among MFMAs and
+//     100-300 next to LDS reads), inside the train step the power budget);
 //   * LDS rows are 64 B with the four 16-byte pieces XOR-swizzled by ((row >> 2) & 3) (128 B / eight pieces /
 //     ((row >> 1) & 7) in the two-stage variant): the lanes of every ds_read_b128 service group then hit 16 distinct
 //     16-byte slots (conflict-free).  The swizzle is applied on the GLOBAL side
@@ -72,7 +73,23 @@ __device__ __forceinline__ int dma_c_col(int tn) {
 // acc[64 x 128 per wave] += A[m0.., 0:K] . B[0:256, 0:K]^T with both operands DMA'd global -> LDS.
 // am: rows of the A operand in ELEMENTS of C::ESZ bytes (im2col windows: element k of a row is real iff the position
 // tau0 + (k >> 8) is inside [0, Lin), otherwise it reads `zeros`); wq: weight rows of 128 bytes, [K / KPR][256][128 B].
-template <class C>
+#ifdef CPC_DMA_TIMING
+// tools/time_dma_slots.py: s_memtime stamps of two ping-pong iterations of one workgroup, [wave][iteration][stamp]
+__device__ unsigned long long g_dma_stamps[8 * 2 * 6];
+#define CPC_STAMP(i) if (kt == 40 || kt == 41) stamp[(kt - 40) * 6 + (i)] = __builtin_readcyclecounter()
+#else
+#define CPC_STAMP(i)
+#endif
+// PP (needs BKE = 16, four stages): the two waves of a SIMD (w and w + 4) alternate roles, one multiplies k-step n from
+// registers while the other reads its fragments of that k-step out of LDS and issues its DMA pieces of stage n + 3, with a
+// barrier between the slots.  Without it all eight waves leave the stage barrier together, issue their DMA pieces and LDS reads
+// together (the texture path takes 16 clocks per 1 KB piece, the eight waves' reads share the LDS) and only then start to
+// multiply: the matrix pipe idles for more than half of every stage.
+// SKEW: the slots are cut differently -- slot A = the l*h and h*l products (16 MFMAs) with the DMA pieces between them,
+// slot B = the low planes of the next k-step's fragments -> the registers that just became free, the h*h products (8 MFMAs),
+// then the high planes; while one wave of a SIMD is in A its partner is in B, so every slot carries 24 MFMAs per SIMD and
+// both waves' non-matrix work runs in the other's matrix time.
+template <class C, int NDC = -1, bool SKEW = false>
 __device__ __forceinline__ void dma_gemm(f32x16 (&acc)[C::TM][C::TN], const RowMap& am, int m0,
                                          const unsigned char* __restrict__ wq, int K, const unsigned char* __restrict__ zeros,
                                          int rot_step, unsigned char* smem) {
@@ -111,7 +128,8 @@ __device__ __forceinline__ void dma_gemm(f32x16 (&acc)[C::TM][C::TN], const RowM
         b_src[i] = wq + (long)row * 128 + piece * 16;       // global weight rows are 128 B whatever the stage depth
     }
     const unsigned char* zsrc = zeros + (lane % C::PPR) * 16;
-    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+    // pieces [lo, hi) of a wave's NPS DMA pieces of stage kt (A pieces first)
+    auto issue_part = [&](int kt, int stage, int lo, int hi) __attribute__((always_inline)) {
         int q = kt + rot;
         q = q >= nkt ? q - nkt : q;
         // tap-fastest walk (gemm_tile.h, tshift), the taps in the order 0, s, 1, s+1, ...: tap j of output row t and tap
@@ -127,13 +145,16 @@ __device__ __forceinline__ void dma_gemm(f32x16 (&acc)[C::TM][C::TN], const RowM
         unsigned char* as = smem + stage * C::STAGE + (wave * C::A_PER) * 1024;
         unsigned char* bs = smem + stage * C::STAGE + C::A_BYTES + (wave * C::B_PER) * 1024;
 #pragma unroll
-        for (int i = 0; i < C::A_PER; ++i) {
-            const bool ok = (unsigned)(a_tau0[i] + tap) < (unsigned)am.Lin;
-            dma16_to_lds(ok ? a_src[i] + koff : zsrc, as + i * 1024);
-        }
+        for (int i = 0; i < C::A_PER; ++i)
+            if (i >= lo && i < hi) {
+                const bool ok = (unsigned)(a_tau0[i] + tap) < (unsigned)am.Lin;
+                dma16_to_lds(ok ? a_src[i] + koff : zsrc, as + i * 1024);
+            }
 #pragma unroll
-        for (int i = 0; i < C::B_PER; ++i) dma16_to_lds(b_src[i] + boff, bs + i * 1024);
+        for (int i = 0; i < C::B_PER; ++i)
+            if (C::A_PER + i >= lo && C::A_PER + i < hi) dma16_to_lds(b_src[i] + boff, bs + i * 1024);
     };
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) { issue_part(kt, stage, 0, C::NPS); };
 
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -145,6 +166,158 @@ __device__ __forceinline__ void dma_gemm(f32x16 (&acc)[C::TM][C::TN], const RowM
     const int sw = ((lane & 31) >> C::SWSH) & (C::PPR - 1), kg = lane >> 5;
     const int a_row0 = (wm * 64 + (lane & 31)) * C::ROWB, b_row0 = (wn * 128 + (lane & 31)) * C::ROWB;
 
+    if constexpr (SKEW) {
+        static_assert(C::KS == 1 && C::NST == 4 && C::NP == 2 && C::NPS == 4, "one k-step per stage, four stages, H2 operands");
+        using SP = SplitPlanes<2>;
+        const int grp = wave >> 2;                              // waves w and w + 4 share a SIMD
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < nkt) issue(j, j);
+        CPC_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();                           // stages 0..2 have landed for everybody
+        s16x8 af[TM][2], bf[TN][2];
+        auto read_plane = [&](int kt, int pl) __attribute__((always_inline)) {
+            const unsigned char* As = smem + (kt & 3) * C::STAGE;
+            const unsigned char* Bs = As + C::A_BYTES;
+            const int off = ((2 * kg + pl) ^ sw) * 16;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                af[tm][pl] = *reinterpret_cast<const s16x8*>(As + a_row0 + tm * 32 * C::ROWB + off);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                bf[tn][pl] = *reinterpret_cast<const s16x8*>(Bs + b_row0 + tn * 32 * C::ROWB + off);
+        };
+        read_plane(0, 0);
+        read_plane(0, 1);
+        CPC_WAIT_LGKMCNT0();
+        if (grp == 1) __builtin_amdgcn_s_barrier();             // the second group runs one slot behind
+#ifdef CPC_DMA_TIMING
+        unsigned long long stamp[12] = {};
+#endif
+        for (int kt = 0; kt < nkt; ++kt) {
+            CPC_STAMP(0);
+            // ---- slot A: l*h and h*l of k-step kt; my DMA pieces of stage kt + 3 (into the buffer of stage kt - 1, read two
+            // slots ago) between the MFMAs
+            const bool more = kt + 3 < nkt;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2 * TM * TN; ++i) {
+                const int q = i / (TM * TN), tm = (i / TN) % TM, tn = i % TN;
+                acc[tm][tn] = SP::mfma(af[tm][SP::pa(q)], bf[tn][SP::pb(q)], acc[tm][tn]);
+                if (i % 4 == 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) issue_part(kt + 3, (kt + 3) & 3, i / 4, i / 4 + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            CPC_STAMP(1);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            CPC_STAMP(2);
+            // ---- slot B: the low planes of k-step kt + 1 (their registers are free), h*h of k-step kt, the high planes
+            const bool next = kt + 1 < nkt;
+            if (next) read_plane(kt + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = SP::mfma(af[tm][0], bf[tn][0], acc[tm][tn]);
+            __builtin_amdgcn_sched_barrier(0);
+            CPC_STAMP(3);
+            if (next) read_plane(kt + 1, 0);
+            CPC_WAIT_LGKMCNT0();
+            if (more) { CPC_WAIT_VMCNT(C::NPS); }               // my pieces of stage kt + 2 have landed (kt + 3 in flight)
+            else { CPC_WAIT_VMCNT(0); }
+            __builtin_amdgcn_sched_barrier(0);
+            CPC_STAMP(4);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            CPC_STAMP(5);
+        }
+#ifdef CPC_DMA_TIMING
+        if (blockIdx.x == 37 && lane == 0)
+            for (int i = 0; i < 12; ++i) g_dma_stamps[wave * 12 + i] = stamp[i];
+#endif
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+        __syncthreads();
+        return;
+    }
+    if constexpr (NDC >= 0) {
+        static_assert(C::KS == 1 && C::NST == 4 && C::NP == 2 && NDC <= C::NPS, "ping-pong: one k-step per stage, four stages, H2 operands");
+        using SP = SplitPlanes<2>;
+        constexpr int NDL = C::NPS - NDC;                       // pieces issued in the load slot
+        const int grp = wave >> 2;                              // waves w and w + 4 share a SIMD
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < nkt) issue(j, j);
+        if (nkt > 2) { CPC_WAIT_VMCNT(2 * C::NPS); }
+        else { CPC_WAIT_VMCNT(0); }
+        __builtin_amdgcn_s_barrier();                           // stage 0 has landed for everybody
+        if (grp == 1) __builtin_amdgcn_s_barrier();             // the second group runs one slot behind
+#ifdef CPC_DMA_TIMING
+        unsigned long long stamp[12] = {};
+#endif
+        for (int kt = 0; kt < nkt; ++kt) {
+            CPC_STAMP(0);
+            // ---- load slot: fragments of k-step kt -> registers; the first NDL DMA pieces of stage kt + 3 into the buffer of
+            // stage kt - 1 (whose last readers finished their load slot before the barrier that opened this one)
+            const unsigned char* As = smem + (kt & 3) * C::STAGE;
+            const unsigned char* Bs = As + C::A_BYTES;
+            s16x8 af[TM][2], bf[TN][2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const int off = ((2 * kg + pl) ^ sw) * 16;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    af[tm][pl] = *reinterpret_cast<const s16x8*>(As + a_row0 + tm * 32 * C::ROWB + off);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    bf[tn][pl] = *reinterpret_cast<const s16x8*>(Bs + b_row0 + tn * 32 * C::ROWB + off);
+            }
+            const bool more = kt + 3 < nkt;
+            if (NDL > 0 && more) issue_part(kt + 3, (kt + 3) & 3, 0, NDL);
+            CPC_STAMP(1);
+            CPC_WAIT_LGKMCNT0();                                // my reads are done before anybody may overwrite the buffer
+            // my pieces of stage kt + 1 have landed; stage kt + 2 and what this slot issued of kt + 3 stay in flight
+            if (more) { CPC_WAIT_VMCNT(C::NPS + NDL); }
+            else if (kt + 2 < nkt) { CPC_WAIT_VMCNT(C::NPS); }
+            else { CPC_WAIT_VMCNT(0); }
+            CPC_STAMP(2);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            CPC_STAMP(3);
+            // ---- multiply slot, the other NDC pieces spread between the MFMAs (a piece issued among MFMAs costs the wave
+            // far less than one issued in a burst of loads, MI355X_MICROARCH.md)
+            constexpr int NM = SP::NPROD * TM * TN;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                const int q = i / (TM * TN), tm = (i / TN) % TM, tn = i % TN;
+                acc[tm][tn] = SP::mfma(af[tm][SP::pa(q)], bf[tn][SP::pb(q)], acc[tm][tn]);
+                if constexpr (NDC > 0) {
+                    constexpr int every = NM / NDC;
+                    if (i % every == every - 3) {               // after MFMAs 3, 9, 15, 21 (NDC = 4)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) issue_part(kt + 3, (kt + 3) & 3, NDL + i / every, NDL + i / every + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            CPC_STAMP(4);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            CPC_STAMP(5);
+        }
+#ifdef CPC_DMA_TIMING
+        if (blockIdx.x == 37 && lane == 0)
+            for (int i = 0; i < 12; ++i) g_dma_stamps[wave * 12 + i] = stamp[i];
+#endif
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+        __syncthreads();
+        return;
+    }
     // NST - 1 stages ahead: at the top of iteration kt the stages kt .. kt + NST - 2 have been issued; stage kt must have
     // landed (vmcnt leaves the NST - 2 younger ones in flight), the barrier publishes it to the other waves and retires
     // everybody's reads of stage kt - 1, whose buffer the DMA of stage kt + NST - 1 then overwrites.
@@ -337,7 +510,7 @@ constexpr int kStoreF32 = 0, kStoreH2 = 1, kStoreBf16 = 2;
 // rows (permute_w_h2 / permute_w_bf16), for NP = 2 max|w| behind it.  y is written as `ykind` says (H2: scaled by
 // scale_for_amax(*y_amax)), xhat as `xkind` (fp32 or bf16), rstd fp32.
 // zeros: >= 128 bytes of zeros (the rows of the conv's zero padding and of the ragged last tile read them).
-template <int BM, int BKE, int NST, int NP, bool PAIR = false>
+template <int BM, int BKE, int NST, int NP, int WALK = 0>      // WALK 1: dma_gemm_pair; 2, 3, 4: ping-pong slots with 0, 2, 4 pieces issued among the MFMAs
 __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd_dma_kernel(
     RowMap am, const unsigned char* __restrict__ wq, int K, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, void* __restrict__ y, int ykind,
@@ -347,13 +520,14 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd
     using C = DmaCfg<BM, BKE, NST, NP>;
     constexpr int TM = C::TM, TN = C::TN;
     // ONE LDS object: a second one makes the compiler drain the DMA queue (vmcnt(0)) before every ds_read of the loop
+    constexpr bool PAIR = WALK == 1;
     static_assert(!PAIR || (BM == 256 && NP == 2), "the pair walk is built for 256-row H2 tiles");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[PAIR ? kPairSmem : C::SMEM_BYTES];
     const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) % C::WAVES_N;
     const int m0 = blockIdx.x * BM;
     f32x16 acc[TM][TN];
     if constexpr (PAIR) dma_gemm_pair(acc, am, m0, wq, K, zeros, rot_step, smem);
-    else dma_gemm<C>(acc, am, m0, wq, K, zeros, rot_step, smem);
+    else dma_gemm<C, (WALK == 0 || WALK == 5) ? -1 : 2 * (WALK - 2), WALK == 5>(acc, am, m0, wq, K, zeros, rot_step, smem);
 
     // ---- epilogue: undo the operand scales, bias, ChannelNorm (two passes over the accumulators), ReLU
     float inv = 1.0f;
@@ -811,9 +985,16 @@ __global__ __launch_bounds__(256) void h2_encode_kernel(const float* __restrict_
 
 static int g_dma_rot = 5;     // K-walk rotation step between neighbouring workgroups (0: all walk in lockstep); measured on
                               // layer 1 at B = 64: 0.224 / 0.217 / 0.209 ms for steps 0 / 1 / 5 (two 32-k stages)
-static int g_dma_pipe = 1;    // 1: two 32-k stages (default); 0: four 16-k stages, three in flight -- measured slower on layer 1 at
-                              // B = 64 (0.223-0.244 vs 0.196-0.206 ms): 64-byte row segments and twice the barriers cost more
-                              // than the deeper prefetch buys
+static int g_dma_pipe = 2;    // main-loop schedule of the forward kernel on 256-row tiles (cpc_set_dma_pipeline), layer 1 at B = 64,
+                              // clocks per 32 k of contraction and CU with zero operands (= at the full clock; floor 3072 = the
+                              // MFMAs of two waves per SIMD), tools/bench_conv_k.py:
+                              //   1: two 32-k stages                                   6130
+                              //   2: tap-pair walk (dma_gemm_pair; where k = 2s and Lout % 256 == 0, else 1; default)  5160
+                              //   0: four 16-k stages, three in flight                 slower than 1 (64-byte rows, twice the barriers)
+                              //   3, 4, 5: ping-pong slots with 0 / 2 / 4 DMA pieces among the MFMAs   5600-6400
+                              //   6: skewed slots (16 + 8 MFMAs per slot and wave)     6400
+                              // Inside the train step all of them take 205-210 us (the kernel runs against
+                              // the chip's power budget there, random operands cost 35-40 % over zeros in every schedule).
 
 int conv_fwd_dma(const float* x_h2, const float* wq, const float* bias, const float* nw, const float* nb, float* y,
                  int y_h2, float* xhat, float* rstd, const float* x_amax, const float* y_amax, const float* zeros, int B,
@@ -832,9 +1013,18 @@ int conv_fwd_dma(const float* x_h2, const float* wq, const float* bias, const fl
                        0, st, am, wqb, K, bias, nw, nb, (void*)y, ykind, (void*)xhat, kStoreF32, rstd, x_amax, w_amax, y_amax, zb,   \
                        g_dma_rot)
     if (bm == 256 && g_dma_pipe == 2 && k == 2 * s && Lout % 256 == 0)          // every input row once (dma_gemm_pair)
-        hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 32, 2, 2, true>), dim3(cdiv(am.M, 256)), dim3(DmaCfg<256, 32, 2, 2>::NTHREADS), 0,
+        hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 32, 2, 2, 1>), dim3(cdiv(am.M, 256)), dim3(DmaCfg<256, 32, 2, 2>::NTHREADS), 0,
                            st, am, wqb, K, bias, nw, nb, (void*)y, ykind, (void*)xhat, kStoreF32, rstd, x_amax, w_amax, y_amax, zb,
                            g_dma_rot);
+#define CPC_LAUNCH_PP(WALK_)                                                                                                       \
+    hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 16, 4, 2, WALK_>), dim3(cdiv(am.M, 256)), dim3(DmaCfg<256, 16, 4, 2>::NTHREADS), 0, \
+                       st, am, wqb, K, bias, nw, nb, (void*)y, ykind, (void*)xhat, kStoreF32, rstd, x_amax, w_amax, y_amax, zb,   \
+                       g_dma_rot)
+    else if (bm == 256 && g_dma_pipe == 3) CPC_LAUNCH_PP(2);                    // ping-pong slots
+    else if (bm == 256 && g_dma_pipe == 4) CPC_LAUNCH_PP(3);
+    else if (bm == 256 && g_dma_pipe == 5) CPC_LAUNCH_PP(4);
+    else if (bm == 256 && g_dma_pipe == 6) CPC_LAUNCH_PP(5);                    // skewed slots
+#undef CPC_LAUNCH_PP
     else if (bm == 256 && g_dma_pipe == 0) CPC_LAUNCH_DMA(256, 16, 4);
     else if (bm == 256) CPC_LAUNCH_DMA(256, 32, 2);
     else if (g_dma_pipe == 0) CPC_LAUNCH_DMA(128, 16, 4);
@@ -952,8 +1142,13 @@ extern "C" int cpc_set_dma_rotation(int step) {
     g_dma_rot = step;
     return 0;
 }
-extern "C" int cpc_set_dma_pipeline(int variant) {   // 2: as 1, with the pair walk (dma_gemm_pair) where the shape allows
-    CPC_RETURN_IF(variant < 0 || variant > 2, CPC_ERR_ARG);
+#ifdef CPC_DMA_TIMING
+extern "C" int cpc_debug_dma_stamps(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(cpc::g_dma_stamps), sizeof(unsigned long long) * 96) == hipSuccess ? 0 : CPC_ERR_ARG;
+}
+#endif
+extern "C" int cpc_set_dma_pipeline(int variant) {   // 2: as 1, with the pair walk (dma_gemm_pair) where the shape allows; 3: ping-pong slots
+    CPC_RETURN_IF(variant < 0 || variant > 6, CPC_ERR_ARG);
     g_dma_pipe = variant;
     return 0;
 }

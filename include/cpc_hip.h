@@ -96,9 +96,12 @@ int cpc_set_gemm_split(int on);          /* 1 (default): plain GEMMs with known 
                                             fp16 pieces in mode >= 2, wide products on the 128 x 256 pipelined tile; 0: three bf16 pieces always;
                                             2: two pieces but never the wide tile; 3: the wide tile whatever the grid size (tests) */
 int cpc_set_dma_rotation(int step);
-int cpc_set_dma_pipeline(int variant);   /* 1 (default): two 32-k LDS stages; 0: four 16-k stages, three in flight;
-                                          * 2: tap-pair walk (an input row reaches LDS once for both taps that read it) where
-                                          * k == 2*stride and Lout % 256 == 0, variant 1 elsewhere — slower, DESIGN §4.10 */
+int cpc_set_dma_pipeline(int variant);   /* main-loop schedule of the forward DMA kernel on 256-row tiles (tuning / measurement switch; results
+                                          * agree to rounding order).  2 (default): tap-pair walk -- an input row reaches LDS once for both
+                                          * taps that read it -- where k == 2*stride and Lout % 256 == 0, variant 1 elsewhere; 1: two 32-k
+                                          * LDS stages; 0: four 16-k stages, three in flight; 3, 4, 5: ping-pong slots (one wave of a SIMD
+                                          * multiplies while its partner loads) with 0 / 2 / 4 DMA pieces issued among the MFMAs; 6: skewed
+                                          * slots.  What each measured: DESIGN.md section 4.10 */
 long cpc_conv0_backward_scratch_floats(int B, int L);
 /* Backward of layer 0 (no dgrad: the waveform needs no gradient, train.py:81-87).
  * dy = gradient w.r.t. y.  Outputs dW0 (256,1,10), dB0, dNW0, dNB0 (256) are overwritten. */

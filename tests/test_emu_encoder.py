@@ -7,6 +7,11 @@ import pytest
 import torch
 
 
+def _lib_default_pipeline():
+    from cpc_audio_amd._lib import DEFAULT_DMA_PIPELINE
+    return DEFAULT_DMA_PIPELINE
+
+
 def _lib_default_mode():
     from cpc_audio_amd._lib import DEFAULT_MFMA_MODE
     return DEFAULT_MFMA_MODE
@@ -109,7 +114,7 @@ def test_encoder_forward_backward_emulated(B, L, bm, mode):
         lib.cpc_set_conv_tile(0)
         lib.cpc_set_mfma_mode(_lib_default_mode())
         lib.cpc_set_h2_layers(0)
-        lib.cpc_set_dma_pipeline(0)
+        lib.cpc_set_dma_pipeline(_lib_default_pipeline())
         lib.cpc_set_h2_dx(1)
 
 
@@ -181,7 +186,10 @@ def test_fp16_split_scaling_extremes_emulated(xs, ws):
 
 @pytest.mark.parametrize("B,Lin,k,s,p,bm,y_h2,pipe", [(1, 300, 8, 4, 2, 128, True, 0), (2, 131, 4, 2, 1, 256, False, 0),
                                                     (1, 70, 8, 4, 2, 256, True, 1), (1, 300, 4, 2, 1, 128, False, 1),
-                                                    (2, 1024, 8, 4, 2, 256, True, 2), (1, 512, 4, 2, 1, 256, False, 2)])
+                                                    (2, 1024, 8, 4, 2, 256, True, 2), (1, 512, 4, 2, 1, 256, False, 2),
+                                                    (1, 300, 8, 4, 2, 256, True, 3), (2, 131, 4, 2, 1, 256, False, 3),
+                                                    (1, 300, 8, 4, 2, 256, True, 4), (2, 131, 4, 2, 1, 256, False, 5),
+                                                    (1, 300, 8, 4, 2, 256, True, 6), (2, 131, 4, 2, 1, 256, False, 6)])
 def test_dma_conv_kernel_matches_the_register_staged_kernel_emulated(B, Lin, k, s, p, bm, y_h2, pipe):
     """cpc_conv_gemm_forward_h2 (both operands DMA'd into XOR-swizzled LDS rows, H2 storage) against
     cpc_conv_layer_forward in mode 2 on the same fp32 data: same pieces, same products, same ChannelNorm -- results agree
@@ -218,7 +226,7 @@ def test_dma_conv_kernel_matches_the_register_staged_kernel_emulated(B, Lin, k, 
         assert lib.cpc_conv_gemm_forward_h2(P(x_h2), P(wq), P(bias), P(nw), P(nb), P(y), P(xh), P(rs), P(xamax),
                                             P(yamax) if y_h2 else None, P(zeros), B, Lin, k, s, p, bm, None) == 0
     finally:
-        lib.cpc_set_dma_pipeline(0)
+        lib.cpc_set_dma_pipeline(_lib_default_pipeline())
     if y_h2:
         dec = torch.full_like(y, float("nan"))
         assert lib.cpc_h2_decode(P(y), P(dec), B * Lout, P(yamax), None) == 0

@@ -12,7 +12,7 @@ def _lib_default_mode():
 from oracle import cpc_oracle as O
 
 pytestmark = pytest.mark.gpu
-DMA_PIPELINE_DEFAULT = 1
+from cpc_audio_amd._lib import DEFAULT_DMA_PIPELINE as DMA_PIPELINE_DEFAULT  # noqa: E402
 
 
 def _dev():
@@ -76,9 +76,9 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None):
                 ref_grads=[leaves[n].grad for n in _names()], saved=saved, sizes=sizes, Ls=Ls, acts=acts, ys=ys)
 
 
-@pytest.mark.parametrize("pipe", [1, 2])
+@pytest.mark.parametrize("pipe", [1, 2, 3, 5, 6])
 def test_encoder_dma_pipelines_match_oracle(pipe):
-    """Layer 1 on 256-row tiles of the DMA kernel at a size the oracle finishes quickly: the two-stage walk (1) and the
+    """Layer 1 on 256-row tiles of the DMA kernel at a size the oracle finishes quickly: the two-stage walk (1), the ping-pong slots (3) and the
     tap-pair walk (2: every input row brought to LDS once, used by both taps that read it)."""
     dev = _dev()
     from cpc_audio_amd import _lib

@@ -83,7 +83,7 @@ def main():
                     t = timeit(new)
                     out[f"conv{layer}_dma_pipe{pipe}_bm{bm}_rot{rot}"] = [round(t, 4), round(flop / t / 1e9, 1)]
         lib.cpc_set_dma_rotation(5)
-        lib.cpc_set_dma_pipeline(0)
+        lib.cpc_set_dma_pipeline(_lib.DEFAULT_DMA_PIPELINE)
         # agreement of the two kernels on the same data
         old()
         xh_old = xh.clone()
