@@ -97,44 +97,93 @@ def _reader_for(path):
 
 
 def loadFile(data):
-    """(speaker, path) -> (speaker, sequence name, mono float waveform), cpc/dataset.py:249-258."""
-    speaker, fullPath = data
-    seq = _reader_for(fullPath)[0](fullPath)
-    seq = seq if torch.is_tensor(seq) else torch.from_numpy(np.ascontiguousarray(seq))
-    return speaker, Path(fullPath).stem, seq.float()
+    """(speaker, path) -> (speaker, sequence name, mono float waveform); what the reference's loader of the same name
+    returns (cpc/dataset.py:249-258), read through the pluggable readers."""
+    spk, where = data
+    wav = _reader_for(where)[0](where)
+    if not torch.is_tensor(wav):
+        wav = torch.from_numpy(np.ascontiguousarray(wav))
+    return spk, Path(where).stem, wav.float()
 
 
 def extractLength(couple):
-    """cpc/dataset.py:411-414."""
-    _, locPath = couple
-    read, length = _reader_for(locPath)
-    return length(locPath) if length is not None else int(read(locPath).shape[0])
+    """Number of samples of a (speaker, path) entry without decoding it where the reader can tell (cpc/dataset.py:411-414)."""
+    where = couple[1]
+    read, length = _reader_for(where)
+    return int(read(where).shape[0]) if length is None else length(where)
 
 
 # ----------------------------------------------------------------------------------------------- the dataset
+def _cut_into_packs(lengths, cap):
+    """Greedy cut of a sequence list into packs of at most ~cap samples -> ([(first, last)], samples counted).  The sequence
+    that overflows a pack opens the next one, and its samples are counted with the pack it overflowed -- the reference's
+    accounting (cpc/dataset.py:104-118), which len(dataset) and the loaders' progress estimates are built on."""
+    packs, counted, first, running = [], 0, 0, 0
+    for i, n in enumerate(lengths):
+        running += n
+        if running > cap:
+            packs.append((first, i))
+            counted += running
+            first, running = i, 0
+    if running:
+        packs.append((first, len(lengths)))
+        counted += running
+    return packs, counted
+
+
+class _Pack:
+    """One pack resident in memory: the waveforms of its sequences back to back, ordered by (speaker, name), with the
+    boundaries the samplers and label look-ups need.  Boundaries are computed with tensor ops from the per-sequence sizes:
+      seq_bounds      (n_seq + 1,)   sample offset of every sequence
+      speaker_bounds  (last speaker + 2,)   sample offset of every speaker index up to the last one present
+    (cpc/dataset.py:142-170 builds the same two lists in a Python loop)."""
+
+    def __init__(self, loaded, n_speakers, phone_labels, phone_size):
+        loaded = sorted(loaded, key=lambda item: (item[0], item[1]))
+        spk = torch.tensor([item[0] for item in loaded], dtype=torch.long)
+        if len(loaded) and (int(spk.min()) < 0 or int(spk.max()) >= n_speakers):
+            bad = int(spk[(spk < 0) | (spk >= n_speakers)][0])
+            raise ValueError(f"{bad} invalid speaker")
+        waves, phones = [], []
+        for _, name, wav in loaded:
+            if phone_labels is not None:                 # a labelled sequence ends where its labels end
+                lab = phone_labels[name]
+                phones.extend(lab)
+                wav = wav[:len(lab) * phone_size]
+            waves.append(wav)
+        sizes = torch.tensor([w.size(0) for w in waves], dtype=torch.long)
+        zero = sizes.new_zeros(1)
+        self.seq_bounds = torch.cat([zero, torch.cumsum(sizes, 0)])
+        per_speaker = torch.zeros(int(spk.max()) + 1 if len(loaded) else 0, dtype=torch.long).index_add_(0, spk, sizes)
+        self.speaker_bounds = torch.cat([zero, torch.cumsum(per_speaker, 0)])
+        self.phones = phones
+        self.wave = torch.cat(waves, dim=0) if waves else torch.zeros(0)
+
+
 class AudioBatchData(Dataset):
-    """cpc/dataset.py:20-246."""
+    """The reference's in-memory audio data set (cpc/dataset.py:20-246) by name, constructor and public attributes:
+    sequences are shuffled and cut into packs of at most MAX_SIZE_LOADED samples; one pack is resident (``data``, with
+    ``speakerLabel`` / ``seqLabel`` sample boundaries and ``phoneLabels``) while the next one is decoded in the background."""
 
     def __init__(self, path, sizeWindow, seqNames, phoneLabelsDict, nSpeakers, nProcessLoader=50,
                  MAX_SIZE_LOADED=4000000000):
-        self.MAX_SIZE_LOADED = MAX_SIZE_LOADED
-        self.nProcessLoader = nProcessLoader
-        self.dbPath = Path(path)
-        self.sizeWindow = sizeWindow
-        self.seqNames = [(s, self.dbPath / x) for s, x in seqNames]
-        self.reload_pool = ThreadPoolExecutor(max_workers=max(1, min(nProcessLoader, os.cpu_count() or 1)))
-        self.device = torch.device("cpu")
-
-        self.prepare()
+        self.dbPath, self.sizeWindow = Path(path), sizeWindow
+        self.MAX_SIZE_LOADED, self.nProcessLoader = MAX_SIZE_LOADED, nProcessLoader
+        self.seqNames = [(spk, self.dbPath / rel) for spk, rel in seqNames]
         self.speakers = list(range(nSpeakers))
-        self.data = []
-
-        self.phoneSize = 0 if phoneLabelsDict is None else phoneLabelsDict["step"]
-        self.phoneStep = 0 if phoneLabelsDict is None else self.sizeWindow // self.phoneSize
-        self.phoneLabelsDict = deepcopy(phoneLabelsDict)
-        self.loadNextPack(first=True)
-        self.loadNextPack()
         self.doubleLabels = False
+        self.device = torch.device("cpu")
+        self.reload_pool = ThreadPoolExecutor(max_workers=max(1, min(nProcessLoader, os.cpu_count() or 1)))
+        self._set_phone_labels(phoneLabelsDict, None if phoneLabelsDict is None else phoneLabelsDict["step"])
+        self.prepare()
+        self.data = []
+        self.loadNextPack(first=True)                    # starts decoding pack 0 ...
+        self.loadNextPack()                              # ... installs it and starts on pack 1
+
+    def _set_phone_labels(self, labels, step):
+        self.phoneLabelsDict = deepcopy(labels)
+        self.phoneSize = 0 if labels is None else step
+        self.phoneStep = 0 if labels is None else self.sizeWindow // step
 
     # -- device residency (addition): keep the packed waveform on the GPU
     def to(self, device):
@@ -145,14 +194,11 @@ class AudioBatchData(Dataset):
     def _place(self):
         if torch.is_tensor(self.data):
             self.data = self.data.to(self.device, non_blocking=True)
-        self._speakerBounds = torch.tensor(self.speakerLabel, dtype=torch.long, device=self.device)
-        self._phones = (torch.tensor(self.phoneLabels, dtype=torch.long, device=self.device)
-                        if self.phoneSize > 0 else None)
+        self._speakerBounds = self._bounds_tensor(self.speakerLabel)
+        self._phones = self._bounds_tensor(self.phoneLabels) if self.phoneSize > 0 else None
 
     def resetPhoneLabels(self, newPhoneLabels, step):
-        self.phoneSize = step
-        self.phoneStep = self.sizeWindow // self.phoneSize
-        self.phoneLabelsDict = deepcopy(newPhoneLabels)
+        self._set_phone_labels(newPhoneLabels, step)
         self.loadNextPack()
 
     @staticmethod
@@ -160,96 +206,67 @@ class AudioBatchData(Dataset):
         return os.path.normpath(seqName).split(os.sep)
 
     def getSeqNames(self):
-        return [str(x[1]) for x in self.seqNames]
+        return [str(where) for _, where in self.seqNames]
 
     def clear(self):
-        for name in ("data", "speakerLabel", "phoneLabels", "seqLabel"):
-            if name in self.__dict__:
-                delattr(self, name)
+        for field in ("data", "speakerLabel", "seqLabel", "phoneLabels"):
+            self.__dict__.pop(field, None)
 
     def prepare(self):
-        """Shuffle the sequences and cut them into packs of at most MAX_SIZE_LOADED samples (cpc/dataset.py:92-121)."""
+        """A new random order of the sequences and its packs (cpc/dataset.py:92-121)."""
         random.shuffle(self.seqNames)
-        allLength = list(self.reload_pool.map(extractLength, self.seqNames))
-        self.packageIndex, self.totSize = [], 0
-        start, packageSize = 0, 0
-        for index, length in enumerate(allLength):
-            packageSize += length
-            if packageSize > self.MAX_SIZE_LOADED:
-                self.packageIndex.append([start, index])
-                self.totSize += packageSize
-                start, packageSize = index, 0
-        if packageSize > 0:
-            self.packageIndex.append([start, len(self.seqNames)])
-            self.totSize += packageSize
-        self.currentPack = -1
-        self.nextPack = 0
+        lengths = list(self.reload_pool.map(extractLength, self.seqNames))
+        packs, self.totSize = _cut_into_packs(lengths, self.MAX_SIZE_LOADED)
+        self.packageIndex = [list(p) for p in packs]
+        self.currentPack, self.nextPack = -1, 0
 
     def getNPacks(self):
         return len(self.packageIndex)
 
     def loadNextPack(self, first=False):
-        """Install the pack that was being prefetched and start prefetching the following one (cpc/dataset.py:126-140)."""
+        """Install the pack that was being decoded and start decoding the one after it; a full turn over the packs
+        reshuffles (cpc/dataset.py:126-140)."""
         self.clear()
         if not first:
             self.currentPack = self.nextPack
-            self.nextData = [f.result() for f in self._pending]
+            self.nextData = [job.result() for job in self._pending]
             self.parseNextDataBlock()
             del self.nextData
-        self.nextPack = (self.currentPack + 1) % len(self.packageIndex)
-        seqStart, seqEnd = self.packageIndex[self.nextPack]
-        if self.nextPack == 0 and len(self.packageIndex) > 1:
+        self.nextPack = (self.currentPack + 1) % self.getNPacks()
+        if self.nextPack == 0 and self.getNPacks() > 1:
             self.prepare()
-        self._pending = [self.reload_pool.submit(loadFile, s) for s in self.seqNames[seqStart:seqEnd]]
+        lo, hi = self.packageIndex[self.nextPack]
+        self._pending = [self.reload_pool.submit(loadFile, entry) for entry in self.seqNames[lo:hi]]
 
     def parseNextDataBlock(self):
-        """Concatenate the pack, speaker-major, and record speaker / sequence boundaries (cpc/dataset.py:142-170)."""
-        self.speakerLabel = [0]
-        self.seqLabel = [0]
-        self.phoneLabels = []
-        speakerSize = 0
-        indexSpeaker = 0
-        self.nextData.sort(key=lambda x: (x[0], x[1]))
-        chunks = []
-        for speaker, seqName, seq in self.nextData:
-            while self.speakers[indexSpeaker] < speaker:
-                indexSpeaker += 1
-                self.speakerLabel.append(speakerSize)
-            if self.speakers[indexSpeaker] != speaker:
-                raise ValueError(f"{speaker} invalid speaker")
-            if self.phoneLabelsDict is not None:
-                self.phoneLabels += self.phoneLabelsDict[seqName]
-                seq = seq[:len(self.phoneLabelsDict[seqName]) * self.phoneSize]
-            sizeSeq = seq.size(0)
-            chunks.append(seq)
-            self.seqLabel.append(self.seqLabel[-1] + sizeSeq)
-            speakerSize += sizeSeq
-        self.speakerLabel.append(speakerSize)
-        self.data = torch.cat(chunks, dim=0)
+        """self.nextData (decoded sequences) -> the resident pack and its boundary lists (cpc/dataset.py:142-170)."""
+        pack = _Pack(self.nextData, len(self.speakers), self.phoneLabelsDict, self.phoneSize)
+        self.data = pack.wave
+        self.seqLabel = pack.seq_bounds.tolist()
+        self.speakerLabel = pack.speaker_bounds.tolist()
+        self.phoneLabels = pack.phones
         self._place()
 
     def getPhonem(self, idx):
-        idPhone = idx // self.phoneSize
-        return self.phoneLabels[idPhone:(idPhone + self.phoneStep)]
+        first = idx // self.phoneSize
+        return self.phoneLabels[first:first + self.phoneStep]
 
     def getSpeakerLabel(self, idx):
-        return next(i for i, bound in enumerate(self.speakerLabel) if bound > idx) - 1
+        """Index of the speaker whose samples contain position idx (empty speakers share a boundary and are skipped)."""
+        return int(torch.bucketize(torch.tensor(idx), torch.as_tensor(self.speakerLabel), right=True)) - 1
 
     def __len__(self):
         return self.totSize // self.sizeWindow
 
     def __getitem__(self, idx):
-        outData = self.data[idx:(self.sizeWindow + idx)].view(1, -1)
-        label = torch.tensor(self.getSpeakerLabel(idx), dtype=torch.long)
-        if self.phoneSize > 0:
-            label_phone = torch.tensor(self.getPhonem(idx), dtype=torch.long)
-            if not self.doubleLabels:
-                label = label_phone
-        else:
-            label_phone = torch.zeros(1)
+        """One window starting at sample idx, (1, sizeWindow), with its speaker label -- or its phone labels when the data
+        set has them -- or both when ``doubleLabels`` is set (cpc/dataset.py:179-201)."""
+        window = self.data[idx:idx + self.sizeWindow].view(1, -1)
+        speaker = torch.tensor(self.getSpeakerLabel(idx), dtype=torch.long)
+        phones = torch.tensor(self.getPhonem(idx), dtype=torch.long) if self.phoneSize > 0 else torch.zeros(1)
         if self.doubleLabels:
-            return outData, label, label_phone
-        return outData, label
+            return window, speaker, phones
+        return window, (phones if self.phoneSize > 0 else speaker)
 
     def get_batch(self, starts):
         """Vectorised counterpart of __getitem__ + default collate for a list of window starts: one gather on the
@@ -261,12 +278,11 @@ class AudioBatchData(Dataset):
         if self.phoneSize > 0:
             pidx = (idx // self.phoneSize)[:, None] + torch.arange(self.phoneStep, device=self.device)[None, :]
             phones = self._phones[pidx]
-            if self.doubleLabels:
-                return batch, speaker, phones
-            return batch, phones
+        else:
+            phones = torch.zeros(len(idx), 1, device=self.device)
         if self.doubleLabels:
-            return batch, speaker, torch.zeros(len(idx), 1, device=self.device)
-        return batch, speaker
+            return batch, speaker, phones
+        return batch, (phones if self.phoneSize > 0 else speaker)
 
     # -- counts (names as in cpc/dataset.py:203-213)
     def getNSpeakers(self):
@@ -281,16 +297,13 @@ class AudioBatchData(Dataset):
     # -- window plans
     def window_plan(self, type, batchSize, offset, generator=None):
         """All window starts of the pack that is loaded now, for one pass, as ONE tensor on the pack's device (WindowPlan)."""
-        n = len(self.data)
-        if type == "samespeaker":
-            return WindowPlan.grouped(self._bounds_tensor(self.speakerLabel), self.sizeWindow, batchSize, offset,
-                                      self.device, generator)
-        if type == "samesequence":
-            return WindowPlan.grouped(self._bounds_tensor(self.seqLabel), self.sizeWindow, batchSize, offset, self.device,
-                                      generator)
+        common = (self.sizeWindow, batchSize, offset, self.device)
+        if type in ("samespeaker", "samesequence"):
+            bounds = self.speakerLabel if type == "samespeaker" else self.seqLabel
+            return WindowPlan.grouped(self._bounds_tensor(bounds), *common, generator)
         if type == "sequential":
-            return WindowPlan.sequential(n, self.sizeWindow, batchSize, offset, self.device)
-        return WindowPlan.uniform(n, self.sizeWindow, batchSize, offset, self.device, generator)
+            return WindowPlan.sequential(len(self.data), *common)
+        return WindowPlan.uniform(len(self.data), *common, generator)
 
     def _bounds_tensor(self, bounds):
         return torch.as_tensor(bounds, dtype=torch.long, device=self.device)
@@ -302,12 +315,11 @@ class AudioBatchData(Dataset):
     def getDataLoader(self, batchSize, type, randomOffset, numWorkers=0, onLoop=-1):
         """cpc/dataset.py:231-258: one pass over every pack (or over pack ``onLoop`` only), a fresh plan -- and a fresh
         random offset in [0, sizeWindow/2] -- per pack.  ``numWorkers`` is accepted and ignored: a batch is one gather."""
-        packs = self.getNPacks()
-        if onLoop >= 0:
-            self.currentPack = onLoop - 1
-            self.loadNextPack()
-            packs = 1
-        return AudioLoader(self, type, batchSize, randomOffset, packs)
+        if onLoop < 0:
+            return AudioLoader(self, type, batchSize, randomOffset, self.getNPacks())
+        self.currentPack = onLoop - 1                    # make pack `onLoop` the resident one
+        self.loadNextPack()
+        return AudioLoader(self, type, batchSize, randomOffset, 1)
 
 
 class WindowPlan:
@@ -450,55 +462,50 @@ class AudioLoader:
 
 # ----------------------------------------------------------------------------------------------- helpers
 def findAllSeqs(dirName, extension=".flac", loadCache=False, speaker_level=1):
-    """cpc/dataset.py:417-488: -> ([(speaker index, path relative to dirName)], [speaker names]); the speaker is the
-    first ``speaker_level`` directory levels below dirName ('' when 0 or when files sit in dirName itself)."""
-    cache_path = os.path.join(dirName, "_seqs_cache.txt")
-    if loadCache:
+    """cpc/dataset.py:417-488: -> ([(speaker index, path relative to dirName)], [speaker names]); the speaker of a file is
+    the first ``speaker_level`` directory levels below dirName ('' when 0 or when the files sit in dirName itself), and
+    speakers are numbered in the order the walk meets them.  The listing is cached in dirName/_seqs_cache.txt."""
+    cache = os.path.join(dirName, "_seqs_cache.txt")
+    if loadCache and os.path.isfile(cache):
         try:
-            outSequences, speakers = torch.load(cache_path)
-            return outSequences, speakers
+            return tuple(torch.load(cache))
         except OSError:
             pass
-    if dirName[-1] != os.sep:
-        dirName += os.sep
-    prefixSize = len(dirName)
-    speakersTarget = {}
-    outSequences = []
-    for root, _, filenames in os.walk(dirName):
-        files = [f for f in filenames if f.endswith(extension)]
-        if not files:
-            continue
-        speakerStr = os.sep.join(root[prefixSize:].split(os.sep)[:speaker_level])
-        speaker = speakersTarget.setdefault(speakerStr, len(speakersTarget))
-        for filename in files:
-            outSequences.append((speaker, os.path.join(root[prefixSize:], filename)))
-    outSpeakers = [None] * len(speakersTarget)
-    for key, index in speakersTarget.items():
-        outSpeakers[index] = key
+    base = dirName if dirName.endswith(os.sep) else dirName + os.sep
+    index_of, found = {}, []
+    for here, _, names in os.walk(base):
+        rel = here[len(base):]
+        hits = [n for n in names if n.endswith(extension)]
+        if hits:
+            tag = os.sep.join(rel.split(os.sep)[:speaker_level])
+            spk = index_of.setdefault(tag, len(index_of))
+            found.extend((spk, os.path.join(rel, n)) for n in hits)
+    names_by_index = sorted(index_of, key=index_of.get)
     try:
-        torch.save((outSequences, outSpeakers), cache_path)
+        torch.save((found, names_by_index), cache)
     except OSError:
         pass
-    return outSequences, outSpeakers
+    return found, names_by_index
 
 
 def parseSeqLabels(pathLabels):
     """cpc/dataset.py:491-501: '<seq> l0 l1 ...' lines -> ({'step': 160, seq: [labels]}, number of classes)."""
-    output = {"step": 160}
-    maxPhone = 0
+    table, top = {"step": 160}, -1
     with open(pathLabels, "r") as f:
-        for line in f:
-            data = line.split()
-            if not data:
-                continue
-            output[data[0]] = [int(x) for x in data[1:]]
-            maxPhone = max(maxPhone, max(output[data[0]]))
-    return output, maxPhone + 1
+        for fields in map(str.split, f):
+            if fields:
+                labels = list(map(int, fields[1:]))
+                table[fields[0]] = labels
+                top = max([top] + labels)
+    return table, top + 1
 
 
 def filterSeqs(pathTxt, seqCouples):
-    """cpc/dataset.py:504-520: keep the sequences whose file stem is listed in pathTxt."""
+    """cpc/dataset.py:504-520: the sequences whose file stem is listed in pathTxt, ordered by stem (the caller's list is
+    sorted in place, as the reference does)."""
+    def stem(couple):
+        return os.path.splitext(os.path.basename(couple[1]))[0]
     with open(pathTxt, "r") as f:
-        wanted = {line.strip() for line in f if line.strip()}
-    seqCouples.sort(key=lambda x: os.path.basename(os.path.splitext(x[1])[0]))
-    return [x for x in seqCouples if os.path.basename(os.path.splitext(x[1])[0]) in wanted]
+        wanted = set(filter(None, map(str.strip, f)))
+    seqCouples.sort(key=stem)
+    return [c for c in seqCouples if stem(c) in wanted]

@@ -19,29 +19,21 @@ class ChannelNorm(nn.Module):
 
     def __init__(self, numFeatures, epsilon=1e-05, affine=True):
         super().__init__()
-        if affine:
-            self.weight = nn.parameter.Parameter(torch.Tensor(1, numFeatures, 1))
-            self.bias = nn.parameter.Parameter(torch.Tensor(1, numFeatures, 1))
-        else:
-            self.weight = None
-            self.bias = None
-        self.epsilon = epsilon
-        self.p = 0
-        self.affine = affine
-        self.reset_parameters()
+        self.epsilon, self.affine, self.p = epsilon, affine, 0
+        shape = (1, numFeatures, 1)                      # broadcast over (batch, channel, time): the checkpoint layout
+        self.weight = nn.Parameter(torch.ones(shape)) if affine else None
+        self.bias = nn.Parameter(torch.zeros(shape)) if affine else None
 
     def reset_parameters(self):
         if self.affine:
-            torch.nn.init.ones_(self.weight)
-            torch.nn.init.zeros_(self.bias)
+            with torch.no_grad():
+                self.weight.fill_(1.0)
+                self.bias.zero_()
 
     def forward(self, x):
-        cumMean = x.mean(dim=1, keepdim=True)
-        cumVar = x.var(dim=1, keepdim=True)
-        x = (x - cumMean) * torch.rsqrt(cumVar + self.epsilon)
-        if self.weight is not None:
-            x = x * self.weight + self.bias
-        return x
+        var, mean = torch.var_mean(x, dim=1, keepdim=True)          # unbiased variance over the channels, as the reference
+        xhat = (x - mean) * torch.rsqrt(var + self.epsilon)
+        return torch.addcmul(self.bias, xhat, self.weight) if self.affine else xhat
 
 
 class CPCEncoder(nn.Module):
@@ -119,15 +111,12 @@ class CPCAR(nn.Module):
         return out
 
     def forward(self, x):
-        if self.reverse:
-            x = torch.flip(x, [1])
-        x, h = GruFunction.apply(x, self.hidden, *self._flat_params())
-        if self.keepHidden:
-            self.hidden = h.detach()
-        # For better modularity, a sequence's order should be preserved by each module
-        if self.reverse:
-            x = torch.flip(x, [1])
-        return x
+        """(B, S, 256) -> (B, S, 256).  In reverse mode the sequence is processed back to front and handed back in its
+        original order (cpc/model.py:185-204); the final hidden state is kept for the next call when keepHidden is set."""
+        flip = (lambda t: torch.flip(t, [1])) if self.reverse else (lambda t: t)
+        y, h_last = GruFunction.apply(flip(x), self.hidden, *self._flat_params())
+        self.hidden = h_last.detach() if self.keepHidden else self.hidden
+        return flip(y)
 
 
 class CPCModel(nn.Module):
