@@ -36,9 +36,10 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
 __global__ __launch_bounds__(256) void nce_fwd_kernel(
     const float* __restrict__ pred, const float* __restrict__ z, const int* __restrict__ ext,
     float* __restrict__ logits, float* __restrict__ lse_out, float* __restrict__ rowstat, int BW, int W,
-    int S, int K, int N) {
+    int S, int K, int N, unsigned* __restrict__ ticket) {
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;      // nce_reduce_finalize_kernel, the next launch on this stream
     if (bt >= BW) return;                           // whole wave leaves together
     const int b = bt / W, t = bt - b * W;
     const int i = lane & 15, kq = lane >> 4;
@@ -119,10 +120,57 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(
     }
 }
 
-__global__ __launch_bounds__(64) void nce_finalize_kernel(const float* __restrict__ sums, float* __restrict__ losses,
-                                                         float* __restrict__ acc, int K, float inv_rows) {
-    const int k = threadIdx.x;
-    if (k < K) { losses[k] = sums[k] * inv_rows; acc[k] = sums[K + k] * inv_rows; }
+// Column sums of rowstat [nrows][n <= 32] -> losses / accuracies, in ONE launch: block g sums its rows_per_group rows into
+// tmp[g] (the arithmetic and order of rows_sum_kernel), takes a ticket, and the block that draws the last ticket folds the
+// groups (again rows_sum_kernel's order) and scales.  `ticket` was cleared by the kernel that produced rowstat.  Replaces two
+// rows_sum launches + nce_finalize_kernel on the step's critical path (three dependent 6 us launches).
+__global__ __launch_bounds__(256) void nce_reduce_finalize_kernel(const float* __restrict__ rowstat, int nrows, int n,
+                                                                 int rows_per_group, float* __restrict__ tmp,
+                                                                 unsigned* __restrict__ ticket, float* __restrict__ losses,
+                                                                 float* __restrict__ acc, int K, float inv_rows) {
+    __shared__ float red[8][33];
+    __shared__ unsigned drawn;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    auto fold = [&](auto load, int r0, int r1) __attribute__((always_inline)) {      // rows r0..r1-1 of one column
+        float s0 = 0.f, s1 = 0.f;
+        if (tx < n) {
+            int r = r0 + ty;
+            for (; r + 8 < r1; r += 16) {
+                s0 += load(r);
+                s1 += load(r + 8);
+            }
+            if (r < r1) s0 += load(r);
+        }
+        red[ty][tx] = s0 + s1;
+        __syncthreads();
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += red[q][tx];
+        __syncthreads();
+        return s;
+    };
+    const int r0 = blockIdx.x * rows_per_group;
+    const float mine = fold([&](int r) { return rowstat[(long)r * n + tx]; }, r0, min(nrows, r0 + rows_per_group));
+    if (ty == 0 && tx < n) tmp[(long)blockIdx.x * n + tx] = mine;
+    __threadfence();                                    // my group's sums are visible device-wide before my ticket is
+    __syncthreads();
+    if (threadIdx.x == 0) drawn = atomicAdd(ticket, 1u);
+    __syncthreads();
+    if (drawn != gridDim.x - 1) return;
+    __threadfence();
+    // the groups' sums, all loads in flight before the first addition (dependent L2 round trips are what this block would
+    // otherwise spend its time on); at most kRowsSumGroups / 8 = 16 per thread
+    float v[kRowsSumGroups / 8];
+#pragma unroll
+    for (int j = 0; j < kRowsSumGroups / 8; ++j) {
+        const int g = ty + 8 * j;
+        v[j] = (tx < n && g < (int)gridDim.x) ? __hip_atomic_load(tmp + (long)g * n + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    }
+    const float total = fold([&](int g) { return v[(g - ty) >> 3]; }, 0, (int)gridDim.x);
+    if (ty == 0 && tx < n) {
+        if (tx < K) losses[tx] = total * inv_rows;
+        else if (tx < 2 * K) acc[tx - K] = total * inv_rows;
+    }
 }
 
 // gscale[k] = dL/dloss_k / (B*W) / C
@@ -130,8 +178,19 @@ __global__ __launch_bounds__(64) void nce_finalize_kernel(const float* __restric
 // gscale[18] = max|wall| (operand bounds of the backward GEMMs, GemmBounds) and the 64 max|dPred| slots at gscale[64..127]
 // are cleared for nce_bwd_dpred_kernel.  (An a-priori bound -- |dPred| <= 2 max|gscale| max|z| -- needs no slots but is far
 // too loose once the softmax is confident: operands 2^-20 of their bound lose the low fp16 piece.)
+// Blocks 1.. (if any) zero dc_tail: the last S - W steps of every sequence of dc [B][S][256], which predict nothing and get no
+// gradient from the GEMM that writes the other rows (this replaces a memset of the whole tensor on the critical path).
 __global__ __launch_bounds__(64) void nce_gscale_kernel(const float* __restrict__ gloss, float* __restrict__ gscale,
-                                                        int K, float f, const float* __restrict__ fwd_bounds) {
+                                                        int K, float f, const float* __restrict__ fwd_bounds,
+                                                        float* __restrict__ dc_tail, int B, int S, int W) {
+    if (blockIdx.x > 0) {
+        const int per = (S - W) * (kC / 4);                           // float4 per sequence
+        for (int i = (blockIdx.x - 1) * 64 + threadIdx.x; i < B * per; i += (gridDim.x - 1) * 64) {
+            const int b = i / per, r = i - b * per;
+            reinterpret_cast<float4*>(dc_tail + ((long)b * S + W) * kC)[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     const int k = threadIdx.x;
     if (k < K) gscale[k] = gloss[k] * f;
     if (fwd_bounds != nullptr) {
@@ -445,13 +504,17 @@ static RowMap window_rows(const float* c, int B, int S, int W) {     // rows (b,
 // scores, log-softmax, per-head loss / accuracy from given predictions
 static int nce_scores_forward(const NceLayout& n, const float* pred, const float* z, const int* ext, float* saved,
                               float* scratch, float* losses, float* acc, int S, int K, int N, hipStream_t st) {
+    unsigned* ticket = reinterpret_cast<unsigned*>(scratch + n.sums + 32);
     hipLaunchKernelGGL(nce_fwd_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
-                       saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N);
+                       saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket);
     CPC_LAUNCH_CHECK();
-    int rc = rows_sum(scratch + n.rowstat, n.BW, 2 * K, scratch + n.tmp, scratch + n.sums, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(64), 0, st, scratch + n.sums, losses, acc, K,
-                       1.0f / (float)n.BW);
+    {                                                   // 2 K <= 32 columns (nce_layout): rows_sum's groups and order of additions
+        int groups = n.BW > 64 ? kRowsSumGroups : 1;
+        const int rpg = cdiv(n.BW, groups);
+        groups = cdiv(n.BW, rpg);
+        hipLaunchKernelGGL(nce_reduce_finalize_kernel, dim3(groups), dim3(256), 0, st, scratch + n.rowstat, n.BW, 2 * K, rpg,
+                           scratch + n.tmp, ticket, losses, acc, K, 1.0f / (float)n.BW);
+    }
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -463,7 +526,7 @@ static int nce_dz_path(const NceLayout& n, const float* pred, const float* saved
     const float* logits = saved + n.logits, *lse = saved + n.lse;
     if (own_gscale)
         hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale_dz, K, 1.0f / ((float)n.BW * (float)kC),
-                           (const float*)nullptr);
+                           (const float*)nullptr, (float*)nullptr, 0, 0, 0);
     hipLaunchKernelGGL(nce_bwd_dz_rows_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, logits, lse, gscale_dz,
                        scratch + n.V, n.BW, K, N);
     hipLaunchKernelGGL(nce_gather_rows_kernel, dim3(B * S), dim3(64), 0, st, scratch + n.V, perm, row_ptr, dz, B * S);
@@ -478,12 +541,13 @@ static int nce_dz_path(const NceLayout& n, const float* pred, const float* saved
 static int nce_scores_backward(const NceLayout& n, const float* pred, const float* z, const int* ext, const int* perm,
                                const int* row_ptr, const float* saved, const float* gloss, float* scratch,
                                float* dpred, float* dz, int B, int S, int K, int N, hipStream_t st, hipStream_t st_dz,
-                               bool do_dz = true, const float* fwd_bounds = nullptr) {
+                               bool do_dz = true, const float* fwd_bounds = nullptr, float* dc_tail = nullptr) {
     const float* logits = saved + n.logits, *lse = saved + n.lse;
     float* gscale = scratch + n.gscale;
     float* gscale_dz = st_dz == st ? gscale : gscale + 32;        // own copy: no cross-stream dependency
     const float gs = 1.0f / ((float)n.BW * (float)kC);
-    hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale, K, gs, fwd_bounds);
+    hipLaunchKernelGGL(nce_gscale_kernel, dim3(dc_tail ? 1 + 128 : 1), dim3(64), 0, st, gloss, gscale, K, gs, fwd_bounds, dc_tail, B,
+                       S, n.W);
     const dim3 grid(cdiv(n.BW, 4));
     hipLaunchKernelGGL(nce_bwd_dpred_kernel, grid, dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
                        n.W, S, K, N, fwd_bounds ? gscale + 64 : (float*)nullptr);
@@ -620,10 +684,9 @@ extern "C" int cpc_nce_backward_streams(const float* c, const float* z, const fl
     CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     float* dpred = scratch + n.dpred, *wallT = scratch + n.wallT;
-    (void)hipMemsetAsync(dc, 0, sizeof(float) * (size_t)B * S * kC, st);
     const bool h2 = g_mfma_mode >= 2;        // the forward left the operand bounds in `saved`
     int rc = nce_scores_backward(n, saved + n.pred, z, ext, perm, row_ptr, saved, gloss, scratch, dpred, dz, B, S, K, N, st,
-                                 (hipStream_t)dz_stream, dz != nullptr, h2 ? saved + n.bounds : nullptr);
+                                 (hipStream_t)dz_stream, dz != nullptr, h2 ? saved + n.bounds : nullptr, dc);
     if (rc) return rc;
     const float* bnd = scratch + n.gscale;                        // [17] max|c|, [18] max|wall|, [64..127] max|dPred| slots
     GemmBounds gdc, gdw;

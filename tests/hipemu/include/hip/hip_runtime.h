@@ -357,6 +357,7 @@ template <class T, class V> static inline void hipemu_atomic_store(T* p, V v, in
 #define __hip_atomic_load(p, order, scope) hipemu_atomic_load((p), (order))
 #define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store((p), (v), (order))
 static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline bool __all(bool pred) {
     const uint32_t* buf = hipemu::exchange(pred ? 1u : 0u);
     const int lo = 0, hi = hipemu::WAVE;
