@@ -41,6 +41,7 @@ SIGNATURES = {
     "cpc_set_gru_poll_pacing": (_I, [_I, _I]),
     "cpc_set_dma_rotation": (_I, [_I]),
     "cpc_set_dma_pipeline": (_I, [_I]),
+    "cpc_set_nce_fuse": (_I, [_I]),
     "cpc_conv0_backward_scratch_floats": (_L, [_I, _I]),
     "cpc_conv0_backward": (_I, [_P] * 13 + [_I, _I, _P]),
     "cpc_conv_layer_forward": (_I, [_P] * 9 + [_I] * 5 + [_P]),

@@ -20,6 +20,7 @@
 //   dPred[16 x 256] = dS[16 x N] . Neg[N x 256]        (gather again, MFMA)
 //   dNeg [N x 256]  = dS^T[N x 16] . P[16 x 256]       (MFMA) -> rows of V, gathered per z row
 // then the head GEMMs:  dc = dPred . W,  dW_k = dPred_k^T . c   (gemm.hip).
+#include <algorithm>
 #include "cpc_common.h"
 #include "cpc_internal.h"
 #include "gemm_tile.h"
@@ -31,18 +32,41 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
+// 1: the forward scoring kernel also forms U = sum_j softmax_j z_j - z_pos for every head while the candidate rows are in its
+// registers (nce_fwd_kernel<true>) and the backward only scales it; 0 (default): the backward gathers the rows again
+// (nce_bwd_dpred_kernel).  Must not change between a forward and its backward (like cpc_set_mfma_mode).  Measured at B = 64
+// (DESIGN.md section 4.10): the second product doubles the forward kernel's f32 MFMAs and halves its occupancy, 160 -> 290 us,
+// which is what the backward's own gather costs (178 us): no gain, so it is off.
+static int g_nce_fuse = 0;
+extern "C" int cpc_set_nce_fuse(int on) {
+    CPC_RETURN_IF(on < 0 || on > 1, CPC_ERR_ARG);
+    g_nce_fuse = on;
+    return 0;
+}
+
 // ------------------------------------------------------------------ forward scores
 // one wavefront per (b,t) row; 4 rows per block.  pred: [BW][K*C]; ext: [BW][N] row ids into z.
+//
+// WITH_U: the same pass over the gathered candidate rows also forms what the backward needs of them,
+//   U[bt][k][:] = sum_j softmax_j z_j - z_pos(k)            (d loss_k / d pred_k up to the per-head factor gscale[k]),
+// so that the backward's own gather of the same 1.16 GB of rows (nce_bwd_dpred_kernel) is not needed: it only scales U.
+// Scores are computed transposed -- S^T = Z . pred^T, i.e. the z rows are the A operand -- so that a lane (i, kq) ends up
+// with the scores of HEAD i against candidates 4 kq + r: exactly the A-operand layout of the second product P . Z (16 heads x
+// 16 candidates times 16 candidates x 256 channels, the channel order absorbed by the output mapping as in
+// nce_bwd_dpred_kernel), no cross-lane traffic in the loop.  The softmax weights are taken against a running reference M
+// (initially the positive's logit) that is only moved -- and the partial sums rescaled -- when a logit exceeds it by more
+// than 40, which no sane model does: exp(l - M) <= e^40 is harmless in fp32, and the normalisation is exact at the end.
+template <bool WITH_U>
 __global__ __launch_bounds__(256) void nce_fwd_kernel(
     const float* __restrict__ pred, const float* __restrict__ z, const int* __restrict__ ext,
     float* __restrict__ logits, float* __restrict__ lse_out, float* __restrict__ rowstat, int BW, int W,
-    int S, int K, int N, unsigned* __restrict__ ticket) {
+    int S, int K, int N, unsigned* __restrict__ ticket, float* __restrict__ U) {
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;      // nce_reduce_finalize_kernel, the next launch on this stream
     if (bt >= BW) return;                           // whole wave leaves together
     const int b = bt / W, t = bt - b * W;
-    const int i = lane & 15, kq = lane >> 4;
+    const int i = lane & 15, kq = lane >> 4;        // i: head (and candidate row of the A operand); kq: k group
     const bool hv = i < K;
     const float inv = 1.0f / kC;
 
@@ -53,28 +77,31 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(
         for (int ii = 0; ii < 16; ++ii) pa[ii] = hv ? ld4(pp + 16 * ii) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // positives: head h <-> z[b, t+h+1].  They go through the SAME MFMA chain as the negatives
-    // (a 16-column tile whose column j is head j's positive row; the diagonal is kept), so a
+    // (a 16-row tile whose row j is head j's positive row; the diagonal is kept), so a
     // negative that happens to be the positive row scores bit-identically and the arg-max tie
     // resolves to class 0 exactly as in the reference (criterion.py:253).
-    float posl[4], m[4], s[4], mneg[4];
+    float posl;
     {
         const float* zp = z + ((long)b * S + t + (hv ? i : 0) + 1) * kC + 4 * kq;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ii = 0; ii < 16; ++ii) {
-            const float4 bf = ld4(zp + 16 * ii);
+            const float4 zf = ld4(zp + 16 * ii);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(pa[ii], jj), f4c(bf, jj), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(zf, jj), f4c(pa[ii], jj), acc, 0, 0, 0);
         }
-        // acc[r] on lane (col, q) = score(head 4q+r, positive row of head col); diagonal: col == 4q+r
+        // acc[r] on lane (i, q) = score(positive row of head 4q+r, head i); the diagonal sits on lane (i, i >> 2), reg i & 3
+        const float mine = (i & 3) == 0 ? acc[0] : (i & 3) == 1 ? acc[1] : (i & 3) == 2 ? acc[2] : acc[3];
+        posl = __shfl(mine, i + 16 * (i >> 2)) * inv;
+    }
+    float M = posl;                                 // reference of the softmax weights, common to the four lanes of a head
+    float ssum = kq == 0 ? 1.0f : 0.0f;             // the positive enters the sum once (exp(posl - M) = 1)
+    float mneg = -3.0e38f;
+    f32x4 O[16];
+    if constexpr (WITH_U) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            posl[r] = __shfl(acc[r], (4 * kq + r) + 16 * kq) * inv;
-            m[r] = posl[r];
-            s[r] = (i == 0) ? 1.0f : 0.0f;              // the positive enters the sum once
-            mneg[r] = -3.0e38f;
-        }
+        for (int q = 0; q < 16; ++q) O[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int nt = 0; nt < N / 16; ++nt) {
         const int row = ext[(long)bt * N + nt * 16 + i];
@@ -82,41 +109,117 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ii = 0; ii < 16; ++ii) {
-            const float4 bf = ld4(zr + 16 * ii);
+            const float4 zf = ld4(zr + 16 * ii);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(pa[ii], jj), f4c(bf, jj), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(zf, jj), f4c(pa[ii], jj), acc, 0, 0, 0);
         }
-        // acc[r] = score of head 4kq+r against negative nt*16+i
+        // acc[r] = score of head i against negative nt*16 + 4 kq + r
+        float l[4], lmax = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            l[r] = acc[r] * inv;
+            if (hv) logits[((long)bt * K + i) * (N + 1) + 1 + nt * 16 + 4 * kq + r] = l[r];
+            lmax = fmaxf(lmax, l[r]);
+        }
+        mneg = fmaxf(mneg, lmax);
+        if (__any(lmax - M > 40.0f)) {              // (wave-uniform) move the reference: rare
+            float tm = fmaxf(lmax, __shfl_xor(lmax, 16));
+            tm = fmaxf(tm, __shfl_xor(tm, 32));
+            const float Mn = fmaxf(M, tm), alpha = expf(M - Mn);
+            ssum *= alpha;
+            M = Mn;
+            if constexpr (WITH_U) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ah = __shfl(alpha, 4 * kq + r);             // O's rows on this lane: heads 4 kq + r
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) O[q][r] *= ah;
+                }
+            }
+        }
+        float pw[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pw[r] = expf(l[r] - M);
+            ssum += pw[r];
+        }
+        if constexpr (WITH_U) {
+            // O[head][channel] += sum over the tile's 16 candidates of pw * z: MFMA r contracts candidates {r, 4+r, 8+r, 12+r}
+            const int* ep = ext + (long)bt * N + nt * 16 + 4 * kq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = hv ? pw[r] : 0.f;
+                const float* z2 = z + (long)ep[r] * kC + 4 * i;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 bv = ld4(z2 + 64 * u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        O[u * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f4c(bv, e), O[u * 4 + e], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // fold the four k groups of a head
+    ssum += __shfl_xor(ssum, 16);
+    ssum += __shfl_xor(ssum, 32);
+    mneg = fmaxf(mneg, __shfl_xor(mneg, 16));
+    mneg = fmaxf(mneg, __shfl_xor(mneg, 32));
+    const float lse = M + logf(ssum);
+    if (kq == 0 && hv) {
+        logits[((long)bt * K + i) * (N + 1)] = posl;
+        lse_out[(long)bt * K + i] = lse;
+        rowstat[(long)bt * 2 * K + i] = lse - posl;                       // CE(target 0)
+        rowstat[(long)bt * 2 * K + K + i] = posl >= mneg ? 1.f : 0.f;     // argmax == 0
+    }
+    if constexpr (WITH_U) {
+        const float fnorm = expf(M - lse), d0 = expf(posl - lse) - 1.0f;  // 1 / sum, softmax(positive) - 1
+        // C layout: head = 4 kq + r, channel = 64 u + 4 i + e
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int head = 4 * kq + r;
-            const float l = acc[r] * inv;
-            if (head < K) logits[((long)bt * K + head) * (N + 1) + 1 + nt * 16 + i] = l;
-            mneg[r] = fmaxf(mneg[r], l);
-            const float mn = fmaxf(m[r], l);
-            s[r] = s[r] * expf(m[r] - mn) + expf(l - mn);
-            m[r] = mn;
+            const float fh = __shfl(fnorm, head), dh = __shfl(d0, head);
+            if (head < K) {
+                const float* zp = z + ((long)b * S + t + head + 1) * kC + 4 * i;
+                float* op = U + ((long)bt * K + head) * kC + 4 * i;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 zv = ld4(zp + 64 * u);
+                    float4 o;
+                    o.x = fmaf(dh, zv.x, O[u * 4 + 0][r] * fh);
+                    o.y = fmaf(dh, zv.y, O[u * 4 + 1][r] * fh);
+                    o.z = fmaf(dh, zv.z, O[u * 4 + 2][r] * fh);
+                    o.w = fmaf(dh, zv.w, O[u * 4 + 3][r] * fh);
+                    *reinterpret_cast<float4*>(op + 64 * u) = o;
+                }
+            }
         }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            const float m2 = __shfl_xor(m[r], off), s2 = __shfl_xor(s[r], off);
-            const float mn = fmaxf(m[r], m2);
-            s[r] = s[r] * expf(m[r] - mn) + s2 * expf(m2 - mn);
-            m[r] = mn;
-            mneg[r] = fmaxf(mneg[r], __shfl_xor(mneg[r], off));
-        }
-        const int head = 4 * kq + r;
-        if (i == 0 && head < K) {
-            const float lse = m[r] + logf(s[r]);
-            logits[((long)bt * K + head) * (N + 1)] = posl[r];
-            lse_out[(long)bt * K + head] = lse;
-            rowstat[(long)bt * 2 * K + head] = lse - posl[r];                      // CE(target 0)
-            rowstat[(long)bt * 2 * K + K + head] = posl[r] >= mneg[r] ? 1.f : 0.f; // argmax == 0
-        }
+}
+
+// dPred = gscale[k] * U (nce_fwd_kernel<true>) + its max|.| slots: the backward's share of the dPred computation when the
+// forward has already gathered the rows.  amax_slots were cleared by nce_gscale_kernel.
+__global__ __launch_bounds__(256) void nce_scale_u_kernel(const float* __restrict__ U, const float* __restrict__ gscale,
+                                                         float* __restrict__ dpred, long rows, int K,
+                                                         float* __restrict__ amax_slots) {
+    // one wave per (bt, head) row of 256 at a time, grid-stride; ONE atomic per wave at the end (one per row serialises
+    // 89 k atomics on 64 addresses: 0.43 ms for a 45 us copy)
+    const int lane = threadIdx.x & 63;
+    const long nwaves = (long)gridDim.x * 4;
+    float amax = 0.f;
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nwaves) {
+        const float g = gscale[row % K];
+        float4 v = ld4(U + row * kC + 4 * lane);
+        v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+        *reinterpret_cast<float4*>(dpred + row * kC + 4 * lane) = v;
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (amax_slots != nullptr) {
+        amax = wave_max(amax);
+        if (lane == 0)
+            atomicMax(reinterpret_cast<unsigned*>(amax_slots + (int)((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kAmaxSlots - 1))),
+                      __float_as_uint(amax));
     }
 }
 
@@ -297,7 +400,9 @@ __global__ __launch_bounds__(256) void nce_bwd_dz_rows_kernel(
         for (int q = 0; q < 16; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sx = 0; sx < 4; ++sx) {
-            const float a = gs[sx] * expf(lp[sx][1 + nt * 16 + i] - ls[sx]);   // d score[head 4sx+kq][n = nt*16+i]
+            // d score[head 4sx+kq][n = nt*16+i]; exactly 0 for the padding heads (0 * exp(.) would be NaN once a logit of
+            // head 0, whose row they alias, exceeds 88)
+            const float a = 4 * sx + kq < K ? gs[sx] * expf(lp[sx][1 + nt * 16 + i] - ls[sx]) : 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -464,7 +569,7 @@ __global__ __launch_bounds__(256) void nce_fill_kernel(const int* __restrict__ d
 // ------------------------------------------------------------------ host side
 struct NceLayout {
     int W, BW;
-    long pred, logits, lse, bounds, saved_total;
+    long pred, logits, lse, bounds, U, saved_total;
     long rowstat, tmp, sums, fwd_total;
     long dpred, wallT, part, gscale, V, bwd_total;
 };
@@ -478,6 +583,7 @@ static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     n.logits = o; o += align64l((long)n.BW * K * (N + 1));
     n.lse = o; o += align64l((long)n.BW * K);
     n.bounds = o; o += 2 * kAmaxSlots;       // max|c|, max|wall| as 64 partial maxima each (linear heads only)
+    n.U = o; o += align64l((long)n.BW * K * kC);     // nce_fwd_kernel<true>: d loss_k / d pred_k up to gscale[k]
     n.saved_total = o;
     o = 0;
     n.rowstat = o; o += align64l((long)n.BW * 2 * K);
@@ -505,8 +611,12 @@ static RowMap window_rows(const float* c, int B, int S, int W) {     // rows (b,
 static int nce_scores_forward(const NceLayout& n, const float* pred, const float* z, const int* ext, float* saved,
                               float* scratch, float* losses, float* acc, int S, int K, int N, hipStream_t st) {
     unsigned* ticket = reinterpret_cast<unsigned*>(scratch + n.sums + 32);
-    hipLaunchKernelGGL(nce_fwd_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
-                       saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket);
+    if (g_nce_fuse)
+        hipLaunchKernelGGL(nce_fwd_kernel<true>, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
+                           saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket, saved + n.U);
+    else
+        hipLaunchKernelGGL(nce_fwd_kernel<false>, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
+                           saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket, (float*)nullptr);
     CPC_LAUNCH_CHECK();
     {                                                   // 2 K <= 32 columns (nce_layout): rows_sum's groups and order of additions
         int groups = n.BW > 64 ? kRowsSumGroups : 1;
@@ -549,8 +659,12 @@ static int nce_scores_backward(const NceLayout& n, const float* pred, const floa
     hipLaunchKernelGGL(nce_gscale_kernel, dim3(dc_tail ? 1 + 128 : 1), dim3(64), 0, st, gloss, gscale, K, gs, fwd_bounds, dc_tail, B,
                        S, n.W);
     const dim3 grid(cdiv(n.BW, 4));
-    hipLaunchKernelGGL(nce_bwd_dpred_kernel, grid, dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
-                       n.W, S, K, N, fwd_bounds ? gscale + 64 : (float*)nullptr);
+    if (g_nce_fuse)                                                // the forward left U: dPred = gscale * U
+        hipLaunchKernelGGL(nce_scale_u_kernel, dim3(std::min(cdiv((long)n.BW * K, 4), 2048)), dim3(256), 0, st, saved + n.U, gscale, dpred,
+                           (long)n.BW * K, K, fwd_bounds ? gscale + 64 : (float*)nullptr);
+    else
+        hipLaunchKernelGGL(nce_bwd_dpred_kernel, grid, dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
+                           n.W, S, K, N, fwd_bounds ? gscale + 64 : (float*)nullptr);
     CPC_LAUNCH_CHECK();
     if (!do_dz) return 0;                                          // dz path launched separately (cpc_nce_backward_dz)
     return nce_dz_path(n, pred, saved, gloss, perm, row_ptr, scratch, gscale_dz, dz, B, S, K, N, st_dz, st_dz != st);

@@ -95,6 +95,11 @@ int cpc_set_h2_dx(int on);               /* mode 3: 1 (default) keeps the gradie
 int cpc_set_gemm_split(int on);          /* 1 (default): plain GEMMs with known operand bounds (the criterion's, see cpc_nce_forward) run on two
                                             fp16 pieces in mode >= 2, wide products on the 128 x 256 pipelined tile; 0: three bf16 pieces always;
                                             2: two pieces but never the wide tile; 3: the wide tile whatever the grid size (tests) */
+int cpc_set_nce_fuse(int on);            /* 1: the forward's scoring kernel also accumulates, per head, the softmax-weighted sum of the
+                                            candidate rows it has gathered (the gradient w.r.t. the prediction up to a per-head factor,
+                                            kept in `saved`), and the backward scales it instead of gathering the rows again; 0 (default:
+                                            measured no faster): the backward recomputes it from the saved logits.
+                                            Set before a forward, keep until its backward has been issued */
 int cpc_set_dma_rotation(int step);
 int cpc_set_dma_pipeline(int variant);   /* main-loop schedule of the forward DMA kernel on 256-row tiles (tuning / measurement switch; results
                                           * agree to rounding order).  2 (default): tap-pair walk -- an input row reaches LDS once for both

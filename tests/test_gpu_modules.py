@@ -77,11 +77,22 @@ def test_reverse_mode_matches_flipped_oracle():
     assert (acc.cpu() - ar_).abs().max().item() <= 2.0 / (116 * B) + 1e-7
 
 
-@pytest.mark.parametrize("K,N,L", [(5, 256, 10240), (16, 64, 20480), (12, 512, 20480)])
-def test_other_heads_negatives_and_window(K, N, L):
+@pytest.mark.parametrize("K,N,L,fuse", [(5, 256, 10240, 0), (16, 64, 20480, 0), (12, 512, 20480, 0), (12, 128, 20480, 1),
+                                         (5, 256, 10240, 1)])
+def test_other_heads_negatives_and_window(K, N, L, fuse):
     """nPredicts != 12, large-negative stress (BASELINE config 5 sweeps N in {128,256,512}) and a
-    shorter window (S = L/160)."""
+    shorter window (S = L/160).  fuse = 1: cpc_set_nce_fuse(1), the forward's scoring kernel also forms the softmax-weighted
+    row sums and the backward scales them instead of gathering the rows again."""
     dev = _dev()
+    from cpc_audio_amd import _lib
+    assert _lib.get().cpc_set_nce_fuse(fuse) == 0
+    try:
+        _heads_negatives_window(dev, K, N, L)
+    finally:
+        _lib.get().cpc_set_nce_fuse(0)
+
+
+def _heads_negatives_window(dev, K, N, L):
     from cpc_audio_amd.train import build_criterion, build_model, load_flat_params
     B = 2
     S = L // 160
