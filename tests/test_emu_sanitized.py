@@ -14,11 +14,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
 
 SUBSET = [
-    "tests/test_emu_nce.py",
+    "tests/test_emu_nce.py::test_nce_forward_backward_emulated[2-20-12-16-1.0-0-0]",
+    "tests/test_emu_nce.py::test_nce_forward_backward_emulated[2-21-7-32-3000.0-0-1]",
+    "tests/test_emu_nce.py::test_out_of_range_negative_indices_are_clamped_and_flagged",
     "tests/test_emu_adam.py",
     "tests/test_emu_encoder.py::test_encoder_forward_backward_emulated[2-1280-0-3]",
     "tests/test_emu_encoder.py::test_encoder_forward_backward_emulated[1-1370-64-1]",
-    "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated",
+    "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[2-131-4-2-1-256-False-0]",
+    "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[1-70-8-4-2-256-True-1]",
+    "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[2-1024-8-4-2-256-True-2]",
+    "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[1-300-8-4-2-256-True-4]",
+    "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[1-300-8-4-2-256-True-6]",
     "tests/test_emu_gru.py::test_gru_forward_backward_emulated[3-6-2-False]",
     "tests/test_emu_gru.py::test_gru_persistent_equals_stepwise_emulated[3-6-False]",
     "tests/test_emu_transformer.py::test_transformer_layer_forward_backward_emulated[1-40-False]",
