@@ -202,8 +202,9 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             # the draws and their index preparation depend on nothing the GPU is still computing (encoder, AR): issued
             # on the side stream they run beside the latency-bound recurrence instead of after it
             main, side = torch.cuda.current_stream(), step.side_stream(cFeature.device)
-            # (holding them back until the recurrence starts was measured: 4.187 vs 4.162 ms/step -- they disturb its
-            # hand-over polling more than they cost beside the first conv layers, where the host-side lead puts them)
+            # (holding them back until the recurrence starts was measured twice: 4.187 vs 4.162 ms/step in round 1, 3.426 vs
+            # 3.373 with the paced polls of round 2 -- they disturb its hand-over more than they cost beside the first conv
+            # layers, where the host-side lead puts them)
             if step.begin is not None:
                 side.wait_event(step.begin)           # fork from the start of the step (ops.StepContext.__enter__)
             with torch.cuda.stream(side):
