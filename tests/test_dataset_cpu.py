@@ -190,3 +190,27 @@ def test_loader_batches_equal_per_item_getitem(db, kind):
             assert len(set(labels.tolist())) == 1
     n = sum(1 for _ in data.getDataLoader(3, kind, True))
     assert n > 0
+
+
+def test_pack_boundaries_and_pack_cutting_follow_the_reference_accounting():
+    """The two helpers behind AudioBatchData: speaker boundaries exist for every speaker index up to the last one present
+    (absent speakers are empty intervals), an out-of-range speaker raises, labelled sequences are cut where their labels
+    end; the pack cutter opens a new pack with the sequence that overflowed and counts it with the pack it overflowed
+    (cpc/dataset.py:104-118, 142-170)."""
+    from cpc_audio_amd.dataset import _Pack, _cut_into_packs
+    loaded = [(3, "b", torch.arange(5.)), (0, "z", torch.arange(4.)), (3, "a", torch.arange(7.))]
+    pk = _Pack(loaded, 5, None, 0)
+    assert pk.seq_bounds.tolist() == [0, 4, 11, 16]                     # (0,z), (3,a), (3,b)
+    assert pk.speaker_bounds.tolist() == [0, 4, 4, 4, 16]               # speakers 1, 2 are empty, speaker 4 is not listed
+    assert torch.equal(pk.wave, torch.cat([torch.arange(4.), torch.arange(7.), torch.arange(5.)]))
+    with pytest.raises(ValueError):
+        _Pack(loaded, 3, None, 0)
+    labelled = _Pack([(0, "u", torch.arange(10.))], 1, {"step": 4, "u": [7, 8]}, 4)
+    assert labelled.wave.numel() == 8 and labelled.phones == [7, 8]
+    # [5, 5 | 5, 5 |]: the second and fourth sequences overflow; each opens the next pack with a running size of zero, so a
+    # pack that would consist of the overflowing LAST sequence alone is never closed (the reference drops it the same way)
+    packs, counted = _cut_into_packs([5, 5, 5, 5], 9)
+    assert packs == [(0, 1), (1, 3)] and counted == 10 + 10
+    packs, counted = _cut_into_packs([5, 5, 5, 5, 2], 9)
+    assert packs == [(0, 1), (1, 3), (3, 5)] and counted == 10 + 10 + 2
+    assert _cut_into_packs([3, 3], 100) == ([(0, 2)], 6)
