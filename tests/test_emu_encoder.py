@@ -189,7 +189,8 @@ def test_fp16_split_scaling_extremes_emulated(xs, ws):
                                                     (2, 1024, 8, 4, 2, 256, True, 2), (1, 512, 4, 2, 1, 256, False, 2),
                                                     (1, 300, 8, 4, 2, 256, True, 3), (2, 131, 4, 2, 1, 256, False, 3),
                                                     (1, 300, 8, 4, 2, 256, True, 4), (2, 131, 4, 2, 1, 256, False, 5),
-                                                    (1, 300, 8, 4, 2, 256, True, 6), (2, 131, 4, 2, 1, 256, False, 6)])
+                                                    (1, 300, 8, 4, 2, 256, True, 6), (2, 131, 4, 2, 1, 256, False, 6),
+                                                    (1, 300, 8, 4, 2, 256, True, 2)])       # Lout % 256 != 0: the pair walk falls back
 def test_dma_conv_kernel_matches_the_register_staged_kernel_emulated(B, Lin, k, s, p, bm, y_h2, pipe):
     """cpc_conv_gemm_forward_h2 (both operands DMA'd into XOR-swizzled LDS rows, H2 storage) against
     cpc_conv_layer_forward in mode 2 on the same fp32 data: same pieces, same products, same ChannelNorm -- results agree
