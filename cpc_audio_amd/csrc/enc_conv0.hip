@@ -45,89 +45,64 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(
     }
     for (int e = tid; e < kC * K0; e += 256) wT[e % K0][e / K0] = w[e];
     __syncthreads();
-    // The kernel is VALU-bound (4 cycles per wave64 instruction, ~1 KB of output per ~100 instructions), so the
-    // 40 FMAs of a time step are issued as 20 packed v_pk_fma_f32 and 1/sqrt is the single v_rsq_f32.
-    f32x2 w01[K0], w23[K0], b01, b23, g01, g23, n01, n23;
+    // Scalar fp32 arithmetic on purpose (and -fno-slp-vectorize for this file, build.py): with the 40 FMAs of a time step issued
+    // as 20 v_pk_fma_f32 whose broadcast operand is an LDS-read sample, this kernel -- like conv0_bwd_kernel before it --
+    // returned different bits whenever a 16-bit-MFMA GEMM kernel shared the chip with it (tests/test_gpu_corun.py; inside one
+    // train step nothing runs beside it, two train loops on one device do).  1/sqrt is the single v_rsq_f32.
+    float4 wj[K0];
     const int c = lane * 4;
 #pragma unroll
-    for (int j = 0; j < K0; ++j) {
-        const float4 wv4 = *reinterpret_cast<const float4*>(&wT[j][c]);
-        w01[j] = f32x2{wv4.x, wv4.y};
-        w23[j] = f32x2{wv4.z, wv4.w};
-    }
-    {
-        const float4 b4 = *reinterpret_cast<const float4*>(bias + c);
-        const float4 w4 = *reinterpret_cast<const float4*>(nw + c);
-        const float4 n4 = *reinterpret_cast<const float4*>(nb + c);
-        b01 = f32x2{b4.x, b4.y}; b23 = f32x2{b4.z, b4.w};
-        g01 = f32x2{w4.x, w4.y}; g23 = f32x2{w4.z, w4.w};
-        n01 = f32x2{n4.x, n4.y}; n23 = f32x2{n4.z, n4.w};
-    }
-    const f32x2 zero2 = f32x2{0.f, 0.f};
+    for (int j = 0; j < K0; ++j) wj[j] = *reinterpret_cast<const float4*>(&wT[j][c]);
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + c);
+    const float4 g4 = *reinterpret_cast<const float4*>(nw + c);
+    const float4 n4 = *reinterpret_cast<const float4*>(nb + c);
     const float sy = YK == 1 ? scale_for_amax(*y_amax) : 1.0f;
+    auto finish = [&](const float4& x, float mu, float rs, long row) __attribute__((always_inline)) {
+        float4 o;
+        o.x = fmaxf(fmaf((x.x - mu) * rs, g4.x, n4.x), 0.f);
+        o.y = fmaxf(fmaf((x.y - mu) * rs, g4.y, n4.y), 0.f);
+        o.z = fmaxf(fmaf((x.z - mu) * rs, g4.z, n4.z), 0.f);
+        o.w = fmaxf(fmaf((x.w - mu) * rs, g4.w, n4.w), 0.f);
+        if constexpr (YK == 1) {
+            h2_store_row_nt(y + row * kC, o.x, o.y, o.z, o.w, sy);
+        } else if constexpr (YK == 2) {
+            const unsigned long long w2 = (unsigned long long)(bf16_rne(o.x) | ((unsigned)bf16_rne(o.y) << 16)) |
+                                          ((unsigned long long)(bf16_rne(o.z) | ((unsigned)bf16_rne(o.w) << 16)) << 32);
+            __builtin_nontemporal_store(w2, reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(y) + row * kC + c));
+        } else {
+            float* yo = y + row * kC + c;       // streamed once, 268 MB per launch at B = 64 (>> L2): non-temporal
+            __builtin_nontemporal_store(o.x, yo);
+            __builtin_nontemporal_store(o.y, yo + 1);
+            __builtin_nontemporal_store(o.z, yo + 2);
+            __builtin_nontemporal_store(o.w, yo + 3);
+        }
+        if (lane == 0) { mean_out[row] = mu; rstd_out[row] = rs; }
+    };
+    auto sq4 = [](const float4& x, float mu) __attribute__((always_inline)) {
+        const float a = x.x - mu, b_ = x.y - mu, c_ = x.z - mu, d = x.w - mu;
+        return fmaf(a, a, c_ * c_) + fmaf(b_, b_, d * d);
+    };
     // two time steps per iteration: their reduction chains are independent and interleave
     for (int tt = wv; tt < C0_TT; tt += 8) {
         const int ta = t0 + tt, tb = ta + 4;
         if (ta >= L0) break;                     // wave-uniform
         const bool has_b = tb < L0;              // wave-uniform
-        f32x2 xa01 = b01, xa23 = b23, xb01 = b01, xb23 = b23;
+        float4 xa = b4, xb = b4;
 #pragma unroll
         for (int j = 0; j < K0; ++j) {
             const float sa = smp[tt * S0 + j], sb = smp[(tt + 4) * S0 + j];
-            const f32x2 sa2 = f32x2{sa, sa}, sb2 = f32x2{sb, sb};
-            xa01 = __builtin_elementwise_fma(w01[j], sa2, xa01);
-            xa23 = __builtin_elementwise_fma(w23[j], sa2, xa23);
-            xb01 = __builtin_elementwise_fma(w01[j], sb2, xb01);
-            xb23 = __builtin_elementwise_fma(w23[j], sb2, xb23);
+            xa.x = fmaf(wj[j].x, sa, xa.x); xa.y = fmaf(wj[j].y, sa, xa.y);
+            xa.z = fmaf(wj[j].z, sa, xa.z); xa.w = fmaf(wj[j].w, sa, xa.w);
+            xb.x = fmaf(wj[j].x, sb, xb.x); xb.y = fmaf(wj[j].y, sb, xb.y);
+            xb.z = fmaf(wj[j].z, sb, xb.z); xb.w = fmaf(wj[j].w, sb, xb.w);
         }
-        const f32x2 sa_ = xa01 + xa23, sb_ = xb01 + xb23;
-        const float mua = wave_sum(sa_.x + sa_.y) * (1.0f / kC);
-        const float mub = wave_sum(sb_.x + sb_.y) * (1.0f / kC);
-        const f32x2 da01 = xa01 - f32x2{mua, mua}, da23 = xa23 - f32x2{mua, mua};
-        const f32x2 db01 = xb01 - f32x2{mub, mub}, db23 = xb23 - f32x2{mub, mub};
-        const f32x2 qa = __builtin_elementwise_fma(da01, da01, da23 * da23);
-        const f32x2 qb = __builtin_elementwise_fma(db01, db01, db23 * db23);
-        const float va = wave_sum(qa.x + qa.y), vb = wave_sum(qb.x + qb.y);
+        const float mua = wave_sum((xa.x + xa.z) + (xa.y + xa.w)) * (1.0f / kC);
+        const float mub = wave_sum((xb.x + xb.z) + (xb.y + xb.w)) * (1.0f / kC);
+        const float va = wave_sum(sq4(xa, mua)), vb = wave_sum(sq4(xb, mub));
         const float rsa = __builtin_amdgcn_rsqf(va * (1.0f / (kC - 1)) + kNormEps);
         const float rsb = __builtin_amdgcn_rsqf(vb * (1.0f / (kC - 1)) + kNormEps);
-        {
-            const long row = (long)b * L0 + ta;
-            float* yo = y + row * kC + c;       // streamed once, 268 MB per launch at B = 64 (>> L2): non-temporal
-            const f32x2 o01 = __builtin_elementwise_max(__builtin_elementwise_fma(da01 * f32x2{rsa, rsa}, g01, n01), zero2);
-            const f32x2 o23 = __builtin_elementwise_max(__builtin_elementwise_fma(da23 * f32x2{rsa, rsa}, g23, n23), zero2);
-            if constexpr (YK == 1) {
-                h2_store_row_nt(y + row * kC, o01.x, o01.y, o23.x, o23.y, sy);
-            } else if constexpr (YK == 2) {
-                const unsigned long long w = (unsigned long long)(bf16_rne(o01.x) | ((unsigned)bf16_rne(o01.y) << 16)) |
-                                             ((unsigned long long)(bf16_rne(o23.x) | ((unsigned)bf16_rne(o23.y) << 16)) << 32);
-                __builtin_nontemporal_store(w, reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(y) + row * kC + c));
-            } else {
-                __builtin_nontemporal_store(o01.x, yo);
-                __builtin_nontemporal_store(o01.y, yo + 1);
-                __builtin_nontemporal_store(o23.x, yo + 2);
-                __builtin_nontemporal_store(o23.y, yo + 3);
-            }
-            if (lane == 0) { mean_out[row] = mua; rstd_out[row] = rsa; }
-        }
-        if (has_b) {
-            const long row = (long)b * L0 + tb;
-            float* yo = y + row * kC + c;
-            const f32x2 o01 = __builtin_elementwise_max(__builtin_elementwise_fma(db01 * f32x2{rsb, rsb}, g01, n01), zero2);
-            const f32x2 o23 = __builtin_elementwise_max(__builtin_elementwise_fma(db23 * f32x2{rsb, rsb}, g23, n23), zero2);
-            if constexpr (YK == 1) {
-                h2_store_row_nt(y + row * kC, o01.x, o01.y, o23.x, o23.y, sy);
-            } else if constexpr (YK == 2) {
-                const unsigned long long w = (unsigned long long)(bf16_rne(o01.x) | ((unsigned)bf16_rne(o01.y) << 16)) |
-                                             ((unsigned long long)(bf16_rne(o23.x) | ((unsigned)bf16_rne(o23.y) << 16)) << 32);
-                __builtin_nontemporal_store(w, reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(y) + row * kC + c));
-            } else {
-                __builtin_nontemporal_store(o01.x, yo);
-                __builtin_nontemporal_store(o01.y, yo + 1);
-                __builtin_nontemporal_store(o23.x, yo + 2);
-                __builtin_nontemporal_store(o23.y, yo + 3);
-            }
-            if (lane == 0) { mean_out[row] = mub; rstd_out[row] = rsb; }
-        }
+        finish(xa, mua, rsa, (long)b * L0 + ta);
+        if (has_b) finish(xb, mub, rsb, (long)b * L0 + tb);
     }
 }
 

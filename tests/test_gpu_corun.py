@@ -119,6 +119,46 @@ def test_conv0_backward_is_bit_exact_beside_the_fp16_gemm_kernels():
     _check_beside(victim, grads, co)
 
 
+def test_conv0_forward_is_bit_exact_beside_the_fp16_gemm_kernels():
+    """conv0's forward never runs beside a GEMM inside ONE train step, but it does as soon as two train loops share a device
+    (test_two_trainers_on_two_threads...): both of its forms (fp32 output, fp16-piece output)."""
+    dev = _dev()
+    co = _Corunner(dev)
+    lib, P = co.lib, co.P
+    B, L = 16, 20480
+    g = torch.Generator(device="cpu").manual_seed(2)
+    wave = (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1).to(dev)
+    w0 = (torch.randn(256, 10, generator=g) * 0.3).to(dev)
+    b0 = (torch.randn(256, generator=g) * 0.1).to(dev)
+    nw, nb = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+    bound = (15.968719 * nw.abs().max() + nb.abs().max()).view(1).clone()
+    for h2 in (False, True):
+        y0 = torch.empty(B, 4096, 256, device=dev)
+        m0, r0 = torch.empty(B * 4096, device=dev), torch.empty(B * 4096, device=dev)
+
+        def victim(st):
+            lib.check(lib.cpc_conv0_forward_h2(P(wave), P(w0), P(b0), P(nw), P(nb), P(y0), P(m0), P(r0),
+                                               P(bound) if h2 else None, B, L, st.cuda_stream))
+        outs = [y0, m0, r0]
+        bits = lambda: [t.view(torch.int32).clone() for t in outs]          # H2 storage: compare bit patterns, not floats
+        s1 = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        victim(s1)
+        torch.cuda.synchronize()
+        ref = bits()
+        for kind in ("wgrad", "dgrad"):
+            for it in range(3):
+                for t in outs:
+                    t.zero_()
+                torch.cuda.synchronize()
+                co.launch(kind, 2)
+                victim(s1)
+                co.launch(kind, 3)
+                torch.cuda.synchronize()
+                bad = [i for i, (a, b_) in enumerate(zip(ref, bits())) if not torch.equal(a, b_)]
+                assert not bad, f"h2={h2}, beside conv_{kind}: outputs {bad} differ from the solo run (round {it})"
+
+
 def test_norm_backward_is_bit_exact_beside_the_fp16_gemm_kernels():
     dev = _dev()
     co = _Corunner(dev)
@@ -205,6 +245,44 @@ def test_overlapped_train_steps_stay_bit_identical_to_the_single_stream_step():
     ref, lref = step(False)
     for i in range(12):
         cur, l = step(True)
+        assert torch.equal(l, lref), i
+        diff = [k for k, (a, b) in enumerate(zip(ref, cur)) if not torch.equal(a, b)]
+        assert not diff, (i, diff)
+
+
+def test_train_steps_are_bit_identical_beside_foreign_fp16_gemm_kernels():
+    """Every kernel of the step at once: whole overlapped train steps at B = 16 while ANOTHER stream keeps 16-bit-MFMA GEMM
+    kernels on the chip (what a second train loop, or another process, on the same device does), against the quiet run."""
+    dev = _dev()
+    co = _Corunner(dev)
+    from cpc_audio_amd import ops
+    from cpc_audio_amd.train import build_criterion, build_model
+    B = 16
+    torch.manual_seed(0)
+    model, crit = build_model().to(dev), build_criterion().to(dev)
+    params = list(model.parameters()) + list(crit.parameters())
+    g = torch.Generator(device="cpu").manual_seed(3)
+    wave = (0.1 * torch.randn(B, 1, 20480, generator=g)).clamp_(-1, 1).to(dev)
+    negs = (torch.randint(0, B, (B * 128 * 116,), generator=g).to(dev),
+            torch.randint(1, 128, (B * 128 * 116,), generator=g).to(dev))
+
+    def step(noise):
+        for q in params:
+            q.grad = None
+        torch.cuda.synchronize()
+        if noise:
+            co.launch(noise, 12)                                   # ~ the duration of the step, on its own stream
+        with ops.StepContext(overlap=True) as sc:
+            c, z, _ = model(wave, None)
+            losses, _ = crit(c, z, None, negatives=negs)
+            torch.autograd.backward([losses], [torch.ones_like(losses)])
+            sc.wait()
+        torch.cuda.synchronize()
+        return [q.grad.clone() for q in params], losses.detach().clone()
+
+    ref, lref = step(None)
+    for i in range(6):
+        cur, l = step("wgrad" if i % 2 == 0 else "dgrad")
         assert torch.equal(l, lref), i
         diff = [k for k, (a, b) in enumerate(zip(ref, cur)) if not torch.equal(a, b)]
         assert not diff, (i, diff)

@@ -245,3 +245,50 @@ def test_device_error_flags_negative_index_and_recurrence_timeout():
     torch.cuda.synchronize()
     assert torch.isfinite(y).all()
     ops.check_device_errors()
+
+
+def test_two_trainers_on_two_threads_of_one_device_do_not_disturb_each_other():
+    """The overlap state (side streams, events, launches held back) belongs to a Trainer's StepContext, the event sets of the C
+    side are per stream and created under a lock: two train loops driven from two Python threads on ONE device -- each on its
+    own stream, what a threaded data-parallel wrapper does -- must each produce, bit for bit, what they produce alone."""
+    import threading
+    dev = _dev()
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
+
+    def make(seed):
+        p = O.make_params(seed=seed, head_scale=64.0)
+        model, crit = build_model().to(dev), build_criterion().to(dev)
+        load_flat_params(model, crit, p)
+        wave = O.make_waveform(4, 20480, seed=seed + 1).to(dev)
+        g = torch.Generator().manual_seed(seed + 2)
+        bi, si = O.draw_negative_indices(4, 128, 116, 128, generator=g)
+        return Trainer(model, crit, graph=False), wave, (bi.to(dev), si.to(dev))
+
+    def run(job, out, key):
+        try:
+            tr, wave, neg = job
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                losses = [tr.step(wave, None, negatives=neg)[0].clone() for _ in range(3)]
+                torch.cuda.current_stream().synchronize()
+            state = dict(tr.model.state_dict())
+            state.update(tr.criterion.state_dict())
+            out[key] = (torch.stack(losses).cpu(), {k: v.detach().cpu().clone() for k, v in state.items()})
+        except BaseException as e:                # surfaced by the assert below
+            out[key] = e
+
+    alone = {}
+    for key, seed in (("a", 31), ("b", 57)):
+        run(make(seed), alone, key)
+    both = {}
+    threads = [threading.Thread(target=run, args=(make(seed), both, key)) for key, seed in (("a", 31), ("b", 57))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for key in ("a", "b"):
+        assert not isinstance(alone[key], BaseException), alone[key]
+        assert not isinstance(both[key], BaseException), both[key]
+        assert torch.equal(alone[key][0], both[key][0]), key
+        for k, v in alone[key][1].items():
+            assert torch.equal(v, both[key][1][k]), (key, k)
