@@ -250,14 +250,15 @@ def test_overlapped_train_steps_stay_bit_identical_to_the_single_stream_step():
         assert not diff, (i, diff)
 
 
-def test_train_steps_are_bit_identical_beside_foreign_fp16_gemm_kernels():
-    """Every kernel of the step at once: whole overlapped train steps at B = 16 while ANOTHER stream keeps 16-bit-MFMA GEMM
-    kernels on the chip (what a second train loop, or another process, on the same device does), against the quiet run."""
+@pytest.mark.parametrize("B,burst", [(16, 12), (64, 60)])
+def test_train_steps_are_bit_identical_beside_foreign_fp16_gemm_kernels(B, burst):
+    """Every kernel of the step at once: whole overlapped train steps (B = 16: the small tiles; B = 64: the benchmark's kernels)
+    while ANOTHER stream keeps 16-bit-MFMA GEMM kernels on the chip (what a second train loop, or another process, on the same
+    device does), against the quiet run."""
     dev = _dev()
     co = _Corunner(dev)
     from cpc_audio_amd import ops
     from cpc_audio_amd.train import build_criterion, build_model
-    B = 16
     torch.manual_seed(0)
     model, crit = build_model().to(dev), build_criterion().to(dev)
     params = list(model.parameters()) + list(crit.parameters())
@@ -271,7 +272,7 @@ def test_train_steps_are_bit_identical_beside_foreign_fp16_gemm_kernels():
             q.grad = None
         torch.cuda.synchronize()
         if noise:
-            co.launch(noise, 12)                                   # ~ the duration of the step, on its own stream
+            co.launch(noise, burst)                                # ~ the duration of the step, on its own stream
         with ops.StepContext(overlap=True) as sc:
             c, z, _ = model(wave, None)
             losses, _ = crit(c, z, None, negatives=negs)
