@@ -31,11 +31,13 @@ int cpc_abi_version(void);
  *   1 bf16 matrix pipe, fp32 operands split by truncation into three bf16 pieces, six
  *     bf16 MFMAs per product, fp32 accumulate: error <= 2^-23 per product (fp32 level), 2.67x the rate;
  *   0 exact-f32 MFMA (v_mfma_f32_32x32x2_f32);
- *   2 (default) fp16 matrix pipe for the 128-row conv tiles, operands scaled by a power of two (from a bound on their max|.|) and split into two
+ *   2 fp16 matrix pipe for the 128-row conv tiles, operands scaled by a power of two (from a bound on their max|.|) and split into two
  *     fp16 pieces, three fp16 MFMAs per product (hh + hl + lh), fp32 accumulate: error <= 2^-21 per product,
  *     half the MFMAs of mode 1.  Applies to the conv layers (forward, dgrad, wgrad), whose operand bounds
  *     come for free (ChannelNorm affine; max|gradient| accumulated by the producing kernel); the small generic
- *     GEMMs (projections, heads, weight gradients of the AR / criterion) run as in mode 1.  *   3 (default) as 2, and the encoder (cpc_encoder_forward / _backward) keeps the output of layer 0 -- at B >= ~100 also
+ *     GEMMs (projections, heads, weight gradients of the AR / criterion) run as in mode 1 unless their operand bounds are
+ *     known (cpc_set_gemm_split);
+ *   3 (default) as 2, and the encoder (cpc_encoder_forward / _backward) keeps the output of layer 0 -- at B >= ~100 also
  *     of layer 1 -- in H2 storage (below): conv1 (conv2), 70 % (87 %) of the conv stack's FLOPs, read both GEMM operands
  *     global -> LDS by DMA (csrc/conv_dma.hip, 256- / 128-row tiles); their weight gradients read the pieces as stored.  The
  *     per-layer entry points (cpc_conv_layer_*, cpc_conv_gemm_forward, cpc_norm_backward) behave as in mode 2. */
