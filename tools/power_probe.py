@@ -65,5 +65,38 @@ def main():
             print("   ", o[:300])
 
 
+def encoder_loop():
+    """The same sampling while the encoder's forward + backward (one stream) and the whole train step run back to back."""
+    import ctypes
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model
+    secs = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model, crit = build_model().to(dev), build_criterion().to(dev)
+    tr = Trainer(model, crit)
+    wave = (0.1 * torch.randn(64, 1, 20480)).clamp_(-1, 1).to(dev)
+    label = torch.zeros(64, dtype=torch.long, device=dev)
+    for _ in range(5):
+        tr.step(wave, label)
+    torch.cuda.synchronize()
+    stop, out = threading.Event(), []
+    th = threading.Thread(target=sample, args=(stop, out))
+    th.start()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < secs:
+        for _ in range(20):
+            tr.step(wave, label)
+        torch.cuda.synchronize()
+        n += 20
+    dt = time.perf_counter() - t0
+    stop.set(); th.join()
+    print(f"== train step: {n} steps in {dt:.2f} s = {1e3 * dt / n:.3f} ms per step")
+    for o in out[1:7]:
+        print("   ", o[:300])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "step":
+        encoder_loop()
+    else:
+        main()
