@@ -11,11 +11,11 @@
 // activation.  Only mean and rstd (8 B per step) are kept for the backward pass,
 // which recomputes the 10-tap conv instead of re-reading a 4 MB pre-norm tensor.
 //
-// Measured (B = 64, 276 MB per launch): 59 us = 4.6 TB/s (a plain fill reaches 6.9 TB/s on the same box).
-// Ablation: 43 us without the activation stores -- the loop sits at the VALU issue limit (~65 VALU
-// instructions per 1 KB row at 4 cycles each: 20 v_pk_fma_f32, two DPP+readlane wave reductions, the
-// normalise/affine/ReLU ops); shuffles (ds_bpermute) and scalar FMAs were already replaced by DPP and
-// packed math, and non-temporal stores are used for the streamed output.
+// Measured (B = 64, 276 MB per launch): 60-65 us in the step = 4.3-4.6 TB/s (a plain fill reaches 6.9 TB/s on the same box).
+// Ablation: 43 us without the activation stores -- the loop sits near the VALU issue limit (two DPP+readlane wave
+// reductions, the normalise/affine/ReLU ops, 40 FMAs per 1 KB row); shuffles (ds_bpermute) were replaced by DPP,
+// non-temporal stores are used for the streamed output.  The FMAs are scalar on purpose: issued as 20 v_pk_fma_f32 (round 1)
+// the kernel changed its results beside another train loop's 16-bit-MFMA kernels (see the kernel).
 #include "cpc_common.h"
 #include "cpc_internal.h"
 #include "gemm_tile.h"
