@@ -11,7 +11,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcpc_hip.so")
 DEFAULT_GRU_MODE = 2       # cpc_set_gru_mode: persistent recurrence, forward products on the fp16 split
-DEFAULT_MFMA_MODE = 3      # what libcpc_hip starts in (cpc_set_mfma_mode): conv layers on the fp16 split, GEMMs on the bf16 split
+DEFAULT_MFMA_MODE = 3      # what libcpc_hip starts in (cpc_set_mfma_mode): mode 2's arithmetic (two fp16 pieces, 3 MFMAs per
+#                            product) with conv1 / its gradients on the DMA-fed kernels reading H2-stored activations
 DEFAULT_DMA_PIPELINE = 2   # cpc_set_dma_pipeline: the tap-pair walk where the shape allows, two 32-k stages elsewhere
 
 _P = ctypes.c_void_p
@@ -22,6 +23,7 @@ _F = ctypes.c_float
 # name -> (restype, argtypes); mirrors include/cpc_hip.h one to one
 SIGNATURES = {
     "cpc_abi_version": (_I, []),
+    "cpc_release_stream": (_I, [_P]),
     "cpc_set_mfma_mode": (_I, [_I]),
     "cpc_get_mfma_mode": (_I, []),
     "cpc_device_error_flags": (_I, [_I]),
@@ -41,7 +43,6 @@ SIGNATURES = {
     "cpc_set_gru_poll_pacing": (_I, [_I, _I]),
     "cpc_set_dma_rotation": (_I, [_I]),
     "cpc_set_dma_pipeline": (_I, [_I]),
-    "cpc_set_nce_fuse": (_I, [_I]),
     "cpc_conv0_backward_scratch_floats": (_L, [_I, _I]),
     "cpc_conv0_backward": (_I, [_P] * 13 + [_I, _I, _P]),
     "cpc_conv_layer_forward": (_I, [_P] * 9 + [_I] * 5 + [_P]),
@@ -84,7 +85,7 @@ SIGNATURES = {
     "cpc_nce_forward": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward": (_I, [_P] * 12 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward_streams": (_I, [_P] * 12 + [_I, _I, _I, _I, _P, _P]),
-    "cpc_nce_backward_dz": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
+    "cpc_nce_backward_dz": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward_dwall": (_I, [_P] * 3 + [_I, _I, _I, _I, _P]),
     "cpc_adam_step": (_I, [_P] * 5 + [_I] + [ctypes.c_double] * 6 + [_P]),
     "cpc_adam_step_capturable": (_I, [_P] * 5 + [_I] + [ctypes.c_double] * 4 + [_P, _P, _P]),

@@ -14,9 +14,11 @@ int g_mfma_mode = 3;
 // harmless).  The pool is keyed by the caller's stream and guarded by a mutex: two host threads driving two streams of
 // one device (nn.DataParallel-style replicas) each get their own events -- with a shared pool one thread's wait could
 // capture the other's record.  Two threads enqueueing on the SAME stream at once is a caller error, as everywhere in HIP.
+// The pool assumes long-lived streams (torch's pooled streams are): a caller that creates a stream per step hands each one
+// back with cpc_release_stream() before destroying it, or a recycled handle would inherit the old pool.
+static std::mutex mu;
+static std::map<std::pair<int, hipStream_t>, hipEvent_t*> pools;
 hipEvent_t* stream_events(hipStream_t st) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, hipEvent_t*> pools;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
@@ -34,7 +36,21 @@ hipEvent_t* stream_events(hipStream_t st) {
 }
 }  // namespace cpc
 
-extern "C" int cpc_abi_version(void) { return 6; }
+// Drop (and destroy) the events this library keeps for `stream` on the current device; a no-op for a stream it never saw.
+// The stream must have no *_streams call of this library in flight.
+extern "C" int cpc_release_stream(void* stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return CPC_ERR_ARG;
+    std::lock_guard<std::mutex> lock(cpc::mu);
+    auto it = cpc::pools.find({dev, (hipStream_t)stream});
+    if (it == cpc::pools.end()) return 0;
+    for (int i = 0; i < cpc::kStreamEvents; ++i) (void)hipEventDestroy(it->second[i]);
+    delete[] it->second;
+    cpc::pools.erase(it);
+    return 0;
+}
+
+extern "C" int cpc_abi_version(void) { return 7; }
 
 // Device-side error flags of the current device, accumulated since they were last cleared:
 //   bit 0  CPC_DEVERR_GRU_POLL_TIMEOUT   a workgroup of the persistent recurrence gave up waiting for another one (its

@@ -64,7 +64,8 @@ int transpose_batch(const float* const* in, float* const* out, int n, int R, int
 // accuracy); 0: exact-f32 MFMA (NtTile).  Set through cpc_set_mfma_mode().
 extern int g_mfma_mode;
 
-// per-(device, caller stream) pool of events for the two-stream entry points: [0..4] encoder backward, [8] GRU backward
+// per-(device, caller stream) pool of events for the two-stream entry points: [0..4] encoder backward, [8] GRU backward,
+// [9] criterion backward (score gradients -> dz stream)
 constexpr int kStreamEvents = 12;
 hipEvent_t* stream_events(hipStream_t caller_stream);
 

@@ -17,9 +17,16 @@
 // logits and K log-sum-exps per row are kept for the backward pass.
 //
 // Backward per (b,t):
-//   dPred[16 x 256] = dS[16 x N] . Neg[N x 256]        (gather again, MFMA)
-//   dNeg [N x 256]  = dS^T[N x 16] . P[16 x 256]       (MFMA) -> rows of V, gathered per z row
+//   dPred[16 x 256] = dS[16 x N] . Neg[N x 256]        (gather again, MFMA; dS is kept, 64 bytes per candidate)
 // then the head GEMMs:  dc = dPred . W,  dW_k = dPred_k^T . c   (gemm.hip).
+// dz -- a scatter of dS[slot,k] * pred_k(window of slot) over random destination rows -- is re-associated through c for
+// the linear heads (pred_k = W_k c):
+//   dz[j] = sum_k W_k . G[j,k,:],   G[j,k,:] = sum over the slots landing on row j of dS[slot,k] * c[window(slot)]
+// i.e. per destination row a gather-GEMM  G_j[16 x 256] = dS_j^T[16 x n_j] . C_j[n_j x 256]  over the destination-sorted
+// slot list (1 KB rows of c from L2 / Infinity Cache: the forward kernel's shape mirrored), then ONE dense GEMM
+// (B*S x K*256) . (K*256 x 256) with the stacked heads.  HBM: ~100 MB of G + 66 MB of dS at B = 64, no atomics.
+// Predictions of a foreign network (cpc_nce_scores_*) are not linear in c: their dz goes through per-candidate gradient
+// rows V (1 GB at B = 64) and a destination-sorted gather.
 #include <algorithm>
 #include "cpc_common.h"
 #include "cpc_internal.h"
@@ -32,35 +39,13 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
-// 1: the forward scoring kernel also forms U = sum_j softmax_j z_j - z_pos for every head while the candidate rows are in its
-// registers (nce_fwd_kernel<true>) and the backward only scales it; 0 (default): the backward gathers the rows again
-// (nce_bwd_dpred_kernel).  Must not change between a forward and its backward (like cpc_set_mfma_mode).  Measured at B = 64
-// (DESIGN.md section 4.10): the second product doubles the forward kernel's f32 MFMAs and halves its occupancy, 160 -> 290 us,
-// which is what the backward's own gather costs (178 us): no gain, so it is off.
-static int g_nce_fuse = 0;
-extern "C" int cpc_set_nce_fuse(int on) {
-    CPC_RETURN_IF(on < 0 || on > 1, CPC_ERR_ARG);
-    g_nce_fuse = on;
-    return 0;
-}
-
 // ------------------------------------------------------------------ forward scores
 // one wavefront per (b,t) row; 4 rows per block.  pred: [BW][K*C]; ext: [BW][N] row ids into z.
 //
-// WITH_U: the same pass over the gathered candidate rows also forms what the backward needs of them,
-//   U[bt][k][:] = sum_j softmax_j z_j - z_pos(k)            (d loss_k / d pred_k up to the per-head factor gscale[k]),
-// so that the backward's own gather of the same 1.16 GB of rows (nce_bwd_dpred_kernel) is not needed: it only scales U.
-// Scores are computed transposed -- S^T = Z . pred^T, i.e. the z rows are the A operand -- so that a lane (i, kq) ends up
-// with the scores of HEAD i against candidates 4 kq + r: exactly the A-operand layout of the second product P . Z (16 heads x
-// 16 candidates times 16 candidates x 256 channels, the channel order absorbed by the output mapping as in
-// nce_bwd_dpred_kernel), no cross-lane traffic in the loop.  The softmax weights are taken against a running reference M
-// (initially the positive's logit) that is only moved -- and the partial sums rescaled -- when a logit exceeds it by more
-// than 40, which no sane model does: exp(l - M) <= e^40 is harmless in fp32, and the normalisation is exact at the end.
-template <bool WITH_U>
 __global__ __launch_bounds__(256) void nce_fwd_kernel(
     const float* __restrict__ pred, const float* __restrict__ z, const int* __restrict__ ext,
     float* __restrict__ logits, float* __restrict__ lse_out, float* __restrict__ rowstat, int BW, int W,
-    int S, int K, int N, unsigned* __restrict__ ticket, float* __restrict__ U) {
+    int S, int K, int N, unsigned* __restrict__ ticket) {
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;      // nce_reduce_finalize_kernel, the next launch on this stream
@@ -98,11 +83,6 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(
     float M = posl;                                 // reference of the softmax weights, common to the four lanes of a head
     float ssum = kq == 0 ? 1.0f : 0.0f;             // the positive enters the sum once (exp(posl - M) = 1)
     float mneg = -3.0e38f;
-    f32x4 O[16];
-    if constexpr (WITH_U) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) O[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
     for (int nt = 0; nt < N / 16; ++nt) {
         const int row = ext[(long)bt * N + nt * 16 + i];
         const float* zr = z + (long)row * kC + 4 * kq;
@@ -129,36 +109,12 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(
             const float Mn = fmaxf(M, tm), alpha = expf(M - Mn);
             ssum *= alpha;
             M = Mn;
-            if constexpr (WITH_U) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ah = __shfl(alpha, 4 * kq + r);             // O's rows on this lane: heads 4 kq + r
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) O[q][r] *= ah;
-                }
-            }
         }
         float pw[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             pw[r] = expf(l[r] - M);
             ssum += pw[r];
-        }
-        if constexpr (WITH_U) {
-            // O[head][channel] += sum over the tile's 16 candidates of pw * z: MFMA r contracts candidates {r, 4+r, 8+r, 12+r}
-            const int* ep = ext + (long)bt * N + nt * 16 + 4 * kq;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = hv ? pw[r] : 0.f;
-                const float* z2 = z + (long)ep[r] * kC + 4 * i;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 bv = ld4(z2 + 64 * u);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        O[u * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f4c(bv, e), O[u * 4 + e], 0, 0, 0);
-                }
-            }
         }
     }
     // fold the four k groups of a head
@@ -172,54 +128,6 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(
         lse_out[(long)bt * K + i] = lse;
         rowstat[(long)bt * 2 * K + i] = lse - posl;                       // CE(target 0)
         rowstat[(long)bt * 2 * K + K + i] = posl >= mneg ? 1.f : 0.f;     // argmax == 0
-    }
-    if constexpr (WITH_U) {
-        const float fnorm = expf(M - lse), d0 = expf(posl - lse) - 1.0f;  // 1 / sum, softmax(positive) - 1
-        // C layout: head = 4 kq + r, channel = 64 u + 4 i + e
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int head = 4 * kq + r;
-            const float fh = __shfl(fnorm, head), dh = __shfl(d0, head);
-            if (head < K) {
-                const float* zp = z + ((long)b * S + t + head + 1) * kC + 4 * i;
-                float* op = U + ((long)bt * K + head) * kC + 4 * i;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 zv = ld4(zp + 64 * u);
-                    float4 o;
-                    o.x = fmaf(dh, zv.x, O[u * 4 + 0][r] * fh);
-                    o.y = fmaf(dh, zv.y, O[u * 4 + 1][r] * fh);
-                    o.z = fmaf(dh, zv.z, O[u * 4 + 2][r] * fh);
-                    o.w = fmaf(dh, zv.w, O[u * 4 + 3][r] * fh);
-                    *reinterpret_cast<float4*>(op + 64 * u) = o;
-                }
-            }
-        }
-    }
-}
-
-// dPred = gscale[k] * U (nce_fwd_kernel<true>) + its max|.| slots: the backward's share of the dPred computation when the
-// forward has already gathered the rows.  amax_slots were cleared by nce_gscale_kernel.
-__global__ __launch_bounds__(256) void nce_scale_u_kernel(const float* __restrict__ U, const float* __restrict__ gscale,
-                                                         float* __restrict__ dpred, long rows, int K,
-                                                         float* __restrict__ amax_slots) {
-    // one wave per (bt, head) row of 256 at a time, grid-stride; ONE atomic per wave at the end (one per row serialises
-    // 89 k atomics on 64 addresses: 0.43 ms for a 45 us copy)
-    const int lane = threadIdx.x & 63;
-    const long nwaves = (long)gridDim.x * 4;
-    float amax = 0.f;
-    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nwaves) {
-        const float g = gscale[row % K];
-        float4 v = ld4(U + row * kC + 4 * lane);
-        v.x *= g; v.y *= g; v.z *= g; v.w *= g;
-        *reinterpret_cast<float4*>(dpred + row * kC + 4 * lane) = v;
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-    }
-    if (amax_slots != nullptr) {
-        amax = wave_max(amax);
-        if (lane == 0)
-            atomicMax(reinterpret_cast<unsigned*>(amax_slots + (int)((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kAmaxSlots - 1))),
-                      __float_as_uint(amax));
     }
 }
 
@@ -278,8 +186,8 @@ __global__ __launch_bounds__(256) void nce_reduce_finalize_kernel(const float* _
 
 // gscale[k] = dL/dloss_k / (B*W) / C
 // fwd_bounds (linear heads; NULL otherwise): the forward's max|c|, max|wall| slots.  Then also gscale[17] = max|c|,
-// gscale[18] = max|wall| (operand bounds of the backward GEMMs, GemmBounds) and the 64 max|dPred| slots at gscale[64..127]
-// are cleared for nce_bwd_dpred_kernel.  (An a-priori bound -- |dPred| <= 2 max|gscale| max|z| -- needs no slots but is far
+// gscale[18] = max|wall| (operand bounds of the backward GEMMs, GemmBounds), the 64 max|dPred| slots at gscale[64..127]
+// are cleared for nce_bwd_dpred_kernel and the 64 max|G| slots at gscale[128..191] for nce_bwd_g_kernel.  (An a-priori bound -- |dPred| <= 2 max|gscale| max|z| -- needs no slots but is far
 // too loose once the softmax is confident: operands 2^-20 of their bound lose the low fp16 piece.)
 // Blocks 1.. (if any) zero dc_tail: the last S - W steps of every sequence of dc [B][S][256], which predict nothing and get no
 // gradient from the GEMM that writes the other rows (this replaces a memset of the whole tensor on the critical path).
@@ -300,14 +208,18 @@ __global__ __launch_bounds__(64) void nce_gscale_kernel(const float* __restrict_
         const float cm = wave_max(fwd_bounds[k]), wm = wave_max(fwd_bounds[kAmaxSlots + k]);
         if (k == 0) { gscale[17] = cm; gscale[18] = wm; }
         gscale[64 + k] = 0.f;
+        gscale[128 + k] = 0.f;
     }
 }
 
 // ------------------------------------------------------------------ backward: dPred
+// dS (optional): the score gradients themselves, one 64-byte row of 16 heads per candidate slot bt * (N + K) + j
+// (j < N: negative j, all K heads; j >= N: positive of head j - N, the other heads 0) -- what the re-associated dz path
+// (nce_bwd_g_kernel) contracts with the rows of c.
 __global__ __launch_bounds__(256) void nce_bwd_dpred_kernel(
     const float* __restrict__ z, const int* __restrict__ ext, const float* __restrict__ logits,
     const float* __restrict__ lse, const float* __restrict__ gscale, float* __restrict__ dpred, int BW,
-    int W, int S, int K, int N, float* __restrict__ amax_slots) {
+    int W, int S, int K, int N, float* __restrict__ amax_slots, float* __restrict__ dS) {
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bt >= BW) return;
@@ -327,6 +239,7 @@ __global__ __launch_bounds__(256) void nce_bwd_dpred_kernel(
         for (int jj = 0; jj < 4; ++jj) {
             const float a = hv ? gs * expf(lp[16 * ii + jj] - ls) : 0.f;   // d score[head i][n]
             const int row = ep[16 * ii + jj];                            // n = 16 ii + 4 kq + jj
+            if (dS != nullptr) dS[((long)bt * (N + K) + 16 * ii + 4 * kq + jj) * 16 + i] = a;
             const float* zr = z + (long)row * kC + 4 * i;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -343,6 +256,7 @@ __global__ __launch_bounds__(256) void nce_bwd_dpred_kernel(
         const int head = 4 * kq + r;
         if (head < K) {
             const float d0 = gscale[head] * (expf(logits[((long)bt * K + head) * (N + 1)] - lse[(long)bt * K + head]) - 1.0f);
+            if (dS != nullptr) dS[((long)bt * (N + K) + N + head) * 16 + i] = i == head ? d0 : 0.f;
             const float* zp = z + ((long)b * S + t + head + 1) * kC + 4 * i;
             float* op = dpred + ((long)bt * K + head) * kC + 4 * i;
 #pragma unroll
@@ -364,7 +278,100 @@ __global__ __launch_bounds__(256) void nce_bwd_dpred_kernel(
     }
 }
 
-// ------------------------------------------------------------------ backward: dz
+// ------------------------------------------------------------------ backward: dz, linear heads (re-associated through c)
+// Wcat[o][k*256 + i] = W_k[o][i] = wall[(k*256 + o)*256 + i]: the B operand (N = 256 rows o, contraction k*256 + i) of
+// dz = G . Wcat^T.  One 1 KB row per wave.
+__global__ __launch_bounds__(256) void nce_wcat_kernel(const float* __restrict__ wall, float* __restrict__ wcat, int K) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);          // (k, o)
+    if (row >= K * kC) return;
+    const int k = row >> kCLog2, o = row & (kC - 1);
+    *reinterpret_cast<float4*>(wcat + ((long)o * K + k) * kC + 4 * lane) = ld4(wall + (long)row * kC + 4 * lane);
+}
+
+// G[j][k][:] = sum over the candidate slots s that land on row j of z (perm[row_ptr[j] .. row_ptr[j+1]), cpc_nce_prepare)
+// of dS[s][k] * c[window of s]: one wavefront (= one 64-thread workgroup) per destination row,
+//   G_j[16 heads x 256] = dS_j^T[16 x n_j] . C_j[n_j x 256]        on v_mfma_f32_16x16x4_f32,
+// four slots per MFMA step (lane group kq takes slot 4 q + kq: its 16 lanes read that slot's 64-byte dS row as the A
+// operand and 4 x 256 bytes of its c row as B operands), nce_bwd_dpred_kernel's loop with the roles of windows and
+// destination rows exchanged.  The slot list of a row arrives in arbitrary order (nce_fill_kernel places slots with an
+// integer atomic cursor); it is rank-sorted in LDS first, so the summation order is the ascending slot order whatever the
+// fill order was: results are bit-reproducible.  amax_slots: 64 partial maxima of |G| (cleared by nce_gscale_kernel), the
+// operand bound of the GEMM that follows.
+constexpr int GATHER_MAX_SORT = 1024;
+__global__ __launch_bounds__(64) void nce_bwd_g_kernel(const float* __restrict__ c, const float* __restrict__ dS,
+                                                       const int* __restrict__ perm, const int* __restrict__ row_ptr,
+                                                       float* __restrict__ G, int W, int S, int K, int NK,
+                                                       float* __restrict__ amax_slots) {
+    __shared__ int raw[GATHER_MAX_SORT];          // the slot list as filled; after the sort: row of c per sorted slot
+    __shared__ int sorted[GATHER_MAX_SORT];
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x;
+    const int beg = row_ptr[j], len = row_ptr[j + 1] - beg;
+    const bool do_sort = len <= GATHER_MAX_SORT;
+    auto crow_of = [&](int slot) __attribute__((always_inline)) {     // slot -> window (b,t) -> row b*S + t of c
+        const int bt = slot / NK, b = bt / W;
+        return b * S + (bt - b * W);
+    };
+    if (do_sort) {
+        for (int q = lane; q < len; q += 64) raw[q] = perm[beg + q];
+        __syncthreads();
+        for (int q = lane; q < len; q += 64) {
+            const int e = raw[q];
+            int rank = 0;
+            for (int v = 0; v < len; ++v) rank += raw[v] < e ? 1 : 0;      // slots are unique
+            sorted[rank] = e;
+        }
+        __syncthreads();
+        for (int q = lane; q < len; q += 64) raw[q] = crow_of(sorted[q]);
+        __syncthreads();
+    }
+    const int i = lane & 15, kq = lane >> 4;
+    f32x4 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p0 = 0; p0 < len; p0 += 16) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int p = p0 + 4 * jj + kq;
+            const bool ok = p < len;
+            const int pc = ok ? p : 0;                                   // a valid slot: its row is read and multiplied by 0
+            const int slot = do_sort ? sorted[pc] : perm[beg + pc];
+            const int crow = do_sort ? raw[pc] : crow_of(slot);
+            const float a = ok ? dS[(long)slot * 16 + i] : 0.f;          // d score[head i][slot]
+            const float* cr = c + (long)crow * kC + 4 * i;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 bv = ld4(cr + 64 * u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[u * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f4c(bv, e), acc[u * 4 + e], 0, 0, 0);
+            }
+        }
+    }
+    // C layout: head = 4kq + r, channel = 64u + 4i + e
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int head = 4 * kq + r;
+        if (head < K) {
+            float* op = G + ((long)j * K + head) * kC + 4 * i;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float4 o;
+                o.x = acc[u * 4 + 0][r]; o.y = acc[u * 4 + 1][r]; o.z = acc[u * 4 + 2][r]; o.w = acc[u * 4 + 3][r];
+                *reinterpret_cast<float4*>(op + 64 * u) = o;
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            }
+        }
+    }
+    if (amax_slots != nullptr) {
+        amax = wave_max(amax);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(amax_slots + (j & (kAmaxSlots - 1))), __float_as_uint(amax));
+    }
+}
+
+// ------------------------------------------------------------------ backward: dz, any prediction network
 // Every candidate (negative n or positive k of window (b,t)) contributes one 256-float row to
 // dz[its row of z].  Destinations are random, so instead of 32k float atomics per window the
 // contributions are first written as rows of V (slot = bt*(N+K) + candidate, plain coalesced
@@ -445,7 +452,6 @@ __global__ __launch_bounds__(256) void nce_bwd_dz_rows_kernel(
 // a row arrives in arbitrary order (nce_fill_kernel places slots with an integer atomic cursor); it is
 // rank-sorted in LDS first, so the floating-point summation order is the ascending slot order whatever
 // the fill order was: results are bit-reproducible and equal to a stable sort by destination.
-constexpr int GATHER_MAX_SORT = 1024;
 __global__ __launch_bounds__(64) void nce_gather_rows_kernel(const float* __restrict__ V,
                                                              const int* __restrict__ perm,
                                                              const int* __restrict__ row_ptr,
@@ -569,10 +575,12 @@ __global__ __launch_bounds__(256) void nce_fill_kernel(const int* __restrict__ d
 // ------------------------------------------------------------------ host side
 struct NceLayout {
     int W, BW;
-    long pred, logits, lse, bounds, U, saved_total;
+    long pred, logits, lse, bounds, saved_total;
     long rowstat, tmp, sums, fwd_total;
-    long dpred, wallT, part, gscale, V, bwd_total;
+    long dpred, wallT, part, gscale, V, dS, G, wcat, part_dz, bwd_total;
 };
+
+constexpr int kDzSplits = 4;      // K-walk splits the dz GEMM's partial buffer is sized for (SplitK)
 
 static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     if (B <= 0 || K <= 0 || K > 16 || S <= K || N <= 0 || N % 16 != 0) return false;
@@ -583,7 +591,6 @@ static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     n.logits = o; o += align64l((long)n.BW * K * (N + 1));
     n.lse = o; o += align64l((long)n.BW * K);
     n.bounds = o; o += 2 * kAmaxSlots;       // max|c|, max|wall| as 64 partial maxima each (linear heads only)
-    n.U = o; o += align64l((long)n.BW * K * kC);     // nce_fwd_kernel<true>: d loss_k / d pred_k up to gscale[k]
     n.saved_total = o;
     o = 0;
     n.rowstat = o; o += align64l((long)n.BW * 2 * K);
@@ -594,9 +601,18 @@ static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     n.dpred = o; o += align64l((long)n.BW * K * kC);
     n.wallT = o; o += (long)kC * K * kC;
     n.part = o; o += align64l(tn_gemm_part_floats(n.BW, K * kC, kC));
-    n.gscale = o; o += 128;                  // [0..15] gscale, [17..18] bounds, [32..47] the dz path's copy, [64..127] max|dPred| slots
-    n.V = o; o += align64l((long)n.BW * (N + K) * kC);
-    n.bwd_total = o;
+    n.gscale = o; o += 192;                  // [0..15] gscale, [17..18] bounds, [32..47] the V path's copy, [64..127] max|dPred| slots,
+                                             // [128..191] max|G| slots
+    // the two dz paths never run in one call: the linear heads' dS / G / Wcat / split partials share the space of the
+    // candidate-row buffer V of the foreign-prediction path
+    n.V = o;
+    const long v_floats = align64l((long)n.BW * (N + K) * kC);
+    long q = o;
+    n.dS = q; q += align64l((long)n.BW * (N + K) * 16);
+    n.G = q; q += align64l((long)B * S * K * kC);
+    n.wcat = q; q += (long)kC * K * kC;
+    n.part_dz = q; q += align64l((long)kDzSplits * B * S * kC);
+    n.bwd_total = std::max(o + v_floats, q);
     return true;
 }
 
@@ -611,12 +627,8 @@ static RowMap window_rows(const float* c, int B, int S, int W) {     // rows (b,
 static int nce_scores_forward(const NceLayout& n, const float* pred, const float* z, const int* ext, float* saved,
                               float* scratch, float* losses, float* acc, int S, int K, int N, hipStream_t st) {
     unsigned* ticket = reinterpret_cast<unsigned*>(scratch + n.sums + 32);
-    if (g_nce_fuse)
-        hipLaunchKernelGGL(nce_fwd_kernel<true>, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
-                           saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket, saved + n.U);
-    else
-        hipLaunchKernelGGL(nce_fwd_kernel<false>, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
-                           saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket, (float*)nullptr);
+    hipLaunchKernelGGL(nce_fwd_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
+                       saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket);
     CPC_LAUNCH_CHECK();
     {                                                   // 2 K <= 32 columns (nce_layout): rows_sum's groups and order of additions
         int groups = n.BW > 64 ? kRowsSumGroups : 1;
@@ -629,10 +641,11 @@ static int nce_scores_forward(const NceLayout& n, const float* pred, const float
     return 0;
 }
 
-// dz = scatter of the per-candidate gradient rows, as candidate rows V + destination-sorted gather
-static int nce_dz_path(const NceLayout& n, const float* pred, const float* saved, const float* gloss, const int* perm,
-                       const int* row_ptr, float* scratch, float* gscale_dz, float* dz, int B, int S, int K, int N,
-                       hipStream_t st, bool own_gscale) {
+// dz for predictions of any network = scatter of the per-candidate gradient rows, as candidate rows V + destination-sorted
+// gather.  Needs only saved / gloss / perm / row_ptr: with its own copy of gscale it is independent of the dPred kernel.
+static int nce_dz_rows_path(const NceLayout& n, const float* pred, const float* saved, const float* gloss, const int* perm,
+                            const int* row_ptr, float* scratch, float* gscale_dz, float* dz, int B, int S, int K, int N,
+                            hipStream_t st, bool own_gscale) {
     const float* logits = saved + n.logits, *lse = saved + n.lse;
     if (own_gscale)
         hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, gscale_dz, K, 1.0f / ((float)n.BW * (float)kC),
@@ -644,30 +657,39 @@ static int nce_dz_path(const NceLayout& n, const float* pred, const float* saved
     return 0;
 }
 
-// dPred and dz from the upstream per-head gradients.  The dz path (candidate gradient rows + destination-sorted
-// gather, ~half of the criterion's backward, HBM-bound) does not depend on dPred: it may be given its own stream
-// `st_dz` so that it runs next to whatever consumes dPred / dc (the auto-regressive network's backward, which is
-// latency-bound and leaves most of the chip idle).  Ordering across the two streams is the caller's business.
-static int nce_scores_backward(const NceLayout& n, const float* pred, const float* z, const int* ext, const int* perm,
-                               const int* row_ptr, const float* saved, const float* gloss, float* scratch,
-                               float* dpred, float* dz, int B, int S, int K, int N, hipStream_t st, hipStream_t st_dz,
-                               bool do_dz = true, const float* fwd_bounds = nullptr, float* dc_tail = nullptr) {
+// dz for the linear heads, from the dS rows nce_bwd_dpred_kernel left in scratch (and the max|wall| bound / cleared
+// max|G| slots nce_gscale_kernel left there): Wcat, the per-destination gather-GEMM G, then dz = G . Wcat^T on the
+// split-K wide tile.  Reads nothing of V's size: ~100 MB of G + 66 MB of dS at B = 64.
+static int nce_dz_linear_path(const NceLayout& n, const float* c, const float* wall, const int* perm, const int* row_ptr,
+                              float* scratch, float* dz, int B, int S, int K, int N, hipStream_t st) {
+    float* G = scratch + n.G, *wcat = scratch + n.wcat;
+    float* bnd = scratch + n.gscale;
+    const bool h2 = g_mfma_mode >= 2;
+    hipLaunchKernelGGL(nce_wcat_kernel, dim3(cdiv(K * kC, 4)), dim3(256), 0, st, wall, wcat, K);
+    hipLaunchKernelGGL(nce_bwd_g_kernel, dim3(B * S), dim3(64), 0, st, c, scratch + n.dS, perm, row_ptr, G, n.W, S, K, N + K,
+                       h2 ? bnd + 128 : (float*)nullptr);
+    CPC_LAUNCH_CHECK();
+    GemmBounds gb;
+    if (h2) { gb.a = bnd + 128; gb.a_slots = kAmaxSlots; gb.b = bnd + 18; }
+    SplitK sk;
+    sk.part = scratch + n.part_dz;
+    sk.floats = (long)kDzSplits * B * S * kC;
+    return nt_gemm(plain_rows(G, B * S, K * kC), wcat, K * kC, nullptr, dz, kC, kC, K * kC, st, 0, 0, gb, GemmGroup(), sk);
+}
+
+// dPred (and, for the linear heads, the dS rows of the re-associated dz path) from the upstream per-head gradients.
+static int nce_scores_backward(const NceLayout& n, const float* z, const int* ext, const float* saved, const float* gloss,
+                               float* scratch, float* dpred, int B, int S, int K, int N, hipStream_t st,
+                               const float* fwd_bounds = nullptr, float* dc_tail = nullptr, float* dS = nullptr) {
     const float* logits = saved + n.logits, *lse = saved + n.lse;
     float* gscale = scratch + n.gscale;
-    float* gscale_dz = st_dz == st ? gscale : gscale + 32;        // own copy: no cross-stream dependency
     const float gs = 1.0f / ((float)n.BW * (float)kC);
     hipLaunchKernelGGL(nce_gscale_kernel, dim3(dc_tail ? 1 + 128 : 1), dim3(64), 0, st, gloss, gscale, K, gs, fwd_bounds, dc_tail, B,
                        S, n.W);
-    const dim3 grid(cdiv(n.BW, 4));
-    if (g_nce_fuse)                                                // the forward left U: dPred = gscale * U
-        hipLaunchKernelGGL(nce_scale_u_kernel, dim3(std::min(cdiv((long)n.BW * K, 4), 2048)), dim3(256), 0, st, saved + n.U, gscale, dpred,
-                           (long)n.BW * K, K, fwd_bounds ? gscale + 64 : (float*)nullptr);
-    else
-        hipLaunchKernelGGL(nce_bwd_dpred_kernel, grid, dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
-                           n.W, S, K, N, fwd_bounds ? gscale + 64 : (float*)nullptr);
+    hipLaunchKernelGGL(nce_bwd_dpred_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
+                       n.W, S, K, N, fwd_bounds ? gscale + 64 : (float*)nullptr, dS);
     CPC_LAUNCH_CHECK();
-    if (!do_dz) return 0;                                          // dz path launched separately (cpc_nce_backward_dz)
-    return nce_dz_path(n, pred, saved, gloss, perm, row_ptr, scratch, gscale_dz, dz, B, S, K, N, st_dz, st_dz != st);
+    return 0;
 }
 
 // bit 1 of cpc_device_error_flags(): cpc_nce_prepare saw an out-of-range negative index
@@ -758,8 +780,10 @@ extern "C" int cpc_nce_scores_backward(const float* pred, const float* z, const 
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!pred || !z || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dpred || !dz, CPC_ERR_ARG);
-    return nce_scores_backward(n, pred, z, ext, perm, row_ptr, saved, gloss, scratch, dpred, dz, B, S, K, N,
-                               (hipStream_t)stream, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = nce_scores_backward(n, z, ext, saved, gloss, scratch, dpred, B, S, K, N, st);
+    if (rc) return rc;
+    return nce_dz_rows_path(n, pred, saved, gloss, perm, row_ptr, scratch, scratch + n.gscale, dz, B, S, K, N, st, false);
 }
 
 // gloss: K upstream gradients dL/dloss_k (device).  Outputs (overwritten): dc, dz (B,S,256), dwall (K*256,256).
@@ -770,25 +794,24 @@ extern "C" int cpc_nce_backward(const float* c, const float* z, const float* wal
                                 const int* perm, const int* row_ptr, const float* saved, const float* gloss,
                                 float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K, int N,
                                 void* stream) {
+    CPC_RETURN_IF(!dz, CPC_ERR_ARG);
     return cpc_nce_backward_streams(c, z, wall, ext, perm, row_ptr, saved, gloss, scratch, dc, dz, dwall, B, S, K, N,
                                     stream, stream);
 }
 
-// The dz path alone (linear-head criterion; pred is taken from `saved`), for callers that launch it separately.
-extern "C" int cpc_nce_backward_dz(const float* z, const int* ext, const int* perm, const int* row_ptr,
-                                   const float* saved, const float* gloss, float* scratch, float* dz, int B, int S,
-                                   int K, int N, void* stream) {
+// The dz path alone (linear heads), from the score gradients the cpc_nce_backward_streams(dz = NULL) call left in
+// `scratch`: `stream` must wait for that call.
+extern "C" int cpc_nce_backward_dz(const float* c, const float* wall, const int* perm, const int* row_ptr, float* scratch,
+                                   float* dz, int B, int S, int K, int N, void* stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
-    CPC_RETURN_IF(!z || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dz, CPC_ERR_ARG);
-    return nce_dz_path(n, saved + n.pred, saved, gloss, perm, row_ptr, scratch, scratch + n.gscale + 32, dz, B, S, K, N,
-                       (hipStream_t)stream, true);
+    CPC_RETURN_IF(!c || !wall || !perm || !row_ptr || !scratch || !dz, CPC_ERR_ARG);
+    return nce_dz_linear_path(n, c, wall, perm, row_ptr, scratch, dz, B, S, K, N, (hipStream_t)stream);
 }
 
-// As cpc_nce_backward, with the dz path (which needs only saved / gloss / perm / row_ptr and writes only dz and its own
-// part of scratch) launched on `dz_stream`; dz == NULL leaves the dz path out altogether (cpc_nce_backward_dz runs it
-// later).  No cross-stream synchronisation is done here: the caller makes dz_stream wait until gloss is ready, and
-// makes every consumer of dz wait for dz_stream.
+// As cpc_nce_backward, with the dz path launched on `dz_stream` behind an event recorded on `stream` once the score
+// gradients are written (the rest of dz_stream's ordering -- every consumer of dz waits for it -- is the caller's
+// business); dz == NULL leaves the dz path out altogether (cpc_nce_backward_dz runs it later).
 extern "C" int cpc_nce_backward_streams(const float* c, const float* z, const float* wall, const int* ext,
                                         const int* perm, const int* row_ptr, const float* saved, const float* gloss,
                                         float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K,
@@ -796,12 +819,21 @@ extern "C" int cpc_nce_backward_streams(const float* c, const float* z, const fl
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc, CPC_ERR_ARG);
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = (hipStream_t)stream, st_dz = (hipStream_t)dz_stream;
     float* dpred = scratch + n.dpred, *wallT = scratch + n.wallT;
     const bool h2 = g_mfma_mode >= 2;        // the forward left the operand bounds in `saved`
-    int rc = nce_scores_backward(n, saved + n.pred, z, ext, perm, row_ptr, saved, gloss, scratch, dpred, dz, B, S, K, N, st,
-                                 (hipStream_t)dz_stream, dz != nullptr, h2 ? saved + n.bounds : nullptr, dc);
+    int rc = nce_scores_backward(n, z, ext, saved, gloss, scratch, dpred, B, S, K, N, st, h2 ? saved + n.bounds : nullptr, dc,
+                                 scratch + n.dS);
     if (rc) return rc;
+    if (dz != nullptr) {
+        if (st_dz != st) {
+            hipEvent_t* ev = stream_events(st);
+            CPC_RETURN_IF(!ev, CPC_ERR_ARG);
+            CPC_RETURN_IF(hipEventRecord(ev[9], st) != hipSuccess || hipStreamWaitEvent(st_dz, ev[9], 0) != hipSuccess, CPC_ERR_ARG);
+        }
+        rc = nce_dz_linear_path(n, c, wall, perm, row_ptr, scratch, dz, B, S, K, N, st_dz);
+        if (rc) return rc;
+    }
     const float* bnd = scratch + n.gscale;                        // [17] max|c|, [18] max|wall|, [64..127] max|dPred| slots
     GemmBounds gdc, gdw;
     if (h2) {

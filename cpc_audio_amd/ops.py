@@ -53,7 +53,7 @@ def check_device_errors(clear=True):
         raise _lib.CpcHipError("device-side error: " + "; ".join(what))
 
 # ---- stream-level overlap inside one train step ---------------------------------------------------------------------
-# The candidate-row + sorted-gather half of the criterion's backward depends only on the upstream loss gradients, and
+# The dz half of the criterion's backward (per-destination gather-GEMM + one dense GEMM) is not on the way to dc, and
 # the network that consumes dc (the persistent GRU backward: 128 workgroups, latency-bound) leaves most of the chip
 # idle; the weight-gradient GEMMs hang off the dx chain.  A train loop that wants them on side streams owns a
 # StepContext and runs forward + backward inside ``with ctx:``.  All overlap state (streams, events, launches held back)
@@ -448,9 +448,9 @@ class InfoNCEFunction(torch.autograd.Function):
 
                 def dz_path():            # ... dz later, on the side stream, once the AR backward has been launched
                     side.wait_event(ready)
-                    lib.check(lib.cpc_nce_backward_dz(_p(z), _p(ext), _p(perm), _p(row_ptr), _p(saved), _p(gloss),
-                                                      _p(scratch), _p(dz), B, S, K, N, side.cuda_stream), "nce_backward_dz")
-                    for t in (dz, scratch, saved, gloss, perm, row_ptr, z, ext):
+                    lib.check(lib.cpc_nce_backward_dz(_p(c), _p(wall), _p(perm), _p(row_ptr), _p(scratch), _p(dz),
+                                                      B, S, K, N, side.cuda_stream), "nce_backward_dz")
+                    for t in (dz, scratch, c, wall, perm, row_ptr):
                         t.record_stream(side)                     # the allocator must not recycle them early
                     ev = torch.cuda.Event()
                     ev.record(side)
@@ -460,8 +460,8 @@ class InfoNCEFunction(torch.autograd.Function):
                 else:
                     # somebody this package does not know may read dz as soon as this backward returns (criterion mode
                     # 'reverse': a torch.flip; a foreign autoregressor): it is formed now, on this stream
-                    lib.check(lib.cpc_nce_backward_dz(_p(z), _p(ext), _p(perm), _p(row_ptr), _p(saved), _p(gloss),
-                                                      _p(scratch), _p(dz), B, S, K, N, main.cuda_stream), "nce_backward_dz")
+                    lib.check(lib.cpc_nce_backward_dz(_p(c), _p(wall), _p(perm), _p(row_ptr), _p(scratch), _p(dz),
+                                                      B, S, K, N, main.cuda_stream), "nce_backward_dz")
                     ready.record(main)         # the head gradient on the side stream reads the same scratch
                 if heads:
                     dheads = dwall

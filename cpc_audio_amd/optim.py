@@ -32,6 +32,9 @@ class Adam(torch.optim.Adam):
                 self.sync_step_state()
             self._device_step = None
             return self
+        if len(self.param_groups) != 1:
+            # one device counter, advanced once per launch: with G groups it would advance G times per step()
+            raise ValueError("device_step_counter() needs a single parameter group (the reference's optimiser has one)")
         params = [p for g in self.param_groups for p in g["params"]]
         counts = {int(self.state[p]["step"].item()) for p in params if len(self.state[p])}
         if len(counts) > 1:
@@ -58,6 +61,28 @@ class Adam(torch.optim.Adam):
     def state_dict(self):
         self.sync_step_state()
         return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        """In graph-capturable mode a captured step points at the moment tensors and at the device step count: the loaded
+        state is copied INTO them (same storage, new values) and the device count re-seeded from the loaded one."""
+        if self._device_step is None:
+            return super().load_state_dict(state_dict)
+        old = {p: (st["exp_avg"], st["exp_avg_sq"]) for p, st in self.state.items() if len(st)}
+        super().load_state_dict(state_dict)
+        counts = set()
+        with torch.no_grad():
+            for p, st in self.state.items():
+                if not len(st):
+                    continue
+                counts.add(int(torch.as_tensor(st["step"]).item()))
+                if p in old:
+                    m, v = old[p]
+                    m.copy_(st["exp_avg"])
+                    v.copy_(st["exp_avg_sq"])
+                    st["exp_avg"], st["exp_avg_sq"] = m, v
+            if len(counts) > 1:
+                raise ValueError("device_step_counter(): the loaded state has more than one step count")
+            self._device_step.fill_(float(counts.pop()) if counts else 0.0)
 
     def _step_on_device(self):
         lib = _lib.get()

@@ -46,8 +46,11 @@ class Trainer:
 
     AUTO_PROBE_STEPS = 6      # graph="auto": eager steps timed (host enqueue time vs GPU time) before deciding
 
-    def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, graph=False):
-        """graph: False (eager), True (HIP graph replay), or "auto": the first steps run eagerly and are timed; the graph is
+    def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, graph=False, check_errors_every=256):
+        """check_errors_every: every that many steps the device-side error flags are read (ops.check_device_errors: a
+        recurrence workgroup that gave up polling, a negative index out of range) and turned into an exception -- one device
+        synchronisation per that many steps; 0 leaves the check to the caller.
+        graph: False (eager), True (HIP graph replay), or "auto": the first steps run eagerly and are timed; the graph is
         used only if the host needs more than 85 % of the GPU's step time to issue a step.  (Measured on MI355X boxes: the
         replayed graph costs 0.24 ms of host time per step instead of 1.5-5 ms, but runs ~3 % longer on the GPU than the
         eagerly issued streams -- a win exactly when the host is the bottleneck.)"""
@@ -62,6 +65,10 @@ class Trainer:
         self.graph = True if graph is True else ("auto" if graph == "auto" else False)
         self._probe = []                  # graph="auto": (host seconds, start event, end event) of the first eager steps
         self._captured = None             # (key, CUDAGraph, static input, static label, static outputs)
+        self._capturing = False           # inside capture(): no host-side throttle, no completion events (see _eager_step)
+        self._done_events = []
+        self.check_errors_every = int(check_errors_every)
+        self._steps = 0
 
     def _ones_like(self, t):
         o = getattr(self, "_ones", None)
@@ -79,8 +86,11 @@ class Trainer:
     def _eager_step(self, batchData, label, negatives=None):
         # the overlap state (side streams, events, launches held back) lives on this Trainer's StepContext: two Trainers
         # on two threads / devices do not share any
-        if batchData.is_cuda:
-            done = self.__dict__.setdefault("_done_events", [])
+        # (not while a capture is being prepared or recorded: an event recorded into a capturing stream belongs to the
+        # graph and must never be synchronised with from the host)
+        throttle = batchData.is_cuda and not self._capturing
+        if throttle:
+            done = self._done_events
             if len(done) >= self.MAX_IN_FLIGHT:
                 import time
                 t0 = time.perf_counter()
@@ -99,7 +109,7 @@ class Trainer:
         self.allreduce()
         self.optimizer.step()
         self.optimizer.zero_grad()
-        if batchData.is_cuda:
+        if throttle:
             ev = torch.cuda.Event()
             ev.record()
             self._done_events.append(ev)
@@ -138,23 +148,43 @@ class Trainer:
         static_label = None if label is None else label.clone()
         side = torch.cuda.Stream(device=batchData.device)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                     # warm-up on a side stream, as torch's capture recipe asks
-            for _ in range(2):
-                self._eager_step(static_in, static_label)
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.no_grad():
-            for p, (w, m, v) in zip(params, snap):
-                p.copy_(w)
-                self.optimizer.state[p]["exp_avg"].copy_(m)
-                self.optimizer.state[p]["exp_avg_sq"].copy_(v)
-            self.optimizer._device_step.copy_(step0)
-        torch.cuda.synchronize(batchData.device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="relaxed"):
-            out = self._eager_step(static_in, static_label)
+        self._capturing = True
+        try:
+            try:
+                with torch.cuda.stream(side):                 # warm-up on a side stream, as torch's capture recipe asks
+                    for _ in range(2):
+                        self._eager_step(static_in, static_label)
+            finally:
+                # whatever the warm-up did -- completed, or raised half-way -- its updates are taken back, so that a caller
+                # who falls back to the eager step does not apply it on top of them
+                torch.cuda.current_stream().wait_stream(side)
+                with torch.no_grad():
+                    for p, (w, m, v) in zip(params, snap):
+                        p.copy_(w)
+                        self.optimizer.state[p]["exp_avg"].copy_(m)
+                        self.optimizer.state[p]["exp_avg_sq"].copy_(v)
+                    self.optimizer._device_step.copy_(step0)
+                    self.optimizer.zero_grad()
+                torch.cuda.synchronize(batchData.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="relaxed"):
+                out = self._eager_step(static_in, static_label)
+        finally:
+            self._capturing = False
+            del self._done_events[:]                          # eager steps before the capture have completed (synchronize above)
         self._captured = (self._graph_key(batchData), g, static_in, static_label, out)
 
     def step(self, batchData, label, negatives=None):
+        """One optimiser step; returns (losses (1,K), accuracies (1,K)) of this step as fresh tensors."""
+        out = self._step(batchData, label, negatives)
+        self._steps += 1
+        if self.check_errors_every > 0 and self._steps % self.check_errors_every == 0 and batchData.is_cuda:
+            from . import ops
+            with torch.cuda.device(batchData.device):
+                ops.check_device_errors()
+        return out
+
+    def _step(self, batchData, label, negatives=None):
         if self.graph == "auto":
             ok = (negatives is None and batchData.is_cuda and not self.allreduce._active() and torch.is_grad_enabled()
                   and self._graph_safe())
@@ -201,4 +231,4 @@ class Trainer:
         if static_label is not None and label is not None and label.data_ptr() != static_label.data_ptr():
             static_label.copy_(label)
         g.replay()
-        return out
+        return out[0].clone(), out[1].clone()      # the graph's static outputs are overwritten by the next replay

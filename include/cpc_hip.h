@@ -26,6 +26,10 @@ extern "C" {
 
 /* ABI version, bumped on any signature change. */
 int cpc_abi_version(void);
+/* The two-stream entry points (*_streams) keep a small pool of hipEvents per (device, caller stream), created on first use and
+ * reused for the life of the process -- right for long-lived streams.  A caller that creates and destroys streams hands each
+ * one back before destroying it (no *_streams call of this library may be in flight on it). */
+int cpc_release_stream(void* stream);
 
 /* Arithmetic of the NT GEMMs (conv forward/dgrad, projections, heads):
  *   1 bf16 matrix pipe, fp32 operands split by truncation into three bf16 pieces, six
@@ -97,11 +101,6 @@ int cpc_set_h2_dx(int on);               /* mode 3: 1 (default) keeps the gradie
 int cpc_set_gemm_split(int on);          /* 1 (default): plain GEMMs with known operand bounds (the criterion's, see cpc_nce_forward) run on two
                                             fp16 pieces in mode >= 2, wide products on the 128 x 256 pipelined tile; 0: three bf16 pieces always;
                                             2: two pieces but never the wide tile; 3: the wide tile whatever the grid size (tests) */
-int cpc_set_nce_fuse(int on);            /* 1: the forward's scoring kernel also accumulates, per head, the softmax-weighted sum of the
-                                            candidate rows it has gathered (the gradient w.r.t. the prediction up to a per-head factor,
-                                            kept in `saved`), and the backward scales it instead of gathering the rows again; 0 (default:
-                                            measured no faster): the backward recomputes it from the saved logits.
-                                            Set before a forward, keep until its backward has been issued */
 int cpc_set_dma_rotation(int step);
 int cpc_set_dma_pipeline(int variant);   /* main-loop schedule of the forward DMA kernel on 256-row tiles (tuning / measurement switch; results
                                           * agree to rounding order).  2 (default): tap-pair walk -- an input row reaches LDS once for both
@@ -302,24 +301,26 @@ int cpc_nce_forward(const float* c, const float* z, const float* wall, const int
 /* gloss: K upstream gradients dL/dloss_k.  dc, dz (B,S,256) and dwall are overwritten.
  * perm (B*W*(N+K)) / row_ptr (B*S+1): candidate slots sorted by destination row of z (slot =
  * (b*W+t)*(N+K)+j; j<N: negative j -> row ext[..j]; j>=N: positive of head j-N -> row b*S+t+j-N+1);
- * they turn the gradient scatter into an atomics-free, reproducible gather. */
+ * they turn the gradient scatter into an atomics-free, reproducible per-row reduction.  With linear heads
+ * (pred_k = W_k c) dz is re-associated through c:  dz[j] = sum_k W_k . G[j,k,:],  G[j,k,:] = sum over the slots landing
+ * on row j of dS[slot,k] * c[window(slot)]  -- a per-row gather-GEMM over 1 KB rows of c, then one dense GEMM with the
+ * stacked heads; no per-candidate gradient rows are materialised (criterion.py:108-116,199-217 backward). */
 int cpc_nce_backward(const float* c, const float* z, const float* wall, const int* ext,
                      const int* perm, const int* row_ptr, const float* saved, const float* gloss,
                      float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K, int N,
                      void* stream);
 
-/* As cpc_nce_backward with the dz path (candidate rows + sorted gather; independent of dpred / dc / dwall) launched on
- * dz_stream, so that it can run beside the auto-regressive network's backward; dz == NULL leaves the dz path out
- * (run it later with cpc_nce_backward_dz, same scratch).  No cross-stream synchronisation inside: dz_stream must
- * already wait for gloss, and every consumer of dz must wait for dz_stream. */
+/* As cpc_nce_backward with the dz path (Wcat + gather-GEMM G + dz GEMM; it depends on the score gradients this call
+ * writes first, not on dpred / dc / dwall) launched on dz_stream behind an event, so that it can run beside the
+ * auto-regressive network's backward; dz == NULL leaves the dz path out (run it later with cpc_nce_backward_dz, same
+ * scratch, on a stream that waits for this call).  Every consumer of dz must wait for dz_stream. */
 int cpc_nce_backward_streams(const float* c, const float* z, const float* wall, const int* ext,
                              const int* perm, const int* row_ptr, const float* saved, const float* gloss,
                              float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K, int N,
                              void* stream, void* dz_stream);
 
-int cpc_nce_backward_dz(const float* z, const int* ext, const int* perm, const int* row_ptr,
-                        const float* saved, const float* gloss, float* scratch, float* dz, int B, int S, int K,
-                        int N, void* stream);
+int cpc_nce_backward_dz(const float* c, const float* wall, const int* perm, const int* row_ptr, float* scratch,
+                        float* dz, int B, int S, int K, int N, void* stream);
 
 /* cpc_nce_backward_streams also accepts dwall == NULL: the head-weight gradient (criterion.py:44-50, the K
  * nn.Linear weights) is then left out and formed later by this call from the dPred kept in `scratch`; nothing on

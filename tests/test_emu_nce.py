@@ -8,20 +8,17 @@ from emu_util import P, emu, rel_err
 from oracle import cpc_oracle as O
 
 
-@pytest.mark.parametrize("B,S,K,N,scale,wide,fuse", [(2, 20, 12, 16, 1.0, 0, 1), (3, 19, 5, 32, 40.0, 0, 1), (2, 20, 12, 16, 1.0, 1, 1),
-                                                         (2, 20, 12, 16, 1.0, 0, 0), (2, 21, 7, 32, 3000.0, 0, 1), (2, 21, 7, 32, 3000.0, 0, 0)])
-def test_nce_forward_backward_emulated(B, S, K, N, scale, wide, fuse):
+@pytest.mark.parametrize("B,S,K,N,scale,wide", [(2, 20, 12, 16, 1.0, 0), (3, 19, 5, 32, 40.0, 0), (2, 20, 12, 16, 1.0, 1),
+                                                    (2, 21, 7, 32, 3000.0, 0), (1, 20, 16, 16, 1.0, 0)])
+def test_nce_forward_backward_emulated(B, S, K, N, scale, wide):
     """wide: the prediction GEMM on the 128 x 256 pipelined tile (cpc_set_gemm_split(3) forces it at test sizes).
-    fuse: 1 = the forward's scoring kernel also forms the softmax-weighted row sums the backward needs, 0 (default) = the
-    backward gathers the rows again.  scale 3000: logits hundreds apart, so the running reference of the fused kernel's softmax
-    weights has to move (its rescaling path) and the softmax is saturated."""
+    scale 3000: logits hundreds apart, the softmax is saturated (most score gradients are exactly 0)."""
     lib = emu()
-    assert lib.cpc_set_gemm_split(3 if wide else 1) == 0 and lib.cpc_set_nce_fuse(fuse) == 0
+    assert lib.cpc_set_gemm_split(3 if wide else 1) == 0
     try:
         _nce_forward_backward(lib, B, S, K, N, scale)
     finally:
         lib.cpc_set_gemm_split(1)
-        lib.cpc_set_nce_fuse(0)
 
 
 def _nce_forward_backward(lib, B, S, K, N, scale):
@@ -107,3 +104,47 @@ def test_out_of_range_negative_indices_are_clamped_and_flagged():
     assert lib.cpc_device_error_flags(0) == 0
     assert int(ext.min()) >= 0 and int(ext.max()) < B * S
     assert int(row_ptr[-1]) == B * W * (N + K)
+
+
+@pytest.mark.parametrize("B,S,K,N", [(2, 20, 12, 16), (2, 21, 7, 32)])
+def test_nce_scores_of_foreign_predictions_emulated(B, S, K, N):
+    """cpc_nce_scores_{forward,backward}: the criterion on predictions some other network made (criterion.py:82-88,
+    --rnnMode transformer).  Such predictions are not linear in c, so dz goes through the per-candidate gradient rows and the
+    destination-sorted gather rather than the re-associated path of the linear heads."""
+    lib = emu()
+    torch.manual_seed(3)
+    W = S - K
+    z = torch.relu(torch.randn(B, S, 256))
+    pred = (2.0 * torch.randn(B, W, K * 256)).requires_grad_(True)
+    zr = z.clone().requires_grad_(True)
+    g = torch.Generator().manual_seed(11)
+    bi, si = O.draw_negative_indices(B, S, W, N, generator=g)
+    ext = O.negative_rows(bi, si, B, S, W, N)                       # (B,N,W)
+    ext_t = ext.permute(0, 2, 1).contiguous().to(torch.int32)
+    # reference: criterion.py:115-116, 245-257 on the given predictions
+    neg = zr.reshape(B * S, 256)[ext.reshape(-1)].view(B, N, W, 256)
+    ref_losses = []
+    for k in range(K):
+        cand = torch.cat([zr[:, k + 1:k + 1 + W].unsqueeze(1), neg], dim=1)            # (B,1+N,W,256)
+        sc = (pred[:, :, k * 256:(k + 1) * 256].unsqueeze(1) * cand).mean(dim=3)      # (B,1+N,W)
+        sc = sc.permute(0, 2, 1).reshape(B * W, 1 + N)
+        ref_losses.append(torch.nn.functional.cross_entropy(sc, torch.zeros(B * W, dtype=torch.long)))
+    ref_losses = torch.stack(ref_losses)
+    gl = torch.randn(K)
+    (ref_losses * gl).sum().backward()
+    sizes = (ctypes.c_long * 6)()
+    assert lib.cpc_nce_layout(B, S, K, N, sizes) == 0
+    saved = torch.full((sizes[0],), float("nan"))
+    fscr = torch.full((sizes[1],), float("nan"))
+    losses = torch.full((K,), float("nan")); acc = torch.full((K,), float("nan"))
+    pd = pred.detach().contiguous()
+    assert lib.cpc_nce_scores_forward(P(pd), P(z), P(ext_t), P(saved), P(fscr), P(losses), P(acc), B, S, K, N, None) == 0
+    assert (losses - ref_losses.detach()).abs().max().item() < 1e-5
+    from cpc_audio_amd.ops import candidate_destinations
+    perm, row_ptr = candidate_destinations(ext_t, B, S, K)
+    bscr = torch.full((sizes[2],), float("nan"))
+    dpred = torch.full((B, W, K * 256), float("nan")); dz = torch.full((B, S, 256), float("nan"))
+    assert lib.cpc_nce_scores_backward(P(pd), P(z), P(ext_t), P(perm), P(row_ptr), P(saved), P(gl), P(bscr), P(dpred),
+                                       P(dz), B, S, K, N, None) == 0
+    assert rel_err(dpred, pred.grad) < 1e-5
+    assert rel_err(dz, zr.grad) < 1e-5

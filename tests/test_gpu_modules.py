@@ -77,19 +77,11 @@ def test_reverse_mode_matches_flipped_oracle():
     assert (acc.cpu() - ar_).abs().max().item() <= 2.0 / (116 * B) + 1e-7
 
 
-@pytest.mark.parametrize("K,N,L,fuse", [(5, 256, 10240, 0), (16, 64, 20480, 0), (12, 512, 20480, 0), (12, 128, 20480, 1),
-                                         (5, 256, 10240, 1)])
-def test_other_heads_negatives_and_window(K, N, L, fuse):
-    """nPredicts != 12, large-negative stress (BASELINE config 5 sweeps N in {128,256,512}) and a
-    shorter window (S = L/160).  fuse = 1: cpc_set_nce_fuse(1), the forward's scoring kernel also forms the softmax-weighted
-    row sums and the backward scales them instead of gathering the rows again."""
-    dev = _dev()
-    from cpc_audio_amd import _lib
-    assert _lib.get().cpc_set_nce_fuse(fuse) == 0
-    try:
-        _heads_negatives_window(dev, K, N, L)
-    finally:
-        _lib.get().cpc_set_nce_fuse(0)
+@pytest.mark.parametrize("K,N,L", [(5, 256, 10240), (16, 64, 20480), (12, 512, 20480)])
+def test_other_heads_negatives_and_window(K, N, L):
+    """nPredicts != 12, large-negative stress (BASELINE config 5 sweeps N in {128,256,512}: ~476 candidate slots per
+    destination row of the re-associated dz path at N = 512) and a shorter window (S = L/160)."""
+    _heads_negatives_window(_dev(), K, N, L)
 
 
 def _heads_negatives_window(dev, K, N, L):
@@ -114,6 +106,8 @@ def _heads_negatives_window(dev, K, N, L):
         name = f"wPrediction.predictors.{k_}.weight"
         assert _rel(crit.wPrediction.predictors[k_].weight.grad.cpu(), ora["grads"][name]) < 2e-4, name
     assert _rel(model.gAR.baseNet.weight_hh_l1.grad.cpu(), ora["grads"]["gAR.baseNet.weight_hh_l1"]) < 2e-4
+    # dz (criterion -> encoder) reaches the last conv layer's weight gradient directly
+    assert _rel(model.gEncoder.conv4.weight.grad.cpu(), ora["grads"]["gEncoder.conv4.weight"]) < 5e-3
 
 
 def test_trainer_step_updates_parameters_like_cpu_adam():

@@ -124,3 +124,54 @@ def test_graph_replayed_step_equals_the_eager_step():
     assert torch.equal(losses[0], losses[1]), (losses[0] - losses[1]).abs().max()
     for k in finals[0]:
         assert torch.equal(finals[0][k], finals[1][k]), k
+
+
+@pytest.mark.gpu
+def test_graph_recapture_after_lr_change_and_eager_interlude():
+    """The paths around a captured step that one capture does not exercise: a learning-rate change re-captures (the lr
+    schedule does that every epoch), a step with caller-supplied negatives runs eagerly in between (leaving capturable mode,
+    device step count -> host state) and the next plain step captures again.  The trajectory must equal the all-eager one
+    bit for bit, each capture's warm-up must leave no trace, and the host-side throttle must not have kept an event that
+    was recorded into a capture."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
+    from oracle import cpc_oracle as O
+    dev = torch.device("cuda:0")
+    B = 4
+    p = O.make_params(seed=16, head_scale=64.0)
+    plan = [(2e-4, False), (2e-4, False), (1e-4, False), (1e-4, True), (1e-4, False), (5e-5, False)]   # (lr, supplied negatives)
+    waves = [O.make_waveform(B, 20480, seed=80 + i).to(dev) for i in range(len(plan))]
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    g = torch.Generator().manual_seed(77)
+    bi, si = O.draw_negative_indices(B, 128, 116, 128, generator=g)
+    neg = (bi.to(dev), si.to(dev))
+    finals, losses = [], []
+    for graph in (False, True):
+        model, crit = build_model().to(dev), build_criterion().to(dev)
+        load_flat_params(model, crit, p)
+        model.train(); crit.train()
+        tr = Trainer(model, crit, graph=graph)
+        ls, captures = [], 0
+        for i, (lr, supplied) in enumerate(plan):
+            for grp in tr.optimizer.param_groups:
+                grp["lr"] = lr
+            if graph and not supplied and (tr._captured is None or tr._captured[0] != tr._graph_key(waves[i])):
+                tr.capture(waves[i], label)                # explicit, so that the generator can be aligned behind the warm-up
+                captures += 1
+                assert not tr._done_events                 # nothing recorded during the capture is kept for the host to wait on
+            torch.manual_seed(9000 + i)
+            l, _ = tr.step(waves[i], label, negatives=neg if supplied else None)
+            ls.append(l.clone())
+            assert (tr._captured is not None) == (graph and not supplied)
+        torch.cuda.synchronize()
+        if graph:
+            assert captures == 4                           # first use, lr 2e-4 -> 1e-4, after the eager interlude, lr -> 5e-5
+        finals.append({k: v.detach().cpu() for k, v in list(model.state_dict().items()) + list(crit.state_dict().items())})
+        losses.append(torch.stack(ls).cpu())
+        sd = tr.optimizer.state_dict()
+        assert {int(s["step"]) for s in sd["state"].values()} == {len(plan)}
+    assert torch.isfinite(losses[1]).all()
+    assert torch.equal(losses[0], losses[1]), (losses[0] - losses[1]).abs().max()
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
