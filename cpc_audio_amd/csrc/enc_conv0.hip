@@ -2,20 +2,12 @@
 //
 // Reference: cpc/model.py:83 (conv0), :50-58 (ChannelNorm), :100 (relu(norm(conv))).
 //
-// This is the one HBM-bound layer of the stack (21 MFLOP vs 4.2 MB of output per
-// 1.28 s window, ~5 FLOP/B): the waveform window of a tile is staged once in LDS
-// (coalesced contiguous read), every wave owns whole time steps so all 256
-// channels of a step live in one wavefront (4 per lane), the mean / unbiased
-// variance are wavefront-shuffle reductions, and the normalised, rectified row is
-// written exactly once as one coalesced 1 KB row of the channels-last (B, L0, C)
-// activation.  Only mean and rstd (8 B per step) are kept for the backward pass,
-// which recomputes the 10-tap conv instead of re-reading a 4 MB pre-norm tensor.
-//
-// Measured (B = 64, 276 MB per launch): 60-65 us in the step = 4.3-4.6 TB/s (a plain fill reaches 6.9 TB/s on the same box).
-// Ablation: 43 us without the activation stores -- the loop sits near the VALU issue limit (two DPP+readlane wave
-// reductions, the normalise/affine/ReLU ops, 40 FMAs per 1 KB row); shuffles (ds_bpermute) were replaced by DPP,
-// non-temporal stores are used for the streamed output.  The FMAs are scalar on purpose: issued as 20 v_pk_fma_f32 (round 1)
-// the kernel changed its results beside another train loop's 16-bit-MFMA kernels (see the kernel).
+// This is the one HBM-bound layer of the stack (21 MFLOP vs 4.2 MB of output per 1.28 s window, ~5 FLOP/B).  A wavefront
+// owns 16 whole time steps: the 10-tap contraction (+ bias) runs on exact-f32 MFMAs with the samples read straight from
+// global memory, all 256 channels of a step live in the 16 lanes of one row group (16 per lane), the mean / unbiased
+// variance are in-lane sums + one DPP row reduction, and the normalised, rectified row is written exactly once into the
+// channels-last (B, L0, C) activation.  Only mean and rstd (8 B per step) are kept for the backward pass, which recomputes
+// the 10-tap conv instead of re-reading a 4 MB pre-norm tensor.
 #include "cpc_common.h"
 #include "cpc_internal.h"
 #include "gemm_tile.h"
@@ -23,86 +15,132 @@
 namespace cpc {
 
 constexpr int K0 = 10, S0 = 5, P0 = 3;     // conv0 geometry, cpc/model.py:83
-constexpr int C0_TT = 128;                 // time steps per block (32 per wave, two at a time)
-constexpr int C0_NS = S0 * C0_TT + (K0 - S0);   // staged samples per block
+constexpr int C0_GPW = 4;                  // 16-step groups per wave
+constexpr int C0_TT = 4 * 16 * C0_GPW;     // time steps per block of four waves
 
+// The 16 bytes lane `slot & 63`-style stores of an H2 row, for a lane that holds channels 4 * slot .. 4 * slot + 3 of the row
+// (slot = 0..63, any mapping of lanes to slots in which lane parity == slot parity and lane ^ 1 holds slot ^ 1): neighbouring
+// lanes swap halves so that the even slot owns the 8 h pieces of its 8-channel group and the odd slot the 8 l pieces, and each
+// lane stores 16 contiguous bytes at row + 16 * slot (h2_store_row_nt is the case slot == lane).
+__device__ __forceinline__ void h2_store_slot_nt(void* row, int slot, float v0, float v1, float v2, float v3, float s, bool live) {
+    _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
+    h2_split(v0, s, h0, l0); h2_split(v1, s, h1, l1); h2_split(v2, s, h2, l2); h2_split(v3, s, h3, l3);
+    const unsigned hw0 = __builtin_bit_cast(unsigned, f16x2{h0, h1}), hw1 = __builtin_bit_cast(unsigned, f16x2{h2, h3});
+    const unsigned lw0 = __builtin_bit_cast(unsigned, f16x2{l0, l1}), lw1 = __builtin_bit_cast(unsigned, f16x2{l2, l3});
+    const bool odd = slot & 1;
+    const unsigned r0 = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, odd ? hw0 : lw0)));
+    const unsigned r1 = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, odd ? hw1 : lw1)));
+    f32x4 o;
+    o.x = __builtin_bit_cast(float, odd ? r0 : hw0);
+    o.y = __builtin_bit_cast(float, odd ? r1 : hw1);
+    o.z = __builtin_bit_cast(float, odd ? lw0 : r0);
+    o.w = __builtin_bit_cast(float, odd ? lw1 : r1);
+    if (live) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(row) + 16 * slot));
+}
+
+// One wavefront computes 16 time steps x 256 channels at a time on the matrix pipe: per 16 x 16 output tile three
+// v_mfma_f32_16x16x4_f32 (exact fp32 products and sums) contract the 10 taps, the bias (tap 10, against a sample of 1) and a
+// zero pad:  A[16 steps x 4] = waveform samples s[5 t - 3 + j] read straight from global memory (a group's 16 windows are 85
+// consecutive floats), B[4 x 16 channels] = conv0.weight / bias, held in 48 registers for the whole kernel.  Tile T of a
+// lane (column n = lane & 15) is channel 64 (T >> 2) + 4 n + (T & 3), so a lane ends up with four runs of four consecutive
+// channels for each of its four time steps 4 (lane >> 4) + r: ChannelNorm's sums over the 256 channels of a step are 16
+// in-lane additions and one DPP row reduction over the 16 lanes of a row group (no cross-row traffic, no LDS at all), and a
+// store instruction writes 256 contiguous bytes of each of four rows.  The VALU only normalises, rectifies and encodes --
+// the scalar-FMA version of this kernel sat at the VALU issue limit (~105 VALU per 1 KB row, 60-65 us at B = 64 against 44 us
+// of HBM time) -- and no LDS-read operand feeds packed fp32 arithmetic any more (the co-residency hazard of DESIGN.md 4.6).
 // YK: storage of y -- 0 fp32, 1 H2 (two fp16 pieces scaled by scale_for_amax(*y_amax), cpc_common.h), 2 bf16
 template <int YK>
-__global__ __launch_bounds__(256) void conv0_fwd_kernel(
+__global__ __launch_bounds__(256, 3) void conv0_fwd_kernel(
     const float* __restrict__ wave, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, int L, int L0, const float* __restrict__ y_amax) {
-    __shared__ float smp[C0_NS];
-    __shared__ float wT[K0][kC];                 // conv0.weight transposed: coalesced global read, float4 LDS reads
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * C0_TT;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = lane & 15, kq = lane >> 4;
     const float* wb = wave + (long)b * L;
-    const int s_begin = t0 * S0 - P0;
-    for (int i = tid; i < C0_NS; i += 256) {
-        int s = s_begin + i;
-        smp[i] = ((unsigned)s < (unsigned)L) ? wb[s] : 0.f;
+    // B operands: wt[T][kk] = tap 4 kk + kq of channel ch(T) (taps 10 / 11: bias / 0)
+    float wt[16][3];
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+        const int ch = 64 * (T >> 2) + 4 * n + (T & 3);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const int j = 4 * kk + kq;
+            wt[T][kk] = j < K0 ? w[ch * K0 + j] : (j == K0 ? bias[ch] : 0.f);
+        }
     }
-    for (int e = tid; e < kC * K0; e += 256) wT[e % K0][e / K0] = w[e];
-    __syncthreads();
-    // Scalar fp32 arithmetic on purpose (and -fno-slp-vectorize for this file, build.py): with the 40 FMAs of a time step issued
-    // as 20 v_pk_fma_f32 whose broadcast operand is an LDS-read sample, this kernel -- like conv0_bwd_kernel before it --
-    // returned different bits whenever a 16-bit-MFMA GEMM kernel shared the chip with it (tests/test_gpu_corun.py; inside one
-    // train step nothing runs beside it, two train loops on one device do).  1/sqrt is the single v_rsq_f32.
-    float4 wj[K0];
-    const int c = lane * 4;
-#pragma unroll
-    for (int j = 0; j < K0; ++j) wj[j] = *reinterpret_cast<const float4*>(&wT[j][c]);
-    const float4 b4 = *reinterpret_cast<const float4*>(bias + c);
-    const float4 g4 = *reinterpret_cast<const float4*>(nw + c);
-    const float4 n4 = *reinterpret_cast<const float4*>(nb + c);
     const float sy = YK == 1 ? scale_for_amax(*y_amax) : 1.0f;
-    auto finish = [&](const float4& x, float mu, float rs, long row) __attribute__((always_inline)) {
-        float4 o;
-        o.x = fmaxf(fmaf((x.x - mu) * rs, g4.x, n4.x), 0.f);
-        o.y = fmaxf(fmaf((x.y - mu) * rs, g4.y, n4.y), 0.f);
-        o.z = fmaxf(fmaf((x.z - mu) * rs, g4.z, n4.z), 0.f);
-        o.w = fmaxf(fmaf((x.w - mu) * rs, g4.w, n4.w), 0.f);
-        if constexpr (YK == 1) {
-            h2_store_row_nt(y + row * kC, o.x, o.y, o.z, o.w, sy);
-        } else if constexpr (YK == 2) {
-            const unsigned long long w2 = (unsigned long long)(bf16_rne(o.x) | ((unsigned)bf16_rne(o.y) << 16)) |
-                                          ((unsigned long long)(bf16_rne(o.z) | ((unsigned)bf16_rne(o.w) << 16)) << 32);
-            __builtin_nontemporal_store(w2, reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(y) + row * kC + c));
-        } else {
-            float* yo = y + row * kC + c;       // streamed once, 268 MB per launch at B = 64 (>> L2): non-temporal
-            __builtin_nontemporal_store(o.x, yo);
-            __builtin_nontemporal_store(o.y, yo + 1);
-            __builtin_nontemporal_store(o.z, yo + 2);
-            __builtin_nontemporal_store(o.w, yo + 3);
-        }
-        if (lane == 0) { mean_out[row] = mu; rstd_out[row] = rs; }
-    };
-    auto sq4 = [](const float4& x, float mu) __attribute__((always_inline)) {
-        const float a = x.x - mu, b_ = x.y - mu, c_ = x.z - mu, d = x.w - mu;
-        return fmaf(a, a, c_ * c_) + fmaf(b_, b_, d * d);
-    };
-    // two time steps per iteration: their reduction chains are independent and interleave
-    for (int tt = wv; tt < C0_TT; tt += 8) {
-        const int ta = t0 + tt, tb = ta + 4;
-        if (ta >= L0) break;                     // wave-uniform
-        const bool has_b = tb < L0;              // wave-uniform
-        float4 xa = b4, xb = b4;
+    // A operands of a group: step tg + n, tap 4 kk + kq (the next group's are requested before this one's arithmetic starts)
+    auto samples = [&](int tg, float (&a)[3]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < K0; ++j) {
-            const float sa = smp[tt * S0 + j], sb = smp[(tt + 4) * S0 + j];
-            xa.x = fmaf(wj[j].x, sa, xa.x); xa.y = fmaf(wj[j].y, sa, xa.y);
-            xa.z = fmaf(wj[j].z, sa, xa.z); xa.w = fmaf(wj[j].w, sa, xa.w);
-            xb.x = fmaf(wj[j].x, sb, xb.x); xb.y = fmaf(wj[j].y, sb, xb.y);
-            xb.z = fmaf(wj[j].z, sb, xb.z); xb.w = fmaf(wj[j].w, sb, xb.w);
+        for (int kk = 0; kk < 3; ++kk) {
+            const int j = 4 * kk + kq;
+            const int s = (tg + n) * S0 - P0 + j;
+            a[kk] = j < K0 ? (((unsigned)s < (unsigned)L) ? wb[s] : 0.f) : (j == K0 ? 1.0f : 0.f);
         }
-        const float mua = wave_sum((xa.x + xa.z) + (xa.y + xa.w)) * (1.0f / kC);
-        const float mub = wave_sum((xb.x + xb.z) + (xb.y + xb.w)) * (1.0f / kC);
-        const float va = wave_sum(sq4(xa, mua)), vb = wave_sum(sq4(xb, mub));
-        const float rsa = __builtin_amdgcn_rsqf(va * (1.0f / (kC - 1)) + kNormEps);
-        const float rsb = __builtin_amdgcn_rsqf(vb * (1.0f / (kC - 1)) + kNormEps);
-        finish(xa, mua, rsa, (long)b * L0 + ta);
-        if (has_b) finish(xb, mub, rsb, (long)b * L0 + tb);
+    };
+    const int tg0 = blockIdx.x * C0_TT + wv * C0_GPW * 16;
+    float a[3];
+    for (int gi = 0; gi < C0_GPW; ++gi) {
+        const int tg = tg0 + gi * 16;                                    // first step of the group
+        if (tg >= L0) break;                                             // wave-uniform
+        samples(tg, a);
+        f32x4 x[16];
+#pragma unroll
+        for (int T = 0; T < 16; ++T) {
+            x[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) x[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wt[T][kk], x[T], 0, 0, 0);
+        }
+        // x[T][r]: step tg + 4 kq + r, channel ch(T).  Mean / unbiased variance over the 256 channels of a step.
+        float mu[4], rs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s0 = (x[0][r] + x[1][r]) + (x[2][r] + x[3][r]), s1 = (x[4][r] + x[5][r]) + (x[6][r] + x[7][r]);
+            float s2 = (x[8][r] + x[9][r]) + (x[10][r] + x[11][r]), s3 = (x[12][r] + x[13][r]) + (x[14][r] + x[15][r]);
+            mu[r] = row16_sum((s0 + s1) + (s2 + s3)) * (1.0f / kC);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int T = 0; T < 16; T += 2) {
+                x[T][r] -= mu[r];
+                x[T + 1][r] -= mu[r];
+                v0 = fmaf(x[T][r], x[T][r], v0);
+                v1 = fmaf(x[T + 1][r], x[T + 1][r], v1);
+            }
+            rs[r] = __builtin_amdgcn_rsqf(row16_sum(v0 + v1) * (1.0f / (kC - 1)) + kNormEps);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = tg + 4 * kq + r;
+            const bool live = t < L0;
+            const long row = (long)b * L0 + (live ? t : tg);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // the affine of channels 64 q + 4 n ..: 2 KB in all, re-read from L1 per use rather than held in 32 registers
+                const float4 g4 = *reinterpret_cast<const float4*>(nw + 64 * q + 4 * n);
+                const float4 n4 = *reinterpret_cast<const float4*>(nb + 64 * q + 4 * n);
+                const float gam[4] = {g4.x, g4.y, g4.z, g4.w}, bet[4] = {n4.x, n4.y, n4.z, n4.w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaf(x[4 * q + e][r] * rs[r], gam[e], bet[e]), 0.f);
+                if constexpr (YK == 1) {
+                    h2_store_slot_nt(y + row * kC, 16 * q + n, o[0], o[1], o[2], o[3], sy, live);
+                } else if constexpr (YK == 2) {
+                    const unsigned long long w2 = (unsigned long long)(bf16_rne(o[0]) | ((unsigned)bf16_rne(o[1]) << 16)) |
+                                                  ((unsigned long long)(bf16_rne(o[2]) | ((unsigned)bf16_rne(o[3]) << 16)) << 32);
+                    if (live)
+                        __builtin_nontemporal_store(w2, reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(y) +
+                                                                                              row * kC + 64 * q + 4 * n));
+                } else {
+                    if (live)      // streamed once, 268 MB per launch at B = 64 (>> L2): non-temporal
+                        __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(y + row * kC + 64 * q + 4 * n));
+                }
+            }
+            if (n == 0 && live) { mean_out[row] = mu[r]; rstd_out[row] = rs[r]; }
+        }
     }
 }
 

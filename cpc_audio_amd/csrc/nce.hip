@@ -215,17 +215,23 @@ __global__ __launch_bounds__(64) void nce_gscale_kernel(const float* __restrict_
 // ------------------------------------------------------------------ backward: dPred
 // dS (optional): the score gradients themselves, one 64-byte row of 16 heads per candidate slot bt * (N + K) + j
 // (j < N: negative j, all K heads; j >= N: positive of head j - N, the other heads 0) -- what the re-associated dz path
-// (nce_bwd_g_kernel) contracts with the rows of c.
+// (nce_bwd_g_kernel) contracts with the rows of c.  A lane of the loop below holds ONE head's gradient for four candidates,
+// a dS row is 16 heads of one candidate: each 16-candidate tile is transposed through a per-wave 1 KB LDS tile and leaves as
+// one contiguous 1 KB store per wave (written lane by lane in 4-byte pieces the same 66 MB cost the kernel 56 us at B = 64).
+constexpr int kDsTile = 256 + 48;       // 16 candidates x 16 heads; the four lane groups' rows start 16 floats further apart
+                                        // each, so that a transposing write hits every LDS bank exactly twice
 __global__ __launch_bounds__(256) void nce_bwd_dpred_kernel(
     const float* __restrict__ z, const int* __restrict__ ext, const float* __restrict__ logits,
     const float* __restrict__ lse, const float* __restrict__ gscale, float* __restrict__ dpred, int BW,
     int W, int S, int K, int N, float* __restrict__ amax_slots, float* __restrict__ dS) {
+    __shared__ float ds_tile[4][kDsTile];
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bt >= BW) return;
     const int b = bt / W, t = bt - b * W;
     float amax = 0.f;
     const int i = lane & 15, kq = lane >> 4;
+    float* tile = ds_tile[threadIdx.x >> 6];
     const bool hv = i < K;
     const float gs = hv ? gscale[i] : 0.f;
     const float ls = hv ? lse[(long)bt * K + i] : 0.f;
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(256) void nce_bwd_dpred_kernel(
         for (int jj = 0; jj < 4; ++jj) {
             const float a = hv ? gs * expf(lp[16 * ii + jj] - ls) : 0.f;   // d score[head i][n]
             const int row = ep[16 * ii + jj];                            // n = 16 ii + 4 kq + jj
-            if (dS != nullptr) dS[((long)bt * (N + K) + 16 * ii + 4 * kq + jj) * 16 + i] = a;
+            if (dS != nullptr) tile[(4 * kq + jj) * 16 + 16 * kq + i] = a;
             const float* zr = z + (long)row * kC + 4 * i;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -248,6 +254,13 @@ __global__ __launch_bounds__(256) void nce_bwd_dpred_kernel(
                 for (int e = 0; e < 4; ++e)
                     acc[u * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f4c(bv, e), acc[u * 4 + e], 0, 0, 0);
             }
+        }
+        if (dS != nullptr) {            // (wave-uniform) lane l leaves with heads 4 (l & 3).. of candidate 16 ii + (l >> 2)
+            __builtin_amdgcn_wave_barrier();
+            const int nl = lane >> 2;
+            const float4 v = *reinterpret_cast<const float4*>(tile + nl * 16 + 16 * (nl >> 2) + 4 * (lane & 3));
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<float4*>(dS + ((long)bt * (N + K) + 16 * ii) * 16 + 4 * lane) = v;
         }
     }
     // C layout: head = 4kq + r, channel = 64u + 4i + e

@@ -20,6 +20,13 @@ import torch
 import torch.distributed as dist
 
 
+class _Done:
+    """Work handle of a collective that has already completed (the host-staged path)."""
+
+    def wait(self):
+        return True
+
+
 class FlatGradAllReduce:
     """Flattens the gradients of ``params`` into one persistent buffer and all-reduces it (SUM).
     ``early``: the subset of ``params`` whose gradients are complete when ``begin()`` is called."""
@@ -36,11 +43,23 @@ class FlatGradAllReduce:
         self.buf = None
         self.views = None
         self._pending = None                                  # work handle of the early bucket
+        self._pending_event = None
         self.single_rank_too = False                          # tests: run the collectives in a 1-rank group as well
 
     def _active(self):
         return (dist.is_available() and dist.is_initialized()
                 and (dist.get_world_size(self.group) > 1 or self.single_rank_too))
+
+    def _reduce(self, t, async_op=False):
+        """SUM all-reduce of ``t`` in place.  RCCL cannot put two ranks on one device and a gloo-only cluster has no device
+        collectives: a GPU tensor in a gloo group is staged through the host (synchronously -- the copy waits for the
+        current stream); the buckets, their order and what waits for what stay as on the RCCL path."""
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return _Done() if async_op else None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def _views(self, params):
         ref = self.params[0]
@@ -81,14 +100,18 @@ class FlatGradAllReduce:
             with torch.cuda.stream(side):
                 self._pack(self.early)
                 bucket = self.buf[:self.n_early]
-                self._pending = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._pending = self._reduce(bucket, async_op=True)
+                done = torch.cuda.Event()
+                done.record(side)
+            self._pending_event = done                       # what the current stream waits for in __call__ (host-staged path)
             for p in self.early:
                 if p.grad is not None:
                     p.grad.record_stream(side)
         else:
             self._pack(self.early)
             bucket = self.buf[:self.n_early]
-            self._pending = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending = self._reduce(bucket, async_op=True)
+            self._pending_event = None
 
     def abort(self):
         """A step raised after begin(): let the early bucket's collective finish (every rank issued it; dropping the
@@ -105,12 +128,14 @@ class FlatGradAllReduce:
             return
         if self._pending is None:                             # begin() was not called: one collective
             self._pack(self.params)
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+            self._reduce(self.buf)
         else:
             if self.late:
                 self._pack(self.late)
-                dist.all_reduce(self.buf[self.n_early:], op=dist.ReduceOp.SUM, group=self.group)
+                self._reduce(self.buf[self.n_early:])
             self._pending.wait()                              # current stream waits for the early bucket
+            if self._pending_event is not None:
+                torch.cuda.current_stream().wait_event(self._pending_event)
             self._pending = None
         views = self._views(self.params)
         have = [(p.grad, v) for p, v in zip(self.params, views) if p.grad is not None]

@@ -32,6 +32,10 @@ class Adam(torch.optim.Adam):
                 self.sync_step_state()
             self._device_step = None
             return self
+        if self._device_step is not None:
+            # already on: the host-side copies of the count are stale (they are only refreshed on demand) -- bring them up to
+            # date before the count is re-seeded from them (a re-capture after a learning-rate change comes through here)
+            self.sync_step_state()
         if len(self.param_groups) != 1:
             # one device counter, advanced once per launch: with G groups it would advance G times per step()
             raise ValueError("device_step_counter() needs a single parameter group (the reference's optimiser has one)")

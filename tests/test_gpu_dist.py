@@ -56,3 +56,109 @@ def test_two_bucket_allreduce_on_side_stream_single_rank():
             assert torch.equal(finals[0][k], finals[1][k]), k
     finally:
         dist.destroy_process_group()
+
+
+# ---- world_size 2: the REAL train step on two ranks ------------------------------------------------------------------
+_WS2_B, _WS2_STEPS = 4, 2
+
+
+def _ws2_inputs(rank):
+    """Rank ``rank``'s half of the global batch: its own sequences and its own negatives, drawn inside the half
+    (criterion.py:176-184 runs per replica: batchIdx in [0, B_local))."""
+    waves = [O.make_waveform(_WS2_B, 20480, seed=300 + 10 * i + rank) for i in range(_WS2_STEPS)]
+    g = torch.Generator().manual_seed(500 + rank)
+    draws = [O.draw_negative_indices(_WS2_B, 128, 116, 128, generator=g) for _ in range(_WS2_STEPS)]
+    return waves, draws
+
+
+def _ws2_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    # both ranks on the box's one GPU: RCCL refuses two ranks on one device, so the group is gloo and FlatGradAllReduce stages
+    # its two buckets through the host -- same buckets, same order, same stream dependencies as over RCCL
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
+        dev = torch.device("cuda:0")
+        model, crit = build_model().to(dev), build_criterion().to(dev)
+        load_flat_params(model, crit, O.make_params(seed=21, head_scale=64.0))
+        model.train(); crit.train()
+        tr = Trainer(model, crit)
+        assert tr.allreduce._active() and tr.allreduce.early and tr.allreduce.late
+        waves, draws = _ws2_inputs(rank)
+        label = torch.zeros(_WS2_B, dtype=torch.long, device=dev)
+        losses = []
+        for wave, (bi, si) in zip(waves, draws):
+            l, _ = tr.step(wave.to(dev), label, negatives=(bi.to(dev), si.to(dev)))
+            losses.append(l.cpu())
+        torch.cuda.synchronize()
+        state = {k: v.detach().cpu() for k, v in list(model.state_dict().items()) + list(crit.state_dict().items())}
+        torch.save({"state": state, "losses": torch.stack(losses)}, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_real_step_equals_one_rank_on_the_summed_gradients(tmp_path):
+    """cpc/train.py:83-87,372-375: every replica runs the step on its own sub-batch with negatives from that sub-batch, the
+    per-replica losses are SUMMED and one optimiser step follows.  Two processes (one per rank) run Trainer.step on their
+    halves with the two-bucket all-reduce live -- early bucket packed on the side stream from the encoder-backward hook,
+    behind the head gradient and the recurrence's weight-gradient stream; late bucket after backward -- for two steps.
+    Required: (a) both ranks end with bit-identical parameters; (b) they equal, bit for bit, ONE rank that forms g(half 0)
+    and g(half 1) in two backward passes, adds them and takes the same Adam steps (a SUM over two ranks is one fp32
+    addition per value); (c) the summed gradient of step 0 and each half's losses match the CPU oracle."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    import torch.multiprocessing as mp
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
+    world = 2
+    mp.spawn(_ws2_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
+    for k in got[0]["state"]:                                                              # (a)
+        assert torch.equal(got[0]["state"][k], got[1]["state"][k]), k
+    # (b) one rank, two backward passes per step
+    dev = torch.device("cuda:0")
+    p = O.make_params(seed=21, head_scale=64.0)
+    model, crit = build_model().to(dev), build_criterion().to(dev)
+    load_flat_params(model, crit, p)
+    model.train(); crit.train()
+    tr = Trainer(model, crit)
+    params = [q for grp in tr.optimizer.param_groups for q in grp["params"]]
+    real_step, real_zero = tr.optimizer.step, tr.optimizer.zero_grad
+    inputs = [_ws2_inputs(r) for r in range(world)]
+    label = torch.zeros(_WS2_B, dtype=torch.long, device=dev)
+    named = dict(model.state_dict(keep_vars=True))
+    named.update(crit.state_dict(keep_vars=True))
+    for i in range(_WS2_STEPS):
+        halves = []
+        for r in range(world):
+            tr.optimizer.step, tr.optimizer.zero_grad = (lambda *a, **k: None), (lambda *a, **k: None)
+            for q in params:
+                q.grad = None
+            bi, si = inputs[r][1][i]
+            l, _ = tr.step(inputs[r][0][i].to(dev), label, negatives=(bi.to(dev), si.to(dev)))
+            torch.cuda.synchronize()
+            assert torch.equal(l.cpu(), got[r]["losses"][i]), (i, r)       # same parameters, same half: same losses, bit for bit
+            halves.append([q.grad.clone() for q in params])
+        if i == 0:                                                                         # (c)
+            for r in range(world):
+                ora = O.train_step(p, inputs[r][0][0], *inputs[r][1][0])
+                assert (got[r]["losses"][0] - ora["losses"]).abs().max().item() < 1e-4
+                halves_ora = ora["grads"] if r == 0 else {k: halves_ora[k] + ora["grads"][k] for k in halves_ora}
+            summed = {id(q): a + b for q, a, b in zip(params, *halves)}
+            for k in ("gAR.baseNet.weight_hh_l0", "gAR.baseNet.bias_ih_l1", "wPrediction.predictors.3.weight",
+                      "gEncoder.conv4.weight", "gEncoder.conv2.weight"):
+                mine, ref = summed[id(named[k])].cpu(), halves_ora[k]
+                rel = ((mine - ref).norm() / ref.norm()).item()
+                assert rel < (5e-3 if "conv2" in k else 2e-4), (k, rel)     # conv2: a ReLU tie may flip a row (DESIGN.md 2)
+        for q, a, b in zip(params, *halves):
+            q.grad = a + b
+        tr.optimizer.step, tr.optimizer.zero_grad = real_step, real_zero
+        tr.optimizer.step()
+        tr.optimizer.zero_grad()
+    torch.cuda.synchronize()
+    mine = {k: v.detach().cpu() for k, v in list(model.state_dict().items()) + list(crit.state_dict().items())}
+    moved = 0
+    for k in mine:
+        assert torch.equal(mine[k], got[0]["state"][k]), k
+        moved += int(not torch.equal(mine[k], p[k]))
+    assert moved == len(mine)                                 # every tensor took the optimiser steps
