@@ -15,8 +15,9 @@
 namespace cpc {
 
 constexpr int K0 = 10, S0 = 5, P0 = 3;     // conv0 geometry, cpc/model.py:83
-constexpr int C0_GPW = 4;                  // 16-step groups per wave
-constexpr int C0_TT = 4 * 16 * C0_GPW;     // time steps per block of four waves
+// 16-step groups per wave (cpc_set_conv0_groups; a block of four waves covers 64 * groups steps): more amortise the 50
+// operand loads of a wave's prologue, fewer leave a shorter tail when the grid is not a multiple of the resident waves
+static int g_conv0_gpw = 4;
 
 // The 16 bytes lane `slot & 63`-style stores of an H2 row, for a lane that holds channels 4 * slot .. 4 * slot + 3 of the row
 // (slot = 0..63, any mapping of lanes to slots in which lane parity == slot parity and lane ^ 1 holds slot ^ 1): neighbouring
@@ -53,7 +54,11 @@ template <int YK>
 __global__ __launch_bounds__(256, 3) void conv0_fwd_kernel(
     const float* __restrict__ wave, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
-    float* __restrict__ mean_out, float* __restrict__ rstd_out, int L, int L0, const float* __restrict__ y_amax) {
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, int L, int L0, const float* __restrict__ y_amax, int gpw) {
+    __shared__ float aff[2][kC];                 // ChannelNorm weight / bias: 2 KB, re-read per use (ds_read_b128) instead of
+    aff[0][threadIdx.x] = nw[threadIdx.x];       // living in 32 registers
+    aff[1][threadIdx.x] = nb[threadIdx.x];
+    __syncthreads();
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n = lane & 15, kq = lane >> 4;
@@ -63,10 +68,14 @@ __global__ __launch_bounds__(256, 3) void conv0_fwd_kernel(
 #pragma unroll
     for (int T = 0; T < 16; ++T) {
         const int ch = 64 * (T >> 2) + 4 * n + (T & 3);
+        // every load unconditional (clamped index + select): a predicated load is a branch and a full vmcnt(0) each, and 16 of
+        // them in a row made this prologue longer than the wave's arithmetic
+        const float bv = bias[ch];
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
             const int j = 4 * kk + kq;
-            wt[T][kk] = j < K0 ? w[ch * K0 + j] : (j == K0 ? bias[ch] : 0.f);
+            const float wv = w[ch * K0 + (j < K0 ? j : K0 - 1)];
+            wt[T][kk] = kk < 2 ? wv : (j < K0 ? wv : (j == K0 ? bv : 0.f));
         }
     }
     const float sy = YK == 1 ? scale_for_amax(*y_amax) : 1.0f;
@@ -76,15 +85,19 @@ __global__ __launch_bounds__(256, 3) void conv0_fwd_kernel(
         for (int kk = 0; kk < 3; ++kk) {
             const int j = 4 * kk + kq;
             const int s = (tg + n) * S0 - P0 + j;
-            a[kk] = j < K0 ? (((unsigned)s < (unsigned)L) ? wb[s] : 0.f) : (j == K0 ? 1.0f : 0.f);
+            const float v = wb[s < 0 ? 0 : (s < L ? s : L - 1)];         // unconditional load, then select
+            a[kk] = j < K0 ? (((unsigned)s < (unsigned)L) ? v : 0.f) : (j == K0 ? 1.0f : 0.f);
         }
     };
-    const int tg0 = blockIdx.x * C0_TT + wv * C0_GPW * 16;
-    float a[3];
-    for (int gi = 0; gi < C0_GPW; ++gi) {
+    const int tg0 = (blockIdx.x * 4 + wv) * gpw * 16;
+    float a[3], an[3];
+    samples(tg0, an);
+    for (int gi = 0; gi < gpw; ++gi) {
         const int tg = tg0 + gi * 16;                                    // first step of the group
         if (tg >= L0) break;                                             // wave-uniform
-        samples(tg, a);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) a[kk] = an[kk];
+        if (gi + 1 < gpw) samples(tg + 16, an);                       // requested before this group's arithmetic starts
         f32x4 x[16];
 #pragma unroll
         for (int T = 0; T < 16; ++T) {
@@ -119,9 +132,8 @@ __global__ __launch_bounds__(256, 3) void conv0_fwd_kernel(
             const long row = (long)b * L0 + (live ? t : tg);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                // the affine of channels 64 q + 4 n ..: 2 KB in all, re-read from L1 per use rather than held in 32 registers
-                const float4 g4 = *reinterpret_cast<const float4*>(nw + 64 * q + 4 * n);
-                const float4 n4 = *reinterpret_cast<const float4*>(nb + 64 * q + 4 * n);
+                const float4 g4 = *reinterpret_cast<const float4*>(&aff[0][64 * q + 4 * n]);
+                const float4 n4 = *reinterpret_cast<const float4*>(&aff[1][64 * q + 4 * n]);
                 const float gam[4] = {g4.x, g4.y, g4.z, g4.w}, bet[4] = {n4.x, n4.y, n4.z, n4.w};
                 float o[4];
 #pragma unroll
@@ -401,6 +413,12 @@ int rows_sum_multi(const RowsSumJob* jobs, int njobs, hipStream_t stream) {
 
 using namespace cpc;
 
+extern "C" int cpc_set_conv0_groups(int groups) {
+    CPC_RETURN_IF(groups < 1 || groups > 64, CPC_ERR_ARG);
+    cpc::g_conv0_gpw = groups;
+    return 0;
+}
+
 extern "C" int cpc_conv0_forward(const float* wave, const float* w, const float* bias,
                                  const float* nw, const float* nb, float* y, float* mean,
                                  float* rstd, int B, int L, void* stream) {
@@ -415,11 +433,11 @@ extern "C" int cpc_conv0_forward_h2(const float* wave, const float* w, const flo
     CPC_RETURN_IF(B <= 0 || L < K0 - 2 * P0, CPC_ERR_SHAPE);
     const int L0 = conv_out_len(L, K0, S0, P0);
     if (y_amax)
-        hipLaunchKernelGGL(conv0_fwd_kernel<1>, dim3(cdiv(L0, C0_TT), B), dim3(256), 0, (hipStream_t)stream,
-                           wave, w, bias, nw, nb, reinterpret_cast<float*>(y), mean, rstd, L, L0, y_amax);
+        hipLaunchKernelGGL(conv0_fwd_kernel<1>, dim3(cdiv(L0, 64 * g_conv0_gpw), B), dim3(256), 0, (hipStream_t)stream,
+                           wave, w, bias, nw, nb, reinterpret_cast<float*>(y), mean, rstd, L, L0, y_amax, g_conv0_gpw);
     else
-        hipLaunchKernelGGL(conv0_fwd_kernel<0>, dim3(cdiv(L0, C0_TT), B), dim3(256), 0, (hipStream_t)stream,
-                           wave, w, bias, nw, nb, reinterpret_cast<float*>(y), mean, rstd, L, L0, y_amax);
+        hipLaunchKernelGGL(conv0_fwd_kernel<0>, dim3(cdiv(L0, 64 * g_conv0_gpw), B), dim3(256), 0, (hipStream_t)stream,
+                           wave, w, bias, nw, nb, reinterpret_cast<float*>(y), mean, rstd, L, L0, y_amax, g_conv0_gpw);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -430,8 +448,8 @@ int conv0_forward_bf16(const float* wave, const float* w, const float* bias, con
                        float* mean, float* rstd, int B, int L, hipStream_t st) {
     CPC_RETURN_IF(B <= 0 || L < K0 - 2 * P0, CPC_ERR_SHAPE);
     const int L0 = conv_out_len(L, K0, S0, P0);
-    hipLaunchKernelGGL(conv0_fwd_kernel<2>, dim3(cdiv(L0, C0_TT), B), dim3(256), 0, st, wave, w, bias, nw, nb,
-                       reinterpret_cast<float*>(y), mean, rstd, L, L0, (const float*)nullptr);
+    hipLaunchKernelGGL(conv0_fwd_kernel<2>, dim3(cdiv(L0, 64 * g_conv0_gpw), B), dim3(256), 0, st, wave, w, bias, nw, nb,
+                       reinterpret_cast<float*>(y), mean, rstd, L, L0, (const float*)nullptr, g_conv0_gpw);
     CPC_LAUNCH_CHECK();
     return 0;
 }

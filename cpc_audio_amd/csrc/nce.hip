@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64) void nce_gscale_kernel(const float* __restrict_
 // one contiguous 1 KB store per wave (written lane by lane in 4-byte pieces the same 66 MB cost the kernel 56 us at B = 64).
 constexpr int kDsTile = 256 + 48;       // 16 candidates x 16 heads; the four lane groups' rows start 16 floats further apart
                                         // each, so that a transposing write hits every LDS bank exactly twice
-__global__ __launch_bounds__(256) void nce_bwd_dpred_kernel(
+__global__ __launch_bounds__(256, 3) void nce_bwd_dpred_kernel(
     const float* __restrict__ z, const int* __restrict__ ext, const float* __restrict__ logits,
     const float* __restrict__ lse, const float* __restrict__ gscale, float* __restrict__ dpred, int BW,
     int W, int S, int K, int N, float* __restrict__ amax_slots, float* __restrict__ dS) {
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void nce_wcat_kernel(const float* __restrict__
 // fill order was: results are bit-reproducible.  amax_slots: 64 partial maxima of |G| (cleared by nce_gscale_kernel), the
 // operand bound of the GEMM that follows.
 constexpr int GATHER_MAX_SORT = 1024;
-__global__ __launch_bounds__(64) void nce_bwd_g_kernel(const float* __restrict__ c, const float* __restrict__ dS,
+__global__ __launch_bounds__(64, 4) void nce_bwd_g_kernel(const float* __restrict__ c, const float* __restrict__ dS,
                                                        const int* __restrict__ perm, const int* __restrict__ row_ptr,
                                                        float* __restrict__ G, int W, int S, int K, int NK,
                                                        float* __restrict__ amax_slots) {

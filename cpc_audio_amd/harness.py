@@ -36,30 +36,30 @@ from . import ops
 from .dist import FlatGradAllReduce
 
 
-# --------------------------------------------------------------------------- schedulers (misc.py:77-121)
+# --------------------------------------------------------------------------- schedulers (semantics of misc.py:77-121)
 def ramp_scheduling_function(n_epoch_ramp, epoch):
-    if epoch >= n_epoch_ramp:
-        return 1
-    return (epoch + 1) / n_epoch_ramp
+    """Learning-rate factor of the linear warm-up: (epoch + 1) / n_epoch_ramp, saturating at 1."""
+    return 1 if epoch >= n_epoch_ramp else (epoch + 1) / n_epoch_ramp
 
 
 class SchedulerCombiner:
-    """Applies a list of learning-rate schedulers sequentially (cpc/utils/misc.py:84-121)."""
+    """A chain of learning-rate schedulers, scheduler i becoming active at ``activation_step[i]`` (ascending).  A call to
+    ``step()`` advances the most recently activated scheduler and every later one, later ones first -- the later ones keep
+    counting epochs before their activation step, which is what cpc/train.py:361-366 relies on when it chains the ramp
+    with StepLR (cpc/utils/misc.py:84-121)."""
 
     def __init__(self, scheduler_list, activation_step, curr_step=0):
         if len(scheduler_list) != len(activation_step):
             raise ValueError("The number of scheduler must be the same as the number of activation step")
         if activation_step[0] > curr_step:
             raise ValueError("The first activation step cannot be higher than the current step.")
-        self.scheduler_list = scheduler_list
-        self.activation_step = deepcopy(activation_step)
-        self.curr_step = curr_step
+        self.scheduler_list, self.activation_step, self.curr_step = scheduler_list, list(activation_step), curr_step
 
     def step(self):
         self.curr_step += 1
-        index = bisect_left(self.activation_step, self.curr_step) - 1
-        for i in reversed(range(index, len(self.scheduler_list))):
-            self.scheduler_list[i].step()
+        active = bisect_left(self.activation_step, self.curr_step)       # schedulers activated strictly before this step
+        for scheduler in reversed(self.scheduler_list[max(active - 1, 0):]):
+            scheduler.step()
 
 
 def build_scheduler(optimizer, scheduler_step=-1, scheduler_ramp=None):
@@ -267,60 +267,85 @@ def run(train_loader_fn, val_loader_fn, model, criterion, n_epoch, path_checkpoi
 
 # --------------------------------------------------------------------------- inference (feature_loader.py)
 class FeatureModule(torch.nn.Module):
-    """cpc/feature_loader.py:15-38: returns the context features c (or the encoder output z when
-    ``get_encoded``) of a (wave, label) pair."""
+    """The feature-extraction interface of cpc/feature_loader.py:15-38 around a CPCModel: ``forward((waves, label))`` returns
+    the context features c -- or the encoder output z with ``get_encoded`` -- of a batch of waveforms (B, 1, n_samples),
+    flattened to (B * frames, dim) with ``collapse``."""
 
     def __init__(self, featureMaker, get_encoded, collapse=False):
         super().__init__()
-        self.get_encoded = get_encoded
-        self.featureMaker = featureMaker
-        self.collapse = collapse
+        self.featureMaker, self.get_encoded, self.collapse = featureMaker, get_encoded, collapse
 
     def getDownsamplingFactor(self):
         return self.featureMaker.gEncoder.DOWNSAMPLING
 
+    def _device(self):
+        return next(self.featureMaker.parameters()).device
+
     def forward(self, data):
-        batchAudio, label = data
-        device = next(self.featureMaker.parameters()).device
-        cFeature, encoded, _ = self.featureMaker(batchAudio.to(device), label)
-        if self.get_encoded:
-            cFeature = encoded
-        if self.collapse:
-            cFeature = cFeature.contiguous().view(-1, cFeature.size(2))
-        return cFeature
+        waves, label = data
+        c, z, _ = self.featureMaker(waves.to(self._device(), non_blocking=True), label)
+        out = z if self.get_encoded else c
+        return out.reshape(-1, out.size(2)) if self.collapse else out
 
 
 def seq_normalization(out):
-    """cpc/feature_loader.py:221-225."""
-    mean = out.mean(dim=1, keepdim=True)
-    var = out.var(dim=1, keepdim=True)
-    return (out - mean) / torch.sqrt(var + 1e-08)
+    """Zero mean / unit (unbiased) variance along the time axis of (B, frames, dim) features, eps 1e-8 under the root
+    (cpc/feature_loader.py:221-225)."""
+    var, mean = torch.var_mean(out, dim=1, keepdim=True)
+    return (out - mean) * torch.rsqrt(var + 1e-08)
 
 
-def build_feature(feature_maker, seq, strict=False, max_size_seq=64000, seq_norm=False):
-    """cpc/feature_loader.py:228-269 on an in-memory waveform ``seq`` of shape (1, n_samples):
-    64000-sample chunks, optional strict tail handling and per-chunk time normalisation; with
-    ``gAR.keepHidden`` the GRU state is carried across chunks (cpc/eval/ABX.py:170).  Returns
-    (1, n_frames, feature_dim) on the CPU."""
-    size_seq = seq.size(1)
-    start, out = 0, []
-    while start < size_seq:
-        if strict and start + max_size_seq > size_seq:
-            break
-        end = min(size_seq, start + max_size_seq)
-        sub = seq[:, start:end].reshape(1, 1, -1)
-        with torch.no_grad():
-            feats = feature_maker((sub, None))
-            if seq_norm:
-                feats = seq_normalization(feats)
-        out.append(feats.detach().cpu())
-        start += max_size_seq
-    if strict and start < size_seq:
-        sub = seq[:, -max_size_seq:].reshape(1, 1, -1)
-        with torch.no_grad():
-            feats = feature_maker((sub, None))
-            if seq_norm:
-                feats = seq_normalization(feats)
-        delta = (size_seq - start) // feature_maker.getDownsamplingFactor()
-        out.append(feats[:, -delta:].detach().cpu())
-    return torch.cat(out, dim=1)
+def chunk_plan(n_samples, max_size_seq, strict, downsampling):
+    """How cpc/feature_loader.py:228-269 cuts a file: [(first sample, end sample, frames kept)] -- consecutive chunks of
+    ``max_size_seq`` samples and the shorter rest; with ``strict`` only whole chunks, plus (if a rest remains) the LAST
+    ``max_size_seq`` samples of the file, of whose features only the trailing frames that cover the rest are kept
+    (frames kept = None: all)."""
+    n_whole = n_samples // max_size_seq
+    plan = [(i * max_size_seq, (i + 1) * max_size_seq, None) for i in range(n_whole)]
+    rest = n_samples - n_whole * max_size_seq
+    if rest and not strict:
+        plan.append((n_whole * max_size_seq, n_samples, None))
+    elif rest:
+        plan.append((max(n_samples - max_size_seq, 0), n_samples, rest // downsampling))
+    return plan
+
+
+def build_feature(feature_maker, seq, strict=False, max_size_seq=64000, seq_norm=False, max_batch=256):
+    """Features of one whole file, cut as ``chunk_plan`` says (cpc/feature_loader.py:228-269), for an in-memory waveform
+    ``seq`` of shape (1, n_samples).  Device-first: the file crosses to the GPU once, all equally long chunks go through
+    the model as ONE batch (the encoder and a stateless autoregressor see a chunk the same whether it arrives alone or as
+    row i of a batch; up to ``max_batch`` rows per launch), per-chunk time normalisation and the strict tail cut are batched
+    tensor ops, the pieces are joined on the device and the result crosses back once.  Only when the autoregressor carries
+    its state from chunk to chunk (``gAR.keepHidden``, cpc/eval/ABX.py:170) -- or the module flattens its output -- do the
+    chunks go through one after the other, still without leaving the device.  Returns (1, n_frames, feature_dim) on the CPU."""
+    n = seq.size(1)
+    try:
+        device = next(feature_maker.parameters()).device
+    except (AttributeError, StopIteration):
+        device = seq.device
+    wave = seq.reshape(-1).to(device, non_blocking=True)
+    plan = chunk_plan(n, max_size_seq, strict, feature_maker.getDownsamplingFactor())
+    ar = getattr(getattr(feature_maker, "featureMaker", None), "gAR", None)
+    one_by_one = bool(getattr(ar, "keepHidden", False)) or bool(getattr(feature_maker, "collapse", False))
+
+    def features(rows):                       # rows: (k, chunk length) waveform windows -> (k, frames, dim)
+        f = feature_maker((rows.unsqueeze(1), None))
+        return seq_normalization(f) if seq_norm else f
+
+    pieces = []
+    with torch.no_grad():
+        i = 0
+        while i < len(plan):
+            first, end, keep = plan[i]
+            k = 1
+            if not one_by_one:                # the run of chunks of this length that follow each other in the file
+                while (i + k < len(plan) and k < max_batch and plan[i + k][2] is None and keep is None
+                       and plan[i + k][0] == plan[i + k - 1][1] and plan[i + k][1] - plan[i + k][0] == end - first):
+                    k += 1
+            f = features(wave[first:first + k * (end - first)].view(k, end - first))
+            if keep is not None:
+                f = f[:, -keep:]              # (keep == 0 keeps everything, as the reference's slice does)
+            pieces.append(f.reshape(1, -1, f.size(-1)))
+            i += k
+    out = pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=1)
+    return out.cpu()

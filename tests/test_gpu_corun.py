@@ -5,7 +5,7 @@ chip with it and the compiler had formed packed fp32 arithmetic (v_pk_fma_f32) i
 vectorisation since.  These tests pin that state for every kernel of the library that contains packed fp32 or polls
 other workgroups' results and that the train step runs beside the 16-bit-MFMA GEMMs on another stream:
 
-    conv0_bwd_kernel, norm_bwd_kernel, gru_bwd_coef_kernel, the persistent recurrence (forward and backward)
+    conv0_bwd_kernel, norm_bwd_kernel, gru_bwd_coef_kernel, the recurrence (persistent and per-step, forward and backward)
 
 each run alone, then again while conv_wgrad_kernel<2> / conv_dgrad_kernel<128,.,2> run on a second stream, compared
 bit for bit; plus a short version of tools/stress_overlap.py (whole overlapped train steps against the single-stream
@@ -185,12 +185,25 @@ def test_norm_backward_is_bit_exact_beside_the_fp16_gemm_kernels():
     _check_beside(victim, [dx, small3, amax], co)
 
 
-def test_persistent_recurrence_is_bit_exact_beside_the_fp16_gemm_kernels():
-    """cpc_gru_forward / cpc_gru_backward_coef / cpc_gru_backward at B = 64 (the persistent kernels): workgroups poll each
-    other's results; a co-runner changes when they become resident, never what they compute."""
+@pytest.mark.parametrize("gru_mode", [2, 1])
+def test_recurrence_is_bit_exact_beside_the_fp16_gemm_kernels(gru_mode):
+    """cpc_gru_forward / cpc_gru_backward_coef / cpc_gru_backward at B = 64.  gru_mode 2 (default): the persistent kernels --
+    workgroups poll each other's results; a co-runner changes when they become resident, never what they compute.  gru_mode 1:
+    the launch-per-step two-layer kernels.  Between them these are the kernels build.PACKED_FP32_ALLOWED lets contain packed
+    fp32 arithmetic (explicit f32x4 operations on MFMA accumulators): gru2_persist_fwd_h2_kernel, gru2_persist_bwd_kernel,
+    gru2_bwd_kernel."""
     dev = _dev()
     co = _Corunner(dev)
     lib, P = co.lib, co.P
+    from cpc_audio_amd import _lib as L
+    lib.check(lib.cpc_set_gru_mode(gru_mode))
+    try:
+        _recurrence_beside(dev, co, lib, P)
+    finally:
+        lib.check(lib.cpc_set_gru_mode(L.DEFAULT_GRU_MODE))
+
+
+def _recurrence_beside(dev, co, lib, P):
     B, S, nl = 64, 128, 2
     g = torch.Generator(device="cpu").manual_seed(3)
     params = []

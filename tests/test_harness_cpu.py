@@ -79,3 +79,67 @@ def test_checkpoint_discovery_and_roundtrip(tmp_path):
     assert set(state.keys()) == {"gEncoder", "cpcCriterion", "optimizer", "best"}
     for (k, v), (k2, v2) in zip(model.state_dict().items(), model2.state_dict().items()):
         assert k == k2 and torch.equal(v, v2)
+
+
+class _PoolMaker(torch.nn.Module):
+    """A stand-in feature maker for the chunking logic: frame f of a chunk = (mean, max) of its 160 samples + the chunk's own
+    first sample (so a feature knows which chunk produced it); optionally stateful like a keepHidden autoregressor (adds the
+    number of chunks seen so far)."""
+
+    def __init__(self, stateful=False):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+        self.stateful, self.calls, self.batch_sizes = stateful, 0, []
+        if stateful:
+            self.featureMaker = type("M", (), {"gAR": type("A", (), {"keepHidden": True})()})()
+
+    def getDownsamplingFactor(self):
+        return 160
+
+    def forward(self, data):
+        x, _ = data
+        self.batch_sizes.append(x.shape[0])
+        fr = x.shape[2] // 160
+        v = x[:, 0, :fr * 160].reshape(x.shape[0], fr, 160)
+        out = torch.stack([v.mean(2), v.amax(2), x[:, 0, :1] * (1.0 + torch.arange(fr))], dim=2)
+        if self.stateful:
+            out = out + self.calls
+            self.calls += 1
+        return out
+
+
+def _reference_chunking(maker, seq, strict, max_size_seq, seq_norm):
+    """The loop of cpc/feature_loader.py:228-269, restated as the test's oracle (one call per chunk)."""
+    n, start, out = seq.size(1), 0, []
+    norm = (lambda f: (f - f.mean(1, keepdim=True)) / torch.sqrt(f.var(1, keepdim=True) + 1e-8)) if seq_norm else (lambda f: f)
+    while start < n:
+        if strict and start + max_size_seq > n:
+            break
+        out.append(norm(maker((seq[:, start:min(n, start + max_size_seq)].view(1, 1, -1), None))))
+        start += max_size_seq
+    if strict and start < n:
+        f = norm(maker((seq[:, -max_size_seq:].view(1, 1, -1), None)))
+        out.append(f[:, -((n - start) // 160):])
+    return torch.cat(out, dim=1)
+
+
+def test_build_feature_batches_equal_chunks_and_cuts_like_the_reference():
+    torch.manual_seed(0)
+    for n in (6400 * 3 + 1777, 6400 * 4, 6400 + 159, 3000):
+        seq = torch.randn(1, n)
+        for strict in (False, True):
+            for seq_norm in (False, True):
+                ref = _reference_chunking(_PoolMaker(), seq, strict, 6400, seq_norm)
+                mk = _PoolMaker()
+                got = H.build_feature(mk, seq, strict=strict, max_size_seq=6400, seq_norm=seq_norm)
+                assert got.shape == ref.shape, (n, strict, got.shape, ref.shape)
+                assert torch.allclose(got, ref, atol=2e-5 if seq_norm else 1e-6), (n, strict, seq_norm)
+                assert mk.batch_sizes[0] == max(n // 6400, 1)          # all whole chunks in one call
+                # a stateful autoregressor sees the chunks one after the other, in file order
+                ref_s = _reference_chunking(_PoolMaker(stateful=True), seq, strict, 6400, seq_norm)
+                mk_s = _PoolMaker(stateful=True)
+                got_s = H.build_feature(mk_s, seq, strict=strict, max_size_seq=6400, seq_norm=seq_norm)
+                assert torch.allclose(got_s, ref_s, atol=2e-5 if seq_norm else 1e-6) and set(mk_s.batch_sizes) == {1}
+    plan = H.chunk_plan(64000 * 2 + 12345, 64000, True, 160)
+    assert plan == [(0, 64000, None), (64000, 128000, None), (76345, 140345, 77)]
+    assert H.chunk_plan(1000, 64000, True, 160) == [(0, 1000, 6)]
