@@ -34,7 +34,7 @@ SIGNATURES = {
     "cpc_conv_weight_relayout_h2": (_I, [_P, _P, _I, _P]),
     "cpc_conv_gemm_forward_h2": (_I, [_P] * 11 + [_I] * 6 + [_P]),
     "cpc_set_dma_tile": (_I, [_I]),
-    "cpc_set_conv0_groups": (_I, [_I]),
+    "cpc_set_conv0_tuning": (_I, [_I, _I]),
     "cpc_set_h2_layers": (_I, [_I]),
     "cpc_set_h2_dx": (_I, [_I]),
     "cpc_set_wgrad_dma_groups": (_I, [_I]),

@@ -131,9 +131,11 @@ def build(force=False, verbose=False, extra_flags=(), variant=None, gate=True):
     if jobs:
         with open(stamp, "w") as f:
             f.write(flagline)
-    if gate and (jobs or not os.path.exists(LIB)):
+    # (objects newer than the library: a previous run compiled them and then failed the gate or the link)
+    relink = bool(jobs) or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
+    if gate and relink:
         check_packed_fp32(objs)
-    if jobs or not os.path.exists(LIB):
+    if relink:
         cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -90,13 +90,15 @@ class PredictionNetwork(nn.Module):
             else:
                 self.predictors.append(nn.Linear(dimOutputAR, dimOutputEncoder, bias=False))
 
+    group_predictors = True      # False: the transformer predictors run head by head (the path a mixed set falls back to; tests)
+
     def predictions(self, c):
         """c (B,W,256) -> (B,W,K*256): head k at columns k*256.. (the layout the score kernels read).  K one-layer transformer
         predictors (the only kind buildTransformerAR(.., 1, .., False) builds) run in lock-step, one launch per kernel for all
         of them (ops.TransformerGroupFunction); anything else head by head."""
         from .transformers import TransformerLayer
         layers = [p[0] if isinstance(p, nn.Sequential) and len(p) == 1 else None for p in self.predictors]
-        if (self.rnnMode == "transformer" and len(layers) > 1 and all(isinstance(l, TransformerLayer) for l in layers)
+        if (self.group_predictors and self.rnnMode == "transformer" and len(layers) > 1 and all(isinstance(l, TransformerLayer) for l in layers)
                 and len({(l.dropout_p, l.training, l.multihead.Att.relpos) for l in layers}) == 1 and c.is_cuda):
             from .ops import TransformerGroupFunction
             l0 = layers[0]

@@ -15,34 +15,54 @@
 namespace cpc {
 
 constexpr int K0 = 10, S0 = 5, P0 = 3;     // conv0 geometry, cpc/model.py:83
-// 16-step groups per wave (cpc_set_conv0_groups; a block of four waves covers 64 * groups steps): more amortise the 50
+// 16-step groups per wave (cpc_set_conv0_tuning; a block of four waves covers 64 * groups steps): more amortise the 50
 // operand loads of a wave's prologue, fewer leave a shorter tail when the grid is not a multiple of the resident waves
+constexpr int C0_MAX_GPW = 8;
+constexpr int C0_MAX_NS = S0 * 64 * C0_MAX_GPW + (K0 - S0);      // staged samples per block
 static int g_conv0_gpw = 4;
+static int g_conv0_nt = 0;          // 1: the activation rows leave as non-temporal stores (measured: plain stores are the faster
+                                    // ones, alone -- tools/probe_store_pattern.hip: 6.6 against 5.9 TB/s -- and inside the step)
 
-// The 16 bytes lane `slot & 63`-style stores of an H2 row, for a lane that holds channels 4 * slot .. 4 * slot + 3 of the row
-// (slot = 0..63, any mapping of lanes to slots in which lane parity == slot parity and lane ^ 1 holds slot ^ 1): neighbouring
-// lanes swap halves so that the even slot owns the 8 h pieces of its 8-channel group and the odd slot the 8 l pieces, and each
-// lane stores 16 contiguous bytes at row + 16 * slot (h2_store_row_nt is the case slot == lane).
-__device__ __forceinline__ void h2_store_slot_nt(void* row, int slot, float v0, float v1, float v2, float v3, float s, bool live) {
-    _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
-    h2_split(v0, s, h0, l0); h2_split(v1, s, h1, l1); h2_split(v2, s, h2, l2); h2_split(v3, s, h3, l3);
-    const unsigned hw0 = __builtin_bit_cast(unsigned, f16x2{h0, h1}), hw1 = __builtin_bit_cast(unsigned, f16x2{h2, h3});
-    const unsigned lw0 = __builtin_bit_cast(unsigned, f16x2{l0, l1}), lw1 = __builtin_bit_cast(unsigned, f16x2{l2, l3});
+// The 16 bytes a lane stores of an H2 row when it holds channels 4 * slot .. 4 * slot + 3 of the row (slot = 0..63; any mapping of
+// lanes to slots in which lane parity == slot parity and lane ^ 1 holds slot ^ 1): neighbouring lanes swap halves so that the
+// even slot owns the 8 h pieces of its 8-channel group and the odd slot the 8 l pieces, and each lane stores 16 contiguous
+// bytes at row + 16 * slot.  The pieces come from v_cvt_pk_f16_f32 on explicit products: hipcc forms v_fma_mixlo_f16 from
+// (_Float16)(x * s), which issues at less than half the rate of a plain VALU instruction (10.8 against 4.7 cycles per SIMD at 4
+// waves, tools/probe_valu_rate.hip) and then converts the same product a second time.
+__device__ __forceinline__ unsigned pack_f16x2_rne(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIPEMU)
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return __builtin_bit_cast(unsigned, f16x2{(_Float16)a, (_Float16)b});
+#endif
+}
+__device__ __forceinline__ float f16lo(unsigned p) { return (float)__builtin_bit_cast(f16x2, p).x; }
+__device__ __forceinline__ float f16hi(unsigned p) { return (float)__builtin_bit_cast(f16x2, p).y; }
+template <bool NT>
+__device__ __forceinline__ void h2_store_slot(void* row, int slot, float x0, float x1, float x2, float x3, bool live) {
+    // x0..x3: the four values ALREADY multiplied by the storage scale (the caller folds the power of two into its last FMA)
+    const unsigned hw0 = pack_f16x2_rne(x0, x1), hw1 = pack_f16x2_rne(x2, x3);
+    const unsigned lw0 = pack_f16x2_rne(x0 - f16lo(hw0), x1 - f16hi(hw0)), lw1 = pack_f16x2_rne(x2 - f16lo(hw1), x3 - f16hi(hw1));
+    // even lane: {own h, own h, neighbour's h, neighbour's h};  odd lane: {neighbour's l, neighbour's l, own l, own l}
     const bool odd = slot & 1;
-    const unsigned r0 = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, odd ? hw0 : lw0)));
+    const unsigned r0 = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, odd ? hw0 : lw0)));   // quad_perm [1,0,3,2]
     const unsigned r1 = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, odd ? hw1 : lw1)));
     f32x4 o;
     o.x = __builtin_bit_cast(float, odd ? r0 : hw0);
     o.y = __builtin_bit_cast(float, odd ? r1 : hw1);
     o.z = __builtin_bit_cast(float, odd ? lw0 : r0);
     o.w = __builtin_bit_cast(float, odd ? lw1 : r1);
-    if (live) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(row) + 16 * slot));
+    f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(row) + 16 * slot);
+    if (live) {
+        if constexpr (NT) __builtin_nontemporal_store(o, dst); else *dst = o;
+    }
 }
 
 // One wavefront computes 16 time steps x 256 channels at a time on the matrix pipe: per 16 x 16 output tile three
 // v_mfma_f32_16x16x4_f32 (exact fp32 products and sums) contract the 10 taps, the bias (tap 10, against a sample of 1) and a
-// zero pad:  A[16 steps x 4] = waveform samples s[5 t - 3 + j] read straight from global memory (a group's 16 windows are 85
-// consecutive floats), B[4 x 16 channels] = conv0.weight / bias, held in 48 registers for the whole kernel.  Tile T of a
+// zero pad:  A[16 steps x 4] = waveform samples s[5 t - 3 + j] from the block's window, staged once in LDS, B[4 x 16 channels] = conv0.weight / bias from a transposed table in LDS.  Tile T of a
 // lane (column n = lane & 15) is channel 64 (T >> 2) + 4 n + (T & 3), so a lane ends up with four runs of four consecutive
 // channels for each of its four time steps 4 (lane >> 4) + r: ChannelNorm's sums over the 256 channels of a step are 16
 // in-lane additions and one DPP row reduction over the 16 lanes of a row group (no cross-row traffic, no LDS at all), and a
@@ -50,54 +70,58 @@ __device__ __forceinline__ void h2_store_slot_nt(void* row, int slot, float v0, 
 // the scalar-FMA version of this kernel sat at the VALU issue limit (~105 VALU per 1 KB row, 60-65 us at B = 64 against 44 us
 // of HBM time) -- and no LDS-read operand feeds packed fp32 arithmetic any more (the co-residency hazard of DESIGN.md 4.6).
 // YK: storage of y -- 0 fp32, 1 H2 (two fp16 pieces scaled by scale_for_amax(*y_amax), cpc_common.h), 2 bf16
-template <int YK>
-__global__ __launch_bounds__(256, 3) void conv0_fwd_kernel(
+template <int YK, bool NT>
+__global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(
     const float* __restrict__ wave, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, int L, int L0, const float* __restrict__ y_amax, int gpw) {
     __shared__ float aff[2][kC];                 // ChannelNorm weight / bias: 2 KB, re-read per use (ds_read_b128) instead of
-    aff[0][threadIdx.x] = nw[threadIdx.x];       // living in 32 registers
-    aff[1][threadIdx.x] = nb[threadIdx.x];
+    __shared__ float smp[C0_MAX_NS];             // living in 32 registers; the block's waveform window (zero-padded)
+    __shared__ float wT[12][kC];                 // conv0.weight transposed [tap][channel], tap 10 = conv0.bias, tap 11 = 0: the
+    const int b = blockIdx.y;                    // B operands of a lane are twelve 16-byte reads of this table (read from global
+    const float* wb = wave + (long)b * L;        // memory they were 64 strided 4-byte gathers per lane and wave)
+    // (H2 output: times the storage scale, a power of two -- max(fma(xhat, g s, b s), 0) == s max(fma(xhat, g, b), 0) exactly)
+    const float sy = YK == 1 ? scale_for_amax(*y_amax) : 1.0f;
+    aff[0][threadIdx.x] = nw[threadIdx.x] * sy;
+    aff[1][threadIdx.x] = nb[threadIdx.x] * sy;
+    wT[K0][threadIdx.x] = bias[threadIdx.x];
+    wT[K0 + 1][threadIdx.x] = 0.f;
+    for (int e = threadIdx.x; e < kC * K0; e += 256) wT[e % K0][e / K0] = w[e];
+    // The window is staged ONCE, up front: vmcnt counts loads and stores in one in-order queue on gfx9, so a global load
+    // inside the loop could only be waited for together with every store issued before it -- each 16-step group then waited
+    // for the previous group's 16 KB to drain to HBM (6 us per group and wave; 80 us per launch however many waves).
+    const int t00 = blockIdx.x * 64 * gpw, ns = S0 * 64 * gpw + (K0 - S0);
+    for (int i = threadIdx.x; i < ns; i += 256) {
+        const int sidx = t00 * S0 - P0 + i;
+        const float v = wb[sidx < 0 ? 0 : (sidx < L ? sidx : L - 1)];       // unconditional load from a clamped index, then
+        smp[i] = ((unsigned)sidx < (unsigned)L) ? v : 0.f;                   // a select (a predicated load costs a branch + vmcnt(0))
+    }
     __syncthreads();
-    const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n = lane & 15, kq = lane >> 4;
-    const float* wb = wave + (long)b * L;
-    // B operands: wt[T][kk] = tap 4 kk + kq of channel ch(T) (taps 10 / 11: bias / 0)
-    float wt[16][3];
-#pragma unroll
-    for (int T = 0; T < 16; ++T) {
-        const int ch = 64 * (T >> 2) + 4 * n + (T & 3);
-        // every load unconditional (clamped index + select): a predicated load is a branch and a full vmcnt(0) each, and 16 of
-        // them in a row made this prologue longer than the wave's arithmetic
-        const float bv = bias[ch];
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-            const int j = 4 * kk + kq;
-            const float wv = w[ch * K0 + (j < K0 ? j : K0 - 1)];
-            wt[T][kk] = kk < 2 ? wv : (j < K0 ? wv : (j == K0 ? bv : 0.f));
-        }
-    }
-    const float sy = YK == 1 ? scale_for_amax(*y_amax) : 1.0f;
-    // A operands of a group: step tg + n, tap 4 kk + kq (the next group's are requested before this one's arithmetic starts)
-    auto samples = [&](int tg, float (&a)[3]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-            const int j = 4 * kk + kq;
-            const int s = (tg + n) * S0 - P0 + j;
-            const float v = wb[s < 0 ? 0 : (s < L ? s : L - 1)];         // unconditional load, then select
-            a[kk] = j < K0 ? (((unsigned)s < (unsigned)L) ? v : 0.f) : (j == K0 ? 1.0f : 0.f);
-        }
-    };
     const int tg0 = (blockIdx.x * 4 + wv) * gpw * 16;
-    float a[3], an[3];
-    samples(tg0, an);
     for (int gi = 0; gi < gpw; ++gi) {
         const int tg = tg0 + gi * 16;                                    // first step of the group
         if (tg >= L0) break;                                             // wave-uniform
+        // A operands: step tg + n, tap 4 kk + kq (taps 10 / 11: the bias's 1 / 0)
+        float a[3];
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk) a[kk] = an[kk];
-        if (gi + 1 < gpw) samples(tg + 16, an);                       // requested before this group's arithmetic starts
+        for (int kk = 0; kk < 3; ++kk) {
+            const int j = 4 * kk + kq;
+            const float v = smp[(tg - t00 + n) * S0 + (j < K0 ? j : 0)];
+            a[kk] = j < K0 ? v : (j == K0 ? 1.0f : 0.f);
+        }
+        // B operands: wt[T][kk] = tap 4 kk + kq of channel ch(T) = 64 (T >> 2) + 4 n + (T & 3).  Re-read from LDS for every group
+        // (twelve 16-byte reads) rather than held across the loop: 48 registers fewer while the epilogue runs, i.e. four waves
+        // per SIMD instead of three -- at B = 64 and 4 groups per wave the 1024 blocks are then all resident at once.
+        float wt[16][3];
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(&wT[4 * kk + kq][64 * q + 4 * n]);
+                wt[4 * q + 0][kk] = v.x; wt[4 * q + 1][kk] = v.y; wt[4 * q + 2][kk] = v.z; wt[4 * q + 3][kk] = v.w;
+            }
         f32x4 x[16];
 #pragma unroll
         for (int T = 0; T < 16; ++T) {
@@ -139,16 +163,20 @@ __global__ __launch_bounds__(256, 3) void conv0_fwd_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaf(x[4 * q + e][r] * rs[r], gam[e], bet[e]), 0.f);
                 if constexpr (YK == 1) {
-                    h2_store_slot_nt(y + row * kC, 16 * q + n, o[0], o[1], o[2], o[3], sy, live);
+                    h2_store_slot<NT>(y + row * kC, 16 * q + n, o[0], o[1], o[2], o[3], live);
                 } else if constexpr (YK == 2) {
                     const unsigned long long w2 = (unsigned long long)(bf16_rne(o[0]) | ((unsigned)bf16_rne(o[1]) << 16)) |
                                                   ((unsigned long long)(bf16_rne(o[2]) | ((unsigned)bf16_rne(o[3]) << 16)) << 32);
-                    if (live)
-                        __builtin_nontemporal_store(w2, reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(y) +
-                                                                                              row * kC + 64 * q + 4 * n));
+                    unsigned long long* dst = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(y) + row * kC +
+                                                                                    64 * q + 4 * n);
+                    if (live) {
+                        if constexpr (NT) __builtin_nontemporal_store(w2, dst); else *dst = w2;
+                    }
                 } else {
-                    if (live)      // streamed once, 268 MB per launch at B = 64 (>> L2): non-temporal
-                        __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(y + row * kC + 64 * q + 4 * n));
+                    f32x4* dst = reinterpret_cast<f32x4*>(y + row * kC + 64 * q + 4 * n);
+                    if (live) {      // streamed once, 268 MB per launch at B = 64 (>> L2)
+                        if constexpr (NT) __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, dst); else *dst = f32x4{o[0], o[1], o[2], o[3]};
+                    }
                 }
             }
             if (n == 0 && live) { mean_out[row] = mu[r]; rstd_out[row] = rs[r]; }
@@ -413,11 +441,23 @@ int rows_sum_multi(const RowsSumJob* jobs, int njobs, hipStream_t stream) {
 
 using namespace cpc;
 
-extern "C" int cpc_set_conv0_groups(int groups) {
-    CPC_RETURN_IF(groups < 1 || groups > 64, CPC_ERR_ARG);
+extern "C" int cpc_set_conv0_tuning(int groups, int nontemporal) {
+    CPC_RETURN_IF(groups < 1 || groups > cpc::C0_MAX_GPW || nontemporal < 0 || nontemporal > 1, CPC_ERR_ARG);
     cpc::g_conv0_gpw = groups;
+    cpc::g_conv0_nt = nontemporal;
     return 0;
 }
+
+#define CONV0_LAUNCH(YK, st, y, mean, rstd, amax)                                                                             \
+    do {                                                                                                                      \
+        const dim3 grid(cdiv(L0, 64 * cpc::g_conv0_gpw), B);                                                                  \
+        if (cpc::g_conv0_nt)                                                                                                  \
+            hipLaunchKernelGGL((cpc::conv0_fwd_kernel<YK, true>), grid, dim3(256), 0, st, wave, w, bias, nw, nb, y, mean,     \
+                               rstd, L, L0, amax, cpc::g_conv0_gpw);                                                          \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((cpc::conv0_fwd_kernel<YK, false>), grid, dim3(256), 0, st, wave, w, bias, nw, nb, y, mean,    \
+                               rstd, L, L0, amax, cpc::g_conv0_gpw);                                                          \
+    } while (0)
 
 extern "C" int cpc_conv0_forward(const float* wave, const float* w, const float* bias,
                                  const float* nw, const float* nb, float* y, float* mean,
@@ -433,11 +473,9 @@ extern "C" int cpc_conv0_forward_h2(const float* wave, const float* w, const flo
     CPC_RETURN_IF(B <= 0 || L < K0 - 2 * P0, CPC_ERR_SHAPE);
     const int L0 = conv_out_len(L, K0, S0, P0);
     if (y_amax)
-        hipLaunchKernelGGL(conv0_fwd_kernel<1>, dim3(cdiv(L0, 64 * g_conv0_gpw), B), dim3(256), 0, (hipStream_t)stream,
-                           wave, w, bias, nw, nb, reinterpret_cast<float*>(y), mean, rstd, L, L0, y_amax, g_conv0_gpw);
+        CONV0_LAUNCH(1, (hipStream_t)stream, reinterpret_cast<float*>(y), mean, rstd, y_amax);
     else
-        hipLaunchKernelGGL(conv0_fwd_kernel<0>, dim3(cdiv(L0, 64 * g_conv0_gpw), B), dim3(256), 0, (hipStream_t)stream,
-                           wave, w, bias, nw, nb, reinterpret_cast<float*>(y), mean, rstd, L, L0, y_amax, g_conv0_gpw);
+        CONV0_LAUNCH(0, (hipStream_t)stream, reinterpret_cast<float*>(y), mean, rstd, y_amax);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -448,8 +486,7 @@ int conv0_forward_bf16(const float* wave, const float* w, const float* bias, con
                        float* mean, float* rstd, int B, int L, hipStream_t st) {
     CPC_RETURN_IF(B <= 0 || L < K0 - 2 * P0, CPC_ERR_SHAPE);
     const int L0 = conv_out_len(L, K0, S0, P0);
-    hipLaunchKernelGGL(conv0_fwd_kernel<2>, dim3(cdiv(L0, 64 * g_conv0_gpw), B), dim3(256), 0, st, wave, w, bias, nw, nb,
-                       reinterpret_cast<float*>(y), mean, rstd, L, L0, (const float*)nullptr, g_conv0_gpw);
+    CONV0_LAUNCH(2, st, reinterpret_cast<float*>(y), mean, rstd, (const float*)nullptr);
     CPC_LAUNCH_CHECK();
     return 0;
 }

@@ -91,7 +91,8 @@ int cpc_conv_gemm_forward_h2(const void* x_h2, const float* wq, const float* bia
                              const float* zeros, int B, int Lin, int k, int s, int p, int bm, void* stream);
 /* tuning knobs of the DMA kernel inside the composite encoder: rows per workgroup (0 / 128 / 256) and the K-walk
  * rotation step between neighbouring workgroups (0: lockstep) */
-int cpc_set_conv0_groups(int groups);   /* 16-step groups a wave of the layer-0 forward kernel works through (1..64, default 4) */
+int cpc_set_conv0_tuning(int groups, int nontemporal);   /* layer-0 forward kernel: 16-step groups per wave (1..8, default 4); 1 / 0 (default):
+                                                          * activation rows as non-temporal / plain stores */
 int cpc_set_dma_tile(int bm);
 int cpc_set_h2_layers(int n);            /* mode 3: 1 = only conv1, 2 = conv1 and conv2 read H2 input; 0 = by problem size */
 int cpc_set_wgrad_dma_groups(int wgs);  /* workgroups the DMA weight gradient aims at (row splits = wgs / taps); 64..512 */

@@ -190,9 +190,13 @@ inline int dpp_src_lane(int ctrl, int l) {
     fprintf(stderr, "hipemu: unsupported dpp_ctrl 0x%x\n", ctrl);
     abort();
 }
-inline int update_dpp(int, int src, int ctrl, int, int, bool) {
+// row_mask bit r enables the lanes of row r (16 lanes), bank_mask bit k bank k of every row (its lanes 4k .. 4k+3); a disabled
+// lane keeps `old`
+inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool) {
     const uint32_t* buf = exchange((uint32_t)src);
-    return (int)buf[dpp_src_lane(ctrl, lane_id())];
+    const int l = lane_id();
+    const bool on = ((row_mask >> (l >> 4)) & 1) && ((bank_mask >> ((l >> 2) & 3)) & 1);
+    return on ? (int)buf[dpp_src_lane(ctrl, l)] : old;
 }
 inline int readlane(int v, int lane) {
     const uint32_t* buf = exchange((uint32_t)v);

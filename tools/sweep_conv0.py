@@ -24,8 +24,9 @@ y0 = torch.empty(B, L0, 256, device=dev)
 m0, r0 = torch.empty(B * L0, device=dev), torch.empty(B * L0, device=dev)
 flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)          # pushes y0 out of the 256 MB Infinity Cache
 byts = B * (L * 4 + L0 * 256 * 4 + 2 * L0 * 4)
-for groups in (1, 2, 3, 4, 6, 8, 16):
-    lib.check(lib.cpc_set_conv0_groups(groups))
+configs = [(4, 1)] if len(sys.argv) > 2 else [(g, n) for n in (1, 0) for g in (2, 4, 6, 8)]
+for groups, nt in configs:
+    lib.check(lib.cpc_set_conv0_tuning(groups, nt))
     ts = []
     for it in range(12):
         flush.zero_()
@@ -38,5 +39,5 @@ for groups in (1, 2, 3, 4, 6, 8, 16):
             ts.append(e0.elapsed_time(e1))
     ts.sort()
     med = ts[len(ts) // 2]
-    print(f"groups {groups:2d}: median {1e3 * med:6.1f} us  min {1e3 * ts[0]:6.1f}  = {byts / med / 1e6:6.0f} GB/s "
+    print(f"groups {groups:2d} nt {nt}: median {1e3 * med:6.1f} us  min {1e3 * ts[0]:6.1f}  = {byts / med / 1e6:6.0f} GB/s "
           f"({byts / med / 1e6 / 8000:.3f} of 8 TB/s)", flush=True)
