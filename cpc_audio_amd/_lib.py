@@ -84,6 +84,8 @@ SIGNATURES = {
     "cpc_nce_layout": (_I, [_I, _I, _I, _I, _P]),
     "cpc_nce_prepare": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
     "cpc_nce_forward": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
+    "cpc_nce_forward_prepared": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
+    "cpc_nce_bounds": (_I, [_P, ctypes.c_float, _P, _P, _I, _I, _I, _I, _P]),
     "cpc_nce_backward": (_I, [_P] * 12 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward_streams": (_I, [_P] * 12 + [_I, _I, _I, _I, _P, _P]),
     "cpc_nce_backward_dz": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),

@@ -190,6 +190,35 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         ext = s + batchIdx.view(batchSize, N, windowSize) * seqSize
         return ext.permute(0, 2, 1).contiguous().to(torch.int32)
 
+    def prepare_step(self, step, batchSize, seqSize, device, c_bound=None, negatives=None):
+        """Everything of this criterion's step that depends on nothing the GPU is still to compute, queued on the step's side
+        stream from the START of the step (``step``: the ops.StepContext the train loop has just entered) so that it runs beside
+        the encoder: the negative draws with their index preparation (or the preparation of the caller's ``negatives``), and --
+        linear heads, ``c_bound`` given: the context network bounds its output a priori, |c| <= c_bound (a GRU: 1) -- the
+        operand bounds of the prediction GEMMs, whose reduction otherwise sits on the critical path between the context
+        network and the first GEMM.  forward() picks the result up when the shapes match and falls back to doing it in line
+        otherwise; calling this is optional."""
+        from . import ops
+        if step is None or not step.overlap or torch.device(device).type != "cuda" or self.mode == "reverse":
+            return
+        K, N = self.nPredicts, self.negativeSamplingExt
+        W = seqSize - K
+        main, side = torch.cuda.current_stream(device), step.side_stream(device)
+        if step.begin is not None:
+            side.wait_event(step.begin)
+        given = None if negatives is None else id(negatives[0])
+        with torch.cuda.stream(side):
+            if negatives is None:
+                negatives = self.drawNegatives(batchSize, seqSize, W, device)
+            ext, perm, row_ptr = prepare_negatives(negatives[0], negatives[1], batchSize, seqSize, K, N)
+            saved = None
+            if c_bound is not None and self.wPrediction.rnnMode != "transformer":
+                saved = ops.nce_bounds_into(self.wPrediction.stacked_weight(), c_bound, batchSize, seqSize, K, N)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        step.prepared = {"key": (batchSize, seqSize, K, N, torch.device(device)), "index": (ext, perm, row_ptr),
+                         "saved": saved, "ready": ready, "given": given}
+
     def forward(self, cFeature, encodedData, label, negatives=None):
         """-> (losses (1,K), acc (1,K)) as criterion.py:256-257.  ``negatives`` optionally
         supplies (batchIdx, seqIdx) instead of drawing them (parity tests)."""
@@ -200,7 +229,18 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         windowSize = seqSize - self.nPredicts
         from . import ops
         step = ops.current()
-        if negatives is None and step is not None and step.overlap and cFeature.is_cuda:
+        prepared, saved = (step.prepared if step is not None else None), None
+        if step is not None:
+            step.prepared = None
+        if (prepared is not None and self.mode != "reverse"
+                and prepared["given"] == (None if negatives is None else id(negatives[0])) and prepared["key"] == (batchSize, seqSize, self.nPredicts, self.negativeSamplingExt, cFeature.device)):
+            # queued at the start of the step (prepare_step): long finished by now
+            torch.cuda.current_stream().wait_event(prepared["ready"])
+            ext, perm, row_ptr = prepared["index"]
+            saved = prepared["saved"]
+            for t in (ext, perm, row_ptr) + (() if saved is None else (saved,)):
+                t.record_stream(torch.cuda.current_stream())
+        elif negatives is None and step is not None and step.overlap and cFeature.is_cuda:
             # the draws and their index preparation depend on nothing the GPU is still computing (encoder, AR): issued
             # on the side stream they run beside the latency-bound recurrence instead of after it
             main, side = torch.cuda.current_stream(), step.side_stream(cFeature.device)
@@ -230,5 +270,5 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             # mode 'reverse' (the flip above sits between the criterion and the encoder), not behind a foreign network
             defer = step is not None and step.overlap and ops.dz_may_be_deferred(cFeature, encodedData)
             losses, acc = InfoNCEFunction.apply(cFeature, encodedData, self.wPrediction.stacked_weight(), ext, perm,
-                                                row_ptr, heads, defer)
+                                                row_ptr, heads, defer, saved)
         return losses.view(1, -1), acc.view(1, -1)

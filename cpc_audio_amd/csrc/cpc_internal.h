@@ -25,7 +25,8 @@ struct GemmBounds {
     int a_slots = 1, b_slots = 1;
 };
 // max|x| of up to 4 arrays in one launch, as kAmaxSlots partial maxima each (no memset, no atomics): out[j*64 .. j*64+63]
-int absmax_slots(const float* const* x, const long* n, int njobs, float* out, hipStream_t st);
+// (x[j] == NULL: the bound of job j is known a priori -- its slots all carry cval[j])
+int absmax_slots(const float* const* x, const long* n, int njobs, float* out, hipStream_t st, const float* cval = nullptr);
 
 // G equally shaped problems in one launch (blockIdx.z / .y picks the problem): problem g reads and writes at the given
 // pointers + g * stride (floats).  A stride of 0 shares the operand between the problems.

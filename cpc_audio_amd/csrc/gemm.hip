@@ -220,10 +220,15 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch b, 
 
 // One workgroup of 1024 threads per (array, slot): slot s covers elements [s, s+1) * ceil(n / 64 / 4) * 4 of its array,
 // four 16-byte loads in flight per thread.
-struct AbsmaxJobs { const float* x[4]; long n[4]; };
+// (a job without an array -- x == NULL -- is a bound known a priori: its slots all carry cval)
+struct AbsmaxJobs { const float* x[4]; long n[4]; float cval[4]; };
 __global__ __launch_bounds__(1024) void absmax_slots_kernel(AbsmaxJobs jobs, float* __restrict__ out) {
     __shared__ float red[16];
     const float* __restrict__ x = jobs.x[blockIdx.y];
+    if (x == nullptr) {                                  // block-uniform
+        if (threadIdx.x == 0) out[blockIdx.y * kAmaxSlots + blockIdx.x] = jobs.cval[blockIdx.y];
+        return;
+    }
     const long n = jobs.n[blockIdx.y];
     const long per = ((n + kAmaxSlots - 1) / kAmaxSlots + 3) & ~3L;
     const long beg = (long)blockIdx.x * per, end = beg + per < n ? beg + per : n;
@@ -258,10 +263,13 @@ __global__ __launch_bounds__(1024) void absmax_slots_kernel(AbsmaxJobs jobs, flo
 int g_gemm_wide = 1;
 int g_gemm_split = 1;      // cpc_set_gemm_split: 0 keeps every plain GEMM on three bf16 pieces, bounds or not
 
-int absmax_slots(const float* const* x, const long* n, int njobs, float* out, hipStream_t st) {
+int absmax_slots(const float* const* x, const long* n, int njobs, float* out, hipStream_t st, const float* cval) {
     if (njobs <= 0 || njobs > 4) return CPC_ERR_ARG;
     AbsmaxJobs jobs;
-    for (int j = 0; j < 4; ++j) { jobs.x[j] = x[j < njobs ? j : 0]; jobs.n[j] = n[j < njobs ? j : 0]; }
+    for (int j = 0; j < 4; ++j) {
+        jobs.x[j] = x[j < njobs ? j : 0]; jobs.n[j] = n[j < njobs ? j : 0];
+        jobs.cval[j] = cval ? cval[j < njobs ? j : 0] : 0.f;
+    }
     hipLaunchKernelGGL(absmax_slots_kernel, dim3(kAmaxSlots, njobs), dim3(1024), 0, st, jobs, out);
     CPC_LAUNCH_CHECK();
     return 0;

@@ -754,26 +754,54 @@ extern "C" int cpc_nce_prepare(const long* batchIdx, const long* seqIdx, int* ex
 // c (B,S,256) context, z (B,S,256) encoder output, wall (K*256, 256) = the K head weights stacked,
 // ext (B*W, N) int32 rows into z.view(B*S,256) [i.e. criterion.py:199's extIdx laid out (b,t,n)].
 // losses, acc: K floats each (criterion.py:256-257).
-extern "C" int cpc_nce_forward(const float* c, const float* z, const float* wall, const int* ext, float* saved,
-                               float* scratch, float* losses, float* acc, int B, int S, int K, int N,
-                               void* stream) {
+static int nce_forward(const float* c, const float* z, const float* wall, const int* ext, float* saved, float* scratch,
+                       float* losses, float* acc, int B, int S, int K, int N, hipStream_t st, bool bounds_ready) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!c || !z || !wall || !ext || !saved || !scratch || !losses || !acc, CPC_ERR_ARG);
-    hipStream_t st = (hipStream_t)stream;
     float* pred = saved + n.pred;
     // operand bounds for the fp16-split GEMMs of this call and of the backward (one small launch: 11 MB read)
     // (written in every mode: the backward may run in another one)
-    const float* xs[2] = {c, wall};
-    const long ns[2] = {(long)B * S * kC, (long)K * kC * kC};
-    int rc = absmax_slots(xs, ns, 2, saved + n.bounds, st);
-    if (rc) return rc;
+    if (!bounds_ready) {
+        const float* xs[2] = {c, wall};
+        const long ns[2] = {(long)B * S * kC, (long)K * kC * kC};
+        int rc = absmax_slots(xs, ns, 2, saved + n.bounds, st);
+        if (rc) return rc;
+    }
     GemmBounds gb;
     gb.a = saved + n.bounds; gb.a_slots = kAmaxSlots;
     gb.b = saved + n.bounds + kAmaxSlots; gb.b_slots = kAmaxSlots;
-    rc = nt_gemm(window_rows(c, B, S, n.W), wall, kC, nullptr, pred, (long)K * kC, K * kC, kC, st, 0, 0, gb);
+    int rc = nt_gemm(window_rows(c, B, S, n.W), wall, kC, nullptr, pred, (long)K * kC, K * kC, kC, st, 0, 0, gb);
     if (rc) return rc;
     return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, st);
+}
+
+extern "C" int cpc_nce_forward(const float* c, const float* z, const float* wall, const int* ext, float* saved,
+                               float* scratch, float* losses, float* acc, int B, int S, int K, int N,
+                               void* stream) {
+    return nce_forward(c, z, wall, ext, saved, scratch, losses, acc, B, S, K, N, (hipStream_t)stream, false);
+}
+
+// The operand bounds of the criterion's GEMMs, ahead of time: max|wall| is fixed once the optimiser has stepped, and a
+// recurrent context is bounded a priori (|h| < 1 for a GRU started from 0 or from one of its own states), so neither has to
+// wait for c -- this call writes them into `saved` (on any stream, e.g. beside the encoder) and cpc_nce_forward_prepared then
+// skips the 24 us reduction that otherwise sits between the autoregressive network and the prediction GEMM.
+// c_bound > 0: the a-priori bound of |c|; otherwise c must be given and is reduced here.
+extern "C" int cpc_nce_bounds(const float* c, float c_bound, const float* wall, float* saved, int B, int S, int K, int N,
+                              void* stream) {
+    NceLayout n;
+    CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!wall || !saved || (!(c_bound > 0.f) && !c), CPC_ERR_ARG);
+    const float* xs[2] = {c_bound > 0.f ? nullptr : c, wall};
+    const long ns[2] = {(long)B * S * kC, (long)K * kC * kC};
+    const float cv[2] = {c_bound, 0.f};
+    return absmax_slots(xs, ns, 2, saved + n.bounds, (hipStream_t)stream, cv);
+}
+
+extern "C" int cpc_nce_forward_prepared(const float* c, const float* z, const float* wall, const int* ext, float* saved,
+                                        float* scratch, float* losses, float* acc, int B, int S, int K, int N,
+                                        void* stream) {
+    return nce_forward(c, z, wall, ext, saved, scratch, losses, acc, B, S, K, N, (hipStream_t)stream, true);
 }
 
 // Same criterion on predictions computed by the caller (any prediction network, e.g. --rnnMode transformer):

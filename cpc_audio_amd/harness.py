@@ -75,6 +75,21 @@ def build_scheduler(optimizer, scheduler_step=-1, scheduler_ramp=None):
     return scheduler
 
 
+def prepare_criterion(step, model, criterion, batch, negatives=None):
+    """Queue the criterion's activation-independent share of a step (negative draws, index preparation, GEMM operand bounds) on
+    the step's side stream before the encoder is launched -- CPCUnsupersivedCriterion.prepare_step; a no-op for anything else."""
+    from .model import CPCAR
+    prep, enc = getattr(criterion, "prepare_step", None), getattr(model, "gEncoder", None)
+    if prep is None or enc is None or not torch.is_tensor(batch) or not batch.is_cuda or batch.dim() != 3:
+        return
+    ar = getattr(model, "gAR", None)
+    # |c| <= 1 a priori for a GRU that starts from zero or from one of its own final states (keepHidden); a state assigned from
+    # outside, or another kind of network, gives no such bound
+    bounded = isinstance(ar, CPCAR) and (ar.hidden is None or getattr(ar, "keepHidden", False))
+    prep(step, batch.shape[0], batch.shape[2] // enc.DOWNSAMPLING, batch.device, c_bound=1.0 if bounded else None,
+         negatives=negatives)
+
+
 # --------------------------------------------------------------------------- synthetic data
 class SyntheticLoader:
     """Yields ``n_batches`` of (wave (B,1,L) fp32, label (B,) int64): white noise 0.1*N(0,1) clamped to
@@ -119,6 +134,7 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
             in_flight.pop(0).synchronize()
         try:
             with step_ctx as sc:                          # side streams for the dz path / weight gradients (ops.StepContext)
+                prepare_criterion(sc, model, criterion, batch)
                 c_feature, encoded, label = model(batch, label)
                 all_losses, all_acc = criterion(c_feature, encoded, label)
                 if ones is None or ones.shape != all_losses.shape or ones.device != all_losses.device:

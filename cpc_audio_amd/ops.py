@@ -81,6 +81,8 @@ class StepContext:
         #                             CUs: its 768-thread workgroups cannot squeeze in beside a chip full of gather blocks)
         self.pre_encoder_backward = []   # callables(ctx) run when the encoder's backward starts: every other gradient
         #                             of the step is final (or queued on the side stream) by then -- FlatGradAllReduce.begin
+        self.prepared = None        # what the criterion queued on the side stream at the start of the step
+        #                             (CPCUnsupersivedCriterion.prepare_step): negative draws, index preparation, GEMM bounds
 
     def side_stream(self, device, which=0):
         """which = 0: the criterion's stream (negative draws, dz path, head gradient, early all-reduce bucket);
@@ -99,6 +101,7 @@ class StepContext:
         del self.side_events[:]
         del self.late_events[:]
         del self.wgrad_events[:]
+        self.prepared = None
 
     def launch_deferred(self):
         while self.deferred:
@@ -397,7 +400,8 @@ class InfoNCEFunction(torch.autograd.Function):
     (bit-identical values; ``wall`` itself receives no gradient), which takes that GEMM off the path to the encoder."""
 
     @staticmethod
-    def forward(ctx, c, z, wall, ext, perm, row_ptr, heads=None, defer_dz=False):
+    def forward(ctx, c, z, wall, ext, perm, row_ptr, heads=None, defer_dz=False, saved=None):
+        """saved: optionally the workspace of this call with the GEMM operand bounds already in it (nce_bounds_into)."""
         _require_cuda(c, "InfoNCEFunction")
         lib = _lib.get()
         B, S, H = c.shape
@@ -408,12 +412,15 @@ class InfoNCEFunction(torch.autograd.Function):
         c, z, wall, ext = c.contiguous(), z.contiguous(), wall.detach().contiguous(), ext.contiguous()
         with torch.cuda.device(c.device):
             sizes = _layout("nce_layout", lib.cpc_nce_layout, 6, B, S, K, N)
-            saved = torch.empty(sizes[0], device=c.device, dtype=torch.float32)
+            fwd = lib.cpc_nce_forward_prepared
+            if saved is None or saved.numel() != sizes[0] or saved.device != c.device:
+                saved = torch.empty(sizes[0], device=c.device, dtype=torch.float32)
+                fwd = lib.cpc_nce_forward
             scratch = torch.empty(sizes[1], device=c.device, dtype=torch.float32)
             losses = torch.empty(K, device=c.device, dtype=torch.float32)
             acc = torch.empty(K, device=c.device, dtype=torch.float32)
-            lib.check(lib.cpc_nce_forward(_p(c), _p(z), _p(wall), _p(ext), _p(saved), _p(scratch), _p(losses),
-                                          _p(acc), B, S, K, N, _stream()), "nce_forward")
+            lib.check(fwd(_p(c), _p(z), _p(wall), _p(ext), _p(saved), _p(scratch), _p(losses), _p(acc), B, S, K, N,
+                          _stream()), "nce_forward")
         ctx.save_for_backward(c, z, wall, ext, saved, perm, row_ptr)
         ctx.dims = (B, S, K, N, sizes[2])
         ctx.set_materialize_grads(False)       # no zero-filled gradient for the accuracies
@@ -491,7 +498,19 @@ class InfoNCEFunction(torch.autograd.Function):
                 lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
                                                _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
                                                _stream()), "nce_backward")
-        return dc, dz, dwall, None, None, None, None, None
+        return dc, dz, dwall, None, None, None, None, None, None
+
+
+def nce_bounds_into(wall, c_bound, B, S, K, N):
+    """A workspace for InfoNCEFunction(saved=...) with the operand bounds of the criterion's GEMMs already in it
+    (cpc_nce_bounds on the current stream): max|wall| reduced now -- the weights do not change inside a step -- and |c|
+    bounded a priori by ``c_bound``."""
+    lib = _lib.get()
+    with torch.cuda.device(wall.device):
+        sizes = _layout("nce_layout", lib.cpc_nce_layout, 6, B, S, K, N)
+        saved = torch.empty(sizes[0], device=wall.device, dtype=torch.float32)
+        lib.check(lib.cpc_nce_bounds(None, float(c_bound), _p(wall.detach()), _p(saved), B, S, K, N, _stream()), "nce_bounds")
+    return saved
 
 
 class InfoNCEScoresFunction(torch.autograd.Function):

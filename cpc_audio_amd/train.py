@@ -98,6 +98,7 @@ class Trainer:
                 self.wait_seconds = getattr(self, "wait_seconds", 0.0) + (time.perf_counter() - t0)   # not host WORK
         try:
             with self.ctx as step:
+                self._prepare_criterion(step, batchData, negatives)
                 c_feature, encoded_data, label = self.model(batchData, label)
                 allLosses, allAcc = self.criterion(c_feature, encoded_data, label, negatives=negatives)
                 # allLosses.sum().backward() (train.py:85-87) without the sum / fill / expand kernels: d sum / d loss_k = 1
@@ -114,6 +115,10 @@ class Trainer:
             ev.record()
             self._done_events.append(ev)
         return allLosses.detach(), allAcc.detach()
+
+    def _prepare_criterion(self, step, batchData, negatives):
+        from .harness import prepare_criterion
+        prepare_criterion(step, self.model, self.criterion, batchData, negatives)
 
     def _graph_key(self, batchData):
         lrs = tuple(float(g["lr"]) for g in self.optimizer.param_groups)

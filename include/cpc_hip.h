@@ -300,6 +300,13 @@ int cpc_nce_prepare(const long* batchIdx, const long* seqIdx, int* ext, int* per
 int cpc_nce_forward(const float* c, const float* z, const float* wall, const int* ext, float* saved,
                     float* scratch, float* losses, float* acc, int B, int S, int K, int N,
                     void* stream);
+/* The operand bounds of the criterion's GEMMs (max|c|, max|wall|, kept in `saved`) ahead of time, on any stream: max|wall| is
+ * fixed once the optimiser has stepped and a recurrent context is bounded a priori (c_bound > 0: |c| <= c_bound, e.g. 1 for a
+ * GRU; otherwise c is reduced here), so the reduction need not sit between the autoregressive network and the prediction
+ * GEMM.  cpc_nce_forward_prepared is cpc_nce_forward on a `saved` whose bounds were written by cpc_nce_bounds. */
+int cpc_nce_bounds(const float* c, float c_bound, const float* wall, float* saved, int B, int S, int K, int N, void* stream);
+int cpc_nce_forward_prepared(const float* c, const float* z, const float* wall, const int* ext, float* saved,
+                             float* scratch, float* losses, float* acc, int B, int S, int K, int N, void* stream);
 /* gloss: K upstream gradients dL/dloss_k.  dc, dz (B,S,256) and dwall are overwritten.
  * perm (B*W*(N+K)) / row_ptr (B*S+1): candidate slots sorted by destination row of z (slot =
  * (b*W+t)*(N+K)+j; j<N: negative j -> row ext[..j]; j>=N: positive of head j-N -> row b*S+t+j-N+1);

@@ -39,6 +39,14 @@ def _nce_forward_backward(lib, B, S, K, N, scale):
     fscr = torch.full((sizes[1],), float("nan"))
     losses = torch.full((K,), float("nan")); acc = torch.full((K,), float("nan"))
     assert lib.cpc_nce_forward(P(c), P(z), P(wall), P(ext_t), P(saved), P(fscr), P(losses), P(acc), B, S, K, N, None) == 0
+    # the same forward on a workspace whose GEMM operand bounds were written ahead of time (cpc_nce_bounds: max|wall| reduced,
+    # |c| <= 1 a priori -- c is a tanh here): what the train loops queue beside the encoder (criterion.prepare_step)
+    saved2 = torch.full((sizes[0],), float("nan"))
+    l2 = torch.full((K,), float("nan")); a2 = torch.full((K,), float("nan"))
+    assert lib.cpc_nce_bounds(None, 1.0, P(wall), P(saved2), B, S, K, N, None) == 0
+    assert lib.cpc_nce_forward_prepared(P(c), P(z), P(wall), P(ext_t), P(saved2), P(fscr), P(l2), P(a2), B, S, K, N, None) == 0
+    assert (l2 - losses).abs().max().item() < 1e-5 * max(1.0, losses.abs().max().item()) and torch.equal(a2, acc)
+    assert lib.cpc_nce_bounds(None, 0.0, P(wall), P(saved2), B, S, K, N, None) != 0     # neither a bound nor the tensor
     leaves = {f"wPrediction.predictors.{k}.weight": heads[k].clone().requires_grad_(True) for k in range(K)}
     cr = c.clone().requires_grad_(True); zr = z.clone().requires_grad_(True)
     lr, ar = O.criterion_forward(leaves, cr, zr, ext, K)
