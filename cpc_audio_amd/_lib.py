@@ -78,7 +78,7 @@ SIGNATURES = {
     "cpc_gru_forward": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "cpc_gru_backward": (_I, [_P] * 9 + [_I, _I, _I, _P]),
     "cpc_gru_coef_floats": (_L, [_I, _I, _I]),
-    "cpc_gru_backward_coef": (_I, [_P] * 4 + [_I, _I, _I, _P]),
+    "cpc_gru_backward_coef": (_I, [_P] * 5 + [_I, _I, _I, _P]),
     "cpc_gru_backward_with_coef": (_I, [_P] * 10 + [_I, _I, _I, _P]),
     "cpc_gru_backward_streams": (_I, [_P] * 10 + [_I, _I, _I, _P, _P]),
     "cpc_nce_layout": (_I, [_I, _I, _I, _I, _P]),

@@ -1134,7 +1134,8 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
 extern "C" long cpc_gru_coef_floats(int B, int S, int nl) {
     GruLayout g;
     if (nl != 2 || !gru_layout(B, S, nl, g)) return 0;
-    return 10 * g.frag_floats;       // 8 coefficient arrays + the two hand-over buffers of the persistent backward
+    // 8 coefficient arrays + the two hand-over buffers of the persistent backward + the four transposed weight matrices
+    return 10 * g.frag_floats + 4L * kG * kH;
 }
 
 static void launch_gru_coef(const GruLayout& g, const float* h0, const float* saved, const float* y, float* coef,
@@ -1149,16 +1150,23 @@ static void launch_gru_coef(const GruLayout& g, const float* h0, const float* sa
     }
 }
 
-// Everything in the two-layer backward that depends on the forward pass only (gru_bwd_coef_kernel), into `coef`
+// Everything in the two-layer backward that depends on the forward pass only (gru_bwd_coef_kernel, the weight transposes), into `coef`
 // (cpc_gru_coef_floats floats): a caller may run this any time after the forward, on any stream, and hand the result
 // to cpc_gru_backward_with_coef -- it takes 47 us of HBM streaming off the path between the criterion and the
 // recurrence.
-extern "C" int cpc_gru_backward_coef(const float* h0, const float* saved, const float* y, float* coef, int B, int S,
-                                     int nl, void* stream) {
+extern "C" int cpc_gru_backward_coef(const float* h0, const float* const* params, const float* saved, const float* y,
+                                     float* coef, int B, int S, int nl, void* stream) {
     GruLayout g;
     CPC_RETURN_IF(nl != 2 || !gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
-    CPC_RETURN_IF(!saved || !y || !coef, CPC_ERR_ARG);
+    CPC_RETURN_IF(!params || !saved || !y || !coef, CPC_ERR_ARG);
     launch_gru_coef(g, h0, saved, y, coef, B, S, (hipStream_t)stream);
+    {   // (3H,H) -> (H,3H), the four weight matrices in one launch: W_hh0, W_ih0, W_hh1, W_ih1 behind the hand-over buffers
+        float* wT = coef + 10 * g.frag_floats;
+        const float* tin[4] = {params[1], params[0], params[5], params[4]};
+        float* tout[4] = {wT, wT + (long)kG * kH, wT + 2L * kG * kH, wT + 3L * kG * kH};
+        int rc = transpose_batch(tin, tout, 4, kG, kH, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     // ... and the hand-over buffers of the persistent backward, pre-filled with the "not written yet" pattern
     if (hipMemsetAsync(coef + 8 * g.frag_floats, 0xFF, 2 * g.frag_floats * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return CPC_ERR_ARG;
@@ -1197,8 +1205,10 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
     float* dGi = scratch + g.dGi, *dGh = scratch + g.dGh, *DH = scratch + g.DH;
     const int M = B * S;
     if (nl == 2) {                                   // two-layer wavefront (see gru2_bwd_kernel)
-        float* whhT_[2] = {scratch + g.whhT, scratch + g.whhT2};
-        float* wihT_[2] = {scratch + g.wihT, scratch + g.wihT2};
+        // (the transposed weights come with `coef` when the caller prepared it, cpc_gru_backward_coef)
+        float* cwT = coef ? const_cast<float*>(coef) + 10 * g.frag_floats : nullptr;
+        float* whhT_[2] = {coef ? cwT : scratch + g.whhT, coef ? cwT + 2L * kG * kH : scratch + g.whhT2};
+        float* wihT_[2] = {coef ? cwT + (long)kG * kH : scratch + g.wihT, coef ? cwT + 3L * kG * kH : scratch + g.wihT2};
         float* dGi_[2] = {scratch + g.dGi, scratch + g.dGi2};
         float* dGh_[2] = {scratch + g.dGh, scratch + g.dGh2};
         float* DH_[2] = {scratch + g.DH, scratch + g.DH2};
@@ -1208,7 +1218,7 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
         const float* yl[2] = {saved + g.Y[0], y};
         const float* h0l[2] = {h0, h0 ? h0 + (long)B * kH : nullptr};
         int rc = 0;
-        {   // (3H,H) -> (H,3H), the four weight matrices in one launch
+        if (!coef) {   // (3H,H) -> (H,3H), the four weight matrices in one launch
             const float* tin[4] = {params[1], params[0], params[5], params[4]};
             float* tout[4] = {whhT_[0], wihT_[0], whhT_[1], wihT_[1]};
             rc = transpose_batch(tin, tout, 4, kG, kH, st);

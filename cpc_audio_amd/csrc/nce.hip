@@ -40,42 +40,97 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
 }
 
 // ------------------------------------------------------------------ forward scores
+// Sixteen 1 KB rows -> this lane's fragments of them as an MFMA operand whose non-contracted index is the ROW (lane & 15 =
+// row, lane >> 4 = k group):  out[ii] = floats 16 ii + 4 kq .. + 3 of row i.  Read in that layout directly, the 64 lanes of a
+// load touch 16 rows x four 16-byte pieces and the coalescer -- which merges adjacent lanes only -- makes 64 cache accesses of
+// it: PMC showed nce_fwd_kernel bound by the vector L1's tag lookups (84 M accesses per launch at B = 64, 330 k clocks per CU of
+// a 390 k-clock kernel; the backward kernels, whose gathered rows are the operand with the CHANNEL in the low lane bits, make 19
+// per instruction).  So the rows are loaded the coalesced way -- lane (c = lane & 15, r4 = lane >> 4) reads piece c of rows
+// 4 q + r4: 256 contiguous bytes per row group, 16 accesses per instruction -- and the 16 x 16 transpose of 16-byte pieces goes
+// through a 4 KB LDS tile per wave, one 256-byte column block (four fragments) at a time.  Piece (row, chunk) sits in slot
+// row * 16 + (chunk ^ row): writes cover whole 256-byte rows, reads take 16 distinct slots per 16 lanes -- no bank conflicts.
+struct Gather16 {
+    float4 v[4][4];                                   // [q][g]: piece c of row 4 q + r4, column block g
+    __device__ __forceinline__ void issue(const float* const (&rowp)[4]) {     // rowp[q]: row 4 q + r4, + 4 c floats
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[q][g] = ld4(rowp[q] + 64 * g);
+    }
+    // fragments 4 g .. 4 g + 3 (ii = 4 g + e) of row i; convergent: the whole wave calls it
+    __device__ __forceinline__ void block(int g, float4* tile, float4 (&out)[4]) const {
+        const int lane = threadIdx.x & 63, c = lane & 15, r4 = lane >> 4;
+        __builtin_amdgcn_wave_barrier();                // the previous block's reads are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tile[(4 * q + r4) * 16 + (c ^ (4 * q + r4))] = v[q][g];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = tile[c * 16 + ((4 * e + r4) ^ c)];        // here c plays the row i, r4 the k group
+    }
+};
+
 // one wavefront per (b,t) row; 4 rows per block.  pred: [BW][K*C]; ext: [BW][N] row ids into z.
 //
-__global__ __launch_bounds__(256) void nce_fwd_kernel(
+__global__ __launch_bounds__(256, 3) void nce_fwd_kernel(
     const float* __restrict__ pred, const float* __restrict__ z, const int* __restrict__ ext,
     float* __restrict__ logits, float* __restrict__ lse_out, float* __restrict__ rowstat, int BW, int W,
     int S, int K, int N, unsigned* __restrict__ ticket) {
+    __shared__ float4 tiles[4][256];
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;      // nce_reduce_finalize_kernel, the next launch on this stream
     if (bt >= BW) return;                           // whole wave leaves together
+    float4* tile = tiles[threadIdx.x >> 6];
     const int b = bt / W, t = bt - b * W;
     const int i = lane & 15, kq = lane >> 4;        // i: head (and candidate row of the A operand); kq: k group
     const bool hv = i < K;
     const float inv = 1.0f / kC;
+    Gather16 gt;
+    const float* rowp[4];
 
-    float4 pa[16];
+    float4 pa[16];                                  // pred[head i][16 ii + 4 kq ..]
     {
-        const float* pp = pred + ((long)bt * K + (hv ? i : 0)) * kC + 4 * kq;
 #pragma unroll
-        for (int ii = 0; ii < 16; ++ii) pa[ii] = hv ? ld4(pp + 16 * ii) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 4; ++q) {
+            const int head = 4 * q + kq;
+            rowp[q] = pred + ((long)bt * K + (head < K ? head : 0)) * kC + 4 * i;
+        }
+        gt.issue(rowp);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 o[4];
+            gt.block(g, tile, o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pa[4 * g + e] = hv ? o[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     // positives: head h <-> z[b, t+h+1].  They go through the SAME MFMA chain as the negatives
     // (a 16-row tile whose row j is head j's positive row; the diagonal is kept), so a
     // negative that happens to be the positive row scores bit-identically and the arg-max tie
     // resolves to class 0 exactly as in the reference (criterion.py:253).
-    float posl;
-    {
-        const float* zp = z + ((long)b * S + t + (hv ? i : 0) + 1) * kC + 4 * kq;
+    auto score_tile = [&]() __attribute__((always_inline)) {      // gt holds 16 rows of z: scores of row i against the heads
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ii = 0; ii < 16; ++ii) {
-            const float4 zf = ld4(zp + 16 * ii);
+        for (int g = 0; g < 4; ++g) {
+            float4 zf[4];
+            gt.block(g, tile, zf);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(zf, jj), f4c(pa[ii], jj), acc, 0, 0, 0);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(zf[e], jj), f4c(pa[4 * g + e], jj), acc, 0, 0, 0);
         }
+        return acc;
+    };
+    float posl;
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int head = 4 * q + kq;
+            rowp[q] = z + ((long)b * S + t + (head < K ? head : 0) + 1) * kC + 4 * i;
+        }
+        gt.issue(rowp);
+        const f32x4 acc = score_tile();
         // acc[r] on lane (i, q) = score(positive row of head 4q+r, head i); the diagonal sits on lane (i, i >> 2), reg i & 3
         const float mine = (i & 3) == 0 ? acc[0] : (i & 3) == 1 ? acc[1] : (i & 3) == 2 ? acc[2] : acc[3];
         posl = __shfl(mine, i + 16 * (i >> 2)) * inv;
@@ -84,16 +139,10 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(
     float ssum = kq == 0 ? 1.0f : 0.0f;             // the positive enters the sum once (exp(posl - M) = 1)
     float mneg = -3.0e38f;
     for (int nt = 0; nt < N / 16; ++nt) {
-        const int row = ext[(long)bt * N + nt * 16 + i];
-        const float* zr = z + (long)row * kC + 4 * kq;
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ii = 0; ii < 16; ++ii) {
-            const float4 zf = ld4(zr + 16 * ii);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(zf, jj), f4c(pa[ii], jj), acc, 0, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q) rowp[q] = z + (long)ext[(long)bt * N + nt * 16 + 4 * q + kq] * kC + 4 * i;
+        gt.issue(rowp);
+        const f32x4 acc = score_tile();
         // acc[r] = score of head i against negative nt*16 + 4 kq + r
         float l[4], lmax = -3.0e38f;
 #pragma unroll

@@ -75,12 +75,15 @@ def build_scheduler(optimizer, scheduler_step=-1, scheduler_ramp=None):
     return scheduler
 
 
+PREPARE_CRITERION = True       # A/B switch (tools/ab_step.py "harness.PREPARE_CRITERION" True False)
+
+
 def prepare_criterion(step, model, criterion, batch, negatives=None):
     """Queue the criterion's activation-independent share of a step (negative draws, index preparation, GEMM operand bounds) on
     the step's side stream before the encoder is launched -- CPCUnsupersivedCriterion.prepare_step; a no-op for anything else."""
     from .model import CPCAR
     prep, enc = getattr(criterion, "prepare_step", None), getattr(model, "gEncoder", None)
-    if prep is None or enc is None or not torch.is_tensor(batch) or not batch.is_cuda or batch.dim() != 3:
+    if not PREPARE_CRITERION or prep is None or enc is None or not torch.is_tensor(batch) or not batch.is_cuda or batch.dim() != 3:
         return
     ar = getattr(model, "gAR", None)
     # |c| <= 1 a priori for a GRU that starts from zero or from one of its own final states (keepHidden); a state assigned from

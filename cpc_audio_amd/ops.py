@@ -297,9 +297,9 @@ class GruFunction(torch.autograd.Function):
                     done = torch.cuda.Event()
                     done.record(main)
                     side.wait_event(done)
-                    lib.check(lib.cpc_gru_backward_coef(_p(h0c), _p(saved), _p(y), _p(coef), B, S, nl,
+                    lib.check(lib.cpc_gru_backward_coef(_p(h0c), _ptrs(params), _p(saved), _p(y), _p(coef), B, S, nl,
                                                         side.cuda_stream), "gru_backward_coef")
-                    for t in (coef, saved, y) + (() if h0c is None else (h0c,)):
+                    for t in (coef, saved, y, *params) + (() if h0c is None else (h0c,)):
                         t.record_stream(side)
                     ctx.coef_ready = torch.cuda.Event()
                     ctx.coef_ready.record(side)

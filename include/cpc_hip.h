@@ -228,8 +228,8 @@ int cpc_gru_backward(const float* x, const float* h0, const float* const* params
  * on any stream; cpc_gru_backward_with_coef(coef != NULL) then skips that work (coef == NULL: same as
  * cpc_gru_backward). */
 long cpc_gru_coef_floats(int B, int S, int nl);
-int cpc_gru_backward_coef(const float* h0, const float* saved, const float* y, float* coef, int B, int S, int nl,
-                          void* stream);
+int cpc_gru_backward_coef(const float* h0, const float* const* params, const float* saved, const float* y, float* coef, int B,
+                          int S, int nl, void* stream);
 int cpc_gru_backward_with_coef(const float* x, const float* h0, const float* const* params, const float* saved,
                                const float* y, const float* dy, const float* coef, float* scratch, float* dx,
                                float* const* grads, int B, int S, int nl, void* stream);

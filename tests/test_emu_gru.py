@@ -219,7 +219,7 @@ def test_gru_backward_with_early_coefficients_emulated():
             n = lib.cpc_gru_coef_floats(B, S, nl)
             assert n > 0
             coef = torch.full((n,), float("nan"))
-            assert lib.cpc_gru_backward_coef(None, P(saved), P(y), P(coef), B, S, nl, None) == 0
+            assert lib.cpc_gru_backward_coef(None, parr, P(saved), P(y), P(coef), B, S, nl, None) == 0
             if kind == "coef":
                 rc = lib.cpc_gru_backward_with_coef(P(x), None, parr, P(saved), P(y), P(dy), P(coef), P(bscr), P(dx), garr,
                                                     B, S, nl, None)
