@@ -293,8 +293,10 @@ int cpc_dropout_keep_mask(float* out, long n, int site, float p, unsigned long l
  * sizes[3..5] = offsets of pred, logits (B*W,K,1+N), lse (B*W,K) inside `saved`. */
 int cpc_nce_layout(int B, int S, int K, int N, long* sizes);
 /* Index preparation: the two int64 draws of sampleClean (criterion.py:181-189; B*N*W each, flat (b,n,t)
- * order) -> ext (criterion.py:191-199, laid out (b,t,n)) and the destination-sorted candidate slots
- * (perm, row_ptr) the backward gather uses.  work: B*W*(N+K) + 2*B*S + 2 ints. */
+ * order) -> ext (the rows of criterion.py:191-199, laid out (b,t,n) with the N rows of a window in ASCENDING order: the
+ * criterion is invariant under a permutation of a window's negatives, and sorted lists keep the gathers of the scoring
+ * kernels inside L2) and the destination-sorted candidate slots (perm, row_ptr) the backward uses.
+ * work: B*W*(N+K) + 2*B*S + 2 ints. */
 int cpc_nce_prepare(const long* batchIdx, const long* seqIdx, int* ext, int* perm, int* row_ptr, int* work,
                     int B, int S, int K, int N, void* stream);
 int cpc_nce_forward(const float* c, const float* z, const float* wall, const int* ext, float* saved,

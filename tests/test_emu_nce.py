@@ -70,16 +70,28 @@ def _nce_forward_backward(lib, B, S, K, N, scale):
     row_ptr = torch.full((B * S + 1,), -1, dtype=torch.int32)
     work = torch.zeros(B * W * (N + K) + 2 * B * S + 2, dtype=torch.int32)
     assert lib.cpc_nce_prepare(P(bi), P(si), P(ext_k), P(perm), P(row_ptr), P(work), B, S, K, N, None) == 0
-    assert torch.equal(ext_k, ext_t) and torch.equal(row_ptr, row_ptr_ref)
+    # (a window's negatives come back in ascending order -- the criterion is invariant under their permutation)
+    assert torch.equal(ext_k, torch.sort(ext_t, dim=2).values) and torch.equal(row_ptr, row_ptr_ref)
+    perm_sorted_ref, _ = candidate_destinations(ext_k, B, S, K)
     for r in range(B * S):
         lo, hi = int(row_ptr[r]), int(row_ptr[r + 1])
-        assert sorted(perm[lo:hi].tolist()) == perm_ref[lo:hi].tolist()
-    assert lib.cpc_nce_backward(P(c), P(z), P(wall), P(ext_t), P(perm), P(row_ptr), P(saved), P(gl), P(bscr), P(dc),
+        assert sorted(perm[lo:hi].tolist()) == perm_sorted_ref[lo:hi].tolist()
+    # (the forward above ran on the draw-order rows ext_t: the slot lists that go with THEM)
+    assert lib.cpc_nce_backward(P(c), P(z), P(wall), P(ext_t), P(perm_ref), P(row_ptr_ref), P(saved), P(gl), P(bscr), P(dc),
                                 P(dz), P(dwall), B, S, K, N, None) == 0
     assert rel_err(dc, cr.grad) < 1e-5
     assert rel_err(dz, zr.grad) < 1e-5
     ref_dw = torch.cat([leaves[f"wPrediction.predictors.{k}.weight"].grad for k in range(K)], dim=0)
     assert rel_err(dwall, ref_dw) < 1e-5
+    # ... and the whole criterion on what cpc_nce_prepare made of the same draws (rows ascending per window, slot lists placed by
+    # atomic cursors): losses and every gradient are those of the draw-order computation
+    for t_ in (saved, losses, acc, dc, dz, dwall, bscr):
+        t_.fill_(float("nan"))
+    assert lib.cpc_nce_forward(P(c), P(z), P(wall), P(ext_k), P(saved), P(fscr), P(losses), P(acc), B, S, K, N, None) == 0
+    assert (losses - lr[0].detach()).abs().max().item() < tol and (acc - ar[0]).abs().max().item() < 1e-6
+    assert lib.cpc_nce_backward(P(c), P(z), P(wall), P(ext_k), P(perm), P(row_ptr), P(saved), P(gl), P(bscr), P(dc),
+                                P(dz), P(dwall), B, S, K, N, None) == 0
+    assert rel_err(dc, cr.grad) < 1e-5 and rel_err(dz, zr.grad) < 1e-5 and rel_err(dwall, ref_dw) < 1e-5
 
 
 def test_out_of_range_negative_indices_are_clamped_and_flagged():

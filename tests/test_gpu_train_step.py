@@ -84,8 +84,12 @@ def test_train_step_matches_oracle_and_reference_golden(case, golden_dir):
         # compared directly (no oracle in between).  The reference's ReLU masks are its own: a tie (DESIGN.md
         # section 2) may flip one ChannelNorm row of the first layers, hence the looser bound on the encoder slices.
         ts = [0, 37, 80, 115]
-        assert np.abs(hip["logits"][:, ts, 0, :].permute(0, 2, 1).numpy() - fx["logits_k1"]).max() < 1e-4
-        assert np.abs(hip["logits"][:, ts, 11, :].permute(0, 2, 1).numpy() - fx["logits_k12"]).max() < 1e-4
+        # (class 0, the positive, in place; the negatives as sets: cpc_nce_prepare hands each window's negatives on in ascending
+        # row order, which the criterion cannot see)
+        for kk, key in ((0, "logits_k1"), (11, "logits_k12")):
+            mine, ref = hip["logits"][:, ts, kk, :].permute(0, 2, 1).numpy(), fx[key]
+            assert np.abs(mine[:, 0] - ref[:, 0]).max() < 1e-4
+            assert np.abs(np.sort(mine[:, 1:], axis=1) - np.sort(ref[:, 1:], axis=1)).max() < 1e-4
         g = hip["grads"]
         for key, got, tol in (("dz_slice", hip["dz"][:, ::16, ::4], 2e-4),
                               ("g_whh0_slice", g["gAR.baseNet.weight_hh_l0"][::48, ::16], 2e-4),
