@@ -76,9 +76,10 @@ SIGNATURES = {
     "cpc_dropout_keep_mask": (_I, [_P, _L, _I, _F, ctypes.c_ulonglong, _P]),
     "cpc_gru_layout": (_I, [_I, _I, _I, _P]),
     "cpc_gru_forward": (_I, [_P] * 7 + [_I, _I, _I, _P]),
+    "cpc_gru_forward_coef": (_I, [_P] * 8 + [_I, _I, _I, _P]),
     "cpc_gru_backward": (_I, [_P] * 9 + [_I, _I, _I, _P]),
     "cpc_gru_coef_floats": (_L, [_I, _I, _I]),
-    "cpc_gru_backward_coef": (_I, [_P] * 5 + [_I, _I, _I, _P]),
+    "cpc_gru_backward_coef": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
     "cpc_gru_backward_with_coef": (_I, [_P] * 10 + [_I, _I, _I, _P]),
     "cpc_gru_backward_streams": (_I, [_P] * 10 + [_I, _I, _I, _P, _P]),
     "cpc_nce_layout": (_I, [_I, _I, _I, _I, _P]),

@@ -183,6 +183,9 @@ struct Gru2Fwd {
     float* R[2]; float* Z[2]; float* N[2]; float* GHN[2];
     float* hN;                 // (2,B,H)
     float* xh[2];              // persistent launch only: hand-over copies of y[l] (see xtile)
+    float* coef[2];            // persistent launch only, optional: layer l's four backward coefficient arrays (cr, cz, cnh, cni,
+                               // frag_stride floats apart, fragment order) -- written by the gate threads, which hold every input
+    long frag_stride;          // of gru_bwd_coef_kernel in registers: that kernel's 75 MB read-back is not needed then
     int B, S;
     int spin_limit;            // persistent launch only: polling budget of a wave (cpc_set_gru_spin_limit)
     int ntiles, xcd_pack;      // persistent launch only: see PersistIds
@@ -714,9 +717,17 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
         }
         if (p.h0[LAYER]) hp = p.h0[LAYER][(long)b * kH + j];
     }
+    float* __restrict__ cf = p.coef[LAYER];
+    const int cpos = xpos(e >> 4, j);
     for (int t = 0; t < S; ++t) {
         __syncthreads();
-        if (!live) continue;
+        if (!live) {
+            if (cf) {                                             // padding rows of the last tile: zero coefficients, so that
+                const long c = xtile(t, id.tile, id.ntiles, kH) + cpos;     // the backward recurrence can load them unconditionally
+                cf[c] = 0.f; cf[c + p.frag_stride] = 0.f; cf[c + 2 * p.frag_stride] = 0.f; cf[c + 3 * p.frag_stride] = 0.f;
+            }
+            continue;
+        }
         const long bt = (long)b * S + t;
         float (&pt)[8][3][256] = part[t & 1];
         float gh[3], gi_r = gi[0], gi_z = gi[1], gi_n = gi[2];
@@ -744,6 +755,14 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
         p.N[LAYER][bt * kH + j] = n;
         p.GHN[LAYER][bt * kH + j] = gh[2];
         if (t == S - 1) p.hN[((long)LAYER * B + b) * kH + j] = h;
+        if (cf) {                                                 // gru_bwd_coef_kernel's arithmetic, on the values it would re-read
+            const float a = (1.0f - z) * (1.0f - n * n);
+            const long c = xtile(t, id.tile, id.ntiles, kH) + cpos;
+            cf[c] = a * gh[2] * r * (1.0f - r);                   // cr
+            cf[c + p.frag_stride] = (hp - n) * z * (1.0f - z);    // cz   (hp: h_{t-1})
+            cf[c + 2 * p.frag_stride] = a * r;                    // cnh
+            cf[c + 3 * p.frag_stride] = a;                        // cni
+        }
         hp = h;
         if (LAYER == 0 && t + 1 < S) {                            // next step's input projection, a step ahead
             const float* gip = p.x_gi0 + (bt + 1) * kG;
@@ -1059,8 +1078,19 @@ extern "C" int cpc_gru_layout(int B, int S, int nl, long* sizes) {
 
 // x (B,S,256); h0 NULL or (nl,B,256); params: weight_ih, weight_hh, bias_ih, bias_hh per layer
 // (torch.nn.GRU state-dict order); y (B,S,256) = last layer's output; hN (nl,B,256) final states.
+static void launch_gru_coef(const GruLayout& g, const float* h0, const float* saved, const float* y, float* coef, int B, int S,
+                            hipStream_t st);
+
 extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* const* params, float* saved,
                                float* scratch, float* y, float* hN, int B, int S, int nl, void* stream) {
+    return cpc_gru_forward_coef(x, h0, params, saved, scratch, y, hN, nullptr, B, S, nl, stream);
+}
+
+// coef != NULL (nl == 2; cpc_gru_coef_floats floats): the eight coefficient arrays of the two-layer backward are filled on the way
+// -- by the persistent forward's gate threads where that path runs, by gru_bwd_coef_kernel behind the forward otherwise --
+// and cpc_gru_backward_coef(..., coef_done = 1) only has the hand-over buffers and the weight transposes left to prepare.
+extern "C" int cpc_gru_forward_coef(const float* x, const float* h0, const float* const* params, float* saved,
+                                    float* scratch, float* y, float* hN, float* coef, int B, int S, int nl, void* stream) {
     GruLayout g;
     CPC_RETURN_IF(!gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!x || !params || !saved || !scratch || !y || !hN, CPC_ERR_ARG);
@@ -1083,6 +1113,8 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
         p.hN = hN; p.B = B; p.S = S; p.spin_limit = g_gru_spin_limit;
         p.first_sleep = g_gru_first_sleep[0];
         p.xh[0] = p.xh[1] = nullptr;
+        p.coef[0] = p.coef[1] = nullptr;
+        p.frag_stride = g.frag_floats;
         p.total_tiles = cdiv(B, 16);
         p.tile0 = 0;
         const bool h2 = g_gru_mode == 2 && !h0;
@@ -1094,6 +1126,7 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
                                  : persist_grid(gru2_persist_fwd_kernel, p.ntiles, &p.xcd_pack);
         if (nblocks > 0) {
             p.xh[0] = scratch + g.xh; p.xh[1] = scratch + g.xh + g.xh_floats;
+            if (coef) { p.coef[0] = coef; p.coef[1] = coef + 4 * g.frag_floats; }
             if (hipMemsetAsync(p.xh[0], 0xFF, 2 * g.xh_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
             for (p.tile0 = 0; p.tile0 < p.total_tiles; p.tile0 += p.ntiles) {
                 if (h2) hipLaunchKernelGGL(gru2_persist_fwd_h2_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
@@ -1104,6 +1137,7 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
         }
         const dim3 grid(kH / 16, cdiv(B, 16), 2);
         for (int s = 0; s <= S; ++s) hipLaunchKernelGGL(gru2_fwd_kernel, grid, dim3(512), 0, st, p, s);
+        if (coef) launch_gru_coef(g, h0, saved, y, coef, B, S, st);
         CPC_LAUNCH_CHECK();
         return 0;
     }
@@ -1155,11 +1189,11 @@ static void launch_gru_coef(const GruLayout& g, const float* h0, const float* sa
 // to cpc_gru_backward_with_coef -- it takes 47 us of HBM streaming off the path between the criterion and the
 // recurrence.
 extern "C" int cpc_gru_backward_coef(const float* h0, const float* const* params, const float* saved, const float* y,
-                                     float* coef, int B, int S, int nl, void* stream) {
+                                     float* coef, int coef_done, int B, int S, int nl, void* stream) {
     GruLayout g;
     CPC_RETURN_IF(nl != 2 || !gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!params || !saved || !y || !coef, CPC_ERR_ARG);
-    launch_gru_coef(g, h0, saved, y, coef, B, S, (hipStream_t)stream);
+    if (!coef_done) launch_gru_coef(g, h0, saved, y, coef, B, S, (hipStream_t)stream);     // (else: cpc_gru_forward_coef wrote them)
     {   // (3H,H) -> (H,3H), the four weight matrices in one launch: W_hh0, W_ih0, W_hh1, W_ih1 behind the hand-over buffers
         float* wT = coef + 10 * g.frag_floats;
         const float* tin[4] = {params[1], params[0], params[5], params[4]};

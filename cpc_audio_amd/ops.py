@@ -283,26 +283,31 @@ class GruFunction(torch.autograd.Function):
             scratch = torch.empty(sizes[1], device=x.device, dtype=torch.float32)
             y = torch.empty(B, S, _HID, device=x.device, dtype=torch.float32)
             hN = torch.empty(nl, B, _HID, device=x.device, dtype=torch.float32)
-            lib.check(lib.cpc_gru_forward(_p(x), _p(h0c), _ptrs(params), _p(saved), _p(scratch), _p(y), _p(hN),
-                                          B, S, nl, _stream()), "gru_forward")
-            # train loops (an overlapping StepContext): the forward-only part of the two-layer backward runs now, on the side stream,
-            # beside the criterion's forward, instead of between the criterion's backward and the recurrence
+            # train loops (an overlapping StepContext): everything of the two-layer backward that depends on the forward only is
+            # prepared now -- the gate-derivative coefficients by the forward recurrence itself (its gate threads hold their
+            # inputs in registers), the hand-over buffers and the transposed weights on a side stream beside the criterion's
+            # forward -- instead of between the criterion's backward and the recurrence
             coef = None
             step = ctx.step = current()
             if _overlap(step) and nl == 2 and any(ctx.needs_input_grad):
                 ncoef = lib.cpc_gru_coef_floats(B, S, nl)
                 if ncoef > 0:
                     coef = torch.empty(ncoef, device=x.device, dtype=torch.float32)
-                    main, side = torch.cuda.current_stream(), step.side_stream(x.device, 1)
-                    done = torch.cuda.Event()
-                    done.record(main)
-                    side.wait_event(done)
-                    lib.check(lib.cpc_gru_backward_coef(_p(h0c), _ptrs(params), _p(saved), _p(y), _p(coef), B, S, nl,
-                                                        side.cuda_stream), "gru_backward_coef")
-                    for t in (coef, saved, y, *params) + (() if h0c is None else (h0c,)):
-                        t.record_stream(side)
-                    ctx.coef_ready = torch.cuda.Event()
-                    ctx.coef_ready.record(side)
+                    # the side stream may touch this block only once the current stream has passed this point: the allocator
+                    # hands out memory whose previous user may still be queued on the current stream
+                    allocated = torch.cuda.Event()
+                    allocated.record()
+            lib.check(lib.cpc_gru_forward_coef(_p(x), _p(h0c), _ptrs(params), _p(saved), _p(scratch), _p(y), _p(hN), _p(coef),
+                                               B, S, nl, _stream()), "gru_forward")
+            if coef is not None:
+                main, side = torch.cuda.current_stream(), step.side_stream(x.device, 1)
+                side.wait_event(allocated)                       # (the work itself depends on the parameters only)
+                lib.check(lib.cpc_gru_backward_coef(_p(h0c), _ptrs(params), _p(saved), _p(y), _p(coef), 1, B, S, nl,
+                                                    side.cuda_stream), "gru_backward_coef")
+                for t in (coef, *params):
+                    t.record_stream(side)
+                ctx.coef_ready = torch.cuda.Event()
+                ctx.coef_ready.record(side)
         ctx.coef = coef
         ctx.leaves = list(leaves) if all(isinstance(q, torch.Tensor) and q.is_leaf for q in leaves) else None
         ctx.save_for_backward(x, saved, y, *params)

@@ -228,8 +228,13 @@ int cpc_gru_backward(const float* x, const float* h0, const float* const* params
  * on any stream; cpc_gru_backward_with_coef(coef != NULL) then skips that work (coef == NULL: same as
  * cpc_gru_backward). */
 long cpc_gru_coef_floats(int B, int S, int nl);
-int cpc_gru_backward_coef(const float* h0, const float* const* params, const float* saved, const float* y, float* coef, int B,
-                          int S, int nl, void* stream);
+int cpc_gru_backward_coef(const float* h0, const float* const* params, const float* saved, const float* y, float* coef,
+                          int coef_done, int B, int S, int nl, void* stream);
+/* cpc_gru_forward that also fills the coefficient arrays of `coef` (cpc_gru_coef_floats floats) on the way: the persistent
+ * forward's gate threads hold every input of those coefficients in registers.  Follow with cpc_gru_backward_coef(coef_done = 1),
+ * which then only prepares the hand-over buffers and the transposed weights. */
+int cpc_gru_forward_coef(const float* x, const float* h0, const float* const* params, float* saved, float* scratch, float* y,
+                         float* hN, float* coef, int B, int S, int nl, void* stream);
 int cpc_gru_backward_with_coef(const float* x, const float* h0, const float* const* params, const float* saved,
                                const float* y, const float* dy, const float* coef, float* scratch, float* dx,
                                float* const* grads, int B, int S, int nl, void* stream);

@@ -219,7 +219,7 @@ def test_gru_backward_with_early_coefficients_emulated():
             n = lib.cpc_gru_coef_floats(B, S, nl)
             assert n > 0
             coef = torch.full((n,), float("nan"))
-            assert lib.cpc_gru_backward_coef(None, parr, P(saved), P(y), P(coef), B, S, nl, None) == 0
+            assert lib.cpc_gru_backward_coef(None, parr, P(saved), P(y), P(coef), 0, B, S, nl, None) == 0
             if kind == "coef":
                 rc = lib.cpc_gru_backward_with_coef(P(x), None, parr, P(saved), P(y), P(dy), P(coef), P(bscr), P(dx), garr,
                                                     B, S, nl, None)
@@ -233,3 +233,23 @@ def test_gru_backward_with_early_coefficients_emulated():
     for kind in ("coef", "streams"):
         for a, b in zip(ref, backward(kind)):
             assert torch.equal(a, b), kind
+    # the coefficients written by the forward recurrence itself (cpc_gru_forward_coef) instead of read back by
+    # gru_bwd_coef_kernel: the same values, the same backward
+    n = lib.cpc_gru_coef_floats(B, S, nl)
+    coef_k = torch.full((n,), float("nan"))
+    assert lib.cpc_gru_backward_coef(None, parr, P(saved), P(y), P(coef_k), 0, B, S, nl, None) == 0
+    coef_f = torch.full((n,), float("nan"))
+    y2 = torch.full((B, S, 256), float("nan")); hN2 = torch.full((nl, B, 256), float("nan"))
+    saved2 = torch.full_like(saved, float("nan"))
+    assert lib.cpc_gru_forward_coef(P(x), None, parr, P(saved2), P(fscr), P(y2), P(hN2), P(coef_f), B, S, nl, None) == 0
+    assert torch.equal(y2, y) and torch.equal(hN2, hN)
+    assert lib.cpc_gru_backward_coef(None, parr, P(saved2), P(y2), P(coef_f), 1, B, S, nl, None) == 0
+    assert torch.equal(coef_f.view(torch.int32), coef_k.view(torch.int32))      # (bitwise: the hand-over buffers hold the 0xFFFFFFFF fill)
+    bscr = torch.full((sizes[2],), float("nan"))
+    dx = torch.full((B, S, 256), float("nan"))
+    grads = [torch.full_like(t, float("nan")) for t in plist]
+    garr = (ctypes.c_void_p * (4 * nl))(*[P(t) for t in grads])
+    assert lib.cpc_gru_backward_with_coef(P(x), None, parr, P(saved2), P(y2), P(dy), P(coef_f), P(bscr), P(dx), garr,
+                                          B, S, nl, None) == 0
+    for a, b in zip(ref, [dx] + grads):
+        assert torch.equal(a, b)

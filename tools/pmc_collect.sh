@@ -4,6 +4,7 @@
 # WRITE_SIZE do not fit one pass; no --pmc together with the sys/hip/hsa trace domains).  Writes the per-kernel means
 # to gpurun_out/pmc/pmc_counters.csv and the HBM traffic summary bench.py reads to profiles/pmc_traffic.json.
 B=${1:-64}
+TAG=${2:-r3}
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc
 mkdir -p $OUT
@@ -16,5 +17,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
   if [ -n "$db" ]; then python tools/rocpd_pmc.py $db conv_fwd_dma_kernel conv0_fwd_kernel nce_fwd_kernel | tail -n +2 >> $OUT/pmc_counters.csv; else echo "no db for $grp" >> $OUT/run.log; fi
 done
 python tools/pmc_to_json.py $OUT/pmc_counters.csv $B profiles/pmc_traffic.json
-cp $OUT/pmc_counters.csv profiles/r2_pmc_counters.csv
+cp $OUT/pmc_counters.csv profiles/${TAG}_pmc_counters.csv
 cat profiles/pmc_traffic.json

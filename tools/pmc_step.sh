@@ -4,6 +4,7 @@
 # over all launches of the run go to gpurun_out/pmc_step/pmc_step_counters.csv and, as HBM-side bytes per launch
 # ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction) + matrix-pipe busy fraction, to pmc_step_summary.txt.
 export TMPDIR=/tmp
+TAG=${1:-r3}
 OUT=gpurun_out/pmc_step
 mkdir -p $OUT
 : > $OUT/pmc_step_counters.csv
@@ -32,3 +33,4 @@ with open("gpurun_out/pmc_step/pmc_step_summary.txt", "w") as f:
         f.write(f"{mb:10.1f} MB  mfma_busy {busy:5.2f}  n={n:3d}  {name[:110]}\n")
 print(open("gpurun_out/pmc_step/pmc_step_summary.txt").read()[:3500])
 PY
+cp $OUT/pmc_step_summary.txt profiles/${TAG}_pmc_step_summary.txt; cp $OUT/pmc_step_counters.csv profiles/${TAG}_pmc_step_counters.csv
