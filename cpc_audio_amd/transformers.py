@@ -5,9 +5,11 @@ Same class names, constructor signatures, parameter / buffer names (state-dict k
 and the same ``buildTransformerAR`` factory (cpc/transformers.py:130-139), so checkpoints load both ways.  A
 ``TransformerLayer`` runs as ONE fused HIP layer (csrc/transformer.hip); the sub-modules are parameter holders.
 
-Dropout: the reference hard-codes p = 0.1 inside TransformerLayer (cpc/transformers.py:93); the HIP layer has no
-dropout, so training-mode calls require ``dropout=0`` (the constructors keep the argument) and eval-mode calls
-ignore it, which is also the only setting with a defined parity.
+Dropout: the reference hard-codes p = 0.1 inside TransformerLayer (cpc/transformers.py:18,93,100).  The HIP layer applies
+it in training mode inside its kernels -- Philox4x32-10 keep-masks derived from a 64-bit seed the layer draws per call and
+regenerated (not stored) in the backward pass; ``cpc_dropout_keep_mask`` returns the masks of a seed so that the oracle can be
+run with the very same ones (tests/test_gpu_transformer.py) -- and ignores it in eval mode.  ``dropout=0`` is the setting with
+a parity that does not depend on the random stream.
 """
 import math
 
