@@ -184,129 +184,184 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(
     }
 }
 
-// Backward of layer 0.  Per time step it recomputes conv0 -> xhat from the waveform and
-// the saved (mean, rstd), applies relu'/norm backward to the incoming dY (gradient
-// w.r.t. the post-ReLU activation, produced by conv1's dgrad) and accumulates, in
-// registers, the gradients of conv0.weight (256x10), conv0.bias, batchNorm0.weight and
-// batchNorm0.bias.  The waveform needs no gradient (cpc/train.py:81-87), so there is
-// no dgrad.  Each block reduces its waves through LDS and writes one partial row
-// [13][256] to `part`; a second tiny kernel sums the partial rows in a fixed order
-// (deterministic, no float atomics).
-constexpr int C0B_TT = 256;                // time steps per block in backward (64 per wave); measured alone at B = 64, with
-constexpr int C0B_NBW = 2;                 // C0B_NBW rows in flight per wave: 64/1 174 us, 256/1 138, 256/2 140, 256/4 125 (the
-                                           // last one slower inside the step, beside the layer-1 weight gradient)
+// Backward of layer 0, on the layout of the forward kernel above: a wavefront takes 16 time steps x 256 channels at a time,
+// recomputes conv0 (+ bias) with the SAME three exact-f32 MFMAs per 16 x 16 tile -- so x, and with the saved (mean, rstd) xhat
+// and the ReLU mask, are bit-identical to the forward's -- applies relu' / ChannelNorm backward to the incoming dY (gradient
+// w.r.t. the post-ReLU activation, produced by conv1's data gradient), and forms the gradients of conv0.weight (256 x 10) and
+// conv0.bias as a second product on the matrix pipe:  D[16 channels x 16 taps] += dX^T[16 x 4 steps] . S[4 steps x 16 taps] per
+// tile and step quad, S = the steps' sample windows with a column of ones at tap 10 (the bias gradient) -- the accumulator
+// registers of the recomputation, turned into dx in place, ARE the A operand.  The VALU is left with the norm backward itself
+// (14 operations per element; the scalar kernel of rounds 1-2 spent 32, 20 of them FMAs of the two 10-tap contractions) and the
+// per-channel sums for batchNorm0.weight / .bias.  The waveform needs no gradient (cpc/train.py:81-87), so there is no dgrad.
+// Each block reduces its waves through LDS and writes one partial row [13][256] to `part`; a second tiny kernel sums the partial
+// rows in a fixed order (deterministic, no float atomics).
+constexpr int C0B_GPW = 4;                 // 16-step groups per wave
+constexpr int C0B_TT = 64 * C0B_GPW;       // time steps per block of four waves
 constexpr int C0B_NS = S0 * C0B_TT + (K0 - S0);
 constexpr int C0_NACC = K0 + 3;            // 10 weight taps, conv bias, norm weight, norm bias
 
 // DYB: dy arrives as bf16 (the bf16-storage variant) instead of fp32
 template <bool DYB>
-__global__ __launch_bounds__(256) void conv0_bwd_kernel(
+__global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(
     const float* __restrict__ wave, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, const float* __restrict__ mean_in,
     const float* __restrict__ rstd_in, const float* __restrict__ dy, float* __restrict__ part,
     int L, int L0) {
-    __shared__ float smp[C0B_NS];
-    __shared__ float red[4][C0_NACC][kC];
+    // One LDS block, two lives.  In the loop: operand tables -- wT[12][kC] (conv0.weight transposed [tap][channel], tap 10 = bias,
+    // tap 11 = 0), aff[2][kC] (ChannelNorm weight / bias), smp (the block's waveform window, zero-padded) -- and gb, the running
+    // sums for batchNorm0.weight / .bias, one private slice per (wave, lane group): [4][4][2][kC] (in registers they would be the
+    // 32 that push the kernel into spilling).  At the end: red[4][13][kC], the waves' sums.
+    constexpr int kTab = 12 * kC + 2 * kC + ((C0B_NS + 15) & ~15);
+    constexpr int kGb = 4 * 4 * 2 * kC;
+    constexpr int kRed = 4 * C0_NACC * kC;
+    __shared__ float lds[kTab + kGb > kRed ? kTab + kGb : kRed];
+    float (*wT)[kC] = reinterpret_cast<float (*)[kC]>(lds);
+    float (*aff)[kC] = reinterpret_cast<float (*)[kC]>(lds + 12 * kC);
+    float* smp = lds + 14 * kC;
+    float (*red)[C0_NACC][kC] = reinterpret_cast<float (*)[C0_NACC][kC]>(lds);
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * C0B_TT;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t00 = blockIdx.x * C0B_TT;
     const float* wb = wave + (long)b * L;
-    const int s_begin = t0 * S0 - P0;
-    for (int i = tid; i < C0B_NS; i += 256) {
-        int s = s_begin + i;
-        smp[i] = ((unsigned)s < (unsigned)L) ? wb[s] : 0.f;
+    aff[0][threadIdx.x] = nw[threadIdx.x];
+    aff[1][threadIdx.x] = nb[threadIdx.x];
+    wT[K0][threadIdx.x] = bias[threadIdx.x];
+    wT[K0 + 1][threadIdx.x] = 0.f;
+    for (int e = threadIdx.x; e < kC * K0; e += 256) wT[e % K0][e / K0] = w[e];
+    for (int i = threadIdx.x; i < C0B_NS; i += 256) {
+        const int sidx = t00 * S0 - P0 + i;
+        const float v = wb[sidx < 0 ? 0 : (sidx < L ? sidx : L - 1)];       // unconditional load from a clamped index, then a select
+        smp[i] = ((unsigned)sidx < (unsigned)L) ? v : 0.f;
     }
-    // conv0.weight via LDS (coalesced global read); `red` is free until the final reduction
-    float* wT = &red[0][0][0];                   // [K0][kC]
-    for (int e = tid; e < kC * K0; e += 256) wT[(e % K0) * kC + e / K0] = w[e];
+    for (int i = threadIdx.x; i < kGb; i += 256) lds[kTab + i] = 0.f;
     __syncthreads();
-    float wr[4][K0], br[4], gw[4], gb[4];
-    const int c = lane * 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    float* gb = lds + kTab + (wv * 4 + kq) * 2 * kC;     // this lane group's sums: [0][c] d batchNorm0.weight, [1][c] d batchNorm0.bias
+    // dw[T][e]: d conv0.weight / bias of channel ch(4 kq + e, T), tap n (the D layout of the second product: column = lane & 15 =
+    // tap, row 4 kq + e = channel of the tile).  ch(m, T) = 64 (T >> 2) + 4 m + (T & 3).
+    f32x4 dw[16];
 #pragma unroll
-    for (int j = 0; j < K0; ++j) {
-        const float4 wv4 = *reinterpret_cast<const float4*>(wT + j * kC + c);
-        wr[0][j] = wv4.x; wr[1][j] = wv4.y; wr[2][j] = wv4.z; wr[3][j] = wv4.w;
-    }
-    {
-        const float4 b4 = *reinterpret_cast<const float4*>(bias + c);
-        const float4 w4 = *reinterpret_cast<const float4*>(nw + c);
-        const float4 n4 = *reinterpret_cast<const float4*>(nb + c);
-        br[0] = b4.x; br[1] = b4.y; br[2] = b4.z; br[3] = b4.w;
-        gw[0] = w4.x; gw[1] = w4.y; gw[2] = w4.z; gw[3] = w4.w;
-        gb[0] = n4.x; gb[1] = n4.y; gb[2] = n4.z; gb[3] = n4.w;
-    }
-    __syncthreads();                             // all lanes have their weights before `red` is reused
-    float acc[4][C0_NACC];
+    for (int T = 0; T < 16; ++T) dw[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tg0 = t00 + wv * C0B_GPW * 16;
+    for (int gi = 0; gi < C0B_GPW; ++gi) {
+        const int tg = tg0 + gi * 16;
+        if (tg >= L0) break;                                             // wave-uniform
+        // ---- conv0 again: the forward kernel's operands and instruction sequence
+        float a[3];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int j = 0; j < C0_NACC; ++j) acc[q][j] = 0.f;
-    __syncthreads();
-    // C0B_NBW rows of this wave at a time: their loads, the two wave reductions each needs and the ~130 VALU operations
-    // per row interleave instead of queueing behind one another (one row at a time: 153 us alone at B = 64)
-    for (int tt0 = wv; tt0 < C0B_TT; tt0 += 4 * C0B_NBW) {
-        if (t0 + tt0 >= L0) break;               // wave-uniform
-        float g[C0B_NBW][4], mu[C0B_NBW], rstd[C0B_NBW];
-        bool live[C0B_NBW];
-#pragma unroll
-        for (int u = 0; u < C0B_NBW; ++u) {
-            const int tt = tt0 + 4 * u;
-            live[u] = tt < C0B_TT && t0 + tt < L0;
-            const long row = (long)b * L0 + (live[u] ? t0 + tt : t0 + tt0);
-            if constexpr (DYB) {
-                const uint2 gb = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dy) + row * kC + c);
-                g[u][0] = bf16_val((unsigned short)(gb.x & 0xFFFFu)); g[u][1] = bf16_val((unsigned short)(gb.x >> 16));
-                g[u][2] = bf16_val((unsigned short)(gb.y & 0xFFFFu)); g[u][3] = bf16_val((unsigned short)(gb.y >> 16));
-            } else {
-                const float4 g4 = *reinterpret_cast<const float4*>(dy + row * kC + c);
-                g[u][0] = g4.x; g[u][1] = g4.y; g[u][2] = g4.z; g[u][3] = g4.w;
-            }
-            mu[u] = mean_in[row]; rstd[u] = rstd_in[row];
+        for (int kk = 0; kk < 3; ++kk) {
+            const int j = 4 * kk + kq;
+            const float v = smp[(tg - t00 + n) * S0 + (j < K0 ? j : 0)];
+            a[kk] = j < K0 ? v : (j == K0 ? 1.0f : 0.f);
         }
-        float sv[C0B_NBW][K0], xh[C0B_NBW][4], dxh[C0B_NBW][4], s1[C0B_NBW], s2[C0B_NBW];
+        f32x4 x[16];
+        {
+            float wt[16][3];
 #pragma unroll
-        for (int u = 0; u < C0B_NBW; ++u) {
-            const int tt = live[u] ? tt0 + 4 * u : tt0;
+            for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
-            for (int j = 0; j < K0; ++j) sv[u][j] = smp[tt * S0 + j];
-            s1[u] = 0.f; s2[u] = 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(&wT[4 * kk + kq][64 * q + 4 * n]);
+                    wt[4 * q + 0][kk] = v.x; wt[4 * q + 1][kk] = v.y; wt[4 * q + 2][kk] = v.z; wt[4 * q + 3][kk] = v.w;
+                }
+#pragma unroll
+            for (int T = 0; T < 16; ++T) {
+                x[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) x[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wt[T][kk], x[T], 0, 0, 0);
+            }
+        }
+        // ---- the lane's four steps in two halves (r = 0, 1 and r = 2, 3): a step's reductions run over channels only, so the
+        // halves are independent, and only half of dy (32 registers) is in flight at a time beside x and the gradient tiles
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            // what this half reads from memory: dy of 2 steps x 16 channels, their mean / rstd.  Steps beyond L0 read a valid
+            // row and are masked out below.
+            float4 dyv[2][4];                                            // [r2][q]: channels 64 q + 4 n .. of step tg + 4 kq + 2 hf + r2
+            float mu[2], rs[2];
+            bool live[2];
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                const int t = tg + 4 * kq + 2 * hf + r2;
+                live[r2] = t < L0;
+                const long row = (long)b * L0 + (live[r2] ? t : tg);
+                mu[r2] = mean_in[row];
+                rs[r2] = rstd_in[row];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if constexpr (DYB) {
+                        const uint2 gbits = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dy) + row * kC + 64 * q + 4 * n);
+                        dyv[r2][q] = make_float4(bf16_val((unsigned short)(gbits.x & 0xFFFFu)), bf16_val((unsigned short)(gbits.x >> 16)),
+                                                 bf16_val((unsigned short)(gbits.y & 0xFFFFu)), bf16_val((unsigned short)(gbits.y >> 16)));
+                    } else {
+                        dyv[r2][q] = *reinterpret_cast<const float4*>(dy + row * kC + 64 * q + 4 * n);
+                    }
+                }
+            }
+            // relu' and ChannelNorm backward; x[T][r] becomes xhat, dyv becomes dxhat, then x becomes dx
+            float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float x = br[q];
+                const float4 g4 = *reinterpret_cast<const float4*>(&aff[0][64 * q + 4 * n]);
+                const float4 n4 = *reinterpret_cast<const float4*>(&aff[1][64 * q + 4 * n]);
+                float4 dg = *reinterpret_cast<const float4*>(gb + 64 * q + 4 * n);
+                float4 db = *reinterpret_cast<const float4*>(gb + kC + 64 * q + 4 * n);
 #pragma unroll
-                for (int j = 0; j < K0; ++j) x = fmaf(wr[q][j], sv[u][j], x);
-                xh[u][q] = (x - mu[u]) * rstd[u];
-                const float yv = fmaf(xh[u][q], gw[q], gb[q]);
-                const float dyh = (live[u] && yv > 0.f) ? g[u][q] : 0.f;   // relu'
-                acc[q][K0 + 1] = fmaf(dyh, xh[u][q], acc[q][K0 + 1]);       // d batchNorm0.weight
-                acc[q][K0 + 2] += dyh;                                      // d batchNorm0.bias
-                dxh[u][q] = dyh * gw[q];
-                s1[u] += dxh[u][q];
-                s2[u] = fmaf(dxh[u][q], xh[u][q], s2[u]);
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int T = 4 * q + e, r = 2 * hf + r2;
+                        const float xh = (x[T][r] - mu[r2]) * rs[r2];
+                        const float yv = fmaf(xh, f4c(g4, e), f4c(n4, e));
+                        const float dyh = (live[r2] && yv > 0.f) ? f4c(dyv[r2][q], e) : 0.f;     // relu'
+                        (&dg.x)[e] = fmaf(dyh, xh, (&dg.x)[e]);                                  // d batchNorm0.weight
+                        (&db.x)[e] += dyh;                                                       // d batchNorm0.bias
+                        const float dxh = dyh * f4c(g4, e);
+                        s1[r2] += dxh;
+                        s2[r2] = fmaf(dxh, xh, s2[r2]);
+                        x[T][r] = xh;
+                        (&dyv[r2][q].x)[e] = dxh;
+                    }
+                *reinterpret_cast<float4*>(gb + 64 * q + 4 * n) = dg;
+                *reinterpret_cast<float4*>(gb + kC + 64 * q + 4 * n) = db;
+            }
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                const int r = 2 * hf + r2;
+                const float m1 = row16_sum(s1[r2]) * (1.0f / kC), m2 = row16_sum(s2[r2]) * (1.0f / (kC - 1));
+#pragma unroll
+                for (int T = 0; T < 16; ++T)
+                    x[T][r] = live[r2] ? rs[r2] * (f4c(dyv[r2][T >> 2], T & 3) - m1 - x[T][r] * m2) : 0.f;
+                // d conv0.weight / bias: D[channel][tap] += dx[step][channel] * S[step][tap], steps r, 4 + r, 8 + r, 12 + r per MFMA
+                const float sv = smp[(tg - t00 + 4 * kq + r) * S0 + (n < K0 ? n : 0)];
+                const float bop = n < K0 ? sv : (n == K0 ? 1.0f : 0.f);   // B operand: tap n of step tg + 4 kq + r
+#pragma unroll
+                for (int T = 0; T < 16; ++T) dw[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[T][r], bop, dw[T], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int u = 0; u < C0B_NBW; ++u) {
-            s1[u] = wave_sum(s1[u]) * (1.0f / kC);
-            s2[u] = wave_sum(s2[u]) * (1.0f / (kC - 1));
-        }
-#pragma unroll
-        for (int u = 0; u < C0B_NBW; ++u)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float dx = live[u] ? rstd[u] * (dxh[u][q] - s1[u] - xh[u][q] * s2[u]) : 0.f;
-                acc[q][K0] += dx;                                    // d conv0.bias
-#pragma unroll
-                for (int j = 0; j < K0; ++j) acc[q][j] = fmaf(dx, sv[u][j], acc[q][j]);   // d conv0.weight
-            }
     }
+    // ---- the block's sums.  d batchNorm0.*: the four lane groups of a wave hold different steps of the same channels; lane
+    // (n, kq) folds their slices for channels 64 kq + 4 n ..
+    float4 dgs = make_float4(0.f, 0.f, 0.f, 0.f), dbs = dgs;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int k2 = 0; k2 < 4; ++k2) {
+        const float* g2 = lds + kTab + (wv * 4 + k2) * 2 * kC + 64 * kq + 4 * n;
+        const float4 u = *reinterpret_cast<const float4*>(g2), v = *reinterpret_cast<const float4*>(g2 + kC);
+        dgs.x += u.x; dgs.y += u.y; dgs.z += u.z; dgs.w += u.w;
+        dbs.x += v.x; dbs.y += v.y; dbs.z += v.z; dbs.w += v.w;
+    }
+    __syncthreads();                                                     // everybody is done with the tables and the slices
+    *reinterpret_cast<float4*>(&red[wv][K0 + 1][64 * kq + 4 * n]) = dgs;
+    *reinterpret_cast<float4*>(&red[wv][K0 + 2][64 * kq + 4 * n]) = dbs;
+    if (n <= K0) {
 #pragma unroll
-        for (int j = 0; j < C0_NACC; ++j) red[wv][j][c + q] = acc[q][j];
+        for (int T = 0; T < 16; ++T)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wv][n][64 * (T >> 2) + 4 * (4 * kq + e) + (T & 3)] = dw[T][e];
+    }
     __syncthreads();
     float* prow = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (C0_NACC * kC);
-    for (int i = tid; i < C0_NACC * kC; i += 256) {
+    for (int i = threadIdx.x; i < C0_NACC * kC; i += 256) {
         const int j = i / kC, cc = i - j * kC;
         prow[i] = (red[0][j][cc] + red[1][j][cc]) + (red[2][j][cc] + red[3][j][cc]);
     }
