@@ -37,6 +37,7 @@ SIGNATURES = {
     "cpc_set_conv0_tuning": (_I, [_I, _I]),
     "cpc_set_h2_layers": (_I, [_I]),
     "cpc_set_h2_dx": (_I, [_I]),
+    "cpc_set_wgrad1_early": (_I, [_I]),
     "cpc_set_wgrad_dma_groups": (_I, [_I]),
     "cpc_set_gemm_split": (_I, [_I]),
     "cpc_set_gru_xcd_pack": (_I, [_I]),

@@ -889,6 +889,13 @@ extern "C" int cpc_set_dma_tile(int bm) {
     g_dma_bm = bm;
     return 0;
 }
+// 0 (default): layer 1's weight gradient is released behind its data gradient; 1: together with dx1, i.e. beside that data gradient
+static int g_wgrad1_early = 0;
+extern "C" int cpc_set_wgrad1_early(int on) {
+    g_wgrad1_early = on ? 1 : 0;
+    return 0;
+}
+
 extern "C" int cpc_set_h2_dx(int on) {
     g_h2_dx = on ? 1 : 0;
     g_wgrad_dma = on == 2 ? 0 : 1;            // 2: H2 gradient, but its weight gradient on the register-staged TN tile (A/B)
@@ -1277,11 +1284,12 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
         // dx_i and its bound are final: the weight gradient may start -- except layer 1's, which is as long as its
         // dgrad and only slows it down when both fight for the matrix pipes (0.66 + 0.44 ms together vs 0.29 + 0.30 alone);
         // it is released behind that dgrad and runs beside conv0's VALU-bound backward instead
-        if (ev && i > 1) {
+        const bool late1 = ev && i == 1 && !g_wgrad1_early;
+        if (ev && !late1) {
             if (hipEventRecord(ev[i], st) != hipSuccess || hipStreamWaitEvent(wst, ev[i], 0) != hipSuccess)
                 return CPC_ERR_ARG;
         }
-        if (!(ev && i == 1))
+        if (!late1)
         rc = wgrad(i, xin);
         if (rc) return rc;
         if (e.bf16) {
@@ -1320,7 +1328,7 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                                  kGeom[1].s, kGeom[1].p, st, kAmaxSlots);
         }
         if (rc) return rc;
-        if (ev && i == 1) {
+        if (late1) {
             if (hipEventRecord(ev[1], st) != hipSuccess || hipStreamWaitEvent(wst, ev[1], 0) != hipSuccess) return CPC_ERR_ARG;
             rc = wgrad(1, xin);
         }

@@ -96,6 +96,7 @@ int cpc_set_conv0_tuning(int groups, int nontemporal);   /* layer-0 forward kern
 int cpc_set_dma_tile(int bm);
 int cpc_set_h2_layers(int n);            /* mode 3: 1 = only conv1, 2 = conv1 and conv2 read H2 input; 0 = by problem size */
 int cpc_set_wgrad_dma_groups(int wgs);  /* workgroups the DMA weight gradient aims at (row splits = wgs / taps); 64..512 */
+int cpc_set_wgrad1_early(int on);        /* two-stream encoder backward: 0 (default) layer 1's weight gradient behind its data gradient, 1 beside it */
 int cpc_set_h2_dx(int on);               /* mode 3: 1 (default) keeps the gradient dx of every layer whose input is in H2 storage in H2 storage
                                             too (layer 1; layer 2 where conv2 reads H2 input): data gradient on the DMA kernel, weight
                                             gradient on DMA + transposing LDS reads; 2: the same with the weight gradient on the
