@@ -657,6 +657,11 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_dgr
     const int ph = slot % s, tile = (slot / s) * 8 + xcd;
     const int m0 = tile * BM;
     if (m0 >= am.M) return;                                        // block-uniform
+    // Exact rows (dgrad_rows_exact, am.R == Lout): phase ph covers q = q0 .. q0 + Lout - 1, the only rows whose tau is inside
+    // [0, Lin) when Lin == s * Lout -- B * Lout rows per phase instead of B * (Lout + 1), i.e. no ragged last tile.
+    const int q0 = (am.R == am.Lin && ph < p) ? 1 : 0;
+    am.off += q0 * kC;
+    am.tadd += q0;
     f32x16 acc[TM][TN];
     dma_gemm<C>(acc, am, m0, wd + (long)ph * (kC * 2 * kC * C::ESZ), 2 * kC, zeros, rot_step, smem);
     const bool odd = lane & 1;
@@ -669,7 +674,7 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_dgr
             const int m = m0 + dma_c_row(tm, r);
             long o = -1;
             if (m < am.M) {
-                const int b = m / am.R, q = m - b * am.R;
+                const int b = m / am.R, q = m - b * am.R + q0;
                 const int tau = q * s + ph - p;
                 if ((unsigned)tau < (unsigned)Lin) o = (long)b * Lin + tau;
             }
@@ -1070,8 +1075,7 @@ int conv_dgrad_dma_bf16(const void* dx, const void* wd, void* dprev, const float
     if (k != 2 * s) return CPC_ERR_SHAPE;
     const int Lout = conv_out_len(Lin, k, s, p);
     RowMap am;                                           // 2-row windows [q-1, q] over dx, q in [0, Lout] (enc_conv.hip)
-    am.base = reinterpret_cast<const float*>(dx); am.R = Lout + 1; am.bstride = (long)Lout * kC; am.rstride = kC; am.off = -kC;
-    am.tmul = 1; am.tadd = -1; am.Lin = Lout; am.M = B * (Lout + 1);
+    am = dgrad_rows(reinterpret_cast<const float*>(dx), B, Lin, Lout, s, p);
     const unsigned char* wdb = reinterpret_cast<const unsigned char*>(wd);
     const unsigned char* zb = reinterpret_cast<const unsigned char*>(zeros);
 #define CPC_LAUNCH_DMA(BM_)                                                                                                    \
@@ -1094,8 +1098,7 @@ int conv_dgrad_dma_h2(const void* dx_h2, const float* wd, float* dprev, const fl
     if (k != 2 * s) return CPC_ERR_SHAPE;
     const int Lout = conv_out_len(Lin, k, s, p);
     RowMap am;                                           // 2-row windows [q-1, q] over dx, q in [0, Lout] (enc_conv.hip)
-    am.base = reinterpret_cast<const float*>(dx_h2); am.R = Lout + 1; am.bstride = (long)Lout * kC; am.rstride = kC; am.off = -kC;
-    am.tmul = 1; am.tadd = -1; am.Lin = Lout; am.M = B * (Lout + 1);
+    am = dgrad_rows(reinterpret_cast<const float*>(dx_h2), B, Lin, Lout, s, p);
     const unsigned char* wdb = reinterpret_cast<const unsigned char*>(wd);
     const float* w_amax = wd + (long)kC * k * kC;
     const unsigned char* zb = reinterpret_cast<const unsigned char*>(zeros);

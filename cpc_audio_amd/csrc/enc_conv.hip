@@ -492,6 +492,9 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
     __shared__ float colsum[3][kC];
     const int m0 = blockIdx.x * BM;
     const int ph = blockIdx.y;
+    const int q0 = (am.R == am.Lin && ph < p) ? 1 : 0;              // exact rows (dgrad_rows): phase ph starts at q = q0
+    am.off += q0 * kC;
+    am.tadd += q0;
     f32x16 acc[TM][TN];
     zero_acc(acc);
     if constexpr (ConvCfg<BM, MODE>::H2) {
@@ -526,7 +529,7 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
             const int m = m0 + Tile::c_row(tm, r);
             int o = -1;
             if (m < am.M) {
-                const int b = m / am.R, q = m - b * am.R;
+                const int b = m / am.R, q = m - b * am.R + q0;
                 const int tau = q * s + ph - p;
                 if ((unsigned)tau < (unsigned)Lin) o = b * Lin + tau;
             }
@@ -1026,8 +1029,7 @@ static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const flo
     const float* w_amax = wd + (long)kC * k * kC;
     // 2-row windows [q-1, q] over dx, q in [0, Lout]
     RowMap am;
-    am.base = dx; am.R = Lout + 1; am.bstride = (long)Lout * kC; am.rstride = kC; am.off = -kC;
-    am.tmul = 1; am.tadd = -1; am.Lin = Lout; am.M = B * (Lout + 1);
+    am = dgrad_rows(dx, B, Lin, Lout, s, p);
     const int bm = pick_bm(am.M);
     const int nblk = cdiv(am.M, bm) * s;
     if (fuse) {

@@ -44,6 +44,20 @@ static inline RowMap plain_rows(const float* base, int M, int ld) {
     return r;
 }
 
+// Rows of a data-gradient phase GEMM (k = 2s): the 2-row windows [q-1, q] over dx (B, Lout, C).  Phase r of input step
+// tau = q*s + r - p takes q over [0, Lout]; when Lin == s * Lout (every layer of the encoder at window sizes that are multiples
+// of 160) exactly Lout of those Lout + 1 rows have tau inside [0, Lin): q >= 1 for the phases r < p, q <= Lout - 1 for the
+// others.  Then R = Lout (the "exact" rows: the kernels see R == Lin of the map and start phase r at q0 = r < p), B * Lout rows
+// per phase and no ragged last tile -- B * (Lout + 1) rows cost a whole extra round of 256-row tiles for 4 workgroups' worth
+// of live rows at B = 64.
+static inline RowMap dgrad_rows(const float* dx, int B, int Lin, int Lout, int s, int p) {
+    const bool exact = Lin == s * Lout && p > 0 && p < s;
+    RowMap r;
+    r.base = dx; r.R = exact ? Lout : Lout + 1; r.bstride = (long)Lout * kC; r.rstride = kC; r.off = -kC;
+    r.tmul = 1; r.tadd = -1; r.Lin = Lout; r.M = B * r.R;
+    return r;
+}
+
 // im2col rows of an (B, Lin, C) channels-last activation for a conv (k, s, p):
 // row (b,t) is the contiguous window x[b, t*s-p : t*s-p+k, :]  (k*C floats).
 static inline RowMap conv_rows(const float* x, int B, int Lin, int Lout, int s, int p) {
