@@ -23,10 +23,13 @@ struct GemmBounds {
     const float* a = nullptr;
     const float* b = nullptr;
     int a_slots = 1, b_slots = 1;
+    long a_gs = 0, b_gs = 0;    // grouped launches (GemmGroup): problem g reads its bounds at a + g * a_gs / b + g * b_gs
 };
 // max|x| of up to 4 arrays in one launch, as kAmaxSlots partial maxima each (no memset, no atomics): out[j*64 .. j*64+63]
 // (x[j] == NULL: the bound of job j is known a priori -- its slots all carry cval[j])
 int absmax_slots(const float* const* x, const long* n, int njobs, float* out, hipStream_t st, const float* cval = nullptr);
+// the same for G equally sized arrays per job (array g of job j at x[j] + g * x_gs[j]): out[j * kAmaxSlots + g * out_gs + slot]
+int absmax_group(const float* const* x, const long* n, const long* x_gs, int njobs, int G, float* out, long out_gs, hipStream_t st);
 
 // G equally shaped problems in one launch (blockIdx.z / .y picks the problem): problem g reads and writes at the given
 // pointers + g * stride (floats).  A stride of 0 shares the operand between the problems.

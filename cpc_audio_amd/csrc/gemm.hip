@@ -56,6 +56,8 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
         const long g = blockIdx.z;
         am.base += g * grp.a; Bmat += g * grp.b; C += g * grp.c;
         if (bias) bias += g * grp.bias;
+        if (gb.a) gb.a += g * gb.a_gs;
+        if (gb.b) gb.b += g * gb.b_gs;
     }
     f32x16 acc[NtG::TM][NtG::TN];
     zero_acc(acc);
@@ -95,6 +97,8 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(RowMap am, RowMap bm, int 
     if (grp.G > 1) {                                     // problem blockIdx.y of a group; its partials behind the previous one's
         const long g = blockIdx.y;
         am.base += g * grp.a; bm.base += g * grp.b; part += grp.part ? g * grp.part : g * S * zstride;
+        if (gb.a) gb.a += g * gb.a_gs;
+        if (gb.b) gb.b += g * gb.b_gs;
     }
     const int tn2 = N2 / 128, T = (N1 / 128) * tn2;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -260,6 +264,24 @@ __global__ __launch_bounds__(1024) void absmax_slots_kernel(AbsmaxJobs jobs, flo
     }
 }
 
+// grid (kAmaxSlots, G, njobs), 256 threads: slot s of array g of job j (weights: a few thousand elements per slot)
+struct AbsmaxGroupJobs { const float* x[4]; long n[4]; long gs[4]; };
+__global__ __launch_bounds__(256) void absmax_group_kernel(AbsmaxGroupJobs jobs, float* __restrict__ out, long out_gs) {
+    __shared__ float red[4];
+    const int j = blockIdx.z;
+    const float* __restrict__ x = jobs.x[j] + (long)blockIdx.y * jobs.gs[j];
+    const long n = jobs.n[j];
+    const long per = (n + kAmaxSlots - 1) / kAmaxSlots;
+    const long beg = (long)blockIdx.x * per, end = beg + per < n ? beg + per : n;
+    float m = 0.f;
+    for (long i = beg + threadIdx.x; i < end; i += 256) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[(long)j * kAmaxSlots + (long)blockIdx.y * out_gs + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 int g_gemm_wide = 1;
 int g_gemm_split = 1;      // cpc_set_gemm_split: 0 keeps every plain GEMM on three bf16 pieces, bounds or not
 
@@ -397,6 +419,18 @@ int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, flo
     else
         hipLaunchKernelGGL((tn_gemm_kernel<TnG>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n, bounds, grp);
     hipLaunchKernelGGL(split_reduce_kernel, dim3(cdiv(n, 256), grp.G), dim3(256), 0, st, part, S, n, C, accumulate, grp.c, grp.part);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+int absmax_group(const float* const* x, const long* n, const long* x_gs, int njobs, int G, float* out, long out_gs, hipStream_t st) {
+    if (njobs <= 0 || njobs > 4 || G <= 0) return CPC_ERR_ARG;
+    AbsmaxGroupJobs jobs;
+    for (int j = 0; j < 4; ++j) {
+        const int u = j < njobs ? j : 0;
+        jobs.x[j] = x[u]; jobs.n[j] = n[u]; jobs.gs[j] = x_gs[u];
+    }
+    hipLaunchKernelGGL(absmax_group_kernel, dim3(kAmaxSlots, G, njobs), dim3(256), 0, st, jobs, out, out_gs);
     CPC_LAUNCH_CHECK();
     return 0;
 }

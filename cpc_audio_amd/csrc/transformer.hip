@@ -64,6 +64,41 @@ struct TfStrides {
     long par[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+// Operand bounds for the GEMMs (GemmBounds, cpc_internal.h: with max|A| and max|B| known a product runs on the fp16 pipe with
+// two-piece operands, 3 MFMAs instead of the 6 of three bf16 pieces).  Every tensor a GEMM of the layer reads is written by one
+// of the kernels below, which leaves max|.| of what it wrote in kAmaxSlots slots (zeroed by the host before; integer atomicMax
+// on the bits of non-negative floats; slot by workgroup, so that no address takes more than a few hundred atomics).  The layers
+// Every layer of a group keeps its own bounds (in its own copy of the workspace: `amax` arrives with the layer's offset), so a
+// layer computes the same bits inside a group as alone.
+__device__ __forceinline__ void publish_amax(float* __restrict__ amax, float m) {        // every lane of the wave must call
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && amax != nullptr)
+        atomicMax(reinterpret_cast<unsigned*>(amax) + blockIdx.x % (unsigned)kAmaxSlots, __float_as_uint(m));
+}
+// one atomic per workgroup of 256 threads (atomics of different XCDs on one address take ~1 us each: a kernel must not issue
+// more than a few dozen per slot); every thread of the workgroup must call
+__device__ __forceinline__ void publish_amax_block(float* __restrict__ amax, float m) {
+    __shared__ float wmax[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0 && amax != nullptr)
+        atomicMax(reinterpret_cast<unsigned*>(amax) + blockIdx.x % (unsigned)kAmaxSlots,
+                  __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+__device__ __forceinline__ float amax4(float m, const float4& v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+// Layer blockIdx.x's bound bookkeeping at the start of a forward (nz = 0: backward) pass: out = max(a, b, c) slot by slot (the
+// stacked [Wq; Wk; Wv] of the backward), and the nz slots from `zero` on cleared for the kernels' atomicMax.
+__global__ __launch_bounds__(kAmaxSlots) void bounds_begin_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                                  const float* __restrict__ b, const float* __restrict__ c,
+                                                                  float* __restrict__ zero, int nz, long gs) {
+    const long g = (long)blockIdx.x * gs;
+    if (out != nullptr) out[g + threadIdx.x] = fmaxf(a[g + threadIdx.x], fmaxf(b[g + threadIdx.x], c[g + threadIdx.x]));
+    for (int i = threadIdx.x; i < nz; i += kAmaxSlots) zero[g + i] = 0.f;
+}
+
 // ------------------------------------------------------------------ dropout (cpc/transformers.py:18,50 and :93,100)
 // The reference applies nn.Dropout(0.1) to the attention probabilities and to the feed-forward hidden layer in training
 // mode.  Here the keep decision of an element is a pure function of (seed, site, element index) -- Philox4x32-10, the
@@ -95,11 +130,12 @@ __device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)(
 // drop_p > 0 (training): the probabilities that multiply V are A * keep / (1 - p); A itself (pre-dropout) is what is saved.
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                        float* __restrict__ o, float* __restrict__ A, int S, float drop_p,
-                                                       unsigned long long seed, TfStrides gs) {
+                                                       unsigned long long seed, TfStrides gs, float* __restrict__ o_amax) {
     __shared__ float lds[3 * kSmax * kLdH + kDk * kLdS + 4 * 32 * kLdS];     // 133 KB of the CU's 160 KB
     {                                                 // layer blockIdx.y of a group (TfStrides); its dropout stream: seed + layer
         const long g = blockIdx.y;
         qkv += g * gs.saved; o += g * gs.saved; A += g * gs.saved;
+        if (o_amax != nullptr) o_amax += g * gs.saved;
         if (P != nullptr) P += g * gs.par[4];
         seed += (unsigned long long)g;
     }
@@ -201,11 +237,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         const int k = 2 * kk + khalf;
         ov = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k], Vs[k * kLdH + l31], ov, 0, 0, 0);
     }
+    float m = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = 32 * w + c_row(r, lane);
-        if (i < S) o[(row0 + i) * kC + h * kDk + l31] = ov[r];
+        if (i < S) {
+            o[(row0 + i) * kC + h * kDk + l31] = ov[r];
+            m = fmaxf(m, fabsf(ov[r]));
+        }
     }
+    publish_amax(o_amax, m);
 }
 
 // ------------------------------------------------------------------ attention backward
@@ -214,12 +255,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ o, const float* __restrict__ A,
                                                        const float* __restrict__ dO, float* __restrict__ dqkv,
                                                        float* __restrict__ dPpart, int S, float drop_p,
-                                                       unsigned long long seed, TfStrides gs) {
+                                                       unsigned long long seed, TfStrides gs, float* __restrict__ dqkv_amax) {
     __shared__ float lds[4 * kSmax * kLdH + kDk * kLdS + kSmax * kLdS];      // 150 KB
     {
         const long g = blockIdx.y;
         qkv += g * gs.saved; o += g * gs.saved; A += g * gs.saved;
         dO += g * gs.scratch; dqkv += g * gs.scratch; dPpart += g * gs.scratch;
+        if (dqkv_amax != nullptr) dqkv_amax += g * gs.scratch;
         if (P != nullptr) P += g * gs.par[4];
         seed += (unsigned long long)g;
     }
@@ -234,6 +276,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int l31 = lane & 31, khalf = lane >> 5;
     const long row0 = (long)b * S;
+    float gmax = 0.f;                                 // max|dq|, |dk|, |dv| of what this thread stores
     stage_head(Qs, qkv, row0, 3 * kC, h * kDk, S);
     stage_head(Ks, qkv, row0, 3 * kC, kC + h * kDk, S);
     stage_head(Vs, qkv, row0, 3 * kC, 2 * kC + h * kDk, S);
@@ -311,7 +354,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = 32 * w + c_row(r, lane);
-            if (i < S) dqkv[(row0 + i) * 3 * kC + h * kDk + l31] = acc[r];
+            if (i < S) {
+                dqkv[(row0 + i) * 3 * kC + h * kDk + l31] = acc[r];
+                gmax = fmaxf(gmax, fabsf(acc[r]));
+            }
         }
     }
     {   // dk_j = sum_{i >= j} dS_ij q_i;  dv_j = sum_{i >= j} A_ij dO_i   (rows j of this wave)
@@ -334,9 +380,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             if (j < S) {
                 dqkv[(row0 + j) * 3 * kC + kC + h * kDk + l31] = ak[r];
                 dqkv[(row0 + j) * 3 * kC + 2 * kC + h * kDk + l31] = av[r];
+                gmax = fmaxf(gmax, fmaxf(fabsf(ak[r]), fabsf(av[r])));
             }
         }
     }
+    publish_amax(dqkv_amax, gmax);
     if (P != nullptr) {   // dP[d][c] partial = sum_i q_i[d] dE_ic, columns c of this wave
         f32x16 acc;
 #pragma unroll
@@ -357,36 +405,43 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ residual + LayerNorm
-// out = LN(a + b) * w + bias, one wavefront per 256-wide row; xhat and rstd are kept for backward.
+// out = LN(a + b) * w + bias, one wavefront per 256-wide row, kLnFwdRows rows per workgroup; xhat and rstd are kept for backward.
+constexpr int kLnFwdRows = 16;
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ out, float* __restrict__ xhat,
                                                          float* __restrict__ rstd, int M, long a_gs, long b_gs, long w_gs,
-                                                         long out_gs, int out_ld, long xh_gs) {
+                                                         long out_gs, int out_ld, long xh_gs, float* __restrict__ out_amax) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
     {                                                 // layer blockIdx.y of a group: rows of `out` are out_ld floats apart
         const long g = blockIdx.y;
         a += g * a_gs; b += g * b_gs; w += g * w_gs; bias += g * w_gs; out += g * out_gs; xhat += g * xh_gs; rstd += g * xh_gs;
+        if (out_amax != nullptr) out_amax += g * xh_gs;
     }
-    const float4 va = *reinterpret_cast<const float4*>(a + row * kC + 4 * lane);
-    const float4 vb = *reinterpret_cast<const float4*>(b + row * kC + 4 * lane);
-    float x[4] = {va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w};
-    const float mu = wave_sum((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / kC);
-    float d[4], q = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { d[e] = x[e] - mu; q = fmaf(d[e], d[e], q); }
-    const float var = wave_sum(q) * (1.0f / kC);                   // biased, as nn.LayerNorm
-    const float rs = 1.0f / sqrtf(var + kLnEps);
     const float4 vw = *reinterpret_cast<const float4*>(w + 4 * lane);
     const float4 vbi = *reinterpret_cast<const float4*>(bias + 4 * lane);
-    float4 xh, y;
-    xh.x = d[0] * rs; xh.y = d[1] * rs; xh.z = d[2] * rs; xh.w = d[3] * rs;
-    y.x = xh.x * vw.x + vbi.x; y.y = xh.y * vw.y + vbi.y; y.z = xh.z * vw.z + vbi.z; y.w = xh.w * vw.w + vbi.w;
-    *reinterpret_cast<float4*>(xhat + row * kC + 4 * lane) = xh;
-    *reinterpret_cast<float4*>(out + row * out_ld + 4 * lane) = y;
-    if (lane == 0) rstd[row] = rs;
+    float m = 0.f;
+    for (int it = 0; it < kLnFwdRows / 4; ++it) {
+        const long row = (long)blockIdx.x * kLnFwdRows + it * 4 + (threadIdx.x >> 6);
+        if (row >= M) break;                          // wave-uniform
+        const float4 va = *reinterpret_cast<const float4*>(a + row * kC + 4 * lane);
+        const float4 vb = *reinterpret_cast<const float4*>(b + row * kC + 4 * lane);
+        float x[4] = {va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w};
+        const float mu = wave_sum((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / kC);
+        float d[4], q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d[e] = x[e] - mu; q = fmaf(d[e], d[e], q); }
+        const float var = wave_sum(q) * (1.0f / kC);                   // biased, as nn.LayerNorm
+        const float rs = 1.0f / sqrtf(var + kLnEps);
+        float4 xh, y;
+        xh.x = d[0] * rs; xh.y = d[1] * rs; xh.z = d[2] * rs; xh.w = d[3] * rs;
+        y.x = xh.x * vw.x + vbi.x; y.y = xh.y * vw.y + vbi.y; y.z = xh.z * vw.z + vbi.z; y.w = xh.w * vw.w + vbi.w;
+        *reinterpret_cast<float4*>(xhat + row * kC + 4 * lane) = xh;
+        *reinterpret_cast<float4*>(out + row * out_ld + 4 * lane) = y;
+        if (lane == 0) rstd[row] = rs;
+        m = amax4(m, y);
+    }
+    publish_amax_block(out_amax, m);
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w  (gradient w.r.t. the SUM a + b);
@@ -397,16 +452,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ rstd, const float* __restrict__ w,
                                                      const float* __restrict__ add, float* __restrict__ dx,
                                                      float* __restrict__ part, int M, long dy_gs, int dy_ld, long xh_gs,
-                                                     long w_gs, long dx_gs, long part_gs) {
+                                                     long w_gs, long dx_gs, long part_gs, float* __restrict__ dx_amax) {
     __shared__ float red[4][2][kC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     {                                                 // layer blockIdx.y of a group: rows of dy are dy_ld floats apart
         const long g = blockIdx.y;
         dy += g * dy_gs; xhat += g * xh_gs; rstd += g * xh_gs; w += g * w_gs; dx += g * dx_gs; part += g * part_gs;
         if (add != nullptr) add += g * dx_gs;
+        if (dx_amax != nullptr) dx_amax += g * dx_gs;
     }
     const float4 vw = *reinterpret_cast<const float4*>(w + 4 * lane);
-    float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f}, dmax = 0.f;
     for (int it = 0; it < kLnRowsPerBlock / 4; ++it) {
         const long row = (long)blockIdx.x * kLnRowsPerBlock + it * 4 + wv;
         if (row >= M) break;                                       // wave-uniform
@@ -433,7 +489,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             r.x += a4.x; r.y += a4.y; r.z += a4.z; r.w += a4.w;
         }
         *reinterpret_cast<float4*>(dx + row * kC + 4 * lane) = r;
+        dmax = amax4(dmax, r);
     }
+    publish_amax_block(dx_amax, dmax);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { red[wv][0][4 * lane + e] = aw[e]; red[wv][1][4 * lane + e] = ab[e]; }
     __syncthreads();
@@ -444,36 +502,52 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // x = relu(x), then (drop_p > 0) the hidden layer's dropout: x *= keep / (1 - p)   (transformers.py:93,100)
+// A workgroup covers kReluIters * 256 float4 (grid: cdiv(n4, 256 * kReluIters)) and publishes one max|x|.
+constexpr int kReluIters = 16;
 __global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, long n4, float drop_p, unsigned long long seed,
-                                                   long x_gs) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
+                                                   long x_gs, float* __restrict__ x_amax) {
     x += (long)blockIdx.y * x_gs;                     // layer blockIdx.y of a group, dropout stream seed + layer
+    if (x_amax != nullptr) x_amax += (long)blockIdx.y * x_gs;
     seed += (unsigned long long)blockIdx.y;
-    float4 v = reinterpret_cast<float4*>(x)[i];
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    if (drop_p > 0.f) {
-        const Philox4 r = philox4x32_10(seed, 1u, (unsigned long long)i);      // elements 4i .. 4i+3
-        const unsigned th = drop_threshold(drop_p);
-        const float sc = 1.0f / (1.0f - drop_p);
-        v.x = r.x >= th ? v.x * sc : 0.f; v.y = r.y >= th ? v.y * sc : 0.f;
-        v.z = r.z >= th ? v.z * sc : 0.f; v.w = r.w >= th ? v.w * sc : 0.f;
+    const unsigned th = drop_threshold(drop_p);
+    const float sc = 1.0f / (1.0f - drop_p);
+    float m = 0.f;
+#pragma unroll 4
+    for (int it = 0; it < kReluIters; ++it) {
+        const long i = ((long)blockIdx.x * kReluIters + it) * 256 + threadIdx.x;
+        if (i >= n4) break;
+        float4 v = reinterpret_cast<float4*>(x)[i];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (drop_p > 0.f) {
+            const Philox4 r = philox4x32_10(seed, 1u, (unsigned long long)i);      // elements 4i .. 4i+3
+            v.x = r.x >= th ? v.x * sc : 0.f; v.y = r.y >= th ? v.y * sc : 0.f;
+            v.z = r.z >= th ? v.z * sc : 0.f; v.w = r.w >= th ? v.w * sc : 0.f;
+        }
+        reinterpret_cast<float4*>(x)[i] = v;
+        m = amax4(m, v);
     }
-    reinterpret_cast<float4*>(x)[i] = v;
+    publish_amax_block(x_amax, m);
 }
 // g *= (y > 0) * scale, y the SAVED hidden layer: it is zero where the ReLU cut or the dropout dropped, so the product of
 // the two derivatives is scale = 1 / (1 - p) exactly where y > 0
 __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, long n4, float scale,
-                                                       long g_gs, long y_gs) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
+                                                       long g_gs, long y_gs, float* __restrict__ g_amax) {
     g += (long)blockIdx.y * g_gs;
     y += (long)blockIdx.y * y_gs;
-    float4 v = reinterpret_cast<float4*>(g)[i];
-    const float4 a = reinterpret_cast<const float4*>(y)[i];
-    v.x = a.x > 0.f ? v.x * scale : 0.f; v.y = a.y > 0.f ? v.y * scale : 0.f;
-    v.z = a.z > 0.f ? v.z * scale : 0.f; v.w = a.w > 0.f ? v.w * scale : 0.f;
-    reinterpret_cast<float4*>(g)[i] = v;
+    if (g_amax != nullptr) g_amax += (long)blockIdx.y * g_gs;
+    float m = 0.f;
+#pragma unroll 4
+    for (int it = 0; it < kReluIters; ++it) {
+        const long i = ((long)blockIdx.x * kReluIters + it) * 256 + threadIdx.x;
+        if (i >= n4) break;
+        float4 v = reinterpret_cast<float4*>(g)[i];
+        const float4 a = reinterpret_cast<const float4*>(y)[i];
+        v.x = a.x > 0.f ? v.x * scale : 0.f; v.y = a.y > 0.f ? v.y * scale : 0.f;
+        v.z = a.z > 0.f ? v.z * scale : 0.f; v.w = a.w > 0.f ? v.w * scale : 0.f;
+        reinterpret_cast<float4*>(g)[i] = v;
+        m = amax4(m, v);
+    }
+    publish_amax_block(g_amax, m);
 }
 // out[i] = keep_i / (1 - p) of site `site` (tests: the mask a layer call with this seed applied)
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long n, int site, float drop_p,
@@ -524,10 +598,14 @@ __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const f
 
 // ------------------------------------------------------------------ host side
 struct TfLayout {
-    long qkv, A, o, xhat1, rstd1, y, hid, xhat2, rstd2, saved_total;       // saved for backward
+    long qkv, A, o, xhat1, rstd1, y, hid, xhat2, rstd2, bounds, saved_total;   // saved for backward
     long fwd_total;                                                        // forward scratch: one (M,256) buffer
-    long ds2, dhid, dyb, ds1, dob, dqkv, w2t, w1t, wot, wqkv, wqkvt, part, lnpart, tmp, dppart, bwd_total;
+    long ds2, dhid, dyb, ds1, dob, dqkv, w2t, w1t, wot, wqkv, wqkvt, part, lnpart, tmp, dppart, bbounds, bwd_total;
 };
+// GEMM operand bounds (publish_amax), kAmaxSlots floats each.  Forward's live in `saved` (the backward reads them again; a
+// group keeps them in layer 0's copy), the gradients' in the backward scratch.
+enum { kBX = 0, kBWq, kBWk, kBWv, kBWo, kBW1, kBW2, kBWqkv, kBO, kBY, kBHid, kTfBounds };
+enum { kBDs2 = 0, kBDh, kBDs1, kBDqkv, kTfBwdBounds };
 
 static bool tf_layout(int B, int S, TfLayout& t) {
     if (B <= 0 || S <= 0 || S > kSmax) return false;
@@ -542,6 +620,7 @@ static bool tf_layout(int B, int S, TfLayout& t) {
     t.hid = o; o += align64l(M * kDff);
     t.xhat2 = o; o += align64l(M * kC);
     t.rstd2 = o; o += align64l(M);
+    t.bounds = o; o += (long)kTfBounds * kAmaxSlots;
     t.saved_total = o;
     t.fwd_total = align64l(M * kC);
     o = 0;
@@ -561,6 +640,7 @@ static bool tf_layout(int B, int S, TfLayout& t) {
     t.lnpart = o; o += align64l(nblk * 2 * kC);
     t.tmp = o; o += align64l((long)kRowsSumGroups * (kDk * S > kDff ? kDk * S : kDff));
     t.dppart = o; o += align64l((long)B * kTH * kDk * S);
+    t.bbounds = o; o += (long)kTfBwdBounds * kAmaxSlots;
     t.bwd_total = o;
     return true;
 }
@@ -587,6 +667,10 @@ static TfGroup tf_group(const TfLayout& t, int G, int S) {
     return tg;
 }
 
+// Bounds are kept for a single layer and for a group whose layers share the input and stack their parameters (what the two
+// entry points build); anything else keeps the GEMMs on three bf16 pieces.
+static bool tf_bounded(const TfGroup& tg) { return tg.G == 1 || (tg.x == 0 && tg.ks.par[0] == (long)kC * kC); }
+
 static int tf_forward(const TfGroup& tg, const float* x, const float* const* params, float* saved, float* scratch, float* out,
                       int B, int S, float p, unsigned long long seed, hipStream_t st) {
     TfLayout t;
@@ -599,25 +683,52 @@ static int tf_forward(const TfGroup& tg, const float* x, const float* const* par
     const RowMap xm = plain_rows(x, M, kC);
     auto grp = [&](long a, long b, long bias, long c) { GemmGroup g; g.G = G; g.a = a; g.b = b; g.bias = bias; g.c = c; return g; };
     int rc;
-    if ((rc = nt_gemm(xm, Wq, kC, nullptr, qkv, 3 * kC, kC, kC, st, 0, 0, GemmBounds(), grp(tg.x, ps[2], 0, sv)))) return rc;
-    if ((rc = nt_gemm(xm, Wk, kC, nullptr, qkv + kC, 3 * kC, kC, kC, st, 0, 0, GemmBounds(), grp(tg.x, ps[1], 0, sv)))) return rc;
-    if ((rc = nt_gemm(xm, Wv, kC, nullptr, qkv + 2 * kC, 3 * kC, kC, kC, st, 0, 0, GemmBounds(), grp(tg.x, ps[3], 0, sv)))) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * kTH, G), dim3(256), 0, st, qkv, P, saved + t.o, saved + t.A, S, p, seed, tg.ks);
+    // operand bounds: the input (shared by the layers of a group: kept in layer 0's workspace) and the six weight matrices by
+    // reduction, the intermediates by the kernels that write them
+    float* bnd = saved + t.bounds;
+    const bool bounded = tf_bounded(tg);
+    if (bounded) {
+        const float* ax[1] = {x};
+        const long an[1] = {(long)M * kC};
+        if ((rc = absmax_slots(ax, an, 1, bnd + kBX * kAmaxSlots, st))) return rc;
+        const float* wx[4] = {Wq, Wk, Wv, Wo};                    // in the order of kBWq .. kBWo
+        const long wn[4] = {(long)kC * kC, (long)kC * kC, (long)kC * kC, (long)kC * kC}, wg[4] = {ps[2], ps[1], ps[3], ps[0]};
+        if ((rc = absmax_group(wx, wn, wg, 4, G, bnd + kBWq * kAmaxSlots, sv, st))) return rc;
+        const float* fx[2] = {params[7], params[9]};
+        const long fn[2] = {(long)kDff * kC, (long)kDff * kC}, fg[2] = {ps[7], ps[9]};
+        if ((rc = absmax_group(fx, fn, fg, 2, G, bnd + kBW1 * kAmaxSlots, sv, st))) return rc;
+        hipLaunchKernelGGL(bounds_begin_kernel, dim3(G), dim3(kAmaxSlots), 0, st, bnd + kBWqkv * kAmaxSlots, bnd + kBWq * kAmaxSlots,
+                           bnd + kBWk * kAmaxSlots, bnd + kBWv * kAmaxSlots, bnd + kBO * kAmaxSlots, (kTfBounds - kBO) * kAmaxSlots, sv);
+    }
+    auto gbnd = [&](int ia, int ib) {
+        GemmBounds g;
+        if (bounded) {
+            g.a = bnd + ia * kAmaxSlots; g.b = bnd + ib * kAmaxSlots; g.a_slots = g.b_slots = kAmaxSlots;
+            g.a_gs = ia == kBX ? 0 : sv; g.b_gs = sv;
+        }
+        return g;
+    };
+    auto slot = [&](int i) { return bounded ? bnd + i * kAmaxSlots : (float*)nullptr; };
+    if ((rc = nt_gemm(xm, Wq, kC, nullptr, qkv, 3 * kC, kC, kC, st, 0, 0, gbnd(kBX, kBWq), grp(tg.x, ps[2], 0, sv)))) return rc;
+    if ((rc = nt_gemm(xm, Wk, kC, nullptr, qkv + kC, 3 * kC, kC, kC, st, 0, 0, gbnd(kBX, kBWk), grp(tg.x, ps[1], 0, sv)))) return rc;
+    if ((rc = nt_gemm(xm, Wv, kC, nullptr, qkv + 2 * kC, 3 * kC, kC, kC, st, 0, 0, gbnd(kBX, kBWv), grp(tg.x, ps[3], 0, sv)))) return rc;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * kTH, G), dim3(256), 0, st, qkv, P, saved + t.o, saved + t.A, S, p, seed, tg.ks,
+                       slot(kBO));
     CPC_LAUNCH_CHECK();
     float* att = scratch;
-    if ((rc = nt_gemm(plain_rows(saved + t.o, M, kC), Wo, kC, nullptr, att, kC, kC, kC, st, 0, 0, GemmBounds(), grp(sv, ps[0], 0, sc))))
+    if ((rc = nt_gemm(plain_rows(saved + t.o, M, kC), Wo, kC, nullptr, att, kC, kC, kC, st, 0, 0, gbnd(kBO, kBWo), grp(sv, ps[0], 0, sc))))
         return rc;
-    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, 4), G), dim3(256), 0, st, x, att, params[5], params[6],
-                       saved + t.y, saved + t.xhat1, saved + t.rstd1, M, tg.x, sc, ps[5], sv, kC, sv);
+    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, kLnFwdRows), G), dim3(256), 0, st, x, att, params[5], params[6],
+                       saved + t.y, saved + t.xhat1, saved + t.rstd1, M, tg.x, sc, ps[5], sv, kC, sv, slot(kBY));
     if ((rc = nt_gemm(plain_rows(saved + t.y, M, kC), params[7], kC, params[8], saved + t.hid, kDff, kDff, kC, st, 0, 0,
-                      GemmBounds(), grp(sv, ps[7], ps[8], sv)))) return rc;
-    hipLaunchKernelGGL(relu_kernel, dim3(cdiv((long)M * kDff / 4, 256), G), dim3(256), 0, st, saved + t.hid, (long)M * kDff / 4, p,
-                       seed, sv);
+                      gbnd(kBY, kBW1), grp(sv, ps[7], ps[8], sv)))) return rc;
+    hipLaunchKernelGGL(relu_kernel, dim3(cdiv((long)M * kDff / 4, 256 * kReluIters), G), dim3(256), 0, st, saved + t.hid, (long)M * kDff / 4, p,
+                       seed, sv, slot(kBHid));
     float* ff = scratch;
-    if ((rc = nt_gemm(plain_rows(saved + t.hid, M, kDff), params[9], kDff, params[10], ff, kC, kC, kDff, st, 0, 0, GemmBounds(),
+    if ((rc = nt_gemm(plain_rows(saved + t.hid, M, kDff), params[9], kDff, params[10], ff, kC, kC, kDff, st, 0, 0, gbnd(kBHid, kBW2),
                       grp(sv, ps[9], ps[10], sc)))) return rc;
-    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, 4), G), dim3(256), 0, st, saved + t.y, ff, params[11], params[12],
-                       out, saved + t.xhat2, saved + t.rstd2, M, sv, sc, ps[11], tg.out, tg.out_ld, sv);
+    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, kLnFwdRows), G), dim3(256), 0, st, saved + t.y, ff, params[11], params[12],
+                       out, saved + t.xhat2, saved + t.rstd2, M, sv, sc, ps[11], tg.out, tg.out_ld, sv, (float*)nullptr);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -639,48 +750,63 @@ static int tf_backward(const TfGroup& tg, const float* x, const float* const* pa
     float *tmp = scratch + t.tmp;
     auto grp = [&](long a, long b, long c) { GemmGroup g; g.G = G; g.a = a; g.b = b; g.c = c; g.part = sc; return g; };
     int rc;
+    const float* bnd = saved + t.bounds;              // the forward's operand bounds (tf_forward)
+    float* bb = scratch + t.bbounds;                  // the gradients', left by the kernels that write them
+    const bool bounded = tf_bounded(tg);
+    if (bounded)
+        hipLaunchKernelGGL(bounds_begin_kernel, dim3(G), dim3(kAmaxSlots), 0, st, (float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, bb, kTfBwdBounds * kAmaxSlots, sc);
+    auto gbnd = [&](int ig, int iw) {                 // a: gradient bound ig, b: forward bound iw
+        GemmBounds g;
+        if (bounded) {
+            g.a = bb + ig * kAmaxSlots; g.b = bnd + iw * kAmaxSlots; g.a_slots = g.b_slots = kAmaxSlots;
+            g.a_gs = sc; g.b_gs = iw == kBX ? 0 : sv;
+        }
+        return g;
+    };
+    auto slot = [&](int i) { return bounded ? bb + i * kAmaxSlots : (float*)nullptr; };
     // out = LN2(y + ff)
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk, G), dim3(256), 0, st, dy, saved + t.xhat2, saved + t.rstd2, params[11],
-                       (const float*)nullptr, ds2, lnpart, M, tg.dy, tg.dy_ld, sv, ps[11], sc, sc);
+                       (const float*)nullptr, ds2, lnpart, M, tg.dy, tg.dy_ld, sv, ps[11], sc, sc, slot(kBDs2));
     if ((rc = rows_sum(lnpart, nblk, 2 * kC, tmp, dhid, st, G, sc, sc, sc))) return rc;          // dhid as a 512-float staging area
     gcopy(grads[11], dhid, kC, G, ps[11], sc, st);
     gcopy(grads[12], dhid + kC, kC, G, ps[12], sc, st);
     // ff = hid W2^T + b2
     const RowMap ds2m = plain_rows(ds2, M, kC), hidm = plain_rows(saved + t.hid, M, kDff);
-    if ((rc = tn_gemm(ds2m, kC, hidm, kDff, part, grads[9], 0, st, GemmBounds(), grp(sc, sv, ps[9])))) return rc;   // dW2 (256,2048)
+    if ((rc = tn_gemm(ds2m, kC, hidm, kDff, part, grads[9], 0, st, gbnd(kBDs2, kBHid), grp(sc, sv, ps[9])))) return rc;   // dW2 (256,2048)
     if ((rc = rows_sum(ds2, M, kC, tmp, grads[10], st, G, sc, sc, ps[10]))) return rc;
     if ((rc = transpose(W2, scratch + t.w2t, kC, kDff, st, G, ps[9], sc))) return rc;           // (256,2048) -> (2048,256)
-    if ((rc = nt_gemm(ds2m, scratch + t.w2t, kC, nullptr, dhid, kDff, kDff, kC, st, 0, 0, GemmBounds(), grp(sc, sc, sc)))) return rc;
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(cdiv((long)M * kDff / 4, 256), G), dim3(256), 0, st, dhid, saved + t.hid,
-                       (long)M * kDff / 4, 1.0f / (1.0f - p), sc, sv);
+    if ((rc = nt_gemm(ds2m, scratch + t.w2t, kC, nullptr, dhid, kDff, kDff, kC, st, 0, 0, gbnd(kBDs2, kBW2), grp(sc, sc, sc)))) return rc;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(cdiv((long)M * kDff / 4, 256 * kReluIters), G), dim3(256), 0, st, dhid, saved + t.hid,
+                       (long)M * kDff / 4, 1.0f / (1.0f - p), sc, sv, slot(kBDh));
     // hid = relu(y W1^T + b1)
     const RowMap dhm = plain_rows(dhid, M, kDff), ym = plain_rows(saved + t.y, M, kC);
-    if ((rc = tn_gemm(dhm, kDff, ym, kC, part, grads[7], 0, st, GemmBounds(), grp(sc, sv, ps[7])))) return rc;      // dW1 (2048,256)
+    if ((rc = tn_gemm(dhm, kDff, ym, kC, part, grads[7], 0, st, gbnd(kBDh, kBY), grp(sc, sv, ps[7])))) return rc;      // dW1 (2048,256)
     if ((rc = rows_sum(dhid, M, kDff, tmp, grads[8], st, G, sc, sc, ps[8]))) return rc;
     if ((rc = transpose(W1, scratch + t.w1t, kDff, kC, st, G, ps[7], sc))) return rc;           // (2048,256) -> (256,2048)
-    if ((rc = nt_gemm(dhm, scratch + t.w1t, kDff, nullptr, dyb, kC, kC, kDff, st, 0, 0, GemmBounds(), grp(sc, sc, sc)))) return rc;
+    if ((rc = nt_gemm(dhm, scratch + t.w1t, kDff, nullptr, dyb, kC, kC, kDff, st, 0, 0, gbnd(kBDh, kBW1), grp(sc, sc, sc)))) return rc;
     hipLaunchKernelGGL(add_kernel, dim3(cdiv(n4, 256), G), dim3(256), 0, st, dyb, ds2, n4, sc, sc);   // dy_total = ds2 + dhid W1
     // y = LN1(x + att)
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk, G), dim3(256), 0, st, dyb, saved + t.xhat1, saved + t.rstd1, params[5],
-                       (const float*)nullptr, ds1, lnpart, M, sc, kC, sv, ps[5], sc, sc);
+                       (const float*)nullptr, ds1, lnpart, M, sc, kC, sv, ps[5], sc, sc, slot(kBDs1));
     if ((rc = rows_sum(lnpart, nblk, 2 * kC, tmp, dhid, st, G, sc, sc, sc))) return rc;
     gcopy(grads[5], dhid, kC, G, ps[5], sc, st);
     gcopy(grads[6], dhid + kC, kC, G, ps[6], sc, st);
     // att = o Wo^T
     const RowMap ds1m = plain_rows(ds1, M, kC);
-    if ((rc = tn_gemm(ds1m, kC, plain_rows(saved + t.o, M, kC), kC, part, grads[0], 0, st, GemmBounds(), grp(sc, sv, ps[0])))) return rc;
+    if ((rc = tn_gemm(ds1m, kC, plain_rows(saved + t.o, M, kC), kC, part, grads[0], 0, st, gbnd(kBDs1, kBO), grp(sc, sv, ps[0])))) return rc;
     if ((rc = transpose(Wo, scratch + t.wot, kC, kC, st, G, ps[0], sc))) return rc;
-    if ((rc = nt_gemm(ds1m, scratch + t.wot, kC, nullptr, dob, kC, kC, kC, st, 0, 0, GemmBounds(), grp(sc, sc, sc)))) return rc;
+    if ((rc = nt_gemm(ds1m, scratch + t.wot, kC, nullptr, dob, kC, kC, kC, st, 0, 0, gbnd(kBDs1, kBWo), grp(sc, sc, sc)))) return rc;
     // attention
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * kTH, G), dim3(256), 0, st, saved + t.qkv, P, saved + t.o,
-                       saved + t.A, dob, dqkv, scratch + t.dppart, S, p, seed, tg.ks);
+                       saved + t.A, dob, dqkv, scratch + t.dppart, S, p, seed, tg.ks, slot(kBDqkv));
     CPC_LAUNCH_CHECK();
     if (P != nullptr && (rc = rows_sum(scratch + t.dppart, B * kTH, kDk * S, tmp, grads[4], st, G, sc, sc, ps[4]))) return rc;
     // projections
     const RowMap xm = plain_rows(x, M, kC);
-    if ((rc = tn_gemm(plain_rows(dqkv, M, 3 * kC), kC, xm, kC, part, grads[2], 0, st, GemmBounds(), grp(sc, tg.x, ps[2])))) return rc;            // dWq
-    if ((rc = tn_gemm(plain_rows(dqkv + kC, M, 3 * kC), kC, xm, kC, part, grads[1], 0, st, GemmBounds(), grp(sc, tg.x, ps[1])))) return rc;       // dWk
-    if ((rc = tn_gemm(plain_rows(dqkv + 2 * kC, M, 3 * kC), kC, xm, kC, part, grads[3], 0, st, GemmBounds(), grp(sc, tg.x, ps[3])))) return rc;   // dWv
+    if ((rc = tn_gemm(plain_rows(dqkv, M, 3 * kC), kC, xm, kC, part, grads[2], 0, st, gbnd(kBDqkv, kBX), grp(sc, tg.x, ps[2])))) return rc;            // dWq
+    if ((rc = tn_gemm(plain_rows(dqkv + kC, M, 3 * kC), kC, xm, kC, part, grads[1], 0, st, gbnd(kBDqkv, kBX), grp(sc, tg.x, ps[1])))) return rc;       // dWk
+    if ((rc = tn_gemm(plain_rows(dqkv + 2 * kC, M, 3 * kC), kC, xm, kC, part, grads[3], 0, st, gbnd(kBDqkv, kBX), grp(sc, tg.x, ps[3])))) return rc;   // dWv
     float* wqkv = scratch + t.wqkv;                                               // [Wq; Wk; Wv] (768,256)
     gcopy(wqkv, Wq, (long)kC * kC, G, sc, ps[2], st);
     gcopy(wqkv + kC * kC, Wk, (long)kC * kC, G, sc, ps[1], st);
@@ -689,8 +815,8 @@ static int tf_backward(const TfGroup& tg, const float* x, const float* const* pa
     // dx of layer g: into the caller's buffer when every layer has its own, else into ds2 (free by now) for the sum below
     float* dxg = (G > 1 && tg.dx == 0) ? ds2 : dx;
     const long dxg_gs = (G > 1 && tg.dx == 0) ? sc : tg.dx;
-    if ((rc = nt_gemm(plain_rows(dqkv, M, 3 * kC), scratch + t.wqkvt, 3 * kC, nullptr, dxg, kC, kC, 3 * kC, st, 0, 0, GemmBounds(),
-                      grp(sc, sc, dxg_gs)))) return rc;
+    if ((rc = nt_gemm(plain_rows(dqkv, M, 3 * kC), scratch + t.wqkvt, 3 * kC, nullptr, dxg, kC, kC, 3 * kC, st, 0, 0,
+                      gbnd(kBDqkv, kBWqkv), grp(sc, sc, dxg_gs)))) return rc;
     hipLaunchKernelGGL(add_kernel, dim3(cdiv(n4, 256), G), dim3(256), 0, st, dxg, ds1, n4, dxg_gs, sc);   // + the residual branch
     if (dxg != dx)                                                                // layers that shared x: dx = sum over them
         hipLaunchKernelGGL(gsum_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dx, dxg, n4, G, dxg_gs);
