@@ -38,18 +38,48 @@ __device__ __forceinline__ float half_sum(float v) {
     return v;
 }
 
-// stage the (S, 32) head slice `col0` of a (B*S, ld) matrix into LDS rows of pitch kLdH, zero-padded to 128 rows
-__device__ __forceinline__ void stage_head(float* dst, const float* __restrict__ src, long row0, int ld, int col0, int S) {
-    for (int e = threadIdx.x; e < kSmax * (kDk / 4); e += blockDim.x) {
-        const int i = e >> 3, c4 = (e & 7) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < S) v = *reinterpret_cast<const float4*>(src + (row0 + i) * ld + col0 + c4);
+// Stage the (S, 32) head slice `col0` of a (B*S, ld) matrix into LDS rows of pitch kLdH, zero-padded to 128 rows; 256 threads,
+// four 16-byte pieces each.  Two halves so that a kernel can request all its slices before it waits for the first: the
+// loads are unconditional on a clamped row (a predicated load is a branch and a full vmcnt(0) each -- as a loop of
+// load -> store per piece, staging four slices was 28 round trips to L2 one after the other, half of the kernel's time).
+struct HeadPieces { float4 v[4]; };
+__device__ __forceinline__ HeadPieces load_head(const float* __restrict__ src, long row0, int ld, int col0, int S) {
+    HeadPieces p;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = threadIdx.x + 256 * u, i = e >> 3, c4 = (e & 7) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + (row0 + min(i, S - 1)) * ld + col0 + c4);
+        p.v[u] = i < S ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return p;
+}
+__device__ __forceinline__ void store_head(float* dst, const HeadPieces& p) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = threadIdx.x + 256 * u, i = e >> 3, c4 = (e & 7) * 4;
         float* d = dst + i * kLdH + c4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        d[0] = p.v[u].x; d[1] = p.v[u].y; d[2] = p.v[u].z; d[3] = p.v[u].w;
     }
 }
+// Krelpos (32, S) -> LDS rows of pitch kLdS, zero beyond S (or everywhere without relative positions)
 __device__ __forceinline__ void stage_relpos(float* dst, const float* __restrict__ P, int S) {
-    for (int e = threadIdx.x; e < kDk * kSmax; e += blockDim.x) {
+    if (P != nullptr && (S & 3) == 0) {                       // block-uniform
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = threadIdx.x + 256 * u, d = e >> 5, c4 = (e & 31) * 4;
+            v[u] = *reinterpret_cast<const float4*>(P + d * S + min(c4, S - 4));
+            if (c4 >= S) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = threadIdx.x + 256 * u, d = e >> 5, c4 = (e & 31) * 4;
+            float* q = dst + d * kLdS + c4;
+            q[0] = v[u].x; q[1] = v[u].y; q[2] = v[u].z; q[3] = v[u].w;
+        }
+        return;
+    }
+    for (int e = threadIdx.x; e < kDk * kSmax; e += 256) {
         const int d = e >> 7, c = e & (kSmax - 1);
         dst[d * kLdS + c] = (P != nullptr && c < S) ? P[d * S + c] : 0.f;
     }
@@ -148,10 +178,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int l31 = lane & 31, khalf = lane >> 5;
     const long row0 = (long)b * S;
-    stage_head(Qs, qkv, row0, 3 * kC, h * kDk, S);
-    stage_head(Ks, qkv, row0, 3 * kC, kC + h * kDk, S);
-    stage_head(Vs, qkv, row0, 3 * kC, 2 * kC + h * kDk, S);
-    stage_relpos(Ps, P, S);
+    {
+        const HeadPieces pq = load_head(qkv, row0, 3 * kC, h * kDk, S), pk = load_head(qkv, row0, 3 * kC, kC + h * kDk, S),
+                         pv = load_head(qkv, row0, 3 * kC, 2 * kC + h * kDk, S);
+        stage_relpos(Ps, P, S);
+        store_head(Qs, pq); store_head(Ks, pk); store_head(Vs, pv);
+    }
     __syncthreads();
     if (32 * w >= S) return;                          // wave-uniform: no query rows here (no barrier follows)
 
@@ -277,11 +309,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const int l31 = lane & 31, khalf = lane >> 5;
     const long row0 = (long)b * S;
     float gmax = 0.f;                                 // max|dq|, |dk|, |dv| of what this thread stores
-    stage_head(Qs, qkv, row0, 3 * kC, h * kDk, S);
-    stage_head(Ks, qkv, row0, 3 * kC, kC + h * kDk, S);
-    stage_head(Vs, qkv, row0, 3 * kC, 2 * kC + h * kDk, S);
-    stage_head(Gs, dO, row0, kC, h * kDk, S);
-    stage_relpos(Ps, P, S);
+    {
+        const HeadPieces pq = load_head(qkv, row0, 3 * kC, h * kDk, S), pk = load_head(qkv, row0, 3 * kC, kC + h * kDk, S),
+                         pv = load_head(qkv, row0, 3 * kC, 2 * kC + h * kDk, S), pg = load_head(dO, row0, kC, h * kDk, S);
+        stage_relpos(Ps, P, S);
+        store_head(Qs, pq); store_head(Ks, pk); store_head(Vs, pv); store_head(Gs, pg);
+    }
     if (threadIdx.x < kSmax) {                        // rowdot_i = dO_i . o_i = sum_j dA_ij A_ij
         const int i = threadIdx.x;
         float s = 0.f;
@@ -303,9 +336,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 #pragma unroll 1
         for (int ct = 0; ct < 4; ++ct) {
             f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            float ap[16];                             // this tile's probabilities: requested (unconditionally, on clamped
+#pragma unroll                                        // indices) before the products they will meet
+            for (int r = 0; r < 16; ++r) {
+                acc[r] = 0.f;
+                ap[r] = 0.f;
+            }
             if (ct <= w) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ap[r] = Abh[(long)min(32 * w + c_row(r, lane), S - 1) * S + min(ct * 32 + l31, S - 1)];
                 const float* vrow = Vs + (ct * 32 + l31) * kLdH;
 #pragma unroll
                 for (int kk = 0; kk < kDk / 2; ++kk) {
@@ -323,7 +363,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                     if (drop_p > 0.f)
                         da = philox4x32_10(seed, 0u, ((unsigned long long)bh * S + i) * S + j).x >= drop_threshold(drop_p)
                                  ? da * (1.0f / (1.0f - drop_p)) : 0.f;
-                    ds = Abh[(long)i * S + j] * (da - rdot[i]) * scale;
+                    ds = ap[r] * (da - rdot[i]) * scale;
                 }
                 Ds[i * kLdS + j] = ds;
             }
@@ -365,14 +405,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ak[r] = 0.f; av[r] = 0.f; }
         const int jl = 32 * w + l31;
-        for (int kk = 16 * w; kk < kSmax / 2; ++kk) {
-            const int i = 2 * kk + khalf;
-            ak = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[i * kLdS + jl], Qs[i * kLdH + l31], ak, 0, 0, 0);
-            float a = (i < S && jl < S) ? Abh[(long)i * S + jl] : 0.f;
-            if (drop_p > 0.f && i < S && jl <= i)            // dv sees the probabilities that multiplied V
-                a = philox4x32_10(seed, 0u, ((unsigned long long)bh * S + i) * S + jl).x >= drop_threshold(drop_p)
-                        ? a * (1.0f / (1.0f - drop_p)) : 0.f;
-            av = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Gs[i * kLdH + l31], av, 0, 0, 0);
+        const float* acol = Abh + min(jl, S - 1);
+        for (int kb = 16 * w; kb < kSmax / 2; kb += 8) {      // eight probabilities in flight per lane (they are L2 hits: the
+            float a8[8];                                      // workgroup read them in phase 1)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] = acol[(long)min(2 * (kb + u) + khalf, S - 1) * S];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = 2 * (kb + u) + khalf;
+                ak = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[i * kLdS + jl], Qs[i * kLdH + l31], ak, 0, 0, 0);
+                float a = (i < S && jl < S) ? a8[u] : 0.f;
+                if (drop_p > 0.f && i < S && jl <= i)        // dv sees the probabilities that multiplied V
+                    a = philox4x32_10(seed, 0u, ((unsigned long long)bh * S + i) * S + jl).x >= drop_threshold(drop_p)
+                            ? a * (1.0f / (1.0f - drop_p)) : 0.f;
+                av = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Gs[i * kLdH + l31], av, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
