@@ -74,7 +74,7 @@ SIGNATURES = {
     "cpc_transformer_layer_backward_dropout": (_I, [_P] * 7 + [_I, _I, _F, ctypes.c_ulonglong, _P]),
     "cpc_transformer_group_forward": (_I, [_P] * 5 + [_I, _I, _I, _F, ctypes.c_ulonglong, _P]),
     "cpc_transformer_group_backward": (_I, [_P] * 7 + [_I, _I, _I, _F, ctypes.c_ulonglong, _P]),
-    "cpc_dropout_keep_mask": (_I, [_P, _L, _I, _F, ctypes.c_ulonglong, _P]),
+    "cpc_dropout_keep_mask": (_I, [_P, _L, _I, _I, _F, ctypes.c_ulonglong, _P]),
     "cpc_gru_layout": (_I, [_I, _I, _I, _P]),
     "cpc_gru_forward": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "cpc_gru_forward_coef": (_I, [_P] * 8 + [_I, _I, _I, _P]),

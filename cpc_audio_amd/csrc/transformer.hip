@@ -153,6 +153,24 @@ __device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsign
 }
 // an element is dropped iff its 32 random bits fall below p * 2^32
 __device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)((double)p * 4294967296.0); }
+// Site 0 (attention probabilities): the four words of one Philox block belong to the four rows 4u .. 4u+3 of one column --
+// block index ((b*8 + head) * ceil(S/4) + (i >> 2)) * S + j, word i & 3 -- because that is what one lane of an MFMA
+// accumulator holds (c_row: registers 4m .. 4m+3 are four consecutive rows of one column): a lane draws 16 blocks for its 64
+// probabilities instead of 64 (a block is ~120 integer instructions; drawn one per element they were most of the attention
+// kernels' time in training mode).
+__device__ __forceinline__ unsigned long long attn_drop_block(int bh, int S, int i, int j) {
+    return ((unsigned long long)bh * ((S + 3) >> 2) + (i >> 2)) * S + j;
+}
+// keep bits of the 16 accumulator rows of one lane in tile column j: bit r <-> row 32 w + c_row(r, lane)
+__device__ __forceinline__ unsigned attn_keep_bits(unsigned long long seed, int bh, int S, int w, int lane, int j, unsigned th) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const Philox4 q = philox4x32_10(seed, 0u, attn_drop_block(bh, S, 32 * w + 8 * m + 4 * (lane >> 5), j));
+        bits |= ((q.x >= th ? 1u : 0u) | (q.y >= th ? 2u : 0u) | (q.z >= th ? 4u : 0u) | (q.w >= th ? 8u : 0u)) << (4 * m);
+    }
+    return bits;
+}
 
 // ------------------------------------------------------------------ attention forward
 // grid = B * 8, 256 threads; wave w owns query rows 32w .. 32w+31.
@@ -234,6 +252,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
     __builtin_amdgcn_wave_barrier();                  // every lane has read E; the buffer now takes the probabilities
 
+    unsigned keep[4] = {0u, 0u, 0u, 0u};
+    if (drop_p > 0.f) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            if (ct <= w) keep[ct] = attn_keep_bits(seed, bh, S, w, lane, ct * 32 + l31, drop_threshold(drop_p));
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int il = c_row(r, lane), i = 32 * w + il;
@@ -252,9 +276,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             const float a = p[ct] * inv;
             const int j = ct * 32 + l31;
             float kept = a;
-            if (drop_p > 0.f && i < S && j <= i)
-                kept = philox4x32_10(seed, 0u, ((unsigned long long)bh * S + i) * S + j).x >= drop_threshold(drop_p)
-                           ? a * (1.0f / (1.0f - drop_p)) : 0.f;
+            if (drop_p > 0.f && i < S && j <= i) kept = ((keep[ct] >> r) & 1u) ? a * (1.0f / (1.0f - drop_p)) : 0.f;
             Ww[il * kLdS + j] = kept;
             if (i < S && j < S) A[((long)bh * S + i) * S + j] = a;
         }
@@ -342,10 +364,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 acc[r] = 0.f;
                 ap[r] = 0.f;
             }
+            unsigned keep = 0u;
             if (ct <= w) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     ap[r] = Abh[(long)min(32 * w + c_row(r, lane), S - 1) * S + min(ct * 32 + l31, S - 1)];
+                if (drop_p > 0.f) keep = attn_keep_bits(seed, bh, S, w, lane, ct * 32 + l31, drop_threshold(drop_p));
                 const float* vrow = Vs + (ct * 32 + l31) * kLdH;
 #pragma unroll
                 for (int kk = 0; kk < kDk / 2; ++kk) {
@@ -360,9 +384,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 if (ct <= w && i < S && j <= i) {
                     // through the dropout: dA_ij = (dO_i . v_j) * keep_ij / (1 - p); rowdot_i = dO_i . o_i holds as it is
                     float da = acc[r];
-                    if (drop_p > 0.f)
-                        da = philox4x32_10(seed, 0u, ((unsigned long long)bh * S + i) * S + j).x >= drop_threshold(drop_p)
-                                 ? da * (1.0f / (1.0f - drop_p)) : 0.f;
+                    if (drop_p > 0.f) da = ((keep >> r) & 1u) ? da * (1.0f / (1.0f - drop_p)) : 0.f;
                     ds = ap[r] * (da - rdot[i]) * scale;
                 }
                 Ds[i * kLdS + j] = ds;
@@ -410,14 +432,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             float a8[8];                                      // workgroup read them in phase 1)
 #pragma unroll
             for (int u = 0; u < 8; ++u) a8[u] = acol[(long)min(2 * (kb + u) + khalf, S - 1) * S];
+            // rows i = 2 (kb + u) + khalf of column jl: four Philox blocks of four rows, of which this half-wave has two each
+            unsigned keep = 0u;
+            if (drop_p > 0.f) {
+                const unsigned th = drop_threshold(drop_p);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const Philox4 q = philox4x32_10(seed, 0u, attn_drop_block(bh, S, 2 * kb + 4 * m, jl));
+                    const unsigned lo = khalf ? q.y : q.x, hi = khalf ? q.w : q.z;     // rows 4m + khalf, 4m + 2 + khalf
+                    keep |= ((lo >= th ? 1u : 0u) | (hi >= th ? 2u : 0u)) << (2 * m);  // bit u <-> row 2 (kb + u) + khalf
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = 2 * (kb + u) + khalf;
                 ak = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[i * kLdS + jl], Qs[i * kLdH + l31], ak, 0, 0, 0);
                 float a = (i < S && jl < S) ? a8[u] : 0.f;
                 if (drop_p > 0.f && i < S && jl <= i)        // dv sees the probabilities that multiplied V
-                    a = philox4x32_10(seed, 0u, ((unsigned long long)bh * S + i) * S + jl).x >= drop_threshold(drop_p)
-                            ? a * (1.0f / (1.0f - drop_p)) : 0.f;
+                    a = ((keep >> u) & 1u) ? a * (1.0f / (1.0f - drop_p)) : 0.f;
                 av = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Gs[i * kLdH + l31], av, 0, 0, 0);
             }
         }
@@ -597,19 +629,24 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, co
     publish_amax_block(g_amax, m);
 }
 // out[i] = keep_i / (1 - p) of site `site` (tests: the mask a layer call with this seed applied)
-__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long n, int site, float drop_p,
+// site 0: out (BH, S, S), element (bh, i, j) -- attn_drop_block; site 1: out flat, element i -- block i / 4, word i % 4
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long n, int site, int S, float drop_p,
                                                            unsigned long long seed) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned th = drop_threshold(drop_p);
     const float sc = 1.0f / (1.0f - drop_p);
-    unsigned bits;
+    Philox4 r;
+    int word;
     if (site == 0) {
-        bits = philox4x32_10(seed, 0u, (unsigned long long)i).x;
+        const int bh = (int)(i / ((long)S * S)), rem = (int)(i - (long)bh * S * S), row = rem / S, col = rem - row * S;
+        r = philox4x32_10(seed, 0u, attn_drop_block(bh, S, row, col));
+        word = row & 3;
     } else {
-        const Philox4 r = philox4x32_10(seed, 1u, (unsigned long long)(i >> 2));
-        bits = (i & 3) == 0 ? r.x : ((i & 3) == 1 ? r.y : ((i & 3) == 2 ? r.z : r.w));
+        r = philox4x32_10(seed, 1u, (unsigned long long)(i >> 2));
+        word = (int)(i & 3);
     }
+    const unsigned bits = word == 0 ? r.x : (word == 1 ? r.y : (word == 2 ? r.z : r.w));
     out[i] = bits >= th ? sc : 0.f;
 }
 // dst[0:n] = src[0:n] for G (dst, src) pairs dst_gs / src_gs floats apart (blockIdx.y)
@@ -953,11 +990,12 @@ extern "C" int cpc_transformer_group_backward(const float* x, const float* const
 }
 
 // Test helper: out[i] = keep_i / (1 - p) for element i of dropout site `site` (0: attention probabilities, flat
-// ((b*8 + head)*S + i)*S + j; 1: feed-forward hidden layer, flat row*2048 + col) under `seed` -- the mask a
-// cpc_transformer_layer_forward_dropout call with that seed applies.
-extern "C" int cpc_dropout_keep_mask(float* out, long n, int site, float p, unsigned long long seed, void* stream) {
+// ((b*8 + head)*S + i)*S + j, n a multiple of S*S; 1: feed-forward hidden layer, flat row*2048 + col, S ignored) under `seed`
+// -- the mask a cpc_transformer_layer_forward_dropout call with that seed applies.
+extern "C" int cpc_dropout_keep_mask(float* out, long n, int site, int S, float p, unsigned long long seed, void* stream) {
     CPC_RETURN_IF(!out || n <= 0 || (site != 0 && site != 1) || !(p >= 0.f && p < 1.f), CPC_ERR_ARG);
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, n, site, p, seed);
+    CPC_RETURN_IF(site == 0 && (S <= 0 || S > kSmax || n % ((long)S * S) != 0), CPC_ERR_SHAPE);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, n, site, S, p, seed);
     CPC_LAUNCH_CHECK();
     return 0;
 }

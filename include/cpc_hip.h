@@ -282,9 +282,9 @@ int cpc_transformer_group_forward(const float* x, const float* const* params, fl
 int cpc_transformer_group_backward(const float* x, const float* const* params, const float* saved, const float* dy,
                                    float* scratch, float* dx, float* const* grads, int B, int S, int G, float p,
                                    unsigned long long seed, void* stream);
-/* Test helper: out[i] = keep_i / (1 - p) of dropout site 0 (attention probabilities, flat ((b*8 + head)*S + i)*S + j) or
- * 1 (hidden layer, flat row*2048 + col) under `seed`. */
-int cpc_dropout_keep_mask(float* out, long n, int site, float p, unsigned long long seed, void* stream);
+/* Test helper: out[i] = keep_i / (1 - p) of dropout site 0 (attention probabilities, flat ((b*8 + head)*S + i)*S + j; n a
+ * multiple of S*S) or 1 (hidden layer, flat row*2048 + col; S ignored) under `seed`. */
+int cpc_dropout_keep_mask(float* out, long n, int site, int S, float p, unsigned long long seed, void* stream);
 
 /* ---------------------------------------------------------------- criterion ----
  * CPCUnsupersivedCriterion.forward (criterion.py:225-257) with linear prediction heads

@@ -83,8 +83,8 @@ def test_transformer_layer_training_dropout_emulated(B, S, abspos, p_drop):
     out, dx, grads = run(seed)
     attn_keep = torch.full((B * 8, S, S), float("nan"))
     ffn_keep = torch.full((B, S, 2048), float("nan"))
-    assert lib.cpc_dropout_keep_mask(P(attn_keep), attn_keep.numel(), 0, p_drop, seed, None) == 0
-    assert lib.cpc_dropout_keep_mask(P(ffn_keep), ffn_keep.numel(), 1, p_drop, seed, None) == 0
+    assert lib.cpc_dropout_keep_mask(P(attn_keep), attn_keep.numel(), 0, S, p_drop, seed, None) == 0
+    assert lib.cpc_dropout_keep_mask(P(ffn_keep), ffn_keep.numel(), 1, S, p_drop, seed, None) == 0
     for m in (attn_keep, ffn_keep):
         assert set(m.unique().tolist()) <= {0.0, float(np.float32(1.0) / (np.float32(1.0) - np.float32(p_drop)))}
         assert abs((m > 0).float().mean().item() - (1 - p_drop)) < 0.01
@@ -99,7 +99,7 @@ def test_transformer_layer_training_dropout_emulated(B, S, abspos, p_drop):
     out2, _, _ = run(seed, forward_only=True)
     assert torch.equal(out, out2)                                   # the same seed reproduces the call ...
     other = torch.full_like(ffn_keep, float("nan"))
-    assert lib.cpc_dropout_keep_mask(P(other), other.numel(), 1, p_drop, seed + 1, None) == 0
+    assert lib.cpc_dropout_keep_mask(P(other), other.numel(), 1, S, p_drop, seed + 1, None) == 0
     assert not torch.equal(other, ffn_keep)                         # ... another seed draws other masks
 
 

@@ -158,8 +158,8 @@ def test_transformer_layer_trains_with_the_references_dropout():
     attn_keep = torch.empty(B * 8, S, S, device=dev)
     ffn_keep = torch.empty(B, S, 2048, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    lib.check(lib.cpc_dropout_keep_mask(P(attn_keep), attn_keep.numel(), 0, p_drop, seed, st), "keep_mask")
-    lib.check(lib.cpc_dropout_keep_mask(P(ffn_keep), ffn_keep.numel(), 1, p_drop, seed, st), "keep_mask")
+    lib.check(lib.cpc_dropout_keep_mask(P(attn_keep), attn_keep.numel(), 0, S, p_drop, seed, st), "keep_mask")
+    lib.check(lib.cpc_dropout_keep_mask(P(ffn_keep), ffn_keep.numel(), 1, S, p_drop, seed, st), "keep_mask")
     torch.cuda.synchronize()
     assert abs((ffn_keep > 0).float().mean().item() - 0.9) < 2e-3 and abs((attn_keep > 0).float().mean().item() - 0.9) < 5e-3
     leaves = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
