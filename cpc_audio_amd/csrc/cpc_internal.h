@@ -45,6 +45,26 @@ struct SplitK {
     float* part = nullptr;
     long floats = 0;
 };
+// What the feed-forward GEMMs of the transformer layer do to C on its way out (transformer.hip), fused into the wide fp16-piece
+// tile's epilogue -- nt_gemm_fuses() says whether a product runs on that tile; otherwise the caller launches the elementwise
+// kernel behind the GEMM (same arithmetic, same dropout masks).
+//   kind 1: C = dropout(relu(A.B^T + bias)): keep / (1 - p) by Philox site 1 (philox.h; stream seed + problem index); C's rows
+//           are kFfnWidth wide
+//   kind 2: C = (A.B^T) * scale where mask > 0, else 0 (mask: a tensor of C's shape and row pitch, problem g at + g * mask_gs)
+// amax (or NULL): max|C| into kAmaxSlots slots by atomicMax (zeroed by the caller), problem g at + g * amax_gs.
+struct GemmEpilogue {
+    int kind = 0;
+    float drop_p = 0.f;
+    unsigned long long seed = 0;
+    const float* mask = nullptr;
+    long mask_gs = 0;
+    float scale = 1.f;
+    float* amax = nullptr;
+    long amax_gs = 0;
+};
+bool nt_gemm_fuses(int M, int N, int K, int ldc, const GemmBounds& gb, const GemmGroup& grp);
+int nt_gemm_fused(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc, int N, int K,
+                  hipStream_t st, GemmBounds gb, GemmGroup grp, GemmEpilogue ep);
 // C[M,N] = A . B[N,K]^T (+ bias);  N % 128 == 0, K % 16 == 0
 int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc, int N,
             int K, hipStream_t st, int c_R = 0, long c_bstride = 0, GemmBounds gb = GemmBounds(), GemmGroup grp = GemmGroup(),

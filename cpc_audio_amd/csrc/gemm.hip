@@ -5,6 +5,7 @@
 // that batch-strided views (c[:, :W], h_{t-1} = y[:, t-1]) need no copies.
 #include "cpc_common.h"
 #include "cpc_internal.h"
+#include "philox.h"
 #include "gemm_tile.h"
 
 namespace cpc {
@@ -37,12 +38,14 @@ __device__ __forceinline__ OperandScales operand_scales(const GemmBounds& gb) {
 
 // Output row m goes to C + m*ldc, or, when c_R > 0, to C + (m / c_R)*c_bstride + (m % c_R)*ldc
 // (a batch-strided view such as dc[:, :W]).
-template <class NtG, int BMN, bool H2 = false, int BNN = BMN>
+// EPI: GemmEpilogue kind compiled in (0: none -- `ep` is ignored)
+template <class NtG, int BMN, bool H2 = false, int BNN = BMN, int EPI = 0>
 __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const float* __restrict__ Bmat,
                                                                 int ldb, const float* __restrict__ bias,
                                                                 float* __restrict__ C, long ldc, int K,
                                                                 int c_R, long c_bstride, GemmBounds gb, GemmGroup grp,
-                                                                int ksplit = 1, float* __restrict__ kpart = nullptr) {
+                                                                int ksplit = 1, float* __restrict__ kpart = nullptr,
+                                                                GemmEpilogue ep = GemmEpilogue()) {
     __shared__ float smem[NtG::SMEM_FLOATS];
     const int m0 = blockIdx.x * BMN, n0 = blockIdx.y * BNN;
     if (ksplit > 1) {                                    // slice blockIdx.z of the K walk; a dense (M, N) partial per slice
@@ -58,6 +61,11 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
         if (bias) bias += g * grp.bias;
         if (gb.a) gb.a += g * gb.a_gs;
         if (gb.b) gb.b += g * gb.b_gs;
+        if constexpr (EPI != 0) {
+            ep.seed += (unsigned long long)g;
+            if (ep.mask) ep.mask += g * ep.mask_gs;
+            if (ep.amax) ep.amax += g * ep.amax_gs;
+        }
     }
     f32x16 acc[NtG::TM][NtG::TN];
     zero_acc(acc);
@@ -69,21 +77,51 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
     } else {
         NtG::run(acc, am, m0, Bmat, ldb, n0, K, smem);
     }
+    float cmax = 0.f;
+    const unsigned th = EPI == 1 ? drop_threshold(ep.drop_p) : 0u;
+    const float keep_scale = EPI == 1 ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
 #pragma unroll
     for (int tn = 0; tn < NtG::TN; ++tn) {
         const int col = n0 + NtG::c_col(tn);
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int tm = 0; tm < NtG::TM; ++tm)
+        for (int tm = 0; tm < NtG::TM; ++tm) {
+            [[maybe_unused]] float mk[16];            // kind 2: the tile's mask values, requested together and unconditionally
+            if constexpr (EPI == 2) {                 // (clamped rows; a load inside the guarded store is a round trip each)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mk[r] = ep.mask[(long)min(m0 + NtG::c_row(tm, r), am.M - 1) * ldc + col];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + NtG::c_row(tm, r);
+                [[maybe_unused]] Philox4 draw;        // registers 4q .. 4q+3 are four consecutive rows: one Philox block
+                if constexpr (EPI == 1)
+                    if ((r & 3) == 0 && ep.drop_p > 0.f) draw = philox4x32_10(ep.seed, 1u, ffn_drop_block(m, col));
                 if (m < am.M) {
                     long ro = (long)m * ldc;
                     if (c_R > 0) { const int cb = m / c_R; ro = cb * c_bstride + (long)(m - cb * c_R) * ldc; }
-                    C[ro + col] = H2 ? fmaf(acc[tm][tn][r], inv, bv) : acc[tm][tn][r] + bv;
+                    float v = H2 ? fmaf(acc[tm][tn][r], inv, bv) : acc[tm][tn][r] + bv;
+                    if constexpr (EPI == 1) {
+                        v = fmaxf(v, 0.f);
+                        if (ep.drop_p > 0.f) v = philox_word(draw, r & 3) >= th ? v * keep_scale : 0.f;
+                    }
+                    if constexpr (EPI == 2) v = mk[r] > 0.f ? v * ep.scale : 0.f;
+                    if constexpr (EPI != 0) cmax = fmaxf(cmax, fabsf(v));
+                    C[ro + col] = v;
                 }
             }
+        }
+    }
+    if constexpr (EPI != 0) {                         // one atomic per workgroup (cross-XCD atomics on one address: ~1 us each)
+        __shared__ float wmax[NtG::NTHREADS / 64];
+        cmax = wave_max(cmax);
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = cmax;
+        __syncthreads();
+        if (threadIdx.x == 0 && ep.amax != nullptr) {
+            float m = 0.f;
+            for (int w = 0; w < NtG::NTHREADS / 64; ++w) m = fmaxf(m, wmax[w]);
+            atomicMax(reinterpret_cast<unsigned*>(ep.amax) + (blockIdx.x + 5u * blockIdx.y) % (unsigned)kAmaxSlots, __float_as_uint(m));
+        }
     }
 }
 
@@ -314,6 +352,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     long ro = (long)m * ldc;
     if (c_R > 0) { const int cb = m / c_R; ro = cb * c_bstride + (long)(m - cb * c_R) * ldc; }
     *reinterpret_cast<float4*>(C + ro + c) = s;
+}
+
+// The conditions under which nt_gemm() below picks the wide fp16-piece tile without a K split (the one tile whose epilogue is
+// compiled with the GemmEpilogue kinds), for a dense C.
+bool nt_gemm_fuses(int M, int N, int K, int ldc, const GemmBounds& gb, const GemmGroup& grp) {
+    return M > 0 && g_mfma_mode >= 2 && g_gemm_split && gb.a && gb.b && g_gemm_wide && N % 256 == 0 && K % 64 == 0 && ldc == N &&
+           (g_gemm_wide == 2 || (long)cdiv(M, 128) * (N / 256) * grp.G >= 256);
+}
+int nt_gemm_fused(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc, int N, int K,
+                  hipStream_t st, GemmBounds gb, GemmGroup grp, GemmEpilogue ep) {
+    if (!nt_gemm_fuses(am.M, N, K, (int)ldc, gb, grp) || (ep.kind != 1 && ep.kind != 2)) return CPC_ERR_ARG;
+    if (ep.kind == 1 && (N != kFfnWidth || !(ep.drop_p >= 0.f && ep.drop_p < 1.f))) return CPC_ERR_ARG;
+    if (ep.kind == 2 && !ep.mask) return CPC_ERR_ARG;
+    const dim3 grid(cdiv(am.M, 128), N / 256, grp.G);
+    if (ep.kind == 1)
+        hipLaunchKernelGGL((nt_gemm_kernel<NtWideH2, 128, true, 256, 1>), grid, dim3(NtWideH2::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
+                           ldc, K, 0, 0L, gb, grp, 1, (float*)nullptr, ep);
+    else
+        hipLaunchKernelGGL((nt_gemm_kernel<NtWideH2, 128, true, 256, 2>), grid, dim3(NtWideH2::NTHREADS), 0, st, am, Bmat, ldb, bias, C,
+                           ldc, K, 0, 0L, gb, grp, 1, (float*)nullptr, ep);
+    CPC_LAUNCH_CHECK();
+    return 0;
 }
 
 int nt_gemm(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc,

@@ -1,0 +1,37 @@
+// Philox4x32-10 (the counter-based generator torch uses on GPUs) and the numbering of the dropout sites of the transformer
+// layer (cpc/transformers.py:18,50 and :93,100): a keep decision is a pure function of (seed, site, element), so the backward
+// regenerates it and a test can ask for exactly the mask a call used (cpc_dropout_keep_mask).  Shared by transformer.hip and the
+// GEMM epilogue that applies the hidden layer's dropout (gemm.hip).
+#pragma once
+#include "cpc_common.h"
+
+namespace cpc {
+
+struct Philox4 { unsigned x, y, z, w; };
+__device__ __forceinline__ unsigned mulhi32(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsigned site, unsigned long long ctr) {
+    Philox4 c{(unsigned)ctr, (unsigned)(ctr >> 32), site, 0u};
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = Philox4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+// an element is dropped iff its 32 random bits fall below p * 2^32
+__device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)((double)p * 4294967296.0); }
+// Site 1 (feed-forward hidden layer, rows of kFfnWidth): as site 0 the four words of a block belong to four consecutive ROWS of
+// one column -- block (row >> 2) * 2048 + col, word row & 3 -- which is what a lane of a GEMM tile's accumulator holds.
+constexpr int kFfnWidth = 2048;
+__device__ __forceinline__ unsigned long long ffn_drop_block(long row, int col) {
+    return (unsigned long long)(row >> 2) * kFfnWidth + col;
+}
+__device__ __forceinline__ unsigned philox_word(const Philox4& r, int word) {
+    return word == 0 ? r.x : (word == 1 ? r.y : (word == 2 ? r.z : r.w));
+}
+
+}  // namespace cpc

@@ -15,6 +15,7 @@
 // result is read back skewed (E[i][S-1-i+j]); backward un-skews dScore on the fly as an MFMA operand.
 #include "cpc_common.h"
 #include "cpc_internal.h"
+#include "philox.h"
 
 namespace cpc {
 
@@ -135,24 +136,7 @@ __global__ __launch_bounds__(kAmaxSlots) void bounds_begin_kernel(float* __restr
 // counter-based generator torch uses on GPUs -- so the backward regenerates it instead of reading a saved mask, and a test
 // can ask for exactly the mask a layer call used (cpc_dropout_keep_mask).
 //   site 0: attention probability (b*8 + head, i, j) at flat index ((b*8 + head)*S + i)*S + j
-//   site 1: hidden activation (row, col) at flat index row*2048 + col; one Philox call serves 4 consecutive columns
-struct Philox4 { unsigned x, y, z, w; };
-__device__ __forceinline__ unsigned mulhi32(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
-__device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsigned site, unsigned long long ctr) {
-    Philox4 c{(unsigned)ctr, (unsigned)(ctr >> 32), site, 0u};
-    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const unsigned hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = Philox4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return c;
-}
-// an element is dropped iff its 32 random bits fall below p * 2^32
-__device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)((double)p * 4294967296.0); }
+//   site 1: hidden activation (row, col): block (row >> 2)*2048 + col, word row & 3 (philox.h)
 // Site 0 (attention probabilities): the four words of one Philox block belong to the four rows 4u .. 4u+3 of one column --
 // block index ((b*8 + head) * ceil(S/4) + (i >> 2)) * S + j, word i & 3 -- because that is what one lane of an MFMA
 // accumulator holds (c_row: registers 4m .. 4m+3 are four consecutive rows of one column): a lane draws 16 blocks for its 64
@@ -581,34 +565,58 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // x = relu(x), then (drop_p > 0) the hidden layer's dropout: x *= keep / (1 - p)   (transformers.py:93,100)
-// A workgroup covers kReluIters * 256 float4 (grid: cdiv(n4, 256 * kReluIters)) and publishes one max|x|.
-constexpr int kReluIters = 16;
-__global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, long n4, float drop_p, unsigned long long seed,
+// (the forward runs this as the epilogue of the lin1 GEMM where that GEMM is on the wide fp16-piece tile -- gemm.hip,
+// GemmEpilogue kind 1 -- and as this kernel otherwise: same arithmetic, same masks)
+// x (M, 2048); a thread takes one float4 column of four consecutive rows, whose 16 keep decisions are four Philox blocks; a
+// workgroup covers kReluIters * 256 such pieces (grid: cdiv(cdiv(M, 4) * 512, 256 * kReluIters)) and publishes one max|x|.
+constexpr int kReluIters = 4;
+__global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, int M, float drop_p, unsigned long long seed,
                                                    long x_gs, float* __restrict__ x_amax) {
     x += (long)blockIdx.y * x_gs;                     // layer blockIdx.y of a group, dropout stream seed + layer
     if (x_amax != nullptr) x_amax += (long)blockIdx.y * x_gs;
     seed += (unsigned long long)blockIdx.y;
     const unsigned th = drop_threshold(drop_p);
     const float sc = 1.0f / (1.0f - drop_p);
+    const long npiece = (long)((M + 3) >> 2) * (kDff / 4);
     float m = 0.f;
-#pragma unroll 4
     for (int it = 0; it < kReluIters; ++it) {
-        const long i = ((long)blockIdx.x * kReluIters + it) * 256 + threadIdx.x;
-        if (i >= n4) break;
-        float4 v = reinterpret_cast<float4*>(x)[i];
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        const long e = ((long)blockIdx.x * kReluIters + it) * 256 + threadIdx.x;
+        if (e >= npiece) break;
+        const long row0 = (e / (kDff / 4)) * 4;
+        const int c4 = (int)(e % (kDff / 4)) * 4;
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                   // rows past M: re-read the last row (unconditional loads), never stored
+            v[q] = *reinterpret_cast<const float4*>(x + min(row0 + q, (long)M - 1) * kDff + c4);
+        unsigned keep = 0xFFFFu;                      // bit 4 * column + row
         if (drop_p > 0.f) {
-            const Philox4 r = philox4x32_10(seed, 1u, (unsigned long long)i);      // elements 4i .. 4i+3
-            v.x = r.x >= th ? v.x * sc : 0.f; v.y = r.y >= th ? v.y * sc : 0.f;
-            v.z = r.z >= th ? v.z * sc : 0.f; v.w = r.w >= th ? v.w * sc : 0.f;
+            keep = 0u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const Philox4 r = philox4x32_10(seed, 1u, ffn_drop_block(row0, c4 + c));
+                keep |= ((r.x >= th ? 1u : 0u) | (r.y >= th ? 2u : 0u) | (r.z >= th ? 4u : 0u) | (r.w >= th ? 8u : 0u)) << (4 * c);
+            }
         }
-        reinterpret_cast<float4*>(x)[i] = v;
-        m = amax4(m, v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float* f = reinterpret_cast<float*>(&v[q]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float u = fmaxf(f[c], 0.f);
+                if (drop_p > 0.f) u = ((keep >> (4 * c + q)) & 1u) ? u * sc : 0.f;
+                f[c] = u;
+            }
+            if (row0 + q < M) {
+                *reinterpret_cast<float4*>(x + (row0 + q) * kDff + c4) = v[q];
+                m = amax4(m, v[q]);
+            }
+        }
     }
     publish_amax_block(x_amax, m);
 }
 // g *= (y > 0) * scale, y the SAVED hidden layer: it is zero where the ReLU cut or the dropout dropped, so the product of
 // the two derivatives is scale = 1 / (1 - p) exactly where y > 0
+constexpr int kReluBwdIters = 16;
 __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, long n4, float scale,
                                                        long g_gs, long y_gs, float* __restrict__ g_amax) {
     g += (long)blockIdx.y * g_gs;
@@ -616,8 +624,8 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, co
     if (g_amax != nullptr) g_amax += (long)blockIdx.y * g_gs;
     float m = 0.f;
 #pragma unroll 4
-    for (int it = 0; it < kReluIters; ++it) {
-        const long i = ((long)blockIdx.x * kReluIters + it) * 256 + threadIdx.x;
+    for (int it = 0; it < kReluBwdIters; ++it) {
+        const long i = ((long)blockIdx.x * kReluBwdIters + it) * 256 + threadIdx.x;
         if (i >= n4) break;
         float4 v = reinterpret_cast<float4*>(g)[i];
         const float4 a = reinterpret_cast<const float4*>(y)[i];
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, co
     publish_amax_block(g_amax, m);
 }
 // out[i] = keep_i / (1 - p) of site `site` (tests: the mask a layer call with this seed applied)
-// site 0: out (BH, S, S), element (bh, i, j) -- attn_drop_block; site 1: out flat, element i -- block i / 4, word i % 4
+// site 0: out (BH, S, S), element (bh, i, j) -- attn_drop_block; site 1: out (rows, 2048) -- ffn_drop_block
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long n, int site, int S, float drop_p,
                                                            unsigned long long seed) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -643,11 +651,11 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ o
         r = philox4x32_10(seed, 0u, attn_drop_block(bh, S, row, col));
         word = row & 3;
     } else {
-        r = philox4x32_10(seed, 1u, (unsigned long long)(i >> 2));
-        word = (int)(i & 3);
+        const long row = i / kFfnWidth;
+        r = philox4x32_10(seed, 1u, ffn_drop_block(row, (int)(i - row * kFfnWidth)));
+        word = (int)(row & 3);
     }
-    const unsigned bits = word == 0 ? r.x : (word == 1 ? r.y : (word == 2 ? r.z : r.w));
-    out[i] = bits >= th ? sc : 0.f;
+    out[i] = philox_word(r, word) >= th ? sc : 0.f;
 }
 // dst[0:n] = src[0:n] for G (dst, src) pairs dst_gs / src_gs floats apart (blockIdx.y)
 __global__ __launch_bounds__(256) void gcopy_kernel(float* __restrict__ dst, const float* __restrict__ src, long n, long dst_gs,
@@ -804,10 +812,20 @@ static int tf_forward(const TfGroup& tg, const float* x, const float* const* par
         return rc;
     hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, kLnFwdRows), G), dim3(256), 0, st, x, att, params[5], params[6],
                        saved + t.y, saved + t.xhat1, saved + t.rstd1, M, tg.x, sc, ps[5], sv, kC, sv, slot(kBY));
+    // hid = dropout(relu(y W1^T + b1)): as the GEMM's epilogue where it runs on the tile that has one, else a pass behind it
+    // (with dropout the elementwise kernel draws its Philox blocks at eight waves per SIMD; in the epilogue of a tile that runs
+    // two per SIMD the same draws cost more than the pass they save: 698 vs 377 + 284 us per group at B = 64)
+    if (bounded && p == 0.f && nt_gemm_fuses(M, kDff, kC, kDff, gbnd(kBY, kBW1), grp(sv, ps[7], ps[8], sv))) {
+        GemmEpilogue ep;
+        ep.kind = 1; ep.drop_p = p; ep.seed = seed; ep.amax = slot(kBHid); ep.amax_gs = sv;
+        if ((rc = nt_gemm_fused(plain_rows(saved + t.y, M, kC), params[7], kC, params[8], saved + t.hid, kDff, kDff, kC, st,
+                                gbnd(kBY, kBW1), grp(sv, ps[7], ps[8], sv), ep))) return rc;
+    } else {
     if ((rc = nt_gemm(plain_rows(saved + t.y, M, kC), params[7], kC, params[8], saved + t.hid, kDff, kDff, kC, st, 0, 0,
                       gbnd(kBY, kBW1), grp(sv, ps[7], ps[8], sv)))) return rc;
-    hipLaunchKernelGGL(relu_kernel, dim3(cdiv((long)M * kDff / 4, 256 * kReluIters), G), dim3(256), 0, st, saved + t.hid, (long)M * kDff / 4, p,
-                       seed, sv, slot(kBHid));
+    hipLaunchKernelGGL(relu_kernel, dim3(cdiv((long)cdiv(M, 4) * (kDff / 4), 256 * kReluIters), G), dim3(256), 0, st,
+                       saved + t.hid, M, p, seed, sv, slot(kBHid));
+    }
     float* ff = scratch;
     if ((rc = nt_gemm(plain_rows(saved + t.hid, M, kDff), params[9], kDff, params[10], ff, kC, kC, kDff, st, 0, 0, gbnd(kBHid, kBW2),
                       grp(sv, ps[9], ps[10], sc)))) return rc;
@@ -860,9 +878,17 @@ static int tf_backward(const TfGroup& tg, const float* x, const float* const* pa
     if ((rc = tn_gemm(ds2m, kC, hidm, kDff, part, grads[9], 0, st, gbnd(kBDs2, kBHid), grp(sc, sv, ps[9])))) return rc;   // dW2 (256,2048)
     if ((rc = rows_sum(ds2, M, kC, tmp, grads[10], st, G, sc, sc, ps[10]))) return rc;
     if ((rc = transpose(W2, scratch + t.w2t, kC, kDff, st, G, ps[9], sc))) return rc;           // (256,2048) -> (2048,256)
+    // dh = (ds2 W2) * [hid > 0] / (1 - p): hid is zero where the ReLU cut or the dropout dropped
+    if (bounded && nt_gemm_fuses(M, kDff, kC, kDff, gbnd(kBDs2, kBW2), grp(sc, sc, sc))) {
+        GemmEpilogue ep;
+        ep.kind = 2; ep.mask = saved + t.hid; ep.mask_gs = sv; ep.scale = 1.0f / (1.0f - p); ep.amax = slot(kBDh); ep.amax_gs = sc;
+        if ((rc = nt_gemm_fused(ds2m, scratch + t.w2t, kC, nullptr, dhid, kDff, kDff, kC, st, gbnd(kBDs2, kBW2), grp(sc, sc, sc), ep)))
+            return rc;
+    } else {
     if ((rc = nt_gemm(ds2m, scratch + t.w2t, kC, nullptr, dhid, kDff, kDff, kC, st, 0, 0, gbnd(kBDs2, kBW2), grp(sc, sc, sc)))) return rc;
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(cdiv((long)M * kDff / 4, 256 * kReluIters), G), dim3(256), 0, st, dhid, saved + t.hid,
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(cdiv((long)M * kDff / 4, 256 * kReluBwdIters), G), dim3(256), 0, st, dhid, saved + t.hid,
                        (long)M * kDff / 4, 1.0f / (1.0f - p), sc, sv, slot(kBDh));
+    }
     // hid = relu(y W1^T + b1)
     const RowMap dhm = plain_rows(dhid, M, kDff), ym = plain_rows(saved + t.y, M, kC);
     if ((rc = tn_gemm(dhm, kDff, ym, kC, part, grads[7], 0, st, gbnd(kBDh, kBY), grp(sc, sv, ps[7])))) return rc;      // dW1 (2048,256)

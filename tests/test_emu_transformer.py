@@ -51,8 +51,20 @@ def test_transformer_layer_forward_backward_emulated(B, S, abspos):
     assert not bad, bad
 
 
+@pytest.fixture(params=[1, 3], ids=["elementwise-relu", "relu-in-gemm-epilogue"])
+def gemm_split(request):
+    """cpc_set_gemm_split(3) puts every product on the wide fp16-piece tile however small the grid, which is the tile whose
+    epilogue carries the feed-forward ReLU + dropout (forward) and the ReLU derivative (backward) -- at the sizes of these tests
+    the default takes the small tiles with the elementwise kernels behind them.  Both must produce what the oracle produces
+    with the masks cpc_dropout_keep_mask reports."""
+    lib = emu()
+    assert lib.cpc_set_gemm_split(request.param) == 0
+    yield request.param
+    lib.cpc_set_gemm_split(1)
+
+
 @pytest.mark.parametrize("B,S,abspos,p_drop", [(1, 40, False, 0.1), (1, 48, True, 0.3)])
-def test_transformer_layer_training_dropout_emulated(B, S, abspos, p_drop):
+def test_transformer_layer_training_dropout_emulated(B, S, abspos, p_drop, gemm_split):
     """Training-mode dropout (cpc/transformers.py:18,50,93,100): the layer run with dropout probability p and a seed must
     equal the oracle run with the masks that seed generates (cpc_dropout_keep_mask: Philox4x32-10 over the element index),
     forward and every gradient; the masks keep ~(1 - p) of the elements and the same seed reproduces the call."""
@@ -104,7 +116,7 @@ def test_transformer_layer_training_dropout_emulated(B, S, abspos, p_drop):
 
 
 @pytest.mark.parametrize("abspos,p_drop", [(False, 0.0), (False, 0.2), (True, 0.0)])
-def test_group_of_layers_equals_single_layer_calls_emulated(abspos, p_drop):
+def test_group_of_layers_equals_single_layer_calls_emulated(abspos, p_drop, gemm_split):
     """cpc_transformer_group_forward / _backward (the K transformer predictors of the criterion run in lock-step, one launch
     per kernel): layer g of the group == a single-layer call on the same input with layer g's parameters (and seed + g),
     bit for bit -- outputs interleaved as (B*S, G*256), dx = the sum of the layers' input gradients."""
