@@ -208,7 +208,10 @@ class Trainer:
                 steady = self._probe[2:]                    # the first calls pay allocator / lazy-initialisation costs
                 host_ms = 1e3 * sum(h for h, _, _ in steady) / len(steady)
                 gpu_ms = sum(a.elapsed_time(b) for _, a, b in steady) / len(steady)
-                self.graph = host_ms > 0.85 * gpu_ms
+                # Replay costs the host one launch and runs within 0.5 % of the eager step, so it is taken as
+                # soon as the host is not comfortably ahead: at 0.8 of the GPU time (a box of round 3: 2.4 ms of enqueueing
+                # for a 3.1 ms step) a few slow Python iterations already starve the queue -- mean 3.39 vs median 3.09 ms.
+                self.graph = host_ms > 0.6 * gpu_ms
                 self.launch_decision = {"host_ms_per_step": round(host_ms, 3), "gpu_ms_per_step": round(gpu_ms, 3),
                                         "graph": self.graph}
                 self._probe = []
