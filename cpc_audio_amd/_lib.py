@@ -40,6 +40,7 @@ SIGNATURES = {
     "cpc_set_wgrad1_early": (_I, [_I]),
     "cpc_set_wgrad_dma_groups": (_I, [_I]),
     "cpc_set_gemm_split": (_I, [_I]),
+    "cpc_set_gemm_fuse": (_I, [_I]),
     "cpc_set_gru_xcd_pack": (_I, [_I]),
     "cpc_set_gru_chunk_tiles": (_I, [_I]),
     "cpc_set_gru_poll_pacing": (_I, [_I, _I]),

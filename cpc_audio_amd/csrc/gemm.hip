@@ -356,8 +356,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // The conditions under which nt_gemm() below picks the wide fp16-piece tile without a K split (the one tile whose epilogue is
 // compiled with the GemmEpilogue kinds), for a dense C.
+int g_gemm_fuse = 1;       // cpc_set_gemm_fuse: 0 keeps the elementwise kernels behind the feed-forward GEMMs (tests, A/B)
 bool nt_gemm_fuses(int M, int N, int K, int ldc, const GemmBounds& gb, const GemmGroup& grp) {
-    return M > 0 && g_mfma_mode >= 2 && g_gemm_split && gb.a && gb.b && g_gemm_wide && N % 256 == 0 && K % 64 == 0 && ldc == N &&
+    return g_gemm_fuse && M > 0 && g_mfma_mode >= 2 && g_gemm_split && gb.a && gb.b && g_gemm_wide && N % 256 == 0 && K % 64 == 0 && ldc == N &&
            (g_gemm_wide == 2 || (long)cdiv(M, 128) * (N / 256) * grp.G >= 256);
 }
 int nt_gemm_fused(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc, int N, int K,
@@ -573,6 +574,13 @@ extern "C" int cpc_gemm_tn(const float* A, int lda, const float* B, int ldb, flo
 
 // 1 (default): plain GEMMs whose operand bounds are known run on two fp16 pieces in cpc_set_mfma_mode >= 2; 0: three bf16
 // pieces always (A/B measurements, numerical comparisons)
+// 1 (default): the transformer layer's feed-forward ReLU (forward, without dropout) and ReLU derivative (backward) run as
+// epilogues of their GEMMs where those take the wide fp16-piece tile (GemmEpilogue); 0: always as elementwise kernels behind the
+// GEMMs.  Same bits either way (tests/test_gpu_transformer.py).
+extern "C" int cpc_set_gemm_fuse(int on) {
+    cpc::g_gemm_fuse = on ? 1 : 0;
+    return 0;
+}
 extern "C" int cpc_set_gemm_split(int on) {
     cpc::g_gemm_split = on ? 1 : 0;
     cpc::g_gemm_wide = on == 2 ? 0 : (on == 3 ? 2 : 1);   // 2: two fp16 pieces, but never the 128 x 256 tile (A/B measurements);

@@ -104,6 +104,9 @@ int cpc_set_h2_dx(int on);               /* mode 3: 1 (default) keeps the gradie
 int cpc_set_gemm_split(int on);          /* 1 (default): plain GEMMs with known operand bounds (the criterion's, see cpc_nce_forward) run on two
                                             fp16 pieces in mode >= 2, wide products on the 128 x 256 pipelined tile; 0: three bf16 pieces always;
                                             2: two pieces but never the wide tile; 3: the wide tile whatever the grid size (tests) */
+int cpc_set_gemm_fuse(int on);           /* 1 (default): the transformer layer's feed-forward ReLU (forward, dropout 0) and ReLU derivative
+                                            (backward) as epilogues of their GEMMs on the wide fp16-piece tile; 0: elementwise kernels
+                                            behind the GEMMs (same bits) */
 int cpc_set_dma_rotation(int step);
 int cpc_set_dma_pipeline(int variant);   /* main-loop schedule of the forward DMA kernel on 256-row tiles (tuning / measurement switch; results
                                           * agree to rounding order).  2 (default): tap-pair walk -- an input row reaches LDS once for both

@@ -218,3 +218,47 @@ def test_config4_at_its_quoted_batch_is_finite_reproducible_and_grouped_equals_p
     assert (l1 - l3).abs().max().item() < 1e-5
     worst = max(_rel(a, b) for a, b in zip(g1, g3))
     assert worst < 2e-5, worst
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_feed_forward_epilogues_equal_the_elementwise_kernels_bit_for_bit(p_drop):
+    """At B = 64 the feed-forward GEMMs run on the wide fp16-piece tile, whose epilogue carries the ReLU derivative (backward, any
+    dropout) and the ReLU (forward, dropout 0) -- cpc_set_gemm_fuse(0) puts the elementwise kernels back behind the same GEMMs.
+    Same products, same order, same masks: every output and gradient of a layer call must agree bit for bit."""
+    dev = _dev()
+    import ctypes
+    from cpc_audio_amd import _lib
+    from cpc_audio_amd._lib import ptr as P
+    lib = _lib.get()
+    B, S = 64, 128
+    prm = T.make_layer_params(31, 256, S, False)
+    order = ["multihead.Wo.weight", "multihead.Wk.weight", "multihead.Wq.weight", "multihead.Wv.weight", "multihead.Att.Krelpos",
+             "ln_multihead.weight", "ln_multihead.bias", "ffnetwork.lin1.weight", "ffnetwork.lin1.bias", "ffnetwork.lin2.weight",
+             "ffnetwork.lin2.bias", "ln_ffnetwork.weight", "ln_ffnetwork.bias"]
+    plist = [prm[k].contiguous().to(dev) for k in order]
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, S, 256, generator=g).to(dev)
+    dy = torch.randn(B, S, 256, generator=g).to(dev)
+    sizes = (ctypes.c_long * 8)()
+    lib.check(lib.cpc_transformer_layout(B, S, sizes), "layout")
+    parr = (ctypes.c_void_p * 13)(*[P(t) for t in plist])
+    st = torch.cuda.current_stream().cuda_stream
+    runs = []
+    try:
+        for fuse in (1, 0):
+            lib.check(lib.cpc_set_gemm_fuse(fuse), "fuse")
+            saved = torch.empty(sizes[0], device=dev); fscr = torch.empty(sizes[1], device=dev); bscr = torch.empty(sizes[2], device=dev)
+            out = torch.empty(B, S, 256, device=dev); dx = torch.empty(B, S, 256, device=dev)
+            grads = [torch.empty_like(t) for t in plist]
+            garr = (ctypes.c_void_p * 13)(*[P(t) for t in grads])
+            lib.check(lib.cpc_transformer_layer_forward_dropout(P(x), parr, P(saved), P(fscr), P(out), B, S, p_drop, 99, st), "fwd")
+            lib.check(lib.cpc_transformer_layer_backward_dropout(P(x), parr, P(saved), P(dy), P(bscr), P(dx), garr, B, S, p_drop, 99,
+                                                                 st), "bwd")
+            torch.cuda.synchronize()
+            hid = saved[sizes[7]:sizes[7] + B * S * 2048].clone()
+            runs.append([out, dx, hid] + grads)
+    finally:
+        lib.cpc_set_gemm_fuse(1)
+    assert torch.isfinite(runs[0][0]).all() and (runs[0][2] == 0).float().mean().item() > 0.3     # the ReLU (and dropout) cut
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
