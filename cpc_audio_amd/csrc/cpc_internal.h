@@ -51,6 +51,7 @@ struct SplitK {
 //   kind 1: C = dropout(relu(A.B^T + bias)): keep / (1 - p) by Philox site 1 (philox.h; stream seed + problem index); C's rows
 //           are kFfnWidth wide
 //   kind 2: C = (A.B^T) * scale where mask > 0, else 0 (mask: a tensor of C's shape and row pitch, problem g at + g * mask_gs)
+//           (+ colsum: what the bias gradient of the layer in front needs, without another pass over C)
 // amax (or NULL): max|C| into kAmaxSlots slots by atomicMax (zeroed by the caller), problem g at + g * amax_gs.
 struct GemmEpilogue {
     int kind = 0;
@@ -61,6 +62,8 @@ struct GemmEpilogue {
     float scale = 1.f;
     float* amax = nullptr;
     long amax_gs = 0;
+    float* colsum = nullptr;      // (or NULL) per-row-tile column sums of C: colsum[(m0 / 128) * N + col], problem g at + g * colsum_gs
+    long colsum_gs = 0;           // -- the bias gradient's partials, summed over the row tiles by rows_sum afterwards
 };
 bool nt_gemm_fuses(int M, int N, int K, int ldc, const GemmBounds& gb, const GemmGroup& grp);
 int nt_gemm_fused(const RowMap& am, const float* Bmat, int ldb, const float* bias, float* C, long ldc, int N, int K,

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
             ep.seed += (unsigned long long)g;
             if (ep.mask) ep.mask += g * ep.mask_gs;
             if (ep.amax) ep.amax += g * ep.amax_gs;
+            if (ep.colsum) ep.colsum += g * ep.colsum_gs;
         }
     }
     f32x16 acc[NtG::TM][NtG::TN];
@@ -78,6 +79,9 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
         NtG::run(acc, am, m0, Bmat, ldb, n0, K, smem);
     }
     float cmax = 0.f;
+    [[maybe_unused]] float csum[NtG::TN];
+#pragma unroll
+    for (int tn = 0; tn < NtG::TN; ++tn) csum[tn] = 0.f;
     const unsigned th = EPI == 1 ? drop_threshold(ep.drop_p) : 0u;
     const float keep_scale = EPI == 1 ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
 #pragma unroll
@@ -107,6 +111,7 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
                     }
                     if constexpr (EPI == 2) v = mk[r] > 0.f ? v * ep.scale : 0.f;
                     if constexpr (EPI != 0) cmax = fmaxf(cmax, fabsf(v));
+                    if constexpr (EPI == 2) csum[tn] += v;
                     C[ro + col] = v;
                 }
             }
@@ -121,6 +126,25 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
             float m = 0.f;
             for (int w = 0; w < NtG::NTHREADS / 64; ++w) m = fmaxf(m, wmax[w]);
             atomicMax(reinterpret_cast<unsigned*>(ep.amax) + (blockIdx.x + 5u * blockIdx.y) % (unsigned)kAmaxSlots, __float_as_uint(m));
+        }
+    }
+    if constexpr (EPI == 2) {                         // column sums of the tile, in a fixed order: lane halves, then the waves along M
+        if (ep.colsum != nullptr) {                   // block-uniform
+            constexpr int WAVES_M = BMN / NtG::WM;
+            __shared__ float cs[WAVES_M][BNN];
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+            for (int tn = 0; tn < NtG::TN; ++tn) {
+                const float s = csum[tn] + __shfl_xor(csum[tn], 32);
+                if (lane < 32) cs[wave / (BNN / NtG::WN)][NtG::c_col(tn)] = s;
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < BNN; c += NtG::NTHREADS) {
+                float s = cs[0][c];
+#pragma unroll
+                for (int w = 1; w < WAVES_M; ++w) s += cs[w][c];
+                ep.colsum[(long)blockIdx.x * (gridDim.y * BNN) + n0 + c] = s;
+            }
         }
     }
 }

@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const f
 struct TfLayout {
     long qkv, A, o, xhat1, rstd1, y, hid, xhat2, rstd2, bounds, saved_total;   // saved for backward
     long fwd_total;                                                        // forward scratch: one (M,256) buffer
-    long ds2, dhid, dyb, ds1, dob, dqkv, w2t, w1t, wot, wqkv, wqkvt, part, lnpart, tmp, dppart, bbounds, bwd_total;
+    long ds2, dhid, dyb, ds1, dob, dqkv, w2t, w1t, wot, wqkv, wqkvt, part, lnpart, tmp, dppart, bbounds, colpart, bwd_total;
 };
 // GEMM operand bounds (publish_amax), kAmaxSlots floats each.  Forward's live in `saved` (the backward reads them again; a
 // group keeps them in layer 0's copy), the gradients' in the backward scratch.
@@ -733,6 +733,7 @@ static bool tf_layout(int B, int S, TfLayout& t) {
     t.tmp = o; o += align64l((long)kRowsSumGroups * (kDk * S > kDff ? kDk * S : kDff));
     t.dppart = o; o += align64l((long)B * kTH * kDk * S);
     t.bbounds = o; o += (long)kTfBwdBounds * kAmaxSlots;
+    t.colpart = o; o += align64l((long)cdiv(M, 128) * kDff);          // column sums of dh per 128-row tile (GemmEpilogue::colsum)
     t.bwd_total = o;
     return true;
 }
@@ -879,9 +880,12 @@ static int tf_backward(const TfGroup& tg, const float* x, const float* const* pa
     if ((rc = rows_sum(ds2, M, kC, tmp, grads[10], st, G, sc, sc, ps[10]))) return rc;
     if ((rc = transpose(W2, scratch + t.w2t, kC, kDff, st, G, ps[9], sc))) return rc;           // (256,2048) -> (2048,256)
     // dh = (ds2 W2) * [hid > 0] / (1 - p): hid is zero where the ReLU cut or the dropout dropped
+    bool db1_from_tiles = false;
     if (bounded && nt_gemm_fuses(M, kDff, kC, kDff, gbnd(kBDs2, kBW2), grp(sc, sc, sc))) {
         GemmEpilogue ep;
         ep.kind = 2; ep.mask = saved + t.hid; ep.mask_gs = sv; ep.scale = 1.0f / (1.0f - p); ep.amax = slot(kBDh); ep.amax_gs = sc;
+        ep.colsum = scratch + t.colpart; ep.colsum_gs = sc;            // db1 = column sums of dh, per row tile here
+        db1_from_tiles = true;
         if ((rc = nt_gemm_fused(ds2m, scratch + t.w2t, kC, nullptr, dhid, kDff, kDff, kC, st, gbnd(kBDs2, kBW2), grp(sc, sc, sc), ep)))
             return rc;
     } else {
@@ -892,7 +896,9 @@ static int tf_backward(const TfGroup& tg, const float* x, const float* const* pa
     // hid = relu(y W1^T + b1)
     const RowMap dhm = plain_rows(dhid, M, kDff), ym = plain_rows(saved + t.y, M, kC);
     if ((rc = tn_gemm(dhm, kDff, ym, kC, part, grads[7], 0, st, gbnd(kBDh, kBY), grp(sc, sv, ps[7])))) return rc;      // dW1 (2048,256)
-    if ((rc = rows_sum(dhid, M, kDff, tmp, grads[8], st, G, sc, sc, ps[8]))) return rc;
+    if (db1_from_tiles) rc = rows_sum(scratch + t.colpart, cdiv(M, 128), kDff, tmp, grads[8], st, G, sc, sc, ps[8]);
+    else rc = rows_sum(dhid, M, kDff, tmp, grads[8], st, G, sc, sc, ps[8]);
+    if (rc) return rc;
     if ((rc = transpose(W1, scratch + t.w1t, kDff, kC, st, G, ps[7], sc))) return rc;           // (2048,256) -> (256,2048)
     if ((rc = nt_gemm(dhm, scratch + t.w1t, kDff, nullptr, dyb, kC, kC, kDff, st, 0, 0, gbnd(kBDh, kBW1), grp(sc, sc, sc)))) return rc;
     hipLaunchKernelGGL(add_kernel, dim3(cdiv(n4, 256), G), dim3(256), 0, st, dyb, ds2, n4, sc, sc);   // dy_total = ds2 + dhid W1

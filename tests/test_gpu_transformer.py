@@ -224,7 +224,8 @@ def test_config4_at_its_quoted_batch_is_finite_reproducible_and_grouped_equals_p
 def test_feed_forward_epilogues_equal_the_elementwise_kernels_bit_for_bit(p_drop):
     """At B = 64 the feed-forward GEMMs run on the wide fp16-piece tile, whose epilogue carries the ReLU derivative (backward, any
     dropout) and the ReLU (forward, dropout 0) -- cpc_set_gemm_fuse(0) puts the elementwise kernels back behind the same GEMMs.
-    Same products, same order, same masks: every output and gradient of a layer call must agree bit for bit."""
+    Same products, same order, same masks: every output and gradient of a layer call must agree bit for bit (but lin1's bias
+    gradient, whose column sums the fused backward takes per tile inside the epilogue: rounding order only)."""
     dev = _dev()
     import ctypes
     from cpc_audio_amd import _lib
@@ -260,5 +261,8 @@ def test_feed_forward_epilogues_equal_the_elementwise_kernels_bit_for_bit(p_drop
     finally:
         lib.cpc_set_gemm_fuse(1)
     assert torch.isfinite(runs[0][0]).all() and (runs[0][2] == 0).float().mean().item() > 0.3     # the ReLU (and dropout) cut
-    for a, b in zip(*runs):
-        assert torch.equal(a, b)
+    for i, (a, b) in enumerate(zip(*runs)):
+        if i == 3 + order.index("ffnetwork.lin1.bias"):      # summed per 128-row tile in the epilogue, then over the tiles:
+            assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()       # another order of the same 8192 terms
+        else:
+            assert torch.equal(a, b), i
