@@ -69,6 +69,8 @@ def test_transformer_layer_training_dropout_emulated(B, S, abspos, p_drop, gemm_
     """Training-mode dropout (cpc/transformers.py:18,50,93,100): the layer run with dropout probability p and a seed must
     equal the oracle run with the masks that seed generates (cpc_dropout_keep_mask: Philox4x32-10 over the element index),
     forward and every gradient; the masks keep ~(1 - p) of the elements and the same seed reproduces the call."""
+    if gemm_split == 3 and S != 40:
+        pytest.skip("the wide tile is slow on the emulator: one shape is enough for the epilogue")
     lib = emu()
     prm = T.make_layer_params(seed=9 + S, size_seq=S, abspos=abspos)
     g = torch.Generator().manual_seed(S + 1)
@@ -121,6 +123,8 @@ def test_group_of_layers_equals_single_layer_calls_emulated(abspos, p_drop, gemm
     """cpc_transformer_group_forward / _backward (the K transformer predictors of the criterion run in lock-step, one launch
     per kernel): layer g of the group == a single-layer call on the same input with layer g's parameters (and seed + g),
     bit for bit -- outputs interleaved as (B*S, G*256), dx = the sum of the layers' input gradients."""
+    if gemm_split == 3 and abspos:
+        pytest.skip("the wide tile is slow on the emulator: p = 0 (ReLU epilogue) and p > 0 (ReLU-derivative epilogue) suffice")
     lib = emu()
     B, S, G = 1, 40, 3
     prms = [T.make_layer_params(seed=20 + q, size_seq=S, abspos=abspos) for q in range(G)]
