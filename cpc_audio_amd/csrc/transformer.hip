@@ -416,16 +416,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             float a8[8];                                      // workgroup read them in phase 1)
 #pragma unroll
             for (int u = 0; u < 8; ++u) a8[u] = acol[(long)min(2 * (kb + u) + khalf, S - 1) * S];
-            // rows i = 2 (kb + u) + khalf of column jl: four Philox blocks of four rows, of which this half-wave has two each
+            // rows i = 2 (kb + u) + khalf of column jl: four Philox blocks of four rows each, and the two lanes l31 / l31 + 32
+            // need the same four (one the even words, one the odd): each draws two and they swap the 8 decisions
             unsigned keep = 0u;
             if (drop_p > 0.f) {
                 const unsigned th = drop_threshold(drop_p);
+                unsigned mine = 0u;                                 // bit 4 mm + word, blocks m = 2 khalf + mm
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const Philox4 q = philox4x32_10(seed, 0u, attn_drop_block(bh, S, 2 * kb + 4 * m, jl));
-                    const unsigned lo = khalf ? q.y : q.x, hi = khalf ? q.w : q.z;     // rows 4m + khalf, 4m + 2 + khalf
-                    keep |= ((lo >= th ? 1u : 0u) | (hi >= th ? 2u : 0u)) << (2 * m);  // bit u <-> row 2 (kb + u) + khalf
+                for (int mm = 0; mm < 2; ++mm) {
+                    const Philox4 q = philox4x32_10(seed, 0u, attn_drop_block(bh, S, 2 * kb + 4 * (2 * khalf + mm), jl));
+                    mine |= ((q.x >= th ? 1u : 0u) | (q.y >= th ? 2u : 0u) | (q.z >= th ? 4u : 0u) | (q.w >= th ? 8u : 0u)) << (4 * mm);
                 }
+                const unsigned theirs = (unsigned)__shfl_xor((int)mine, 32);
+                const unsigned all = khalf ? (theirs | (mine << 8)) : (mine | (theirs << 8));     // bit 4 m + word, m = 0..3
+#pragma unroll
+                for (int m = 0; m < 4; ++m)                         // bit u <-> row 2 (kb + u) + khalf: words khalf, 2 + khalf
+                    keep |= (((all >> (4 * m + khalf)) & 1u) | (((all >> (4 * m + 2 + khalf)) & 1u) << 1)) << (2 * m);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
