@@ -43,44 +43,47 @@ __device__ __forceinline__ float half_sum(float v) {
 // four 16-byte pieces each.  Two halves so that a kernel can request all its slices before it waits for the first: the
 // loads are unconditional on a clamped row (a predicated load is a branch and a full vmcnt(0) each -- as a loop of
 // load -> store per piece, staging four slices was 28 round trips to L2 one after the other, half of the kernel's time).
-struct HeadPieces { float4 v[4]; };
-__device__ __forceinline__ HeadPieces load_head(const float* __restrict__ src, long row0, int ld, int col0, int S) {
-    HeadPieces p;
+template <int NT> struct HeadPieces { float4 v[1024 / NT]; };     // NT threads per workgroup
+template <int NT>
+__device__ __forceinline__ HeadPieces<NT> load_head(const float* __restrict__ src, long row0, int ld, int col0, int S) {
+    HeadPieces<NT> p;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int e = threadIdx.x + 256 * u, i = e >> 3, c4 = (e & 7) * 4;
+    for (int u = 0; u < 1024 / NT; ++u) {
+        const int e = threadIdx.x + NT * u, i = e >> 3, c4 = (e & 7) * 4;
         const float4 v = *reinterpret_cast<const float4*>(src + (row0 + min(i, S - 1)) * ld + col0 + c4);
         p.v[u] = i < S ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return p;
 }
-__device__ __forceinline__ void store_head(float* dst, const HeadPieces& p) {
+template <int NT>
+__device__ __forceinline__ void store_head(float* dst, const HeadPieces<NT>& p) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int e = threadIdx.x + 256 * u, i = e >> 3, c4 = (e & 7) * 4;
+    for (int u = 0; u < 1024 / NT; ++u) {
+        const int e = threadIdx.x + NT * u, i = e >> 3, c4 = (e & 7) * 4;
         float* d = dst + i * kLdH + c4;
         d[0] = p.v[u].x; d[1] = p.v[u].y; d[2] = p.v[u].z; d[3] = p.v[u].w;
     }
 }
 // Krelpos (32, S) -> LDS rows of pitch kLdS, zero beyond S (or everywhere without relative positions)
+template <int NT>
 __device__ __forceinline__ void stage_relpos(float* dst, const float* __restrict__ P, int S) {
     if (P != nullptr && (S & 3) == 0) {                       // block-uniform
-        float4 v[4];
+        float4 v[1024 / NT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = threadIdx.x + 256 * u, d = e >> 5, c4 = (e & 31) * 4;
+        for (int u = 0; u < 1024 / NT; ++u) {
+            const int e = threadIdx.x + NT * u, d = e >> 5, c4 = (e & 31) * 4;
             v[u] = *reinterpret_cast<const float4*>(P + d * S + min(c4, S - 4));
             if (c4 >= S) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = threadIdx.x + 256 * u, d = e >> 5, c4 = (e & 31) * 4;
+        for (int u = 0; u < 1024 / NT; ++u) {
+            const int e = threadIdx.x + NT * u, d = e >> 5, c4 = (e & 31) * 4;
             float* q = dst + d * kLdS + c4;
             q[0] = v[u].x; q[1] = v[u].y; q[2] = v[u].z; q[3] = v[u].w;
         }
         return;
     }
-    for (int e = threadIdx.x; e < kDk * kSmax; e += 256) {
+    for (int e = threadIdx.x; e < kDk * kSmax; e += NT) {
         const int d = e >> 7, c = e & (kSmax - 1);
         dst[d * kLdS + c] = (P != nullptr && c < S) ? P[d * S + c] : 0.f;
     }
@@ -181,9 +184,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     const int l31 = lane & 31, khalf = lane >> 5;
     const long row0 = (long)b * S;
     {
-        const HeadPieces pq = load_head(qkv, row0, 3 * kC, h * kDk, S), pk = load_head(qkv, row0, 3 * kC, kC + h * kDk, S),
-                         pv = load_head(qkv, row0, 3 * kC, 2 * kC + h * kDk, S);
-        stage_relpos(Ps, P, S);
+        const HeadPieces<256> pq = load_head<256>(qkv, row0, 3 * kC, h * kDk, S), pk = load_head<256>(qkv, row0, 3 * kC, kC + h * kDk, S),
+                              pv = load_head<256>(qkv, row0, 3 * kC, 2 * kC + h * kDk, S);
+        stage_relpos<256>(Ps, P, S);
         store_head(Qs, pq); store_head(Ks, pk); store_head(Vs, pv);
     }
     __syncthreads();
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------ attention backward
 // dqkv (B*S, 768) = [dq | dk | dv];  dPpart (B*8, 32, S): per-workgroup partial of dKrelpos (reduced afterwards).
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                        const float* __restrict__ o, const float* __restrict__ A,
                                                        const float* __restrict__ dO, float* __restrict__ dqkv,
                                                        float* __restrict__ dPpart, int S, float drop_p,
@@ -311,14 +314,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     float* Ds = Ps + kDk * kLdS;                      // dScore [128][kLdS]
     __shared__ float rdot[kSmax];
     const int bh = blockIdx.x, b = bh / kTH, h = bh % kTH;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;          // eight waves: tasks are dealt out below
     const int l31 = lane & 31, khalf = lane >> 5;
     const long row0 = (long)b * S;
     float gmax = 0.f;                                 // max|dq|, |dk|, |dv| of what this thread stores
     {
-        const HeadPieces pq = load_head(qkv, row0, 3 * kC, h * kDk, S), pk = load_head(qkv, row0, 3 * kC, kC + h * kDk, S),
-                         pv = load_head(qkv, row0, 3 * kC, 2 * kC + h * kDk, S), pg = load_head(dO, row0, kC, h * kDk, S);
-        stage_relpos(Ps, P, S);
+        const HeadPieces<512> pq = load_head<512>(qkv, row0, 3 * kC, h * kDk, S), pk = load_head<512>(qkv, row0, 3 * kC, kC + h * kDk, S),
+                              pv = load_head<512>(qkv, row0, 3 * kC, 2 * kC + h * kDk, S), pg = load_head<512>(dO, row0, kC, h * kDk, S);
+        stage_relpos<512>(Ps, P, S);
         store_head(Qs, pq); store_head(Ks, pk); store_head(Vs, pv); store_head(Gs, pg);
     }
     if (threadIdx.x < kSmax) {                        // rowdot_i = dO_i . o_i = sum_j dA_ij A_ij
@@ -334,52 +337,49 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
     __syncthreads();
 
-    // ---- phase 1: dScore rows of this wave
+    // ---- phase 1: the ten 32 x 32 tiles (row block w, column block ct <= w) of dScore, dealt to the eight waves (tiles above
+    // the diagonal are never read).  One workgroup per CU is all the LDS allows; with four waves -- one per SIMD, which cannot
+    // issue back to back -- the kernel spent its time in instruction issue, so the same tasks now run on two waves per SIMD.
     const float scale = 0.17677669529663687f;
     const float* Abh = A + (long)bh * S * S;
-    {
-        const float* grow = Gs + (32 * w + l31) * kLdH;
 #pragma unroll 1
-        for (int ct = 0; ct < 4; ++ct) {
-            f32x16 acc;
-            float ap[16];                             // this tile's probabilities: requested (unconditionally, on clamped
+    for (int q = wv; q < 10; q += 8) {
+        const int w = q >= 6 ? 3 : (q >= 3 ? 2 : (q >= 1 ? 1 : 0)), ct = q - w * (w + 1) / 2;
+        const float* grow = Gs + (32 * w + l31) * kLdH;
+        f32x16 acc;
+        float ap[16];                                 // this tile's probabilities: requested (unconditionally, on clamped
 #pragma unroll                                        // indices) before the products they will meet
-            for (int r = 0; r < 16; ++r) {
-                acc[r] = 0.f;
-                ap[r] = 0.f;
-            }
-            unsigned keep = 0u;
-            if (ct <= w) {
+        for (int r = 0; r < 16; ++r) {
+            acc[r] = 0.f;
+            ap[r] = Abh[(long)min(32 * w + c_row(r, lane), S - 1) * S + min(ct * 32 + l31, S - 1)];
+        }
+        unsigned keep = 0u;
+        if (drop_p > 0.f) keep = attn_keep_bits(seed, bh, S, w, lane, ct * 32 + l31, drop_threshold(drop_p));
+        const float* vrow = Vs + (ct * 32 + l31) * kLdH;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ap[r] = Abh[(long)min(32 * w + c_row(r, lane), S - 1) * S + min(ct * 32 + l31, S - 1)];
-                if (drop_p > 0.f) keep = attn_keep_bits(seed, bh, S, w, lane, ct * 32 + l31, drop_threshold(drop_p));
-                const float* vrow = Vs + (ct * 32 + l31) * kLdH;
+        for (int kk = 0; kk < kDk / 2; ++kk) {
+            const int k = 2 * kk + khalf;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(grow[k], vrow[k], acc, 0, 0, 0);
+        }
 #pragma unroll
-                for (int kk = 0; kk < kDk / 2; ++kk) {
-                    const int k = 2 * kk + khalf;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(grow[k], vrow[k], acc, 0, 0, 0);
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * w + c_row(r, lane), j = ct * 32 + l31;
+            float ds = 0.f;
+            if (i < S && j <= i) {
+                // through the dropout: dA_ij = (dO_i . v_j) * keep_ij / (1 - p); rowdot_i = dO_i . o_i holds as it is
+                float da = acc[r];
+                if (drop_p > 0.f) da = ((keep >> r) & 1u) ? da * (1.0f / (1.0f - drop_p)) : 0.f;
+                ds = ap[r] * (da - rdot[i]) * scale;
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = 32 * w + c_row(r, lane), j = ct * 32 + l31;
-                float ds = 0.f;
-                if (ct <= w && i < S && j <= i) {
-                    // through the dropout: dA_ij = (dO_i . v_j) * keep_ij / (1 - p); rowdot_i = dO_i . o_i holds as it is
-                    float da = acc[r];
-                    if (drop_p > 0.f) da = ((keep >> r) & 1u) ? da * (1.0f / (1.0f - drop_p)) : 0.f;
-                    ds = ap[r] * (da - rdot[i]) * scale;
-                }
-                Ds[i * kLdS + j] = ds;
-            }
+            Ds[i * kLdS + j] = ds;
         }
     }
     __syncthreads();
 
-    // ---- phase 2
-    const int jlim = 32 * (w + 1);                    // causal: this wave's queries see keys < jlim
-    {   // dq_i = sum_j dS_ij k_j + sum_c dE_ic P[:, c],  dE_ic = dS[i][c - (S-1) + i]
+    // ---- phase 2: three kinds of task per 32-row / 32-column block w
+    auto dq_task = [&](int w) __attribute__((always_inline)) {
+        // dq_i = sum_j dS_ij k_j + sum_c dE_ic P[:, c],  dE_ic = dS[i][c - (S-1) + i]     (query rows of block w)
+        const int jlim = 32 * (w + 1);                // causal: these queries see keys < jlim
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -405,8 +405,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 gmax = fmaxf(gmax, fabsf(acc[r]));
             }
         }
-    }
-    {   // dk_j = sum_{i >= j} dS_ij q_i;  dv_j = sum_{i >= j} A_ij dO_i   (rows j of this wave)
+    };
+    auto dkdv_task = [&](int w) __attribute__((always_inline)) {
+        // dk_j = sum_{i >= j} dS_ij q_i;  dv_j = sum_{i >= j} A_ij dO_i   (key rows j of block w)
         f32x16 ak, av;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ak[r] = 0.f; av[r] = 0.f; }
@@ -452,9 +453,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 gmax = fmaxf(gmax, fmaxf(fabsf(ak[r]), fabsf(av[r])));
             }
         }
-    }
-    publish_amax(dqkv_amax, gmax);
-    if (P != nullptr) {   // dP[d][c] partial = sum_i q_i[d] dE_ic, columns c of this wave
+    };
+    auto dp_task = [&](int w) __attribute__((always_inline)) {
+        // dP[d][c] partial = sum_i q_i[d] dE_ic, columns c of block w
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -470,7 +471,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             const int d = c_row(r, lane);
             if (c < S) dPpart[((long)bh * kDk + d) * S + c] = acc[r];
         }
+    };
+    // in MFMAs (relative positions): dq 16 (w + 1) + 64, dk/dv 32 (4 - w), dP 64 -- 96 to 144 per wave
+    const bool rel = P != nullptr;                    // block-uniform
+    switch (wv) {
+        case 0: dq_task(3); break;
+        case 1: dkdv_task(0); break;
+        case 2: dq_task(2); break;
+        case 3: dq_task(1); dkdv_task(3); break;
+        case 4: dkdv_task(1); break;
+        case 5: dq_task(0); if (rel) dp_task(0); break;
+        case 6: dkdv_task(2); if (rel) dp_task(1); break;
+        default: if (rel) { dp_task(2); dp_task(3); } break;
     }
+    publish_amax(dqkv_amax, gmax);
 }
 
 // ------------------------------------------------------------------ residual + LayerNorm
@@ -920,7 +934,7 @@ static int tf_backward(const TfGroup& tg, const float* x, const float* const* pa
     if ((rc = transpose(Wo, scratch + t.wot, kC, kC, st, G, ps[0], sc))) return rc;
     if ((rc = nt_gemm(ds1m, scratch + t.wot, kC, nullptr, dob, kC, kC, kC, st, 0, 0, gbnd(kBDs1, kBWo), grp(sc, sc, sc)))) return rc;
     // attention
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * kTH, G), dim3(256), 0, st, saved + t.qkv, P, saved + t.o,
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * kTH, G), dim3(512), 0, st, saved + t.qkv, P, saved + t.o,
                        saved + t.A, dob, dqkv, scratch + t.dppart, S, p, seed, tg.ks, slot(kBDqkv));
     CPC_LAUNCH_CHECK();
     if (P != nullptr && (rc = rows_sum(scratch + t.dppart, B * kTH, kDk * S, tmp, grads[4], st, G, sc, sc, ps[4]))) return rc;
