@@ -29,15 +29,18 @@ constexpr float kLnEps = 1e-5f;    // nn.LayerNorm default, transformers.py:107-
 
 __device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-__device__ __forceinline__ float half_max(float v) {       // over the 32 lanes sharing lane >> 5
-    v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 8)); v = fmaxf(v, __shfl_xor(v, 4));
-    v = fmaxf(v, __shfl_xor(v, 2));  v = fmaxf(v, __shfl_xor(v, 1));
-    return v;
+// Reductions over the 32 lanes sharing lane >> 5 (one row of a 32 x 32 accumulator tile): four DPP steps inside each row of 16
+// lanes, the two rows of a half joined through v_readlane -- a butterfly of five ds_bpermute per reduction, two reductions per
+// softmax row, was a dependent chain of LDS round trips.
+__device__ __forceinline__ float half_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));       // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_mov<0x4E>(v));       // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_mov<0x141>(v));      // row_half_mirror
+    v = fmaxf(v, dpp_mov<0x140>(v));      // row_mirror
+    const float lo = fmaxf(lane_value(v, 0), lane_value(v, 16)), hi = fmaxf(lane_value(v, 32), lane_value(v, 48));
+    return (threadIdx.x & 32) ? hi : lo;
 }
-__device__ __forceinline__ float half_sum(float v) {
-    v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-    return v;
-}
+__device__ __forceinline__ float half_sum(float v) { return half_wave_sum(v); }
 
 // Stage the (S, 32) head slice `col0` of a (B*S, ld) matrix into LDS rows of pitch kLdH, zero-padded to 128 rows; 256 threads,
 // four 16-byte pieces each.  Two halves so that a kernel can request all its slices before it waits for the first: the
