@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcpc_hip.so")
 DEFAULT_GRU_MODE = 2       # cpc_set_gru_mode: persistent recurrence, forward products on the fp16 split
 DEFAULT_MFMA_MODE = 3      # what libcpc_hip starts in (cpc_set_mfma_mode): mode 2's arithmetic (two fp16 pieces, 3 MFMAs per
 #                            product) with conv1 / its gradients on the DMA-fed kernels reading H2-stored activations
+EXPECTED_ABI = 8           # cpc_abi_version() of the library these signatures were written for: a stale or variant build that
+#                            exports every symbol with OLDER argument lists would corrupt memory instead of raising -- bind() refuses it
 DEFAULT_DMA_PIPELINE = 2   # cpc_set_dma_pipeline: the tap-pair walk where the shape allows, two 32-k stages elsewhere
 
 _P = ctypes.c_void_p
@@ -120,6 +122,10 @@ class Bound:
             setattr(self, name, fn)
         if missing:
             raise CpcHipError(f"{path} lacks symbols declared in include/cpc_hip.h: {missing}")
+        have = int(self.cpc_abi_version())
+        if have != EXPECTED_ABI:
+            raise CpcHipError(f"{path} reports ABI version {have}, this package binds version {EXPECTED_ABI}: rebuild it "
+                              "(`python -m cpc_audio_amd.build`)")
 
     @staticmethod
     def check(status, what=""):

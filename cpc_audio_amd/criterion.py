@@ -217,7 +217,7 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             ready = torch.cuda.Event()
             ready.record(side)
         step.prepared = {"key": (batchSize, seqSize, K, N, torch.device(device)), "index": (ext, perm, row_ptr),
-                         "saved": saved, "ready": ready, "given": given}
+                         "saved": saved, "ready": ready, "given": given, "c_bound": c_bound}
 
     def forward(self, cFeature, encodedData, label, negatives=None):
         """-> (losses (1,K), acc (1,K)) as criterion.py:256-257.  ``negatives`` optionally
@@ -238,6 +238,12 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             torch.cuda.current_stream().wait_event(prepared["ready"])
             ext, perm, row_ptr = prepared["index"]
             saved = prepared["saved"]
+            # the workspace carries GEMM operand scales for |c| <= c_bound: taken only if THIS cFeature is the tensor the bounded
+            # network returned (CPCAR.forward tags it); a transformed c, or one from a state assigned from outside, has its
+            # bounds reduced in line instead (fp16 pieces overflow silently ~8x above the bound)
+            tag = getattr(cFeature, "_cpc_abs_bound", None)
+            if saved is not None and (tag is None or prepared["c_bound"] is None or tag > prepared["c_bound"]):
+                saved = None
             for t in (ext, perm, row_ptr) + (() if saved is None else (saved,)):
                 t.record_stream(torch.cuda.current_stream())
         elif negatives is None and step is not None and step.overlap and cFeature.is_cuda:

@@ -20,10 +20,21 @@ import torch
 import torch.distributed as dist
 
 
-class _Done:
-    """Work handle of a collective that has already completed (the host-staged path)."""
+class _HostStagedWork:
+    """Work handle of a GPU bucket reduced through the host (a gloo group: RCCL cannot put two ranks on one device, and a
+    gloo-only cluster has no device collectives).  It walks the stream dependencies of the RCCL path instead of replacing them
+    with a blocking ``t.cpu()``: the device-to-host copy into a pinned buffer is queued on the ISSUING stream (non-blocking, an
+    event behind it), a single worker thread -- one per FlatGradAllReduce, so that every rank issues its collectives in the same
+    order -- waits for that event, runs the gloo all-reduce on the pinned buffer and queues the copy back on a copy stream with
+    an event behind it; ``wait()`` makes the CURRENT stream wait for that event (the host blocks only until the copy back has
+    been queued, as ``Work.wait()`` of a process group does until the collective has been enqueued)."""
+
+    def __init__(self, future):
+        self._future = future
 
     def wait(self):
+        done = self._future.result()
+        torch.cuda.current_stream(done[1]).wait_event(done[0])
         return True
 
 
@@ -44,6 +55,9 @@ class FlatGradAllReduce:
         self.views = None
         self._pending = None                                  # work handle of the early bucket
         self._pending_event = None
+        self._stage = {}                                      # host-staged path: (offset, numel) -> pinned buffer
+        self._worker = None                                   # ... its one worker thread (ordered collectives)
+        self._copy_stream = None
         self.single_rank_too = False                          # tests: run the collectives in a 1-rank group as well
 
     def _active(self):
@@ -55,11 +69,39 @@ class FlatGradAllReduce:
         collectives: a GPU tensor in a gloo group is staged through the host (synchronously -- the copy waits for the
         current stream); the buckets, their order and what waits for what stay as on the RCCL path."""
         if t.is_cuda and dist.get_backend(self.group) == "gloo":
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
-            t.copy_(h)
-            return _Done() if async_op else None
+            work = self._reduce_host_staged(t)
+            if async_op:
+                return work
+            work.wait()
+            return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def _reduce_host_staged(self, t):
+        from concurrent.futures import ThreadPoolExecutor
+        if self._worker is None:
+            self._worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cpc-gloo-stage")
+            self._copy_stream = torch.cuda.Stream(device=t.device)
+        key = (t.data_ptr(), t.numel())
+        host = self._stage.get(key)
+        if host is None:
+            host = self._stage[key] = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+        cur = torch.cuda.current_stream(t.device)
+        host.copy_(t.view(-1), non_blocking=True)              # behind everything the issuing stream holds for this bucket
+        staged = torch.cuda.Event()
+        staged.record(cur)
+        group, copy_stream, dev = self.group, self._copy_stream, t.device
+
+        def run():
+            with torch.cuda.device(dev):
+                staged.synchronize()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                with torch.cuda.stream(copy_stream):
+                    t.view(-1).copy_(host, non_blocking=True)
+                    back = torch.cuda.Event()
+                    back.record(copy_stream)
+            return back, dev
+
+        return _HostStagedWork(self._worker.submit(run))
 
     def _views(self, params):
         ref = self.params[0]
@@ -117,6 +159,7 @@ class FlatGradAllReduce:
         """A step raised after begin(): let the early bucket's collective finish (every rank issued it; dropping the
         handle would leave the next step waiting on a stale one and copying last step's sums into .grad) and forget it."""
         pending, self._pending = self._pending, None
+        self._pending_event = None
         if pending is not None:
             try:
                 pending.wait()
@@ -136,7 +179,7 @@ class FlatGradAllReduce:
             self._pending.wait()                              # current stream waits for the early bucket
             if self._pending_event is not None:
                 torch.cuda.current_stream().wait_event(self._pending_event)
-            self._pending = None
+            self._pending = self._pending_event = None
         views = self._views(self.params)
         have = [(p.grad, v) for p, v in zip(self.params, views) if p.grad is not None]
         if have:

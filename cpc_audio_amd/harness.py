@@ -88,7 +88,9 @@ def prepare_criterion(step, model, criterion, batch, negatives=None):
     ar = getattr(model, "gAR", None)
     # |c| <= 1 a priori for a GRU that starts from zero or from one of its own final states (keepHidden); a state assigned from
     # outside, or another kind of network, gives no such bound
-    bounded = isinstance(ar, CPCAR) and (ar.hidden is None or getattr(ar, "keepHidden", False))
+    # (whether the state really is one of its own is decided in CPCAR.forward, which tags the tensor the bound applies to;
+    # the criterion drops the prepared scales for an untagged cFeature)
+    bounded = isinstance(ar, CPCAR) and (ar.hidden is None or ar.hidden is getattr(ar, "_own_hidden", None))
     prep(step, batch.shape[0], batch.shape[2] // enc.DOWNSAMPLING, batch.device, c_bound=1.0 if bounded else None,
          negatives=negatives)
 

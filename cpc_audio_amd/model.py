@@ -114,9 +114,17 @@ class CPCAR(nn.Module):
         """(B, S, 256) -> (B, S, 256).  In reverse mode the sequence is processed back to front and handed back in its
         original order (cpc/model.py:185-204); the final hidden state is kept for the next call when keepHidden is set."""
         flip = (lambda t: torch.flip(t, [1])) if self.reverse else (lambda t: t)
+        # |h_t| <= 1 holds when the recurrence starts from zero or from one of its OWN final states (a convex combination of
+        # tanh outputs and the previous state); a state assigned from outside carries no such bound
+        bounded = self.hidden is None or self.hidden is getattr(self, "_own_hidden", None)
         y, h_last = GruFunction.apply(flip(x), self.hidden, *self._flat_params())
-        self.hidden = h_last.detach() if self.keepHidden else self.hidden
-        return flip(y)
+        if self.keepHidden:
+            self.hidden = self._own_hidden = h_last.detach()
+        out = flip(y)
+        if bounded:
+            out._cpc_abs_bound = 1.0      # read by CPCUnsupersivedCriterion.forward: the a-priori operand bound of its fp16-piece
+            #                               GEMMs applies to THIS tensor only (anything derived from it loses the tag)
+        return out
 
 
 class CPCModel(nn.Module):

@@ -86,7 +86,17 @@ class Adam(torch.optim.Adam):
                     st["exp_avg"], st["exp_avg_sq"] = m, v
             if len(counts) > 1:
                 raise ValueError("device_step_counter(): the loaded state has more than one step count")
-            self._device_step.fill_(float(counts.pop()) if counts else 0.0)
+            k = float(counts.pop()) if counts else 0.0
+            # parameters the loaded state does not mention (a step-0 checkpoint has an empty state; a partial one lacks some):
+            # torch leaves self.state[p] empty for them, but a captured step still points at the OLD moment tensors -- they
+            # restart from zero in place, at the loaded count
+            for p, (m, v) in old.items():
+                if not len(self.state[p]):
+                    m.zero_()
+                    v.zero_()
+                    self.state[p]["step"] = torch.tensor(k, dtype=torch.float32)
+                    self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"] = m, v
+            self._device_step.fill_(k)
 
     def _step_on_device(self):
         lib = _lib.get()

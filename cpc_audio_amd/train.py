@@ -51,9 +51,9 @@ class Trainer:
         recurrence workgroup that gave up polling, a negative index out of range) and turned into an exception -- one device
         synchronisation per that many steps; 0 leaves the check to the caller.
         graph: False (eager), True (HIP graph replay), or "auto": the first steps run eagerly and are timed; the graph is
-        used only if the host needs more than 85 % of the GPU's step time to issue a step.  (Measured on MI355X boxes: the
-        replayed graph costs 0.24 ms of host time per step instead of 1.5-5 ms, but runs ~3 % longer on the GPU than the
-        eagerly issued streams -- a win exactly when the host is the bottleneck.)"""
+        used only if the host needs more than 60 % of the GPU's step time to issue a step.  (Measured on MI355X boxes: the
+        replayed graph costs 0.24 ms of host time per step instead of 1.5-5 ms and runs within 0.5 % of the eagerly issued
+        streams on the GPU -- a win as soon as the host is not comfortably ahead, see _step.)"""
         self.model, self.criterion = model, criterion
         params = list(criterion.parameters()) + list(model.parameters())      # train.py:332
         self.optimizer = Adam(params, lr=lr, betas=betas, eps=eps)      # train.py:335-337; one launch per step on the GPU

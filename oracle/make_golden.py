@@ -69,7 +69,11 @@ def run_reference(params, wave, idx_seed):
     z.retain_grad()
     c.retain_grad()
     torch.manual_seed(idx_seed)
+    # the reference's own logits: what PredictionNetwork.forward (criterion.py:97-118) returns -- K tensors (B, 1+N, W)
+    logits = []
+    lh = crit.wPrediction.register_forward_hook(lambda m, i_, o: logits.extend(t.detach().clone() for t in o))
     losses, acc = crit(c, z, None)
+    lh.remove()
     losses.sum().backward()
     grads = {}
     for k, v in model.state_dict(keep_vars=True).items():
@@ -77,7 +81,7 @@ def run_reference(params, wave, idx_seed):
     for k, v in crit.state_dict(keep_vars=True).items():
         grads[k] = v.grad
     return dict(c=c.detach(), z=z.detach().contiguous(), losses=losses.detach(), acc=acc.detach(),
-                grads=grads, dz=z.grad.contiguous(), dc=c.grad, acts=acts)
+                grads=grads, dz=z.grad.contiguous(), dc=c.grad, acts=acts, logits=logits)
 
 
 def main():
@@ -124,9 +128,15 @@ def main():
             fx["z_slice"] = ref["z"][:, ::16, :].numpy()
             fx["c_slice"] = ref["c"][:, ::16, :].numpy()
             fx["dz_slice"] = ref["dz"][:, ::16, ::4].numpy()
-            # logits of heads k=1 and k=12 at 4 time steps, straight from the reference maths
+            # logits of heads k=1 and k=12 at 4 time steps: the REFERENCE's own (forward hook on wPrediction in
+            # run_reference); the oracle's restatement of them on the reference's c / z is asserted equal first
             ext = O.negative_rows(bidx, sidx, B, S, W, N)
-            lg = O.criterion_logits(params, ref["c"], ref["z"], ext)
+            lo = O.criterion_logits(params, ref["c"], ref["z"], ext)
+            lg = ref["logits"]
+            assert len(lg) == K and tuple(lg[0].shape) == tuple(lo[0].shape), (len(lg), lg[0].shape, lo[0].shape)
+            dlg = max((a - b).abs().max().item() for a, b in zip(lg, lo))
+            assert dlg <= 1e-5 * max(1.0, max(a.abs().max().item() for a in lg)), dlg
+            print(f"[{name}] oracle logits == reference logits: max|d| = {dlg:.2e}")
             fx["logits_k1"] = lg[0][:, :, [0, 37, 80, 115]].numpy()
             fx["logits_k12"] = lg[11][:, :, [0, 37, 80, 115]].numpy()
             g = ref["grads"]

@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     from cpc_audio_amd import _lib, build
     path = build.build()
     bound = _lib.bind(path)          # raises if any declared symbol is missing
-    assert bound.cpc_abi_version() >= 1
+    assert bound.cpc_abi_version() == _lib.EXPECTED_ABI
     # argument validation happens before any launch, so it is testable without a GPU
     import ctypes
     sizes = (ctypes.c_long * 22)()

@@ -162,3 +162,61 @@ def test_world_size_2_real_step_equals_one_rank_on_the_summed_gradients(tmp_path
         assert torch.equal(mine[k], got[0]["state"][k]), k
         moved += int(not torch.equal(mine[k], p[k]))
     assert moved == len(mine)                                 # every tensor took the optimiser steps
+
+
+# ---- the launcher path the driver's scaling run uses --------------------------------------------------------------------
+def _run_bench(args, env_extra, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable] + args, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_through_the_launcher_walks_the_multi_rank_code_paths_on_one_gpu():
+    """``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+    ...`` is how the driver measures N = 2, 4, 8.  A 1-GPU box can host one rank, so the same command runs with N = 1 and
+    CPC_BENCH_FORCE_DIST=1, which switches on everything N > 1 adds: ``init_process_group("nccl", device_id=...)``, the barriers
+    around the timed region, the two-bucket RCCL all-reduce (early bucket async on the side stream, behind the heads' and the
+    recurrence's gradient streams), the MAX over ranks of the elapsed time, graph replay off, the sustained run.  The line must
+    be well-formed and its loss must equal the plain single-process run's (a SUM over one rank is the identity)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    common = ["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-probes",
+              "--sustained-seconds", "0.5", "--launch", "eager"]
+    forced = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                         "--master-port", str(_free_port())] + common, {"CPC_BENCH_FORCE_DIST": "1"})
+    plain = _run_bench(common, {})
+    for line in (forced, plain):
+        assert line["n_gpus"] == 1 and line["steps"] == 6 and line["scaling"] == "weak" and line["higher_is_better"] is True
+        assert line["config"]["parallelism"] == "dp1" and line["config"]["global_batch"] == 64
+        assert line["value"] > 0 and line["value"] == line["value"] and line["ms_per_step"] > 0
+        assert abs(line["value"] - 64 * 1.28 / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
+        assert line["sustained"]["steps"] >= 6 and line["sustained"]["ms_per_step"] > 0
+        assert line["config"]["launch"].startswith("eager")
+    assert "forced_dist" in forced["config"] and "forced_dist" not in plain["config"]
+    # same seeds, same steps; the all-reduce of one rank adds nothing
+    assert forced["config"]["loss_mean_over_heads"] == plain["config"]["loss_mean_over_heads"]
+
+
+def test_bench_self_spawn_refuses_more_ranks_than_gpus():
+    """``python bench.py --gpus 2`` on a 1-GPU box: the self-spawning launcher must fail loudly, not print a 1-GPU line."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one visible GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and '"metric"' not in r.stdout
+    assert "only 1 GPU" in (r.stdout + r.stderr)
