@@ -916,11 +916,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_bf16_kernel(
 // 32-row stages
 static int g_wgrad_dma_wgs = 256;     // cpc_set_wgrad_dma_groups (<= 512: the partial buffer is sized for 512).  One workgroup per CU
                                       // (its LDS fills one): measured in the step at B = 64, 512 / 384 / 256 workgroups: 3.44 / 3.49 / 3.42 ms
+static int g_wgrad_dma_min_rows = 512; // fewest rows a split walks (cpc_set_wgrad_dma_min_rows): every split costs a 256 KB partial tile
+                                      // written and read again, and a prologue; the short layers get fewer splits instead of short ones
 void conv_wgrad_dma_plan(int M, int k, int* splits, int* rows, int wgs) {
     int S = cdiv(wgs > 0 ? wgs : g_wgrad_dma_wgs, k);
     S = cdiv(S, 8) * 8;
     int r = cdiv(cdiv(M, S), kWgRowsB) * kWgRowsB;        // whole stages of either kernel (32 / 64 rows)
     if (r < 2 * kWgRowsB) r = 2 * kWgRowsB;
+    if (wgs <= 0 && r < g_wgrad_dma_min_rows) r = g_wgrad_dma_min_rows;
     *rows = r;
     *splits = cdiv(M, r);
 }
@@ -1138,6 +1141,11 @@ using namespace cpc;
 extern "C" int cpc_set_wgrad_dma_groups(int wgs) {
     if (wgs < 64 || wgs > 512) return CPC_ERR_ARG;
     g_wgrad_dma_wgs = wgs;
+    return 0;
+}
+extern "C" int cpc_set_wgrad_dma_min_rows(int rows) {
+    if (rows < 128 || rows > 8192 || rows % 64 != 0) return CPC_ERR_ARG;
+    g_wgrad_dma_min_rows = rows;
     return 0;
 }
 extern "C" int cpc_set_dma_rotation(int step) {

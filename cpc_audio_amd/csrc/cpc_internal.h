@@ -92,8 +92,8 @@ int transpose_batch(const float* const* in, float* const* out, int n, int R, int
 extern int g_mfma_mode;
 
 // per-(device, caller stream) pool of events for the two-stream entry points: [0..4] encoder backward, [8] GRU backward,
-// [9] criterion backward (score gradients -> dz stream)
-constexpr int kStreamEvents = 12;
+// [9] criterion backward (score gradients -> dz stream), [12..18] the composite train step (train_step.hip)
+constexpr int kStreamEvents = 20;
 hipEvent_t* stream_events(hipStream_t caller_stream);
 
 // conv_dma.hip: forward conv layer with both operands DMA'd into LDS (H2 storage, cpc_common.h)

@@ -205,8 +205,11 @@ __global__ __launch_bounds__(256) void enc_prep_permute_kernel(PrepArgs a) {
 // ------------------------------------------------------------------ forward
 // MODE: 0 = exact-f32 MFMA, 1 = three bf16 pieces (6 MFMAs per product), 2 = two fp16 pieces (3 MFMAs per
 // product; operands scaled by powers of two derived from bounds on their max|.|, see gemm_tile.h)
-template <int BM, int MODE>
+// AH2 (MODE 2 only): the A operand (the layer's input activation, or its output gradient in the data-gradient kernel) lies in
+// H2 storage and is staged without conversion (NtTileX3's AH2)
+template <int BM, int MODE, bool AH2 = false>
 struct ConvCfg {
+    static_assert(!AH2 || MODE == 2, "H2 operands belong to the fp16-split mode");
     static constexpr bool X3 = MODE != 0;
     static constexpr int NP = MODE == 2 ? 2 : 3;
     static constexpr bool H2 = NP == 2;
@@ -217,19 +220,34 @@ struct ConvCfg {
     // mode 2: the weight re-layout kernels also split (same 4 bytes per weight, no VALU left for B in the main loop --
     // what made the 32-row tiles of the short layers slower with on-the-fly fp16 conversion: 108 vs 76 us)
     static constexpr bool kPreSplitW = MODE == 2;
-    using X3Tile = typename std::conditional<BM == 128, NtTileX3<BM, kC, WAVES_M, 4, 16, 2, true, kPreSplitW, NP>,
-                                             NtTileX3<BM, kC, WAVES_M, 4, 32, 1, false, kPreSplitW, NP>>::type;
+    using X3Tile = typename std::conditional<BM == 128, NtTileX3<BM, kC, WAVES_M, 4, 16, 2, true, kPreSplitW, NP, AH2>,
+                                             NtTileX3<BM, kC, WAVES_M, 4, 32, 1, false, kPreSplitW, NP, AH2>>::type;
     using Tile = typename std::conditional<X3, X3Tile, NtTile<BM, kC, WAVES_M, 4>>::type;
 };
 
+// One accumulator element per lane, lanes 2j / 2j + 1 holding channels c / c + 1 (c even) of one row: the value's two fp16 pieces
+// into H2 storage with ONE dword store per lane -- neighbours swap a piece (quad_perm [1,0,3,2]) so that the even lane owns
+// the h pair of the two channels and the odd lane the l pair.  Convergent: every lane of the wave calls it (`live` guards the store).
+__device__ __forceinline__ void h2_store_lane(unsigned char* row, int c, float v, float s, bool live) {
+    _Float16 h, l;
+    h2_split(v, s, h, l);
+    const unsigned hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
+    const bool odd = c & 1;
+    const unsigned got = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, odd ? hb : lb)));
+    const unsigned word = odd ? (got | (lb << 16)) : (hb | (got << 16));
+    if (live) *reinterpret_cast<unsigned*>(row + h2_byte_of(c & ~1) + (odd ? 16 : 0)) = word;
+}
+
 // x_amax / w_amax (MODE 2 only): device floats holding upper bounds of max|x| and max|w|
-template <int BM, int MODE>
-__global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_fwd_kernel(
+// y_amax (MODE 2, may be NULL): y is written in H2 storage scaled for the bound *y_amax (which must bound |y|: the layer's
+// ChannelNorm bound) instead of fp32
+template <int BM, int MODE, bool AH2 = false>
+__global__ __launch_bounds__((ConvCfg<BM, MODE, AH2>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_fwd_kernel(
     RowMap am, const float* __restrict__ wp, int K, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
     float* __restrict__ xhat, float* __restrict__ rstd_out, const float* __restrict__ x_amax,
-    const float* __restrict__ w_amax) {
-    using Tile = typename ConvCfg<BM, MODE>::Tile;
+    const float* __restrict__ w_amax, const float* __restrict__ y_amax = nullptr) {
+    using Tile = typename ConvCfg<BM, MODE, AH2>::Tile;
     constexpr bool X3 = MODE != 0;
     constexpr int TM = Tile::TM, TN = Tile::TN;
     __shared__ float smem[Tile::SMEM_FLOATS];
@@ -237,7 +255,7 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
     const int m0 = blockIdx.x * BM;
     f32x16 acc[TM][TN];
     zero_acc(acc);
-    if constexpr (ConvCfg<BM, MODE>::H2) {
+    if constexpr (ConvCfg<BM, MODE, AH2>::H2) {
         const float sa = scale_for_amax(*x_amax), sb = scale_for_amax(*w_amax);
         Tile::run(acc, am, m0, wp, 16, 0, K, smem, 0, kC * 16, (int)((blockIdx.x * 4u) % (unsigned)(K / Tile::BK)), sa, sb,
                   ((K >> kCLog2) & ((K >> kCLog2) - 1)) == 0 ? 31 - __builtin_clz(K >> kCLog2) : 0);   // tap-fastest K walk
@@ -313,6 +331,21 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 
             const float var = ((red[row][0] + red[row][1]) + (red[row][2] + red[row][3])) * (1.0f / (kC - 1));
             rstd[tm][r] = 1.0f / sqrtf(var + kNormEps);
             const int m = m0 + row;
+            if constexpr (MODE == 2) {
+                if (y_amax != nullptr) {                     // y in H2 storage (block-uniform branch; every lane takes part in the swap)
+                    const float sy = scale_for_amax(*y_amax);
+                    const bool live = m < am.M;
+                    if (live && wn == 0 && (lane & 31) == 0) rstd_out[m] = rstd[tm][r];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        const float xh = (acc[tm][tn][r] - mean[tm][r]) * rstd[tm][r];
+                        if (live) __builtin_nontemporal_store(xh, xhat + (long)m * kC + col[tn]);
+                        h2_store_lane(reinterpret_cast<unsigned char*>(y) + (long)(live ? m : 0) * (kC * 4), col[tn],
+                                      fmaxf(fmaf(xh, gw[tn], gb[tn]), 0.f), sy, live);
+                    }
+                    continue;
+                }
+            }
             if (m < am.M) {
                 if (wn == 0 && (lane & 31) == 0) rstd_out[m] = rstd[tm][r];
 #pragma unroll
@@ -477,16 +510,17 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
 // ------------------------------------------------------------------ dgrad (+ fused norm backward)
 // grid = (row tiles over B*(Lout+1), s phases).  am = 2-row windows over dx of THIS layer.
 // MODE 2: dx_amax / w_amax bound the operands; prev_amax (FUSE, may be NULL) receives max|dprev|.
-template <int BM, bool FUSE, int MODE>
-__global__ __launch_bounds__((ConvCfg<BM, MODE>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_dgrad_kernel(
+template <int BM, bool FUSE, int MODE, bool AH2 = false>
+__global__ __launch_bounds__((ConvCfg<BM, MODE, AH2>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_dgrad_kernel(
     RowMap am, const float* __restrict__ wd, int s, int p, int Lin,
     const float* __restrict__ xhat_prev, const float* __restrict__ y_prev,
     const float* __restrict__ rstd_prev, const float* __restrict__ nw_prev,
     float* __restrict__ dprev, float* __restrict__ colpart, const float* __restrict__ dx_amax,
     const float* __restrict__ w_amax, float* __restrict__ prev_amax, int amax_slots) {
-    using Tile = typename ConvCfg<BM, MODE>::Tile;
+    static_assert(!(AH2 && FUSE), "the H2-input data gradient is the plain (unfused) one");
+    using Tile = typename ConvCfg<BM, MODE, AH2>::Tile;
     constexpr bool X3 = MODE != 0;
-    constexpr int TM = Tile::TM, TN = Tile::TN, WAVES_M = ConvCfg<BM, MODE>::WAVES_M;
+    constexpr int TM = Tile::TM, TN = Tile::TN, WAVES_M = ConvCfg<BM, MODE, AH2>::WAVES_M;
     __shared__ float smem[Tile::SMEM_FLOATS];
     __shared__ float red[2][BM][4];
     __shared__ float colsum[3][kC];
@@ -709,6 +743,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     dw[((long)co * kC + ci) * k + kk] = sum;
 }
 
+// the same for up to three layers in one launch (the short layers' DMA weight gradients leave their partials in own buffers)
+struct WgReduceJobs { const float* part[3]; float* dw[3]; int S[3], k[3], blk0[4]; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgReduceJobs j) {
+    int q = 0;
+    while (q < 2 && (int)blockIdx.x >= j.blk0[q + 1]) ++q;           // block-uniform
+    const int k = j.k[q], S = j.S[q];
+    const long idx = (long)(blockIdx.x - j.blk0[q]) * 256 + threadIdx.x;
+    const long total = (long)kC * k * kC;
+    if (idx >= total) return;
+    const float* part = j.part[q];
+    float sum = 0.f;
+    for (int z = 0; z < S; ++z) sum += part[(long)z * total + idx];
+    const int co = (int)(idx / (k * kC));
+    const int rem = (int)(idx - (long)co * k * kC);
+    const int kk = rem >> kCLog2, ci = rem & (kC - 1);
+    j.dw[q][((long)co * kC + ci) * k + kk] = sum;
+}
+
 struct GradPtrs { float* p[12]; };
 // small[i] = [d norm.weight | d norm.bias | d conv.bias] of layer i+1 -> the 12 parameter-gradient tensors
 __global__ __launch_bounds__(256) void small_to_grads_kernel(const float* __restrict__ small, GradPtrs g) {
@@ -735,7 +787,10 @@ struct EncLayout {
     long bwd_total;
     int wg_splits[5], wg_rows[5];
     bool h2[4];                            // output of layer i kept in H2 storage (cpc_common.h) -- see act_h2 below
-    bool dxh2[5];                          // gradient dx of layer i kept in H2 storage (norm_bwd_kernel DXH2): DMA dgrad, wgrad<5>
+    bool dma[5];                           // layer i (1..4) reads its H2 input -- and its H2 gradient -- on the DMA-fed kernels (conv_dma.hip);
+                                           // false with h2[i-1]: on the register-staged tiles, which stage H2 operands as they lie (AH2)
+    bool dxh2[5];                          // gradient dx of layer i kept in H2 storage (norm_bwd_kernel DXH2): DMA / AH2 dgrad, DMA wgrad
+    long partl[5];                         // weight-gradient partials of layer i (own buffers: one batched reduction for layers 2..4)
     long dxbound, dyamax;                  // [i] the bound dx_i was scaled for; [i][slot] partial max|dy_i| (dy_i: dgrad output)
     bool bf16;                             // mode 4
 };
@@ -749,7 +804,8 @@ static int g_dma_bm = 0;     // 0 = by problem size; 128 / 256 = tuning override
 static int g_wgrad_dma = 1;  // weight gradient of a layer with dx and x in H2 storage: 1 = DMA + transposing LDS reads (conv_dma.hip),
                              // 0 = the register-staged TN tile (conv_wgrad_kernel<5>)
 static int g_h2_dx = 1;      // mode 3: layer 1's gradient dx in H2 storage (DMA data gradient); 0 = fp32 dx, register-staged dgrad
-static int g_h2_layers = 0;  // 0 = by problem size; 1 / 2 = tuning / test override: how many layers (conv1, conv2) read H2 input
+static int g_h2_layers = 0;  // 0 = by problem size; 1 / 2 / 4 = tuning / test override: how many layers read H2 input (see enc_layout)
+static int g_h2_all = 0;     // what "by problem size" means: 0 = conv1 (conv2 at B >= ~100) read H2 input, 1 = every layer does
 static int g_force_bm = 0;   // 0 = choose by problem size; 32/64/128 = tuning / test override
 static constexpr int g_unfuse_big = 2;   // 2: every dgrad runs unfused + streaming norm backward, 1: only the 128-row tiles,
                                          // 0: fused epilogue (cpc_conv_layer_dgrad fuse=1).  Measured 4.69 / 4.76 / 4.79 ms per step
@@ -769,11 +825,16 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
         lin = e.L[i];
     }
     e.bf16 = g_mfma_mode == 4;             // bf16-storage variant: y0..y3, xhat1..4 and every gradient tensor as bf16
-    const int nh2 = g_mfma_mode != 3 ? 0 : (g_h2_layers ? g_h2_layers : ((long)B * e.L[2] >= 256L * 200 ? 2 : 1));
+    // layers reading H2 input: 1 = conv1, 2 = conv1 and conv2 (both on the DMA kernel), 4 = all four -- conv1 on the DMA kernel,
+    // conv2 too once its 256-row tiles fill the chip, the short layers on the register-staged tiles fed H2 rows as they lie
+    const bool big2 = (long)B * e.L[2] >= 256L * 200;
+    const int nh2 = g_mfma_mode != 3 ? 0 : (g_h2_layers ? g_h2_layers : (g_h2_all ? 4 : (big2 ? 2 : 1)));
     for (int i = 0; i < 4; ++i) e.h2[i] = i < nh2;
-    // the gradient of a layer whose input is kept in H2 storage is kept so too: its data gradient runs on the DMA kernel, its
-    // weight gradient reads both operands as pieces (layer 1 always in mode 3, layer 2 where conv2 reads H2 input)
-    for (int i = 0; i < 5; ++i) e.dxh2[i] = (i == 1 || i == 2) && g_h2_dx && e.h2[i - 1];
+    e.dma[0] = false;
+    for (int i = 1; i < 5; ++i) e.dma[i] = e.h2[i - 1] && (i == 1 || (i == 2 && (nh2 == 2 || big2)));
+    // the gradient of a layer whose input is kept in H2 storage is kept so too: its data gradient reads the pieces as stored
+    // (DMA kernel or AH2 tile), its weight gradient reads both operands as pieces by DMA
+    for (int i = 0; i < 5; ++i) e.dxh2[i] = i >= 1 && g_h2_dx && e.h2[i - 1];
     long o = 0;
     for (int i = 0; i < 4; ++i) { e.y[i] = o; o += align64((long)B * e.L[i] * kC); }
     e.xhat[0] = -1;
@@ -820,6 +881,12 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     }
     for (int i = 1; i < 5; ++i) col_max = std::max(col_max, (long)cdiv(B * e.L[i], NB_ROWS));   // stand-alone norm backward
     e.part = o; o += align64(part_max);
+    e.partl[0] = -1;
+    for (int i = 1; i < 5; ++i) {            // (sized for the finest plan, as part_max: a size must not depend on a knob)
+        int Sd, rd;
+        conv_wgrad_dma_plan(B * e.L[i], kGeom[i].k, &Sd, &rd, 512);
+        e.partl[i] = o; o += align64((long)Sd * kC * kGeom[i].k * kC);
+    }
     e.colpart = o; o += align64(col_max * 3 * kC);
     e.tmp = o; o += align64((long)kRowsSumGroups * 3 * kC);
     e.small = o; o += align64(5L * 3 * kC);
@@ -839,10 +906,14 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
 template <int BM>
 static void launch_conv_fwd(const RowMap& am, const float* wp, int K, const float* bias,
                             const float* nw, const float* nb, float* y, float* xhat, float* rstd,
-                            const float* x_amax, const float* w_amax, hipStream_t st) {
-    if (g_mfma_mode >= 2 && K % 32 == 0)
+                            const float* x_amax, const float* w_amax, hipStream_t st, bool x_h2 = false,
+                            const float* y_amax = nullptr) {
+    if (x_h2)          // input in H2 storage (fp16-split modes): staged as it lies; y in H2 storage too when y_amax is given
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 2, true>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, 2, true>::Tile::NTHREADS),
+                           0, st, am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, y_amax);
+    else if (g_mfma_mode >= 2 && K % 32 == 0)
         hipLaunchKernelGGL((conv_fwd_kernel<BM, 2>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, 2>::Tile::NTHREADS),
-                           0, st, am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax);
+                           0, st, am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, y_amax);
     else if (g_mfma_mode != 0 && K % 32 == 0)
         hipLaunchKernelGGL((conv_fwd_kernel<BM, 1>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, 1>::Tile::NTHREADS),
                            0, st, am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax);
@@ -855,7 +926,15 @@ template <int BM, bool FUSE>
 static void launch_conv_dgrad(const RowMap& am, const float* wd, int s, int p, int Lin,
                               const float* xhat_prev, const float* y_prev, const float* rstd_prev,
                               const float* nw_prev, float* dprev, float* colpart, const float* dx_amax,
-                              const float* w_amax, float* prev_amax, int amax_slots, hipStream_t st) {
+                              const float* w_amax, float* prev_amax, int amax_slots, hipStream_t st, bool dx_h2 = false) {
+    if constexpr (!FUSE) {
+        if (dx_h2) {   // dx in H2 storage scaled for the single bound *dx_amax (amax_slots == 1)
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM, false, 2, true>), dim3(cdiv(am.M, BM), s),
+                               dim3(ConvCfg<BM, 2, true>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
+                               rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, prev_amax, amax_slots);
+            return;
+        }
+    }
     if (g_mfma_mode >= 2)
         hipLaunchKernelGGL((conv_dgrad_kernel<BM, FUSE, 2>), dim3(cdiv(am.M, BM), s),
                            dim3(ConvCfg<BM, 2>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
@@ -880,7 +959,7 @@ static int weight_split() {
 static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const float* xhat_prev, const float* y_prev,
                            const float* rstd_prev, const float* nw_prev, float* dprev, float* colpart, float* tmp,
                            float* small3, const float* dx_amax, float* dprev_amax, int B, int Lin, int k, int s, int p,
-                           hipStream_t st, int amax_slots = 1, float* dprev_slots = nullptr);
+                           hipStream_t st, int amax_slots = 1, float* dprev_slots = nullptr, bool dx_h2 = false);
 
 extern "C" int cpc_set_conv_tile(int bm) {
     CPC_RETURN_IF(bm != 0 && bm != 32 && bm != 64 && bm != 128, CPC_ERR_ARG);
@@ -905,7 +984,7 @@ extern "C" int cpc_set_h2_dx(int on) {
     return 0;
 }
 extern "C" int cpc_set_h2_layers(int n) {
-    CPC_RETURN_IF(n < 0 || n > 2, CPC_ERR_ARG);
+    CPC_RETURN_IF(n < 0 || n == 3 || n > 4, CPC_ERR_ARG);
     g_h2_layers = n;
     return 0;
 }
@@ -937,23 +1016,29 @@ extern "C" int cpc_absmax(const float* x, long n, float* out, void* stream) {
 // The forward GEMM kernel alone, on a weight prepared by cpc_conv_weight_relayout (exactly one
 // kernel launch: this is what bench.py times for the roofline figure).
 // x_amax: device float, an upper bound of max|x| (read in the fp16-split mode only; see cpc_absmax).
-extern "C" int cpc_conv_gemm_forward(const float* x, const float* wp, const float* bias, const float* nw,
-                                     const float* nb, float* y, float* xhat, float* rstd, const float* x_amax,
-                                     int B, int Lin, int k, int s, int p, void* stream) {
+// x_h2: x lies in H2 storage scaled for *x_amax; y_amax != NULL: y is written in H2 storage scaled for *y_amax (fp16-split modes)
+static int conv_gemm_forward_impl(const float* x, const float* wp, const float* bias, const float* nw, const float* nb,
+                                  float* y, float* xhat, float* rstd, const float* x_amax, int B, int Lin, int k, int s, int p,
+                                  hipStream_t st, bool x_h2, const float* y_amax) {
     CPC_RETURN_IF(B <= 0 || Lin <= 0 || k != 2 * s || Lin + 2 * p < k, CPC_ERR_SHAPE);
     CPC_RETURN_IF(g_mfma_mode >= 2 && !x_amax, CPC_ERR_ARG);
-    hipStream_t st = (hipStream_t)stream;
+    CPC_RETURN_IF((x_h2 || y_amax) && (g_mfma_mode < 2 || (k * kC) % 32 != 0), CPC_ERR_ARG);
     const int Lout = conv_out_len(Lin, k, s, p);
     const RowMap am = conv_rows(x, B, Lin, Lout, s, p);
     const int K = k * kC;
     const float* w_amax = wp + (long)kC * k * kC;
     switch (pick_bm(am.M)) {
-        case 128: launch_conv_fwd<128>(am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, st); break;
-        case 64: launch_conv_fwd<64>(am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, st); break;
-        default: launch_conv_fwd<32>(am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, st); break;
+        case 128: launch_conv_fwd<128>(am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, st, x_h2, y_amax); break;
+        case 64: launch_conv_fwd<64>(am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, st, x_h2, y_amax); break;
+        default: launch_conv_fwd<32>(am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, st, x_h2, y_amax); break;
     }
     CPC_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int cpc_conv_gemm_forward(const float* x, const float* wp, const float* bias, const float* nw,
+                                     const float* nb, float* y, float* xhat, float* rstd, const float* x_amax,
+                                     int B, int Lin, int k, int s, int p, void* stream) {
+    return conv_gemm_forward_impl(x, wp, bias, nw, nb, y, xhat, rstd, x_amax, B, Lin, k, s, p, (hipStream_t)stream, false, nullptr);
 }
 
 // One conv layer forward (layers 1..4): x (B,Lin,C) -> y, xhat (B,Lout,C), rstd (B*Lout).
@@ -1023,8 +1108,10 @@ extern "C" int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, 
 static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const float* xhat_prev, const float* y_prev,
                            const float* rstd_prev, const float* nw_prev, float* dprev, float* colpart, float* tmp,
                            float* small3, const float* dx_amax, float* dprev_amax, int B, int Lin, int k, int s, int p,
-                           hipStream_t st, int amax_slots, float* dprev_slots) {
+                           hipStream_t st, int amax_slots, float* dprev_slots, bool dx_h2) {
     // dprev_slots (plain dgrad only, may be NULL): kAmaxSlots floats that receive max|dprev| (atomicMax: zero them first)
+    // dx_h2 (plain dgrad, fp16-split modes): dx lies in H2 storage scaled for the single bound *dx_amax (amax_slots == 1)
+    CPC_RETURN_IF(dx_h2 && (fuse || g_mfma_mode < 2 || amax_slots != 1), CPC_ERR_ARG);
     const int Lout = conv_out_len(Lin, k, s, p);
     const float* w_amax = wd + (long)kC * k * kC;
     // 2-row windows [q-1, q] over dx, q in [0, Lout]
@@ -1042,9 +1129,9 @@ static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const flo
         return rows_sum(colpart, nblk, 3 * kC, tmp, small3, st);
     }
     switch (bm) {
-        case 128: launch_conv_dgrad<128, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, dprev_slots, amax_slots, st); break;
-        case 64: launch_conv_dgrad<64, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, dprev_slots, amax_slots, st); break;
-        default: launch_conv_dgrad<32, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, dprev_slots, amax_slots, st); break;
+        case 128: launch_conv_dgrad<128, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, dprev_slots, amax_slots, st, dx_h2); break;
+        case 64: launch_conv_dgrad<64, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, dprev_slots, amax_slots, st, dx_h2); break;
+        default: launch_conv_dgrad<32, false>(am, wd, s, p, Lin, nullptr, nullptr, nullptr, nullptr, dprev, nullptr, dx_amax, w_amax, dprev_slots, amax_slots, st, dx_h2); break;
     }
     CPC_LAUNCH_CHECK();
     return 0;
@@ -1125,6 +1212,13 @@ extern "C" int cpc_encoder_saved_activation(const float* saved, int layer, float
     return 0;
 }
 
+// train_step.hip: an event to record on the forward's stream right behind layer 0's launch (the composite step releases the
+// criterion's index preparation there when asked to); per host thread, nullptr = none
+namespace cpc {
+static thread_local hipEvent_t t_after_conv0 = nullptr;
+void enc_set_after_conv0_event(hipEvent_t ev) { t_after_conv0 = ev; }
+}  // namespace cpc
+
 // params: 20 pointers in the reference's state-dict order
 //   conv{i}.weight, conv{i}.bias, batchNorm{i}.weight, batchNorm{i}.bias  for i = 0..4
 extern "C" int cpc_encoder_forward(const float* wave, const float* const* params, float* saved,
@@ -1144,8 +1238,8 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
         a.nw[i - 1] = params[4 * (i - 1) + 2];
         a.nb[i - 1] = params[4 * (i - 1) + 3];
         a.k[i - 1] = kGeom[i].k;
-        a.dgrad_h2[i - 1] = e.dxh2[i];
-        a.fwd_h2[i - 1] = e.bf16 ? 2 : act_h2(i - 1);   // 1: layer i consumes an H2 activation (DMA kernel, DMA weight layout);
+        a.dgrad_h2[i - 1] = e.dxh2[i] && e.dma[i];      // (the register-staged tiles keep the k-blocked weight layouts)
+        a.fwd_h2[i - 1] = e.bf16 ? 2 : e.dma[i];        // 1: layer i runs on the DMA kernel (its K-tile-major H2 weight rows);
                                                         // 2: bf16 storage (both layouts in bf16 K-tile-major rows)
         const int per = cdiv((long)kC * kGeom[i].k * kC, 256);
         a.blk0[2 * (i - 1)] = nblk; nblk += per;
@@ -1165,6 +1259,7 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
         // re-layout, one bf16 MFMA per product, fp32 accumulators and ChannelNorm statistics; z stays fp32
         int rc = conv0_forward_bf16(wave, params[0], params[1], params[2], params[3], saved + e.y[0], saved + e.mean0,
                                     saved + e.rstd[0], B, L, st);
+        if (!rc && t_after_conv0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
         for (int i = 1; i < 5 && !rc; ++i)
             rc = conv_fwd_dma_bf16(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2], params[4 * i + 3],
                                    i == 4 ? z : saved + e.y[i], i == 4, saved + e.xhat[i], saved + e.rstd[i], saved + e.szero,
@@ -1174,18 +1269,20 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
     int rc = cpc_conv0_forward_h2(wave, params[0], params[1], params[2], params[3], saved + e.y[0], saved + e.mean0,
                                   saved + e.rstd[0], act_h2(0) ? saved + e.sbound + 1 : nullptr, B, L, stream);
     if (rc) return rc;
+    if (t_after_conv0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
     for (int i = 1; i < 5; ++i) {
         float* yo = i == 4 ? z : saved + e.y[i];
-        if (act_h2(i - 1)) {
+        if (e.dma[i]) {
             const long M = (long)B * e.L[i];
             rc = conv_fwd_dma(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2], params[4 * i + 3],
                               yo, i < 4 && act_h2(i), saved + e.xhat[i], saved + e.rstd[i], saved + e.sbound + i,
                               saved + e.sbound + i + 1, saved + e.szero, B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p,
                               g_dma_bm ? g_dma_bm : (M >= 256L * 200 ? 256 : 128), st);
         } else {
-            rc = cpc_conv_gemm_forward(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2],
-                                       params[4 * i + 3], yo, saved + e.xhat[i], saved + e.rstd[i], saved + e.sbound + i, B,
-                                       e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, stream);
+            rc = conv_gemm_forward_impl(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2],
+                                        params[4 * i + 3], yo, saved + e.xhat[i], saved + e.rstd[i], saved + e.sbound + i, B,
+                                        e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, st, act_h2(i - 1),
+                                        i < 4 && act_h2(i) ? saved + e.sbound + i + 1 : nullptr);
         }
         if (rc) return rc;
     }
@@ -1262,16 +1359,33 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     };
     // weight gradient of layer i on the wgrad stream: operand storages as the layout says; a dx in H2 storage comes with the
     // single bound it was scaled for instead of the kAmaxSlots partial maxima
+    // Layers 2..4 with both operands in H2 storage leave their partials in own buffers and are reduced by ONE launch behind the
+    // last of them (layer 2's): three reductions of 16-64 MB cost 114 us as three launches behind three short GEMMs.
+    WgReduceJobs rj;
+    int nrj = 0, rj_blocks = 0;
     auto wgrad = [&](int i, const float* xin) {
         if ((e.dxh2[i] || e.bf16) && g_wgrad_dma) {
+            const bool batch = !e.bf16 && i >= 2;
+            float* part = batch ? scratch + e.partl[i] : scratch + e.part;
             int S = 0;
-            int rcw = e.bf16 ? conv_wgrad_dma_bf16(scratch + e.dx[i], xin, scratch + e.part, saved + e.szero, B, e.L[i - 1],
+            int rcw = e.bf16 ? conv_wgrad_dma_bf16(scratch + e.dx[i], xin, part, saved + e.szero, B, e.L[i - 1],
                                                    kGeom[i].k, kGeom[i].s, kGeom[i].p, &S, wst)
-                             : conv_wgrad_dma(scratch + e.dx[i], xin, scratch + e.part, dxbound + i, xbound + i, saved + e.szero, B,
+                             : conv_wgrad_dma(scratch + e.dx[i], xin, part, dxbound + i, xbound + i, saved + e.szero, B,
                                               e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, &S, wst);
             if (rcw) return rcw;
             const long total = (long)kC * kGeom[i].k * kC;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, wst, scratch + e.part, S, kGeom[i].k,
+            if (batch) {
+                rj.part[nrj] = part; rj.dw[nrj] = grads[4 * i]; rj.S[nrj] = S; rj.k[nrj] = kGeom[i].k;
+                rj.blk0[nrj] = rj_blocks;
+                rj_blocks += cdiv(total, 256);
+                rj.blk0[++nrj] = rj_blocks;
+                if (i == 2) {
+                    for (int q = nrj; q < 3; ++q) { rj.part[q] = part; rj.dw[q] = grads[4 * i]; rj.S[q] = 0; rj.k[q] = 1; rj.blk0[q + 1] = rj_blocks; }
+                    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(rj_blocks), dim3(256), 0, wst, rj);
+                }
+                return 0;
+            }
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, wst, part, S, kGeom[i].k,
                                grads[4 * i]);
             return 0;
         }
@@ -1280,6 +1394,12 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                                 kGeom[i].p, e.wg_splits[i], e.wg_rows[i], (void*)wst, e.dxh2[i] ? 1 : kAmaxSlots);
     };
     int rc = 0;
+    if (e.dxh2[4] && !e.bf16) {          // the top layer's dy is the caller's dz: its maximum (the H2 scale of dx4 derives from it) is reduced here
+        const float* xs[1] = {dz};
+        const long ns[1] = {(long)B * e.L[4] * kC};
+        rc = absmax_slots(xs, ns, 1, dyamax + 4 * kAmaxSlots, st);
+        if (rc) return rc;
+    }
     norm_bwd(4, dz, z, scratch + e.dx[4]);
     for (int i = 4; i >= 1; --i) {
         const float* xin = saved + e.y[i - 1];
@@ -1307,9 +1427,13 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
             // A layer below that keeps its gradient in H2 storage needs max|dy| from this kernel (slots).
             float* tmpd = scratch + e.dy0;
             float* slots = e.dxh2[i - 1] ? dyamax + (i - 1) * kAmaxSlots : nullptr;
-            if (e.dxh2[i])
+            if (e.dxh2[i] && e.dma[i])
                 rc = conv_dgrad_dma_h2(scratch + e.dx[i], saved + e.swd[i], tmpd, saved + e.szero, dxbound + i, slots, B,
                                        e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, st);
+            else if (e.dxh2[i])          // H2 gradient on the register-staged tile (staged as it lies)
+                rc = conv_dgrad_core(scratch + e.dx[i], saved + e.swd[i], 0, nullptr, nullptr, nullptr, nullptr, tmpd, nullptr,
+                                     nullptr, nullptr, dxbound + i, nullptr, B, e.L[i - 1], kGeom[i].k, kGeom[i].s,
+                                     kGeom[i].p, st, 1, slots, true);
             else
                 rc = conv_dgrad_core(scratch + e.dx[i], saved + e.swd[i], 0, nullptr, nullptr, nullptr, nullptr, tmpd, nullptr,
                                      nullptr, nullptr, amax + i * kAmaxSlots, nullptr, B, e.L[i - 1], kGeom[i].k, kGeom[i].s,

@@ -483,9 +483,14 @@ __device__ __forceinline__ void x3_compute(f32x16 (&acc)[TM][TN], const unsigned
 // step by the weight re-layout kernels), so only the A operand is split while staging.
 // NP: 3 = three bf16 pieces / six products (no operand scaling), 2 = two fp16 pieces / three products (operands
 // pre-multiplied by the power-of-two scales sa, sb given to run(); the caller multiplies the result by 1/(sa*sb)).
+// AH2 (NP == 2 only): the A operand lies in H2 storage (cpc_common.h: per 8 channels [h x 8 | l x 8], the 4 bytes per element
+// and the 1 KB rows of fp32) scaled by sa -- the pieces are what the split would produce, so a 16-byte slot is loaded as it
+// lies (float offset 4 kv of the chunk: k-group kv >> 1, piece kv & 1) and stored into its plane with one 16-byte LDS write:
+// no conversion VALU for A at all.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = 32, int STAGES = 1, bool SKEW = false, bool BSPLIT = false,
-          int NP = 3>
+          int NP = 3, bool AH2 = false>
 struct NtTileX3 {
+    static_assert(!AH2 || NP == 2, "H2 operands are two fp16 pieces");
     using SP = SplitPlanes<NP>;
     // BSPLIT: the B operand is stored pre-split (NP == 3: three bf16 planes; NP == 2: interleaved fp16 slots, BSplitH2)
     static constexpr int BK = BK_;       // 32 with one LDS stage (default), or 16 double-buffered
@@ -538,7 +543,7 @@ struct NtTileX3 {
             const int r = slot / SPR, kv = slot % SPR;
             ar[i] = resolve_row(am, m0 + r, a_on[i] ? am.M : 0);
             a_k[i] = kv * 4;
-            a_lds[i] = r * LDH + kv * 4;
+            a_lds[i] = AH2 ? (kv & 1) * PLANE_A + r * LDH + (kv >> 1) * 8 : r * LDH + kv * 4;
         }
         const float* bp[B_PER];
         const unsigned short* bp16[B_PER];
@@ -574,10 +579,15 @@ struct NtTileX3 {
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
                 if (A_EXACT || a_on[i]) {            // exact tilings stay branch-free: one basic block, so the
-                    uint2 pp[NP];                    //  split can be scheduled into the MFMA shadow
-                    SP::split(ra[i], sa, pp);
+                    if constexpr (AH2) {             //  split can be scheduled into the MFMA shadow
+                        *reinterpret_cast<uint4*>(smem + a_lds[i]) =
+                            make_uint4(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y), __float_as_uint(ra[i].z), __float_as_uint(ra[i].w));
+                    } else {
+                        uint2 pp[NP];
+                        SP::split(ra[i], sa, pp);
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(smem + pl * PLANE_A + a_lds[i]) = pp[pl];
+                        for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(smem + pl * PLANE_A + a_lds[i]) = pp[pl];
+                    }
                 }
 #pragma unroll
             for (int i = 0; i < B_PER; ++i)

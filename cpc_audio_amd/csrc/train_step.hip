@@ -1,0 +1,199 @@
+// The whole north-star train step behind ONE C call: every launch of forward and backward (cpc/train.py:78-87: model,
+// criterion, allLosses.sum().backward()) enqueued on the caller's four streams from here, in the order and with the
+// cross-stream dependencies the Python train loop (ops.py, train.Trainer._eager_step) uses -- same entry points, same
+// kernels, same arithmetic: bit-identical results.  What it removes is the host's share: ~60 launches, three autograd nodes,
+// a dozen allocator calls and as many torch events issued from Python cost 1.4-1.8 ms per 3.1 ms step (5 ms on a busy box);
+// from here the step costs the host the launches alone.  With that the eager step no longer depends on HIP-graph replay,
+// which is not available where the gradient all-reduce runs (N > 1).
+//
+// Streams (all owned by the caller):
+//   main    the dx chain: encoder, recurrence, criterion forward, dPred / dc, recurrence backward, encoder backward
+//   side    the criterion's step-independent preparation (index lists of the negative draws, GEMM operand bounds), later the dz
+//           path (per-destination gather-GEMM + dense GEMM) beside the recurrence's backward, then the heads' weight gradient
+//   prep    forward-only preparation of the recurrence's backward (weight transposes, hand-over buffers)
+//   wgrad   weight gradients of the recurrence and of the conv layers, beside the dx chain
+// Phases (bit mask; a data-parallel caller runs them as separate calls with its gradient all-reduce in between):
+//   1  forward + backward down to the encoder's input gradient dz_total: every gradient but the encoder's is final or queued
+//      (heads: side stream; recurrence: wgrad stream) when it returns
+//   2  encoder backward; main waits for side and wgrad before it returns: all gradients final on main
+#include "cpc_common.h"
+#include "cpc_internal.h"
+
+namespace cpc {
+namespace {
+
+constexpr int kEncParams = 20, kGruParams = 8;      // + 1: the K stacked head weights
+
+struct StepLayout {
+    int S, W;
+    long enc[22], gru[3], nce[6], coef;
+    long enc_saved, enc_fscr, z, gru_saved, gru_fscr, c, gcoef, nce_saved, nce_fscr, ext, perm, row_ptr, work;
+    long nce_bscr, dc, dz, gru_bscr, dx, enc_bscr, total;
+};
+
+bool step_layout(int B, int L, int K, int N, StepLayout& s) {
+    if (B <= 0 || cpc_encoder_layout(B, L, s.enc) != 0) return false;
+    s.S = (int)s.enc[7];
+    s.W = s.S - K;
+    if (s.W <= 0 || cpc_gru_layout(B, s.S, 2, s.gru) != 0 || cpc_nce_layout(B, s.S, K, N, s.nce) != 0) return false;
+    s.coef = cpc_gru_coef_floats(B, s.S, 2);
+    if (s.coef <= 0) return false;
+    const long act = (long)B * s.S * kC, slots = (long)B * s.W * (N + K), rows = (long)B * s.S;
+    long o = 0;
+    auto take = [&](long n) { const long at = o; o += align64l(n); return at; };
+    s.enc_saved = take(s.enc[0]); s.enc_fscr = take(std::max(1L, s.enc[1])); s.z = take(act);
+    s.gru_saved = take(s.gru[0]); s.gru_fscr = take(s.gru[1]); s.c = take(act); s.gcoef = take(s.coef);
+    s.nce_saved = take(s.nce[0]); s.nce_fscr = take(s.nce[1]);
+    s.ext = take((long)B * s.W * N); s.perm = take(slots); s.row_ptr = take(rows + 1); s.work = take(slots + 2 * rows + 2);
+    s.nce_bscr = take(s.nce[2]); s.dc = take(act); s.dz = take(act);
+    s.gru_bscr = take(s.gru[2]); s.dx = take(act); s.enc_bscr = take(s.enc[2]);
+    s.total = o;
+    return true;
+}
+
+// a += b  (n % 4 == 0): the two gradients of the encoder output -- through the criterion and through the recurrence -- summed
+// as autograd does between the two backward nodes (one fp32 addition per element; the order of the operands does not matter)
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 x = reinterpret_cast<float4*>(a)[i];
+    const float4 y = reinterpret_cast<const float4*>(b)[i];
+    x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+    reinterpret_cast<float4*>(a)[i] = x;
+}
+
+// tuning / measurement switches (cpc_set_step_schedule)
+int g_prep_point = 0;     // where the criterion's index preparation is released on the side stream: 0 step begin (beside conv0),
+                          // 1 behind conv0 (beside conv1), 2 behind the encoder (beside the recurrence)
+int g_dz_early = 0;       // 1: the dz path on MAIN before the recurrence's backward (which then has the memory system to itself)
+                          // instead of beside it on the side stream
+
+inline bool rec(hipEvent_t e, hipStream_t s) { return hipEventRecord(e, s) == hipSuccess; }
+inline bool wait(hipStream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess; }
+
+}  // namespace
+
+// enc_conv.hip: an event cpc_encoder_forward records on its stream right behind layer 0's launch (nullptr: none)
+void enc_set_after_conv0_event(hipEvent_t ev);
+
+}  // namespace cpc
+
+using namespace cpc;
+
+extern "C" int cpc_set_step_schedule(int prep_point, int dz_early) {
+    CPC_RETURN_IF(prep_point < 0 || prep_point > 2 || dz_early < 0 || dz_early > 1, CPC_ERR_ARG);
+    g_prep_point = prep_point;
+    g_dz_early = dz_early;
+    return 0;
+}
+
+// sizes[0] = floats of the step's workspace; [1], [2] = offsets of z and c (B, S, 256) inside it (outputs of phase 1, valid
+// until the next step); [3] = S; [4..7] = offsets of ext (B, W, N int32), dz_total, dc, dx (tests)
+extern "C" int cpc_train_step_layout(int B, int L, int K, int N, long* sizes) {
+    StepLayout s;
+    CPC_RETURN_IF(!sizes || !step_layout(B, L, K, N, s), CPC_ERR_SHAPE);
+    sizes[0] = s.total; sizes[1] = s.z; sizes[2] = s.c; sizes[3] = s.S;
+    sizes[4] = s.ext; sizes[5] = s.dz; sizes[6] = s.dc; sizes[7] = s.dx;
+    return 0;
+}
+
+extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const long* seqIdx, const float* h0, float c_bound,
+                              const float* const* params, float* const* grads, const float* gloss, float* workspace,
+                              float* losses, float* acc, float* hN, int B, int L, int K, int N, int phases, void* main_stream,
+                              void* side_stream, void* prep_stream, void* wgrad_stream) {
+    StepLayout s;
+    CPC_RETURN_IF(!step_layout(B, L, K, N, s), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!wave || !params || !grads || !workspace || (phases & ~3) || !(phases & 3), CPC_ERR_ARG);
+    hipStream_t M = (hipStream_t)main_stream, S0 = (hipStream_t)side_stream, S1 = (hipStream_t)prep_stream,
+                S2 = (hipStream_t)wgrad_stream;
+    // (equal handles are allowed: the launches then simply queue up in issue order, which respects every dependency below)
+    hipEvent_t* pool = stream_events(M);
+    CPC_RETURN_IF(!pool, CPC_ERR_ARG);
+    hipEvent_t* ev = pool + 12;     // [0] begin, [1] index lists + bounds ready, [2] recurrence-backward preparation ready,
+                                    // [3] score gradients ready, [4] dz done, [5] head gradient done, [6] conv0 launched / encoder done
+    float* ws = workspace;
+    const float* const* enc_p = params;
+    const float* const* gru_p = params + kEncParams;
+    const float* wall = params[kEncParams + kGruParams];
+    float* const* enc_g = grads;
+    float* const* gru_g = grads + kEncParams;
+    float* dwall = grads[kEncParams + kGruParams];
+    float* z = ws + s.z, *c = ws + s.c, *coef = ws + s.gcoef, *dz = ws + s.dz, *dc = ws + s.dc, *dx = ws + s.dx;
+    int* ext = reinterpret_cast<int*>(ws + s.ext), *perm = reinterpret_cast<int*>(ws + s.perm);
+    int* row_ptr = reinterpret_cast<int*>(ws + s.row_ptr), *work = reinterpret_cast<int*>(ws + s.work);
+    const int S = s.S;
+    int rc = 0;
+    if (phases & 1) {
+        CPC_RETURN_IF(!batchIdx || !seqIdx || !gloss || !losses || !acc || !hN, CPC_ERR_ARG);
+        // ---- forward ----
+        // the step begins here on main: the other streams fork from this point (the workspace is the previous step's, whose
+        // last users main has waited for)
+        CPC_RETURN_IF(!rec(ev[0], M) || !wait(S1, ev[0]), CPC_ERR_ARG);
+        auto prepare = [&]() -> int {      // index lists of the draws + operand bounds of the prediction GEMMs: depend on no activation
+            int r = cpc_nce_prepare(batchIdx, seqIdx, ext, perm, row_ptr, work, B, S, K, N, S0);
+            if (r) return r;
+            if (c_bound > 0.f) r = cpc_nce_bounds(nullptr, c_bound, wall, ws + s.nce_saved, B, S, K, N, S0);
+            if (r) return r;
+            return rec(ev[1], S0) ? 0 : CPC_ERR_ARG;
+        };
+        if (g_prep_point == 0) {
+            CPC_RETURN_IF(!wait(S0, ev[0]), CPC_ERR_ARG);
+            if ((rc = prepare())) return rc;
+        }
+        enc_set_after_conv0_event(g_prep_point == 1 ? ev[6] : nullptr);
+        rc = cpc_encoder_forward(wave, enc_p, ws + s.enc_saved, ws + s.enc_fscr, z, B, L, M);
+        enc_set_after_conv0_event(nullptr);
+        if (rc) return rc;
+        if (g_prep_point == 1) {
+            CPC_RETURN_IF(!wait(S0, ev[6]), CPC_ERR_ARG);
+            if ((rc = prepare())) return rc;
+        } else if (g_prep_point == 2) {
+            CPC_RETURN_IF(!rec(ev[6], M) || !wait(S0, ev[6]), CPC_ERR_ARG);
+            if ((rc = prepare())) return rc;
+        }
+        rc = cpc_gru_forward_coef(z, h0, gru_p, ws + s.gru_saved, ws + s.gru_fscr, c, hN, coef, B, S, 2, M);
+        if (rc) return rc;
+        // what the recurrence's backward needs beyond the coefficients the forward writes on its way (weight transposes,
+        // hand-over buffers: disjoint parts of `coef`) depends on the parameters only: beside the forward, on its own stream
+        rc = cpc_gru_backward_coef(h0, gru_p, ws + s.gru_saved, c, coef, 1, B, S, 2, S1);
+        if (rc) return rc;
+        CPC_RETURN_IF(!rec(ev[2], S1) || !wait(M, ev[1]), CPC_ERR_ARG);
+        rc = c_bound > 0.f ? cpc_nce_forward_prepared(c, z, wall, ext, ws + s.nce_saved, ws + s.nce_fscr, losses, acc, B, S, K, N, M)
+                           : cpc_nce_forward(c, z, wall, ext, ws + s.nce_saved, ws + s.nce_fscr, losses, acc, B, S, K, N, M);
+        if (rc) return rc;
+        // ---- backward ----
+        // criterion: score gradients, dPred and dc on main; the dz path and the heads' weight gradient are held back
+        rc = cpc_nce_backward_streams(c, z, wall, ext, perm, row_ptr, ws + s.nce_saved, gloss, ws + s.nce_bscr, dc, nullptr,
+                                      nullptr, B, S, K, N, M, M);
+        if (rc) return rc;
+        if (g_dz_early) {
+            rc = cpc_nce_backward_dz(c, wall, perm, row_ptr, ws + s.nce_bscr, dz, B, S, K, N, M);
+            if (rc) return rc;
+        }
+        CPC_RETURN_IF(!rec(ev[3], M) || !wait(M, ev[2]), CPC_ERR_ARG);
+        // recurrence: dx on main, its weight / bias gradients straight into `grads` on the wgrad stream (no join here)
+        rc = cpc_gru_backward_streams(z, h0, gru_p, ws + s.gru_saved, c, dc, coef, ws + s.gru_bscr, dx, gru_g, B, S, 2, M, S2);
+        if (rc) return rc;
+        // ... and only now, with the persistent recurrence in flight (its 768-thread workgroups could not become resident beside
+        // a chip full of gather blocks), the dz path and behind it the heads' gradient on the side stream
+        CPC_RETURN_IF(!wait(S0, ev[3]), CPC_ERR_ARG);
+        if (!g_dz_early) {
+            rc = cpc_nce_backward_dz(c, wall, perm, row_ptr, ws + s.nce_bscr, dz, B, S, K, N, S0);
+            if (rc) return rc;
+            CPC_RETURN_IF(!rec(ev[4], S0), CPC_ERR_ARG);
+        }
+        rc = cpc_nce_backward_dwall(c, ws + s.nce_bscr, dwall, B, S, K, N, S0);
+        if (rc) return rc;
+        CPC_RETURN_IF(!rec(ev[5], S0), CPC_ERR_ARG);
+        if (!g_dz_early) CPC_RETURN_IF(!wait(M, ev[4]), CPC_ERR_ARG);
+        const long n4 = (long)B * S * kC / 4;
+        hipLaunchKernelGGL(add_inplace_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, M, dz, dx, n4);
+        CPC_LAUNCH_CHECK();
+    }
+    if (phases & 2) {
+        rc = cpc_encoder_backward_streams(wave, enc_p, ws + s.enc_saved, z, dz, ws + s.enc_bscr, enc_g, B, L, M, S2);
+        if (rc) return rc;          // (joins the wgrad stream -- the recurrence's gradients were queued there before the conv layers')
+        CPC_RETURN_IF(!wait(M, ev[5]), CPC_ERR_ARG);
+    }
+    return 0;
+}

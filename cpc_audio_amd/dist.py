@@ -116,7 +116,8 @@ class FlatGradAllReduce:
 
     def _pack(self, params):
         views = self._views(params)
-        have = [(v, p.grad) for v, p in zip(views, params) if p.grad is not None]
+        # (a gradient that already IS its slice of the buffer -- train.Trainer's composite step writes them there -- needs no copy)
+        have = [(v, p.grad) for v, p in zip(views, params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         for v, p in zip(views, params):
@@ -181,7 +182,7 @@ class FlatGradAllReduce:
                 torch.cuda.current_stream().wait_event(self._pending_event)
             self._pending = self._pending_event = None
         views = self._views(self.params)
-        have = [(p.grad, v) for p, v in zip(self.params, views) if p.grad is not None]
+        have = [(p.grad, v) for p, v in zip(self.params, views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if have:
             torch._foreach_copy_([g for g, _ in have], [v for _, v in have])
         for p, v in zip(self.params, views):

@@ -46,7 +46,8 @@ class Trainer:
 
     AUTO_PROBE_STEPS = 6      # graph="auto": eager steps timed (host enqueue time vs GPU time) before deciding
 
-    def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, graph=False, check_errors_every=256):
+    def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, graph=False, check_errors_every=256,
+                 fused=True):
         """check_errors_every: every that many steps the device-side error flags are read (ops.check_device_errors: a
         recurrence workgroup that gave up polling, a negative index out of range) and turned into an exception -- one device
         synchronisation per that many steps; 0 leaves the check to the caller.
@@ -54,7 +55,14 @@ class Trainer:
         used only if the host needs more than 60 % of the GPU's step time to issue a step.  (Measured on MI355X boxes: the
         replayed graph costs 0.24 ms of host time per step instead of 1.5-5 ms and runs within 0.5 % of the eagerly issued
         streams on the GPU -- a win as soon as the host is not comfortably ahead, see _step.)"""
+        """fused (default True): where the configuration is the north-star one -- CPCEncoder + 2-layer GRU CPCAR + linear
+        heads, every parameter trainable -- forward and backward of a step are issued by ONE C call (cpc_train_step, csrc/
+        train_step.hip: the same entry points in the same order on the same four streams, bit-identical results) into a
+        persistent workspace, with the gradients written straight into the flat all-reduce buffer; anything else (transformer
+        AR / predictors, criterion mode 'reverse', frozen parameters) runs the autograd path below."""
         self.model, self.criterion = model, criterion
+        self.fused = bool(fused)
+        self._fused = None                # cached pointer tables / workspace of the composite step
         params = list(criterion.parameters()) + list(model.parameters())      # train.py:332
         self.optimizer = Adam(params, lr=lr, betas=betas, eps=eps)      # train.py:335-337; one launch per step on the GPU
         enc = {id(p) for p in model.gEncoder.parameters()} if hasattr(model, "gEncoder") else set()
@@ -83,7 +91,146 @@ class Trainer:
     # memory still growing.  Two steps ahead keep the GPU fed and bound both.
     MAX_IN_FLIGHT = 2
 
+    # ---- the composite step (cpc_train_step) ---------------------------------------------------------------------------
+    def _fused_ok(self, batchData, negatives):
+        from . import ops
+        from .model import CPCAR, CPCEncoder, CPCModel
+        m, cr = self.model, self.criterion
+        if not (self.fused and torch.is_tensor(batchData) and batchData.is_cuda and batchData.dtype == torch.float32
+                and batchData.dim() == 3 and batchData.shape[1] == 1 and torch.is_grad_enabled() and not ops.KEEP_DEBUG):
+            return False
+        if not (isinstance(m, CPCModel) and isinstance(m.gEncoder, CPCEncoder) and isinstance(m.gAR, CPCAR)
+                and isinstance(cr, CPCUnsupersivedCriterion)):
+            return False
+        ar = m.gAR
+        if ar.reverse or ar.baseNet.num_layers != 2 or cr.mode is not None or cr.wPrediction.rnnMode == "transformer":
+            return False
+        if negatives is not None and not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int64 for t in negatives):
+            return False
+        return all(p.requires_grad and p.is_cuda and p.dtype == torch.float32 for p in self.allreduce.params) \
+            and len(self.allreduce.params) == 20 + 8 + cr.nPredicts
+
+    def _fused_tables(self, batchData):
+        """Pointer tables and workspace of cpc_train_step for this batch shape; rebuilt when a parameter got new storage."""
+        import ctypes
+        from . import _lib
+        lib = _lib.get()
+        m, cr = self.model, self.criterion
+        with torch.no_grad():
+            wall = cr.wPrediction.stacked_weight()                    # (re-)establishes the K heads as views of one buffer
+        heads = [p.weight for p in cr.wPrediction.predictors]
+        plist = m.gEncoder._flat_params() + m.gAR._flat_params()
+        B, _, L = batchData.shape
+        K, N = cr.nPredicts, cr.negativeSamplingExt
+        key = (B, L, K, N, batchData.device, lib.cpc_get_mfma_mode(), wall.data_ptr()) + tuple(p.data_ptr() for p in plist)
+        f = self._fused
+        if f is not None and f["key"] == key:
+            return f
+        views = self.allreduce._views(plist + heads)                   # the flat gradient buffer: gradients are written in place
+        hv = views[len(plist):]
+        step = hv[0].numel() * hv[0].element_size()
+        if any(v.data_ptr() != hv[0].data_ptr() + k * step for k, v in enumerate(hv)):
+            raise RuntimeError("Trainer: the prediction heads' gradients are not contiguous in the flat buffer")
+        for p in plist:
+            if not p.is_contiguous():
+                raise RuntimeError("Trainer: non-contiguous parameter")
+        arr = ctypes.c_void_p * 29
+        sizes = (ctypes.c_long * 8)()
+        with torch.cuda.device(batchData.device):
+            lib.check(lib.cpc_train_step_layout(B, L, K, N, sizes), "train_step_layout")
+            ws = torch.empty(sizes[0], device=batchData.device, dtype=torch.float32)
+        f = self._fused = {
+            "key": key, "params": arr(*([p.data_ptr() for p in plist] + [wall.data_ptr()])),
+            "grads": arr(*([v.data_ptr() for v in views[:len(plist)]] + [hv[0].data_ptr()])),
+            "plist": plist + heads, "views": views, "ws": ws, "S": int(sizes[3]), "sizes": tuple(sizes),
+            "ones": torch.ones(K, device=batchData.device), "hN": torch.empty(2, B, 256, device=batchData.device)}
+        return f
+
+    def _fused_step(self, batchData, label, negatives=None):
+        from . import _lib, ops
+        lib = _lib.get()
+        dev = batchData.device
+        throttle = not self._capturing
+        if throttle:
+            done = self._done_events
+            if len(done) >= self.MAX_IN_FLIGHT:
+                import time
+                t0 = time.perf_counter()
+                done.pop(0).synchronize()
+                self.wait_seconds = getattr(self, "wait_seconds", 0.0) + (time.perf_counter() - t0)
+        batchData = batchData.contiguous()
+        f = self._fused_tables(batchData)
+        m, cr, ctx = self.model, self.criterion, self.ctx
+        ar = m.gAR
+        B, _, L = batchData.shape
+        K, N, S = cr.nPredicts, cr.negativeSamplingExt, f["S"]
+        with torch.cuda.device(dev):
+            main = torch.cuda.current_stream(dev)
+            side, prep, wst = ctx.side_stream(dev, 0), ctx.side_stream(dev, 1), ctx.side_stream(dev, 2)
+            if negatives is None:
+                # the two draws of sampleClean (criterion.py:181-189) on the side stream, forked from the start of the step:
+                # torch's generator, in the reference's order
+                begin = torch.cuda.Event()
+                begin.record(main)
+                side.wait_event(begin)
+                with torch.cuda.stream(side):
+                    bidx, sidx = cr.drawNegatives(B, S, S - K, dev)
+            else:
+                bidx, sidx = negatives[0].contiguous(), negatives[1].contiguous()
+                if bidx.numel() != B * N * (S - K) or sidx.numel() != bidx.numel():
+                    raise ValueError("Trainer.step: negatives must be two int64 tensors of B*N*W draws")
+                bidx.record_stream(side)
+                sidx.record_stream(side)
+            h0 = ar.hidden
+            bounded = h0 is None or h0 is getattr(ar, "_own_hidden", None)
+            if h0 is not None:
+                h0 = h0.contiguous()
+                if h0.shape != (2, B, 256) or not h0.is_cuda or h0.dtype != torch.float32:
+                    raise ValueError("CPCAR.hidden does not match the batch")
+            out = torch.empty(2, K, device=dev, dtype=torch.float32)
+            hN = torch.empty(2, B, 256, device=dev, dtype=torch.float32) if ar.keepHidden else f["hN"]
+            for p, v in zip(f["plist"], f["views"]):
+                if p.grad is not v:
+                    p.grad = v                                  # gradients live in the flat buffer, overwritten by every step
+            P = _lib.ptr
+
+            def call(phases):
+                lib.check(lib.cpc_train_step(P(batchData), P(bidx), P(sidx), P(h0), 1.0 if bounded else 0.0, f["params"],
+                                             f["grads"], P(f["ones"]), P(f["ws"]), out[0].data_ptr(), out[1].data_ptr(), P(hN),
+                                             B, L, K, N, phases, main.cuda_stream, side.cuda_stream, prep.cuda_stream,
+                                             wst.cuda_stream), "train_step")
+            try:
+                if self.allreduce._active():
+                    # data parallel: the heads' and the recurrence's gradients leave for the other ranks while the encoder's
+                    # backward runs (dist.FlatGradAllReduce.begin: on the side stream, behind the heads' gradient there and
+                    # behind the recurrence's on the weight-gradient stream)
+                    call(1)
+                    ev = torch.cuda.Event()
+                    ev.record(wst)
+                    ctx.wgrad_events.append(ev)
+                    self.allreduce.begin(ctx)
+                    del ctx.wgrad_events[:]
+                    call(2)
+                else:
+                    call(3)
+            except BaseException:
+                del ctx.wgrad_events[:]
+                self.allreduce.abort()
+                raise
+            if ar.keepHidden:
+                ar.hidden = ar._own_hidden = hN                 # cpc/model.py:194-198 (a fresh tensor per step: nothing aliases it)
+            self.allreduce()
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+            if throttle:
+                ev = torch.cuda.Event()
+                ev.record()
+                self._done_events.append(ev)
+        return out[0:1], out[1:2]
+
     def _eager_step(self, batchData, label, negatives=None):
+        if self._fused_ok(batchData, negatives):
+            return self._fused_step(batchData, label, negatives)
         # the overlap state (side streams, events, launches held back) lives on this Trainer's StepContext: two Trainers
         # on two threads / devices do not share any
         # (not while a capture is being prepared or recorded: an event recorded into a capturing stream belongs to the

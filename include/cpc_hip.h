@@ -94,8 +94,12 @@ int cpc_conv_gemm_forward_h2(const void* x_h2, const float* wq, const float* bia
 int cpc_set_conv0_tuning(int groups, int nontemporal);   /* layer-0 forward kernel: 16-step groups per wave (1..8, default 4); 1 / 0 (default):
                                                           * activation rows as non-temporal / plain stores */
 int cpc_set_dma_tile(int bm);
-int cpc_set_h2_layers(int n);            /* mode 3: 1 = only conv1, 2 = conv1 and conv2 read H2 input; 0 = by problem size */
+int cpc_set_h2_layers(int n);            /* mode 3, which layers read their input (and write their gradient) in H2 storage: 1 = conv1, 2 = conv1 and
+                                            conv2, both on the DMA kernels; 4 = all four -- conv1 (conv2 from B ~ 100 on) on the DMA kernels, the
+                                            short layers on the register-staged tiles, which stage H2 rows as they lie, and every weight
+                                            gradient on the DMA + transposing-read kernel with one batched reduction; 0 = by problem size */
 int cpc_set_wgrad_dma_groups(int wgs);  /* workgroups the DMA weight gradient aims at (row splits = wgs / taps); 64..512 */
+int cpc_set_wgrad_dma_min_rows(int rows); /* ... and the fewest rows one of its splits walks (default 512; 128..8192, a multiple of 64) */
 int cpc_set_wgrad1_early(int on);        /* two-stream encoder backward: 0 (default) layer 1's weight gradient behind its data gradient, 1 beside it */
 int cpc_set_h2_dx(int on);               /* mode 3: 1 (default) keeps the gradient dx of every layer whose input is in H2 storage in H2 storage
                                             too (layer 1; layer 2 where conv2 reads H2 input): data gradient on the DMA kernel, weight
@@ -357,6 +361,35 @@ int cpc_nce_scores_forward(const float* pred, const float* z, const int* ext, fl
 int cpc_nce_scores_backward(const float* pred, const float* z, const int* ext, const int* perm,
                             const int* row_ptr, const float* saved, const float* gloss, float* scratch,
                             float* dpred, float* dz, int B, int S, int K, int N, void* stream);
+
+/* ---- the whole step ---------------------------------------------------------------------------------------------------
+ * cpc/train.py:78-87 for the north-star configuration (CPCEncoder + 2-layer GRU CPCAR + K linear InfoNCE heads): model
+ * forward, criterion forward, allLosses.sum().backward() -- every launch of the entry points above, issued from ONE call on
+ * four caller-owned streams with the cross-stream order of the package's Python train loop (ops.py / train.Trainer), i.e. the
+ * same kernels in the same order: results are bit-identical to that loop.  What it saves is host time (~60 launches, three
+ * autograd nodes and a dozen allocator calls per step from Python), which is what an eager data-parallel rank is bound by.
+ *   wave (B,1,L); batchIdx, seqIdx: the two int64 draws of sampleClean (criterion.py:181-189), B*N*W each, ready on
+ *   side_stream (or earlier on main_stream); h0: NULL or the carried GRU state (2,B,256), hN (2,B,256) receives the final one
+ *   (cpc/model.py:193-198); c_bound > 0: an a-priori bound of |c| (1 for a GRU started from zero or from one of its own final
+ *   states), <= 0: max|c| is reduced in line; params / grads: 29 pointers -- the 20 encoder tensors (cpc_encoder_forward's
+ *   order), the 8 GRU tensors (cpc_gru_forward's order), the K head weights stacked (K*256, 256); grads are OVERWRITTEN
+ *   (= zero_grad + backward); gloss: K floats dL/dloss_k (ones for train.py:85's sum); workspace: cpc_train_step_layout
+ *   sizes[0] floats, reused from step to step (z and c of the step live in it at sizes[1], sizes[2] until the next call);
+ *   losses, acc: K floats each (criterion.py:256-257).
+ * phases (bit mask): 1 = forward + backward down to the encoder's input gradient -- on return the heads' gradient is queued
+ * on side_stream, the recurrence's on wgrad_stream, everything else of the non-encoder gradients is final on main_stream (a
+ * data-parallel caller starts reducing that bucket here); 2 = the encoder's backward, after which main_stream has waited for
+ * side_stream and wgrad_stream: every gradient is final on main_stream.  3 = both.  No host synchronisation anywhere. */
+int cpc_train_step_layout(int B, int L, int K, int N, long* sizes);
+int cpc_train_step(const float* wave, const long* batchIdx, const long* seqIdx, const float* h0, float c_bound,
+                   const float* const* params, float* const* grads, const float* gloss, float* workspace, float* losses,
+                   float* acc, float* hN, int B, int L, int K, int N, int phases, void* main_stream, void* side_stream,
+                   void* prep_stream, void* wgrad_stream);
+/* Measurement switches of cpc_train_step's schedule.  prep_point: where the criterion's index preparation (190 MB of index
+ * traffic at B = 64) is released on side_stream -- 0 (default) at the step's start (beside conv0), 1 behind conv0 (beside
+ * conv1), 2 behind the encoder (beside the recurrence).  dz_early: 1 = the dz path on main_stream BEFORE the recurrence's
+ * backward (which then has the memory system to itself) instead of beside it on side_stream (0, default). */
+int cpc_set_step_schedule(int prep_point, int dz_early);
 
 /* ---- optimiser -------------------------------------------------------------------------------------------------
  * One Adam step (cpc/train.py:335-337: torch.optim.Adam(params, lr, betas, eps); :88-89 optimizer.step()) on n dense

@@ -1,0 +1,152 @@
+"""cpc_train_step (csrc/train_step.hip) -- the whole step behind one C call -- on the host SIMT emulator: against the CPU oracle
+(cpc/train.py:78-87: forward, allLosses.sum().backward()) and, bit for bit, against the same step issued stage by stage through
+the per-stage entry points the Python train loop uses (ops.py), for every schedule switch and for the two-call phase split a
+data-parallel rank uses."""
+import ctypes
+
+import pytest
+import torch
+
+from emu_util import P, emu, rel_err
+from oracle import cpc_oracle as O
+
+ENC = [f"gEncoder.{n}{i}.{w}" for i in range(5)
+       for n, w in (("conv", "weight"), ("conv", "bias"), ("batchNorm", "weight"), ("batchNorm", "bias"))]
+GRU = [f"gAR.baseNet.{n}_l{l}" for l in range(2) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+
+
+def _setup(B, L, K, N, seed=0, head_scale=64.0):
+    p = O.make_params(seed=seed, head_scale=head_scale)
+    p = {k: v for k, v in p.items() if not k.startswith("wPrediction") or int(k.split(".")[2]) < K}
+    wave = O.make_waveform(B, L, seed=5)
+    S = L // 160
+    g = torch.Generator().manual_seed(3)
+    bidx, sidx = O.draw_negative_indices(B, S, S - K, N, generator=g)
+    wall = torch.cat([p[f"wPrediction.predictors.{k}.weight"] for k in range(K)], 0).contiguous()
+    plist = [p[n].contiguous() for n in ENC + GRU] + [wall]
+    return p, wave, S, bidx, sidx, plist
+
+
+def _composite(lib, wave, bidx, sidx, h0, c_bound, plist, B, L, K, N, phases=(3,), schedule=(0, 0)):
+    sizes = (ctypes.c_long * 8)()
+    assert lib.cpc_train_step_layout(B, L, K, N, sizes) == 0
+    ws = torch.full((sizes[0],), float("nan"))
+    grads = [torch.full_like(t, float("nan")) for t in plist]
+    parr = (ctypes.c_void_p * 29)(*[P(t) for t in plist])
+    garr = (ctypes.c_void_p * 29)(*[P(t) for t in grads])
+    out = torch.full((2, K), float("nan"))
+    hN = torch.full((2, B, 256), float("nan"))
+    ones = torch.ones(K)
+    assert lib.cpc_set_step_schedule(*schedule) == 0
+    try:
+        for ph in phases:
+            rc = lib.cpc_train_step(P(wave), P(bidx), P(sidx), P(h0), c_bound, parr, garr, P(ones), P(ws), out[0].data_ptr(),
+                                    out[1].data_ptr(), P(hN), B, L, K, N, ph, None, None, None, None)
+            assert rc == 0
+    finally:
+        lib.cpc_set_step_schedule(0, 0)
+    S = sizes[3]
+    z = ws[sizes[1]:sizes[1] + B * S * 256].view(B, S, 256).clone()
+    c = ws[sizes[2]:sizes[2] + B * S * 256].view(B, S, 256).clone()
+    return out, hN, grads, z, c
+
+
+def _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N):
+    """The same step through the per-stage entry points, in the order ops.py / train.Trainer issue them."""
+    S = L // 160
+    W = S - K
+    enc_p, gru_p, wall = plist[:20], plist[20:28], plist[28]
+    es, gs, ns = (ctypes.c_long * 22)(), (ctypes.c_long * 3)(), (ctypes.c_long * 6)()
+    assert lib.cpc_encoder_layout(B, L, es) == 0 and lib.cpc_gru_layout(B, S, 2, gs) == 0 and lib.cpc_nce_layout(B, S, K, N, ns) == 0
+    nan = lambda n: torch.full((max(1, n),), float("nan"))
+    ext = torch.zeros(B * W * N, dtype=torch.int32)
+    perm = torch.zeros(B * W * (N + K), dtype=torch.int32)
+    row_ptr = torch.zeros(B * S + 1, dtype=torch.int32)
+    work = torch.zeros(B * W * (N + K) + 2 * B * S + 2, dtype=torch.int32)
+    assert lib.cpc_nce_prepare(P(bidx), P(sidx), P(ext), P(perm), P(row_ptr), P(work), B, S, K, N, None) == 0
+    nsaved = nan(ns[0])
+    assert lib.cpc_nce_bounds(None, 1.0, P(wall), P(nsaved), B, S, K, N, None) == 0
+    esaved, z = nan(es[0]), nan(B * S * 256).view(B, S, 256)
+    earr = (ctypes.c_void_p * 20)(*[P(t) for t in enc_p])
+    assert lib.cpc_encoder_forward(P(wave), earr, P(esaved), P(nan(es[1])), P(z), B, L, None) == 0
+    gsaved, c, hN = nan(gs[0]), nan(B * S * 256).view(B, S, 256), nan(2 * B * 256).view(2, B, 256)
+    coef = nan(lib.cpc_gru_coef_floats(B, S, 2))
+    garr_p = (ctypes.c_void_p * 8)(*[P(t) for t in gru_p])
+    assert lib.cpc_gru_forward_coef(P(z), P(h0), garr_p, P(gsaved), P(nan(gs[1])), P(c), P(hN), P(coef), B, S, 2, None) == 0
+    assert lib.cpc_gru_backward_coef(P(h0), garr_p, P(gsaved), P(c), P(coef), 1, B, S, 2, None) == 0
+    losses, acc = nan(K), nan(K)
+    assert lib.cpc_nce_forward_prepared(P(c), P(z), P(wall), P(ext), P(nsaved), P(nan(ns[1])), P(losses), P(acc), B, S, K, N,
+                                        None) == 0
+    nscr, dc, dz, dwall = nan(ns[2]), torch.full_like(c, float("nan")), torch.full_like(z, float("nan")), torch.full_like(wall, float("nan"))
+    ones = torch.ones(K)
+    assert lib.cpc_nce_backward_streams(P(c), P(z), P(wall), P(ext), P(perm), P(row_ptr), P(nsaved), P(ones), P(nscr), P(dc), None,
+                                        None, B, S, K, N, None, None) == 0
+    dx = torch.full_like(z, float("nan"))
+    ggr = [torch.full_like(t, float("nan")) for t in gru_p]
+    ggarr = (ctypes.c_void_p * 8)(*[P(t) for t in ggr])
+    assert lib.cpc_gru_backward_streams(P(z), P(h0), garr_p, P(gsaved), P(c), P(dc), P(coef), P(nan(gs[2])), P(dx), ggarr, B, S, 2,
+                                        None, None) == 0
+    assert lib.cpc_nce_backward_dz(P(c), P(wall), P(perm), P(row_ptr), P(nscr), P(dz), B, S, K, N, None) == 0
+    assert lib.cpc_nce_backward_dwall(P(c), P(nscr), P(dwall), B, S, K, N, None) == 0
+    dzt = dz + dx
+    egr = [torch.full_like(t, float("nan")) for t in enc_p]
+    egarr = (ctypes.c_void_p * 20)(*[P(t) for t in egr])
+    assert lib.cpc_encoder_backward_streams(P(wave), earr, P(esaved), P(z), P(dzt), P(nan(es[2])), egarr, B, L, None, None) == 0
+    return torch.stack([losses, acc]), hN, egr + ggr + [dwall], z, c
+
+
+@pytest.mark.parametrize("B,L,K,N,use_h0", [(2, 3200, 4, 16, False), (3, 2880, 5, 32, True)])
+def test_composite_step_matches_oracle_and_the_stagewise_step_emulated(B, L, K, N, use_h0):
+    lib = emu()
+    p, wave, S, bidx, sidx, plist = _setup(B, L, K, N)
+    h0 = (0.3 * torch.randn(2, B, 256, generator=torch.Generator().manual_seed(9))) if use_h0 else None
+    out, hN, grads, z, c = _composite(lib, wave, bidx, sidx, h0, 0.0 if use_h0 else 1.0, plist, B, L, K, N)
+    # ---- the oracle: losses, accuracies, outputs, every gradient
+    ora = O.train_step(p, wave, bidx, sidx, n_predicts=K, n_neg=N, h0=h0)
+    assert (z - ora["z"]).abs().max().item() < 1e-4 and (c - ora["c"]).abs().max().item() < 1e-4
+    assert (out[0] - ora["losses"].view(-1)).abs().max().item() < 1e-4
+    assert (out[1] - ora["acc"].view(-1)).abs().max().item() < 1.5 / (B * (S - K))
+    assert (hN - ora["hN"]).abs().max().item() < 1e-4
+    names = ENC + GRU
+    bad = {}
+    for n, g in zip(names, grads[:28]):
+        ref = ora["grads"][n]
+        e = rel_err(g.view_as(ref), ref) if torch.isfinite(g).all() else float("inf")
+        if not e < (5e-3 if n.startswith("gEncoder") else 2e-4):       # encoder: a ReLU tie may flip a row
+            bad[n] = e
+    dwall_ref = torch.cat([ora["grads"][f"wPrediction.predictors.{k}.weight"] for k in range(K)], 0)
+    e = rel_err(grads[28], dwall_ref)
+    if not e < 2e-4:
+        bad["wall"] = e
+    assert not bad, bad
+    # ---- bit-identical to the stage-by-stage issue order of the Python loop (its a-priori |c| bound needs h0 = None)
+    if not use_h0:
+        out2, hN2, grads2, z2, c2 = _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N)
+        assert torch.equal(out, out2) and torch.equal(hN, hN2) and torch.equal(z, z2) and torch.equal(c, c2)
+        for n, a, b in zip(names + ["wall"], grads, grads2):
+            assert torch.equal(a, b), n
+
+
+def test_composite_step_phase_split_and_schedule_switches_change_no_bit_emulated():
+    """phases 1 then 2 (what a data-parallel rank issues around its early gradient bucket) and every value of
+    cpc_set_step_schedule move launches between streams and calls, never arithmetic."""
+    lib = emu()
+    B, L, K, N = 2, 3200, 4, 16
+    p, wave, S, bidx, sidx, plist = _setup(B, L, K, N, seed=1)
+    ref = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N)
+    for phases, schedule in (((1, 2), (0, 0)), ((3,), (1, 0)), ((3,), (2, 1)), ((1, 2), (1, 1))):
+        got = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N, phases=phases, schedule=schedule)
+        assert torch.equal(ref[0], got[0]) and torch.equal(ref[3], got[3]) and torch.equal(ref[4], got[4])
+        for a, b in zip(ref[2], got[2]):
+            assert torch.equal(a, b), (phases, schedule)
+
+
+def test_composite_step_argument_errors():
+    lib = emu()
+    sizes = (ctypes.c_long * 8)()
+    assert lib.cpc_train_step_layout(0, 3200, 4, 16, sizes) == 1              # CPC_ERR_SHAPE
+    assert lib.cpc_train_step_layout(2, 3200, 4, 10, sizes) == 1              # N % 16
+    assert lib.cpc_train_step_layout(2, 1600, 12, 16, sizes) == 1             # S = 10 <= K
+    assert lib.cpc_set_step_schedule(3, 0) == 2 and lib.cpc_set_step_schedule(0, 2) == 2
+    assert lib.cpc_train_step(None, None, None, None, 1.0, None, None, None, None, None, None, None, 2, 3200, 4, 16, 3,
+                              None, None, None, None) == 2

@@ -49,7 +49,7 @@ def test_two_bucket_allreduce_on_side_stream_single_rank():
                 tr.step(wave, label, negatives=(bidx.to(dev), sidx.to(dev)))
             torch.cuda.synchronize()
             assert tr.allreduce._pending is None
-            assert (tr.allreduce.buf is not None) == on
+            assert tr.allreduce.buf is not None and tr._fused is not None     # the composite step keeps its gradients in the flat buffer
             finals.append({k: v.detach().cpu() for k, v in list(model.state_dict().items())
                            + list(crit.state_dict().items())})
         for k in finals[0]:

@@ -1,0 +1,170 @@
+"""train.Trainer's composite step (cpc_train_step, csrc/train_step.hip: forward + backward of the north-star configuration issued
+by ONE C call on the trainer's four streams, gradients written into the flat all-reduce buffer) on a real MI355X: bit-identical
+to the autograd-driven step it replaces -- same kernels in the same order -- over several optimiser steps, for drawn and for
+caller-supplied negatives, with the recurrent state carried (BASELINE config 5), and in the two-call form a data-parallel rank
+uses (reference semantics: cpc/train.py:78-99)."""
+import os
+import socket
+import time
+
+import pytest
+import torch
+
+from oracle import cpc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    return torch.device("cuda:0")
+
+
+def _trainer(p, dev, fused, keepHidden=False):
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
+    model, crit = build_model(keepHidden=keepHidden).to(dev), build_criterion().to(dev)
+    load_flat_params(model, crit, p)
+    model.train(); crit.train()
+    return Trainer(model, crit, fused=fused), model, crit
+
+
+def _state(model, crit):
+    return {k: v.detach().cpu().clone() for k, v in list(model.state_dict().items()) + list(crit.state_dict().items())}
+
+
+@pytest.mark.parametrize("given,keepHidden", [(True, False), (False, False), (True, True)])
+def test_composite_step_equals_the_autograd_step_bit_for_bit(given, keepHidden):
+    dev = _dev()
+    B, steps = 4, 3
+    p = O.make_params(seed=31, head_scale=64.0)
+    waves = [O.make_waveform(B, 20480, seed=40 + i).to(dev) for i in range(steps)]
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    g = torch.Generator().manual_seed(17)
+    draws = [O.draw_negative_indices(B, 128, 116, 128, generator=g) for _ in range(steps)]
+    res = []
+    for fused in (False, True):
+        tr, model, crit = _trainer(p, dev, fused, keepHidden)
+        torch.manual_seed(123)                       # drawn negatives: torch's generator, consumed in the same order by both
+        losses = []
+        for i in range(steps):
+            neg = (draws[i][0].to(dev), draws[i][1].to(dev)) if given else None
+            l, a = tr.step(waves[i], label, negatives=neg)
+            losses.append(torch.cat([l, a]).cpu())
+        torch.cuda.synchronize()
+        assert (tr._fused is not None) == fused
+        from cpc_audio_amd import ops
+        ops.check_device_errors()
+        hid = None if not keepHidden else model.gAR.hidden.cpu()
+        res.append((torch.stack(losses), _state(model, crit), hid, tr.optimizer.state_dict()))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+        assert not torch.equal(res[1][1][k], p[k]), k                  # every tensor took the optimiser steps
+    if keepHidden:
+        assert torch.equal(res[0][2], res[1][2])
+    s0, s1 = res[0][3]["state"], res[1][3]["state"]
+    for i in s0:                                                       # optimiser state incl. the step counts (fast path of optim.Adam)
+        assert float(s0[i]["step"]) == float(s1[i]["step"]) == steps
+        assert torch.equal(s0[i]["exp_avg"], s1[i]["exp_avg"]) and torch.equal(s0[i]["exp_avg_sq"], s1[i]["exp_avg_sq"])
+
+
+def test_composite_step_first_step_matches_the_oracle():
+    dev = _dev()
+    B = 3
+    p = O.make_params(seed=32, head_scale=64.0)
+    wave = O.make_waveform(B, 20480, seed=50)
+    g = torch.Generator().manual_seed(18)
+    bidx, sidx = O.draw_negative_indices(B, 128, 116, 128, generator=g)
+    tr, model, crit = _trainer(p, dev, True)
+    tr.optimizer.step = lambda *a, **k: None              # keep the gradients and the parameters of step 0
+    tr.optimizer.zero_grad = lambda *a, **k: None
+    l, a = tr.step(wave.to(dev), torch.zeros(B, dtype=torch.long, device=dev), negatives=(bidx.to(dev), sidx.to(dev)))
+    torch.cuda.synchronize()
+    ora = O.train_step(p, wave, bidx, sidx)
+    assert (l.cpu() - ora["losses"]).abs().max().item() < 1e-4
+    assert (a.cpu() - ora["acc"]).abs().max().item() < 1.5 / (B * 116)
+    named = dict(model.state_dict(keep_vars=True))
+    named.update(crit.state_dict(keep_vars=True))
+    bad = {}
+    for k, ref in ora["grads"].items():
+        rel = ((named[k].grad.cpu() - ref).norm() / (ref.norm() + 1e-30)).item()
+        if not rel < (5e-3 if k.startswith("gEncoder") else 2e-4):     # encoder: a ReLU tie may flip a row
+            bad[k] = rel
+    assert not bad, bad
+
+
+def test_composite_step_in_two_phases_around_the_early_gradient_bucket():
+    """world_size > 1 issues the step as phase 1, early bucket, phase 2, late bucket.  In a one-rank RCCL group (a SUM over one
+    rank is the identity) the trajectory must equal the single-call step's, bit for bit."""
+    dev = _dev()
+    import torch.distributed as dist
+    B, steps = 4, 3
+    p = O.make_params(seed=33, head_scale=64.0)
+    wave = O.make_waveform(B, 20480, seed=60).to(dev)
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        finals = []
+        for on in (False, True):
+            tr, model, crit = _trainer(p, dev, True)
+            tr.allreduce.single_rank_too = on
+            torch.manual_seed(7)
+            for _ in range(steps):
+                tr.step(wave, label)
+            torch.cuda.synchronize()
+            assert tr._fused is not None and tr.allreduce._pending is None
+            finals.append(_state(model, crit))
+        for k in finals[0]:
+            assert torch.equal(finals[0][k], finals[1][k]), k
+    finally:
+        dist.destroy_process_group()
+
+
+def test_composite_step_costs_the_host_a_fraction_of_the_autograd_step():
+    """What the composite is for: host time to ENQUEUE a step (B = 64, the benchmark size).  The bound is loose (a busy box), the
+    ratio is the claim: the autograd-driven step needs 1.4-1.8 ms from Python on a quiet box."""
+    dev = _dev()
+    B = 64
+    p = O.make_params(seed=34)
+    wave = O.make_waveform(B, 20480, seed=70).to(dev)
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    host = {}
+    for fused in (False, True):
+        tr, _, _ = _trainer(p, dev, fused)
+        for _ in range(6):
+            tr.step(wave, label)
+        torch.cuda.synchronize()
+        tr.wait_seconds = 0.0
+        t0 = time.perf_counter()
+        for _ in range(20):
+            tr.step(wave, label)
+        host[fused] = (time.perf_counter() - t0 - tr.wait_seconds) / 20
+        torch.cuda.synchronize()
+    print(f"host enqueue per step: autograd {1e3 * host[False]:.3f} ms, composite {1e3 * host[True]:.3f} ms")
+    assert host[True] < 0.6 * host[False]
+    assert host[True] < 1.0e-3
+
+
+def test_a_hidden_state_assigned_from_outside_drops_the_a_priori_bound():
+    """ADVICE (round 3): |c| <= 1 is taken a priori only for a recurrence started from zero or from its OWN final state.  A state
+    assigned from outside with |h| >> 1 makes |c| large; both step paths must then reduce max|c| in line and still match the oracle
+    (with the a-priori scale 2^13 such a c would overflow the fp16 pieces)."""
+    dev = _dev()
+    B = 2
+    p = O.make_params(seed=35, head_scale=64.0)
+    wave = O.make_waveform(B, 20480, seed=80)
+    g = torch.Generator().manual_seed(19)
+    bidx, sidx = O.draw_negative_indices(B, 128, 116, 128, generator=g)
+    h0 = 40.0 * torch.randn(2, B, 256, generator=g)
+    ora = O.train_step(p, wave, bidx, sidx, h0=h0)
+    assert ora["c"].abs().max().item() > 8.0
+    for fused in (False, True):
+        tr, model, crit = _trainer(p, dev, fused, keepHidden=True)
+        model.gAR.hidden = h0.to(dev)
+        l, _ = tr.step(wave.to(dev), torch.zeros(B, dtype=torch.long, device=dev), negatives=(bidx.to(dev), sidx.to(dev)))
+        torch.cuda.synchronize()
+        assert torch.isfinite(l).all()
+        assert (l.cpu() - ora["losses"]).abs().max().item() < 2e-4 * max(1.0, ora["losses"].abs().max().item()), fused
