@@ -15,7 +15,10 @@ DEFAULT_MFMA_MODE = 3      # what libcpc_hip starts in (cpc_set_mfma_mode): mode
 #                            product) with conv1 / its gradients on the DMA-fed kernels reading H2-stored activations
 EXPECTED_ABI = 9           # cpc_abi_version() of the library these signatures were written for: a stale or variant build that
 #                            exports every symbol with OLDER argument lists would corrupt memory instead of raising -- bind() refuses it
-DEFAULT_DMA_PIPELINE = 2   # cpc_set_dma_pipeline: the tap-pair walk where the shape allows, two 32-k stages elsewhere
+DEFAULT_DMA_PIPELINE = 2
+DEFAULT_WGRAD_DMA_STAGES = 4   # cpc_set_wgrad_dma_stages
+DEFAULT_CONV_SMALL_PIPE = 1    # cpc_set_conv_small_pipe
+DEFAULT_STEP_SCHEDULE = (1, 0)  # cpc_set_step_schedule: index preparation behind conv0, dz path beside the recurrence   # cpc_set_dma_pipeline: the tap-pair walk where the shape allows, two 32-k stages elsewhere
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -40,7 +43,10 @@ SIGNATURES = {
     "cpc_set_h2_layers": (_I, [_I]),
     "cpc_set_h2_dx": (_I, [_I]),
     "cpc_set_wgrad1_early": (_I, [_I]),
+    "cpc_set_conv_small_tile": (_I, [_I]),
+    "cpc_set_conv_small_pipe": (_I, [_I]),
     "cpc_set_wgrad_dma_groups": (_I, [_I]),
+    "cpc_set_wgrad_dma_stages": (_I, [_I]),
     "cpc_set_wgrad_dma_min_rows": (_I, [_I]),
     "cpc_set_gemm_split": (_I, [_I]),
     "cpc_set_gemm_fuse": (_I, [_I]),

@@ -719,14 +719,52 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_dgr
 //     overlapping x rows); part[z][co][K] partials are summed by wgrad_reduce_kernel in a fixed order;
 //   * LDS rows are 1024 + 64 bytes apart: the four rows a 16-lane group reads then start 16 banks apart.
 // Arithmetic: hh + hl + lh of the fp16 pieces, fp32 accumulators, the two power-of-two scales undone exactly.
+// ds_read_b64_tr_b16 at `base + OFF` (OFF: immediate).  By inline asm, because hipcc drains the whole DMA queue (s_waitcnt vmcnt(0))
+// in front of every __builtin_amdgcn_ds_read_tr16_b64 that follows a global_load_lds -- it cannot tell that the read touches another
+// stage than the requests in flight (plain ds_read_b128 of the forward kernel are spared that) -- which left round 2's
+// weight-gradient kernel with NO overlap of DMA and MFMAs: request a stage, wait for it, multiply (rocprofv3: 4-4.6 us per 32-row
+// stage against 1.3 us of MFMAs, whatever the grid size).  The asm reads are invisible to the waitcnt pass: the kernel waits for
+// them itself (lds_wait_tr16 below) before the first MFMA that consumes them.
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_read_tr16(const unsigned char* base) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIPEMU)
+    s16x4 v;
+    const unsigned a = (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)base;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+#else
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + OFF));
+#endif
+}
+// s_waitcnt lgkmcnt(0) that the twelve fragments (24 half reads) of a k-step pass THROUGH: nothing that consumes them can be
+// scheduled in front of it, and no copy of them is made before it
+__device__ __forceinline__ void lds_wait_tr16(s16x4 (&a)[2][2][2], s16x4 (&b)[4][2][2]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIPEMU)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0][0][0]), "+v"(a[0][0][1]), "+v"(a[0][1][0]), "+v"(a[0][1][1]), "+v"(a[1][0][0]), "+v"(a[1][0][1]),
+                   "+v"(a[1][1][0]), "+v"(a[1][1][1]), "+v"(b[0][0][0]), "+v"(b[0][0][1]), "+v"(b[0][1][0]), "+v"(b[0][1][1]),
+                   "+v"(b[1][0][0]), "+v"(b[1][0][1]), "+v"(b[1][1][0]), "+v"(b[1][1][1]), "+v"(b[2][0][0]), "+v"(b[2][0][1]),
+                   "+v"(b[2][1][0]), "+v"(b[2][1][1]), "+v"(b[3][0][0]), "+v"(b[3][0][1]), "+v"(b[3][1][0]), "+v"(b[3][1][1]));
+#endif
+}
+
 constexpr int kWgPitch = 1024 + 64;
 constexpr int kWgRows = 32;
 constexpr int kWgStage = 2 * kWgRows * kWgPitch;
+// ROWS x NST: contraction rows per LDS stage x stages.  32 x 2 (round 2): one stage in flight while the other is multiplied --
+// and the DMA queue drains completely (vmcnt(0)) before the next stage is requested: rocprofv3 shows 4-4.6 us per 32-row stage
+// whatever the grid size (64, 128 or 256 workgroups), against 1.3 us of MFMAs: the loop waits for the round trip of its own 64 KB.
+// 16 x 4: the same 136 KB of LDS as four 16-row stages, three of them in flight (counted vmcnt waits), one barrier per 16 rows;
+// rows stay whole 1 KB DMA pieces either way (the stage dimension is the row count, not k).
+template <int ROWS, int NST>
 __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(
     const unsigned char* __restrict__ dx, const unsigned char* __restrict__ x, int B, int Lin, int Lout, int k, int s, int p,
     int rows_per_split, int S, float* __restrict__ part, const float* __restrict__ dx_bound, const float* __restrict__ x_bound,
     const unsigned char* __restrict__ zeros) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * kWgStage];
+    static_assert(ROWS * NST == 64 && (ROWS == 16 || ROWS == 32), "136 KB of LDS: 32 x 2 or 16 x 4");
+    constexpr int STAGE = 2 * ROWS * kWgPitch;
+    constexpr int RPW = ROWS / 8;                                  // rows (of each operand) a wave requests per stage
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -735,16 +773,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(
     const int M = B * Lout, K = k * kC;
     const int mbeg = z * rows_per_split;
     const int mend = min(M, mbeg + rows_per_split);
-    const int nch = (mend - mbeg + kWgRows - 1) / kWgRows;
+    const int nch = (mend - mbeg + ROWS - 1) / ROWS;
     const unsigned char* zsrc = zeros + (lane & 7) * 16;
 
     auto issue = [&](int ch, int stage) __attribute__((always_inline)) {
-        unsigned char* as = smem + stage * kWgStage;
-        unsigned char* bs = as + kWgRows * kWgPitch;
+        unsigned char* as = smem + stage * STAGE;
+        unsigned char* bs = as + ROWS * kWgPitch;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * wave + r;
-            const int m = mbeg + kWgRows * ch + row;               // wave-uniform
+        for (int r = 0; r < RPW; ++r) {
+            const int row = RPW * wave + r;
+            const int m = mbeg + ROWS * ch + row;                  // wave-uniform
             const unsigned char* a_src = zsrc;
             const unsigned char* b_src = zsrc;
             if (m < mend) {
@@ -769,34 +807,44 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(
     // this lane inside its 16-lane group: source row (p >> 2), channel quad (p & 3) of the group's 16 channels
     const int G = lane >> 4, pq = lane & 15, q = pq & 3;
     const int lane_off = (pq >> 2) * kWgPitch + (2 * (G & 1) + (q >> 1)) * 32 + (q & 1) * 8 + 8 * (G >> 1) * kWgPitch;
-    const int a_off = lane_off + wm * 64 * 4, b_off = lane_off + kWgRows * kWgPitch + wn * 128 * 4;
+    const int a_off = lane_off + wm * 64 * 4, b_off = lane_off + ROWS * kWgPitch + wn * 128 * 4;
 
-    if (nch > 0) issue(0, 0);
-    for (int ch = 0; ch < nch; ++ch) {
-        CPC_WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();          // stage ch has landed for everybody; everybody is done with stage ch - 1
-        if (ch + 1 < nch) issue(ch + 1, (ch + 1) & 1);
-        const unsigned char* st = smem + (ch & 1) * kWgStage;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+    for (int c0 = 0; c0 < NST - 1; ++c0)
+        if (c0 < nch) issue(c0, c0);
+    for (int ch = 0; ch < nch; ++ch) {
+        // stage ch has landed once at most the requests of the later stages are outstanding (2 * RPW per stage and wave)
+        if constexpr (NST == 2) {
+            CPC_WAIT_VMCNT(0);
+        } else {
+            if (ch + 2 < nch) CPC_WAIT_VMCNT(2 * 2 * RPW);
+            else if (ch + 1 < nch) CPC_WAIT_VMCNT(2 * RPW);
+            else CPC_WAIT_VMCNT(0);
+        }
+        __builtin_amdgcn_s_barrier();          // stage ch has landed for everybody; everybody is done with stage ch - 1
+        if (ch + NST - 1 < nch) issue(ch + NST - 1, (ch + NST - 1) % NST);
+        const unsigned char* st = smem + (ch % NST) * STAGE;
+        const unsigned char* sa = st + a_off, *sb = st + b_off;
+        auto kstep = [&](auto KS) __attribute__((always_inline)) {
+            constexpr int ks = decltype(KS)::value;
             using SP = SplitPlanes<2>;
+            s16x4 ah[2][2][2], bh[4][2][2];                         // [tile][piece][rows 0-3 / 4-7 of the 8-row operand]
+#define CPC_TR_A(tm, pl) ah[tm][pl][0] = lds_read_tr16<16 * ks * kWgPitch + 16 * pl + tm * 128>(sa); \
+                         ah[tm][pl][1] = lds_read_tr16<16 * ks * kWgPitch + 16 * pl + tm * 128 + 4 * kWgPitch>(sa)
+#define CPC_TR_B(tn, pl) bh[tn][pl][0] = lds_read_tr16<16 * ks * kWgPitch + 16 * pl + tn * 128>(sb); \
+                         bh[tn][pl][1] = lds_read_tr16<16 * ks * kWgPitch + 16 * pl + tn * 128 + 4 * kWgPitch>(sb)
+            CPC_TR_A(0, 0); CPC_TR_A(1, 0); CPC_TR_B(0, 0); CPC_TR_B(1, 0); CPC_TR_B(2, 0); CPC_TR_B(3, 0);
+            CPC_TR_A(0, 1); CPC_TR_A(1, 1); CPC_TR_B(0, 1); CPC_TR_B(1, 1); CPC_TR_B(2, 1); CPC_TR_B(3, 1);
+#undef CPC_TR_A
+#undef CPC_TR_B
+            lds_wait_tr16(ah, bh);
             s16x8 af[2][2], bf[4][2];
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                const unsigned char* ra = st + a_off + 16 * ks * kWgPitch + 16 * pl;
-                const unsigned char* rb = st + b_off + 16 * ks * kWgPitch + 16 * pl;
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ra + tm * 128));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ra + tm * 128 + 4 * kWgPitch));
-                    af[tm][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
+                for (int tm = 0; tm < 2; ++tm) af[tm][pl] = __builtin_shufflevector(ah[tm][pl][0], ah[tm][pl][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(rb + tn * 128));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(rb + tn * 128 + 4 * kWgPitch));
-                    bf[tn][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
+                for (int tn = 0; tn < 4; ++tn) bf[tn][pl] = __builtin_shufflevector(bh[tn][pl][0], bh[tn][pl][1], 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
             for (int qq = 0; qq < SP::NPROD; ++qq)                  // small terms first (l*h, h*l, h*h)
@@ -805,7 +853,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(
 #pragma unroll
                     for (int tn = 0; tn < 4; ++tn)
                         acc[tm][tn] = SP::mfma(af[tm][SP::pa(qq)], bf[tn][SP::pb(qq)], acc[tm][tn]);
-        }
+        };
+        kstep(std::integral_constant<int, 0>());
+        if constexpr (ROWS == 32) kstep(std::integral_constant<int, 1>());
     }
     const float inv = 1.0f / (scale_for_amax(*dx_bound) * scale_for_amax(*x_bound));      // powers of two: exact
     float* out = part + (long)z * kC * K + tap * kC;
@@ -916,6 +966,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_bf16_kernel(
 // 32-row stages
 static int g_wgrad_dma_wgs = 256;     // cpc_set_wgrad_dma_groups (<= 512: the partial buffer is sized for 512).  One workgroup per CU
                                       // (its LDS fills one): measured in the step at B = 64, 512 / 384 / 256 workgroups: 3.44 / 3.49 / 3.42 ms
+static int g_wgrad_dma_stages = 4;     // LDS stages of the H2 weight-gradient kernel: 2 x 32 rows or 4 x 16 rows (cpc_set_wgrad_dma_stages)
 static int g_wgrad_dma_min_rows = 512; // fewest rows a split walks (cpc_set_wgrad_dma_min_rows): every split costs a 256 KB partial tile
                                       // written and read again, and a prologue; the short layers get fewer splits instead of short ones
 void conv_wgrad_dma_plan(int M, int k, int* splits, int* rows, int wgs) {
@@ -935,9 +986,14 @@ int conv_wgrad_dma(const void* dx_h2, const void* x_h2, float* part, const float
     const int Lout = conv_out_len(Lin, k, s, p);
     int S, rows;
     conv_wgrad_dma_plan(B * Lout, k, &S, &rows, 0);
-    hipLaunchKernelGGL(conv_wgrad_dma_kernel, dim3(8 * k * cdiv(S, 8)), dim3(512), 0, st,
-                       reinterpret_cast<const unsigned char*>(dx_h2), reinterpret_cast<const unsigned char*>(x_h2), B, Lin, Lout,
-                       k, s, p, rows, S, part, dx_bound, x_bound, reinterpret_cast<const unsigned char*>(zeros));
+    if (g_wgrad_dma_stages == 4)
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<16, 4>), dim3(8 * k * cdiv(S, 8)), dim3(512), 0, st,
+                           reinterpret_cast<const unsigned char*>(dx_h2), reinterpret_cast<const unsigned char*>(x_h2), B, Lin, Lout,
+                           k, s, p, rows, S, part, dx_bound, x_bound, reinterpret_cast<const unsigned char*>(zeros));
+    else
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<32, 2>), dim3(8 * k * cdiv(S, 8)), dim3(512), 0, st,
+                           reinterpret_cast<const unsigned char*>(dx_h2), reinterpret_cast<const unsigned char*>(x_h2), B, Lin, Lout,
+                           k, s, p, rows, S, part, dx_bound, x_bound, reinterpret_cast<const unsigned char*>(zeros));
     CPC_LAUNCH_CHECK();
     *splits_out = S;
     return 0;
@@ -1141,6 +1197,11 @@ using namespace cpc;
 extern "C" int cpc_set_wgrad_dma_groups(int wgs) {
     if (wgs < 64 || wgs > 512) return CPC_ERR_ARG;
     g_wgrad_dma_wgs = wgs;
+    return 0;
+}
+extern "C" int cpc_set_wgrad_dma_stages(int n) {
+    if (n != 2 && n != 4) return CPC_ERR_ARG;
+    g_wgrad_dma_stages = n;
     return 0;
 }
 extern "C" int cpc_set_wgrad_dma_min_rows(int rows) {

@@ -207,7 +207,10 @@ __global__ __launch_bounds__(256) void enc_prep_permute_kernel(PrepArgs a) {
 // product; operands scaled by powers of two derived from bounds on their max|.|, see gemm_tile.h)
 // AH2 (MODE 2 only): the A operand (the layer's input activation, or its output gradient in the data-gradient kernel) lies in
 // H2 storage and is staged without conversion (NtTileX3's AH2)
-template <int BM, int MODE, bool AH2 = false>
+// PIPE: the software-pipelined 16-k schedule (two LDS stages, four register sets of global loads in flight) for the 32- / 64-row
+// tiles as well; without it they run one 32-k LDS stage with ONE chunk prefetched, i.e. a global-load latency per chunk
+// with 12 MFMAs to hide it behind (the short layers at B = 64)
+template <int BM, int MODE, bool AH2 = false, bool PIPE = false>
 struct ConvCfg {
     static_assert(!AH2 || MODE == 2, "H2 operands belong to the fp16-split mode");
     static constexpr bool X3 = MODE != 0;
@@ -220,7 +223,7 @@ struct ConvCfg {
     // mode 2: the weight re-layout kernels also split (same 4 bytes per weight, no VALU left for B in the main loop --
     // what made the 32-row tiles of the short layers slower with on-the-fly fp16 conversion: 108 vs 76 us)
     static constexpr bool kPreSplitW = MODE == 2;
-    using X3Tile = typename std::conditional<BM == 128, NtTileX3<BM, kC, WAVES_M, 4, 16, 2, true, kPreSplitW, NP, AH2>,
+    using X3Tile = typename std::conditional<BM == 128 || PIPE, NtTileX3<BM, kC, WAVES_M, 4, 16, 2, true, kPreSplitW, NP, AH2>,
                                              NtTileX3<BM, kC, WAVES_M, 4, 32, 1, false, kPreSplitW, NP, AH2>>::type;
     using Tile = typename std::conditional<X3, X3Tile, NtTile<BM, kC, WAVES_M, 4>>::type;
 };
@@ -241,13 +244,13 @@ __device__ __forceinline__ void h2_store_lane(unsigned char* row, int c, float v
 // x_amax / w_amax (MODE 2 only): device floats holding upper bounds of max|x| and max|w|
 // y_amax (MODE 2, may be NULL): y is written in H2 storage scaled for the bound *y_amax (which must bound |y|: the layer's
 // ChannelNorm bound) instead of fp32
-template <int BM, int MODE, bool AH2 = false>
-__global__ __launch_bounds__((ConvCfg<BM, MODE, AH2>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_fwd_kernel(
+template <int BM, int MODE, bool AH2 = false, bool PIPE = false>
+__global__ __launch_bounds__((ConvCfg<BM, MODE, AH2, PIPE>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_fwd_kernel(
     RowMap am, const float* __restrict__ wp, int K, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
     float* __restrict__ xhat, float* __restrict__ rstd_out, const float* __restrict__ x_amax,
     const float* __restrict__ w_amax, const float* __restrict__ y_amax = nullptr) {
-    using Tile = typename ConvCfg<BM, MODE, AH2>::Tile;
+    using Tile = typename ConvCfg<BM, MODE, AH2, PIPE>::Tile;
     constexpr bool X3 = MODE != 0;
     constexpr int TM = Tile::TM, TN = Tile::TN;
     __shared__ float smem[Tile::SMEM_FLOATS];
@@ -510,17 +513,17 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
 // ------------------------------------------------------------------ dgrad (+ fused norm backward)
 // grid = (row tiles over B*(Lout+1), s phases).  am = 2-row windows over dx of THIS layer.
 // MODE 2: dx_amax / w_amax bound the operands; prev_amax (FUSE, may be NULL) receives max|dprev|.
-template <int BM, bool FUSE, int MODE, bool AH2 = false>
-__global__ __launch_bounds__((ConvCfg<BM, MODE, AH2>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_dgrad_kernel(
+template <int BM, bool FUSE, int MODE, bool AH2 = false, bool PIPE = false>
+__global__ __launch_bounds__((ConvCfg<BM, MODE, AH2, PIPE>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_dgrad_kernel(
     RowMap am, const float* __restrict__ wd, int s, int p, int Lin,
     const float* __restrict__ xhat_prev, const float* __restrict__ y_prev,
     const float* __restrict__ rstd_prev, const float* __restrict__ nw_prev,
     float* __restrict__ dprev, float* __restrict__ colpart, const float* __restrict__ dx_amax,
     const float* __restrict__ w_amax, float* __restrict__ prev_amax, int amax_slots) {
     static_assert(!(AH2 && FUSE), "the H2-input data gradient is the plain (unfused) one");
-    using Tile = typename ConvCfg<BM, MODE, AH2>::Tile;
+    using Tile = typename ConvCfg<BM, MODE, AH2, PIPE>::Tile;
     constexpr bool X3 = MODE != 0;
-    constexpr int TM = Tile::TM, TN = Tile::TN, WAVES_M = ConvCfg<BM, MODE, AH2>::WAVES_M;
+    constexpr int TM = Tile::TM, TN = Tile::TN, WAVES_M = ConvCfg<BM, MODE, AH2, PIPE>::WAVES_M;
     __shared__ float smem[Tile::SMEM_FLOATS];
     __shared__ float red[2][BM][4];
     __shared__ float colsum[3][kC];
@@ -805,15 +808,18 @@ static int g_wgrad_dma = 1;  // weight gradient of a layer with dx and x in H2 s
                              // 0 = the register-staged TN tile (conv_wgrad_kernel<5>)
 static int g_h2_dx = 1;      // mode 3: layer 1's gradient dx in H2 storage (DMA data gradient); 0 = fp32 dx, register-staged dgrad
 static int g_h2_layers = 0;  // 0 = by problem size; 1 / 2 / 4 = tuning / test override: how many layers read H2 input (see enc_layout)
-static int g_h2_all = 0;     // what "by problem size" means: 0 = conv1 (conv2 at B >= ~100) read H2 input, 1 = every layer does
+static int g_h2_all = 1;     // what "by problem size" means: 1 (default since round 4) = every layer reads H2 input; 0 = conv1 (conv2 at
+                             // B >= ~100) only -- cpc_set_h2_layers(1 / 2) selects the round-3 behaviour explicitly
 static int g_force_bm = 0;   // 0 = choose by problem size; 32/64/128 = tuning / test override
+static int g_small_bm = 32;  // rows of the small tile pick_bm() chooses below 32000 rows (cpc_set_conv_small_tile): 32 or 64
+static int g_small_pipe = 1; // 1: the 32- / 64-row tiles of the H2-fed register-staged kernels on the pipelined 16-k schedule (ConvCfg PIPE)
 static constexpr int g_unfuse_big = 2;   // 2: every dgrad runs unfused + streaming norm backward, 1: only the 128-row tiles,
                                          // 0: fused epilogue (cpc_conv_layer_dgrad fuse=1).  Measured 4.69 / 4.76 / 4.79 ms per step
 static int pick_bm(int M) {
     if (g_force_bm) return g_force_bm;
     // measured on MI355X (tools/bench_kernels.py): 128-row tiles win as soon as they give ~256 blocks
     // (the 256-column weight tile is re-read from L2 once per block); below that the 32-row tile wins.
-    return M >= 32000 ? 128 : 32;
+    return M >= 32000 ? 128 : g_small_bm;
 }
 
 static bool enc_layout(int B, int Lw, EncLayout& e) {
@@ -876,7 +882,7 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
         // dgrad of layer i (i >= 2) writes colpart of layer i-1; norm_bwd writes layer 4's
         if (i >= 2) {
             const int Md = B * (e.L[i] + 1);
-            col_max = std::max(col_max, (long)cdiv(Md, pick_bm(Md)) * kGeom[i].s);
+            col_max = std::max(col_max, (long)cdiv(Md, 32) * kGeom[i].s);     // (the smallest tile: a size must not depend on a knob)
         }
     }
     for (int i = 1; i < 5; ++i) col_max = std::max(col_max, (long)cdiv(B * e.L[i], NB_ROWS));   // stand-alone norm backward
@@ -908,7 +914,10 @@ static void launch_conv_fwd(const RowMap& am, const float* wp, int K, const floa
                             const float* nw, const float* nb, float* y, float* xhat, float* rstd,
                             const float* x_amax, const float* w_amax, hipStream_t st, bool x_h2 = false,
                             const float* y_amax = nullptr) {
-    if (x_h2)          // input in H2 storage (fp16-split modes): staged as it lies; y in H2 storage too when y_amax is given
+    if (x_h2 && g_small_pipe && BM < 128 && K % 64 == 0)
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 2, true, true>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, 2, true, true>::Tile::NTHREADS),
+                           0, st, am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, y_amax);
+    else if (x_h2)     // input in H2 storage (fp16-split modes): staged as it lies; y in H2 storage too when y_amax is given
         hipLaunchKernelGGL((conv_fwd_kernel<BM, 2, true>), dim3(cdiv(am.M, BM)), dim3(ConvCfg<BM, 2, true>::Tile::NTHREADS),
                            0, st, am, wp, K, bias, nw, nb, y, xhat, rstd, x_amax, w_amax, y_amax);
     else if (g_mfma_mode >= 2 && K % 32 == 0)
@@ -928,6 +937,12 @@ static void launch_conv_dgrad(const RowMap& am, const float* wd, int s, int p, i
                               const float* nw_prev, float* dprev, float* colpart, const float* dx_amax,
                               const float* w_amax, float* prev_amax, int amax_slots, hipStream_t st, bool dx_h2 = false) {
     if constexpr (!FUSE) {
+        if (dx_h2 && g_small_pipe && BM < 128) {
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM, false, 2, true, true>), dim3(cdiv(am.M, BM), s),
+                               dim3(ConvCfg<BM, 2, true, true>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
+                               rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, prev_amax, amax_slots);
+            return;
+        }
         if (dx_h2) {   // dx in H2 storage scaled for the single bound *dx_amax (amax_slots == 1)
             hipLaunchKernelGGL((conv_dgrad_kernel<BM, false, 2, true>), dim3(cdiv(am.M, BM), s),
                                dim3(ConvCfg<BM, 2, true>::Tile::NTHREADS), 0, st, am, wd, s, p, Lin, xhat_prev, y_prev,
@@ -964,6 +979,15 @@ static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const flo
 extern "C" int cpc_set_conv_tile(int bm) {
     CPC_RETURN_IF(bm != 0 && bm != 32 && bm != 64 && bm != 128, CPC_ERR_ARG);
     g_force_bm = bm;
+    return 0;
+}
+extern "C" int cpc_set_conv_small_tile(int bm) {
+    CPC_RETURN_IF(bm != 32 && bm != 64, CPC_ERR_ARG);
+    g_small_bm = bm;
+    return 0;
+}
+extern "C" int cpc_set_conv_small_pipe(int on) {
+    g_small_pipe = on ? 1 : 0;
     return 0;
 }
 extern "C" int cpc_set_dma_tile(int bm) {

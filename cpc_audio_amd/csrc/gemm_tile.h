@@ -580,8 +580,10 @@ struct NtTileX3 {
             for (int i = 0; i < A_PER; ++i)
                 if (A_EXACT || a_on[i]) {            // exact tilings stay branch-free: one basic block, so the
                     if constexpr (AH2) {             //  split can be scheduled into the MFMA shadow
-                        *reinterpret_cast<uint4*>(smem + a_lds[i]) =
-                            make_uint4(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y), __float_as_uint(ra[i].z), __float_as_uint(ra[i].w));
+                        uint4 raw;
+                        raw.x = __float_as_uint(ra[i].x); raw.y = __float_as_uint(ra[i].y);
+                        raw.z = __float_as_uint(ra[i].z); raw.w = __float_as_uint(ra[i].w);
+                        *reinterpret_cast<uint4*>(smem + a_lds[i]) = raw;
                     } else {
                         uint2 pp[NP];
                         SP::split(ra[i], sa, pp);

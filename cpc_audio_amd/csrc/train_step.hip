@@ -63,8 +63,9 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a,
 }
 
 // tuning / measurement switches (cpc_set_step_schedule)
-int g_prep_point = 0;     // where the criterion's index preparation is released on the side stream: 0 step begin (beside conv0),
-                          // 1 behind conv0 (beside conv1), 2 behind the encoder (beside the recurrence)
+int g_prep_point = 1;     // where the criterion's index preparation is released on the side stream: 0 step begin (beside conv0: the one
+                          // HBM-bound layer goes from 50 to 96 us), 1 (default) behind conv0 (beside conv1 / conv2: +20 us there),
+                          // 2 behind the encoder (beside the recurrence, whose hand-over it disturbs)
 int g_dz_early = 0;       // 1: the dz path on MAIN before the recurrence's backward (which then has the memory system to itself)
                           // instead of beside it on the side stream
 

@@ -98,7 +98,11 @@ int cpc_set_h2_layers(int n);            /* mode 3, which layers read their inpu
                                             conv2, both on the DMA kernels; 4 = all four -- conv1 (conv2 from B ~ 100 on) on the DMA kernels, the
                                             short layers on the register-staged tiles, which stage H2 rows as they lie, and every weight
                                             gradient on the DMA + transposing-read kernel with one batched reduction; 0 = by problem size */
+int cpc_set_conv_small_tile(int bm);     /* rows per workgroup of the register-staged conv tiles below 32000 rows: 32 (default) or 64 */
+int cpc_set_conv_small_pipe(int on);     /* 1 (default): the 32- / 64-row tiles of the H2-fed register-staged conv kernels (cpc_set_h2_layers(4)) run the software-
+                                            pipelined 16-k schedule of the 128-row tiles (four chunks of global loads in flight); 0: one 32-k stage */
 int cpc_set_wgrad_dma_groups(int wgs);  /* workgroups the DMA weight gradient aims at (row splits = wgs / taps); 64..512 */
+int cpc_set_wgrad_dma_stages(int n);     /* its LDS pipeline: 2 stages of 32 contraction rows (one in flight) or 4 (default) of 16 (three in flight) */
 int cpc_set_wgrad_dma_min_rows(int rows); /* ... and the fewest rows one of its splits walks (default 512; 128..8192, a multiple of 64) */
 int cpc_set_wgrad1_early(int on);        /* two-stream encoder backward: 0 (default) layer 1's weight gradient behind its data gradient, 1 beside it */
 int cpc_set_h2_dx(int on);               /* mode 3: 1 (default) keeps the gradient dx of every layer whose input is in H2 storage in H2 storage
@@ -386,8 +390,8 @@ int cpc_train_step(const float* wave, const long* batchIdx, const long* seqIdx, 
                    float* acc, float* hN, int B, int L, int K, int N, int phases, void* main_stream, void* side_stream,
                    void* prep_stream, void* wgrad_stream);
 /* Measurement switches of cpc_train_step's schedule.  prep_point: where the criterion's index preparation (190 MB of index
- * traffic at B = 64) is released on side_stream -- 0 (default) at the step's start (beside conv0), 1 behind conv0 (beside
- * conv1), 2 behind the encoder (beside the recurrence).  dz_early: 1 = the dz path on main_stream BEFORE the recurrence's
+ * traffic at B = 64) is released on side_stream -- 0 at the step's start (beside conv0, the one HBM-bound layer: 50 -> 96 us), 1
+ * (default) behind conv0 (beside conv1 / conv2), 2 behind the encoder (beside the recurrence).  dz_early: 1 = the dz path on main_stream BEFORE the recurrence's
  * backward (which then has the memory system to itself) instead of beside it on side_stream (0, default). */
 int cpc_set_step_schedule(int prep_point, int dz_early);
 

@@ -3,6 +3,8 @@ SIMT emulator and compared with the oracle: validates tile indexing, MFMA fragme
 padding/ragged edges, the fused ChannelNorm epilogues and every gradient -- on CPU."""
 import ctypes
 
+from cpc_audio_amd import _lib as _L
+
 import pytest
 import torch
 
@@ -47,15 +49,26 @@ def _saved_acts(lib, saved, B, L, Ls):
 @pytest.mark.parametrize("B,L,bm,mode", [(2, 1280, 0, 1), (1, 1370, 64, 1), (1, 1600, 128, 1), (3, 1290, 128, 0),
                                           (2, 1280, 0, 0), (1, 1600, 128, 2), (2, 1280, 0, 2), (1, 1370, 64, 2),
                                           (2, 1280, 0, 3), (1, 1370, 64, 3), (3, 1290, 128, 3), (2, 1280, 0, 32),
-                                          (1, 1370, 0, 132), (2, 1280, 0, 30)])
+                                          (1, 1370, 0, 132), (2, 1280, 0, 30), (2, 1280, 0, 34), (1, 1370, 64, 34),
+                                          (3, 1290, 128, 34), (2, 2560, 32, 34), (4, 2560, 0, 234), (2, 2560, 32, 334), (1, 1370, 64, 334), (4, 2560, 0, 434), (1, 1370, 0, 434)])
 def test_encoder_forward_backward_emulated(B, L, bm, mode):
     """mode 1: NT GEMMs on the bf16 pipe with 3-piece split operands; mode 0: exact-f32 MFMA; mode 2: fp16 pipe with
     scaled 2-piece split operands; mode 3 (default): mode 2 + layers 1, 2 on the DMA kernel reading H2 activations
     (ragged lengths: partial 128-row tiles, padding rows from the zero buffer)."""
     lib = emu()
     # mode 32: mode 3 with conv2 on the DMA kernel as well (what B >= ~100 selects); 132: that with two 32-k LDS stages;
-    # mode 30: mode 3 with layer 1's gradient kept fp32 (cpc_set_h2_dx(0): register-staged data gradient) instead of H2 storage
-    h2_layers, pipe = (2, mode // 100) if mode >= 32 else (0, 0)
+    # mode 30: mode 3 with layer 1's gradient kept fp32 (cpc_set_h2_dx(0): register-staged data gradient) instead of H2 storage;
+    # mode 34: every activation y0..y3 and every gradient dx1..dx4 in H2 storage (cpc_set_h2_layers(4)): the short layers on the
+    # register-staged tiles fed H2 rows as they lie (32 / 64 / 128-row tiles), all weight gradients on the DMA kernel, one reduction
+    # (234: that with the weight-gradient splits down to 128 rows, so that the short layers run several splits + the batched reduction)
+    # (334: mode 34 with the short tiles on the software-pipelined 16-k schedule, cpc_set_conv_small_pipe(1))
+    # (434: mode 234 with the weight-gradient kernel on four 16-row LDS stages, cpc_set_wgrad_dma_stages(4))
+    min_rows = 128 if mode in (234, 434) else 512
+    assert lib.cpc_set_conv_small_pipe(1 if mode == 334 else 0) == 0
+    assert lib.cpc_set_wgrad_dma_stages(4 if mode == 434 else 2) == 0
+    mode = 34 if mode in (234, 334, 434) else mode
+    assert lib.cpc_set_wgrad_dma_min_rows(min_rows) == 0
+    h2_layers, pipe = (4, 0) if mode == 34 else ((2, mode // 100) if mode >= 32 else (0, 0))
     h2_dx = 0 if mode == 30 else 1
     mode = 3 if mode >= 30 else mode
     assert lib.cpc_set_h2_dx(h2_dx) == 0
@@ -116,6 +129,9 @@ def test_encoder_forward_backward_emulated(B, L, bm, mode):
         lib.cpc_set_h2_layers(0)
         lib.cpc_set_dma_pipeline(_lib_default_pipeline())
         lib.cpc_set_h2_dx(1)
+        lib.cpc_set_wgrad_dma_min_rows(512)
+        lib.cpc_set_conv_small_pipe(_L.DEFAULT_CONV_SMALL_PIPE)
+        lib.cpc_set_wgrad_dma_stages(_L.DEFAULT_WGRAD_DMA_STAGES)
 
 
 @pytest.mark.parametrize("mode", [1, 2])

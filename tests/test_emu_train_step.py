@@ -4,6 +4,8 @@ the per-stage entry points the Python train loop uses (ops.py), for every schedu
 data-parallel rank uses."""
 import ctypes
 
+from cpc_audio_amd import _lib as _L
+
 import pytest
 import torch
 
@@ -27,7 +29,7 @@ def _setup(B, L, K, N, seed=0, head_scale=64.0):
     return p, wave, S, bidx, sidx, plist
 
 
-def _composite(lib, wave, bidx, sidx, h0, c_bound, plist, B, L, K, N, phases=(3,), schedule=(0, 0)):
+def _composite(lib, wave, bidx, sidx, h0, c_bound, plist, B, L, K, N, phases=(3,), schedule=_L.DEFAULT_STEP_SCHEDULE):
     sizes = (ctypes.c_long * 8)()
     assert lib.cpc_train_step_layout(B, L, K, N, sizes) == 0
     ws = torch.full((sizes[0],), float("nan"))
@@ -44,7 +46,7 @@ def _composite(lib, wave, bidx, sidx, h0, c_bound, plist, B, L, K, N, phases=(3,
                                     out[1].data_ptr(), P(hN), B, L, K, N, ph, None, None, None, None)
             assert rc == 0
     finally:
-        lib.cpc_set_step_schedule(0, 0)
+        lib.cpc_set_step_schedule(*_L.DEFAULT_STEP_SCHEDULE)
     S = sizes[3]
     z = ws[sizes[1]:sizes[1] + B * S * 256].view(B, S, 256).clone()
     c = ws[sizes[2]:sizes[2] + B * S * 256].view(B, S, 256).clone()
@@ -134,7 +136,7 @@ def test_composite_step_phase_split_and_schedule_switches_change_no_bit_emulated
     B, L, K, N = 2, 3200, 4, 16
     p, wave, S, bidx, sidx, plist = _setup(B, L, K, N, seed=1)
     ref = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N)
-    for phases, schedule in (((1, 2), (0, 0)), ((3,), (1, 0)), ((3,), (2, 1)), ((1, 2), (1, 1))):
+    for phases, schedule in (((1, 2), (0, 0)), ((3,), (1, 0)), ((3,), (0, 0)), ((3,), (2, 1)), ((1, 2), (1, 1))):
         got = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N, phases=phases, schedule=schedule)
         assert torch.equal(ref[0], got[0]) and torch.equal(ref[3], got[3]) and torch.equal(ref[4], got[4])
         for a, b in zip(ref[2], got[2]):

@@ -1,6 +1,8 @@
 """Encoder HIP kernels on a real MI355X vs the CPU oracle (through the C ABI)."""
 import ctypes
 
+from cpc_audio_amd import _lib as _L
+
 import pytest
 import torch
 
@@ -28,6 +30,13 @@ def _names():
 
 def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None):
     from cpc_audio_amd._lib import ptr as P
+    h2_layers, stages, small_pipe = 0, 2, 0
+    if mode in (34, 334, 434):  # mode 3 with every activation and every gradient of layers 1..4 in H2 storage (cpc_set_h2_layers(4));
+        stages = 4 if mode == 434 else 2         # 434: + the weight-gradient kernel on four 16-row LDS stages
+        small_pipe = 1 if mode == 334 else 0     # 334: + the short tiles on the software-pipelined 16-k schedule
+        mode, h2_layers = 3, 4
+    assert lib.cpc_set_h2_layers(h2_layers) == 0 and lib.cpc_set_wgrad_dma_stages(stages) == 0
+    assert lib.cpc_set_conv_small_pipe(small_pipe) == 0
     p = O.make_params(seed=pseed)
     plist = [p[n].contiguous().to(dev) for n in _names()]
     wave = O.make_waveform(B, L, seed=5)
@@ -60,6 +69,9 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None):
         ys.append(yi)
     torch.cuda.synchronize()
     lib.cpc_set_conv_tile(0)
+    lib.cpc_set_h2_layers(0)
+    lib.cpc_set_wgrad_dma_stages(_L.DEFAULT_WGRAD_DMA_STAGES)
+    lib.cpc_set_conv_small_pipe(_L.DEFAULT_CONV_SMALL_PIPE)
     lib.cpc_set_mfma_mode(_lib_default_mode())
     if dma is not None:
         lib.cpc_set_dma_tile(0)
@@ -93,11 +105,15 @@ def test_encoder_dma_pipelines_match_oracle(pipe):
 @pytest.mark.parametrize("B,L,bm,mode", [(2, 20480, 0, 1), (3, 20480, 128, 1), (1, 4330, 64, 1), (8, 20480, 0, 1),
                                           (3, 20480, 0, 0), (2, 10240, 32, 0), (8, 20480, 0, 2), (3, 20480, 128, 2),
                                           (1, 4330, 64, 2), (2, 10240, 32, 2), (8, 20480, 0, 3), (3, 20480, 128, 3),
-                                          (1, 4330, 64, 3), (2, 10240, 32, 3), (64, 20480, 0, 3)])
+                                          (1, 4330, 64, 3), (2, 10240, 32, 3), (64, 20480, 0, 3), (8, 20480, 0, 34),
+                                          (3, 20480, 128, 34), (1, 4330, 64, 34), (2, 10240, 32, 34), (64, 20480, 0, 34),
+                                          (8, 20480, 0, 434), (1, 4330, 64, 434), (64, 20480, 0, 434), (8, 20480, 0, 334),
+                                          (2, 10240, 64, 334), (64, 20480, 0, 334), (8, 20480, 0, 3)])
 def test_encoder_matches_oracle(B, L, bm, mode):
     """mode 1 = bf16 pipe with 3-piece split operands, mode 0 = exact-f32 MFMA, mode 2 = fp16 pipe with scaled
     2-piece split operands, mode 3 (default) = mode 2 + layers 1, 2 on the DMA kernel reading H2 activations (B = 64:
-    256-row tiles on layer 1, 128-row tiles on layer 2 -- the benchmark's shapes)."""
+    256-row tiles on layer 1, 128-row tiles on layer 2 -- the benchmark's shapes); 34 = mode 3 with y0..y3 and dx1..dx4 all in H2
+    storage: the short layers on the register-staged tiles fed H2 rows as they lie, every weight gradient on the DMA kernel."""
     dev = _dev()
     from cpc_audio_amd import _lib
     lib = _lib.get()
