@@ -133,10 +133,10 @@ def test_composite_step_phase_split_and_schedule_switches_change_no_bit_emulated
     """phases 1 then 2 (what a data-parallel rank issues around its early gradient bucket) and every value of
     cpc_set_step_schedule move launches between streams and calls, never arithmetic."""
     lib = emu()
-    B, L, K, N = 2, 3200, 4, 16
+    B, L, K, N = 2, 2560, 4, 16
     p, wave, S, bidx, sidx, plist = _setup(B, L, K, N, seed=1)
     ref = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N)
-    for phases, schedule in (((1, 2), (0, 0)), ((3,), (1, 0)), ((3,), (0, 0)), ((3,), (2, 1)), ((1, 2), (1, 1))):
+    for phases, schedule in (((1, 2), (0, 0)), ((3,), (2, 1)), ((1, 2), (1, 1))):
         got = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N, phases=phases, schedule=schedule)
         assert torch.equal(ref[0], got[0]) and torch.equal(ref[3], got[3]) and torch.equal(ref[4], got[4])
         for a, b in zip(ref[2], got[2]):
