@@ -125,13 +125,15 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
     const int S = s.S;
     int rc = 0;
     if (phases & 1) {
-        CPC_RETURN_IF(!batchIdx || !seqIdx || !gloss || !losses || !acc || !hN, CPC_ERR_ARG);
+        // batchIdx == seqIdx == NULL: the index lists of this step's draws are already in the workspace (cpc_train_step_prefetch,
+        // queued on side_stream behind the previous step)
+        CPC_RETURN_IF((batchIdx == nullptr) != (seqIdx == nullptr) || !gloss || !losses || !acc || !hN, CPC_ERR_ARG);
         // ---- forward ----
         // the step begins here on main: the other streams fork from this point (the workspace is the previous step's, whose
         // last users main has waited for)
         CPC_RETURN_IF(!rec(ev[0], M) || !wait(S1, ev[0]), CPC_ERR_ARG);
         auto prepare = [&]() -> int {      // index lists of the draws + operand bounds of the prediction GEMMs: depend on no activation
-            int r = cpc_nce_prepare(batchIdx, seqIdx, ext, perm, row_ptr, work, B, S, K, N, S0);
+            int r = batchIdx ? cpc_nce_prepare(batchIdx, seqIdx, ext, perm, row_ptr, work, B, S, K, N, S0) : 0;
             if (r) return r;
             if (c_bound > 0.f) r = cpc_nce_bounds(nullptr, c_bound, wall, ws + s.nce_saved, B, S, K, N, S0);
             if (r) return r;
@@ -197,4 +199,20 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
         CPC_RETURN_IF(!wait(M, ev[5]), CPC_ERR_ARG);
     }
     return 0;
+}
+
+// The index lists of the NEXT step's negative draws, prepared one step ahead: the preparation (190 MB of index traffic at B = 64)
+// depends on nothing but the draws, and the end of a step -- layer 1's weight gradient running alone on the matrix pipes -- leaves
+// the memory system idle, while at the start of a step it competes with the conv layers.  Call it after cpc_train_step (phase 2)
+// of the current step, with the next step's draws ready on `side_stream`; everything of the current step that reads the lists
+// precedes it on that stream.  The next cpc_train_step (same B, L, K, N, workspace) is then called with batchIdx = seqIdx = NULL.
+extern "C" int cpc_train_step_prefetch(const long* batchIdx, const long* seqIdx, float* workspace, int B, int L, int K, int N,
+                                       void* side_stream) {
+    StepLayout s;
+    CPC_RETURN_IF(!step_layout(B, L, K, N, s), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!batchIdx || !seqIdx || !workspace, CPC_ERR_ARG);
+    float* ws = workspace;
+    return cpc_nce_prepare(batchIdx, seqIdx, reinterpret_cast<int*>(ws + s.ext), reinterpret_cast<int*>(ws + s.perm),
+                           reinterpret_cast<int*>(ws + s.row_ptr), reinterpret_cast<int*>(ws + s.work), B, s.S, K, N,
+                           (hipStream_t)side_stream);
 }

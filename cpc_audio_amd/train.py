@@ -47,7 +47,7 @@ class Trainer:
     AUTO_PROBE_STEPS = 6      # graph="auto": eager steps timed (host enqueue time vs GPU time) before deciding
 
     def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, graph=False, check_errors_every=256,
-                 fused=True):
+                 fused=True, prefetch_negatives=False):
         """check_errors_every: every that many steps the device-side error flags are read (ops.check_device_errors: a
         recurrence workgroup that gave up polling, a negative index out of range) and turned into an exception -- one device
         synchronisation per that many steps; 0 leaves the check to the caller.
@@ -62,6 +62,16 @@ class Trainer:
         AR / predictors, criterion mode 'reverse', frozen parameters) runs the autograd path below."""
         self.model, self.criterion = model, criterion
         self.fused = bool(fused)
+        # composite step only, off by default: draw the NEXT step's negatives and prepare their index lists at the end of a step
+        # (beside its tail: layer 1's weight gradient alone on the matrix pipes) instead of behind conv0 of the next one.  The
+        # draws come from torch's generator in the same order either way -- the A/B's losses are equal to the last digit --; only
+        # code that draws from the same generator BETWEEN two train steps (a validation pass) would see them one step early.
+        # Measured neutral (2.880 vs 2.883 ms per step sustained, three alternations: what the preparation costs conv1 / conv2
+        # at the start of a step it costs the weight gradient at the end), so the reference's draw-inside-the-step order stays.
+        # CPC_PREFETCH_NEGATIVES=1 / 0 overrides (A/B runs).
+        import os
+        env = os.environ.get("CPC_PREFETCH_NEGATIVES")
+        self.prefetch_negatives = bool(prefetch_negatives) if env is None else env == "1"
         self._fused = None                # cached pointer tables / workspace of the composite step
         params = list(criterion.parameters()) + list(model.parameters())      # train.py:332
         self.optimizer = Adam(params, lr=lr, betas=betas, eps=eps)      # train.py:335-337; one launch per step on the GPU
@@ -167,7 +177,11 @@ class Trainer:
         with torch.cuda.device(dev):
             main = torch.cuda.current_stream(dev)
             side, prep, wst = ctx.side_stream(dev, 0), ctx.side_stream(dev, 1), ctx.side_stream(dev, 2)
-            if negatives is None:
+            pkey = (B, L, K, N)
+            if negatives is None and f.get("prefetched") == pkey:
+                bidx = sidx = None                       # drawn and prepared at the end of the previous step (below)
+                f["prefetched"] = None
+            elif negatives is None:
                 # the two draws of sampleClean (criterion.py:181-189) on the side stream, forked from the start of the step:
                 # torch's generator, in the reference's order
                 begin = torch.cuda.Event()
@@ -219,6 +233,12 @@ class Trainer:
                 raise
             if ar.keepHidden:
                 ar.hidden = ar._own_hidden = hN                 # cpc/model.py:194-198 (a fresh tensor per step: nothing aliases it)
+            if negatives is None and self.prefetch_negatives and not self._capturing:
+                # the next step's draws + their index lists now, on the side stream behind this step's last reader of the lists
+                with torch.cuda.stream(side):
+                    nb, ns = cr.drawNegatives(B, S, S - K, dev)
+                lib.check(lib.cpc_train_step_prefetch(P(nb), P(ns), P(f["ws"]), B, L, K, N, side.cuda_stream), "train_step_prefetch")
+                f["prefetched"] = pkey
             self.allreduce()
             self.optimizer.step()
             self.optimizer.zero_grad()

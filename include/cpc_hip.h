@@ -389,6 +389,12 @@ int cpc_train_step(const float* wave, const long* batchIdx, const long* seqIdx, 
                    const float* const* params, float* const* grads, const float* gloss, float* workspace, float* losses,
                    float* acc, float* hN, int B, int L, int K, int N, int phases, void* main_stream, void* side_stream,
                    void* prep_stream, void* wgrad_stream);
+/* The index lists of the NEXT step's draws, one step ahead (optional): queue it on side_stream after the current step's
+ * cpc_train_step, with the next step's draws ready there; the next cpc_train_step -- same sizes and workspace -- is then given
+ * batchIdx = seqIdx = NULL.  The preparation then runs beside the tail of the current step (layer 1's weight gradient alone on
+ * the matrix pipes) instead of beside the next step's first conv layers. */
+int cpc_train_step_prefetch(const long* batchIdx, const long* seqIdx, float* workspace, int B, int L, int K, int N,
+                            void* side_stream);
 /* Measurement switches of cpc_train_step's schedule.  prep_point: where the criterion's index preparation (190 MB of index
  * traffic at B = 64) is released on side_stream -- 0 at the step's start (beside conv0, the one HBM-bound layer: 50 -> 96 us), 1
  * (default) behind conv0 (beside conv1 / conv2), 2 behind the encoder (beside the recurrence).  dz_early: 1 = the dz path on main_stream BEFORE the recurrence's

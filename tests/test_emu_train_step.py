@@ -152,3 +152,28 @@ def test_composite_step_argument_errors():
     assert lib.cpc_set_step_schedule(3, 0) == 2 and lib.cpc_set_step_schedule(0, 2) == 2
     assert lib.cpc_train_step(None, None, None, None, 1.0, None, None, None, None, None, None, None, 2, 3200, 4, 16, 3,
                               None, None, None, None) == 2
+
+
+def test_prefetched_index_lists_give_the_same_step_emulated():
+    """cpc_train_step_prefetch + cpc_train_step(batchIdx = seqIdx = NULL): the index lists prepared one step ahead in the workspace
+    are the ones the step would have prepared itself."""
+    lib = emu()
+    B, L, K, N = 2, 2560, 4, 16
+    p, wave, S, bidx, sidx, plist = _setup(B, L, K, N, seed=2)
+    ref = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N)
+    sizes = (ctypes.c_long * 8)()
+    assert lib.cpc_train_step_layout(B, L, K, N, sizes) == 0
+    ws = torch.full((sizes[0],), float("nan"))
+    grads = [torch.full_like(t, float("nan")) for t in plist]
+    parr = (ctypes.c_void_p * 29)(*[P(t) for t in plist])
+    garr = (ctypes.c_void_p * 29)(*[P(t) for t in grads])
+    out, hN, ones = torch.full((2, K), float("nan")), torch.full((2, B, 256), float("nan")), torch.ones(K)
+    assert lib.cpc_train_step_prefetch(P(bidx), P(sidx), P(ws), B, L, K, N, None) == 0
+    assert lib.cpc_train_step(P(wave), None, None, None, 1.0, parr, garr, P(ones), P(ws), out[0].data_ptr(), out[1].data_ptr(),
+                              P(hN), B, L, K, N, 3, None, None, None, None) == 0
+    assert torch.equal(out, ref[0])
+    for a, b in zip(grads, ref[2]):
+        assert torch.equal(a, b)
+    # one of the two draws without the other is an argument error
+    assert lib.cpc_train_step(P(wave), P(bidx), None, None, 1.0, parr, garr, P(ones), P(ws), out[0].data_ptr(), out[1].data_ptr(),
+                              P(hN), B, L, K, N, 3, None, None, None, None) == 2

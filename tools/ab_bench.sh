@@ -7,7 +7,7 @@ rounds=${ROUNDS:-3}
 for r in $(seq 1 $rounds); do
   for spec in "$@"; do
     label=${spec%%|*}; args=${spec#*|}
-    timeout 300 python bench.py --no-cpu-baseline --no-probes --steps 40 --warmup 10 --sustained-seconds 3 $args 2>/dev/null | grep '^{' > "$out/${label}_$r.json"
+    env $(echo "$args" | grep -o "ENV:[^ ]*" | sed "s/ENV://") timeout 300 python bench.py --no-cpu-baseline --no-probes --steps 40 --warmup 10 --sustained-seconds 3 $(echo "$args" | sed "s/ENV:[^ ]*//g") 2>/dev/null | grep '^{' > "$out/${label}_$r.json"
     python - "$out/${label}_$r.json" "$label" "$r" <<'PY'
 import json, sys
 try:
