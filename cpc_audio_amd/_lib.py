@@ -43,6 +43,7 @@ SIGNATURES = {
     "cpc_set_h2_layers": (_I, [_I]),
     "cpc_set_h2_dx": (_I, [_I]),
     "cpc_set_wgrad1_early": (_I, [_I]),
+    "cpc_set_dma_layer2": (_I, [_I]),
     "cpc_set_conv_small_tile": (_I, [_I]),
     "cpc_set_conv_small_pipe": (_I, [_I]),
     "cpc_set_wgrad_dma_groups": (_I, [_I]),

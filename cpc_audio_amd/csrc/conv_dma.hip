@@ -748,6 +748,14 @@ __device__ __forceinline__ void lds_wait_tr16(s16x4 (&a)[2][2][2], s16x4 (&b)[4]
 #endif
 }
 
+__device__ __forceinline__ void lds_wait_tr16(s16x4 (&a)[2][2], s16x4 (&b)[4][2]) {      // one piece (bf16 storage): 12 half reads
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIPEMU)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]),
+                   "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[3][0]), "+v"(b[3][1]));
+#endif
+}
+
 constexpr int kWgPitch = 1024 + 64;
 constexpr int kWgRows = 32;
 constexpr int kWgStage = 2 * kWgRows * kWgPitch;
@@ -926,30 +934,32 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_bf16_kernel(
         __builtin_amdgcn_s_barrier();
         if (ch + 1 < nch) issue(ch + 1, (ch + 1) & 1);
         const unsigned char* st = smem + (ch & 1) * kWgStageB;
-#pragma unroll
-        for (int ks = 0; ks < kWgRowsB / 16; ++ks) {
+        const unsigned char* sa = st + a_off, *sb = st + b_off;
+        auto kstep = [&](auto KS) __attribute__((always_inline)) {          // (asm reads: see lds_read_tr16)
+            constexpr int ks = decltype(KS)::value;
+            s16x4 ah[2][2], bh[4][2];
+#define CPC_TR_A(tm) ah[tm][0] = lds_read_tr16<16 * ks * kWgPitch + tm * 64>(sa); ah[tm][1] = lds_read_tr16<16 * ks * kWgPitch + tm * 64 + 4 * kWgPitch>(sa)
+#define CPC_TR_B(tn) bh[tn][0] = lds_read_tr16<16 * ks * kWgPitch + tn * 64>(sb); bh[tn][1] = lds_read_tr16<16 * ks * kWgPitch + tn * 64 + 4 * kWgPitch>(sb)
+            CPC_TR_A(0); CPC_TR_A(1); CPC_TR_B(0); CPC_TR_B(1); CPC_TR_B(2); CPC_TR_B(3);
+#undef CPC_TR_A
+#undef CPC_TR_B
+            lds_wait_tr16(ah, bh);
             s16x8 af[2], bf[4];
-            const unsigned char* ra = st + a_off + 16 * ks * kWgPitch;
-            const unsigned char* rb = st + b_off + 16 * ks * kWgPitch;
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ra + tm * 64));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ra + tm * 64 + 4 * kWgPitch));
-                af[tm] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
+            for (int tm = 0; tm < 2; ++tm) af[tm] = __builtin_shufflevector(ah[tm][0], ah[tm][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(rb + tn * 64));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(rb + tn * 64 + 4 * kWgPitch));
-                bf[tn] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
+            for (int tn = 0; tn < 4; ++tn) bf[tn] = __builtin_shufflevector(bh[tn][0], bh[tn][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[tm]),
                                                                           __builtin_bit_cast(bf16x8, bf[tn]), acc[tm][tn], 0, 0, 0);
-        }
+        };
+        kstep(std::integral_constant<int, 0>());
+        kstep(std::integral_constant<int, 1>());
+        kstep(std::integral_constant<int, 2>());
+        kstep(std::integral_constant<int, 3>());
     }
     float* out = part + (long)z * kC * K + tap * kC;
 #pragma unroll

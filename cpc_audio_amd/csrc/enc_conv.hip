@@ -811,6 +811,7 @@ static int g_h2_layers = 0;  // 0 = by problem size; 1 / 2 / 4 = tuning / test o
 static int g_h2_all = 1;     // what "by problem size" means: 1 (default since round 4) = every layer reads H2 input; 0 = conv1 (conv2 at
                              // B >= ~100) only -- cpc_set_h2_layers(1 / 2) selects the round-3 behaviour explicitly
 static int g_force_bm = 0;   // 0 = choose by problem size; 32/64/128 = tuning / test override
+static int g_dma_layer2 = 0; // 1: layer 2 on the DMA-fed kernels whatever the batch (cpc_set_dma_layer2; by default from B ~ 100 on)
 static int g_small_bm = 32;  // rows of the small tile pick_bm() chooses below 32000 rows (cpc_set_conv_small_tile): 32 or 64
 static int g_small_pipe = 1; // 1: the 32- / 64-row tiles of the H2-fed register-staged kernels on the pipelined 16-k schedule (ConvCfg PIPE)
 static constexpr int g_unfuse_big = 2;   // 2: every dgrad runs unfused + streaming norm backward, 1: only the 128-row tiles,
@@ -837,7 +838,7 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     const int nh2 = g_mfma_mode != 3 ? 0 : (g_h2_layers ? g_h2_layers : (g_h2_all ? 4 : (big2 ? 2 : 1)));
     for (int i = 0; i < 4; ++i) e.h2[i] = i < nh2;
     e.dma[0] = false;
-    for (int i = 1; i < 5; ++i) e.dma[i] = e.h2[i - 1] && (i == 1 || (i == 2 && (nh2 == 2 || big2)));
+    for (int i = 1; i < 5; ++i) e.dma[i] = e.h2[i - 1] && (i == 1 || (i == 2 && (nh2 == 2 || big2 || g_dma_layer2)));
     // the gradient of a layer whose input is kept in H2 storage is kept so too: its data gradient reads the pieces as stored
     // (DMA kernel or AH2 tile), its weight gradient reads both operands as pieces by DMA
     for (int i = 0; i < 5; ++i) e.dxh2[i] = i >= 1 && g_h2_dx && e.h2[i - 1];
@@ -979,6 +980,10 @@ static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const flo
 extern "C" int cpc_set_conv_tile(int bm) {
     CPC_RETURN_IF(bm != 0 && bm != 32 && bm != 64 && bm != 128, CPC_ERR_ARG);
     g_force_bm = bm;
+    return 0;
+}
+extern "C" int cpc_set_dma_layer2(int on) {
+    g_dma_layer2 = on ? 1 : 0;
     return 0;
 }
 extern "C" int cpc_set_conv_small_tile(int bm) {

@@ -98,6 +98,7 @@ int cpc_set_h2_layers(int n);            /* mode 3, which layers read their inpu
                                             conv2, both on the DMA kernels; 4 = all four -- conv1 (conv2 from B ~ 100 on) on the DMA kernels, the
                                             short layers on the register-staged tiles, which stage H2 rows as they lie, and every weight
                                             gradient on the DMA + transposing-read kernel with one batched reduction; 0 = by problem size */
+int cpc_set_dma_layer2(int on);          /* 1: layer 2 (forward and data gradient) on the DMA-fed kernels whatever the batch size; 0 (default): from B ~ 100 on */
 int cpc_set_conv_small_tile(int bm);     /* rows per workgroup of the register-staged conv tiles below 32000 rows: 32 (default) or 64 */
 int cpc_set_conv_small_pipe(int on);     /* 1 (default): the 32- / 64-row tiles of the H2-fed register-staged conv kernels (cpc_set_h2_layers(4)) run the software-
                                             pipelined 16-k schedule of the 128-row tiles (four chunks of global loads in flight); 0: one 32-k stage */

@@ -75,12 +75,14 @@ def test_transformer_layer_matches_oracle_and_reference_fixture(case, golden_dir
     assert not bad, bad
 
 
-def test_config4_transformer_ar_and_predictors_train_step():
-    """Whole config-4 step: conv encoder -> transformer AR (S=128) -> 12 transformer predictors (S=116) -> InfoNCE."""
+@pytest.mark.parametrize("B", [3, 16])
+def test_config4_transformer_ar_and_predictors_train_step(B):
+    """Whole config-4 step: conv encoder -> transformer AR (S=128) -> 12 transformer predictors (S=116) -> InfoNCE, against the
+    oracle; B = 16 puts 2048 / 1856 rows through the projection and feed-forward GEMMs (other tile choices than B = 3's 384 / 348)."""
     dev = _dev()
     from cpc_audio_amd import ops
     from cpc_audio_amd.train import build_criterion, build_model
-    B, K, N = 3, 12, 128
+    K, N = 12, 128
     base = O.make_params(seed=9, head_scale=1.0)
     p = {k: v for k, v in base.items() if k.startswith("gEncoder.")}
     p.update(T.make_layer_params(31, 256, 128, False, prefix="gAR.0."))
