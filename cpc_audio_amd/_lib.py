@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcpc_hip.so")
 DEFAULT_GRU_MODE = 2       # cpc_set_gru_mode: persistent recurrence, forward products on the fp16 split
 DEFAULT_MFMA_MODE = 3      # what libcpc_hip starts in (cpc_set_mfma_mode): mode 2's arithmetic (two fp16 pieces, 3 MFMAs per
 #                            product) with conv1 / its gradients on the DMA-fed kernels reading H2-stored activations
-EXPECTED_ABI = 10          # cpc_abi_version() of the library these signatures were written for: a stale or variant build that
+EXPECTED_ABI = 11          # cpc_abi_version() of the library these signatures were written for: a stale or variant build that
 #                            exports every symbol with OLDER argument lists would corrupt memory instead of raising -- bind() refuses it
 DEFAULT_DMA_PIPELINE = 2
 DEFAULT_WGRAD_DMA_STAGES = 4   # cpc_set_wgrad_dma_stages
@@ -89,6 +89,8 @@ SIGNATURES = {
     "cpc_gru_layout": (_I, [_I, _I, _I, _P]),
     "cpc_gru_forward": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "cpc_gru_forward_coef": (_I, [_P] * 8 + [_I, _I, _I, _P]),
+    "cpc_gru_forward_prepare": (_I, [_P, _I, _I, _I, _P]),
+    "cpc_gru_forward_coef_prepared": (_I, [_P] * 8 + [_I, _I, _I, _P]),
     "cpc_gru_backward": (_I, [_P] * 9 + [_I, _I, _I, _P]),
     "cpc_gru_coef_floats": (_L, [_I, _I, _I]),
     "cpc_gru_backward_coef": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
@@ -99,6 +101,9 @@ SIGNATURES = {
     "cpc_nce_forward": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
     "cpc_nce_forward_prepared": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
     "cpc_nce_bounds": (_I, [_P, ctypes.c_float, _P, _P, _I, _I, _I, _I, _P]),
+    "cpc_nce_forward_streams": (_I, [_P] * 8 + [_I, _I, _I, _I, _I, _P, _P]),
+    "cpc_nce_backward_prepare": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
+    "cpc_nce_backward_prepared": (_I, [_P] * 10 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward": (_I, [_P] * 12 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward_streams": (_I, [_P] * 12 + [_I, _I, _I, _I, _P, _P]),
     "cpc_nce_backward_dz": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),

@@ -50,7 +50,7 @@ extern "C" int cpc_release_stream(void* stream) {
     return 0;
 }
 
-extern "C" int cpc_abi_version(void) { return 10; }
+extern "C" int cpc_abi_version(void) { return 11; }
 
 // Device-side error flags of the current device, accumulated since they were last cleared:
 //   bit 0  CPC_DEVERR_GRU_POLL_TIMEOUT   a workgroup of the persistent recurrence gave up waiting for another one (its

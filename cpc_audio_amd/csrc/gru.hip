@@ -1089,8 +1089,28 @@ extern "C" int cpc_gru_forward(const float* x, const float* h0, const float* con
 // coef != NULL (nl == 2; cpc_gru_coef_floats floats): the eight coefficient arrays of the two-layer backward are filled on the way
 // -- by the persistent forward's gate threads where that path runs, by gru_bwd_coef_kernel behind the forward otherwise --
 // and cpc_gru_backward_coef(..., coef_done = 1) only has the hand-over buffers and the weight transposes left to prepare.
+static int gru_forward_impl(const float* x, const float* h0, const float* const* params, float* saved, float* scratch, float* y,
+                            float* hN, float* coef, int B, int S, int nl, void* stream, bool xh_ready);
 extern "C" int cpc_gru_forward_coef(const float* x, const float* h0, const float* const* params, float* saved,
                                     float* scratch, float* y, float* hN, float* coef, int B, int S, int nl, void* stream) {
+    return gru_forward_impl(x, h0, params, saved, scratch, y, hN, coef, B, S, nl, stream, false);
+}
+// The forward's only activation-independent launch -- the "not written yet" fill of the persistent recurrence's hand-over
+// buffers in `scratch` -- ahead of time on any stream; cpc_gru_forward_coef_prepared (on a stream that has waited for it) then
+// goes from the input projection straight into the recurrence.  nl == 2.
+extern "C" int cpc_gru_forward_prepare(float* scratch, int B, int S, int nl, void* stream) {
+    GruLayout g;
+    CPC_RETURN_IF(nl != 2 || !gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!scratch, CPC_ERR_ARG);
+    if (hipMemsetAsync(scratch + g.xh, 0xFF, 2 * g.xh_floats * sizeof(float), (hipStream_t)stream) != hipSuccess) return CPC_ERR_ARG;
+    return 0;
+}
+extern "C" int cpc_gru_forward_coef_prepared(const float* x, const float* h0, const float* const* params, float* saved,
+                                             float* scratch, float* y, float* hN, float* coef, int B, int S, int nl, void* stream) {
+    return gru_forward_impl(x, h0, params, saved, scratch, y, hN, coef, B, S, nl, stream, true);
+}
+static int gru_forward_impl(const float* x, const float* h0, const float* const* params, float* saved, float* scratch, float* y,
+                            float* hN, float* coef, int B, int S, int nl, void* stream, bool xh_ready) {
     GruLayout g;
     CPC_RETURN_IF(!gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!x || !params || !saved || !scratch || !y || !hN, CPC_ERR_ARG);
@@ -1127,7 +1147,7 @@ extern "C" int cpc_gru_forward_coef(const float* x, const float* h0, const float
         if (nblocks > 0) {
             p.xh[0] = scratch + g.xh; p.xh[1] = scratch + g.xh + g.xh_floats;
             if (coef) { p.coef[0] = coef; p.coef[1] = coef + 4 * g.frag_floats; }
-            if (hipMemsetAsync(p.xh[0], 0xFF, 2 * g.xh_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+            if (!xh_ready && hipMemsetAsync(p.xh[0], 0xFF, 2 * g.xh_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
             for (p.tile0 = 0; p.tile0 < p.total_tiles; p.tile0 += p.ntiles) {
                 if (h2) hipLaunchKernelGGL(gru2_persist_fwd_h2_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
                 else hipLaunchKernelGGL(gru2_persist_fwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);

@@ -715,11 +715,20 @@ static RowMap window_rows(const float* c, int B, int S, int W) {     // rows (b,
 
 // scores, log-softmax, per-head loss / accuracy from given predictions
 static int nce_scores_forward(const NceLayout& n, const float* pred, const float* z, const int* ext, float* saved,
-                              float* scratch, float* losses, float* acc, int S, int K, int N, hipStream_t st) {
+                              float* scratch, float* losses, float* acc, int S, int K, int N, hipStream_t st,
+                              hipStream_t fin = nullptr) {
+    // fin (nullptr: st): the stream the loss / accuracy reduction runs on.  Nothing of the backward reads its results (the
+    // score gradients come from the saved logits), so a caller that joins `fin` later takes 15 us off its critical path.
     unsigned* ticket = reinterpret_cast<unsigned*>(scratch + n.sums + 32);
     hipLaunchKernelGGL(nce_fwd_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
                        saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket);
     CPC_LAUNCH_CHECK();
+    if (fin != nullptr && fin != st) {
+        hipEvent_t* ev = stream_events(st);
+        CPC_RETURN_IF(!ev, CPC_ERR_ARG);
+        CPC_RETURN_IF(hipEventRecord(ev[10], st) != hipSuccess || hipStreamWaitEvent(fin, ev[10], 0) != hipSuccess, CPC_ERR_ARG);
+        st = fin;
+    }
     {                                                   // 2 K <= 32 columns (nce_layout): rows_sum's groups and order of additions
         int groups = n.BW > 64 ? kRowsSumGroups : 1;
         const int rpg = cdiv(n.BW, groups);
@@ -770,10 +779,12 @@ static int nce_dz_linear_path(const NceLayout& n, const float* c, const float* w
 // dPred (and, for the linear heads, the dS rows of the re-associated dz path) from the upstream per-head gradients.
 static int nce_scores_backward(const NceLayout& n, const float* z, const int* ext, const float* saved, const float* gloss,
                                float* scratch, float* dpred, int B, int S, int K, int N, hipStream_t st,
-                               const float* fwd_bounds = nullptr, float* dc_tail = nullptr, float* dS = nullptr) {
+                               const float* fwd_bounds = nullptr, float* dc_tail = nullptr, float* dS = nullptr,
+                               bool gscale_done = false) {
     const float* logits = saved + n.logits, *lse = saved + n.lse;
     float* gscale = scratch + n.gscale;
     const float gs = 1.0f / ((float)n.BW * (float)kC);
+    if (!gscale_done)      // (else: cpc_nce_backward_prepare ran it, on a stream this one has waited for)
     hipLaunchKernelGGL(nce_gscale_kernel, dim3(dc_tail ? 1 + 128 : 1), dim3(64), 0, st, gloss, gscale, K, gs, fwd_bounds, dc_tail, B,
                        S, n.W);
     hipLaunchKernelGGL(nce_bwd_dpred_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
@@ -833,7 +844,8 @@ extern "C" int cpc_nce_prepare(const long* batchIdx, const long* seqIdx, int* ex
 // ext (B*W, N) int32 rows into z.view(B*S,256) [i.e. criterion.py:199's extIdx laid out (b,t,n)].
 // losses, acc: K floats each (criterion.py:256-257).
 static int nce_forward(const float* c, const float* z, const float* wall, const int* ext, float* saved, float* scratch,
-                       float* losses, float* acc, int B, int S, int K, int N, hipStream_t st, bool bounds_ready) {
+                       float* losses, float* acc, int B, int S, int K, int N, hipStream_t st, bool bounds_ready,
+                       hipStream_t fin = nullptr) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!c || !z || !wall || !ext || !saved || !scratch || !losses || !acc, CPC_ERR_ARG);
@@ -851,7 +863,7 @@ static int nce_forward(const float* c, const float* z, const float* wall, const 
     gb.b = saved + n.bounds + kAmaxSlots; gb.b_slots = kAmaxSlots;
     int rc = nt_gemm(window_rows(c, B, S, n.W), wall, kC, nullptr, pred, (long)K * kC, K * kC, kC, st, 0, 0, gb);
     if (rc) return rc;
-    return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, st);
+    return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, st, fin);
 }
 
 extern "C" int cpc_nce_forward(const float* c, const float* z, const float* wall, const int* ext, float* saved,
@@ -880,6 +892,31 @@ extern "C" int cpc_nce_forward_prepared(const float* c, const float* z, const fl
                                         float* scratch, float* losses, float* acc, int B, int S, int K, int N,
                                         void* stream) {
     return nce_forward(c, z, wall, ext, saved, scratch, losses, acc, B, S, K, N, (hipStream_t)stream, true);
+}
+
+// cpc_nce_forward / cpc_nce_forward_prepared (bounds_ready != 0) with the loss / accuracy reduction on `finalize_stream`
+// (ordered behind the scoring kernel by an event; the caller joins that stream before anybody reads losses / acc).
+extern "C" int cpc_nce_forward_streams(const float* c, const float* z, const float* wall, const int* ext, float* saved,
+                                       float* scratch, float* losses, float* acc, int B, int S, int K, int N, int bounds_ready,
+                                       void* stream, void* finalize_stream) {
+    return nce_forward(c, z, wall, ext, saved, scratch, losses, acc, B, S, K, N, (hipStream_t)stream, bounds_ready != 0,
+                       (hipStream_t)finalize_stream);
+}
+
+// The weight- and bound-only share of cpc_nce_backward_streams, ahead of time on any stream that has seen cpc_nce_bounds:
+// the per-head gradient scales from gloss, the GEMM operand bounds, the cleared max|dPred| / max|G| slots, the zeroed tail of
+// dc, and wall^T.  cpc_nce_backward_prepared then starts with the score-gradient kernel.
+extern "C" int cpc_nce_backward_prepare(const float* wall, const float* saved, const float* gloss, float* scratch, float* dc,
+                                        int B, int S, int K, int N, void* stream) {
+    NceLayout n;
+    CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!wall || !saved || !gloss || !scratch || !dc, CPC_ERR_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    const bool h2 = g_mfma_mode >= 2;
+    hipLaunchKernelGGL(nce_gscale_kernel, dim3(1 + 128), dim3(64), 0, st, gloss, scratch + n.gscale, K,
+                       1.0f / ((float)n.BW * (float)kC), h2 ? saved + n.bounds : (const float*)nullptr, dc, B, S, n.W);
+    CPC_LAUNCH_CHECK();
+    return transpose(wall, scratch + n.wallT, K * kC, kC, st);
 }
 
 // Same criterion on predictions computed by the caller (any prediction network, e.g. --rnnMode transformer):
@@ -931,10 +968,25 @@ extern "C" int cpc_nce_backward_dz(const float* c, const float* wall, const int*
 // As cpc_nce_backward, with the dz path launched on `dz_stream` behind an event recorded on `stream` once the score
 // gradients are written (the rest of dz_stream's ordering -- every consumer of dz waits for it -- is the caller's
 // business); dz == NULL leaves the dz path out altogether (cpc_nce_backward_dz runs it later).
+static int nce_backward_impl(const float* c, const float* z, const float* wall, const int* ext, const int* perm,
+                             const int* row_ptr, const float* saved, const float* gloss, float* scratch, float* dc, float* dz,
+                             float* dwall, int B, int S, int K, int N, void* stream, void* dz_stream, bool prepared);
 extern "C" int cpc_nce_backward_streams(const float* c, const float* z, const float* wall, const int* ext,
                                         const int* perm, const int* row_ptr, const float* saved, const float* gloss,
                                         float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K,
                                         int N, void* stream, void* dz_stream) {
+    return nce_backward_impl(c, z, wall, ext, perm, row_ptr, saved, gloss, scratch, dc, dz, dwall, B, S, K, N, stream, dz_stream, false);
+}
+// cpc_nce_backward_streams(dz = NULL, dwall = NULL) behind a cpc_nce_backward_prepare of the same step: score gradients, dPred
+// and dc on `stream`; the dz path and the heads' gradient follow through cpc_nce_backward_dz / _dwall.
+extern "C" int cpc_nce_backward_prepared(const float* c, const float* z, const float* wall, const int* ext, const int* perm,
+                                         const int* row_ptr, const float* saved, const float* gloss, float* scratch, float* dc,
+                                         int B, int S, int K, int N, void* stream) {
+    return nce_backward_impl(c, z, wall, ext, perm, row_ptr, saved, gloss, scratch, dc, nullptr, nullptr, B, S, K, N, stream, stream, true);
+}
+static int nce_backward_impl(const float* c, const float* z, const float* wall, const int* ext, const int* perm,
+                             const int* row_ptr, const float* saved, const float* gloss, float* scratch, float* dc, float* dz,
+                             float* dwall, int B, int S, int K, int N, void* stream, void* dz_stream, bool prepared) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc, CPC_ERR_ARG);
@@ -942,7 +994,7 @@ extern "C" int cpc_nce_backward_streams(const float* c, const float* z, const fl
     float* dpred = scratch + n.dpred, *wallT = scratch + n.wallT;
     const bool h2 = g_mfma_mode >= 2;        // the forward left the operand bounds in `saved`
     int rc = nce_scores_backward(n, z, ext, saved, gloss, scratch, dpred, B, S, K, N, st, h2 ? saved + n.bounds : nullptr, dc,
-                                 scratch + n.dS);
+                                 scratch + n.dS, prepared);
     if (rc) return rc;
     if (dz != nullptr) {
         if (st_dz != st) {
@@ -960,7 +1012,7 @@ extern "C" int cpc_nce_backward_streams(const float* c, const float* z, const fl
         gdc.b = bnd + 18; gdw.b = bnd + 17;
     }
     // dc[:, :W] = dPred . Wall  (NT against Wall^T [256][K*256])
-    rc = transpose(wall, wallT, K * kC, kC, st);
+    if (!prepared) rc = transpose(wall, wallT, K * kC, kC, st);
     if (rc) return rc;
     SplitK sk;                           // N = 256: 58 row tiles at B = 64; the head gradient's partial buffer is free until it
     sk.part = scratch + n.part;          // starts (behind this GEMM, on either stream)

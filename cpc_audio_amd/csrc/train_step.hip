@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a,
 int g_prep_point = 1;     // where the criterion's index preparation is released on the side stream: 0 step begin (beside conv0: the one
                           // HBM-bound layer goes from 50 to 96 us), 1 (default) behind conv0 (beside conv1 / conv2: +20 us there),
                           // 2 behind the encoder (beside the recurrence, whose hand-over it disturbs)
+int g_no_early = 0;
 int g_dz_early = 0;       // 1: the dz path on MAIN before the recurrence's backward (which then has the memory system to itself)
                           // instead of beside it on the side stream
 
@@ -82,9 +83,10 @@ void enc_set_after_conv0_event(hipEvent_t ev);
 using namespace cpc;
 
 extern "C" int cpc_set_step_schedule(int prep_point, int dz_early) {
-    CPC_RETURN_IF(prep_point < 0 || prep_point > 2 || dz_early < 0 || dz_early > 1, CPC_ERR_ARG);
+    CPC_RETURN_IF(prep_point < 0 || prep_point > 2 || dz_early < 0 || dz_early > 3, CPC_ERR_ARG);
     g_prep_point = prep_point;
-    g_dz_early = dz_early;
+    g_dz_early = dz_early & 1;
+    g_no_early = (dz_early >> 1) & 1;      // + 2: the small weight-only launches stay on the main stream where round 3 had them (A/B)
     return 0;
 }
 
@@ -111,7 +113,8 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
     hipEvent_t* pool = stream_events(M);
     CPC_RETURN_IF(!pool, CPC_ERR_ARG);
     hipEvent_t* ev = pool + 12;     // [0] begin, [1] index lists + bounds ready, [2] recurrence-backward preparation ready,
-                                    // [3] score gradients ready, [4] dz done, [5] head gradient done, [6] conv0 launched / encoder done
+                                    // [3] score gradients ready, [4] dz done, [5] head gradient done, [6] conv0 launched / encoder done,
+                                    // [7] forward recurrence's hand-over buffers filled
     float* ws = workspace;
     const float* const* enc_p = params;
     const float* const* gru_p = params + kEncParams;
@@ -132,10 +135,21 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
         // the step begins here on main: the other streams fork from this point (the workspace is the previous step's, whose
         // last users main has waited for)
         CPC_RETURN_IF(!rec(ev[0], M) || !wait(S1, ev[0]), CPC_ERR_ARG);
+        // the hand-over buffers of the forward recurrence pre-filled beside the encoder instead of between the input projection
+        // and the recurrence
+        rc = cpc_gru_forward_prepare(ws + s.gru_fscr, B, S, 2, S1);
+        if (rc) return rc;
+        CPC_RETURN_IF(!rec(ev[7], S1), CPC_ERR_ARG);
+        const bool bounds_early = c_bound > 0.f;
+        const bool early = bounds_early && !g_no_early;      // the criterion's operand bounds do not depend on c: its backward's weight-only share too
         auto prepare = [&]() -> int {      // index lists of the draws + operand bounds of the prediction GEMMs: depend on no activation
             int r = batchIdx ? cpc_nce_prepare(batchIdx, seqIdx, ext, perm, row_ptr, work, B, S, K, N, S0) : 0;
             if (r) return r;
-            if (c_bound > 0.f) r = cpc_nce_bounds(nullptr, c_bound, wall, ws + s.nce_saved, B, S, K, N, S0);
+            if (bounds_early) r = cpc_nce_bounds(nullptr, c_bound, wall, ws + s.nce_saved, B, S, K, N, S0);
+            if (r) return r;
+            // ... and what the criterion's backward needs of the weights and of gloss alone (gradient scales, GEMM bounds, cleared
+            // maximum slots, the zeroed tail of dc, wall^T): three small launches off the chain criterion -> recurrence
+            if (early) r = cpc_nce_backward_prepare(wall, ws + s.nce_saved, gloss, ws + s.nce_bscr, dc, B, S, K, N, S0);
             if (r) return r;
             return rec(ev[1], S0) ? 0 : CPC_ERR_ARG;
         };
@@ -154,20 +168,25 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
             CPC_RETURN_IF(!rec(ev[6], M) || !wait(S0, ev[6]), CPC_ERR_ARG);
             if ((rc = prepare())) return rc;
         }
-        rc = cpc_gru_forward_coef(z, h0, gru_p, ws + s.gru_saved, ws + s.gru_fscr, c, hN, coef, B, S, 2, M);
+        CPC_RETURN_IF(!wait(M, ev[7]), CPC_ERR_ARG);
+        rc = cpc_gru_forward_coef_prepared(z, h0, gru_p, ws + s.gru_saved, ws + s.gru_fscr, c, hN, coef, B, S, 2, M);
         if (rc) return rc;
         // what the recurrence's backward needs beyond the coefficients the forward writes on its way (weight transposes,
         // hand-over buffers: disjoint parts of `coef`) depends on the parameters only: beside the forward, on its own stream
         rc = cpc_gru_backward_coef(h0, gru_p, ws + s.gru_saved, c, coef, 1, B, S, 2, S1);
         if (rc) return rc;
         CPC_RETURN_IF(!rec(ev[2], S1) || !wait(M, ev[1]), CPC_ERR_ARG);
-        rc = c_bound > 0.f ? cpc_nce_forward_prepared(c, z, wall, ext, ws + s.nce_saved, ws + s.nce_fscr, losses, acc, B, S, K, N, M)
-                           : cpc_nce_forward(c, z, wall, ext, ws + s.nce_saved, ws + s.nce_fscr, losses, acc, B, S, K, N, M);
+        // (the loss / accuracy reduction runs on the side stream: the backward reads the saved logits, not the losses; the side
+        // stream is joined before the step ends)
+        rc = cpc_nce_forward_streams(c, z, wall, ext, ws + s.nce_saved, ws + s.nce_fscr, losses, acc, B, S, K, N, bounds_early ? 1 : 0, M,
+                                     early ? S0 : M);
         if (rc) return rc;
         // ---- backward ----
         // criterion: score gradients, dPred and dc on main; the dz path and the heads' weight gradient are held back
-        rc = cpc_nce_backward_streams(c, z, wall, ext, perm, row_ptr, ws + s.nce_saved, gloss, ws + s.nce_bscr, dc, nullptr,
-                                      nullptr, B, S, K, N, M, M);
+        rc = early ? cpc_nce_backward_prepared(c, z, wall, ext, perm, row_ptr, ws + s.nce_saved, gloss, ws + s.nce_bscr, dc, B, S, K,
+                                               N, M)
+                   : cpc_nce_backward_streams(c, z, wall, ext, perm, row_ptr, ws + s.nce_saved, gloss, ws + s.nce_bscr, dc, nullptr,
+                                              nullptr, B, S, K, N, M, M);
         if (rc) return rc;
         if (g_dz_early) {
             rc = cpc_nce_backward_dz(c, wall, perm, row_ptr, ws + s.nce_bscr, dz, B, S, K, N, M);

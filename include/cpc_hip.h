@@ -252,6 +252,13 @@ int cpc_gru_backward_with_coef(const float* x, const float* h0, const float* con
                                const float* y, const float* dy, const float* coef, float* scratch, float* dx,
                                float* const* grads, int B, int S, int nl, void* stream);
 
+/* cpc_gru_forward_coef split for callers that keep launches off their critical stream: cpc_gru_forward_prepare fills the
+ * persistent recurrence's hand-over buffers in `scratch` (the forward's only activation-independent launch) on any stream;
+ * cpc_gru_forward_coef_prepared, on a stream that has waited for it, skips that fill.  nl == 2. */
+int cpc_gru_forward_prepare(float* scratch, int B, int S, int nl, void* stream);
+int cpc_gru_forward_coef_prepared(const float* x, const float* h0, const float* const* params, float* saved, float* scratch,
+                                  float* y, float* hN, float* coef, int B, int S, int nl, void* stream);
+
 /* As cpc_gru_backward_with_coef, with the weight and bias gradients (what only the optimiser reads) on
  * `wgrad_stream`, released by an event behind the recurrence; dx stays on `stream`.  There is NO join: the caller
  * orders every consumer of `grads` after `wgrad_stream` and keeps `scratch` alive until then.  (nl == 2; other depths
@@ -327,6 +334,21 @@ int cpc_nce_forward(const float* c, const float* z, const float* wall, const int
 int cpc_nce_bounds(const float* c, float c_bound, const float* wall, float* saved, int B, int S, int K, int N, void* stream);
 int cpc_nce_forward_prepared(const float* c, const float* z, const float* wall, const int* ext, float* saved,
                              float* scratch, float* losses, float* acc, int B, int S, int K, int N, void* stream);
+/* cpc_nce_forward (bounds_ready == 0) / cpc_nce_forward_prepared (!= 0) with the loss / accuracy reduction on finalize_stream,
+ * ordered behind the scoring kernel by an event: the backward reads the saved logits, never the losses, so a caller that joins
+ * finalize_stream before reading losses / acc keeps that launch off its critical stream. */
+int cpc_nce_forward_streams(const float* c, const float* z, const float* wall, const int* ext, float* saved, float* scratch,
+                            float* losses, float* acc, int B, int S, int K, int N, int bounds_ready, void* stream,
+                            void* finalize_stream);
+/* The share of the backward that depends on the weights, the operand bounds in `saved` (cpc_nce_bounds) and gloss only --
+ * gradient scales, GEMM operand bounds, cleared maximum slots, the zeroed tail rows of dc, wall^T -- ahead of time on any stream
+ * that has seen cpc_nce_bounds; cpc_nce_backward_prepared, on a stream that has waited for it, is then
+ * cpc_nce_backward_streams(dz = NULL, dwall = NULL) without those launches (cpc_nce_backward_dz / _dwall follow as usual). */
+int cpc_nce_backward_prepare(const float* wall, const float* saved, const float* gloss, float* scratch, float* dc, int B, int S,
+                             int K, int N, void* stream);
+int cpc_nce_backward_prepared(const float* c, const float* z, const float* wall, const int* ext, const int* perm,
+                              const int* row_ptr, const float* saved, const float* gloss, float* scratch, float* dc, int B,
+                              int S, int K, int N, void* stream);
 /* gloss: K upstream gradients dL/dloss_k.  dc, dz (B,S,256) and dwall are overwritten.
  * perm (B*W*(N+K)) / row_ptr (B*S+1): candidate slots sorted by destination row of z (slot =
  * (b*W+t)*(N+K)+j; j<N: negative j -> row ext[..j]; j>=N: positive of head j-N -> row b*S+t+j-N+1);
