@@ -168,3 +168,28 @@ def test_a_hidden_state_assigned_from_outside_drops_the_a_priori_bound():
         torch.cuda.synchronize()
         assert torch.isfinite(l).all()
         assert (l.cpu() - ora["losses"]).abs().max().item() < 2e-4 * max(1.0, ora["losses"].abs().max().item()), fused
+
+
+@pytest.mark.parametrize("B", [128, 256])
+def test_composite_step_equals_the_autograd_step_at_the_large_per_gpu_batches(B):
+    """BASELINE configs[2] is B = 256 per GPU: the recurrence runs as two persistent launches over 8 batch tiles each, layer 2 moves
+    to the DMA-fed kernels (from B ~ 100 on), the weight-gradient plans change.  Two optimiser steps, composite against autograd:
+    bit for bit."""
+    dev = _dev()
+    p = O.make_params(seed=36, head_scale=64.0)
+    wave = O.make_waveform(B, 20480, seed=90).to(dev)
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    res = []
+    for fused in (False, True):
+        tr, model, crit = _trainer(p, dev, fused)
+        torch.manual_seed(321)
+        losses = [torch.cat(tr.step(wave, label)).cpu() for _ in range(2)]
+        torch.cuda.synchronize()
+        from cpc_audio_amd import ops
+        ops.check_device_errors()
+        res.append((torch.stack(losses), _state(model, crit)))
+        del tr, model, crit
+        torch.cuda.empty_cache()
+    assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
