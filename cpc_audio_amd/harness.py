@@ -75,6 +75,7 @@ def build_scheduler(optimizer, scheduler_step=-1, scheduler_ramp=None):
     return scheduler
 
 
+COMPOSITE_STEP = True          # train_epoch: forward + backward through cpc_train_step where it applies (False: always autograd)
 PREPARE_CRITERION = True       # A/B switch (tools/ab_step.py "harness.PREPARE_CRITERION" True False)
 
 
@@ -131,12 +132,41 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
     step_ctx = ops.StepContext(overlap=True)
     if allreduce is not None:
         step_ctx.pre_encoder_backward.append(allreduce.begin)
+    # Forward + backward through one C call where the configuration is the one the composite covers (train.CompositeStep:
+    # CPCEncoder + 2-layer GRU + linear heads, everything trainable) -- same kernels in the same order, bit-identical results,
+    # a third of the host time; its gradients live in a flat buffer (the all-reduce's, or a private one without a process
+    # group).  Anything else takes the autograd-driven path below.
+    from .dist import FlatGradAllReduce
+    from .train import CompositeStep
+    flat = allreduce
+    if flat is None and device.type == "cuda":
+        flat = FlatGradAllReduce([p for g in optimizer.param_groups for p in g["params"]])
+    composite = CompositeStep(model, criterion, step_ctx, flat) if flat is not None else None
     in_flight = []                                        # at most two steps ahead of the GPU (train.Trainer.MAX_IN_FLIGHT)
     for step, (batch, label) in enumerate(loader):
         batch, label = _to_device(batch, device), _to_device(label, device)
         n_ex += batch.size(0)
         if device.type == "cuda" and len(in_flight) >= 2:
             in_flight.pop(0).synchronize()
+        if composite is not None and COMPOSITE_STEP and composite.ok(batch):
+            all_losses, all_acc = composite.forward_backward(batch)
+            if allreduce is not None:
+                allreduce()
+            optimizer.step()
+            optimizer.zero_grad()
+            in_flight.append(torch.cuda.Event())
+            in_flight[-1].record()
+            with torch.no_grad():
+                l, a = all_losses.mean(dim=0), all_acc.mean(dim=0)
+                sum_loss = l if sum_loss is None else sum_loss + l
+                sum_acc = a if sum_acc is None else sum_acc + a
+            n_iter += 1
+            if verbose and (step + 1) % logging_step == 0:
+                el = time.perf_counter() - t0
+                print(f"Update {step + 1}: {1000.0 * el / logging_step:.1f} ms per batch, "
+                      f"{1000.0 * el / n_ex:.2f} ms / example, loss {float((sum_loss / n_iter).mean()):.4f}")
+                t0, n_ex = time.perf_counter(), 0
+            continue
         try:
             with step_ctx as sc:                          # side streams for the dz path / weight gradients (ops.StepContext)
                 prepare_criterion(sc, model, criterion, batch)

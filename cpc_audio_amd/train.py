@@ -37,76 +37,23 @@ def load_flat_params(model, criterion, params):
     criterion.load_state_dict({k: v for k, v in params.items() if k.startswith("wPrediction")}, strict=True)
 
 
-class Trainer:
-    """``graph=True`` (single GPU): the whole step -- forward, backward on all streams, Adam, zero_grad -- is captured
-    ONCE as a HIP graph and replayed with one launch per step.  The step is ~70 kernel launches on four streams issued from
-    Python (3-5 ms of host time per step, measured, against 3.9 ms of GPU time): on a slow or busy host the eager loop is
-    host-bound, the replayed graph is not.  Static shapes only (a new batch shape re-captures); ``negatives`` supplied by
-    the caller, a learning-rate change or world_size > 1 fall back to the eager step."""
+class CompositeStep:
+    """Forward + backward of the north-star configuration through ONE C call (cpc_train_step, csrc/train_step.hip) on the four
+    streams of an ops.StepContext, with the gradients written straight into the flat buffer of a dist.FlatGradAllReduce
+    (``p.grad`` become views of it) -- what train.Trainer and harness.train_epoch run wherever ``ok()`` says the configuration
+    is the one the composite covers; both fall back to the autograd-driven path otherwise.  ``forward_backward`` leaves every
+    gradient final on the current stream (in a process group: with the early bucket's all-reduce started; the caller's
+    ``allreduce()`` finishes the exchange) and returns (losses (1, K), accuracies (1, K)) as fresh tensors."""
 
-    AUTO_PROBE_STEPS = 6      # graph="auto": eager steps timed (host enqueue time vs GPU time) before deciding
+    def __init__(self, model, criterion, ctx, allreduce):
+        self.model, self.criterion, self.ctx, self.allreduce = model, criterion, ctx, allreduce
+        self.tables = None                # pointer tables / workspace of the last batch shape
 
-    def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, graph=False, check_errors_every=256,
-                 fused=True, prefetch_negatives=False):
-        """check_errors_every: every that many steps the device-side error flags are read (ops.check_device_errors: a
-        recurrence workgroup that gave up polling, a negative index out of range) and turned into an exception -- one device
-        synchronisation per that many steps; 0 leaves the check to the caller.
-        graph: False (eager), True (HIP graph replay), or "auto": the first steps run eagerly and are timed; the graph is
-        used only if the host needs more than 60 % of the GPU's step time to issue a step.  (Measured on MI355X boxes: the
-        replayed graph costs 0.24 ms of host time per step instead of 1.5-5 ms and runs within 0.5 % of the eagerly issued
-        streams on the GPU -- a win as soon as the host is not comfortably ahead, see _step.)"""
-        """fused (default True): where the configuration is the north-star one -- CPCEncoder + 2-layer GRU CPCAR + linear
-        heads, every parameter trainable -- forward and backward of a step are issued by ONE C call (cpc_train_step, csrc/
-        train_step.hip: the same entry points in the same order on the same four streams, bit-identical results) into a
-        persistent workspace, with the gradients written straight into the flat all-reduce buffer; anything else (transformer
-        AR / predictors, criterion mode 'reverse', frozen parameters) runs the autograd path below."""
-        self.model, self.criterion = model, criterion
-        self.fused = bool(fused)
-        # composite step only, off by default: draw the NEXT step's negatives and prepare their index lists at the end of a step
-        # (beside its tail: layer 1's weight gradient alone on the matrix pipes) instead of behind conv0 of the next one.  The
-        # draws come from torch's generator in the same order either way -- the A/B's losses are equal to the last digit --; only
-        # code that draws from the same generator BETWEEN two train steps (a validation pass) would see them one step early.
-        # Measured neutral (2.880 vs 2.883 ms per step sustained, three alternations: what the preparation costs conv1 / conv2
-        # at the start of a step it costs the weight gradient at the end), so the reference's draw-inside-the-step order stays.
-        # CPC_PREFETCH_NEGATIVES=1 / 0 overrides (A/B runs).
-        import os
-        env = os.environ.get("CPC_PREFETCH_NEGATIVES")
-        self.prefetch_negatives = bool(prefetch_negatives) if env is None else env == "1"
-        self._fused = None                # cached pointer tables / workspace of the composite step
-        params = list(criterion.parameters()) + list(model.parameters())      # train.py:332
-        self.optimizer = Adam(params, lr=lr, betas=betas, eps=eps)      # train.py:335-337; one launch per step on the GPU
-        enc = {id(p) for p in model.gEncoder.parameters()} if hasattr(model, "gEncoder") else set()
-        self.allreduce = FlatGradAllReduce(params, early=[p for p in params if id(p) not in enc] if enc else None)
-        from . import ops
-        self.ctx = ops.StepContext(overlap=True)
-        self.ctx.pre_encoder_backward.append(self.allreduce.begin)
-        self.graph = True if graph is True else ("auto" if graph == "auto" else False)
-        self._probe = []                  # graph="auto": (host seconds, start event, end event) of the first eager steps
-        self._captured = None             # (key, CUDAGraph, static input, static label, static outputs)
-        self._capturing = False           # inside capture(): no host-side throttle, no completion events (see _eager_step)
-        self._done_events = []
-        self.check_errors_every = int(check_errors_every)
-        self._steps = 0
-
-    def _ones_like(self, t):
-        o = getattr(self, "_ones", None)
-        if o is None or o.shape != t.shape or o.device != t.device or o.dtype != t.dtype:
-            o = self._ones = torch.ones_like(t)
-        return o
-
-    # Eager steps in flight.  The host issues a step in ~1.5 ms, the GPU runs it in 3.4: unchecked, the host runs ahead until
-    # the stream's queue pushes back, every step in flight holds its own workspaces (blocks used on a side stream return
-    # to torch's allocator only when that stream has passed them), and the allocator keeps asking the driver for more --
-    # measured at B = 128: 27 hipMalloc calls in 10 steps after warm-up, steps of 6 ms with stalls to 9-17 ms, reserved
-    # memory still growing.  Two steps ahead keep the GPU fed and bound both.
-    MAX_IN_FLIGHT = 2
-
-    # ---- the composite step (cpc_train_step) ---------------------------------------------------------------------------
-    def _fused_ok(self, batchData, negatives):
+    def ok(self, batchData, negatives=None):
         from . import ops
         from .model import CPCAR, CPCEncoder, CPCModel
         m, cr = self.model, self.criterion
-        if not (self.fused and torch.is_tensor(batchData) and batchData.is_cuda and batchData.dtype == torch.float32
+        if not (torch.is_tensor(batchData) and batchData.is_cuda and batchData.dtype == torch.float32
                 and batchData.dim() == 3 and batchData.shape[1] == 1 and torch.is_grad_enabled() and not ops.KEEP_DEBUG):
             return False
         if not (isinstance(m, CPCModel) and isinstance(m.gEncoder, CPCEncoder) and isinstance(m.gAR, CPCAR)
@@ -117,10 +64,12 @@ class Trainer:
             return False
         if negatives is not None and not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int64 for t in negatives):
             return False
-        return all(p.requires_grad and p.is_cuda and p.dtype == torch.float32 for p in self.allreduce.params) \
-            and len(self.allreduce.params) == 20 + 8 + cr.nPredicts
+        ps = self.allreduce.params
+        own = {id(p) for p in list(cr.parameters()) + list(m.parameters())}
+        return (len(ps) == 20 + 8 + cr.nPredicts and all(id(p) in own for p in ps)
+                and all(p.requires_grad and p.is_cuda and p.dtype == torch.float32 for p in ps))
 
-    def _fused_tables(self, batchData):
+    def _tables(self, batchData):
         """Pointer tables and workspace of cpc_train_step for this batch shape; rebuilt when a parameter got new storage."""
         import ctypes
         from . import _lib
@@ -133,43 +82,35 @@ class Trainer:
         B, _, L = batchData.shape
         K, N = cr.nPredicts, cr.negativeSamplingExt
         key = (B, L, K, N, batchData.device, lib.cpc_get_mfma_mode(), wall.data_ptr()) + tuple(p.data_ptr() for p in plist)
-        f = self._fused
+        f = self.tables
         if f is not None and f["key"] == key:
             return f
         views = self.allreduce._views(plist + heads)                   # the flat gradient buffer: gradients are written in place
         hv = views[len(plist):]
         step = hv[0].numel() * hv[0].element_size()
         if any(v.data_ptr() != hv[0].data_ptr() + k * step for k, v in enumerate(hv)):
-            raise RuntimeError("Trainer: the prediction heads' gradients are not contiguous in the flat buffer")
+            raise RuntimeError("CompositeStep: the prediction heads' gradients are not contiguous in the flat buffer")
         for p in plist:
             if not p.is_contiguous():
-                raise RuntimeError("Trainer: non-contiguous parameter")
+                raise RuntimeError("CompositeStep: non-contiguous parameter")
         arr = ctypes.c_void_p * 29
         sizes = (ctypes.c_long * 8)()
         with torch.cuda.device(batchData.device):
             lib.check(lib.cpc_train_step_layout(B, L, K, N, sizes), "train_step_layout")
             ws = torch.empty(sizes[0], device=batchData.device, dtype=torch.float32)
-        f = self._fused = {
+        f = self.tables = {
             "key": key, "params": arr(*([p.data_ptr() for p in plist] + [wall.data_ptr()])),
             "grads": arr(*([v.data_ptr() for v in views[:len(plist)]] + [hv[0].data_ptr()])),
             "plist": plist + heads, "views": views, "ws": ws, "S": int(sizes[3]), "sizes": tuple(sizes),
             "ones": torch.ones(K, device=batchData.device), "hN": torch.empty(2, B, 256, device=batchData.device)}
         return f
 
-    def _fused_step(self, batchData, label, negatives=None):
-        from . import _lib, ops
+    def forward_backward(self, batchData, negatives=None, prefetch=False):
+        from . import _lib
         lib = _lib.get()
         dev = batchData.device
-        throttle = not self._capturing
-        if throttle:
-            done = self._done_events
-            if len(done) >= self.MAX_IN_FLIGHT:
-                import time
-                t0 = time.perf_counter()
-                done.pop(0).synchronize()
-                self.wait_seconds = getattr(self, "wait_seconds", 0.0) + (time.perf_counter() - t0)
         batchData = batchData.contiguous()
-        f = self._fused_tables(batchData)
+        f = self._tables(batchData)
         m, cr, ctx = self.model, self.criterion, self.ctx
         ar = m.gAR
         B, _, L = batchData.shape
@@ -192,7 +133,7 @@ class Trainer:
             else:
                 bidx, sidx = negatives[0].contiguous(), negatives[1].contiguous()
                 if bidx.numel() != B * N * (S - K) or sidx.numel() != bidx.numel():
-                    raise ValueError("Trainer.step: negatives must be two int64 tensors of B*N*W draws")
+                    raise ValueError("negatives must be two int64 tensors of B*N*W draws")
                 bidx.record_stream(side)
                 sidx.record_stream(side)
             h0 = ar.hidden
@@ -233,12 +174,99 @@ class Trainer:
                 raise
             if ar.keepHidden:
                 ar.hidden = ar._own_hidden = hN                 # cpc/model.py:194-198 (a fresh tensor per step: nothing aliases it)
-            if negatives is None and self.prefetch_negatives and not self._capturing:
+            if negatives is None and prefetch:
                 # the next step's draws + their index lists now, on the side stream behind this step's last reader of the lists
                 with torch.cuda.stream(side):
                     nb, ns = cr.drawNegatives(B, S, S - K, dev)
                 lib.check(lib.cpc_train_step_prefetch(P(nb), P(ns), P(f["ws"]), B, L, K, N, side.cuda_stream), "train_step_prefetch")
                 f["prefetched"] = pkey
+        return out[0:1], out[1:2]
+
+
+class Trainer:
+    """``graph=True`` (single GPU): the whole step -- forward, backward on all streams, Adam, zero_grad -- is captured
+    ONCE as a HIP graph and replayed with one launch per step.  The step is ~70 kernel launches on four streams issued from
+    Python (3-5 ms of host time per step, measured, against 3.9 ms of GPU time): on a slow or busy host the eager loop is
+    host-bound, the replayed graph is not.  Static shapes only (a new batch shape re-captures); ``negatives`` supplied by
+    the caller, a learning-rate change or world_size > 1 fall back to the eager step."""
+
+    AUTO_PROBE_STEPS = 6      # graph="auto": eager steps timed (host enqueue time vs GPU time) before deciding
+
+    def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, graph=False, check_errors_every=256,
+                 fused=True, prefetch_negatives=False):
+        """check_errors_every: every that many steps the device-side error flags are read (ops.check_device_errors: a
+        recurrence workgroup that gave up polling, a negative index out of range) and turned into an exception -- one device
+        synchronisation per that many steps; 0 leaves the check to the caller.
+        graph: False (eager), True (HIP graph replay), or "auto": the first steps run eagerly and are timed; the graph is
+        used only if the host needs more than 60 % of the GPU's step time to issue a step.  (Measured on MI355X boxes: the
+        replayed graph costs 0.24 ms of host time per step instead of 1.5-5 ms and runs within 0.5 % of the eagerly issued
+        streams on the GPU -- a win as soon as the host is not comfortably ahead, see _step.)"""
+        """fused (default True): where the configuration is the north-star one -- CPCEncoder + 2-layer GRU CPCAR + linear
+        heads, every parameter trainable -- forward and backward of a step are issued by ONE C call (cpc_train_step, csrc/
+        train_step.hip: the same entry points in the same order on the same four streams, bit-identical results) into a
+        persistent workspace, with the gradients written straight into the flat all-reduce buffer; anything else (transformer
+        AR / predictors, criterion mode 'reverse', frozen parameters) runs the autograd path below."""
+        self.model, self.criterion = model, criterion
+        self.fused = bool(fused)
+        # composite step only, off by default: draw the NEXT step's negatives and prepare their index lists at the end of a step
+        # (beside its tail: layer 1's weight gradient alone on the matrix pipes) instead of behind conv0 of the next one.  The
+        # draws come from torch's generator in the same order either way -- the A/B's losses are equal to the last digit --; only
+        # code that draws from the same generator BETWEEN two train steps (a validation pass) would see them one step early.
+        # Measured neutral (2.880 vs 2.883 ms per step sustained, three alternations: what the preparation costs conv1 / conv2
+        # at the start of a step it costs the weight gradient at the end), so the reference's draw-inside-the-step order stays.
+        # CPC_PREFETCH_NEGATIVES=1 / 0 overrides (A/B runs).
+        import os
+        env = os.environ.get("CPC_PREFETCH_NEGATIVES")
+        self.prefetch_negatives = bool(prefetch_negatives) if env is None else env == "1"
+        params = list(criterion.parameters()) + list(model.parameters())      # train.py:332
+        self.optimizer = Adam(params, lr=lr, betas=betas, eps=eps)      # train.py:335-337; one launch per step on the GPU
+        enc = {id(p) for p in model.gEncoder.parameters()} if hasattr(model, "gEncoder") else set()
+        self.allreduce = FlatGradAllReduce(params, early=[p for p in params if id(p) not in enc] if enc else None)
+        from . import ops
+        self.ctx = ops.StepContext(overlap=True)
+        self.ctx.pre_encoder_backward.append(self.allreduce.begin)
+        self._composite = CompositeStep(model, criterion, self.ctx, self.allreduce)
+        self.graph = True if graph is True else ("auto" if graph == "auto" else False)
+        self._probe = []                  # graph="auto": (host seconds, start event, end event) of the first eager steps
+        self._captured = None             # (key, CUDAGraph, static input, static label, static outputs)
+        self._capturing = False           # inside capture(): no host-side throttle, no completion events (see _eager_step)
+        self._done_events = []
+        self.check_errors_every = int(check_errors_every)
+        self._steps = 0
+
+    def _ones_like(self, t):
+        o = getattr(self, "_ones", None)
+        if o is None or o.shape != t.shape or o.device != t.device or o.dtype != t.dtype:
+            o = self._ones = torch.ones_like(t)
+        return o
+
+    # Eager steps in flight.  The host issues a step in ~1.5 ms, the GPU runs it in 3.4: unchecked, the host runs ahead until
+    # the stream's queue pushes back, every step in flight holds its own workspaces (blocks used on a side stream return
+    # to torch's allocator only when that stream has passed them), and the allocator keeps asking the driver for more --
+    # measured at B = 128: 27 hipMalloc calls in 10 steps after warm-up, steps of 6 ms with stalls to 9-17 ms, reserved
+    # memory still growing.  Two steps ahead keep the GPU fed and bound both.
+    MAX_IN_FLIGHT = 2
+
+    # ---- the composite step (cpc_train_step): CompositeStep below ----------------------------------------------------------
+    @property
+    def _fused(self):                      # (tests look at it: the pointer tables / workspace of the composite, None until used)
+        return self._composite.tables
+
+    def _fused_ok(self, batchData, negatives):
+        return self.fused and self._composite.ok(batchData, negatives)
+
+    def _fused_step(self, batchData, label, negatives=None):
+        throttle = not self._capturing
+        if throttle:
+            done = self._done_events
+            if len(done) >= self.MAX_IN_FLIGHT:
+                import time
+                t0 = time.perf_counter()
+                done.pop(0).synchronize()
+                self.wait_seconds = getattr(self, "wait_seconds", 0.0) + (time.perf_counter() - t0)
+        with torch.cuda.device(batchData.device):
+            losses, acc = self._composite.forward_backward(batchData, negatives,
+                                                           prefetch=self.prefetch_negatives and not self._capturing)
             self.allreduce()
             self.optimizer.step()
             self.optimizer.zero_grad()
@@ -246,7 +274,7 @@ class Trainer:
                 ev = torch.cuda.Event()
                 ev.record()
                 self._done_events.append(ev)
-        return out[0:1], out[1:2]
+        return losses, acc
 
     def _eager_step(self, batchData, label, negatives=None):
         if self._fused_ok(batchData, negatives):

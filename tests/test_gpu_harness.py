@@ -171,3 +171,34 @@ def test_device_side_window_plans_against_the_per_item_path(tmp_path, kind):
             assert torch.isfinite(losses).all() and model.gAR.hidden is not None
             n += 1
         assert n == len(data.window_plan("sequential", B, 0)) >= 2
+
+
+def test_train_epoch_through_the_composite_step_equals_the_autograd_loop():
+    """harness.train_epoch issues forward + backward through cpc_train_step where the configuration allows (train.CompositeStep);
+    the logged losses / accuracies and the parameters after an epoch must equal the autograd-driven loop's bit for bit, with the
+    package's Adam and with torch's own (the gradients are views of a flat buffer either optimiser reads)."""
+    dev = _dev()
+    from cpc_audio_amd import harness as H
+    from cpc_audio_amd.optim import Adam
+    from cpc_audio_amd.train import build_criterion, build_model, load_flat_params
+    p = O.make_params(seed=41, head_scale=64.0)
+    for make_opt in (lambda ps: Adam(ps, lr=2e-4), lambda ps: torch.optim.Adam(ps, lr=2e-4)):
+        res = []
+        for composite in (False, True):
+            model, crit = build_model().to(dev), build_criterion().to(dev)
+            load_flat_params(model, crit, p)
+            opt = make_opt(list(crit.parameters()) + list(model.parameters()))
+            H.COMPOSITE_STEP = composite
+            try:
+                torch.manual_seed(77)
+                logs = H.train_epoch(H.SyntheticLoader(3, 4, 20480, seed=5, device=dev), model, crit, opt)
+            finally:
+                H.COMPOSITE_STEP = True
+            torch.cuda.synchronize()
+            state = {k: v.detach().cpu().clone() for k, v in list(model.state_dict().items()) + list(crit.state_dict().items())}
+            res.append((logs, state))
+        assert res[0][0]["iter"] == res[1][0]["iter"] == 3
+        for k in ("locLoss_train", "locAcc_train"):
+            assert (res[0][0][k] == res[1][0][k]).all(), k
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], res[1][1][k]), k
