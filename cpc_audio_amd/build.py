@@ -27,10 +27,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
 # altogether, and check_packed_fp32() below fails the build if a kernel outside PACKED_FP32_ALLOWED contains any.
 FILE_FLAGS = {}
 
-# Kernels that may contain v_pk_{fma,mul,add}_f32: explicit f32x4 arithmetic on MFMA accumulators (register operands, no LDS-fed
-# broadcast).  Every one of them is run beside the 16-bit-MFMA GEMM kernels and compared bit for bit with its solo run in
-# tests/test_gpu_corun.py (test_recurrence_is_bit_exact_beside_the_fp16_gemm_kernels, persistent and per-step modes).
-PACKED_FP32_ALLOWED = ("gru2_persist_fwd_h2_kernel", "gru2_persist_bwd_kernel", "gru2_bwd_kernel")
+# Kernels that may contain v_pk_{fma,mul,add}_f32: NONE since round 4.  Until then three recurrence kernels carried explicit f32x4
+# arithmetic on MFMA accumulators (36 packed adds / multiplies in all, never seen to misbehave beside the 16-bit-MFMA GEMMs in
+# tests/test_gpu_corun.py); they are written component by component now (gru.hip: add4 / scale4, no measurable cost), so the
+# library as a whole is free of the instruction class and the gate below has nothing to excuse.
+PACKED_FP32_ALLOWED = ()
 
 
 def _llvm(tool):
@@ -67,7 +68,7 @@ def packed_fp32_kernels(obj):
 
 def check_packed_fp32(objs):
     """The build-time gate: no packed fp32 arithmetic outside the allow-list (see FILE_FLAGS above)."""
-    ok = tuple(f"{len(n)}{n}E" for n in PACKED_FP32_ALLOWED)          # Itanium-mangled name component
+    ok = tuple(f"{len(n)}{n}E" for n in PACKED_FP32_ALLOWED)          # Itanium-mangled name component (empty: nothing is excused)
     bad = {}
     for o in objs:
         for sym, cnt in packed_fp32_kernels(o).items():

@@ -193,6 +193,19 @@ struct Gru2Fwd {
     int first_sleep;           // persistent launch only: see PollPace (< 0: self-steering)
 };
 
+// Component-wise f32x4 arithmetic on MFMA accumulators written out scalar by scalar: f32x4 operators compile to v_pk_{add,mul}_f32,
+// the instruction class behind the co-residency corruption of rounds 1-2 -- with these three kernels
+// scalar as well the library contains NO packed fp32 arithmetic and build.py's allow-list is empty.
+__device__ __forceinline__ f32x4 add4(const f32x4& a, const f32x4& b) {
+    f32x4 r;
+    r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = a[3] + b[3];
+    return r;
+}
+__device__ __forceinline__ f32x4 scale4(const f32x4& a, float s) {
+    f32x4 r;
+    r[0] = a[0] * s; r[1] = a[1] * s; r[2] = a[2] * s; r[3] = a[3] * s;
+    return r;
+}
 __device__ __forceinline__ void mfma_slice(f32x4 (&acc)[3], const float* __restrict__ arow, bool ok,
                                            const float* __restrict__ w, int j0i, int koff, int nii) {
     // acc[g] += A[16 x (16*nii)] . W[g*H + j0 + i][koff ...]^T for the three gates
@@ -391,7 +404,7 @@ __device__ __forceinline__ f32x4 mfma_gate_rows(f32x4 acc, const float* __restri
 #pragma unroll
             for (int g = 0; g < 3; ++g)
                 ag[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[ii][g], jj), f4c(bw[ii][g], jj), ag[g], 0, 0, 0);
-    return acc + ((ag[0] + ag[1]) + ag[2]);
+    return add4(acc, add4(add4(ag[0], ag[1]), ag[2]));
 }
 
 // Launch s (s = 0..S): blockIdx.z = 0 -> top layer (1) step t = S-1-s; blockIdx.z = 1 -> bottom
@@ -686,7 +699,7 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
             if constexpr (H2) {
                 mfma_gates_h2<NII>(acc, a, bh, sa);
 #pragma unroll
-                for (int g = 0; g < 3; ++g) acc[g] *= inv;
+                for (int g = 0; g < 3; ++g) acc[g] = scale4(acc[g], inv);
             } else {
                 mfma_gates<NII>(acc, a, bw);
             }
@@ -855,7 +868,7 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
                         for (int g = 0; g < 3; ++g)
                             ag[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(dh[ii], jj) * f4c(cf[ii][g], jj),
                                                                          f4c(bw[ii][g], jj), ag[g], 0, 0, 0);
-                acc = acc + ((ag[0] + ag[1]) + ag[2]);
+                acc = add4(acc, add4(add4(ag[0], ag[1]), ag[2]));
             }
             if (t > 0)                                            // next iteration's coefficients: step ts - 1
                 load_coef<NU>(cf, c0, c1, c2, xtile(ts - 1, id.tile, id.ntiles, kH) + lane_off);

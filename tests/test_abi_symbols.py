@@ -68,3 +68,20 @@ def test_module_api_matches_reference_surface():
         CPCEncoder(256, "nope")
     with pytest.raises(ValueError):
         CPCUnsupersivedCriterion(12, 256, 256, 128, mode="bogus")
+
+
+def test_library_contains_no_packed_fp32_arithmetic():
+    """build.py's gate with an EMPTY allow-list (round 4): no code object of the library contains v_pk_{fma,mul,add}_f32 -- the
+    instruction class behind the co-residency corruption of rounds 1-2."""
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    import glob
+    from cpc_audio_amd import build
+    build.build()
+    assert build.PACKED_FP32_ALLOWED == ()
+    objs = sorted(glob.glob(os.path.join(build.LIBDIR, "obj", "*.o")))
+    assert len(objs) >= len(build.sources())
+    found = {}
+    for o in objs:
+        found.update(build.packed_fp32_kernels(o))
+    assert found == {}, found

@@ -189,7 +189,7 @@ def test_norm_backward_is_bit_exact_beside_the_fp16_gemm_kernels():
 def test_recurrence_is_bit_exact_beside_the_fp16_gemm_kernels(gru_mode):
     """cpc_gru_forward / cpc_gru_backward_coef / cpc_gru_backward at B = 64.  gru_mode 2 (default): the persistent kernels --
     workgroups poll each other's results; a co-runner changes when they become resident, never what they compute.  gru_mode 1:
-    the launch-per-step two-layer kernels.  Between them these are the kernels build.PACKED_FP32_ALLOWED lets contain packed
+    the launch-per-step two-layer kernels.  Between them these are the kernels that contained packed (until round 4: build.PACKED_FP32_ALLOWED is empty now)
     fp32 arithmetic (explicit f32x4 operations on MFMA accumulators): gru2_persist_fwd_h2_kernel, gru2_persist_bwd_kernel,
     gru2_bwd_kernel."""
     dev = _dev()
