@@ -1245,7 +1245,9 @@ extern "C" int cpc_encoder_saved_activation(const float* saved, int layer, float
 // criterion's index preparation there when asked to); per host thread, nullptr = none
 namespace cpc {
 static thread_local hipEvent_t t_after_conv0 = nullptr;
-void enc_set_after_conv0_event(hipEvent_t ev) { t_after_conv0 = ev; }
+static thread_local int t_event_layer = 0;               // the event is recorded behind this layer's launch (0 or 1)
+void enc_set_after_conv0_event(hipEvent_t ev) { t_after_conv0 = ev; t_event_layer = 0; }
+void enc_set_forward_event(int layer, hipEvent_t ev) { t_after_conv0 = ev; t_event_layer = layer; }
 }  // namespace cpc
 
 // params: 20 pointers in the reference's state-dict order
@@ -1298,8 +1300,9 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
     int rc = cpc_conv0_forward_h2(wave, params[0], params[1], params[2], params[3], saved + e.y[0], saved + e.mean0,
                                   saved + e.rstd[0], act_h2(0) ? saved + e.sbound + 1 : nullptr, B, L, stream);
     if (rc) return rc;
-    if (t_after_conv0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
+    if (t_after_conv0 && t_event_layer == 0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
     for (int i = 1; i < 5; ++i) {
+        if (i == 2 && t_after_conv0 && t_event_layer == 1 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
         float* yo = i == 4 ? z : saved + e.y[i];
         if (e.dma[i]) {
             const long M = (long)B * e.L[i];

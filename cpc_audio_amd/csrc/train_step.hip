@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a,
 // tuning / measurement switches (cpc_set_step_schedule)
 int g_prep_point = 1;     // where the criterion's index preparation is released on the side stream: 0 step begin (beside conv0: the one
                           // HBM-bound layer goes from 50 to 96 us), 1 (default) behind conv0 (beside conv1 / conv2: +20 us there),
-                          // 2 behind the encoder (beside the recurrence, whose hand-over it disturbs)
+                          // 2 behind the encoder (beside the recurrence, whose hand-over it disturbs), 3 behind conv1 (beside conv2..4)
 int g_no_early = 0;
 int g_dz_early = 0;       // 1: the dz path on MAIN before the recurrence's backward (which then has the memory system to itself)
                           // instead of beside it on the side stream
@@ -77,13 +77,14 @@ inline bool wait(hipStream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 
 
 // enc_conv.hip: an event cpc_encoder_forward records on its stream right behind layer 0's launch (nullptr: none)
 void enc_set_after_conv0_event(hipEvent_t ev);
+void enc_set_forward_event(int layer, hipEvent_t ev);
 
 }  // namespace cpc
 
 using namespace cpc;
 
 extern "C" int cpc_set_step_schedule(int prep_point, int dz_early) {
-    CPC_RETURN_IF(prep_point < 0 || prep_point > 2 || dz_early < 0 || dz_early > 3, CPC_ERR_ARG);
+    CPC_RETURN_IF(prep_point < 0 || prep_point > 3 || dz_early < 0 || dz_early > 3, CPC_ERR_ARG);
     g_prep_point = prep_point;
     g_dz_early = dz_early & 1;
     g_no_early = (dz_early >> 1) & 1;      // + 2: the small weight-only launches stay on the main stream where round 3 had them (A/B)
@@ -157,11 +158,12 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
             CPC_RETURN_IF(!wait(S0, ev[0]), CPC_ERR_ARG);
             if ((rc = prepare())) return rc;
         }
-        enc_set_after_conv0_event(g_prep_point == 1 ? ev[6] : nullptr);
+        if (g_prep_point == 3) enc_set_forward_event(1, ev[6]);
+        else enc_set_after_conv0_event(g_prep_point == 1 ? ev[6] : nullptr);
         rc = cpc_encoder_forward(wave, enc_p, ws + s.enc_saved, ws + s.enc_fscr, z, B, L, M);
         enc_set_after_conv0_event(nullptr);
         if (rc) return rc;
-        if (g_prep_point == 1) {
+        if (g_prep_point == 1 || g_prep_point == 3) {
             CPC_RETURN_IF(!wait(S0, ev[6]), CPC_ERR_ARG);
             if ((rc = prepare())) return rc;
         } else if (g_prep_point == 2) {

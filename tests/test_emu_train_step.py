@@ -136,7 +136,7 @@ def test_composite_step_phase_split_and_schedule_switches_change_no_bit_emulated
     B, L, K, N = 2, 2560, 4, 16
     p, wave, S, bidx, sidx, plist = _setup(B, L, K, N, seed=1)
     ref = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N)
-    for phases, schedule in (((1, 2), (0, 0)), ((3,), (2, 1)), ((1, 2), (1, 1))):
+    for phases, schedule in (((1, 2), (0, 0)), ((3,), (2, 1)), ((1, 2), (3, 3))):
         got = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N, phases=phases, schedule=schedule)
         assert torch.equal(ref[0], got[0]) and torch.equal(ref[3], got[3]) and torch.equal(ref[4], got[4])
         for a, b in zip(ref[2], got[2]):
@@ -149,7 +149,7 @@ def test_composite_step_argument_errors():
     assert lib.cpc_train_step_layout(0, 3200, 4, 16, sizes) == 1              # CPC_ERR_SHAPE
     assert lib.cpc_train_step_layout(2, 3200, 4, 10, sizes) == 1              # N % 16
     assert lib.cpc_train_step_layout(2, 1600, 12, 16, sizes) == 1             # S = 10 <= K
-    assert lib.cpc_set_step_schedule(3, 0) == 2 and lib.cpc_set_step_schedule(0, 2) == 2
+    assert lib.cpc_set_step_schedule(4, 0) == 2 and lib.cpc_set_step_schedule(0, 4) == 2
     assert lib.cpc_train_step(None, None, None, None, 1.0, None, None, None, None, None, None, None, 2, 3200, 4, 16, 3,
                               None, None, None, None) == 2
 
