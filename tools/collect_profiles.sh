@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 timeout 400 python bench.py > $O/bench_$TAG.json 2> $O/bench.err
 # 2. kernel trace of the fp32 step (eager launch, no probes): per-kernel totals, last full step, step period
 rm -rf /tmp/prof_fp32
-timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_fp32 -o res -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-probes --launch eager > $O/bench_trace.json 2> $O/trace.err
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_fp32 -o res -- python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-probes --launch eager --sustained-seconds 0 > $O/bench_trace.json 2> $O/trace.err
 db=$(find /tmp/prof_fp32 -name "*.db" | head -1)
 python tools/rocpd_stats.py $db $O/${TAG}_step_kernel_stats.csv > /dev/null
 python tools/step_timeline.py $db --stats > $O/${TAG}_step_stats.txt
@@ -18,7 +18,7 @@ python tools/step_timeline.py $db > $O/${TAG}_step_timeline.txt
 python tools/step_timeline.py $db --period > $O/${TAG}_step_period.txt
 # 3. the same for the bf16-storage variant
 rm -rf /tmp/prof_bf16
-timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_bf16 -o res -- python bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-probes --launch eager > $O/bench_trace_bf16.json 2>> $O/trace.err
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_bf16 -o res -- python bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-probes --launch eager --sustained-seconds 0 > $O/bench_trace_bf16.json 2>> $O/trace.err
 db=$(find /tmp/prof_bf16 -name "*.db" | head -1)
 python tools/step_timeline.py $db --stats > $O/${TAG}_bf16_step_stats.txt
 python tools/step_timeline.py $db > $O/${TAG}_bf16_step_timeline.txt

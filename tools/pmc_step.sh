@@ -11,7 +11,7 @@ mkdir -p $OUT
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   d=/tmp/pmcs_$(echo $grp | tr ' ' '_')
   rm -rf $d
-  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d $d -o res -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-probes --launch eager > $OUT/run.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d $d -o res -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-probes --launch eager --sustained-seconds 0 > $OUT/run.log 2>&1
   db=$(find $d -name "*.db" | head -1)
   if [ -n "$db" ]; then python tools/rocpd_pmc.py $db cpc:: | tail -n +2 >> $OUT/pmc_step_counters.csv; else echo "no db for $grp" >> $OUT/run.log; fi
 done
