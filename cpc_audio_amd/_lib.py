@@ -18,6 +18,7 @@ EXPECTED_ABI = 11          # cpc_abi_version() of the library these signatures w
 DEFAULT_DMA_PIPELINE = 2
 DEFAULT_WGRAD_DMA_STAGES = 4   # cpc_set_wgrad_dma_stages
 DEFAULT_CONV_SMALL_PIPE = 1    # cpc_set_conv_small_pipe
+DEFAULT_DGRAD_NSPLIT = 0       # cpc_set_dgrad_nsplit
 DEFAULT_STEP_SCHEDULE = (1, 0)  # cpc_set_step_schedule: index preparation behind conv0, dz path beside the recurrence   # cpc_set_dma_pipeline: the tap-pair walk where the shape allows, two 32-k stages elsewhere
 
 _P = ctypes.c_void_p
@@ -45,6 +46,7 @@ SIGNATURES = {
     "cpc_set_wgrad1_early": (_I, [_I]),
     "cpc_set_dma_layer2": (_I, [_I]),
     "cpc_set_conv_small_tile": (_I, [_I]),
+    "cpc_set_dgrad_nsplit": (_I, [_I]),
     "cpc_set_conv_small_pipe": (_I, [_I]),
     "cpc_set_wgrad_dma_groups": (_I, [_I]),
     "cpc_set_wgrad_dma_stages": (_I, [_I]),

@@ -680,6 +680,53 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE, AH2, PIPE>::Tile::NTHREADS), (BM
     }
 }
 
+// The plain H2-fed data gradient on 128 x 128 tiles: two workgroups per 128-row tile, each 128 of the 256 input channels
+// (blockIdx.z).  A workgroup's operand traffic through L2 is (rows + columns) x K, so for a fixed number of workgroups -- the chip
+// wants >= 256 -- square tiles move the least: layer 3 at B = 64, 16384 rows x 2 phases, goes from 1024 workgroups of 32 x 256
+// (537 MB of weight re-reads) to 512 of 128 x 128 (2.25x less).  The data gradient has no ChannelNorm in its epilogue, so
+// splitting the channels costs nothing but the second read of the gradient rows.  Pipelined 16-k schedule, fp16 pieces.
+using DgradNsTile = NtTileX3<128, 128, 2, 2, 16, 2, true, true, 2, true>;
+__global__ __launch_bounds__(DgradNsTile::NTHREADS) void conv_dgrad_nsplit_kernel(
+    RowMap am, const float* __restrict__ wd, int s, int p, int Lin, float* __restrict__ dprev,
+    const float* __restrict__ dx_bound, const float* __restrict__ w_amax, float* __restrict__ prev_amax) {
+    using Tile = DgradNsTile;
+    constexpr int TM = Tile::TM, TN = Tile::TN;
+    __shared__ float smem[Tile::SMEM_FLOATS];
+    const int m0 = blockIdx.x * 128, ph = blockIdx.y, n0 = blockIdx.z * 128;
+    const int q0 = (am.R == am.Lin && ph < p) ? 1 : 0;              // exact rows (dgrad_rows): phase ph starts at q = q0
+    am.off += q0 * kC;
+    am.tadd += q0;
+    f32x16 acc[TM][TN];
+    zero_acc(acc);
+    const float sa = scale_for_amax(*dx_bound), sb = scale_for_amax(*w_amax);
+    Tile::run(acc, am, m0, wd + (long)ph * kC * 2 * kC, 16, n0, 2 * kC, smem, 0, kC * 16, 0, sa, sb, 1);
+    const float inv = 1.0f / (sa * sb);
+    float amax = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + Tile::c_row(tm, r);
+            if (m >= am.M) continue;
+            const int b = m / am.R, q = m - b * am.R + q0;
+            const int tau = q * s + ph - p;
+            if ((unsigned)tau >= (unsigned)Lin) continue;
+            float* out = dprev + ((long)b * Lin + tau) * kC + n0;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const float v = acc[tm][tn][r] * inv;
+                out[Tile::c_col(tn)] = v;
+                amax = fmaxf(amax, fabsf(v));
+            }
+        }
+    if (prev_amax != nullptr) {              // max|dprev| for the norm backward below, which writes H2 (64 slots)
+        amax = wave_max(amax);
+        if ((threadIdx.x & 63) == 0)
+            atomicMax(reinterpret_cast<unsigned*>(prev_amax + (int)((blockIdx.x + blockIdx.y + blockIdx.z) % (unsigned)kAmaxSlots)),
+                      __float_as_uint(amax));
+    }
+}
+
 // ------------------------------------------------------------------ wgrad
 // MODE 3: as 2 with the activation operand (x) in H2 storage; MODE 4: both operands are bf16 tensors, one product;
 // MODE 5: as 3 with dx in H2 storage too (scaled for the bound *dx_amax that the norm backward left, norm_bwd_kernel DXH2)
@@ -813,7 +860,9 @@ static int g_h2_all = 1;     // what "by problem size" means: 1 (default since r
 static int g_force_bm = 0;   // 0 = choose by problem size; 32/64/128 = tuning / test override
 static int g_dma_layer2 = 0; // 1: layer 2 on the DMA-fed kernels whatever the batch (cpc_set_dma_layer2; by default from B ~ 100 on)
 static int g_small_bm = 32;  // rows of the small tile pick_bm() chooses below 32000 rows (cpc_set_conv_small_tile): 32 or 64
-static int g_small_pipe = 1; // 1: the 32- / 64-row tiles of the H2-fed register-staged kernels on the pipelined 16-k schedule (ConvCfg PIPE)
+static int g_small_pipe = 1;
+static int g_dgrad_nsplit = 0;  // > 0: the H2-fed data gradient of the short layers on 128 x 128 tiles when that gives at least this many
+                                // workgroups (cpc_set_dgrad_nsplit; 0 = off) // 1: the 32- / 64-row tiles of the H2-fed register-staged kernels on the pipelined 16-k schedule (ConvCfg PIPE)
 static constexpr int g_unfuse_big = 2;   // 2: every dgrad runs unfused + streaming norm backward, 1: only the 128-row tiles,
                                          // 0: fused epilogue (cpc_conv_layer_dgrad fuse=1).  Measured 4.69 / 4.76 / 4.79 ms per step
 static int pick_bm(int M) {
@@ -991,6 +1040,11 @@ extern "C" int cpc_set_conv_small_tile(int bm) {
     g_small_bm = bm;
     return 0;
 }
+extern "C" int cpc_set_dgrad_nsplit(int min_wgs) {
+    CPC_RETURN_IF(min_wgs < 0, CPC_ERR_ARG);
+    g_dgrad_nsplit = min_wgs;
+    return 0;
+}
 extern "C" int cpc_set_conv_small_pipe(int on) {
     g_small_pipe = on ? 1 : 0;
     return 0;
@@ -1148,6 +1202,13 @@ static int conv_dgrad_core(const float* dx, const float* wd, int fuse, const flo
     am = dgrad_rows(dx, B, Lin, Lout, s, p);
     const int bm = pick_bm(am.M);
     const int nblk = cdiv(am.M, bm) * s;
+    // H2 gradient below the 128-row regime: 128 x 128 tiles (conv_dgrad_nsplit_kernel) where they still give the chip >= 256 workgroups
+    if (dx_h2 && g_dgrad_nsplit && bm < 128 && (long)cdiv(am.M, 128) * s * 2 >= g_dgrad_nsplit) {
+        hipLaunchKernelGGL(conv_dgrad_nsplit_kernel, dim3(cdiv(am.M, 128), s, 2), dim3(DgradNsTile::NTHREADS), 0, st, am, wd, s, p, Lin,
+                           dprev, dx_amax, w_amax, dprev_slots);
+        CPC_LAUNCH_CHECK();
+        return 0;
+    }
     if (fuse) {
         switch (bm) {
             case 128: launch_conv_dgrad<128, true>(am, wd, s, p, Lin, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, dx_amax, w_amax, dprev_amax, amax_slots, st); break;

@@ -100,6 +100,8 @@ int cpc_set_h2_layers(int n);            /* mode 3, which layers read their inpu
                                             gradient on the DMA + transposing-read kernel with one batched reduction; 0 = by problem size */
 int cpc_set_dma_layer2(int on);          /* 1: layer 2 (forward and data gradient) on the DMA-fed kernels whatever the batch size; 0 (default): from B ~ 100 on */
 int cpc_set_conv_small_tile(int bm);     /* rows per workgroup of the register-staged conv tiles below 32000 rows: 32 (default) or 64 */
+int cpc_set_dgrad_nsplit(int min_wgs);    /* > 0: the H2-fed data gradient of layers below the 128-row regime runs on 128 x 128 tiles (two workgroups
+                                            per row tile, 128 input channels each) where that still gives min_wgs workgroups; 0: 32-row tiles */
 int cpc_set_conv_small_pipe(int on);     /* 1 (default): the 32- / 64-row tiles of the H2-fed register-staged conv kernels (cpc_set_h2_layers(4)) run the software-
                                             pipelined 16-k schedule of the 128-row tiles (four chunks of global loads in flight); 0: one 32-k stage */
 int cpc_set_wgrad_dma_groups(int wgs);  /* workgroups the DMA weight gradient aims at (row splits = wgs / taps); 64..512 */

@@ -31,9 +31,11 @@ def _names():
 def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None):
     from cpc_audio_amd._lib import ptr as P
     h2_layers, stages, small_pipe = 0, 2, 0
+    nsplit = 1 if mode == 634 else 0             # 634: + the short layers' data gradients on 128 x 128 tiles (cpc_set_dgrad_nsplit)
+    assert lib.cpc_set_dgrad_nsplit(nsplit) == 0
     dma2 = 1 if mode == 534 else 0               # 534: + layer 2 on the DMA-fed kernels (what B >= ~100 selects by itself: the B = 128 case)
     assert lib.cpc_set_dma_layer2(dma2) == 0
-    if mode in (34, 334, 434, 534):  # mode 3 with every activation and every gradient of layers 1..4 in H2 storage (cpc_set_h2_layers(4));
+    if mode in (34, 334, 434, 534, 634):  # mode 3 with every activation and every gradient of layers 1..4 in H2 storage (cpc_set_h2_layers(4));
         stages = 4 if mode == 434 else 2         # 434: + the weight-gradient kernel on four 16-row LDS stages
         small_pipe = 1 if mode == 334 else 0     # 334: + the short tiles on the software-pipelined 16-k schedule
         mode, h2_layers = 3, 4
@@ -75,6 +77,7 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None):
     lib.cpc_set_wgrad_dma_stages(_L.DEFAULT_WGRAD_DMA_STAGES)
     lib.cpc_set_conv_small_pipe(_L.DEFAULT_CONV_SMALL_PIPE)
     lib.cpc_set_dma_layer2(0)
+    lib.cpc_set_dgrad_nsplit(_L.DEFAULT_DGRAD_NSPLIT)
     lib.cpc_set_mfma_mode(_lib_default_mode())
     if dma is not None:
         lib.cpc_set_dma_tile(0)
@@ -111,7 +114,7 @@ def test_encoder_dma_pipelines_match_oracle(pipe):
                                           (1, 4330, 64, 3), (2, 10240, 32, 3), (64, 20480, 0, 3), (8, 20480, 0, 34),
                                           (3, 20480, 128, 34), (1, 4330, 64, 34), (2, 10240, 32, 34), (64, 20480, 0, 34),
                                           (8, 20480, 0, 434), (1, 4330, 64, 434), (64, 20480, 0, 434), (8, 20480, 0, 334),
-                                          (2, 10240, 64, 334), (64, 20480, 0, 334), (8, 20480, 0, 3), (8, 20480, 0, 534), (128, 20480, 0, 34)])
+                                          (2, 10240, 64, 334), (64, 20480, 0, 334), (8, 20480, 0, 3), (8, 20480, 0, 534), (128, 20480, 0, 34), (8, 20480, 0, 634), (64, 20480, 0, 634)])
 def test_encoder_matches_oracle(B, L, bm, mode):
     """mode 1 = bf16 pipe with 3-piece split operands, mode 0 = exact-f32 MFMA, mode 2 = fp16 pipe with scaled
     2-piece split operands, mode 3 (default) = mode 2 + layers 1, 2 on the DMA kernel reading H2 activations (B = 64:
