@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcpc_hip.so")
 DEFAULT_GRU_MODE = 2       # cpc_set_gru_mode: persistent recurrence, forward products on the fp16 split
 DEFAULT_MFMA_MODE = 3      # what libcpc_hip starts in (cpc_set_mfma_mode): mode 2's arithmetic (two fp16 pieces, 3 MFMAs per
 #                            product) with conv1 / its gradients on the DMA-fed kernels reading H2-stored activations
-EXPECTED_ABI = 11          # cpc_abi_version() of the library these signatures were written for: a stale or variant build that
+EXPECTED_ABI = 12          # cpc_abi_version() of the library these signatures were written for: a stale or variant build that
 #                            exports every symbol with OLDER argument lists would corrupt memory instead of raising -- bind() refuses it
 DEFAULT_DMA_PIPELINE = 2
 DEFAULT_WGRAD_DMA_STAGES = 4   # cpc_set_wgrad_dma_stages
@@ -30,6 +30,7 @@ _F = ctypes.c_float
 SIGNATURES = {
     "cpc_abi_version": (_I, []),
     "cpc_release_stream": (_I, [_P]),
+    "cpc_streams_overlap": (_I, [_P, _P, _P]),
     "cpc_set_mfma_mode": (_I, [_I]),
     "cpc_get_mfma_mode": (_I, []),
     "cpc_device_error_flags": (_I, [_I]),

@@ -50,7 +50,49 @@ extern "C" int cpc_release_stream(void* stream) {
     return 0;
 }
 
-extern "C" int cpc_abi_version(void) { return 11; }
+extern "C" int cpc_abi_version(void) { return 12; }
+
+// A kernel that keeps one wavefront busy for `ticks` of the 100 MHz wall clock (bounded: it gives up after ~2^14 sleeps).
+__global__ void spin_kernel(unsigned long long ticks) {
+#ifndef HIPEMU
+    unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < (1 << 14) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(64);
+#else
+    (void)ticks;
+#endif
+}
+
+// Do kernels on stream `b` run while stream `a` is busy?  The runtime multiplexes hipStreams onto a handful of hardware queues
+// (GPU_MAX_HW_QUEUES: 4 per priority level by default) in creation order, and two streams on one queue execute in submission
+// order whatever their events say: with 4 queues, pool stream i of torch shares one with stream i + 4 or so, and where the
+// step's streams land depends on how many streams the process created before (RCCL creates six).  a runs ONE wavefront for
+// 3 ms; b's empty kernel finishes at once unless the two share a queue.  The host side picks the step's streams with this
+// probe (ops.pick_concurrent_stream).  Blocks the calling thread for ~3 ms.  *overlap = 1 if b's kernel finished while a's ran.
+extern "C" int cpc_streams_overlap(void* stream_a, void* stream_b, int* overlap) {
+    CPC_RETURN_IF(!overlap, CPC_ERR_ARG);
+#ifdef HIPEMU
+    *overlap = stream_a != stream_b;
+    return 0;
+#else
+    hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    int rc = 1000 + (int)hipErrorUnknown;
+    if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&eb, hipEventDisableTiming) == hipSuccess) {
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, 300000ull);       // 3 ms
+        bool ok = hipEventRecord(ea, a) == hipSuccess;
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, 0ull);
+        ok = ok && hipEventRecord(eb, b) == hipSuccess && hipEventSynchronize(eb) == hipSuccess;
+        if (ok) {
+            *overlap = hipEventQuery(ea) == hipErrorNotReady ? 1 : 0;
+            rc = hipEventSynchronize(ea) == hipSuccess && hipGetLastError() == hipSuccess ? 0 : rc;
+        }
+    }
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    return rc;
+#endif
+}
 
 // Device-side error flags of the current device, accumulated since they were last cleared:
 //   bit 0  CPC_DEVERR_GRU_POLL_TIMEOUT   a workgroup of the persistent recurrence gave up waiting for another one (its

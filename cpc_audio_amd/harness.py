@@ -120,28 +120,40 @@ def _to_device(t, device):
     return t if t.device == device else t.to(device, non_blocking=True)
 
 
+def _step_state(model, criterion, optimizer, allreduce, device):
+    """(composite step or None, step context) of a run, kept from epoch to epoch on the optimiser object (it lives as long as the
+    run): the composite owns a workspace of a couple of GB and the flat gradient buffer, the context the four streams."""
+    from .dist import FlatGradAllReduce
+    from .train import CompositeStep
+    cached = optimizer.__dict__.get("_cpc_composite")
+    if cached is not None and cached[0] is model and cached[1] is criterion and cached[2] is allreduce:
+        return cached[3], cached[4]
+    step_ctx = ops.StepContext(overlap=True)
+    if allreduce is not None:
+        step_ctx.pre_encoder_backward.append(allreduce.begin)
+    composite = None
+    if device.type == "cuda":
+        step_ctx.reserve(device)
+        flat = allreduce if allreduce is not None else FlatGradAllReduce([p for g in optimizer.param_groups for p in g["params"]])
+        composite = CompositeStep(model, criterion, step_ctx, flat)
+    optimizer.__dict__["_cpc_composite"] = (model, criterion, allreduce, composite, step_ctx)
+    return composite, step_ctx
+
+
 def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_step=1000, allreduce=None,
                 verbose=False):
     """One pass over ``loader``; returns {"locLoss_train", "locAcc_train", "iter"} (numpy, averaged)."""
+    composite, step_ctx = _step_state(model, criterion, optimizer, allreduce, next(model.parameters()).device)
     model.train()
     criterion.train()
     device = next(model.parameters()).device
     sum_loss = sum_acc = None
     n_iter, t0, n_ex = 0, time.perf_counter(), 0
     ones = None
-    step_ctx = ops.StepContext(overlap=True)
-    if allreduce is not None:
-        step_ctx.pre_encoder_backward.append(allreduce.begin)
     # Forward + backward through one C call where the configuration is the one the composite covers (train.CompositeStep:
     # CPCEncoder + 2-layer GRU + linear heads, everything trainable) -- same kernels in the same order, bit-identical results,
     # a third of the host time; its gradients live in a flat buffer (the all-reduce's, or a private one without a process
     # group).  Anything else takes the autograd-driven path below.
-    from .dist import FlatGradAllReduce
-    from .train import CompositeStep
-    flat = allreduce
-    if flat is None and device.type == "cuda":
-        flat = FlatGradAllReduce([p for g in optimizer.param_groups for p in g["params"]])
-    composite = CompositeStep(model, criterion, step_ctx, flat) if flat is not None else None
     in_flight = []                                        # at most two steps ahead of the GPU (train.Trainer.MAX_IN_FLIGHT)
     for step, (batch, label) in enumerate(loader):
         batch, label = _to_device(batch, device), _to_device(label, device)

@@ -7,6 +7,7 @@ scratch) comes from torch's caching allocator; kernels are enqueued on torch's c
 stream of the input's device.  There is no CPU implementation: CPU tensors raise.
 """
 import ctypes
+import os
 from contextlib import nullcontext as _nullcontext
 
 import torch
@@ -66,6 +67,42 @@ import threading
 _tls = threading.local()
 
 
+MAX_STREAM_CANDIDATES = 12
+
+
+def streams_overlap(a, b):
+    """True if a kernel on stream ``b`` runs while stream ``a`` is busy, i.e. the two do not share a hardware queue
+    (cpc_streams_overlap: a ~3 ms blocking probe)."""
+    lib = _lib.get()
+    out = ctypes.c_int(0)
+    lib.check(lib.cpc_streams_overlap(ctypes.c_void_p(a.cuda_stream), ctypes.c_void_p(b.cuda_stream), ctypes.byref(out)),
+              "streams_overlap")
+    return bool(out.value)
+
+
+def pick_concurrent_stream(device, priority, beside):
+    """A pooled stream that really executes beside every stream in ``beside``.  The HIP runtime maps streams onto four hardware
+    queues per priority level in creation order (measured with this probe: torch's pool streams 1..6 pair up as (1,6) (2,5) (3,4)
+    in a fresh process; after init_process_group("nccl"), which creates six streams of its own, the default stream shares a queue
+    with pool stream 4), and two streams on one queue run in submission order whatever their events say.  Draw from torch's
+    pool until the probe says the candidate overlaps with all of ``beside`` (at most MAX_STREAM_CANDIDATES draws, ~3 ms per
+    probe, once per process); if none does, the last one is used and a warning names the cost.  During a stream capture nothing
+    can be probed: plain draw.  CPC_STREAM_PROBE=0 switches the probe off."""
+    st = torch.cuda.Stream(device=device, priority=priority)
+    if os.environ.get("CPC_STREAM_PROBE", "1") == "0" or torch.cuda.is_current_stream_capturing():
+        return st
+    with torch.cuda.device(device):
+        for n in range(MAX_STREAM_CANDIDATES):
+            if all(streams_overlap(o, st) for o in beside):
+                return st
+            if n + 1 < MAX_STREAM_CANDIDATES:
+                st = torch.cuda.Stream(device=device, priority=priority)
+    import warnings
+    warnings.warn(f"no stream found that runs beside the step's other streams after {MAX_STREAM_CANDIDATES} draws: the overlapped "
+                  "parts of the train step will run in submission order (slower, not wrong)")
+    return st
+
+
 class StepContext:
     """Overlap state of one train loop.  ``overlap``: the criterion's dz path and head gradient on a side stream;
     ``wgrad_stream`` (with overlap): the encoder's / recurrence's weight-gradient GEMMs on their own stream."""
@@ -95,11 +132,18 @@ class StepContext:
             # layer's data gradient -- is the tail of the step, and with priority its workgroups are dispatched ahead of conv0's
             # backward beside it (measured: 2.865-2.873 vs 2.880-2.884 ms per step sustained, three alternations; the criterion's
             # stream at high priority: no difference).  CPC_SIDE_PRIORITY="0,2"-style lists override (A/B runs).
-            import os
             env = os.environ.get("CPC_SIDE_PRIORITY")
             hi = which == 2 if env is None else str(which) in env.split(",")
-            st = self._streams[key] = torch.cuda.Stream(device=device, priority=-1 if hi else 0)
+            beside = [torch.cuda.current_stream(device)] + [v for k, v in self._streams.items() if k[0] == key[0]]
+            st = self._streams[key] = pick_concurrent_stream(device, -1 if hi else 0, beside)
         return st
+
+    def reserve(self, device):
+        """Create the three side streams now (their hardware queues are handed out in creation order: see
+        pick_concurrent_stream and DESIGN.md section 5 for why a data-parallel run wants them created before
+        init_process_group)."""
+        with torch.cuda.device(device):
+            return [self.side_stream(device, which) for which in range(3)]
 
     def abandon(self):
         """After an exception inside an overlapped step: forget the launches still held back and the events not yet

@@ -224,6 +224,11 @@ class Trainer:
         self.allreduce = FlatGradAllReduce(params, early=[p for p in params if id(p) not in enc] if enc else None)
         from . import ops
         self.ctx = ops.StepContext(overlap=True)
+        if params and params[0].is_cuda and not torch.cuda.is_current_stream_capturing():
+            # the side streams exist from here on: a Trainer built before init_process_group("nccl") keeps hardware queues of
+            # its own (the same step took 2.9 ms with them created before RCCL's streams, 4.6 after, when
+            # the process had touched the GPU before the group was set up)
+            self.ctx.reserve(params[0].device)
         self.ctx.pre_encoder_backward.append(self.allreduce.begin)
         self._composite = CompositeStep(model, criterion, self.ctx, self.allreduce)
         self.graph = True if graph is True else ("auto" if graph == "auto" else False)

@@ -30,6 +30,11 @@ int cpc_abi_version(void);
  * reused for the life of the process -- right for long-lived streams.  A caller that creates and destroys streams hands each
  * one back before destroying it (no *_streams call of this library may be in flight on it). */
 int cpc_release_stream(void* stream);
+/* *overlap = 1 if a kernel on stream_b completes while stream_a is busy, 0 if the two execute in submission order: the runtime
+ * maps hipStreams onto a few hardware queues (4 per priority level) in creation order, and two streams on one queue serialise
+ * whatever their events allow.  Launches a 3 ms one-wavefront wait kernel on stream_a and blocks the calling thread until both
+ * streams drain: a start-up probe, used by the host side to choose the side streams of cpc_train_step. */
+int cpc_streams_overlap(void* stream_a, void* stream_b, int* overlap);
 
 /* Arithmetic of the NT GEMMs (conv forward/dgrad, projections, heads):
  *   1 bf16 matrix pipe, fp32 operands split by truncation into three bf16 pieces, six

@@ -154,6 +154,16 @@ def test_composite_step_argument_errors():
                               None, None, None, None) == 2
 
 
+def test_stream_overlap_probe_entry_point_on_the_emulator():
+    """cpc_streams_overlap (the start-up probe that picks the step's side streams): argument check; on the emulator, where every
+    stream is the one host thread, two handles count as concurrent exactly if they differ."""
+    lib = emu()
+    out = ctypes.c_int(-1)
+    assert lib.cpc_streams_overlap(None, None, None) == 2                     # CPC_ERR_ARG
+    assert lib.cpc_streams_overlap(None, None, ctypes.byref(out)) == 0 and out.value == 0
+    assert lib.cpc_streams_overlap(None, ctypes.c_void_p(8), ctypes.byref(out)) == 0 and out.value == 1
+
+
 def test_prefetched_index_lists_give_the_same_step_emulated():
     """cpc_train_step_prefetch + cpc_train_step(batchIdx = seqIdx = NULL): the index lists prepared one step ahead in the workspace
     are the ones the step would have prepared itself."""
