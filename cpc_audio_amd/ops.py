@@ -70,6 +70,16 @@ _tls = threading.local()
 MAX_STREAM_CANDIDATES = 12
 
 
+def _rccl_is_up():
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    try:
+        return "nccl" in str(dist.get_backend())
+    except Exception:
+        return True
+
+
 def streams_overlap(a, b):
     """True if a kernel on stream ``b`` runs while stream ``a`` is busy, i.e. the two do not share a hardware queue
     (cpc_streams_overlap: a ~3 ms blocking probe)."""
@@ -132,16 +142,24 @@ class StepContext:
             # layer's data gradient -- is the tail of the step, and with priority its workgroups are dispatched ahead of conv0's
             # backward beside it (measured: 2.865-2.873 vs 2.880-2.884 ms per step sustained, three alternations; the criterion's
             # stream at high priority: no difference).  CPC_SIDE_PRIORITY="0,2"-style lists override (A/B runs).
+            # NOT in a process that has set up RCCL: a high-priority stream gets a hardware queue of its own, and that queue
+            # must not be the process's FIFTH.  ROCclr logs (AMD_LOG_LEVEL=3) show what happens: the default stream creates
+            # queue 1, init_process_group("nccl") queues 2-4 (RCCL's streams; the normal-priority pool is full at four), the
+            # side streams share those, and the high-priority stream creates queue 5 -- after which every kernel of the main
+            # stream on queue 1 runs 20-40 us longer, alone or not, and the step takes 4.6 ms instead of 2.9 (the same with
+            # the roles mirrored, with all side streams at high priority, or with GPU_MAX_HW_QUEUES=8; with the priority
+            # dropped, or GPU_MAX_HW_QUEUES <= 3, 2.89 ms in every creation order).  Four queues or fewer is the rule this
+            # keeps: default + two side streams + this one without RCCL, normal priority only (four shared queues) with it.
             env = os.environ.get("CPC_SIDE_PRIORITY")
-            hi = which == 2 if env is None else str(which) in env.split(",")
+            hi = (which == 2 and not _rccl_is_up()) if env is None else str(which) in env.split(",")
             beside = [torch.cuda.current_stream(device)] + [v for k, v in self._streams.items() if k[0] == key[0]]
             st = self._streams[key] = pick_concurrent_stream(device, -1 if hi else 0, beside)
         return st
 
     def reserve(self, device):
-        """Create the three side streams now (their hardware queues are handed out in creation order: see
-        pick_concurrent_stream and DESIGN.md section 5 for why a data-parallel run wants them created before
-        init_process_group)."""
+        """Create the three side streams now.  Hardware queues are handed out in creation order and a process should not need
+        more than four (side_stream above): streams created before init_process_group get queues of
+        their own, RCCL's then share the fourth."""
         with torch.cuda.device(device):
             return [self.side_stream(device, which) for which in range(3)]
 
