@@ -57,8 +57,8 @@ def check_device_errors(clear=True):
 # The dz half of the criterion's backward (per-destination gather-GEMM + one dense GEMM) is not on the way to dc, and
 # the network that consumes dc (the persistent GRU backward: 128 workgroups, latency-bound) leaves most of the chip
 # idle; the weight-gradient GEMMs hang off the dx chain.  A train loop that wants them on side streams owns a
-# StepContext and runs forward + backward inside ``with ctx:``.  All overlap state (streams, events, launches held back)
-# lives on that object -- nothing is module-global -- so two loops on two threads / devices (nn.DataParallel-style
+# StepContext and runs forward + backward inside ``with ctx:``.  All overlap state (events, launches held back)
+# lives on that object -- only the side streams are per process, see _side_streams -- so two loops on two threads / devices (nn.DataParallel-style
 # replicas) do not see each other.  The Functions pick the context up in forward (on the caller's
 # thread) and carry it to backward on their autograd ctx: autograd runs backward on its own worker thread.
 # Without an active context every Function is single-stream.
@@ -113,6 +113,41 @@ def pick_concurrent_stream(device, priority, beside):
     return st
 
 
+# The side streams themselves are per process and device, shared by every StepContext: a second train loop in the process (a
+# second Trainer, the bench's bf16 pass) must not draw a second high-priority stream -- its queue would be the process's fifth --
+# and has nothing to gain from more normal-priority ones either (four queues serve them all).  Two loops on two threads then
+# enqueue on the same side streams: each orders its own work with its own events, the streams only add FIFO order between them.
+_side_streams = {}
+_side_streams_lock = threading.Lock()
+
+
+def _new_side_stream(key, device, which):
+    # The weight-gradient stream runs at high priority: its last kernel -- layer 1's weight gradient, released behind that
+    # layer's data gradient -- is the tail of the step, and with priority its workgroups are dispatched ahead of conv0's
+    # backward beside it (measured: 2.865-2.873 vs 2.880-2.884 ms per step sustained, three alternations; the criterion's
+    # stream at high priority: no difference).  CPC_SIDE_PRIORITY="0,2"-style lists override (A/B runs).
+    # NOT in a process that has set up RCCL: a high-priority stream gets a hardware queue of its own, and that queue
+    # must not be the process's FIFTH.  ROCclr logs (AMD_LOG_LEVEL=3) show what happens: the default stream creates
+    # queue 1, init_process_group("nccl") queues 2-4 (RCCL's streams; the normal-priority pool is full at four), the
+    # side streams share those, and the high-priority stream creates queue 5 -- after which every kernel of the main
+    # stream on queue 1 runs 20-40 us longer, alone or not, and the step takes 4.6 ms instead of 2.9 (the same with
+    # the roles mirrored, with all side streams at high priority, or with GPU_MAX_HW_QUEUES=8; with the priority
+    # dropped, or GPU_MAX_HW_QUEUES <= 3, 2.89 ms in every creation order).  Four queues or fewer is the rule this
+    # keeps: default + two side streams + this one without RCCL, normal priority only (four shared queues) with it.
+    env = os.environ.get("CPC_SIDE_PRIORITY")
+    hi = (which == 2 and not _rccl_is_up()) if env is None else str(which) in env.split(",")
+    beside = [torch.cuda.current_stream(device)] + [v for k, v in _side_streams.items() if k[0] == key[0]]
+    return pick_concurrent_stream(device, -1 if hi else 0, beside)
+
+
+def _process_side_stream(key, device, which):
+    with _side_streams_lock:
+        st = _side_streams.get(key)
+        if st is None:
+            st = _side_streams[key] = _new_side_stream(key, device, which)
+        return st
+
+
 class StepContext:
     """Overlap state of one train loop.  ``overlap``: the criterion's dz path and head gradient on a side stream;
     ``wgrad_stream`` (with overlap): the encoder's / recurrence's weight-gradient GEMMs on their own stream."""
@@ -138,22 +173,7 @@ class StepContext:
         key = (torch.device(device).index, which)
         st = self._streams.get(key)
         if st is None:
-            # The weight-gradient stream runs at high priority: its last kernel -- layer 1's weight gradient, released behind that
-            # layer's data gradient -- is the tail of the step, and with priority its workgroups are dispatched ahead of conv0's
-            # backward beside it (measured: 2.865-2.873 vs 2.880-2.884 ms per step sustained, three alternations; the criterion's
-            # stream at high priority: no difference).  CPC_SIDE_PRIORITY="0,2"-style lists override (A/B runs).
-            # NOT in a process that has set up RCCL: a high-priority stream gets a hardware queue of its own, and that queue
-            # must not be the process's FIFTH.  ROCclr logs (AMD_LOG_LEVEL=3) show what happens: the default stream creates
-            # queue 1, init_process_group("nccl") queues 2-4 (RCCL's streams; the normal-priority pool is full at four), the
-            # side streams share those, and the high-priority stream creates queue 5 -- after which every kernel of the main
-            # stream on queue 1 runs 20-40 us longer, alone or not, and the step takes 4.6 ms instead of 2.9 (the same with
-            # the roles mirrored, with all side streams at high priority, or with GPU_MAX_HW_QUEUES=8; with the priority
-            # dropped, or GPU_MAX_HW_QUEUES <= 3, 2.89 ms in every creation order).  Four queues or fewer is the rule this
-            # keeps: default + two side streams + this one without RCCL, normal priority only (four shared queues) with it.
-            env = os.environ.get("CPC_SIDE_PRIORITY")
-            hi = (which == 2 and not _rccl_is_up()) if env is None else str(which) in env.split(",")
-            beside = [torch.cuda.current_stream(device)] + [v for k, v in self._streams.items() if k[0] == key[0]]
-            st = self._streams[key] = pick_concurrent_stream(device, -1 if hi else 0, beside)
+            st = self._streams[key] = _process_side_stream(key, device, which)
         return st
 
     def reserve(self, device):

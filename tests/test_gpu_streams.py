@@ -47,6 +47,7 @@ def test_without_rccl_the_weight_gradient_stream_has_priority():
     from cpc_audio_amd import ops
     if dist.is_initialized():
         pytest.skip("a process group is up in this process")
+    ops._side_streams.clear()          # (the streams are per process: earlier tests may have created them beside RCCL)
     pri = [st.priority for st in ops.StepContext(overlap=True).reserve(dev)]
     assert pri == [0, 0, -1], pri
 
@@ -65,8 +66,10 @@ def test_step_context_streams_are_pairwise_concurrent_after_rccl_created_its_own
     try:
         t = torch.ones(8, device=dev)
         dist.all_reduce(t)
+        ops._side_streams.clear()
         ctx = ops.StepContext(overlap=True)
         streams = [torch.cuda.current_stream(dev)] + ctx.reserve(dev)
+        assert ops.StepContext(overlap=True).reserve(dev) == streams[1:]          # one set of side streams per process
         # no high-priority stream beside RCCL: its queue would be the process's fifth
         assert all(st.priority == 0 for st in streams[1:]), [st.priority for st in streams]
         for i in range(4):
@@ -74,5 +77,6 @@ def test_step_context_streams_are_pairwise_concurrent_after_rccl_created_its_own
                 if i != j:
                     assert ops.streams_overlap(streams[i], streams[j]), (i, j)
     finally:
+        ops._side_streams.clear()
         if own:
             dist.destroy_process_group()
