@@ -70,16 +70,6 @@ _tls = threading.local()
 MAX_STREAM_CANDIDATES = 12
 
 
-def _rccl_is_up():
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return False
-    try:
-        return "nccl" in str(dist.get_backend())
-    except Exception:
-        return True
-
-
 def streams_overlap(a, b):
     """True if a kernel on stream ``b`` runs while stream ``a`` is busy, i.e. the two do not share a hardware queue
     (cpc_streams_overlap: a ~3 ms blocking probe)."""
@@ -114,28 +104,27 @@ def pick_concurrent_stream(device, priority, beside):
 
 
 # The side streams themselves are per process and device, shared by every StepContext: a second train loop in the process (a
-# second Trainer, the bench's bf16 pass) must not draw a second high-priority stream -- its queue would be the process's fifth --
-# and has nothing to gain from more normal-priority ones either (four queues serve them all).  Two loops on two threads then
+# second Trainer, the bench's bf16 pass) has nothing to gain from more of them (four hardware queues serve them all).  Two loops on two threads then
 # enqueue on the same side streams: each orders its own work with its own events, the streams only add FIFO order between them.
 _side_streams = {}
 _side_streams_lock = threading.Lock()
 
 
 def _new_side_stream(key, device, which):
-    # The weight-gradient stream runs at high priority: its last kernel -- layer 1's weight gradient, released behind that
-    # layer's data gradient -- is the tail of the step, and with priority its workgroups are dispatched ahead of conv0's
-    # backward beside it (measured: 2.865-2.873 vs 2.880-2.884 ms per step sustained, three alternations; the criterion's
-    # stream at high priority: no difference).  CPC_SIDE_PRIORITY="0,2"-style lists override (A/B runs).
-    # NOT in a process that has set up RCCL: a high-priority stream gets a hardware queue of its own, and that queue
-    # must not be the process's FIFTH.  ROCclr logs (AMD_LOG_LEVEL=3) show what happens: the default stream creates
-    # queue 1, init_process_group("nccl") queues 2-4 (RCCL's streams; the normal-priority pool is full at four), the
-    # side streams share those, and the high-priority stream creates queue 5 -- after which every kernel of the main
-    # stream on queue 1 runs 20-40 us longer, alone or not, and the step takes 4.6 ms instead of 2.9 (the same with
-    # the roles mirrored, with all side streams at high priority, or with GPU_MAX_HW_QUEUES=8; with the priority
-    # dropped, or GPU_MAX_HW_QUEUES <= 3, 2.89 ms in every creation order).  Four queues or fewer is the rule this
-    # keeps: default + two side streams + this one without RCCL, normal priority only (four shared queues) with it.
+    # All side streams at normal priority.  Round 4 ran the weight-gradient stream at high priority for a while -- its last
+    # kernel, layer 1's weight gradient, is the tail of the step, and with priority its workgroups are dispatched ahead of
+    # conv0's backward beside it: 2.865-2.873 vs 2.880-2.884 ms per step sustained on one box, no difference on another -- but
+    # a high-priority stream gets a hardware queue of its own, and that queue must not be the process's FIFTH.  ROCclr's log
+    # (AMD_LOG_LEVEL=3) of a run that had touched the GPU before init_process_group("nccl"): the default stream creates queue
+    # 1, RCCL's streams queues 2-4 (the normal-priority pool is full at four), the side streams share those, the
+    # high-priority stream creates queue 5 -- after which every kernel of the main stream on queue 1 runs 20-40 us longer,
+    # alone or not, and the step takes 4.6 ms instead of 2.9 (the same with the roles mirrored, with all side streams at high
+    # priority, or with GPU_MAX_HW_QUEUES=8; with the priority dropped, or GPU_MAX_HW_QUEUES <= 3, 2.89 ms in every creation
+    # order).  A graph capture's warm-up stream, a second train loop or a caller's own stream would be a fifth queue just the
+    # same; with normal-priority streams only, the process stays within the four queues of the normal pool whatever else it
+    # creates.  CPC_SIDE_PRIORITY="2"-style lists of `which` opt back in (A/B runs).
     env = os.environ.get("CPC_SIDE_PRIORITY")
-    hi = (which == 2 and not _rccl_is_up()) if env is None else str(which) in env.split(",")
+    hi = env is not None and str(which) in env.split(",")
     beside = [torch.cuda.current_stream(device)] + [v for k, v in _side_streams.items() if k[0] == key[0]]
     return pick_concurrent_stream(device, -1 if hi else 0, beside)
 

@@ -198,9 +198,9 @@ class Trainer:
         recurrence workgroup that gave up polling, a negative index out of range) and turned into an exception -- one device
         synchronisation per that many steps; 0 leaves the check to the caller.
         graph: False (eager), True (HIP graph replay), or "auto": the first steps run eagerly and are timed; the graph is
-        used only if the host needs more than 60 % of the GPU's step time to issue a step.  (Measured on MI355X boxes: the
-        replayed graph costs 0.24 ms of host time per step instead of 1.5-5 ms and runs within 0.5 % of the eagerly issued
-        streams on the GPU -- a win as soon as the host is not comfortably ahead, see _step.)"""
+        used only if the host needs more than 85 % of the GPU's step time to issue a step.  (Measured on MI355X boxes: the
+        replayed graph costs 0.24-0.28 ms of host time per step (the composite step issued eagerly: 0.5 ms) and runs 6 % longer on
+        the GPU than the eagerly issued streams (3.10 vs 2.93 ms, round 4) -- a win only where the host cannot keep up, see step.)"""
         """fused (default True): where the configuration is the north-star one -- CPCEncoder + 2-layer GRU CPCAR + linear
         heads, every parameter trainable -- forward and backward of a step are issued by ONE C call (cpc_train_step, csrc/
         train_step.hip: the same entry points in the same order on the same four streams, bit-identical results) into a
@@ -408,10 +408,10 @@ class Trainer:
                 steady = self._probe[2:]                    # the first calls pay allocator / lazy-initialisation costs
                 host_ms = 1e3 * sum(h for h, _, _ in steady) / len(steady)
                 gpu_ms = sum(a.elapsed_time(b) for _, a, b in steady) / len(steady)
-                # Replay costs the host one launch and runs within 0.5 % of the eager step, so it is taken as
-                # soon as the host is not comfortably ahead: at 0.8 of the GPU time (a box of round 3: 2.4 ms of enqueueing
-                # for a 3.1 ms step) a few slow Python iterations already starve the queue -- mean 3.39 vs median 3.09 ms.
-                self.graph = host_ms > 0.6 * gpu_ms
+                # Replay costs the host one launch but the GPU 6 % more than the eagerly issued streams (round 4: 3.10 vs 2.93 ms,
+                # DESIGN.md 4.9), and the composite step needs 0.5 ms of host time where round 3's eager step needed 1.7-2.4:
+                # the graph is taken only when the host could not keep up otherwise.
+                self.graph = host_ms > 0.85 * gpu_ms
                 self.launch_decision = {"host_ms_per_step": round(host_ms, 3), "gpu_ms_per_step": round(gpu_ms, 3),
                                         "graph": self.graph}
                 self._probe = []

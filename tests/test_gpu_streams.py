@@ -41,17 +41,6 @@ def test_pool_streams_share_hardware_queues_and_the_pick_avoids_that():
         assert ops.streams_overlap(x, y) and ops.streams_overlap(y, x)
 
 
-def test_without_rccl_the_weight_gradient_stream_has_priority():
-    dev = _dev()
-    import torch.distributed as dist
-    from cpc_audio_amd import ops
-    if dist.is_initialized():
-        pytest.skip("a process group is up in this process")
-    ops._side_streams.clear()          # (the streams are per process: earlier tests may have created them beside RCCL)
-    pri = [st.priority for st in ops.StepContext(overlap=True).reserve(dev)]
-    assert pri == [0, 0, -1], pri
-
-
 def test_step_context_streams_are_pairwise_concurrent_after_rccl_created_its_own():
     """What a data-parallel rank sees: the process group (and its six streams) first, the train loop's streams after."""
     dev = _dev()
@@ -70,7 +59,7 @@ def test_step_context_streams_are_pairwise_concurrent_after_rccl_created_its_own
         ctx = ops.StepContext(overlap=True)
         streams = [torch.cuda.current_stream(dev)] + ctx.reserve(dev)
         assert ops.StepContext(overlap=True).reserve(dev) == streams[1:]          # one set of side streams per process
-        # no high-priority stream beside RCCL: its queue would be the process's fifth
+        # no high-priority stream: its queue would be the process's fifth
         assert all(st.priority == 0 for st in streams[1:]), [st.priority for st in streams]
         for i in range(4):
             for j in range(4):
