@@ -71,8 +71,6 @@ class PredictionNetwork(nn.Module):
         if rnnMode in ("RNN", "LSTM", "ffd", "conv4", "conv8", "conv12"):
             raise NotImplementedError(f"rnnMode={rnnMode!r}: the HIP criterion implements the linear prediction heads "
                                       "(--rnnMode linear) and the transformer predictors (--rnnMode transformer)")
-        if dropout:
-            raise NotImplementedError("dropout on the predictions is not implemented in the fused criterion")
         if dimOutputAR != 256 or dimOutputEncoder != 256:
             raise NotImplementedError("the HIP criterion is built for hiddenGar == hiddenEncoder == 256")
         if nPredicts > 16:
@@ -80,7 +78,11 @@ class PredictionNetwork(nn.Module):
         self.predictors = nn.ModuleList()
         self.RESIDUAL_STD = 0.01
         self.dimOutputAR = dimOutputAR
-        self.dropout = None
+        # criterion.py:59,113-114: nn.Dropout(p=0.5) on every head's prediction (``--dropout``).  While it is active (training
+        # mode) the predictions are formed as a tensor of their own -- one library GEMM for the K linear heads, or the transformer
+        # predictors -- dropped out by torch and scored by the same kernels the transformer predictors use (scores_apart below);
+        # in eval mode it is the identity and the linear heads stay fused in the criterion kernels.
+        self.dropout = nn.Dropout(p=0.5) if dropout else None
         self.rnnMode = rnnMode
         for _ in range(nPredicts):
             if rnnMode == "transformer":
@@ -90,12 +92,23 @@ class PredictionNetwork(nn.Module):
             else:
                 self.predictors.append(nn.Linear(dimOutputAR, dimOutputEncoder, bias=False))
 
+    @property
+    def scores_apart(self):
+        """True where the predictions exist as a tensor between the prediction networks and the scores (transformer predictors;
+        any predictor with the reference's dropout active): InfoNCEScoresFunction instead of the fused InfoNCEFunction."""
+        return self.rnnMode == "transformer" or (self.dropout is not None and self.training)
+
     group_predictors = True      # False: the transformer predictors run head by head (the path a mixed set falls back to; tests)
 
     def predictions(self, c):
         """c (B,W,256) -> (B,W,K*256): head k at columns k*256.. (the layout the score kernels read).  K one-layer transformer
         predictors (the only kind buildTransformerAR(.., 1, .., False) builds) run in lock-step, one launch per kernel for all
-        of them (ops.TransformerGroupFunction); anything else head by head."""
+        of them (ops.TransformerGroupFunction); the K linear heads as one GEMM on the stacked weight; anything else head by head.
+        The reference's dropout (criterion.py:113-114: per head, independent elementwise masks) is one dropout of the whole tensor."""
+        pred = self._predictions(c)
+        return pred if self.dropout is None else self.dropout(pred)
+
+    def _predictions(self, c):
         from .transformers import TransformerLayer
         layers = [p[0] if isinstance(p, nn.Sequential) and len(p) == 1 else None for p in self.predictors]
         if (self.group_predictors and self.rnnMode == "transformer" and len(layers) > 1 and all(isinstance(l, TransformerLayer) for l in layers)
@@ -111,6 +124,8 @@ class PredictionNetwork(nn.Module):
                 ps = [get(l) for l in layers]
                 kinds.append(None if ps[0] is None else stacked_parameters(self, f"layer{i}", ps))
             return TransformerGroupFunction.apply(c, p, seed, len(layers), *kinds)
+        if all(isinstance(p, nn.Linear) and p.bias is None for p in self.predictors):
+            return torch.nn.functional.linear(c, self.stacked_weight())
         return torch.cat([p(c) for p in self.predictors], dim=2)
 
     def stacked_weight(self):
@@ -125,6 +140,8 @@ class PredictionNetwork(nn.Module):
         out = []
         for k in range(len(self.predictors)):
             locC = self.predictors[k](c)
+            if self.dropout is not None:
+                locC = self.dropout(locC)
             locC = locC.view(locC.size(0), 1, locC.size(1), locC.size(2))
             out.append((locC * candidates[k]).mean(dim=3))
         return out
@@ -212,7 +229,7 @@ class CPCUnsupersivedCriterion(BaseCriterion):
                 negatives = self.drawNegatives(batchSize, seqSize, W, device)
             ext, perm, row_ptr = prepare_negatives(negatives[0], negatives[1], batchSize, seqSize, K, N)
             saved = None
-            if c_bound is not None and self.wPrediction.rnnMode != "transformer":
+            if c_bound is not None and not self.wPrediction.scores_apart:
                 saved = ops.nce_bounds_into(self.wPrediction.stacked_weight(), c_bound, batchSize, seqSize, K, N)
             ready = torch.cuda.Event()
             ready.record(side)
@@ -267,7 +284,7 @@ class CPCUnsupersivedCriterion(BaseCriterion):
                 negatives = self.drawNegatives(batchSize, seqSize, windowSize, cFeature.device)
             ext, perm, row_ptr = prepare_negatives(negatives[0], negatives[1], batchSize, seqSize, self.nPredicts,
                                                    self.negativeSamplingExt)
-        if self.wPrediction.rnnMode == "transformer":
+        if self.wPrediction.scores_apart:
             pred = self.wPrediction.predictions(cFeature[:, :windowSize].contiguous())
             losses, acc = InfoNCEScoresFunction.apply(pred, encodedData, ext, perm, row_ptr)
         else:

@@ -25,9 +25,9 @@ def build_model(hiddenEncoder=256, hiddenGar=256, nLevelsGRU=2, keepHidden=False
 
 
 def build_criterion(nPredicts=12, hiddenGar=256, hiddenEncoder=256, negativeSamplingExt=128,
-                    sizeWindow=20480, downsampling=160, mode=None, rnnMode="linear", transformerDropout=0.1):
+                    sizeWindow=20480, downsampling=160, mode=None, rnnMode="linear", transformerDropout=0.1, dropout=False):
     return CPCUnsupersivedCriterion(nPredicts, hiddenGar, hiddenEncoder, negativeSamplingExt, mode=mode,
-                                    rnnMode=rnnMode, dropout=False, sizeInputSeq=sizeWindow // downsampling,
+                                    rnnMode=rnnMode, dropout=dropout, sizeInputSeq=sizeWindow // downsampling,
                                     transformerDropout=transformerDropout)
 
 
@@ -60,7 +60,7 @@ class CompositeStep:
                 and isinstance(cr, CPCUnsupersivedCriterion)):
             return False
         ar = m.gAR
-        if ar.reverse or ar.baseNet.num_layers != 2 or cr.mode is not None or cr.wPrediction.rnnMode == "transformer":
+        if ar.reverse or ar.baseNet.num_layers != 2 or cr.mode is not None or cr.wPrediction.scores_apart:
             return False
         if negatives is not None and not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int64 for t in negatives):
             return False
@@ -331,6 +331,9 @@ class Trainer:
         (CPCAR.keepHidden swaps a tensor per step) and per-call host random numbers (the transformer layers' dropout seeds)."""
         ar = getattr(self.model, "gAR", None)
         if getattr(ar, "keepHidden", False):
+            return False
+        wp = getattr(self.criterion, "wPrediction", None)
+        if getattr(wp, "dropout", None) is not None and wp.training:      # torch draws the masks per call
             return False
         from .transformers import TransformerLayer
         for mod in list(self.model.modules()) + list(self.criterion.modules()):

@@ -70,6 +70,29 @@ def test_module_api_matches_reference_surface():
         CPCUnsupersivedCriterion(12, 256, 256, 128, mode="bogus")
 
 
+def test_prediction_dropout_option_has_the_reference_surface():
+    """cpc/criterion/criterion.py:59,113-114: ``dropout=True`` holds nn.Dropout(p=0.5) (no parameters: the state dict is unchanged),
+    applies it to each head's prediction in the reference-API forward while training, and is the identity in eval mode."""
+    import torch
+    from cpc_audio_amd.criterion import CPCUnsupersivedCriterion, PredictionNetwork
+    plain = PredictionNetwork(12, 256, 256, rnnMode="linear", dropout=False)
+    pn = PredictionNetwork(12, 256, 256, rnnMode="linear", dropout=True)
+    assert plain.dropout is None and not plain.scores_apart
+    assert isinstance(pn.dropout, torch.nn.Dropout) and pn.dropout.p == 0.5 and pn.scores_apart
+    assert list(pn.state_dict().keys()) == list(plain.state_dict().keys())
+    pn.load_state_dict(plain.state_dict())
+    c = torch.randn(2, 5, 256)
+    cand = [torch.randn(2, 3, 5, 256) for _ in range(12)]
+    torch.manual_seed(0)
+    dropped = pn(c, cand)
+    pn.eval()
+    assert not pn.scores_apart
+    for a, b, d in zip(pn(c, cand), plain(c, cand), dropped):
+        assert torch.equal(a, b) and a.shape == (2, 3, 5) and not torch.allclose(a, d)
+    crit = CPCUnsupersivedCriterion(12, 256, 256, 128, dropout=True)
+    assert isinstance(crit.wPrediction.dropout, torch.nn.Dropout)
+
+
 def test_library_contains_no_packed_fp32_arithmetic():
     """build.py's gate with an EMPTY allow-list (round 4): no code object of the library contains v_pk_{fma,mul,add}_f32 -- the
     instruction class behind the co-residency corruption of rounds 1-2."""

@@ -286,3 +286,76 @@ def test_two_trainers_on_two_threads_of_one_device_do_not_disturb_each_other():
         assert torch.equal(alone[key][0], both[key][0]), key
         for k, v in alone[key][1].items():
             assert torch.equal(v, both[key][1][k]), (key, k)
+
+
+class _FixedMask(torch.nn.Module):
+    """Stands in for nn.Dropout(p=0.5) with a mask the oracle can use too: keep -> x / (1 - p)."""
+
+    def __init__(self, keep):
+        super().__init__()
+        self.keep = keep
+
+    def forward(self, x):
+        return x * self.keep * 2.0 if self.training else x
+
+
+def test_prediction_dropout_option_matches_the_oracle_with_the_same_masks():
+    """criterion.py:59,113-114 (``--dropout``): nn.Dropout(p = 0.5) on every head's prediction before the scores.  With the
+    module's masks fixed, losses, accuracies and the gradients of everything in front of the criterion must equal the oracle's
+    (its ``predict`` hook: linear head, then the same mask); in eval mode the option is the identity."""
+    dev = _dev()
+    from cpc_audio_amd.train import build_criterion, build_model, load_flat_params
+    B, K, N, L = 2, 12, 128, 20480
+    S, C = L // 160, 256
+    W = S - K
+    p = O.make_params(seed=7, head_scale=128.0)
+    model = build_model().to(dev)
+    crit = build_criterion(dropout=True).to(dev)
+    assert isinstance(crit.wPrediction.dropout, torch.nn.Dropout) and crit.wPrediction.dropout.p == 0.5
+    load_flat_params(model, crit, p)
+    keep = (torch.rand(B, W, K * C, generator=torch.Generator().manual_seed(21)) < 0.5).float()
+    crit.wPrediction.dropout = _FixedMask(keep.to(dev))
+    wave = O.make_waveform(B, L, seed=10)
+    bi, si = O.draw_negative_indices(B, S, W, N, generator=torch.Generator().manual_seed(5))
+    c, z, _ = model(wave.to(dev), None)
+    losses, acc = crit(c, z, None, negatives=(bi.to(dev), si.to(dev)))
+    losses.sum().backward()
+    # oracle: the same step with predict(k, cw) = dropout_k(W_k cw)
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    co, zo, _ = O.model_forward(leaves, wave)
+    ext = O.negative_rows(bi, si, B, S, W, N)
+    predict = lambda k, cw: (cw @ leaves[f"wPrediction.predictors.{k}.weight"].t()) * keep[:, :, k * C:(k + 1) * C] * 2.0
+    lo, ao = O.criterion_forward(leaves, co, zo, ext, K, predict=predict)
+    lo.sum().backward()
+    assert (losses.detach().cpu() - lo.detach()).abs().max().item() < 1e-4
+    assert (acc.detach().cpu() - ao).abs().max().item() < 2e-3
+    for k_ in range(K):
+        name = f"wPrediction.predictors.{k_}.weight"
+        assert _rel(crit.wPrediction.predictors[k_].weight.grad.cpu(), leaves[name].grad) < 2e-4, name
+    assert _rel(model.gAR.baseNet.weight_hh_l1.grad.cpu(), leaves["gAR.baseNet.weight_hh_l1"].grad) < 2e-4
+    assert _rel(model.gEncoder.conv4.weight.grad.cpu(), leaves["gEncoder.conv4.weight"].grad) < 5e-3
+    # the masked step differs from the plain one (the option does something), and eval mode is the plain criterion
+    plain = O.criterion_forward(leaves, co, zo, ext, K)[0].detach()
+    assert (plain - lo.detach()).abs().max().item() > 1e-3
+    crit.eval()
+    with torch.no_grad():
+        le, _ = crit(c.detach(), z.detach(), None, negatives=(bi.to(dev), si.to(dev)))
+    assert (le.cpu() - plain).abs().max().item() < 1e-4
+
+
+def test_prediction_dropout_with_torchs_own_masks_trains_through_the_trainer():
+    """The real nn.Dropout: the Trainer takes the autograd path (the composite step does not cover it), losses are finite and
+    above the no-dropout loss of the same parameters on average."""
+    dev = _dev()
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model
+    torch.manual_seed(3)
+    model, crit = build_model().to(dev), build_criterion(dropout=True).to(dev)
+    tr = Trainer(model, crit)
+    wave = O.make_waveform(4, 20480, seed=2).to(dev)
+    first = None
+    for _ in range(3):
+        losses, acc = tr.step(wave, None)
+        assert torch.isfinite(losses).all()
+        first = losses if first is None else first
+    assert tr._fused is None                    # never went through cpc_train_step
+    assert float(losses.mean()) < float(first.mean())
