@@ -2,6 +2,7 @@
 #include "cpc_common.h"
 #include "cpc_internal.h"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -25,8 +26,13 @@ hipEvent_t* stream_events(hipStream_t st) {
     auto it = pools.find({dev, st});
     if (it != pools.end()) return it->second;
     hipEvent_t* ev = new hipEvent_t[kStreamEvents];
+    // These events only ever order streams of ONE device against each other (nobody synchronises the host with them, no other
+    // device reads behind them): without the system-scope fence a record does not write the caches back for the host's sake.
+    // CPC_EVENT_SYSTEM_FENCE=1 restores the default (A/B runs).
+    const char* env = getenv("CPC_EVENT_SYSTEM_FENCE");
+    const unsigned flags = hipEventDisableTiming | ((env && env[0] == '1') ? 0u : (unsigned)hipEventDisableSystemFence);
     for (int i = 0; i < kStreamEvents; ++i)
-        if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+        if (hipEventCreateWithFlags(&ev[i], flags) != hipSuccess) {
             for (int j = 0; j < i; ++j) (void)hipEventDestroy(ev[j]);
             delete[] ev;
             return nullptr;
