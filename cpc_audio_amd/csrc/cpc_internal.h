@@ -93,7 +93,7 @@ extern int g_mfma_mode;
 
 // per-(device, caller stream) pool of events for the two-stream entry points: [0..4] encoder backward, [8] GRU backward,
 // [9] criterion backward (score gradients -> dz stream), [12..18] the composite train step (train_step.hip)
-constexpr int kStreamEvents = 20;
+constexpr int kStreamEvents = 21;
 hipEvent_t* stream_events(hipStream_t caller_stream);
 
 // conv_dma.hip: forward conv layer with both operands DMA'd into LDS (H2 storage, cpc_common.h)

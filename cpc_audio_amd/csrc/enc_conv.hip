@@ -176,6 +176,11 @@ __global__ __launch_bounds__(256) void enc_prep_amax_kernel(PrepArgs a) {
     const float m = block_absmax(a.w[y], (long)kC * a.k[y] * kC, blockIdx.x, kPrepParts);
     if (threadIdx.x == 0) a.partial[y * kPrepParts + blockIdx.x] = m;
 }
+// row 4 of enc_prep_amax_kernel on its own (4 workgroups): what layer 0 needs of the preparation -- the bound its H2 output is
+// scaled by -- when the rest runs on another stream beside it (enc_set_weight_prep_stream)
+__global__ __launch_bounds__(256) void enc_prep_bounds_kernel(PrepArgs a) {
+    norm_bound_block(a.nw[blockIdx.x], a.nb[blockIdx.x], a.bound + blockIdx.x);
+}
 __global__ __launch_bounds__(256) void enc_prep_permute_kernel(PrepArgs a) {
     const int b = blockIdx.x;
     int seg = 0;
@@ -1309,6 +1314,12 @@ static thread_local hipEvent_t t_after_conv0 = nullptr;
 static thread_local int t_event_layer = 0;               // the event is recorded behind this layer's launch (0 or 1)
 void enc_set_after_conv0_event(hipEvent_t ev) { t_after_conv0 = ev; t_event_layer = 0; }
 void enc_set_forward_event(int layer, hipEvent_t ev) { t_after_conv0 = ev; t_event_layer = layer; }
+// train_step.hip: a second stream (already ordered behind the start of the step) for the weight preparation of layers 1..4 --
+// 36 us of small kernels that depend on the parameters only and that layer 0 does not need (but for the four ChannelNorm
+// bounds, which then get a 4-workgroup launch of their own in front of it) -- and the event layer 1 waits for; per host thread
+static thread_local hipStream_t t_prep_stream = nullptr;
+static thread_local hipEvent_t t_prep_done = nullptr;
+void enc_set_weight_prep_stream(hipStream_t st, hipEvent_t done) { t_prep_stream = st; t_prep_done = done; }
 }  // namespace cpc
 
 // params: 20 pointers in the reference's state-dict order
@@ -1342,16 +1353,23 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
     a.partial = scratch + e.famax;
     a.split = weight_split();
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(enc_prep_amax_kernel, dim3(kPrepParts, 5), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(enc_prep_permute_kernel, dim3(nblk), dim3(256), 0, st, a);
+    const bool apart = t_prep_stream && t_prep_done && t_prep_stream != st;
+    hipStream_t pst = apart ? t_prep_stream : st;
+    if (apart) hipLaunchKernelGGL(enc_prep_bounds_kernel, dim3(4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(enc_prep_amax_kernel, dim3(kPrepParts, apart ? 4 : 5), dim3(256), 0, pst, a);
+    hipLaunchKernelGGL(enc_prep_permute_kernel, dim3(nblk), dim3(256), 0, pst, a);
     CPC_LAUNCH_CHECK();
-    if (g_mfma_mode >= 3 && hipMemsetAsync(saved + e.szero, 0, 64 * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+    if (g_mfma_mode >= 3 && hipMemsetAsync(saved + e.szero, 0, 64 * sizeof(float), pst) != hipSuccess) return CPC_ERR_ARG;
+    if (apart && hipEventRecord(t_prep_done, pst) != hipSuccess) return CPC_ERR_ARG;
+    // (layer 0 reads none of it; layers 1..4 wait below)
+    auto join_prep = [&]() { return !apart || hipStreamWaitEvent(st, t_prep_done, 0) == hipSuccess; };
     if (e.bf16) {
         // bf16-storage variant: y0..y3 and xhat1..4 as bf16 (half the activation bytes), weights rounded to bf16 by the
         // re-layout, one bf16 MFMA per product, fp32 accumulators and ChannelNorm statistics; z stays fp32
         int rc = conv0_forward_bf16(wave, params[0], params[1], params[2], params[3], saved + e.y[0], saved + e.mean0,
                                     saved + e.rstd[0], B, L, st);
         if (!rc && t_after_conv0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
+        if (!join_prep()) return CPC_ERR_ARG;
         for (int i = 1; i < 5 && !rc; ++i)
             rc = conv_fwd_dma_bf16(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2], params[4 * i + 3],
                                    i == 4 ? z : saved + e.y[i], i == 4, saved + e.xhat[i], saved + e.rstd[i], saved + e.szero,
@@ -1362,6 +1380,7 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
                                   saved + e.rstd[0], act_h2(0) ? saved + e.sbound + 1 : nullptr, B, L, stream);
     if (rc) return rc;
     if (t_after_conv0 && t_event_layer == 0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
+    if (!join_prep()) return CPC_ERR_ARG;
     for (int i = 1; i < 5; ++i) {
         if (i == 2 && t_after_conv0 && t_event_layer == 1 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
         float* yo = i == 4 ? z : saved + e.y[i];

@@ -67,6 +67,8 @@ int g_prep_point = 1;     // where the criterion's index preparation is released
                           // HBM-bound layer goes from 50 to 96 us), 1 (default) behind conv0 (beside conv1 / conv2: +20 us there),
                           // 2 behind the encoder (beside the recurrence, whose hand-over it disturbs), 3 behind conv1 (beside conv2..4)
 int g_no_early = 0;
+int g_weight_prep_apart = 0;   // 1: the conv weight layouts on the preparation stream beside layer 0 instead of in front of it on main
+                               // (measured: +8 us per step -- the 36 us they free on main, layer 0 and layer 1's wait give back)
 int g_dz_early = 0;       // 1: the dz path on MAIN before the recurrence's backward (which then has the memory system to itself)
                           // instead of beside it on the side stream
 
@@ -78,16 +80,18 @@ inline bool wait(hipStream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 
 // enc_conv.hip: an event cpc_encoder_forward records on its stream right behind layer 0's launch (nullptr: none)
 void enc_set_after_conv0_event(hipEvent_t ev);
 void enc_set_forward_event(int layer, hipEvent_t ev);
+void enc_set_weight_prep_stream(hipStream_t st, hipEvent_t done);
 
 }  // namespace cpc
 
 using namespace cpc;
 
 extern "C" int cpc_set_step_schedule(int prep_point, int dz_early) {
-    CPC_RETURN_IF(prep_point < 0 || prep_point > 3 || dz_early < 0 || dz_early > 3, CPC_ERR_ARG);
+    CPC_RETURN_IF(prep_point < 0 || prep_point > 3 || dz_early < 0 || dz_early > 7, CPC_ERR_ARG);
     g_prep_point = prep_point;
     g_dz_early = dz_early & 1;
     g_no_early = (dz_early >> 1) & 1;      // + 2: the small weight-only launches stay on the main stream where round 3 had them (A/B)
+    g_weight_prep_apart = (dz_early >> 2) & 1;      // + 4: the conv weight layouts beside layer 0 on the preparation stream (A/B)
     return 0;
 }
 
@@ -115,7 +119,7 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
     CPC_RETURN_IF(!pool, CPC_ERR_ARG);
     hipEvent_t* ev = pool + 12;     // [0] begin, [1] index lists + bounds ready, [2] recurrence-backward preparation ready,
                                     // [3] score gradients ready, [4] dz done, [5] head gradient done, [6] conv0 launched / encoder done,
-                                    // [7] forward recurrence's hand-over buffers filled
+                                    // [7] forward recurrence's hand-over buffers filled, [8] conv weight layouts ready
     float* ws = workspace;
     const float* const* enc_p = params;
     const float* const* gru_p = params + kEncParams;
@@ -136,11 +140,6 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
         // the step begins here on main: the other streams fork from this point (the workspace is the previous step's, whose
         // last users main has waited for)
         CPC_RETURN_IF(!rec(ev[0], M) || !wait(S1, ev[0]), CPC_ERR_ARG);
-        // the hand-over buffers of the forward recurrence pre-filled beside the encoder instead of between the input projection
-        // and the recurrence
-        rc = cpc_gru_forward_prepare(ws + s.gru_fscr, B, S, 2, S1);
-        if (rc) return rc;
-        CPC_RETURN_IF(!rec(ev[7], S1), CPC_ERR_ARG);
         const bool bounds_early = c_bound > 0.f;
         const bool early = bounds_early && !g_no_early;      // the criterion's operand bounds do not depend on c: its backward's weight-only share too
         auto prepare = [&]() -> int {      // index lists of the draws + operand bounds of the prediction GEMMs: depend on no activation
@@ -160,9 +159,18 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
         }
         if (g_prep_point == 3) enc_set_forward_event(1, ev[6]);
         else enc_set_after_conv0_event(g_prep_point == 1 ? ev[6] : nullptr);
+        // (switch, off: the weight layouts of layers 1..4 -- 36 us of small kernels on the parameters alone -- first thing on the
+        // preparation stream, beside layer 0, which needs only their four bounds)
+        enc_set_weight_prep_stream(g_weight_prep_apart ? S1 : nullptr, ev[8]);
         rc = cpc_encoder_forward(wave, enc_p, ws + s.enc_saved, ws + s.enc_fscr, z, B, L, M);
         enc_set_after_conv0_event(nullptr);
+        enc_set_weight_prep_stream(nullptr, nullptr);
         if (rc) return rc;
+        // the hand-over buffers of the forward recurrence pre-filled beside the encoder instead of between the input projection
+        // and the recurrence (queued behind the weight layouts: the recurrence is 0.4 ms away)
+        rc = cpc_gru_forward_prepare(ws + s.gru_fscr, B, S, 2, S1);
+        if (rc) return rc;
+        CPC_RETURN_IF(!rec(ev[7], S1), CPC_ERR_ARG);
         if (g_prep_point == 1 || g_prep_point == 3) {
             CPC_RETURN_IF(!wait(S0, ev[6]), CPC_ERR_ARG);
             if ((rc = prepare())) return rc;

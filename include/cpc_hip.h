@@ -428,7 +428,9 @@ int cpc_train_step_prefetch(const long* batchIdx, const long* seqIdx, float* wor
 /* Measurement switches of cpc_train_step's schedule.  prep_point: where the criterion's index preparation (190 MB of index
  * traffic at B = 64) is released on side_stream -- 0 at the step's start (beside conv0, the one HBM-bound layer: 50 -> 96 us), 1
  * (default) behind conv0 (beside conv1 / conv2), 2 behind the encoder (beside the recurrence), 3 behind conv1 (beside conv2..conv4).  dz_early: 1 = the dz path on main_stream BEFORE the recurrence's
- * backward (which then has the memory system to itself) instead of beside it on side_stream (0, default). */
+ * backward (which then has the memory system to itself) instead of beside it on side_stream (0, default); + 2 = the small
+ * weight-only launches of the criterion / recurrence stay on main_stream; + 4 = the weight layouts of conv layers 1..4 are
+ * prepared beside layer 0 on prep_stream instead of in front of it on main_stream (measured 8 us slower). */
 int cpc_set_step_schedule(int prep_point, int dz_early);
 
 /* ---- optimiser -------------------------------------------------------------------------------------------------

@@ -61,6 +61,7 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 // events: every launch of the emulator completes before it returns, so ordering between streams is trivially kept
 typedef struct ihipEvent_t* hipEvent_t;
 #define hipEventDisableTiming 2
+#define hipEventDisableSystemFence 0x20000000
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }

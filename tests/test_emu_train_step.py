@@ -29,7 +29,8 @@ def _setup(B, L, K, N, seed=0, head_scale=64.0):
     return p, wave, S, bidx, sidx, plist
 
 
-def _composite(lib, wave, bidx, sidx, h0, c_bound, plist, B, L, K, N, phases=(3,), schedule=_L.DEFAULT_STEP_SCHEDULE):
+def _composite(lib, wave, bidx, sidx, h0, c_bound, plist, B, L, K, N, phases=(3,), schedule=_L.DEFAULT_STEP_SCHEDULE,
+               streams=(None, None, None, None)):
     sizes = (ctypes.c_long * 8)()
     assert lib.cpc_train_step_layout(B, L, K, N, sizes) == 0
     ws = torch.full((sizes[0],), float("nan"))
@@ -43,7 +44,7 @@ def _composite(lib, wave, bidx, sidx, h0, c_bound, plist, B, L, K, N, phases=(3,
     try:
         for ph in phases:
             rc = lib.cpc_train_step(P(wave), P(bidx), P(sidx), P(h0), c_bound, parr, garr, P(ones), P(ws), out[0].data_ptr(),
-                                    out[1].data_ptr(), P(hN), B, L, K, N, ph, None, None, None, None)
+                                    out[1].data_ptr(), P(hN), B, L, K, N, ph, *[None if h is None else ctypes.c_void_p(h) for h in streams])
             assert rc == 0
     finally:
         lib.cpc_set_step_schedule(*_L.DEFAULT_STEP_SCHEDULE)
@@ -136,8 +137,12 @@ def test_composite_step_phase_split_and_schedule_switches_change_no_bit_emulated
     B, L, K, N = 2, 2560, 4, 16
     p, wave, S, bidx, sidx, plist = _setup(B, L, K, N, seed=1)
     ref = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N)
-    for phases, schedule in (((1, 2), (0, 0)), ((3,), (2, 1)), ((1, 2), (3, 3))):
-        got = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N, phases=phases, schedule=schedule)
+    # (distinct stream handles take the branches that fork work onto the side streams -- e.g. the conv weight layouts prepared
+    #  on the preparation stream beside layer 0 with only their bounds in front of it; the emulator runs every stream in issue order)
+    apart = (None, 64, 128, 192)
+    for phases, schedule, streams in (((1, 2), (0, 0), (None,) * 4), ((3,), (2, 1), (None,) * 4), ((1, 2), (3, 3), apart),
+                                      ((3,), (1, 0), apart), ((3,), (1, 4), apart)):
+        got = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N, phases=phases, schedule=schedule, streams=streams)
         assert torch.equal(ref[0], got[0]) and torch.equal(ref[3], got[3]) and torch.equal(ref[4], got[4])
         for a, b in zip(ref[2], got[2]):
             assert torch.equal(a, b), (phases, schedule)
@@ -149,7 +154,7 @@ def test_composite_step_argument_errors():
     assert lib.cpc_train_step_layout(0, 3200, 4, 16, sizes) == 1              # CPC_ERR_SHAPE
     assert lib.cpc_train_step_layout(2, 3200, 4, 10, sizes) == 1              # N % 16
     assert lib.cpc_train_step_layout(2, 1600, 12, 16, sizes) == 1             # S = 10 <= K
-    assert lib.cpc_set_step_schedule(4, 0) == 2 and lib.cpc_set_step_schedule(0, 4) == 2
+    assert lib.cpc_set_step_schedule(4, 0) == 2 and lib.cpc_set_step_schedule(0, 8) == 2
     assert lib.cpc_train_step(None, None, None, None, 1.0, None, None, None, None, None, None, None, 2, 3200, 4, 16, 3,
                               None, None, None, None) == 2
 
