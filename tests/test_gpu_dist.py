@@ -206,6 +206,10 @@ def test_bench_through_the_launcher_walks_the_multi_rank_code_paths_on_one_gpu()
         assert line["sustained"]["steps"] >= 6 and line["sustained"]["ms_per_step"] > 0
         assert line["config"]["launch"].startswith("eager")
     assert "forced_dist" in forced["config"] and "forced_dist" not in plain["config"]
+    # the N > 1 line carries what its two gradient all-reduces cost on their own (11.6 MB in two buckets)
+    assert "dist" not in plain and forced["dist"]["backend"] == "nccl"
+    assert sum(forced["dist"]["bytes"].values()) == 4 * 2893056
+    assert all(0 < v < 5.0 for v in forced["dist"]["allreduce_ms"].values()), forced["dist"]
     # same seeds, same steps; the all-reduce of one rank adds nothing
     assert forced["config"]["loss_mean_over_heads"] == plain["config"]["loss_mean_over_heads"]
     ratio = forced["sustained"]["ms_per_step"] / plain["sustained"]["ms_per_step"]
