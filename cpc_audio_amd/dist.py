@@ -176,10 +176,12 @@ class FlatGradAllReduce:
         """A step raised after begin(): let the early bucket's collective finish (every rank issued it; dropping the
         handle would leave the next step waiting on a stale one and copying last step's sums into .grad) and forget it."""
         pending, self._pending = self._pending, None
-        self._pending_event = None
+        event, self._pending_event = self._pending_event, None
         if pending is not None:
             try:
                 pending.wait()
+                if event is not None:                          # ... and the next step's writers of the flat buffer come behind it
+                    torch.cuda.current_stream().wait_event(event)
             except Exception:                                  # the group may be the thing that failed
                 pass
 
