@@ -51,6 +51,18 @@ def _worker(rank, world, port, out):
         p.grad = torch.full_like(p, float(rank + i))
     ar2()
     ok = ok and all(torch.equal(p.grad, torch.full_like(p, float(1 + 2 * i))) for i, p in enumerate(params))
+    # a step that raised after begin(): abort() lets the early bucket's collective finish on every rank and forgets it; the next
+    # step's two-bucket exchange starts clean
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, 100.0)
+    ar2.begin()
+    ar2.abort()
+    ok = ok and ar2._pending is None and ar2._pending_event is None
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+    ar2.begin()
+    ar2()
+    ok = ok and all(torch.equal(p.grad, torch.full_like(p, float(3 * (i + 1)))) for i, p in enumerate(params))
     # sharding: each rank draws its own sequences; no overlap, identical parameters
     g = torch.Generator().manual_seed(1234 + rank)
     wave = (0.1 * torch.randn(2, 1, 64, generator=g)).clamp_(-1, 1)

@@ -45,6 +45,11 @@ def test_two_bucket_allreduce_on_side_stream_single_rank():
             tr.allreduce.single_rank_too = on
             assert tr.allreduce.early and tr.allreduce.late
             assert {id(q) for q in tr.allreduce.late} == {id(q) for q in model.gEncoder.parameters()}
+            if on:      # a step that raised after its early bucket went out: abort() drains it, the next step starts clean
+                tr.allreduce.begin(tr.ctx)
+                assert tr.allreduce._pending is not None and tr.allreduce._pending_event is not None
+                tr.allreduce.abort()
+                assert tr.allreduce._pending is None and tr.allreduce._pending_event is None
             for bidx, sidx in draws:
                 tr.step(wave, label, negatives=(bidx.to(dev), sidx.to(dev)))
             torch.cuda.synchronize()
