@@ -13,13 +13,13 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcpc_hip.so")
 DEFAULT_GRU_MODE = 2       # cpc_set_gru_mode: persistent recurrence, forward products on the fp16 split
 DEFAULT_MFMA_MODE = 3      # what libcpc_hip starts in (cpc_set_mfma_mode): mode 2's arithmetic (two fp16 pieces, 3 MFMAs per
 #                            product) with conv1 / its gradients on the DMA-fed kernels reading H2-stored activations
-EXPECTED_ABI = 12          # cpc_abi_version() of the library these signatures were written for: a stale or variant build that
+EXPECTED_ABI = 13          # cpc_abi_version() of the library these signatures were written for: a stale or variant build that
 #                            exports every symbol with OLDER argument lists would corrupt memory instead of raising -- bind() refuses it
-DEFAULT_DMA_PIPELINE = 2
+DEFAULT_DMA_PIPELINE = 2       # cpc_set_dma_pipeline: the tap-pair walk where the shape allows, two 32-k stages elsewhere
 DEFAULT_WGRAD_DMA_STAGES = 4   # cpc_set_wgrad_dma_stages
 DEFAULT_CONV_SMALL_PIPE = 1    # cpc_set_conv_small_pipe
 DEFAULT_DGRAD_NSPLIT = 0       # cpc_set_dgrad_nsplit
-DEFAULT_STEP_SCHEDULE = (1, 0)  # cpc_set_step_schedule: index preparation behind conv0, dz path beside the recurrence   # cpc_set_dma_pipeline: the tap-pair walk where the shape allows, two 32-k stages elsewhere
+DEFAULT_STEP_SCHEDULE = (1, 0)  # cpc_set_step_schedule: index preparation behind conv0, dz path beside the recurrence
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -71,6 +71,7 @@ SIGNATURES = {
     "cpc_encoder_layout": (_I, [_I, _I, _P]),
     "cpc_encoder_saved_activation": (_I, [_P, _I, _P, _I, _I, _P]),
     "cpc_encoder_forward": (_I, [_P] * 5 + [_I, _I, _P]),
+    "cpc_encoder_prepare_weights": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "cpc_encoder_backward": (_I, [_P] * 7 + [_I, _I, _P]),
     "cpc_encoder_backward_streams": (_I, [_P] * 7 + [_I, _I, _P, _P]),
     "cpc_set_conv_tile": (_I, [_I]),
@@ -115,6 +116,10 @@ SIGNATURES = {
     "cpc_train_step_layout": (_I, [_I, _I, _I, _I, _P]),
     "cpc_train_step_prefetch": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "cpc_train_step": (_I, [_P, _P, _P, _P, _F] + [_P] * 7 + [_I] * 5 + [_P] * 4),
+    "cpc_train_step_tail": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "cpc_train_step_wait": (_I, [_P, _I, _P]),
+    "cpc_set_step_timing": (_I, [_I]),
+    "cpc_get_step_timing": (_I, [_P]),
     "cpc_adam_step": (_I, [_P] * 5 + [_I] + [ctypes.c_double] * 6 + [_P]),
     "cpc_adam_step_capturable": (_I, [_P] * 5 + [_I] + [ctypes.c_double] * 4 + [_P, _P, _P]),
 }

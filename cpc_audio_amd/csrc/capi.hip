@@ -40,6 +40,10 @@ hipEvent_t* stream_events(hipStream_t st) {
     pools[{dev, st}] = ev;
     return ev;
 }
+StepHooks& step_hooks() {
+    static thread_local StepHooks h;
+    return h;
+}
 }  // namespace cpc
 
 // Drop (and destroy) the events this library keeps for `stream` on the current device; a no-op for a stream it never saw.
@@ -56,7 +60,7 @@ extern "C" int cpc_release_stream(void* stream) {
     return 0;
 }
 
-extern "C" int cpc_abi_version(void) { return 12; }
+extern "C" int cpc_abi_version(void) { return 13; }
 
 // A kernel that keeps one wavefront busy for `ticks` of the 100 MHz wall clock (bounded: it gives up after ~2^14 sleeps).
 __global__ void spin_kernel(unsigned long long ticks) {

@@ -91,10 +91,34 @@ int transpose_batch(const float* const* in, float* const* out, int n, int R, int
 // accuracy); 0: exact-f32 MFMA (NtTile).  Set through cpc_set_mfma_mode().
 extern int g_mfma_mode;
 
-// per-(device, caller stream) pool of events for the two-stream entry points: [0..4] encoder backward, [8] GRU backward,
-// [9] criterion backward (score gradients -> dz stream), [12..18] the composite train step (train_step.hip)
-constexpr int kStreamEvents = 21;
+// per-(device, caller stream) pool of events for the two-stream entry points: [0..4] encoder backward, [5] everything of the
+// weight-gradient stream but layer 1's weight gradient is done (recorded there by the encoder's backward: what a mid gradient
+// bucket / an open-tailed step waits for), [7] layer 1's weight gradient reduced, [8] GRU backward, [9] criterion backward
+// (score gradients -> dz stream), [12..20] the composite train step (train_step.hip), [21] conv1's updated weight and its
+// layouts ready for the next step (cpc_train_step_tail)
+constexpr int kStreamEvents = 24;
+constexpr int kEvWgradRest = 5, kEvWgrad1 = 7, kEvNextConv1 = 21;
 hipEvent_t* stream_events(hipStream_t caller_stream);
+
+// ---- hooks of the composite step into the per-stage entry points (train_step.hip sets them around its calls; per host
+// thread; all default to "off") -------------------------------------------------------------------------------------------
+struct StepHooks {
+    int parity = 0;               // which of the two y0 buffers / input-bound sets of the encoder workspace this step uses
+    bool weights_ready = false;   // the conv weight layouts, max|w| and input bounds of this parity were prepared by the previous
+                                  // step's tail (cpc_train_step_tail): the forward launches no preparation
+    hipEvent_t conv1_wait = nullptr;   // the forward's stream waits for this event in front of layer 1 (its updated weight)
+    bool open_tail = false;       // encoder backward: the caller's stream is joined with everything of the weight-gradient stream
+                                  // BUT layer 1's weight gradient (event kEvWgradRest); kEvWgrad1 is recorded behind that one
+    hipEvent_t* timers = nullptr; // in-step timing (cpc_set_step_timing): 8 timing-enabled events, or nullptr
+};
+StepHooks& step_hooks();
+// record timing event `idx` on `st` if in-step timing is on: [0] before conv0, [1] behind conv0, [7] in front of conv1 (behind
+// its stream waits), [2] behind conv1, [3] / [4] around the forward recurrence's persistent launch(es), [5] / [6] around the
+// backward recurrence's
+inline void step_timer_mark(int idx, hipStream_t st) {
+    hipEvent_t* t = step_hooks().timers;
+    if (t) (void)hipEventRecord(t[idx], st);
+}
 
 // conv_dma.hip: forward conv layer with both operands DMA'd into LDS (H2 storage, cpc_common.h)
 int conv_fwd_dma(const float* x_h2, const float* wq, const float* bias, const float* nw, const float* nb, float* y,

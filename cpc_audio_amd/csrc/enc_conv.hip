@@ -166,13 +166,15 @@ struct PrepArgs {
     int fwd_h2[4];          // 1: forward layout of layer y+1 in K-tile-major H2 rows (the DMA kernel's, conv_dma.hip);
                             // 2: forward AND dgrad layouts in K-tile-major bf16 rows (mode 4)
     int dgrad_h2[4];        // 1: dgrad layout of layer y+1 in K-tile-major H2 rows (conv_dgrad_dma_kernel<.., 2>)
+    int mask;               // bit i (1..4): layer i is prepared by this launch; bit 0: the four input bounds
 };
 __global__ __launch_bounds__(256) void enc_prep_amax_kernel(PrepArgs a) {
     const int y = blockIdx.y;
     if (y == 4) {
-        if (blockIdx.x < 4) norm_bound_block(a.nw[blockIdx.x], a.nb[blockIdx.x], a.bound + blockIdx.x);
+        if (blockIdx.x < 4 && (a.mask & 1)) norm_bound_block(a.nw[blockIdx.x], a.nb[blockIdx.x], a.bound + blockIdx.x);
         return;
     }
+    if (!((a.mask >> (y + 1)) & 1)) return;                   // block-uniform
     const float m = block_absmax(a.w[y], (long)kC * a.k[y] * kC, blockIdx.x, kPrepParts);
     if (threadIdx.x == 0) a.partial[y * kPrepParts + blockIdx.x] = m;
 }
@@ -898,13 +900,20 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     for (int i = 0; i < 5; ++i) e.dxh2[i] = i >= 1 && g_h2_dx && e.h2[i - 1];
     long o = 0;
     for (int i = 0; i < 4; ++i) { e.y[i] = o; o += align64((long)B * e.L[i] * kC); }
+    // Layer 0's output twice: the composite train step alternates between the two (StepHooks::parity) so that the NEXT step's
+    // layer 0 may run while this step's last kernel -- layer 1's weight gradient, which reads y0 -- is still at work
+    // (cpc_train_step, open tail).  Every other caller uses buffer 0.
+    const long y0b = o; o += align64((long)B * e.L[0] * kC);
+    const int parity = step_hooks().parity & 1;
+    if (parity) e.y[0] = y0b;
     e.xhat[0] = -1;
     for (int i = 1; i < 5; ++i) { e.xhat[i] = o; o += align64((long)B * e.L[i] * kC); }
     for (int i = 0; i < 5; ++i) { e.rstd[i] = o; o += align64((long)B * e.L[i]); }
     e.mean0 = o; o += align64((long)B * e.L[0]);
     e.swd[0] = -1;
     for (int i = 1; i < 5; ++i) { e.swd[i] = o; o += align64((long)kC * kGeom[i].k * kC * 3 / 2); }
-    e.sbound = o; o += 64;                 // [i] = bound of layer i's input (fp16-split mode), i = 1..4
+    e.sbound = o + 16 * parity; o += 64;   // [i] = bound of layer i's input (fp16-split mode), i = 1..4; one set per parity: the next
+                                           // step's bounds (new norm parameters) are written while layer 1's weight gradient reads this step's
     e.szero = o; o += 64;                  // zeros: what the DMA kernel reads for the conv's padding rows
     e.saved_total = o;
 
@@ -1322,16 +1331,12 @@ static thread_local hipEvent_t t_prep_done = nullptr;
 void enc_set_weight_prep_stream(hipStream_t st, hipEvent_t done) { t_prep_stream = st; t_prep_done = done; }
 }  // namespace cpc
 
-// params: 20 pointers in the reference's state-dict order
-//   conv{i}.weight, conv{i}.bias, batchNorm{i}.weight, batchNorm{i}.bias  for i = 0..4
-extern "C" int cpc_encoder_forward(const float* wave, const float* const* params, float* saved,
-                                   float* scratch, float* z, int B, int L, void* stream) {
-    EncLayout e;
-    CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
-    // every weight-only quantity of layers 1..4 -- both GEMM layouts, max|w|, the bounds of the layers' inputs (the
-    // previous layer's ChannelNorm + ReLU output is bounded by its affine) -- in two launches; the backward finds the
-    // dgrad layouts and the bounds in `saved`.  First, because in mode 3 conv0 already writes its output scaled by the
-    // bound of layer 1's input.
+// Every weight-only quantity of layers 1..4 -- both GEMM layouts, max|w|, the bounds of the layers' inputs (the previous layer's
+// ChannelNorm + ReLU output is bounded by its affine) -- in two launches; the backward finds the dgrad layouts and the bounds in
+// `saved`.  mask: bit i (1..4) = layer i's layouts, bit 0 = the four input bounds (+ the zero row the DMA kernels read for the
+// conv's padding).  apart: the bounds by a 4-workgroup launch of their own on `st`, everything else on `pst`.
+static int enc_prepare_weights(const EncLayout& e, const float* const* params, float* saved, float* scratch, int mask,
+                               hipStream_t st, hipStream_t pst) {
     PrepArgs a;
     int nblk = 0;
     for (int i = 1; i < 5; ++i) {
@@ -1344,7 +1349,7 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
         a.dgrad_h2[i - 1] = e.dxh2[i] && e.dma[i];      // (the register-staged tiles keep the k-blocked weight layouts)
         a.fwd_h2[i - 1] = e.bf16 ? 2 : e.dma[i];        // 1: layer i runs on the DMA kernel (its K-tile-major H2 weight rows);
                                                         // 2: bf16 storage (both layouts in bf16 K-tile-major rows)
-        const int per = cdiv((long)kC * kGeom[i].k * kC, 256);
+        const int per = ((mask >> i) & 1) ? cdiv((long)kC * kGeom[i].k * kC, 256) : 0;
         a.blk0[2 * (i - 1)] = nblk; nblk += per;
         a.blk0[2 * (i - 1) + 1] = nblk; nblk += per;
     }
@@ -1352,36 +1357,78 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
     a.bound = saved + e.sbound + 1;
     a.partial = scratch + e.famax;
     a.split = weight_split();
-    hipStream_t st = (hipStream_t)stream;
-    const bool apart = t_prep_stream && t_prep_done && t_prep_stream != st;
-    hipStream_t pst = apart ? t_prep_stream : st;
-    if (apart) hipLaunchKernelGGL(enc_prep_bounds_kernel, dim3(4), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(enc_prep_amax_kernel, dim3(kPrepParts, apart ? 4 : 5), dim3(256), 0, pst, a);
-    hipLaunchKernelGGL(enc_prep_permute_kernel, dim3(nblk), dim3(256), 0, pst, a);
+    a.mask = mask;
+    const bool apart = pst != st;
+    if (apart && (mask & 1)) hipLaunchKernelGGL(enc_prep_bounds_kernel, dim3(4), dim3(256), 0, st, a);
+    if (apart) a.mask &= ~1;
+    hipLaunchKernelGGL(enc_prep_amax_kernel, dim3(kPrepParts, (a.mask & 1) ? 5 : 4), dim3(256), 0, pst, a);
+    if (nblk > 0) hipLaunchKernelGGL(enc_prep_permute_kernel, dim3(nblk), dim3(256), 0, pst, a);
     CPC_LAUNCH_CHECK();
-    if (g_mfma_mode >= 3 && hipMemsetAsync(saved + e.szero, 0, 64 * sizeof(float), pst) != hipSuccess) return CPC_ERR_ARG;
+    if ((mask & 1) && g_mfma_mode >= 3 && hipMemsetAsync(saved + e.szero, 0, 64 * sizeof(float), pst) != hipSuccess) return CPC_ERR_ARG;
+    return 0;
+}
+
+// The preparation alone, for a caller that runs it ahead of the forward (cpc_train_step_tail: at the end of the previous step,
+// right behind the optimiser's update, into the NEXT step's parity -- StepHooks -- and with layer 1's share on the stream its
+// weight arrives on).  The forward that follows must be told (StepHooks::weights_ready).
+extern "C" int cpc_encoder_prepare_weights(const float* const* params, float* saved, float* scratch, int B, int L, int mask,
+                                           void* stream) {
+    EncLayout e;
+    CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!params || !saved || !scratch || mask <= 0 || mask > 31, CPC_ERR_ARG);
+    return enc_prepare_weights(e, params, saved, scratch, mask, (hipStream_t)stream, (hipStream_t)stream);
+}
+
+// params: 20 pointers in the reference's state-dict order
+//   conv{i}.weight, conv{i}.bias, batchNorm{i}.weight, batchNorm{i}.bias  for i = 0..4
+extern "C" int cpc_encoder_forward(const float* wave, const float* const* params, float* saved,
+                                   float* scratch, float* z, int B, int L, void* stream) {
+    EncLayout e;
+    CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
+    // the weight preparation first, because in mode 3 conv0 already writes its output scaled by the bound of layer 1's input
+    // (unless the previous step's tail has done it: StepHooks::weights_ready)
+    hipStream_t st = (hipStream_t)stream;
+    const StepHooks& hk = step_hooks();
+    const bool apart = !hk.weights_ready && t_prep_stream && t_prep_done && t_prep_stream != st;
+    hipStream_t pst = apart ? t_prep_stream : st;
+    if (!hk.weights_ready) {
+        const int rcp = enc_prepare_weights(e, params, saved, scratch, 31, st, pst);
+        if (rcp) return rcp;
+    }
     if (apart && hipEventRecord(t_prep_done, pst) != hipSuccess) return CPC_ERR_ARG;
-    // (layer 0 reads none of it; layers 1..4 wait below)
-    auto join_prep = [&]() { return !apart || hipStreamWaitEvent(st, t_prep_done, 0) == hipSuccess; };
+    // (layer 0 reads none of it; layers 1..4 wait below -- for the preparation stream, or for the event behind layer 1's updated
+    // weight when the previous step left its tail open)
+    auto join_prep = [&]() {
+        if (hk.conv1_wait && hipStreamWaitEvent(st, hk.conv1_wait, 0) != hipSuccess) return false;
+        return !apart || hipStreamWaitEvent(st, t_prep_done, 0) == hipSuccess;
+    };
+    step_timer_mark(0, st);
     if (e.bf16) {
         // bf16-storage variant: y0..y3 and xhat1..4 as bf16 (half the activation bytes), weights rounded to bf16 by the
         // re-layout, one bf16 MFMA per product, fp32 accumulators and ChannelNorm statistics; z stays fp32
         int rc = conv0_forward_bf16(wave, params[0], params[1], params[2], params[3], saved + e.y[0], saved + e.mean0,
                                     saved + e.rstd[0], B, L, st);
         if (!rc && t_after_conv0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
+        step_timer_mark(1, st);
         if (!join_prep()) return CPC_ERR_ARG;
-        for (int i = 1; i < 5 && !rc; ++i)
+        step_timer_mark(7, st);
+        for (int i = 1; i < 5 && !rc; ++i) {
             rc = conv_fwd_dma_bf16(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2], params[4 * i + 3],
                                    i == 4 ? z : saved + e.y[i], i == 4, saved + e.xhat[i], saved + e.rstd[i], saved + e.szero,
                                    B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p, st);
+            if (i == 1) step_timer_mark(2, st);
+        }
         return rc;
     }
     int rc = cpc_conv0_forward_h2(wave, params[0], params[1], params[2], params[3], saved + e.y[0], saved + e.mean0,
                                   saved + e.rstd[0], act_h2(0) ? saved + e.sbound + 1 : nullptr, B, L, stream);
     if (rc) return rc;
     if (t_after_conv0 && t_event_layer == 0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
+    step_timer_mark(1, st);
     if (!join_prep()) return CPC_ERR_ARG;
+    step_timer_mark(7, st);
     for (int i = 1; i < 5; ++i) {
+        if (i == 2) step_timer_mark(2, st);
         if (i == 2 && t_after_conv0 && t_event_layer == 1 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
         float* yo = i == 4 ? z : saved + e.y[i];
         if (e.dma[i]) {
@@ -1519,6 +1566,7 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
         // dgrad and only slows it down when both fight for the matrix pipes (0.66 + 0.44 ms together vs 0.29 + 0.30 alone);
         // it is released behind that dgrad and runs beside conv0's VALU-bound backward instead
         const bool late1 = ev && i == 1 && !g_wgrad1_early;
+        if (late1 && hipEventRecord(ev[kEvWgradRest], wst) != hipSuccess) return CPC_ERR_ARG;   // all of wst but layer 1's weight gradient
         if (ev && !late1) {
             if (hipEventRecord(ev[i], st) != hipSuccess || hipStreamWaitEvent(wst, ev[i], 0) != hipSuccess)
                 return CPC_ERR_ARG;
@@ -1587,8 +1635,13 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     hipLaunchKernelGGL(small_to_grads_kernel, dim3(12), dim3(256), 0, st, small, gp);
     CPC_LAUNCH_CHECK();
     if (ev) {                                            // join: everything written on the weight-gradient stream
-        if (hipEventRecord(ev[0], wst) != hipSuccess || hipStreamWaitEvent(st, ev[0], 0) != hipSuccess)
-            return CPC_ERR_ARG;
+        const bool late1 = !g_wgrad1_early;
+        if (hipEventRecord(ev[kEvWgrad1], wst) != hipSuccess) return CPC_ERR_ARG;
+        if (!late1 && hipEventRecord(ev[kEvWgradRest], wst) != hipSuccess) return CPC_ERR_ARG;      // (no earlier point in this order)
+        // open tail (the composite step at N = 1, StepHooks): `st` takes up everything but layer 1's weight gradient; the caller
+        // orders what reads that gradient -- its optimiser update, on wst itself -- and the next step's layer 1 behind it
+        const bool open = step_hooks().open_tail && late1;
+        if (hipStreamWaitEvent(st, ev[open ? kEvWgradRest : kEvWgrad1], 0) != hipSuccess) return CPC_ERR_ARG;
     }
     return 0;
 }

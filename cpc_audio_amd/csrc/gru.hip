@@ -1161,10 +1161,12 @@ static int gru_forward_impl(const float* x, const float* h0, const float* const*
             p.xh[0] = scratch + g.xh; p.xh[1] = scratch + g.xh + g.xh_floats;
             if (coef) { p.coef[0] = coef; p.coef[1] = coef + 4 * g.frag_floats; }
             if (!xh_ready && hipMemsetAsync(p.xh[0], 0xFF, 2 * g.xh_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+            step_timer_mark(3, st);
             for (p.tile0 = 0; p.tile0 < p.total_tiles; p.tile0 += p.ntiles) {
                 if (h2) hipLaunchKernelGGL(gru2_persist_fwd_h2_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
                 else hipLaunchKernelGGL(gru2_persist_fwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
             }
+            step_timer_mark(4, st);
             CPC_LAUNCH_CHECK();
             return 0;
         }
@@ -1307,8 +1309,10 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
         const int nblocks = g_gru_mode < 1 || p.ntiles <= 0 ? 0 : persist_grid(gru2_persist_bwd_kernel, p.ntiles, &p.xcd_pack);
         if (nblocks > 0) {
             if (!coef && hipMemsetAsync(p.xdh[0], 0xFF, 2 * g.frag_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+            step_timer_mark(5, st);
             for (p.tile0 = 0; p.tile0 < p.total_tiles; p.tile0 += p.ntiles)
                 hipLaunchKernelGGL(gru2_persist_bwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+            step_timer_mark(6, st);
         } else {
             const dim3 grid(kH / 16, cdiv(B, 16), 2);
             for (int s = 0; s <= S; ++s) hipLaunchKernelGGL(gru2_bwd_kernel, grid, dim3(512), 0, st, p, s);

@@ -16,6 +16,12 @@
 //   1  forward + backward down to the encoder's input gradient dz_total: every gradient but the encoder's is final or queued
 //      (heads: side stream; recurrence: wgrad stream) when it returns
 //   2  encoder backward; main waits for side and wgrad before it returns: all gradients final on main
+//   4  (with 2) OPEN TAIL: main does not wait for the step's last kernel -- layer 1's weight gradient, which runs 0.13 ms past
+//      the end of the main stream's chain -- but only for everything else; the caller updates conv1.weight on the wgrad stream
+//      behind it and everything else on main, calls cpc_train_step_tail, and the NEXT step (bits 8, 16) starts under the tail
+//   8  (with 1) the conv weight layouts / bounds of this step were prepared by cpc_train_step_tail at the end of the previous
+//      one; main waits for conv1's (event kEvNextConv1, recorded on the wgrad stream) in front of layer 1
+//  16  this step uses the second y0 buffer / bound set of the workspace (the caller alternates while it leaves tails open)
 #include "cpc_common.h"
 #include "cpc_internal.h"
 
@@ -75,6 +81,20 @@ int g_dz_early = 0;       // 1: the dz path on MAIN before the recurrence's back
 inline bool rec(hipEvent_t e, hipStream_t s) { return hipEventRecord(e, s) == hipSuccess; }
 inline bool wait(hipStream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess; }
 
+// in-step timing (cpc_set_step_timing): timing-enabled events recorded around layer 0, layer 1 and the two recurrence launches
+// INSIDE the step (StepHooks::timers, step_timer_mark); a diagnostic of its own steps, never of the timed ones -- every marker
+// costs the stream 6-8 us
+int g_step_timing = 0;
+hipEvent_t g_timers[8];
+bool g_timers_made = false;
+
+// the hooks of one cpc_train_step call, restored when it returns
+struct HookScope {
+    StepHooks saved;
+    HookScope() : saved(step_hooks()) {}
+    ~HookScope() { step_hooks() = saved; }
+};
+
 }  // namespace
 
 // enc_conv.hip: an event cpc_encoder_forward records on its stream right behind layer 0's launch (nullptr: none)
@@ -111,12 +131,20 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
                               void* side_stream, void* prep_stream, void* wgrad_stream) {
     StepLayout s;
     CPC_RETURN_IF(!step_layout(B, L, K, N, s), CPC_ERR_SHAPE);
-    CPC_RETURN_IF(!wave || !params || !grads || !workspace || (phases & ~3) || !(phases & 3), CPC_ERR_ARG);
+    CPC_RETURN_IF(!wave || !params || !grads || !workspace || (phases & ~31) || !(phases & 3), CPC_ERR_ARG);
+    CPC_RETURN_IF(((phases & 4) && !(phases & 2)) || ((phases & 8) && !(phases & 1)), CPC_ERR_ARG);
     hipStream_t M = (hipStream_t)main_stream, S0 = (hipStream_t)side_stream, S1 = (hipStream_t)prep_stream,
                 S2 = (hipStream_t)wgrad_stream;
     // (equal handles are allowed: the launches then simply queue up in issue order, which respects every dependency below)
     hipEvent_t* pool = stream_events(M);
     CPC_RETURN_IF(!pool, CPC_ERR_ARG);
+    HookScope scope;
+    StepHooks& hk = step_hooks();
+    hk.parity = (phases & 16) ? 1 : 0;
+    hk.weights_ready = (phases & 8) != 0;
+    hk.conv1_wait = (phases & 8) ? pool[kEvNextConv1] : nullptr;
+    hk.open_tail = (phases & 4) != 0 && S2 != M;
+    hk.timers = (g_step_timing && g_timers_made) ? g_timers : nullptr;
     hipEvent_t* ev = pool + 12;     // [0] begin, [1] index lists + bounds ready, [2] recurrence-backward preparation ready,
                                     // [3] score gradients ready, [4] dz done, [5] head gradient done, [6] conv0 launched / encoder done,
                                     // [7] forward recurrence's hand-over buffers filled, [8] conv weight layouts ready
@@ -226,6 +254,70 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
         rc = cpc_encoder_backward_streams(wave, enc_p, ws + s.enc_saved, z, dz, ws + s.enc_bscr, enc_g, B, L, M, S2);
         if (rc) return rc;          // (joins the wgrad stream -- the recurrence's gradients were queued there before the conv layers')
         CPC_RETURN_IF(!wait(M, ev[5]), CPC_ERR_ARG);
+    }
+    return 0;
+}
+
+// The tail of an open-tailed step (phases & 4), called after the optimiser's two launches (everything but conv1.weight on
+// main, conv1.weight on the wgrad stream behind its gradient): the weight-only preparation of the NEXT step -- the GEMM layouts
+// and max|w| of conv2..4 and the four input bounds on main, where the stream would otherwise idle for layer 1's weight gradient;
+// conv1's layouts on the wgrad stream behind its update -- written for parity `next_parity`, and the event the next step's layer 1
+// waits for (phases & 8).  Same kernels on the same values as the preparation at the head of a step: bit-identical results.
+extern "C" int cpc_train_step_tail(const float* const* params, float* workspace, int B, int L, int K, int N, int next_parity,
+                                   void* main_stream, void* wgrad_stream) {
+    StepLayout s;
+    CPC_RETURN_IF(!step_layout(B, L, K, N, s), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!params || !workspace, CPC_ERR_ARG);
+    hipStream_t M = (hipStream_t)main_stream, S2 = (hipStream_t)wgrad_stream;
+    hipEvent_t* pool = stream_events(M);
+    CPC_RETURN_IF(!pool, CPC_ERR_ARG);
+    HookScope scope;
+    step_hooks().parity = next_parity & 1;
+    float* ws = workspace;
+    int rc = cpc_encoder_prepare_weights(params, ws + s.enc_saved, ws + s.enc_fscr, B, L, 1 | 4 | 8 | 16, M);
+    if (rc) return rc;
+    rc = cpc_encoder_prepare_weights(params, ws + s.enc_saved, ws + s.enc_fscr, B, L, 2, S2);
+    if (rc) return rc;
+    CPC_RETURN_IF(!rec(pool[kEvNextConv1], S2), CPC_ERR_ARG);
+    return 0;
+}
+
+// Make `waiting_stream` wait for one of the events the step recorded for the caller (pool of `main_stream`):
+//   0  everything of the weight-gradient stream but layer 1's weight gradient (the short layers' weight gradients: a data-parallel
+//      caller's mid gradient bucket, dist.FlatGradAllReduce)
+//   1  layer 1's weight gradient
+//   2  the tail of an open-tailed step (cpc_train_step_tail): conv1's updated weight and layouts -- a caller that touches the
+//      parameters outside cpc_train_step joins with this first
+extern "C" int cpc_train_step_wait(void* main_stream, int which, void* waiting_stream) {
+    CPC_RETURN_IF(which < 0 || which > 2, CPC_ERR_ARG);
+    hipEvent_t* pool = stream_events((hipStream_t)main_stream);
+    CPC_RETURN_IF(!pool, CPC_ERR_ARG);
+    const int idx = which == 0 ? kEvWgradRest : (which == 1 ? kEvWgrad1 : kEvNextConv1);
+    CPC_RETURN_IF(!wait((hipStream_t)waiting_stream, pool[idx]), CPC_ERR_ARG);
+    return 0;
+}
+
+// In-step timing: while on, every cpc_train_step records timing events around layer 0, layer 1 and the two persistent recurrence
+// launches on its main stream.  cpc_get_step_timing waits for the last of them and returns the four durations of the most
+// recent step in microseconds: [0] conv0, [1] conv1, [2] forward recurrence, [3] backward recurrence (the markers' own cost --
+// 6-8 us each, measured by the caller with back-to-back events -- is included).
+extern "C" int cpc_set_step_timing(int on) {
+    if (on && !g_timers_made) {
+        for (int i = 0; i < 8; ++i)
+            if (hipEventCreate(&g_timers[i]) != hipSuccess) return CPC_ERR_ARG;
+        g_timers_made = true;
+    }
+    g_step_timing = on ? 1 : 0;
+    return 0;
+}
+extern "C" int cpc_get_step_timing(float* us) {
+    CPC_RETURN_IF(!us || !g_timers_made, CPC_ERR_ARG);
+    CPC_RETURN_IF(hipEventSynchronize(g_timers[6]) != hipSuccess, CPC_ERR_ARG);
+    const int a[4] = {0, 7, 3, 5}, b[4] = {1, 2, 4, 6};
+    for (int i = 0; i < 4; ++i) {
+        float ms = 0.f;
+        CPC_RETURN_IF(hipEventElapsedTime(&ms, g_timers[a[i]], g_timers[b[i]]) != hipSuccess, CPC_ERR_ARG);
+        us[i] = ms * 1000.f;
     }
     return 0;
 }

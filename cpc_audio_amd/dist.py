@@ -9,7 +9,7 @@ all-reduce of the 2,893,056 gradient values (11.57 MB) over xGMI.  SUM, not mean
 reference sums the per-replica losses (train.py:85, ``allLosses.sum()`` over the gathered
 (nGPU, K) tensor), see SURVEY.md T8.
 
-Two buckets of one persistent flat buffer, because the backward pass ends with the encoder (about a third of the
+Buckets of one persistent flat buffer (two, or three with ``mid``: see FlatGradAllReduce), because the backward pass ends with the encoder (about a third of the
 step) and everything else -- prediction heads and auto-regressive network, 55 % of the values -- is final before it
 starts: ``begin()`` (hooked to the start of the encoder's backward by the package's train loops, ops.
 pre_encoder_backward) sends that ``early`` bucket off on the side stream while the encoder's backward runs, and
@@ -48,24 +48,32 @@ class _IssuedOnStream:
 
 class FlatGradAllReduce:
     """Flattens the gradients of ``params`` into one persistent buffer and all-reduces it (SUM).
-    ``early``: the subset of ``params`` whose gradients are complete when ``begin()`` is called."""
+    ``early``: the subset of ``params`` whose gradients are complete when ``begin()`` is called (heads + auto-regressive
+    network: final when the encoder's backward starts).  ``mid``: a subset that becomes final during the encoder's backward on a
+    stream of its own -- the weight gradients of conv layers 2..4, done on the weight-gradient stream ~0.5 ms before the
+    backward ends; the caller of ``__call__`` says how a stream waits for them (``mid_wait``).  What is left -- conv0, conv1
+    and the 256-element bias / norm gradients, 0.53 M values -- is the one collective a step exposes."""
 
-    def __init__(self, params, early=None, group=None):
+    def __init__(self, params, early=None, mid=None, group=None):
         params = [p for p in params if p.requires_grad]
         ids = {id(p) for p in (early or [])}
+        mids = {id(p) for p in (mid or [])} - ids
         self.early = [p for p in params if id(p) in ids]
-        self.late = [p for p in params if id(p) not in ids]
-        self.params = self.early + self.late                 # buffer order: early bucket first
+        self.mid = [p for p in params if id(p) in mids]
+        self.late = [p for p in params if id(p) not in ids and id(p) not in mids]
+        self.params = self.early + self.mid + self.late      # buffer order: early bucket first, then mid, then late
         self.n_early = sum(p.numel() for p in self.early)
+        self.n_mid = sum(p.numel() for p in self.mid)
         self.group = group
         self.numel = sum(p.numel() for p in self.params)
         self.buf = None
         self.views = None
         self._pending = None                                  # work handle of the early bucket
         self._pending_event = None
-        self._stage = {}                                      # host-staged path: (offset, numel) -> pinned buffer
+        self._stage = {}                                      # host-staged path: (data_ptr, numel) of a bucket -> pinned buffer
         self._worker = None                                   # ... its one worker thread (ordered collectives)
         self._copy_stream = None
+        self._side = None                                     # the stream begin() issued the early bucket on
         self.single_rank_too = False                          # tests: run the collectives in a 1-rank group as well
 
     def _active(self):
@@ -74,8 +82,9 @@ class FlatGradAllReduce:
 
     def _reduce(self, t, async_op=False):
         """SUM all-reduce of ``t`` in place.  RCCL cannot put two ranks on one device and a gloo-only cluster has no device
-        collectives: a GPU tensor in a gloo group is staged through the host (synchronously -- the copy waits for the
-        current stream); the buckets, their order and what waits for what stay as on the RCCL path."""
+        collectives: a GPU tensor in a gloo group is staged through the host by a worker thread (_HostStagedWork: copies
+        queued on the issuing stream, nothing blocks the host); the buckets, their order and what waits for what stay as
+        on the RCCL path."""
         if t.is_cuda and dist.get_backend(self.group) == "gloo":
             work = self._reduce_host_staged(t)
             if async_op:
@@ -162,7 +171,8 @@ class FlatGradAllReduce:
                 self._pending = _IssuedOnStream() if direct else work
                 done = torch.cuda.Event()
                 done.record(side)
-            self._pending_event = done                       # what the current stream waits for in __call__ (host-staged path)
+            self._pending_event = done                       # what the current stream waits for in __call__
+            self._side = side
             for p in self.early:
                 if p.grad is not None:
                     p.grad.record_stream(side)
@@ -171,6 +181,7 @@ class FlatGradAllReduce:
             bucket = self.buf[:self.n_early]
             self._pending = self._reduce(bucket, async_op=True)
             self._pending_event = None
+            self._side = None
 
     def abort(self):
         """A step raised after begin(): let the early bucket's collective finish (every rank issued it; dropping the
@@ -185,19 +196,47 @@ class FlatGradAllReduce:
             except Exception:                                  # the group may be the thing that failed
                 pass
 
-    def __call__(self):
+    def __call__(self, mid_wait=None):
+        """Finish the exchange: every gradient is final on the current stream when this is called.
+        ``mid_wait`` (GPU, after ``begin()``): ``mid_wait(stream)`` makes ``stream`` wait for the ``mid`` parameters'
+        gradients -- they became final earlier, on another stream; the mid bucket is then issued on the side stream behind the
+        early one (both run beside the rest of the backward) and only the late bucket on the current stream.  Without it mid
+        and late -- contiguous in the buffer -- go out as one collective.  Every rank must make the same choice."""
         if not self._active():
             return
         if self._pending is None:                             # begin() was not called: one collective
             self._pack(self.params)
             self._reduce(self.buf)
         else:
-            if self.late:
-                self._pack(self.late)
-                self._reduce(self.buf[self.n_early:])
-            self._pending.wait()                              # current stream waits for the early bucket
+            cur_ev = []
+            lo = self.n_early
+            if self.mid and mid_wait is not None and self._side is not None:
+                side = self._side
+                mid_wait(side)
+                with torch.cuda.stream(side):                 # (FIFO behind the early bucket: one communicator, one order)
+                    self._pack(self.mid)
+                    direct = dist.get_backend(self.group) != "gloo"
+                    work = self._reduce(self.buf[lo:lo + self.n_mid], async_op=not direct)
+                    if not direct:
+                        work.wait()                           # host-staged: the side stream waits for the copy back
+                    done = torch.cuda.Event()
+                    done.record(side)
+                cur_ev.append(done)
+                for p in self.mid:
+                    if p.grad is not None:
+                        p.grad.record_stream(side)
+                lo += self.n_mid
+            # the collectives of one communicator in one order on the device as well: the current stream takes up the early
+            # (and mid) bucket's completion BEFORE it issues the last one -- they finished long ago, the wait costs nothing
+            self._pending.wait()
             if self._pending_event is not None:
                 torch.cuda.current_stream().wait_event(self._pending_event)
+            for e in cur_ev:
+                torch.cuda.current_stream().wait_event(e)
+            rest = self.params[len(self.early) + (len(self.mid) if lo > self.n_early else 0):]
+            if rest:
+                self._pack(rest)
+                self._reduce(self.buf[lo:])
             self._pending = self._pending_event = None
         views = self._views(self.params)
         have = [(p.grad, v) for p, v in zip(self.params, views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]

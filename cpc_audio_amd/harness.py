@@ -75,6 +75,7 @@ def build_scheduler(optimizer, scheduler_step=-1, scheduler_ramp=None):
     return scheduler
 
 
+PIPELINE_TAIL = True           # train_epoch: leave the tail of a composite step open (train.CompositeStep.finish); joined at the epoch's end
 COMPOSITE_STEP = True          # train_epoch: forward + backward through cpc_train_step where it applies (False: always autograd)
 PREPARE_CRITERION = True       # A/B switch (tools/ab_step.py "harness.PREPARE_CRITERION" True False)
 
@@ -161,10 +162,13 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
         if device.type == "cuda" and len(in_flight) >= 2:
             in_flight.pop(0).synchronize()
         if composite is not None and COMPOSITE_STEP and composite.ok(batch):
-            all_losses, all_acc = composite.forward_backward(batch)
+            # (open tail: the next step's conv0 under this step's last weight gradient, train.CompositeStep; this loop touches
+            # no parameter between two steps, and joins before it returns)
+            all_losses, all_acc = composite.forward_backward(batch, open_tail=PIPELINE_TAIL)
             if allreduce is not None:
-                allreduce()
-            optimizer.step()
+                allreduce(mid_wait=composite.mid_wait)
+            if not composite.finish(optimizer):
+                optimizer.step()
             optimizer.zero_grad()
             in_flight.append(torch.cuda.Event())
             in_flight[-1].record()
@@ -179,6 +183,8 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
                       f"{1000.0 * el / n_ex:.2f} ms / example, loss {float((sum_loss / n_iter).mean()):.4f}")
                 t0, n_ex = time.perf_counter(), 0
             continue
+        if composite is not None:
+            composite.join()
         try:
             with step_ctx as sc:                          # side streams for the dz path / weight gradients (ops.StepContext)
                 prepare_criterion(sc, model, criterion, batch)
@@ -209,6 +215,8 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
             print(f"Update {step + 1}: {1000.0 * el / logging_step:.1f} ms per batch, "
                   f"{1000.0 * el / n_ex:.2f} ms / example, loss {float((sum_loss / n_iter).mean()):.4f}")
             t0, n_ex = time.perf_counter(), 0
+    if composite is not None:
+        composite.join()                                  # parameters and optimiser state are the current stream's again
     if scheduler is not None:
         scheduler.step()
     if n_iter == 0:
@@ -299,7 +307,8 @@ def run(train_loader_fn, val_loader_fn, model, criterion, n_epoch, path_checkpoi
     best_acc, best_state = 0.0, None
     enc = {id(p) for p in model.gEncoder.parameters()} if hasattr(model, "gEncoder") else set()
     every = list(criterion.parameters()) + list(model.parameters())
-    allreduce = FlatGradAllReduce(every, early=[p for p in every if id(p) not in enc] if enc else None)
+    mid = [getattr(model.gEncoder, f"conv{i}").weight for i in (2, 3, 4)] if enc and hasattr(model.gEncoder, "conv4") else None
+    allreduce = FlatGradAllReduce(every, early=[p for p in every if id(p) not in enc] if enc else None, mid=mid)
     if path_checkpoint is not None and args is not None:
         os.makedirs(os.path.dirname(path_checkpoint) or ".", exist_ok=True)
         with open(os.path.join(os.path.dirname(path_checkpoint) or ".", "checkpoint_args.json"), "w") as f:

@@ -122,9 +122,12 @@ class Adam(torch.optim.Adam):
         loops keep their gradients in one persistent flat buffer (train.Trainer), so this is every step after the first."""
         t = getattr(self, "_dev_tables", None)
         if (t is not None and t["group"] is group and len(t["params"]) == len(params)
+                and self._group_ok(group)              # weight_decay / amsgrad / maximize / a tensor lr set since: not this kernel's
                 and all(p is q and p.grad is g for p, q, g in zip(params, t["params"], t["grads"]))
-                and all(p.data_ptr() == a for p, a in zip(params, t["pptr"]))):
+                and all(p.data_ptr() == a for p, a in zip(params, t["pptr"]))
+                and all(g.data_ptr() == a for g, a in zip(t["grads"], t["gptr"]))):
             return t
+        self._dev_tables = None
         if not self._hip_ok(group, params):
             return None
         n = len(params)
@@ -132,6 +135,7 @@ class Adam(torch.optim.Adam):
         pptr = [p.data_ptr() for p in params]
         t = self._dev_tables = {
             "group": group, "params": list(params), "grads": [p.grad for p in params], "pptr": pptr, "n": n,
+            "gptr": [p.grad.data_ptr() for p in params],
             "ps": arr(*pptr), "gs": arr(*[p.grad.data_ptr() for p in params]),
             "ms": arr(*[self.state[p]["exp_avg"].data_ptr() for p in params]),
             "vs": arr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in params]),
@@ -156,12 +160,17 @@ class Adam(torch.optim.Adam):
                                                        torch.cuda.current_stream(dev).cuda_stream), "adam_step_capturable")
 
     @staticmethod
-    def _hip_ok(group, params):
+    def _group_ok(group):
+        """The group-level half of _hip_ok: options the one-launch kernel does not implement (the reference uses none)."""
         if group["weight_decay"] != 0 or group["amsgrad"] or group.get("maximize", False):
             return False
         if group.get("capturable", False) or group.get("differentiable", False):
             return False
-        if isinstance(group["lr"], torch.Tensor):
+        return not isinstance(group["lr"], torch.Tensor)
+
+    @staticmethod
+    def _hip_ok(group, params):
+        if not Adam._group_ok(group):
             return False
         for p in params:
             g = p.grad
@@ -232,12 +241,54 @@ class Adam(torch.optim.Adam):
                 self.param_groups = keep
         return loss
 
-    def _launch_tables(self, t, lr, beta1, beta2, eps, step):
+    def _launch_tables(self, t, lr, beta1, beta2, eps, step, stream=None):
         bc1 = 1.0 - beta1 ** step
         bc2s = math.sqrt(1.0 - beta2 ** step)
         with torch.cuda.device(t["dev"]):
+            st = torch.cuda.current_stream(t["dev"]) if stream is None else stream
             _lib.get().check(_lib.get().cpc_adam_step(t["ps"], t["gs"], t["ms"], t["vs"], t["ns"], t["n"], lr, beta1, beta2, eps,
-                                                      bc1, bc2s, torch.cuda.current_stream(t["dev"]).cuda_stream), "adam_step")
+                                                      bc1, bc2s, st.cuda_stream), "adam_step")
+
+    @torch.no_grad()
+    def step_split(self, late, late_stream):
+        """One optimiser step as TWO launches of the same update: the parameters in ``late`` on ``late_stream`` (where their
+        gradients become final -- layer 1's weight gradient at the tail of train.CompositeStep's open-tailed step), every other
+        parameter on the current stream.  Element-wise arithmetic: bit-identical to ``step()``.  Only on the fast path of
+        ``step()`` (one group, the tensors of the previous call, a shared step count); returns False -- nothing launched,
+        nothing counted -- when that does not apply, and the caller runs ``step()`` instead."""
+        fast = self._fast
+        if self._device_step is not None or fast is None or len(self.param_groups) != 1:
+            return False
+        group = self.param_groups[0]
+        params = group["params"]
+        if any(p.grad is None for p in params):
+            return False
+        t = self._tables(group, params)
+        if t is None or t is not fast["tables"]:
+            return False
+        key = tuple(id(p) for p in late)
+        sp = t.get("split")
+        if sp is None or sp["key"] != key:
+            ids = set(key)
+            halves = []
+            for sel in ([p for p in params if id(p) not in ids], [p for p in params if id(p) in ids]):
+                n = len(sel)
+                arr = ctypes.c_void_p * n
+                halves.append({"n": n, "dev": t["dev"], "ps": arr(*[p.data_ptr() for p in sel]),
+                               "gs": arr(*[p.grad.data_ptr() for p in sel]),
+                               "ms": arr(*[self.state[p]["exp_avg"].data_ptr() for p in sel]),
+                               "vs": arr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in sel]),
+                               "ns": (ctypes.c_long * n)(*[p.numel() for p in sel])})
+            if halves[1]["n"] == 0:
+                return False
+            sp = t["split"] = {"key": key, "halves": halves}
+        fast["k"] += 1
+        beta1, beta2 = group["betas"]
+        a, b = sp["halves"]
+        if a["n"]:
+            self._launch_tables(a, float(group["lr"]), beta1, beta2, float(group["eps"]), fast["k"])
+        self._launch_tables(b, float(group["lr"]), beta1, beta2, float(group["eps"]), fast["k"], stream=late_stream)
+        return True
 
     def _launch(self, params, lr, beta1, beta2, eps, step):
         lib = _lib.get()

@@ -48,6 +48,56 @@ class CompositeStep:
     def __init__(self, model, criterion, ctx, allreduce):
         self.model, self.criterion, self.ctx, self.allreduce = model, criterion, ctx, allreduce
         self.tables = None                # pointer tables / workspace of the last batch shape
+        self.mid_wait = None              # data parallel: how a stream waits for conv2..4's weight gradients of the last step
+
+    # ---- cross-step pipelining of a single-rank loop (``forward_backward(open_tail=True)`` + ``finish(optimizer)``) -------------
+    # The step's last kernel is layer 1's weight gradient on the weight-gradient stream: it runs ~0.13 ms past the end of the
+    # main stream's chain, and behind it came Adam, 40-60 us of weight re-layout and conv0 -- which needs none of
+    # conv1.weight.  With an open tail the main stream does not wait for that kernel: ``finish`` updates conv1.weight on the
+    # weight-gradient stream behind it and everything else on the main stream (optim.Adam.step_split), prepares the next step's
+    # weight layouts right there (cpc_train_step_tail) and the next ``forward_backward`` starts with conv0 under the tail; its
+    # layer 1 waits for conv1's update.  Same kernels on the same values: bit-identical results.  Between an open-tailed step and
+    # the next one conv1.weight and its optimiser state belong to the weight-gradient stream -- ``join()`` before anything else
+    # reads or writes parameters on the current stream (the train loops of this package do; a parameter changed in place by
+    # torch in between is detected by its version counter and costs one preparation at the head of the step, as before).
+    def join(self):
+        """The current stream waits for the tail of the last open-tailed step (no host synchronisation)."""
+        f = self.tables
+        if f is not None and f.get("open"):
+            from . import _lib
+            dev = f["ws"].device
+            with torch.cuda.device(dev):
+                _lib.get().check(_lib.get().cpc_train_step_wait(f["main"], 2, torch.cuda.current_stream(dev).cuda_stream),
+                                 "train_step_wait")
+            f["open"] = False
+
+    def finish(self, optimizer):
+        """After ``forward_backward(open_tail=True)`` (and instead of ``optimizer.step()`` when it returns True): the split
+        update and the next step's weight preparation.  False: the tail has been closed (the current stream has waited for layer
+        1's weight gradient) and the caller runs ``optimizer.step()`` as usual -- the first step of a run (the optimiser's
+        one-launch path arms itself there), a foreign optimiser."""
+        f = self.tables
+        if f is None or not f.get("tail"):
+            return False
+        from . import _lib
+        from .optim import Adam
+        lib = _lib.get()
+        f["tail"] = False
+        dev = f["ws"].device
+        with torch.cuda.device(dev):
+            main = torch.cuda.current_stream(dev)
+            wst = self.ctx.side_stream(dev, 2)
+            conv1w = self.model.gEncoder.conv1.weight
+            if main.cuda_stream != f["main"] or not (isinstance(optimizer, Adam) and optimizer.step_split([conv1w], wst)):
+                lib.check(lib.cpc_train_step_wait(f["main"], 1, main.cuda_stream), "train_step_wait")
+                return False
+            B, L, K, N = f["key"][:4]
+            f["parity"] ^= 1
+            lib.check(lib.cpc_train_step_tail(f["params"], _lib.ptr(f["ws"]), B, L, K, N, f["parity"], main.cuda_stream,
+                                              wst.cuda_stream), "train_step_tail")
+            f["open"] = True
+            f["ready"] = tuple(p._version for p in f["plist"])
+        return True
 
     def ok(self, batchData, negatives=None):
         from . import ops
@@ -56,9 +106,16 @@ class CompositeStep:
         if not (torch.is_tensor(batchData) and batchData.is_cuda and batchData.dtype == torch.float32
                 and batchData.dim() == 3 and batchData.shape[1] == 1 and torch.is_grad_enabled() and not ops.KEEP_DEBUG):
             return False
-        if not (isinstance(m, CPCModel) and isinstance(m.gEncoder, CPCEncoder) and isinstance(m.gAR, CPCAR)
-                and isinstance(cr, CPCUnsupersivedCriterion)):
+        # exactly this package's classes, without hooks or parametrizations: the composite never calls a module's __call__ /
+        # forward, so a subclass override, a forward / backward hook or a parametrized weight would be skipped silently --
+        # such setups take the autograd path
+        if not (type(m) is CPCModel and type(m.gEncoder) is CPCEncoder and type(m.gAR) is CPCAR
+                and type(cr) is CPCUnsupersivedCriterion):
             return False
+        for mod in list(m.modules()) + list(cr.modules()):
+            if (mod._forward_hooks or mod._forward_pre_hooks or mod._backward_hooks or mod._backward_pre_hooks
+                    or getattr(mod, "parametrizations", None)):
+                return False
         ar = m.gAR
         if ar.reverse or ar.baseNet.num_layers != 2 or cr.mode is not None or cr.wPrediction.scores_apart:
             return False
@@ -66,8 +123,14 @@ class CompositeStep:
             return False
         ps = self.allreduce.params
         own = {id(p) for p in list(cr.parameters()) + list(m.parameters())}
-        return (len(ps) == 20 + 8 + cr.nPredicts and all(id(p) in own for p in ps)
-                and all(p.requires_grad and p.is_cuda and p.dtype == torch.float32 for p in ps))
+        if not (len(ps) == 20 + 8 + cr.nPredicts and all(id(p) in own for p in ps)
+                and all(p.requires_grad and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps)):
+            return False
+        # the K heads' gradients must be one contiguous block of the flat buffer, in head order (a caller-supplied
+        # FlatGradAllReduce may order them otherwise: autograd path instead of an exception from _tables)
+        pos = {id(p): i for i, p in enumerate(ps)}
+        heads = [pos.get(id(h.weight)) for h in cr.wPrediction.predictors]
+        return None not in heads and all(b == a + 1 for a, b in zip(heads, heads[1:]))
 
     def _tables(self, batchData):
         """Pointer tables and workspace of cpc_train_step for this batch shape; rebuilt when a parameter got new storage."""
@@ -85,6 +148,7 @@ class CompositeStep:
         f = self.tables
         if f is not None and f["key"] == key:
             return f
+        self.join()                                                    # (the old workspace may still be in use by an open tail)
         views = self.allreduce._views(plist + heads)                   # the flat gradient buffer: gradients are written in place
         hv = views[len(plist):]
         step = hv[0].numel() * hv[0].element_size()
@@ -102,10 +166,11 @@ class CompositeStep:
             "key": key, "params": arr(*([p.data_ptr() for p in plist] + [wall.data_ptr()])),
             "grads": arr(*([v.data_ptr() for v in views[:len(plist)]] + [hv[0].data_ptr()])),
             "plist": plist + heads, "views": views, "ws": ws, "S": int(sizes[3]), "sizes": tuple(sizes),
-            "ones": torch.ones(K, device=batchData.device), "hN": torch.empty(2, B, 256, device=batchData.device)}
+            "ones": torch.ones(K, device=batchData.device), "hN": torch.empty(2, B, 256, device=batchData.device),
+            "parity": 0, "open": False, "ready": None, "tail": False, "main": None}
         return f
 
-    def forward_backward(self, batchData, negatives=None, prefetch=False):
+    def forward_backward(self, batchData, negatives=None, prefetch=False, open_tail=False):
         from . import _lib
         lib = _lib.get()
         dev = batchData.device
@@ -148,6 +213,18 @@ class CompositeStep:
                 if p.grad is not v:
                     p.grad = v                                  # gradients live in the flat buffer, overwritten by every step
             P = _lib.ptr
+            # the weight layouts the previous step's tail prepared are valid if nothing touched a parameter since (torch's
+            # version counters; this package's kernels do not count) and the step runs on the stream they were ordered for
+            ready = (f["ready"] is not None and f["main"] == main.cuda_stream
+                     and f["ready"] == tuple(p._version for p in f["plist"]))
+            if f["open"] and not ready:
+                self.join()
+            f["ready"] = None
+            f["open"] = False                              # (ready: the call itself waits, in front of layer 1)
+            f["main"] = main.cuda_stream
+            flags = (8 if ready else 0) | (16 if f["parity"] else 0)
+            tail = bool(open_tail) and not self.allreduce._active() and not torch.cuda.is_current_stream_capturing()
+            f["tail"] = False
 
             def call(phases):
                 lib.check(lib.cpc_train_step(P(batchData), P(bidx), P(sidx), P(h0), 1.0 if bounded else 0.0, f["params"],
@@ -159,15 +236,21 @@ class CompositeStep:
                     # data parallel: the heads' and the recurrence's gradients leave for the other ranks while the encoder's
                     # backward runs (dist.FlatGradAllReduce.begin: on the side stream, behind the heads' gradient there and
                     # behind the recurrence's on the weight-gradient stream)
-                    call(1)
+                    call(1 | flags)
                     ev = torch.cuda.Event()
                     ev.record(wst)
                     ctx.wgrad_events.append(ev)
                     self.allreduce.begin(ctx)
                     del ctx.wgrad_events[:]
-                    call(2)
+                    call(2 | (flags & 16))
+                    # conv2..4's weight gradients were final on the weight-gradient stream long before the call's last kernel:
+                    # their bucket goes out beside the rest of the backward (dist.FlatGradAllReduce.__call__(mid_wait=...))
+                    self.mid_wait = lambda stream, m=main.cuda_stream: lib.check(
+                        lib.cpc_train_step_wait(m, 0, stream.cuda_stream), "train_step_wait")
                 else:
-                    call(3)
+                    self.mid_wait = None
+                    call(3 | flags | (4 if tail else 0))
+                    f["tail"] = tail
             except BaseException:
                 del ctx.wgrad_events[:]
                 self.allreduce.abort()
@@ -193,21 +276,29 @@ class Trainer:
     AUTO_PROBE_STEPS = 6      # graph="auto": eager steps timed (host enqueue time vs GPU time) before deciding
 
     def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, graph=False, check_errors_every=256,
-                 fused=True, prefetch_negatives=False):
+                 fused=True, prefetch_negatives=False, pipeline_tail=False):
         """check_errors_every: every that many steps the device-side error flags are read (ops.check_device_errors: a
         recurrence workgroup that gave up polling, a negative index out of range) and turned into an exception -- one device
         synchronisation per that many steps; 0 leaves the check to the caller.
         graph: False (eager), True (HIP graph replay), or "auto": the first steps run eagerly and are timed; the graph is
         used only if the host needs more than 85 % of the GPU's step time to issue a step.  (Measured on MI355X boxes: the
         replayed graph costs 0.24-0.28 ms of host time per step (the composite step issued eagerly: 0.5 ms) and runs 6 % longer on
-        the GPU than the eagerly issued streams (3.10 vs 2.93 ms, round 4) -- a win only where the host cannot keep up, see step.)"""
-        """fused (default True): where the configuration is the north-star one -- CPCEncoder + 2-layer GRU CPCAR + linear
+        the GPU than the eagerly issued streams (3.10 vs 2.93 ms, round 4) -- a win only where the host cannot keep up, see step.)
+        fused (default True): where the configuration is the north-star one -- CPCEncoder + 2-layer GRU CPCAR + linear
         heads, every parameter trainable -- forward and backward of a step are issued by ONE C call (cpc_train_step, csrc/
         train_step.hip: the same entry points in the same order on the same four streams, bit-identical results) into a
         persistent workspace, with the gradients written straight into the flat all-reduce buffer; anything else (transformer
         AR / predictors, criterion mode 'reverse', frozen parameters) runs the autograd path below."""
         self.model, self.criterion = model, criterion
         self.fused = bool(fused)
+        # pipeline_tail (composite step, one rank, eager launches): leave the tail of every step open -- the next step's conv0 runs
+        # under this step's last weight gradient, conv1.weight is updated on the weight-gradient stream (CompositeStep.finish).
+        # Off by default because of what it asks of the caller: between two steps conv1.weight belongs to that stream, so
+        # anything else that touches parameters, gradients or optimiser state on the current stream calls ``join()`` first
+        # (state_dict(), validation, a checkpoint -- harness.train_epoch and bench.py do).  CPC_PIPELINE_TAIL=1 / 0 overrides.
+        import os as _os
+        env_pt = _os.environ.get("CPC_PIPELINE_TAIL")
+        self.pipeline_tail = bool(pipeline_tail) if env_pt is None else env_pt == "1"
         # composite step only, off by default: draw the NEXT step's negatives and prepare their index lists at the end of a step
         # (beside its tail: layer 1's weight gradient alone on the matrix pipes) instead of behind conv0 of the next one.  The
         # draws come from torch's generator in the same order either way -- the A/B's losses are equal to the last digit --; only
@@ -221,7 +312,11 @@ class Trainer:
         params = list(criterion.parameters()) + list(model.parameters())      # train.py:332
         self.optimizer = Adam(params, lr=lr, betas=betas, eps=eps)      # train.py:335-337; one launch per step on the GPU
         enc = {id(p) for p in model.gEncoder.parameters()} if hasattr(model, "gEncoder") else set()
-        self.allreduce = FlatGradAllReduce(params, early=[p for p in params if id(p) not in enc] if enc else None)
+        # three buckets: heads + recurrence (final when the encoder's backward starts), the weight gradients of conv2..4 (final
+        # on the weight-gradient stream ~0.5 ms before the backward ends; composite step only), the rest -- conv0, conv1 and the
+        # 256-element bias / norm gradients, 0.53 M values = 2.1 MB: the one collective a step exposes
+        mid = [getattr(model.gEncoder, f"conv{i}").weight for i in (2, 3, 4)] if enc and hasattr(model.gEncoder, "conv4") else None
+        self.allreduce = FlatGradAllReduce(params, early=[p for p in params if id(p) not in enc] if enc else None, mid=mid)
         from . import ops
         self.ctx = ops.StepContext(overlap=True)
         if params and params[0].is_cuda and not torch.cuda.is_current_stream_capturing():
@@ -271,9 +366,11 @@ class Trainer:
                 self.wait_seconds = getattr(self, "wait_seconds", 0.0) + (time.perf_counter() - t0)
         with torch.cuda.device(batchData.device):
             losses, acc = self._composite.forward_backward(batchData, negatives,
-                                                           prefetch=self.prefetch_negatives and not self._capturing)
-            self.allreduce()
-            self.optimizer.step()
+                                                           prefetch=self.prefetch_negatives and not self._capturing,
+                                                           open_tail=self.pipeline_tail and not self._capturing)
+            self.allreduce(mid_wait=self._composite.mid_wait)
+            if not self._composite.finish(self.optimizer):
+                self.optimizer.step()
             self.optimizer.zero_grad()
             if throttle:
                 ev = torch.cuda.Event()
@@ -281,9 +378,15 @@ class Trainer:
                 self._done_events.append(ev)
         return losses, acc
 
+    def join(self):
+        """The current stream waits for the open tail of the last step (``pipeline_tail``): call it before reading or writing
+        parameters, gradients or optimiser state outside ``step()``.  No host synchronisation; a no-op otherwise."""
+        self._composite.join()
+
     def _eager_step(self, batchData, label, negatives=None):
         if self._fused_ok(batchData, negatives):
             return self._fused_step(batchData, label, negatives)
+        self._composite.join()
         # the overlap state (side streams, events, launches held back) lives on this Trainer's StepContext: two Trainers
         # on two threads / devices do not share any
         # (not while a capture is being prepared or recorded: an event recorded into a capturing stream belongs to the
@@ -345,6 +448,7 @@ class Trainer:
         """Capture the step for batches shaped like ``batchData`` (step() does it on demand).  The two warm-up steps torch's
         capture recipe needs run on a snapshot: parameters, optimiser moments and the step count are restored afterwards,
         so the first call to step() performs exactly one update, like every other."""
+        self._composite.join()
         self._ones_like(torch.empty(1, len(self.criterion.wPrediction.predictors), device=batchData.device))
         self.optimizer.device_step_counter(True)
         params = [p for g in self.optimizer.param_groups for p in g["params"]]

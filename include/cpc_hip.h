@@ -208,6 +208,10 @@ int cpc_encoder_layout(int B, int L, long* sizes);
 int cpc_encoder_saved_activation(const float* saved, int layer, float* dst, int B, int L, void* stream);
 int cpc_encoder_forward(const float* wave, const float* const* params, float* saved,
                         float* scratch, float* z, int B, int L, void* stream);
+/* The weight-only preparation cpc_encoder_forward starts with (GEMM layouts and max|w| of conv1..4, bounds of the layers'
+ * inputs from the ChannelNorm affines; what cpc/model.py:83-92's nn.Conv1d does inside MIOpen, hoisted), alone, for a caller
+ * that runs it ahead of the forward: mask bit i (1..4) = layer i, bit 0 = the four bounds.  Used by cpc_train_step_tail. */
+int cpc_encoder_prepare_weights(const float* const* params, float* saved, float* scratch, int B, int L, int mask, void* stream);
 int cpc_encoder_backward(const float* wave, const float* const* params, const float* saved,
                          const float* z, const float* dz, float* scratch, float* const* grads,
                          int B, int L, void* stream);
@@ -413,7 +417,14 @@ int cpc_nce_scores_backward(const float* pred, const float* z, const int* ext, c
  * phases (bit mask): 1 = forward + backward down to the encoder's input gradient -- on return the heads' gradient is queued
  * on side_stream, the recurrence's on wgrad_stream, everything else of the non-encoder gradients is final on main_stream (a
  * data-parallel caller starts reducing that bucket here); 2 = the encoder's backward, after which main_stream has waited for
- * side_stream and wgrad_stream: every gradient is final on main_stream.  3 = both.  No host synchronisation anywhere. */
+ * side_stream and wgrad_stream: every gradient is final on main_stream.  3 = both.  No host synchronisation anywhere.
+ * Cross-step pipelining of a single-rank loop (cpc/train.py:78-91 is strictly serial: backward, optimizer.step, next forward):
+ *   + 4 (with 2) open tail: main_stream does not wait for the step's LAST kernel, layer 1's weight gradient on wgrad_stream
+ *     (0.13 ms past the end of main_stream's chain), only for everything else.  The caller then updates every parameter but
+ *     conv1.weight on main_stream and conv1.weight on wgrad_stream (cpc_adam_step twice), calls cpc_train_step_tail, and gives
+ *     the NEXT step + 8 (its weight layouts are ready; main_stream waits for conv1's in front of layer 1) and alternates + 16
+ *     (second y0 buffer / bound set of the workspace: the next layer 0 runs while layer 1's weight gradient still reads y0).
+ *   A caller that touches parameters or gradients outside these calls first joins with cpc_train_step_wait(main, 2, main). */
 int cpc_train_step_layout(int B, int L, int K, int N, long* sizes);
 int cpc_train_step(const float* wave, const long* batchIdx, const long* seqIdx, const float* h0, float c_bound,
                    const float* const* params, float* const* grads, const float* gloss, float* workspace, float* losses,
@@ -425,6 +436,20 @@ int cpc_train_step(const float* wave, const long* batchIdx, const long* seqIdx, 
  * the matrix pipes) instead of beside the next step's first conv layers. */
 int cpc_train_step_prefetch(const long* batchIdx, const long* seqIdx, float* workspace, int B, int L, int K, int N,
                             void* side_stream);
+/* The tail of an open-tailed step (phases + 4), after the optimiser's two launches: the next step's weight preparation (conv2..4
+ * and the input bounds on main_stream, conv1's on wgrad_stream behind its update) for parity next_parity, and the event the next
+ * step's layer 1 waits for.  params: the 20 encoder tensors (cpc_encoder_forward's order). */
+int cpc_train_step_tail(const float* const* params, float* workspace, int B, int L, int K, int N, int next_parity,
+                        void* main_stream, void* wgrad_stream);
+/* waiting_stream waits for an event the last cpc_train_step on main_stream recorded: 0 = everything of wgrad_stream but layer 1's
+ * weight gradient (conv2..4's weight gradients: a data-parallel caller's mid gradient bucket), 1 = layer 1's weight gradient,
+ * 2 = cpc_train_step_tail's end (conv1's updated weight and layouts). */
+int cpc_train_step_wait(void* main_stream, int which, void* waiting_stream);
+/* In-step timing (diagnostic): while on, cpc_train_step records timing events around layer 0, layer 1 and the two persistent
+ * recurrence launches on main_stream; cpc_get_step_timing waits for the last and writes the 4 durations of the most recent step
+ * in microseconds (conv0, conv1, forward recurrence, backward recurrence; each includes one marker's cost). */
+int cpc_set_step_timing(int on);
+int cpc_get_step_timing(float* us);
 /* Measurement switches of cpc_train_step's schedule.  prep_point: where the criterion's index preparation (190 MB of index
  * traffic at B = 64) is released on side_stream -- 0 at the step's start (beside conv0, the one HBM-bound layer: 50 -> 96 us), 1
  * (default) behind conv0 (beside conv1 / conv2), 2 behind the encoder (beside the recurrence), 3 behind conv1 (beside conv2..conv4).  dz_early: 1 = the dz path on main_stream BEFORE the recurrence's

@@ -192,3 +192,63 @@ def test_prefetched_index_lists_give_the_same_step_emulated():
     # one of the two draws without the other is an argument error
     assert lib.cpc_train_step(P(wave), P(bidx), None, None, 1.0, parr, garr, P(ones), P(ws), out[0].data_ptr(), out[1].data_ptr(),
                               P(hN), B, L, K, N, 3, None, None, None, None) == 2
+
+
+def test_open_tail_steps_with_the_weight_preparation_at_the_tail_change_no_bit_emulated():
+    """Three consecutive steps, parameters updated in between: (a) every step closed, its weight layouts prepared at its head
+    (phases 3) against (b) open tails (phases + 4), the next step's layouts / bounds prepared by cpc_train_step_tail for the
+    other parity (phases + 8, alternating + 16), one persistent workspace.  Same kernels on the same values: every loss, output
+    and gradient equal bit for bit.  (The emulator runs streams in issue order: this pins the arithmetic -- buffers, parities,
+    what is skipped -- not the cross-stream ordering, which tests/test_gpu_fused_step.py checks on hardware.)"""
+    lib = emu()
+    B, L, K, N = 2, 2560, 4, 16
+    _, wave, S, bidx, sidx, plist0 = _setup(B, L, K, N, seed=4)
+    sizes = (ctypes.c_long * 8)()
+    assert lib.cpc_train_step_layout(B, L, K, N, sizes) == 0
+    apart = [ctypes.c_void_p(h) for h in (64, 128, 192)]
+
+    def run(pipelined):
+        plist = [t.clone() for t in plist0]
+        ws = torch.full((sizes[0],), float("nan"))
+        grads = [torch.full_like(t, float("nan")) for t in plist]
+        parr = (ctypes.c_void_p * 29)(*[P(t) for t in plist])
+        garr = (ctypes.c_void_p * 29)(*[P(t) for t in grads])
+        ones = torch.ones(K)
+        res, parity, ready = [], 0, False
+        for step in range(3):
+            out, hN = torch.full((2, K), float("nan")), torch.full((2, B, 256), float("nan"))
+            phases = 3
+            if pipelined:
+                phases |= 4 | (8 if ready else 0) | (16 if parity else 0)
+            assert lib.cpc_train_step(P(wave), P(bidx), P(sidx), None, 1.0, parr, garr, P(ones), P(ws), out[0].data_ptr(),
+                                      out[1].data_ptr(), P(hN), B, L, K, N, phases, None, *apart) == 0
+            z = ws[sizes[1]:sizes[1] + B * S * 256].clone()
+            res.append((out.clone(), hN.clone(), z, [g.clone() for g in grads]))
+            for t, g in zip(plist, grads):                  # the optimiser's update (any in-place change of every parameter)
+                t.sub_(0.05 * g / (g.abs().max() + 1e-12) * t.abs().max())
+            if pipelined:
+                parity ^= 1
+                assert lib.cpc_train_step_tail(parr, P(ws), B, L, K, N, parity, None, apart[2]) == 0
+                assert lib.cpc_train_step_wait(None, 2, None) == 0
+                ready = True
+        return res
+
+    ref, got = run(False), run(True)
+    for step, (a, b) in enumerate(zip(ref, got)):
+        assert torch.isfinite(a[0]).all() and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), step
+        for n, (x, y) in enumerate(zip(a[3], b[3])):
+            assert torch.equal(x, y), (step, n)
+    assert not torch.equal(ref[0][0], ref[2][0])             # the updates did move the losses
+    # argument checks of the new entry points
+    assert lib.cpc_train_step_wait(None, 3, None) == 2
+    assert lib.cpc_train_step_tail(None, None, B, L, K, N, 0, None, None) == 2
+    assert lib.cpc_encoder_prepare_weights(None, None, None, B, L, 2, None) == 2
+    # in-step timing markers on: same results (the emulator's events carry no time)
+    assert lib.cpc_set_step_timing(1) == 0
+    try:
+        again = run(True)
+        us = (ctypes.c_float * 4)()
+        assert lib.cpc_get_step_timing(us) == 0
+    finally:
+        assert lib.cpc_set_step_timing(0) == 0
+    assert torch.equal(again[2][0], ref[2][0])

@@ -193,3 +193,81 @@ def test_composite_step_equals_the_autograd_step_at_the_large_per_gpu_batches(B)
     assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0])
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+@pytest.mark.parametrize("B,steps", [(4, 6), (64, 12)])
+def test_open_tailed_steps_equal_the_closed_steps_bit_for_bit(B, steps):
+    """Trainer(pipeline_tail=True): the next step's conv0 starts under this step's last kernel (layer 1's weight gradient), the
+    optimiser's update is split over two streams, the weight layouts are prepared at the tail for the other parity of the
+    workspace (train.CompositeStep.finish, cpc_train_step_tail).  The same kernels on the same values: every loss of the
+    trajectory, every parameter and the optimiser state after it equal the closed-tail run's bit for bit -- at B = 64 with the
+    tail genuinely overlapping the next step (a missing cross-stream dependency would show as a differing bit)."""
+    dev = _dev()
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
+    p = O.make_params(seed=37, head_scale=64.0)
+    waves = [O.make_waveform(B, 20480, seed=95 + (i % 3)).to(dev) for i in range(steps)]
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    res = []
+    for pipe in (False, True):
+        model, crit = build_model().to(dev), build_criterion().to(dev)
+        load_flat_params(model, crit, p)
+        tr = Trainer(model, crit, pipeline_tail=pipe)
+        torch.manual_seed(5)
+        losses = []
+        for i in range(steps):
+            l, a = tr.step(waves[i], label)
+            losses.append(torch.cat([l, a]))
+            if i == steps // 2:
+                # a parameter changed in place by torch between two steps (a scheduler, a load_state_dict): the prepared layouts
+                # are stale -- detected through the version counter; the step joins and prepares at its head
+                tr.join()
+                with torch.no_grad():
+                    model.gEncoder.conv1.weight.mul_(1.0009765625)
+                    model.gEncoder.batchNorm0.weight.mul_(1.03125)
+        tr.join()
+        torch.cuda.synchronize()
+        f = tr._fused
+        assert f is not None and (f["ready"] is not None) == pipe
+        from cpc_audio_amd import ops
+        ops.check_device_errors()
+        res.append((torch.stack(losses).cpu(), _state(model, crit), tr.optimizer.state_dict()))
+        del tr, model, crit
+    assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    s0, s1 = res[0][2]["state"], res[1][2]["state"]
+    for i in s0:
+        assert float(s0[i]["step"]) == float(s1[i]["step"]) == steps
+        assert torch.equal(s0[i]["exp_avg"], s1[i]["exp_avg"]) and torch.equal(s0[i]["exp_avg_sq"], s1[i]["exp_avg_sq"])
+
+
+def test_open_tailed_steps_in_the_bf16_storage_variant_and_across_a_mode_switch():
+    """The same in mode 4 (other kernels read y0 / the bounds), then back to fp32 in the same Trainer: the switch rebuilds the
+    workspace, which must first join the tail still running in the old one."""
+    dev = _dev()
+    import cpc_audio_amd
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
+    B, steps = 16, 4
+    p = O.make_params(seed=38, head_scale=64.0)
+    wave = O.make_waveform(B, 20480, seed=99).to(dev)
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    res = []
+    for pipe in (False, True):
+        model, crit = build_model().to(dev), build_criterion().to(dev)
+        load_flat_params(model, crit, p)
+        tr = Trainer(model, crit, pipeline_tail=pipe)
+        torch.manual_seed(6)
+        losses = []
+        try:
+            for mode in ("bf16", "fp32"):
+                cpc_audio_amd.set_activation_storage(mode)
+                for _ in range(steps):
+                    losses.append(torch.cat(tr.step(wave, label)))
+        finally:
+            cpc_audio_amd.set_activation_storage("fp32")
+        tr.join()
+        torch.cuda.synchronize()
+        res.append((torch.stack(losses).cpu(), _state(model, crit)))
+    assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
