@@ -116,9 +116,10 @@ SIGNATURES = {
     "cpc_train_step_layout": (_I, [_I, _I, _I, _I, _P]),
     "cpc_train_step_prefetch": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "cpc_train_step": (_I, [_P, _P, _P, _P, _F] + [_P] * 7 + [_I] * 5 + [_P] * 4),
-    "cpc_train_step_tail": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "cpc_train_step_tail": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "cpc_train_step_wait": (_I, [_P, _I, _P]),
     "cpc_set_step_timing": (_I, [_I]),
+    "cpc_set_tail_schedule": (_I, [_I]),
     "cpc_get_step_timing": (_I, [_P]),
     "cpc_adam_step": (_I, [_P] * 5 + [_I] + [ctypes.c_double] * 6 + [_P]),
     "cpc_adam_step_capturable": (_I, [_P] * 5 + [_I] + [ctypes.c_double] * 4 + [_P, _P, _P]),

@@ -596,7 +596,7 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const float xh = (acc[tm][tn][r] - mean[tm][r]) * rs;
-                const float yv = fmaxf(fmaf(xh, gw[tn], gb[tn]), 0.f);
+                const float yv = fmaxf(relu_in(fmaf(xh, gw[tn], gb[tn])), 0.f);
                 const int c0 = col[tn] & ~1;
                 // Neighbouring lanes hold neighbouring channels.  16-bit storages are written as one dword per lane pair
                 // and tensor: the exchanges are unconditional (convergent), the stores are guarded.

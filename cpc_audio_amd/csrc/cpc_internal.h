@@ -95,9 +95,10 @@ extern int g_mfma_mode;
 // weight-gradient stream but layer 1's weight gradient is done (recorded there by the encoder's backward: what a mid gradient
 // bucket / an open-tailed step waits for), [7] layer 1's weight gradient reduced, [8] GRU backward, [9] criterion backward
 // (score gradients -> dz stream), [12..20] the composite train step (train_step.hip), [21] conv1's updated weight and its
-// layouts ready for the next step (cpc_train_step_tail)
+// layouts ready for the next step (cpc_train_step_tail), [22] the same for every other parameter but conv0's, [6] / [23] open
+// tail: the last stand-alone norm backward is done (main) / the batched column sums are (sums stream)
 constexpr int kStreamEvents = 24;
-constexpr int kEvWgradRest = 5, kEvWgrad1 = 7, kEvNextConv1 = 21;
+constexpr int kEvWgradRest = 5, kEvNorm1 = 6, kEvWgrad1 = 7, kEvNextConv1 = 21, kEvNextRest = 22, kEvSums = 23;
 hipEvent_t* stream_events(hipStream_t caller_stream);
 
 // ---- hooks of the composite step into the per-stage entry points (train_step.hip sets them around its calls; per host
@@ -106,9 +107,11 @@ struct StepHooks {
     int parity = 0;               // which of the two y0 buffers / input-bound sets of the encoder workspace this step uses
     bool weights_ready = false;   // the conv weight layouts, max|w| and input bounds of this parity were prepared by the previous
                                   // step's tail (cpc_train_step_tail): the forward launches no preparation
-    hipEvent_t conv1_wait = nullptr;   // the forward's stream waits for this event in front of layer 1 (its updated weight)
+    hipEvent_t conv1_wait[2] = {nullptr, nullptr};   // the forward's stream waits for these in front of layer 1 (updated weights)
     bool open_tail = false;       // encoder backward: the caller's stream is joined with everything of the weight-gradient stream
                                   // BUT layer 1's weight gradient (event kEvWgradRest); kEvWgrad1 is recorded behind that one
+    hipStream_t sums_stream = nullptr;   // open tail: the batched column sums of the norm backwards (bias / norm gradients of layers
+                                  // 1..4) run HERE, released behind layer 1's norm backward, instead of at the end of the chain
     hipEvent_t* timers = nullptr; // in-step timing (cpc_set_step_timing): 8 timing-enabled events, or nullptr
 };
 StepHooks& step_hooks();

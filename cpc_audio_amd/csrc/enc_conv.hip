@@ -166,12 +166,14 @@ struct PrepArgs {
     int fwd_h2[4];          // 1: forward layout of layer y+1 in K-tile-major H2 rows (the DMA kernel's, conv_dma.hip);
                             // 2: forward AND dgrad layouts in K-tile-major bf16 rows (mode 4)
     int dgrad_h2[4];        // 1: dgrad layout of layer y+1 in K-tile-major H2 rows (conv_dgrad_dma_kernel<.., 2>)
-    int mask;               // bit i (1..4): layer i is prepared by this launch; bit 0: the four input bounds
+    int mask;               // bit i (1..4): layer i is prepared by this launch; bit 0: the input bounds of layers 2..4 (the
+                            // ChannelNorm affines of layers 1..3); bit 5: the input bound of layer 1 (layer 0's affine)
 };
 __global__ __launch_bounds__(256) void enc_prep_amax_kernel(PrepArgs a) {
     const int y = blockIdx.y;
     if (y == 4) {
-        if (blockIdx.x < 4 && (a.mask & 1)) norm_bound_block(a.nw[blockIdx.x], a.nb[blockIdx.x], a.bound + blockIdx.x);
+        if (blockIdx.x < 4 && (a.mask & (blockIdx.x == 0 ? 32 : 1)))
+            norm_bound_block(a.nw[blockIdx.x], a.nb[blockIdx.x], a.bound + blockIdx.x);
         return;
     }
     if (!((a.mask >> (y + 1)) & 1)) return;                   // block-uniform
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void enc_prep_amax_kernel(PrepArgs a) {
 // row 4 of enc_prep_amax_kernel on its own (4 workgroups): what layer 0 needs of the preparation -- the bound its H2 output is
 // scaled by -- when the rest runs on another stream beside it (enc_set_weight_prep_stream)
 __global__ __launch_bounds__(256) void enc_prep_bounds_kernel(PrepArgs a) {
-    norm_bound_block(a.nw[blockIdx.x], a.nb[blockIdx.x], a.bound + blockIdx.x);
+    if (a.mask & (blockIdx.x == 0 ? 32 : 1)) norm_bound_block(a.nw[blockIdx.x], a.nb[blockIdx.x], a.bound + blockIdx.x);
 }
 __global__ __launch_bounds__(256) void enc_prep_permute_kernel(PrepArgs a) {
     const int b = blockIdx.x;
@@ -223,7 +225,9 @@ struct ConvCfg {
     static constexpr bool X3 = MODE != 0;
     static constexpr int NP = MODE == 2 ? 2 : 3;
     static constexpr bool H2 = NP == 2;
-    static constexpr int WAVES_M = BM >= 128 ? 2 : 1;
+    // (64-row tiles on the pipelined schedule: EIGHT waves of 32 x 64, like two 32-row tiles sharing one weight stage -- half the
+    // weight bytes through L2 per output row at the same two waves per SIMD; with four 64 x 64 waves the tile lost to fill)
+    static constexpr int WAVES_M = BM >= 128 ? 2 : (BM == 64 && PIPE ? 2 : 1);
     // 128-row tiles: two LDS stages of 16 k with the skewed (store-first / MFMA-first) wave schedule
     // (pre-split weight planes, BSPLIT = true, measured slower: 162 vs 176 TF on layer 1 -- three 8-byte loads per
     //  slot instead of one 16-byte load cost more than the VALU they save)
@@ -252,7 +256,7 @@ __device__ __forceinline__ void h2_store_lane(unsigned char* row, int c, float v
 // y_amax (MODE 2, may be NULL): y is written in H2 storage scaled for the bound *y_amax (which must bound |y|: the layer's
 // ChannelNorm bound) instead of fp32
 template <int BM, int MODE, bool AH2 = false, bool PIPE = false>
-__global__ __launch_bounds__((ConvCfg<BM, MODE, AH2, PIPE>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_fwd_kernel(
+__global__ __launch_bounds__((ConvCfg<BM, MODE, AH2, PIPE>::Tile::NTHREADS), (BM == 64 && !PIPE ? 2 : 1)) void conv_fwd_kernel(
     RowMap am, const float* __restrict__ wp, int K, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ y,
     float* __restrict__ xhat, float* __restrict__ rstd_out, const float* __restrict__ x_amax,
@@ -351,7 +355,7 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE, AH2, PIPE>::Tile::NTHREADS), (BM
                         const float xh = (acc[tm][tn][r] - mean[tm][r]) * rstd[tm][r];
                         if (live) __builtin_nontemporal_store(xh, xhat + (long)m * kC + col[tn]);
                         h2_store_lane(reinterpret_cast<unsigned char*>(y) + (long)(live ? m : 0) * (kC * 4), col[tn],
-                                      fmaxf(fmaf(xh, gw[tn], gb[tn]), 0.f), sy, live);
+                                      fmaxf(relu_in(fmaf(xh, gw[tn], gb[tn])), 0.f), sy, live);
                     }
                     continue;
                 }
@@ -362,7 +366,7 @@ __global__ __launch_bounds__((ConvCfg<BM, MODE, AH2, PIPE>::Tile::NTHREADS), (BM
                 for (int tn = 0; tn < TN; ++tn) {
                     const float xh = (acc[tm][tn][r] - mean[tm][r]) * rstd[tm][r];
                     __builtin_nontemporal_store(xh, xhat + (long)m * kC + col[tn]);     // read again only in backward
-                    y[(long)m * kC + col[tn]] = fmaxf(fmaf(xh, gw[tn], gb[tn]), 0.f);
+                    y[(long)m * kC + col[tn]] = fmaxf(relu_in(fmaf(xh, gw[tn], gb[tn])), 0.f);
                 }
             }
         }
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
             s1[j] = 0.f; s2[j] = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float yq = MASK == 2 ? fmaf(x4[j][q], gw[q], gb[q]) : yv[j][q];
+                const float yq = MASK == 2 ? relu_in(fmaf(x4[j][q], gw[q], gb[q])) : yv[j][q];
                 const float dyh = (live[j] && yq > 0.f) ? g4[j][q] : 0.f;
                 cs[0][q] = fmaf(dyh, x4[j][q], cs[0][q]);
                 cs[1][q] += dyh;
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(
 // grid = (row tiles over B*(Lout+1), s phases).  am = 2-row windows over dx of THIS layer.
 // MODE 2: dx_amax / w_amax bound the operands; prev_amax (FUSE, may be NULL) receives max|dprev|.
 template <int BM, bool FUSE, int MODE, bool AH2 = false, bool PIPE = false>
-__global__ __launch_bounds__((ConvCfg<BM, MODE, AH2, PIPE>::Tile::NTHREADS), (BM == 64 ? 2 : 1)) void conv_dgrad_kernel(
+__global__ __launch_bounds__((ConvCfg<BM, MODE, AH2, PIPE>::Tile::NTHREADS), (BM == 64 && !PIPE ? 2 : 1)) void conv_dgrad_kernel(
     RowMap am, const float* __restrict__ wd, int s, int p, int Lin,
     const float* __restrict__ xhat_prev, const float* __restrict__ y_prev,
     const float* __restrict__ rstd_prev, const float* __restrict__ nw_prev,
@@ -876,7 +880,9 @@ static int pick_bm(int M) {
     if (g_force_bm) return g_force_bm;
     // measured on MI355X (tools/bench_kernels.py): 128-row tiles win as soon as they give ~256 blocks
     // (the 256-column weight tile is re-read from L2 once per block); below that the 32-row tile wins.
-    return M >= 32000 ? 128 : g_small_bm;
+    if (M >= 32000) return 128;
+    // 64-row tiles (cpc_set_conv_small_tile(64)) only where they still give the chip ~a workgroup per CU
+    return (g_small_bm == 64 && cdiv(M, 64) < 192) ? 32 : g_small_bm;
 }
 
 static bool enc_layout(int B, int Lw, EncLayout& e) {
@@ -1066,6 +1072,11 @@ extern "C" int cpc_set_conv_small_pipe(int on) {
 extern "C" int cpc_set_dma_tile(int bm) {
     CPC_RETURN_IF(bm != 0 && bm != 128 && bm != 256, CPC_ERR_ARG);
     g_dma_bm = bm;
+    return 0;
+}
+static int g_tail_conv0_early = 0;      // cpc_set_tail_schedule (see cpc_encoder_forward)
+extern "C" int cpc_set_tail_schedule(int conv0_early) {
+    g_tail_conv0_early = conv0_early ? 1 : 0;
     return 0;
 }
 // 0 (default): layer 1's weight gradient is released behind its data gradient; 1: together with dx1, i.e. beside that data gradient
@@ -1333,8 +1344,9 @@ void enc_set_weight_prep_stream(hipStream_t st, hipEvent_t done) { t_prep_stream
 
 // Every weight-only quantity of layers 1..4 -- both GEMM layouts, max|w|, the bounds of the layers' inputs (the previous layer's
 // ChannelNorm + ReLU output is bounded by its affine) -- in two launches; the backward finds the dgrad layouts and the bounds in
-// `saved`.  mask: bit i (1..4) = layer i's layouts, bit 0 = the four input bounds (+ the zero row the DMA kernels read for the
-// conv's padding).  apart: the bounds by a 4-workgroup launch of their own on `st`, everything else on `pst`.
+// `saved`.  mask: bit i (1..4) = layer i's layouts, bit 0 = the input bounds of layers 2..4 (+ the zero row the DMA kernels read
+// for the conv's padding), bit 5 = the input bound of layer 1.  pst != st: the bounds by a 4-workgroup launch of their own on
+// `st`, everything else on `pst`.
 static int enc_prepare_weights(const EncLayout& e, const float* const* params, float* saved, float* scratch, int mask,
                                hipStream_t st, hipStream_t pst) {
     PrepArgs a;
@@ -1358,13 +1370,15 @@ static int enc_prepare_weights(const EncLayout& e, const float* const* params, f
     a.partial = scratch + e.famax;
     a.split = weight_split();
     a.mask = mask;
-    const bool apart = pst != st;
-    if (apart && (mask & 1)) hipLaunchKernelGGL(enc_prep_bounds_kernel, dim3(4), dim3(256), 0, st, a);
-    if (apart) a.mask &= ~1;
-    hipLaunchKernelGGL(enc_prep_amax_kernel, dim3(kPrepParts, (a.mask & 1) ? 5 : 4), dim3(256), 0, pst, a);
+    const bool apart = pst != st || !(mask & 30);            // (bounds alone: the 4-workgroup launch)
+    if (apart && (mask & 33)) hipLaunchKernelGGL(enc_prep_bounds_kernel, dim3(4), dim3(256), 0, st, a);
+    if (apart) a.mask &= ~33;
+    if (a.mask) hipLaunchKernelGGL(enc_prep_amax_kernel, dim3(kPrepParts, (a.mask & 33) ? 5 : 4), dim3(256), 0, pst, a);
     if (nblk > 0) hipLaunchKernelGGL(enc_prep_permute_kernel, dim3(nblk), dim3(256), 0, pst, a);
     CPC_LAUNCH_CHECK();
-    if ((mask & 1) && g_mfma_mode >= 3 && hipMemsetAsync(saved + e.szero, 0, 64 * sizeof(float), pst) != hipSuccess) return CPC_ERR_ARG;
+    // (the zero row the DMA kernels read for the conv's padding: with the full preparation only -- a partial one runs while the
+    // previous step's last weight gradient may still be reading it, and zeros stay zeros)
+    if (mask == 63 && g_mfma_mode >= 3 && hipMemsetAsync(saved + e.szero, 0, 64 * sizeof(float), pst) != hipSuccess) return CPC_ERR_ARG;
     return 0;
 }
 
@@ -1375,7 +1389,7 @@ extern "C" int cpc_encoder_prepare_weights(const float* const* params, float* sa
                                            void* stream) {
     EncLayout e;
     CPC_RETURN_IF(B <= 0 || !enc_layout(B, L, e), CPC_ERR_SHAPE);
-    CPC_RETURN_IF(!params || !saved || !scratch || mask <= 0 || mask > 31, CPC_ERR_ARG);
+    CPC_RETURN_IF(!params || !saved || !scratch || mask <= 0 || mask > 63, CPC_ERR_ARG);
     return enc_prepare_weights(e, params, saved, scratch, mask, (hipStream_t)stream, (hipStream_t)stream);
 }
 
@@ -1392,16 +1406,26 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
     const bool apart = !hk.weights_ready && t_prep_stream && t_prep_done && t_prep_stream != st;
     hipStream_t pst = apart ? t_prep_stream : st;
     if (!hk.weights_ready) {
-        const int rcp = enc_prepare_weights(e, params, saved, scratch, 31, st, pst);
+        const int rcp = enc_prepare_weights(e, params, saved, scratch, 63, st, pst);
         if (rcp) return rcp;
     }
     if (apart && hipEventRecord(t_prep_done, pst) != hipSuccess) return CPC_ERR_ARG;
     // (layer 0 reads none of it; layers 1..4 wait below -- for the preparation stream, or for the event behind layer 1's updated
     // weight when the previous step left its tail open)
+    // Where the stream takes up the previous step's open tail: in front of layer 0 (default) or only in front of layer 1, with
+    // layer 0 running UNDER the tail (cpc_set_tail_schedule(1); measured a loss: beside layer 1's weight gradient -- 194 VGPRs, two
+    // waves per SIMD resident -- layer 0 gets one wave per SIMD instead of four and takes 107-131 us instead of 50, and the
+    // small kernels that end the tail queue up behind its workgroups: 15 -> 66 us for the split reduction alone)
+    auto wait_tail = [&]() {
+        for (hipEvent_t w : hk.conv1_wait)
+            if (w && hipStreamWaitEvent(st, w, 0) != hipSuccess) return false;
+        return true;
+    };
     auto join_prep = [&]() {
-        if (hk.conv1_wait && hipStreamWaitEvent(st, hk.conv1_wait, 0) != hipSuccess) return false;
+        if (g_tail_conv0_early && !wait_tail()) return false;
         return !apart || hipStreamWaitEvent(st, t_prep_done, 0) == hipSuccess;
     };
+    if (!g_tail_conv0_early && !wait_tail()) return CPC_ERR_ARG;
     step_timer_mark(0, st);
     if (e.bf16) {
         // bf16-storage variant: y0..y3 and xhat1..4 as bf16 (half the activation bytes), weights rounded to bf16 by the
@@ -1552,6 +1576,23 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                                 e.dxh2[i] ? dxbound + i : amax + i * kAmaxSlots, xbound + i, B, e.L[i - 1], kGeom[i].k, kGeom[i].s,
                                 kGeom[i].p, e.wg_splits[i], e.wg_rows[i], (void*)wst, e.dxh2[i] ? 1 : kAmaxSlots);
     };
+    // open tail (StepHooks): the batched column sums -- the bias / norm gradients of layers 1..4 -- on their own stream as soon
+    // as the last stand-alone norm backward (layer 1's) is done, instead of at the end of the chain behind conv0's backward: the
+    // caller's optimiser takes these parameters up beside the chain's last two kernels
+    const StepHooks& hk = step_hooks();
+    hipStream_t sums_st = (ev && hk.open_tail && !g_wgrad1_early && hk.sums_stream && hk.sums_stream != st) ? hk.sums_stream : nullptr;
+    GradPtrs gp;
+    for (int i = 1; i < 5; ++i) {        // layers 1..4: small[i] = [d norm.weight | d norm.bias | d conv.bias]
+        gp.p[(i - 1) * 3 + 0] = grads[4 * i + 2];
+        gp.p[(i - 1) * 3 + 1] = grads[4 * i + 3];
+        gp.p[(i - 1) * 3 + 2] = grads[4 * i + 1];
+    }
+    auto sums = [&](hipStream_t s_) {
+        const int r_ = rows_sum_multi(jobs, njobs, s_);
+        if (r_) return r_;
+        hipLaunchKernelGGL(small_to_grads_kernel, dim3(12), dim3(256), 0, s_, small, gp);
+        return 0;
+    };
     int rc = 0;
     if (e.dxh2[4] && !e.bf16) {          // the top layer's dy is the caller's dz: its maximum (the H2 scale of dx4 derives from it) is reduced here
         const float* xs[1] = {dz};
@@ -1614,6 +1655,13 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                                  kGeom[1].s, kGeom[1].p, st, kAmaxSlots);
         }
         if (rc) return rc;
+        if (i == 2 && sums_st) {         // (layer 1's norm backward has just been queued: every partial of the sums is final behind it)
+            if (hipEventRecord(ev[kEvNorm1], st) != hipSuccess || hipStreamWaitEvent(sums_st, ev[kEvNorm1], 0) != hipSuccess)
+                return CPC_ERR_ARG;
+            rc = sums(sums_st);
+            if (rc) return rc;
+            if (hipEventRecord(ev[kEvSums], sums_st) != hipSuccess) return CPC_ERR_ARG;
+        }
         if (late1) {
             if (hipEventRecord(ev[1], st) != hipSuccess || hipStreamWaitEvent(wst, ev[1], 0) != hipSuccess) return CPC_ERR_ARG;
             rc = wgrad(1, xin);
@@ -1623,16 +1671,10 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
     rc = conv0_backward(wave, params[0], params[1], params[2], params[3], saved + e.mean0, saved + e.rstd[0],
                         scratch + e.dy0, e.bf16, scratch + e.conv0, grads[0], grads[1], grads[2], grads[3], B, L, st);
     if (rc) return rc;
-    rc = rows_sum_multi(jobs, njobs, st);
-    if (rc) return rc;
-    // layers 1..4: small[i] = [d norm.weight | d norm.bias | d conv.bias]
-    GradPtrs gp;
-    for (int i = 1; i < 5; ++i) {
-        gp.p[(i - 1) * 3 + 0] = grads[4 * i + 2];
-        gp.p[(i - 1) * 3 + 1] = grads[4 * i + 3];
-        gp.p[(i - 1) * 3 + 2] = grads[4 * i + 1];
+    if (!sums_st) {
+        rc = sums(st);
+        if (rc) return rc;
     }
-    hipLaunchKernelGGL(small_to_grads_kernel, dim3(12), dim3(256), 0, st, small, gp);
     CPC_LAUNCH_CHECK();
     if (ev) {                                            // join: everything written on the weight-gradient stream
         const bool late1 = !g_wgrad1_early;

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(
                 const float gam[4] = {g4.x, g4.y, g4.z, g4.w}, bet[4] = {n4.x, n4.y, n4.z, n4.w};
                 float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaf(x[4 * q + e][r] * rs[r], gam[e], bet[e]), 0.f);
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(relu_in(fmaf(x[4 * q + e][r] * rs[r], gam[e], bet[e])), 0.f);
                 if constexpr (YK == 1) {
                     h2_store_slot<NT>(y + row * kC, 16 * q + n, o[0], o[1], o[2], o[3], live);
                 } else if constexpr (YK == 2) {
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(
                     for (int e = 0; e < 4; ++e) {
                         const int T = 4 * q + e, r = 2 * hf + r2;
                         const float xh = (x[T][r] - mu[r2]) * rs[r2];
-                        const float yv = fmaf(xh, f4c(g4, e), f4c(n4, e));
+                        const float yv = relu_in(fmaf(xh, f4c(g4, e), f4c(n4, e)));
                         const float dyh = (live[r2] && yv > 0.f) ? f4c(dyv[r2][q], e) : 0.f;     // relu'
                         (&dg.x)[e] = fmaf(dyh, xh, (&dg.x)[e]);                                  // d batchNorm0.weight
                         (&db.x)[e] += dyh;                                                       // d batchNorm0.bias

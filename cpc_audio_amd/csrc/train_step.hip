@@ -142,8 +142,10 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
     StepHooks& hk = step_hooks();
     hk.parity = (phases & 16) ? 1 : 0;
     hk.weights_ready = (phases & 8) != 0;
-    hk.conv1_wait = (phases & 8) ? pool[kEvNextConv1] : nullptr;
+    hk.conv1_wait[0] = (phases & 8) ? pool[kEvNextConv1] : nullptr;
+    hk.conv1_wait[1] = (phases & 8) ? pool[kEvNextRest] : nullptr;
     hk.open_tail = (phases & 4) != 0 && S2 != M;
+    hk.sums_stream = hk.open_tail && S1 != M ? S1 : nullptr;
     hk.timers = (g_step_timing && g_timers_made) ? g_timers : nullptr;
     hipEvent_t* ev = pool + 12;     // [0] begin, [1] index lists + bounds ready, [2] recurrence-backward preparation ready,
                                     // [3] score gradients ready, [4] dz done, [5] head gradient done, [6] conv0 launched / encoder done,
@@ -168,6 +170,9 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
         // the step begins here on main: the other streams fork from this point (the workspace is the previous step's, whose
         // last users main has waited for)
         CPC_RETURN_IF(!rec(ev[0], M) || !wait(S1, ev[0]), CPC_ERR_ARG);
+        // (after an open-tailed step the optimiser's update of everything but conv0 / conv1.weight ran on the preparation stream,
+        // S1 itself: the side stream reads the heads' weights and must come behind it -- long done by now)
+        if (phases & 8) CPC_RETURN_IF(!wait(S0, pool[kEvNextRest]), CPC_ERR_ARG);
         const bool bounds_early = c_bound > 0.f;
         const bool early = bounds_early && !g_no_early;      // the criterion's operand bounds do not depend on c: its backward's weight-only share too
         auto prepare = [&]() -> int {      // index lists of the draws + operand bounds of the prediction GEMMs: depend on no activation
@@ -258,42 +263,56 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
     return 0;
 }
 
-// The tail of an open-tailed step (phases & 4), called after the optimiser's two launches (everything but conv1.weight on
-// main, conv1.weight on the wgrad stream behind its gradient): the weight-only preparation of the NEXT step -- the GEMM layouts
-// and max|w| of conv2..4 and the four input bounds on main, where the stream would otherwise idle for layer 1's weight gradient;
-// conv1's layouts on the wgrad stream behind its update -- written for parity `next_parity`, and the event the next step's layer 1
-// waits for (phases & 8).  Same kernels on the same values as the preparation at the head of a step: bit-identical results.
+// The tail of an open-tailed step (phases & 4), called after the optimiser's three launches -- conv0's parameters on main behind
+// conv0's backward, conv1.weight on the wgrad stream behind its gradient, every other parameter on the preparation stream (where
+// the step left the bias / norm gradients of layers 1..4; the caller made it wait for events 0 and 3 of cpc_train_step_wait) --:
+// the weight-only preparation of the NEXT step, each share on the stream its parameters arrive on, written for parity
+// `next_parity`, and the two events the next step waits for in front of layer 1 (phases & 8).  Main gets one 4-workgroup launch
+// (layer 1's input bound, from layer 0's new affine) between conv0's update and the next step's conv0.  Same kernels on the same
+// values as the preparation at the head of a step: bit-identical results.
 extern "C" int cpc_train_step_tail(const float* const* params, float* workspace, int B, int L, int K, int N, int next_parity,
-                                   void* main_stream, void* wgrad_stream) {
+                                   void* main_stream, void* prep_stream, void* wgrad_stream) {
     StepLayout s;
     CPC_RETURN_IF(!step_layout(B, L, K, N, s), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!params || !workspace, CPC_ERR_ARG);
-    hipStream_t M = (hipStream_t)main_stream, S2 = (hipStream_t)wgrad_stream;
+    hipStream_t M = (hipStream_t)main_stream, S1 = (hipStream_t)prep_stream, S2 = (hipStream_t)wgrad_stream;
     hipEvent_t* pool = stream_events(M);
     CPC_RETURN_IF(!pool, CPC_ERR_ARG);
     HookScope scope;
     step_hooks().parity = next_parity & 1;
     float* ws = workspace;
-    int rc = cpc_encoder_prepare_weights(params, ws + s.enc_saved, ws + s.enc_fscr, B, L, 1 | 4 | 8 | 16, M);
+    int rc = cpc_encoder_prepare_weights(params, ws + s.enc_saved, ws + s.enc_fscr, B, L, 32, M);
     if (rc) return rc;
+    rc = cpc_encoder_prepare_weights(params, ws + s.enc_saved, ws + s.enc_fscr, B, L, 1 | 4 | 8 | 16, S1);
+    if (rc) return rc;
+    CPC_RETURN_IF(!rec(pool[kEvNextRest], S1), CPC_ERR_ARG);
     rc = cpc_encoder_prepare_weights(params, ws + s.enc_saved, ws + s.enc_fscr, B, L, 2, S2);
     if (rc) return rc;
     CPC_RETURN_IF(!rec(pool[kEvNextConv1], S2), CPC_ERR_ARG);
     return 0;
 }
 
-// Make `waiting_stream` wait for one of the events the step recorded for the caller (pool of `main_stream`):
-//   0  everything of the weight-gradient stream but layer 1's weight gradient (the short layers' weight gradients: a data-parallel
-//      caller's mid gradient bucket, dist.FlatGradAllReduce)
-//   1  layer 1's weight gradient
-//   2  the tail of an open-tailed step (cpc_train_step_tail): conv1's updated weight and layouts -- a caller that touches the
+// Make `waiting_stream` wait for events the step recorded for the caller (pool of `main_stream`):
+//   0  everything of the weight-gradient stream but layer 1's weight gradient (the recurrence's and the short layers' weight
+//      gradients: a data-parallel caller's mid gradient bucket, dist.FlatGradAllReduce; an open tail's update of "the rest")
+//   1  what an open-tailed step (phases & 4) left open: layer 1's weight gradient and the batched bias / norm gradient sums --
+//      closes the tail for a caller that will not call cpc_train_step_tail
+//   2  the tail of an open-tailed step (cpc_train_step_tail): every updated weight and layout -- a caller that touches the
 //      parameters outside cpc_train_step joins with this first
+//   3  the heads' weight gradient (side stream)
+//   4  the batched bias / norm gradient sums of an open-tailed step alone
 extern "C" int cpc_train_step_wait(void* main_stream, int which, void* waiting_stream) {
-    CPC_RETURN_IF(which < 0 || which > 2, CPC_ERR_ARG);
+    CPC_RETURN_IF(which < 0 || which > 4, CPC_ERR_ARG);
     hipEvent_t* pool = stream_events((hipStream_t)main_stream);
     CPC_RETURN_IF(!pool, CPC_ERR_ARG);
-    const int idx = which == 0 ? kEvWgradRest : (which == 1 ? kEvWgrad1 : kEvNextConv1);
-    CPC_RETURN_IF(!wait((hipStream_t)waiting_stream, pool[idx]), CPC_ERR_ARG);
+    hipStream_t w = (hipStream_t)waiting_stream;
+    bool ok = true;
+    if (which == 0) ok = wait(w, pool[kEvWgradRest]);
+    else if (which == 1) ok = wait(w, pool[kEvWgrad1]) && wait(w, pool[kEvSums]);
+    else if (which == 2) ok = wait(w, pool[kEvNextConv1]) && wait(w, pool[kEvNextRest]);
+    else if (which == 3) ok = wait(w, pool[12 + 5]);
+    else ok = wait(w, pool[kEvSums]);
+    CPC_RETURN_IF(!ok, CPC_ERR_ARG);
     return 0;
 }
 

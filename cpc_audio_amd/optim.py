@@ -250,12 +250,12 @@ class Adam(torch.optim.Adam):
                                                       bc1, bc2s, st.cuda_stream), "adam_step")
 
     @torch.no_grad()
-    def step_split(self, late, late_stream):
-        """One optimiser step as TWO launches of the same update: the parameters in ``late`` on ``late_stream`` (where their
-        gradients become final -- layer 1's weight gradient at the tail of train.CompositeStep's open-tailed step), every other
-        parameter on the current stream.  Element-wise arithmetic: bit-identical to ``step()``.  Only on the fast path of
-        ``step()`` (one group, the tensors of the previous call, a shared step count); returns False -- nothing launched,
-        nothing counted -- when that does not apply, and the caller runs ``step()`` instead."""
+    def step_split(self, groups):
+        """One optimiser step as SEVERAL launches of the same update: ``groups`` is a list of (parameters, stream) -- each set
+        is updated on its stream (where its gradients become final: train.CompositeStep's open-tailed step has three such
+        places); every parameter not named runs on the current stream.  Element-wise arithmetic: bit-identical to ``step()``.
+        Only on the fast path of ``step()`` (one group, the tensors of the previous call, a shared step count); returns False --
+        nothing launched, nothing counted -- when that does not apply, and the caller runs ``step()`` instead."""
         fast = self._fast
         if self._device_step is not None or fast is None or len(self.param_groups) != 1:
             return False
@@ -266,12 +266,18 @@ class Adam(torch.optim.Adam):
         t = self._tables(group, params)
         if t is None or t is not fast["tables"]:
             return False
-        key = tuple(id(p) for p in late)
+        key = tuple(tuple(id(p) for p in ps) for ps, _ in groups)
         sp = t.get("split")
         if sp is None or sp["key"] != key:
-            ids = set(key)
+            taken = set()
+            parts = []
+            for ids in key:
+                sel = [p for p in params if id(p) in set(ids) and id(p) not in taken]
+                taken.update(id(p) for p in sel)
+                parts.append(sel)
+            parts.append([p for p in params if id(p) not in taken])         # the remainder: current stream
             halves = []
-            for sel in ([p for p in params if id(p) not in ids], [p for p in params if id(p) in ids]):
+            for sel in parts:
                 n = len(sel)
                 arr = ctypes.c_void_p * n
                 halves.append({"n": n, "dev": t["dev"], "ps": arr(*[p.data_ptr() for p in sel]),
@@ -279,15 +285,13 @@ class Adam(torch.optim.Adam):
                                "ms": arr(*[self.state[p]["exp_avg"].data_ptr() for p in sel]),
                                "vs": arr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in sel]),
                                "ns": (ctypes.c_long * n)(*[p.numel() for p in sel])})
-            if halves[1]["n"] == 0:
-                return False
             sp = t["split"] = {"key": key, "halves": halves}
         fast["k"] += 1
         beta1, beta2 = group["betas"]
-        a, b = sp["halves"]
-        if a["n"]:
-            self._launch_tables(a, float(group["lr"]), beta1, beta2, float(group["eps"]), fast["k"])
-        self._launch_tables(b, float(group["lr"]), beta1, beta2, float(group["eps"]), fast["k"], stream=late_stream)
+        lr, eps = float(group["lr"]), float(group["eps"])
+        for h, stream in zip(sp["halves"], [st for _, st in groups] + [None]):
+            if h["n"]:
+                self._launch_tables(h, lr, beta1, beta2, eps, fast["k"], stream=stream)
         return True
 
     def _launch(self, params, lr, beta1, beta2, eps, step):

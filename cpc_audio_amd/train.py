@@ -86,15 +86,26 @@ class CompositeStep:
         dev = f["ws"].device
         with torch.cuda.device(dev):
             main = torch.cuda.current_stream(dev)
-            wst = self.ctx.side_stream(dev, 2)
-            conv1w = self.model.gEncoder.conv1.weight
-            if main.cuda_stream != f["main"] or not (isinstance(optimizer, Adam) and optimizer.step_split([conv1w], wst)):
+            prep, wst = self.ctx.side_stream(dev, 1), self.ctx.side_stream(dev, 2)
+            enc = self.model.gEncoder
+            conv0 = [enc.conv0.weight, enc.conv0.bias, enc.batchNorm0.weight, enc.batchNorm0.bias]
+            c0 = {id(p) for p in conv0}
+            rest = [p for p in f["plist"] if id(p) not in c0 and p is not enc.conv1.weight]
+            ok = main.cuda_stream == f["main"] and isinstance(optimizer, Adam)
+            if ok:
+                # the gradients of "the rest" -- the recurrence's and conv2..4's weights (weight-gradient stream), the heads' (side
+                # stream), the bias / norm gradients of layers 1..4 (already on the preparation stream) -- were final long before
+                # the chain's last kernels: their update and their layouts run on the preparation stream beside those
+                for which in (0, 3):
+                    lib.check(lib.cpc_train_step_wait(f["main"], which, prep.cuda_stream), "train_step_wait")
+                ok = optimizer.step_split([([enc.conv1.weight], wst), (rest, prep)])      # conv0's four tensors: current stream
+            if not ok:
                 lib.check(lib.cpc_train_step_wait(f["main"], 1, main.cuda_stream), "train_step_wait")
                 return False
             B, L, K, N = f["key"][:4]
             f["parity"] ^= 1
             lib.check(lib.cpc_train_step_tail(f["params"], _lib.ptr(f["ws"]), B, L, K, N, f["parity"], main.cuda_stream,
-                                              wst.cuda_stream), "train_step_tail")
+                                              prep.cuda_stream, wst.cuda_stream), "train_step_tail")
             f["open"] = True
             f["ready"] = tuple(p._version for p in f["plist"])
         return True

@@ -420,8 +420,9 @@ int cpc_nce_scores_backward(const float* pred, const float* z, const int* ext, c
  * side_stream and wgrad_stream: every gradient is final on main_stream.  3 = both.  No host synchronisation anywhere.
  * Cross-step pipelining of a single-rank loop (cpc/train.py:78-91 is strictly serial: backward, optimizer.step, next forward):
  *   + 4 (with 2) open tail: main_stream does not wait for the step's LAST kernel, layer 1's weight gradient on wgrad_stream
- *     (0.13 ms past the end of main_stream's chain), only for everything else.  The caller then updates every parameter but
- *     conv1.weight on main_stream and conv1.weight on wgrad_stream (cpc_adam_step twice), calls cpc_train_step_tail, and gives
+ *     (0.13 ms past the end of main_stream's chain), and the bias / norm gradient sums of layers 1..4 run on prep_stream beside
+ *     the chain's last kernels.  The caller then updates conv0's parameters on main_stream, conv1.weight on wgrad_stream and the
+ *     rest on prep_stream (cpc_adam_step three times, cpc_train_step_wait for their gradients), calls cpc_train_step_tail, and gives
  *     the NEXT step + 8 (its weight layouts are ready; main_stream waits for conv1's in front of layer 1) and alternates + 16
  *     (second y0 buffer / bound set of the workspace: the next layer 0 runs while layer 1's weight gradient still reads y0).
  *   A caller that touches parameters or gradients outside these calls first joins with cpc_train_step_wait(main, 2, main). */
@@ -436,19 +437,24 @@ int cpc_train_step(const float* wave, const long* batchIdx, const long* seqIdx, 
  * the matrix pipes) instead of beside the next step's first conv layers. */
 int cpc_train_step_prefetch(const long* batchIdx, const long* seqIdx, float* workspace, int B, int L, int K, int N,
                             void* side_stream);
-/* The tail of an open-tailed step (phases + 4), after the optimiser's two launches: the next step's weight preparation (conv2..4
- * and the input bounds on main_stream, conv1's on wgrad_stream behind its update) for parity next_parity, and the event the next
- * step's layer 1 waits for.  params: the 20 encoder tensors (cpc_encoder_forward's order). */
+/* The tail of an open-tailed step (phases + 4), after the optimiser's three launches (conv0's parameters on main_stream,
+ * conv1.weight on wgrad_stream, every other parameter on prep_stream behind cpc_train_step_wait(main, 0 / 3 / 4, prep)): the
+ * next step's weight preparation, each share on the stream its parameters arrive on, for parity next_parity, and the events the
+ * next step's layer 1 waits for.  params: the 20 encoder tensors (cpc_encoder_forward's order). */
 int cpc_train_step_tail(const float* const* params, float* workspace, int B, int L, int K, int N, int next_parity,
-                        void* main_stream, void* wgrad_stream);
-/* waiting_stream waits for an event the last cpc_train_step on main_stream recorded: 0 = everything of wgrad_stream but layer 1's
- * weight gradient (conv2..4's weight gradients: a data-parallel caller's mid gradient bucket), 1 = layer 1's weight gradient,
- * 2 = cpc_train_step_tail's end (conv1's updated weight and layouts). */
+                        void* main_stream, void* prep_stream, void* wgrad_stream);
+/* waiting_stream waits for events the last cpc_train_step on main_stream recorded: 0 = everything of wgrad_stream but layer 1's
+ * weight gradient (the recurrence's and conv2..4's weight gradients: a data-parallel caller's mid gradient bucket), 1 = what an
+ * open-tailed step left open (layer 1's weight gradient + the bias / norm gradient sums on prep_stream), 2 =
+ * cpc_train_step_tail's end (every updated weight and layout), 3 = the heads' weight gradient, 4 = the bias / norm sums alone. */
 int cpc_train_step_wait(void* main_stream, int which, void* waiting_stream);
 /* In-step timing (diagnostic): while on, cpc_train_step records timing events around layer 0, layer 1 and the two persistent
  * recurrence launches on main_stream; cpc_get_step_timing waits for the last and writes the 4 durations of the most recent step
  * in microseconds (conv0, conv1, forward recurrence, backward recurrence; each includes one marker's cost). */
 int cpc_set_step_timing(int on);
+/* Measurement switch of the open tail: 0 (default) the next step's layer 0 starts behind the tail, 1 it runs under it and only
+ * layer 1 waits (measured slower: layer 0 gets a quarter of its wave slots beside layer 1's weight gradient). */
+int cpc_set_tail_schedule(int conv0_early);
 int cpc_get_step_timing(float* us);
 /* Measurement switches of cpc_train_step's schedule.  prep_point: where the criterion's index preparation (190 MB of index
  * traffic at B = 64) is released on side_stream -- 0 at the step's start (beside conv0, the one HBM-bound layer: 50 -> 96 us), 1

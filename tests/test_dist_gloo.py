@@ -63,6 +63,17 @@ def _worker(rank, world, port, out):
     ar2.begin()
     ar2()
     ok = ok and all(torch.equal(p.grad, torch.full_like(p, float(3 * (i + 1)))) for i, p in enumerate(params))
+    # three buckets (early | mid | late): on CPU tensors the mid bucket has no stream of its own and travels with the late one;
+    # buffer order and sums as with two
+    ar3 = FlatGradAllReduce(params, early=[params[1]], mid=[params[2]])
+    ok = ok and [id(p) for p in ar3.params] == [id(params[1]), id(params[2]), id(params[0])]
+    ok = ok and (ar3.n_early, ar3.n_mid, ar3.numel) == (7, 4, 26)
+    for rep in range(2):
+        for i, p in enumerate(params):
+            p.grad = torch.full_like(p, float((rank + 1) * (i + 1) + rep))
+        ar3.begin()
+        ar3(mid_wait=lambda stream: None)
+        ok = ok and all(torch.equal(p.grad, torch.full_like(p, float(3 * (i + 1) + 2 * rep))) for i, p in enumerate(params))
     # sharding: each rank draws its own sequences; no overlap, identical parameters
     g = torch.Generator().manual_seed(1234 + rank)
     wave = (0.1 * torch.randn(2, 1, 64, generator=g)).clamp_(-1, 1)

@@ -228,7 +228,8 @@ def test_open_tail_steps_with_the_weight_preparation_at_the_tail_change_no_bit_e
                 t.sub_(0.05 * g / (g.abs().max() + 1e-12) * t.abs().max())
             if pipelined:
                 parity ^= 1
-                assert lib.cpc_train_step_tail(parr, P(ws), B, L, K, N, parity, None, apart[2]) == 0
+                assert lib.cpc_train_step_wait(None, 0, apart[1]) == 0 and lib.cpc_train_step_wait(None, 3, apart[1]) == 0
+                assert lib.cpc_train_step_tail(parr, P(ws), B, L, K, N, parity, None, apart[1], apart[2]) == 0
                 assert lib.cpc_train_step_wait(None, 2, None) == 0
                 ready = True
         return res
@@ -240,8 +241,8 @@ def test_open_tail_steps_with_the_weight_preparation_at_the_tail_change_no_bit_e
             assert torch.equal(x, y), (step, n)
     assert not torch.equal(ref[0][0], ref[2][0])             # the updates did move the losses
     # argument checks of the new entry points
-    assert lib.cpc_train_step_wait(None, 3, None) == 2
-    assert lib.cpc_train_step_tail(None, None, B, L, K, N, 0, None, None) == 2
+    assert lib.cpc_train_step_wait(None, 5, None) == 2
+    assert lib.cpc_train_step_tail(None, None, B, L, K, N, 0, None, None, None) == 2
     assert lib.cpc_encoder_prepare_weights(None, None, None, B, L, 2, None) == 2
     # in-step timing markers on: same results (the emulator's events carry no time)
     assert lib.cpc_set_step_timing(1) == 0

@@ -87,8 +87,12 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None):
     acts = []
     # ReLU derivative of numerically tied pre-activations follows the device path (see oracle)
     ys = [t.cpu() for t in ys] + [z.cpu()]
+    O.tie_report()
     zr = O.encoder_forward(leaves, wave, collect=acts,
                            relu_override=[(y > 0).permute(0, 2, 1) for y in ys]).permute(0, 2, 1)
+    ties = O.tie_report()                    # (how many elements took the device's ReLU derivative: oracle.tie_report)
+    print(f"relu ties [B={B} L={L} mode={mode}]: {ties}")
+    assert O.tie_ok(ties) and ties["disagree_outside"] == 0, ties
     (zr * dz).sum().backward()
     return dict(z=z.cpu(), z_ref=zr.detach(), grads=[g_.cpu() for g_ in grads],
                 ref_grads=[leaves[n].grad for n in _names()], saved=saved, sizes=sizes, Ls=Ls, acts=acts, ys=ys)

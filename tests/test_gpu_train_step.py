@@ -68,7 +68,13 @@ def test_train_step_matches_oracle_and_reference_golden(case, golden_dir):
     bidx = torch.from_numpy(fx["batch_idx"].astype(np.int64))
     sidx = torch.from_numpy(fx["seq_idx"].astype(np.int64))
     hip = _hip_step(p, wave, bidx, sidx, dev)
+    O.tie_report()
     ora = O.train_step(p, wave, bidx, sidx, relu_override=hip["masks"])
+    # accounting of the ReLU-tie override: how many elements took the device's derivative (the rounding-tie rate of two correct
+    # fp32 paths, about one per million; never a systematic share of the window), none disagreeing outside the window
+    ties = O.tie_report()
+    print(f"relu ties [{case}]: {ties}")
+    assert O.tie_ok(ties) and ties["disagree_outside"] == 0, ties
 
     # --- north-star tolerance: encoder/context outputs and InfoNCE loss within 1e-4 (fp32)
     assert (hip["z"] - ora["z"]).abs().max().item() < 1e-4
@@ -94,8 +100,9 @@ def test_train_step_matches_oracle_and_reference_golden(case, golden_dir):
         for key, got, tol in (("dz_slice", hip["dz"][:, ::16, ::4], 2e-4),
                               ("g_whh0_slice", g["gAR.baseNet.weight_hh_l0"][::48, ::16], 2e-4),
                               ("g_head5_slice", g["wPrediction.predictors.5.weight"][::16, ::16], 2e-4),
-                              ("g_conv1_w_slice", g["gEncoder.conv1.weight"][::32, ::32, :], 5e-3),
-                              ("g_conv0_w", g["gEncoder.conv0.weight"], 5e-3)):
+                              # (no element took the override: the device's masks ARE the oracle's, and the fixtures' -- 2e-4)
+                              ("g_conv1_w_slice", g["gEncoder.conv1.weight"][::32, ::32, :], 5e-3 if ties["overridden"] else 2e-4),
+                              ("g_conv0_w", g["gEncoder.conv0.weight"], 5e-3 if ties["overridden"] else 2e-4)):
             ref = torch.from_numpy(fx[key])
             rel = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
             assert rel < tol, (key, rel)
