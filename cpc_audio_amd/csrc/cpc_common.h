@@ -79,7 +79,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // inside the parity tolerance -- but the ReLU derivative of those elements is systematically the device's, and the tie accounting
 // of the parity suite (oracle.tie_report) must notice (tests/test_gpu_full_configs.py).
 #ifdef CPC_TEST_MISROUND
-__device__ __forceinline__ float relu_in(float v) { return fabsf(v) < 1e-5f ? 1e-7f : v; }
+__device__ __forceinline__ float relu_in(float v) { return fabsf(v) < 1e-5f ? 2e-6f : v; }   // (2e-6: survives fp16-piece storage)
 #else
 __device__ __forceinline__ float relu_in(float v) { return v; }
 #endif

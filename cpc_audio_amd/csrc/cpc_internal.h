@@ -37,6 +37,10 @@ struct GemmGroup {
     int G = 1;
     long a = 0, b = 0, bias = 0, c = 0;
     long part = 0;      // tn_gemm: stride of the split partials (0: problem g's S * N1 * N2 floats right behind problem g-1's)
+    // tn_gemm: rows [k * out_scale_rows, (k + 1) * out_scale_rows) of C are multiplied by out_scale[k] (device floats) on their
+    // way out of the split reduction (the K prediction heads' weight gradient from the unit-gradient dPred, nce.hip)
+    const float* out_scale = nullptr;
+    int out_scale_rows = 0;
 };
 // A scratch buffer a narrow NT product may use to split its K walk over several workgroups per output tile (N = 256 gives
 // M / 128 tiles of the wide kernel -- 58 for the criterion's dc: a quarter of the chip): partial products land in `part`

@@ -193,11 +193,19 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(RowMap am, RowMap bm, int 
 
 __global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restrict__ part, int S,
                                                            long n, float* __restrict__ C, int accumulate, long c_gs,
-                                                           long part_gs) {
+                                                           long part_gs, const float* __restrict__ out_scale = nullptr,
+                                                           long scale_block = 0) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     part += part_gs ? (long)blockIdx.y * part_gs : (long)blockIdx.y * S * n;      // blockIdx.y: problem of a group
     C += (long)blockIdx.y * c_gs;
+    if (out_scale != nullptr) {               // (block k of scale_block elements) * out_scale[k]; accumulate adds the scaled sum
+        float s = 0.f;
+        for (int z = 0; z < S; ++z) s += part[(long)z * n + idx];
+        s *= out_scale[idx / scale_block];
+        C[idx] = accumulate ? C[idx] + s : s;
+        return;
+    }
     float s = accumulate ? C[idx] : 0.f;
     for (int z = 0; z < S; ++z) s += part[(long)z * n + idx];
     C[idx] = s;
@@ -503,7 +511,8 @@ int tn_gemm(const RowMap& am, int N1, const RowMap& bm, int N2, float* part, flo
         hipLaunchKernelGGL((tn_gemm_kernel<TnGX3>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n, bounds, grp);
     else
         hipLaunchKernelGGL((tn_gemm_kernel<TnG>), grid, dim3(256), 0, st, am, bm, N1, N2, rows, S, part, n, bounds, grp);
-    hipLaunchKernelGGL(split_reduce_kernel, dim3(cdiv(n, 256), grp.G), dim3(256), 0, st, part, S, n, C, accumulate, grp.c, grp.part);
+    hipLaunchKernelGGL(split_reduce_kernel, dim3(cdiv(n, 256), grp.G), dim3(256), 0, st, part, S, n, C, accumulate, grp.c, grp.part,
+                       grp.out_scale, (long)grp.out_scale_rows * N2);
     CPC_LAUNCH_CHECK();
     return 0;
 }

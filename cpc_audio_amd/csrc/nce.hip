@@ -180,6 +180,235 @@ __global__ __launch_bounds__(256, 3) void nce_fwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------ forward scores + the prediction gradient, ONE gather pass
+// The backward needs dPred[head][:] = sum_n dS[head][n] * cand[n][:] with dS = g_head * (softmax - [n = 0]) -- the same 1 KB
+// candidate rows the scores were just formed from (1.06 GB of gathers at B = 64, of which 625 MB miss the 4 MB L2 and come out of
+// the Infinity Cache: nce_bwd_dpred_kernel spent 170 us of the main stream on fetching them a second time).  The softmax weights
+// of a window are only known after its last candidate, but the weighted row sum can be carried along unnormalised, exactly as
+// the denominator is (the "online softmax" of the scores above):
+//     U[head][:] = sum_n exp(l[head][n] - M[head]) * neg[n][:]         (rescaled by exp(M - M') whenever the reference moves)
+//     T[head][:] = exp(M - lse) * U[head][:] + (p0 - 1) * pos[head][:]  = d loss_head / d pred_head   for a UNIT upstream gradient
+// so this kernel does in one pass over the gathered rows what nce_fwd_kernel + nce_bwd_dpred_kernel did in two: the rows a
+// lane group has just gathered for the transposition ARE the B operand of the second product (candidate = contraction index,
+// channel in the low lane bits), and the weights exp(l - M) come out of the first product in the A-operand layout -- once
+// lane group r4 gathers candidates 4 r4 + q instead of 4 q + r4 -- so the second product costs 64 more MFMAs per 16-candidate
+// tile and no data movement.  The per-head upstream gradients g_head (gloss / (B W C)) are applied by the consumers: the dc GEMM
+// reads the stacked head weights pre-multiplied by g_head, the heads' weight gradient is scaled per 256-row block on its way
+// out of the split reduction, the dz path forms its dS rows from the saved logits (nce_ds_kernel).  T replaces dPred.
+constexpr int kNceFusedMaxN = 512;      // nce_ds_kernel's LDS tile: negatives per window the one-pass path takes
+
+struct Gather16R {                                      // Gather16 with lane group r4 holding rows 4 r4 + q
+    float4 v[4][4];                                   // [q][g]: piece c of row 4 r4 + q, column block g
+    __device__ __forceinline__ void issue(const float* const (&rowp)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[q][g] = ld4(rowp[q] + 64 * g);
+    }
+    __device__ __forceinline__ void block(int g, float4* tile, float4 (&out)[4]) const {
+        const int lane = threadIdx.x & 63, c = lane & 15, r4 = lane >> 4;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tile[(4 * r4 + q) * 16 + (c ^ (4 * r4 + q))] = v[q][g];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = tile[c * 16 + ((4 * e + r4) ^ c)];
+    }
+};
+
+// as nce_fwd_kernel, plus tpred [BW][K*C] = T and its max|.| into tamax (kAmaxSlots slots, zeroed by the caller)
+__global__ __launch_bounds__(256, 2) void nce_fwd_fused_kernel(
+    const float* __restrict__ pred, const float* __restrict__ z, const int* __restrict__ ext,
+    float* __restrict__ logits, float* __restrict__ lse_out, float* __restrict__ rowstat, float* __restrict__ tpred,
+    float* __restrict__ tamax, int BW, int W, int S, int K, int N, unsigned* __restrict__ ticket) {
+    __shared__ float4 tiles[4][256];
+    const int lane = threadIdx.x & 63;
+    const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;
+    if (bt >= BW) return;
+    float4* tile = tiles[threadIdx.x >> 6];
+    const int b = bt / W, t = bt - b * W;
+    const int i = lane & 15, kq = lane >> 4;
+    const bool hv = i < K;
+    const float inv = 1.0f / kC;
+    Gather16R gt;
+    const float* rowp[4];
+
+    float4 pa[16];                                  // pred[head i][16 ii + 4 kq ..]
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int head = 4 * kq + q;
+            rowp[q] = pred + ((long)bt * K + (head < K ? head : 0)) * kC + 4 * i;
+        }
+        gt.issue(rowp);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 o[4];
+            gt.block(g, tile, o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pa[4 * g + e] = hv ? o[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    auto score_tile = [&]() __attribute__((always_inline)) {      // gt holds 16 rows of z: scores of row i against the heads
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 zf[4];
+            gt.block(g, tile, zf);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(zf[e], jj), f4c(pa[4 * g + e], jj), acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    float posl;
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int head = 4 * kq + q;
+            rowp[q] = z + ((long)b * S + t + (head < K ? head : 0) + 1) * kC + 4 * i;
+        }
+        gt.issue(rowp);
+        const f32x4 acc = score_tile();
+        // acc[r] on lane (i, q) = score(positive row of head 4q+r, head i); the diagonal sits on lane (i, i >> 2), reg i & 3
+        const float mine = (i & 3) == 0 ? acc[0] : (i & 3) == 1 ? acc[1] : (i & 3) == 2 ? acc[2] : acc[3];
+        posl = __shfl(mine, i + 16 * (i >> 2)) * inv;
+    }
+    float M = posl;
+    float ssum = kq == 0 ? 1.0f : 0.0f;
+    float mneg = -3.0e38f;
+    f32x4 U[16];                                     // U[4 g + e][r]: head 4 kq + r, channel 64 g + 4 i + e
+#pragma unroll
+    for (int q = 0; q < 16; ++q) U[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < N / 16; ++nt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rowp[q] = z + (long)ext[(long)bt * N + nt * 16 + 4 * kq + q] * kC + 4 * i;
+        gt.issue(rowp);
+        const f32x4 acc = score_tile();
+        // acc[r] = score of head i against negative nt*16 + 4 kq + r
+        float l[4], lmax = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            l[r] = acc[r] * inv;
+            if (hv) logits[((long)bt * K + i) * (N + 1) + 1 + nt * 16 + 4 * kq + r] = l[r];
+            lmax = fmaxf(lmax, l[r]);
+        }
+        mneg = fmaxf(mneg, lmax);
+        if (__any(lmax - M > 40.0f)) {              // (wave-uniform) move the reference: rare
+            float tm = fmaxf(lmax, __shfl_xor(lmax, 16));
+            tm = fmaxf(tm, __shfl_xor(tm, 32));
+            const float Mn = fmaxf(M, tm), alpha = expf(M - Mn);
+            ssum *= alpha;
+            M = Mn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {           // head 4 kq + r's factor lives on lane 4 kq + r (any lane group)
+                const float ar = __shfl(alpha, 4 * kq + r);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) U[q][r] *= ar;
+            }
+        }
+        float pw[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pw[r] = hv ? expf(l[r] - M) : 0.f;      // (padding heads: exactly 0 -- their logits alias head 0's row)
+            ssum += hv ? pw[r] : expf(l[r] - M);    // (their sums are never read; kept finite either way)
+        }
+        // second product: U[head][channel] += sum over this tile's candidates of exp(l - M) * row.  Call q contracts the four
+        // candidates 4 r4 + q (one per lane group): A = pw[q] on lane (head i, r4 = kq), B = the row lane group r4 gathered
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    U[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[q], f4c(gt.v[q][g], e), U[4 * g + e], 0, 0, 0);
+    }
+    ssum += __shfl_xor(ssum, 16);
+    ssum += __shfl_xor(ssum, 32);
+    mneg = fmaxf(mneg, __shfl_xor(mneg, 16));
+    mneg = fmaxf(mneg, __shfl_xor(mneg, 32));
+    const float lse = M + logf(ssum);
+    if (kq == 0 && hv) {
+        logits[((long)bt * K + i) * (N + 1)] = posl;
+        lse_out[(long)bt * K + i] = lse;
+        rowstat[(long)bt * 2 * K + i] = lse - posl;
+        rowstat[(long)bt * 2 * K + K + i] = posl >= mneg ? 1.f : 0.f;
+    }
+    // ---- T = exp(M - lse) * U + (p0 - 1) * pos;  C layout of U: head = 4 kq + r, channel = 64 g + 4 i + e
+    const float fac = expf(M - lse), p0m1 = expf(posl - lse) - 1.0f;       // per head i (equal over the lane groups)
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int head = 4 * kq + r;
+        const float fr = __shfl(fac, head), dr = __shfl(p0m1, head);       // convergent: before the guard
+        if (head < K) {
+            const float* zp = z + ((long)b * S + t + head + 1) * kC + 4 * i;
+            float* op = tpred + ((long)bt * K + head) * kC + 4 * i;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 zv = ld4(zp + 64 * g);
+                float4 o;
+                o.x = fmaf(dr, zv.x, fr * U[4 * g + 0][r]);
+                o.y = fmaf(dr, zv.y, fr * U[4 * g + 1][r]);
+                o.z = fmaf(dr, zv.z, fr * U[4 * g + 2][r]);
+                o.w = fmaf(dr, zv.w, fr * U[4 * g + 3][r]);
+                *reinterpret_cast<float4*>(op + 64 * g) = o;
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            }
+        }
+    }
+    amax = wave_max(amax);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(tamax + (bt & (kAmaxSlots - 1))), __float_as_uint(amax));
+}
+
+// dS rows of the re-associated dz path (nce_bwd_g_kernel) from the saved logits: slot bt * (N + K) + j carries the 16 heads'
+// score gradients of candidate j (j < N: g_head * exp(l - lse); j >= N: the positive of head j - N, g (p0 - 1) on its own head,
+// 0 elsewhere) -- what nce_bwd_dpred_kernel wrote on its way.  One workgroup per window; the (head, candidate) -> (candidate,
+// head) transposition goes through LDS.
+__global__ __launch_bounds__(256) void nce_ds_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                     const float* __restrict__ gscale, float* __restrict__ dS, int K, int N) {
+    __shared__ float ds_lds[(kNceFusedMaxN + 16) * 16];      // [(N + K)][16]
+    const int bt = blockIdx.x, tid = threadIdx.x;
+    const int NK = N + K;
+    for (int idx = tid; idx < NK * 16; idx += 256) ds_lds[idx] = 0.f;
+    __syncthreads();
+    // (two iterations at a time, the compiler pairs the subtractions / multiplies into v_pk_*_f32: build.py's gate)
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (int idx = tid; idx < K * N; idx += 256) {
+        const int head = idx / N, j = idx - head * N;
+        const float a = gscale[head] * expf(logits[((long)bt * K + head) * (N + 1) + 1 + j] - lse[(long)bt * K + head]);
+        ds_lds[j * 16 + head] = a;
+    }
+    if (tid < K)
+        ds_lds[(N + tid) * 16 + tid] = gscale[tid] * (expf(logits[((long)bt * K + tid) * (N + 1)] - lse[(long)bt * K + tid]) - 1.0f);
+    __syncthreads();
+    float* out = dS + (long)bt * NK * 16;
+    for (int idx = tid; idx < NK * 4; idx += 256)
+        reinterpret_cast<float4*>(out)[idx] = reinterpret_cast<const float4*>(ds_lds)[idx];
+}
+
+// wallT_g[i][k*256 + o] = g_k * wall[(k*256 + o)*256 + i]: the stacked head weights transposed AND pre-multiplied by the heads'
+// upstream gradients -- the B operand of dc = T . wallT_g^T (the one-pass criterion keeps T, the unit-gradient dPred)
+__global__ __launch_bounds__(256) void nce_wallT_scaled_kernel(const float* __restrict__ wall, const float* __restrict__ gscale,
+                                                               float* __restrict__ out, int K) {
+    __shared__ float tile[32][33];
+    const int R = K * kC;                               // rows of wall
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int q = ty; q < 32; q += 8) {
+        const int r = r0 + q;
+        tile[q][tx] = r < R ? wall[(long)r * kC + c0 + tx] * gscale[r >> kCLog2] : 0.f;
+    }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {
+        const int r = r0 + tx;
+        if (r < R) out[(long)(c0 + q) * R + r] = tile[tx][q];
+    }
+}
+
 // Column sums of rowstat [nrows][n <= 32] -> losses / accuracies, in ONE launch: block g sums its rows_per_group rows into
 // tmp[g] (the arithmetic and order of rows_sum_kernel), takes a ticket, and the block that draws the last ticket folds the
 // groups (again rows_sum_kernel's order) and scales.  `ticket` was cleared by the kernel that produced rowstat.  Replaces two
@@ -252,10 +481,11 @@ __global__ __launch_bounds__(64) void nce_gscale_kernel(const float* __restrict_
         return;
     }
     const int k = threadIdx.x;
-    if (k < K) gscale[k] = gloss[k] * f;
+    const float gk = k < K ? gloss[k] * f : 0.f;
+    if (k < K) gscale[k] = gk;
     if (fwd_bounds != nullptr) {
-        const float cm = wave_max(fwd_bounds[k]), wm = wave_max(fwd_bounds[kAmaxSlots + k]);
-        if (k == 0) { gscale[17] = cm; gscale[18] = wm; }
+        const float cm = wave_max(fwd_bounds[k]), wm = wave_max(fwd_bounds[kAmaxSlots + k]), gm = wave_max(fabsf(gk));
+        if (k == 0) { gscale[17] = cm; gscale[18] = wm; gscale[19] = wm * gm; }    // [19]: bound of the heads' weights * g_k (fused)
         gscale[64 + k] = 0.f;
         gscale[128 + k] = 0.f;
     }
@@ -663,9 +893,12 @@ __global__ __launch_bounds__(256) void nce_fill_kernel(const int* __restrict__ d
 }
 
 // ------------------------------------------------------------------ host side
+int g_nce_fused = 1;       // cpc_set_nce_fused: 1 (default) the one-pass criterion (nce_fwd_fused_kernel: scores and the unit-gradient
+                           // dPred from ONE gather pass; linear heads, N <= 512), 0 the two-pass kernels (nce_fwd_kernel + nce_bwd_dpred_kernel)
+
 struct NceLayout {
     int W, BW;
-    long pred, logits, lse, bounds, saved_total;
+    long pred, logits, lse, bounds, tpred, saved_total;
     long rowstat, tmp, sums, fwd_total;
     long dpred, wallT, part, gscale, V, dS, G, wcat, part_dz, bwd_total;
 };
@@ -680,7 +913,8 @@ static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     n.pred = o; o += align64l((long)n.BW * K * kC);
     n.logits = o; o += align64l((long)n.BW * K * (N + 1));
     n.lse = o; o += align64l((long)n.BW * K);
-    n.bounds = o; o += 2 * kAmaxSlots;       // max|c|, max|wall| as 64 partial maxima each (linear heads only)
+    n.bounds = o; o += 3 * kAmaxSlots;       // max|c|, max|wall| as 64 partial maxima each (linear heads only); max|T| slots (fused)
+    n.tpred = o; o += align64l((long)n.BW * K * kC);      // T: d loss_k / d pred_k for a unit upstream gradient (one-pass criterion)
     n.saved_total = o;
     o = 0;
     n.rowstat = o; o += align64l((long)n.BW * 2 * K);
@@ -714,12 +948,28 @@ static RowMap window_rows(const float* c, int B, int S, int W) {     // rows (b,
 }
 
 // scores, log-softmax, per-head loss / accuracy from given predictions
+static bool nce_fused(int N) { return g_nce_fused && N <= kNceFusedMaxN; }
+// wall^T for dc = dPred . wall: plain, or -- one-pass criterion, whose dPred is the unit-gradient T -- pre-multiplied by the heads'
+// upstream gradients (scratch + gscale must hold them: nce_gscale_kernel on this stream or one it has waited for)
+static int nce_wallT(const float* wall, float* scratch, const NceLayout& n, int K, int N, hipStream_t st) {
+    if (!nce_fused(N)) return transpose(wall, scratch + n.wallT, K * kC, kC, st);
+    hipLaunchKernelGGL(nce_wallT_scaled_kernel, dim3(kC / 32, cdiv(K * kC, 32)), dim3(256), 0, st, wall, scratch + n.gscale,
+                       scratch + n.wallT, K);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
 static int nce_scores_forward(const NceLayout& n, const float* pred, const float* z, const int* ext, float* saved,
                               float* scratch, float* losses, float* acc, int S, int K, int N, hipStream_t st,
-                              hipStream_t fin = nullptr) {
+                              hipStream_t fin = nullptr, bool fused = false) {
     // fin (nullptr: st): the stream the loss / accuracy reduction runs on.  Nothing of the backward reads its results (the
     // score gradients come from the saved logits), so a caller that joins `fin` later takes 15 us off its critical path.
+    // fused: the one-pass kernel, which also leaves T (unit-gradient dPred) and max|T| in `saved` (slots zeroed by the caller)
     unsigned* ticket = reinterpret_cast<unsigned*>(scratch + n.sums + 32);
+    if (fused)
+        hipLaunchKernelGGL(nce_fwd_fused_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
+                           saved + n.lse, scratch + n.rowstat, saved + n.tpred, saved + n.bounds + 2 * kAmaxSlots, n.BW, n.W, S,
+                           K, N, ticket);
+    else
     hipLaunchKernelGGL(nce_fwd_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
                        saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket);
     CPC_LAUNCH_CHECK();
@@ -760,10 +1010,16 @@ static int nce_dz_rows_path(const NceLayout& n, const float* pred, const float* 
 // max|G| slots nce_gscale_kernel left there): Wcat, the per-destination gather-GEMM G, then dz = G . Wcat^T on the
 // split-K wide tile.  Reads nothing of V's size: ~100 MB of G + 66 MB of dS at B = 64.
 static int nce_dz_linear_path(const NceLayout& n, const float* c, const float* wall, const int* perm, const int* row_ptr,
-                              float* scratch, float* dz, int B, int S, int K, int N, hipStream_t st) {
+                              float* scratch, float* dz, int B, int S, int K, int N, hipStream_t st,
+                              const float* saved_for_ds = nullptr) {
     float* G = scratch + n.G, *wcat = scratch + n.wcat;
     float* bnd = scratch + n.gscale;
     const bool h2 = g_mfma_mode >= 2;
+    // one-pass criterion: nobody has written the dS rows yet -- they come from the saved logits here (46 MB read, 66 MB
+    // written at B = 64), on the stream of the dz path
+    if (saved_for_ds != nullptr)
+        hipLaunchKernelGGL(nce_ds_kernel, dim3(n.BW), dim3(256), 0, st, saved_for_ds + n.logits, saved_for_ds + n.lse,
+                           scratch + n.gscale, scratch + n.dS, K, N);
     hipLaunchKernelGGL(nce_wcat_kernel, dim3(cdiv(K * kC, 4)), dim3(256), 0, st, wall, wcat, K);
     hipLaunchKernelGGL(nce_bwd_g_kernel, dim3(B * S), dim3(64), 0, st, c, scratch + n.dS, perm, row_ptr, G, n.W, S, K, N + K,
                        h2 ? bnd + 128 : (float*)nullptr);
@@ -852,10 +1108,10 @@ static int nce_forward(const float* c, const float* z, const float* wall, const 
     float* pred = saved + n.pred;
     // operand bounds for the fp16-split GEMMs of this call and of the backward (one small launch: 11 MB read)
     // (written in every mode: the backward may run in another one)
-    if (!bounds_ready) {
-        const float* xs[2] = {c, wall};
-        const long ns[2] = {(long)B * S * kC, (long)K * kC * kC};
-        int rc = absmax_slots(xs, ns, 2, saved + n.bounds, st);
+    if (!bounds_ready) {                         // (third job: the max|T| slots of the one-pass kernel, zeroed)
+        const float* xs[3] = {c, wall, nullptr};
+        const long ns[3] = {(long)B * S * kC, (long)K * kC * kC, 0};
+        int rc = absmax_slots(xs, ns, 3, saved + n.bounds, st);
         if (rc) return rc;
     }
     GemmBounds gb;
@@ -863,7 +1119,7 @@ static int nce_forward(const float* c, const float* z, const float* wall, const 
     gb.b = saved + n.bounds + kAmaxSlots; gb.b_slots = kAmaxSlots;
     int rc = nt_gemm(window_rows(c, B, S, n.W), wall, kC, nullptr, pred, (long)K * kC, K * kC, kC, st, 0, 0, gb);
     if (rc) return rc;
-    return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, st, fin);
+    return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, st, fin, nce_fused(N));
 }
 
 extern "C" int cpc_nce_forward(const float* c, const float* z, const float* wall, const int* ext, float* saved,
@@ -882,10 +1138,10 @@ extern "C" int cpc_nce_bounds(const float* c, float c_bound, const float* wall, 
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!wall || !saved || (!(c_bound > 0.f) && !c), CPC_ERR_ARG);
-    const float* xs[2] = {c_bound > 0.f ? nullptr : c, wall};
-    const long ns[2] = {(long)B * S * kC, (long)K * kC * kC};
-    const float cv[2] = {c_bound, 0.f};
-    return absmax_slots(xs, ns, 2, saved + n.bounds, (hipStream_t)stream, cv);
+    const float* xs[3] = {c_bound > 0.f ? nullptr : c, wall, nullptr};
+    const long ns[3] = {(long)B * S * kC, (long)K * kC * kC, 0};
+    const float cv[3] = {c_bound, 0.f, 0.f};
+    return absmax_slots(xs, ns, 3, saved + n.bounds, (hipStream_t)stream, cv);
 }
 
 extern "C" int cpc_nce_forward_prepared(const float* c, const float* z, const float* wall, const int* ext, float* saved,
@@ -916,7 +1172,7 @@ extern "C" int cpc_nce_backward_prepare(const float* wall, const float* saved, c
     hipLaunchKernelGGL(nce_gscale_kernel, dim3(1 + 128), dim3(64), 0, st, gloss, scratch + n.gscale, K,
                        1.0f / ((float)n.BW * (float)kC), h2 ? saved + n.bounds : (const float*)nullptr, dc, B, S, n.W);
     CPC_LAUNCH_CHECK();
-    return transpose(wall, scratch + n.wallT, K * kC, kC, st);
+    return nce_wallT(wall, scratch, n, K, N, st);
 }
 
 // Same criterion on predictions computed by the caller (any prediction network, e.g. --rnnMode transformer):
@@ -957,12 +1213,13 @@ extern "C" int cpc_nce_backward(const float* c, const float* z, const float* wal
 
 // The dz path alone (linear heads), from the score gradients the cpc_nce_backward_streams(dz = NULL) call left in
 // `scratch`: `stream` must wait for that call.
-extern "C" int cpc_nce_backward_dz(const float* c, const float* wall, const int* perm, const int* row_ptr, float* scratch,
-                                   float* dz, int B, int S, int K, int N, void* stream) {
+extern "C" int cpc_nce_backward_dz(const float* c, const float* wall, const int* perm, const int* row_ptr, const float* saved,
+                                   float* scratch, float* dz, int B, int S, int K, int N, void* stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
-    CPC_RETURN_IF(!c || !wall || !perm || !row_ptr || !scratch || !dz, CPC_ERR_ARG);
-    return nce_dz_linear_path(n, c, wall, perm, row_ptr, scratch, dz, B, S, K, N, (hipStream_t)stream);
+    CPC_RETURN_IF(!c || !wall || !perm || !row_ptr || !saved || !scratch || !dz, CPC_ERR_ARG);
+    return nce_dz_linear_path(n, c, wall, perm, row_ptr, scratch, dz, B, S, K, N, (hipStream_t)stream,
+                              nce_fused(N) ? saved : nullptr);
 }
 
 // As cpc_nce_backward, with the dz path launched on `dz_stream` behind an event recorded on `stream` once the score
@@ -991,28 +1248,39 @@ static int nce_backward_impl(const float* c, const float* z, const float* wall, 
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream, st_dz = (hipStream_t)dz_stream;
-    float* dpred = scratch + n.dpred, *wallT = scratch + n.wallT;
+    const bool fused = nce_fused(N);         // the forward left T (unit-gradient dPred) and max|T| in `saved`: no score-gradient pass
+    float* dpred = fused ? const_cast<float*>(saved) + n.tpred : scratch + n.dpred, *wallT = scratch + n.wallT;
     const bool h2 = g_mfma_mode >= 2;        // the forward left the operand bounds in `saved`
-    int rc = nce_scores_backward(n, z, ext, saved, gloss, scratch, dpred, B, S, K, N, st, h2 ? saved + n.bounds : nullptr, dc,
+    int rc = 0;
+    if (fused) {
+        if (!prepared)
+            hipLaunchKernelGGL(nce_gscale_kernel, dim3(1 + 128), dim3(64), 0, st, gloss, scratch + n.gscale, K,
+                               1.0f / ((float)n.BW * (float)kC), h2 ? saved + n.bounds : (const float*)nullptr, dc, B, S, n.W);
+        CPC_LAUNCH_CHECK();
+    } else {
+        rc = nce_scores_backward(n, z, ext, saved, gloss, scratch, dpred, B, S, K, N, st, h2 ? saved + n.bounds : nullptr, dc,
                                  scratch + n.dS, prepared);
-    if (rc) return rc;
+        if (rc) return rc;
+    }
     if (dz != nullptr) {
         if (st_dz != st) {
             hipEvent_t* ev = stream_events(st);
             CPC_RETURN_IF(!ev, CPC_ERR_ARG);
             CPC_RETURN_IF(hipEventRecord(ev[9], st) != hipSuccess || hipStreamWaitEvent(st_dz, ev[9], 0) != hipSuccess, CPC_ERR_ARG);
         }
-        rc = nce_dz_linear_path(n, c, wall, perm, row_ptr, scratch, dz, B, S, K, N, st_dz);
+        rc = nce_dz_linear_path(n, c, wall, perm, row_ptr, scratch, dz, B, S, K, N, st_dz, fused ? saved : nullptr);
         if (rc) return rc;
     }
-    const float* bnd = scratch + n.gscale;                        // [17] max|c|, [18] max|wall|, [64..127] max|dPred| slots
+    const float* bnd = scratch + n.gscale;   // [17] max|c|, [18] max|wall|, [19] max|wall| max|g|, [64..127] max|dPred| slots
     GemmBounds gdc, gdw;
+    GemmGroup gdw_grp;
     if (h2) {
-        gdc.a = gdw.a = bnd + 64; gdc.a_slots = gdw.a_slots = kAmaxSlots;
-        gdc.b = bnd + 18; gdw.b = bnd + 17;
+        gdc.a = gdw.a = fused ? saved + n.bounds + 2 * kAmaxSlots : bnd + 64; gdc.a_slots = gdw.a_slots = kAmaxSlots;
+        gdc.b = fused ? bnd + 19 : bnd + 18; gdw.b = bnd + 17;
     }
-    // dc[:, :W] = dPred . Wall  (NT against Wall^T [256][K*256])
-    if (!prepared) rc = transpose(wall, wallT, K * kC, kC, st);
+    if (fused) { gdw_grp.out_scale = bnd; gdw_grp.out_scale_rows = kC; }      // dW_k = g_k T_k^T . c
+    // dc[:, :W] = dPred . Wall  (NT against Wall^T [256][K*256]; fused: T against g_k-scaled rows)
+    if (!prepared) rc = nce_wallT(wall, scratch, n, K, N, st);
     if (rc) return rc;
     SplitK sk;                           // N = 256: 58 row tiles at B = 64; the head gradient's partial buffer is free until it
     sk.part = scratch + n.part;          // starts (behind this GEMM, on either stream)
@@ -1022,18 +1290,32 @@ static int nce_backward_impl(const float* c, const float* z, const float* wall, 
     if (rc || !dwall) return rc;
     // dW_k = dPred_k^T . c[:, :W]
     return tn_gemm(plain_rows(dpred, n.BW, K * kC), K * kC, window_rows(c, B, S, n.W), kC, scratch + n.part,
-                   dwall, 0, st, gdw);
+                   dwall, 0, st, gdw, gdw_grp);
 }
 
 // The head-weight gradient alone, from the dPred that cpc_nce_backward_streams(dwall = NULL) left in `scratch`:
 // nothing on the way to the encoder depends on it, so the caller may run it on any stream that waits for that call.
-extern "C" int cpc_nce_backward_dwall(const float* c, float* scratch, float* dwall, int B, int S, int K, int N,
-                                      void* stream) {
+extern "C" int cpc_nce_backward_dwall(const float* c, const float* saved, float* scratch, float* dwall, int B, int S, int K,
+                                      int N, void* stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
-    CPC_RETURN_IF(!c || !scratch || !dwall, CPC_ERR_ARG);
+    CPC_RETURN_IF(!c || !saved || !scratch || !dwall, CPC_ERR_ARG);
+    const bool fused = nce_fused(N);
     GemmBounds gdw;                                               // left by cpc_nce_backward_streams (nce_gscale_kernel)
-    if (g_mfma_mode >= 2) { gdw.a = scratch + n.gscale + 64; gdw.a_slots = kAmaxSlots; gdw.b = scratch + n.gscale + 17; }
-    return tn_gemm(plain_rows(scratch + n.dpred, n.BW, K * kC), K * kC, window_rows(c, B, S, n.W), kC,
-                   scratch + n.part, dwall, 0, (hipStream_t)stream, gdw);
+    GemmGroup grp;
+    if (g_mfma_mode >= 2) {
+        gdw.a = fused ? saved + n.bounds + 2 * kAmaxSlots : scratch + n.gscale + 64; gdw.a_slots = kAmaxSlots;
+        gdw.b = scratch + n.gscale + 17;
+    }
+    if (fused) { grp.out_scale = scratch + n.gscale; grp.out_scale_rows = kC; }
+    return tn_gemm(plain_rows(fused ? saved + n.tpred : scratch + n.dpred, n.BW, K * kC), K * kC, window_rows(c, B, S, n.W), kC,
+                   scratch + n.part, dwall, 0, (hipStream_t)stream, gdw, grp);
+}
+
+// 1 (default): the linear heads' criterion in one gather pass -- the forward leaves T, the unit-gradient dPred, in its saved
+// workspace and the backward starts with the dc GEMM; 0: the two-pass kernels (nce_fwd_kernel, nce_bwd_dpred_kernel).  A forward
+// and its backward must run under the same setting.
+extern "C" int cpc_set_nce_fused(int on) {
+    g_nce_fused = on ? 1 : 0;
+    return 0;
 }

@@ -232,7 +232,7 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
                                               nullptr, B, S, K, N, M, M);
         if (rc) return rc;
         if (g_dz_early) {
-            rc = cpc_nce_backward_dz(c, wall, perm, row_ptr, ws + s.nce_bscr, dz, B, S, K, N, M);
+            rc = cpc_nce_backward_dz(c, wall, perm, row_ptr, ws + s.nce_saved, ws + s.nce_bscr, dz, B, S, K, N, M);
             if (rc) return rc;
         }
         CPC_RETURN_IF(!rec(ev[3], M) || !wait(M, ev[2]), CPC_ERR_ARG);
@@ -243,11 +243,11 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
         // a chip full of gather blocks), the dz path and behind it the heads' gradient on the side stream
         CPC_RETURN_IF(!wait(S0, ev[3]), CPC_ERR_ARG);
         if (!g_dz_early) {
-            rc = cpc_nce_backward_dz(c, wall, perm, row_ptr, ws + s.nce_bscr, dz, B, S, K, N, S0);
+            rc = cpc_nce_backward_dz(c, wall, perm, row_ptr, ws + s.nce_saved, ws + s.nce_bscr, dz, B, S, K, N, S0);
             if (rc) return rc;
             CPC_RETURN_IF(!rec(ev[4], S0), CPC_ERR_ARG);
         }
-        rc = cpc_nce_backward_dwall(c, ws + s.nce_bscr, dwall, B, S, K, N, S0);
+        rc = cpc_nce_backward_dwall(c, ws + s.nce_saved, ws + s.nce_bscr, dwall, B, S, K, N, S0);
         if (rc) return rc;
         CPC_RETURN_IF(!rec(ev[5], S0), CPC_ERR_ARG);
         if (!g_dz_early) CPC_RETURN_IF(!wait(M, ev[4]), CPC_ERR_ARG);

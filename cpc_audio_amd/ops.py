@@ -538,9 +538,9 @@ class InfoNCEFunction(torch.autograd.Function):
 
                 def dz_path():            # ... dz later, on the side stream, once the AR backward has been launched
                     side.wait_event(ready)
-                    lib.check(lib.cpc_nce_backward_dz(_p(c), _p(wall), _p(perm), _p(row_ptr), _p(scratch), _p(dz),
+                    lib.check(lib.cpc_nce_backward_dz(_p(c), _p(wall), _p(perm), _p(row_ptr), _p(saved), _p(scratch), _p(dz),
                                                       B, S, K, N, side.cuda_stream), "nce_backward_dz")
-                    for t in (dz, scratch, c, wall, perm, row_ptr):
+                    for t in (dz, scratch, c, wall, perm, row_ptr, saved):
                         t.record_stream(side)                     # the allocator must not recycle them early
                     ev = torch.cuda.Event()
                     ev.record(side)
@@ -550,7 +550,7 @@ class InfoNCEFunction(torch.autograd.Function):
                 else:
                     # somebody this package does not know may read dz as soon as this backward returns (criterion mode
                     # 'reverse': a torch.flip; a foreign autoregressor): it is formed now, on this stream
-                    lib.check(lib.cpc_nce_backward_dz(_p(c), _p(wall), _p(perm), _p(row_ptr), _p(scratch), _p(dz),
+                    lib.check(lib.cpc_nce_backward_dz(_p(c), _p(wall), _p(perm), _p(row_ptr), _p(saved), _p(scratch), _p(dz),
                                                       B, S, K, N, main.cuda_stream), "nce_backward_dz")
                     ready.record(main)         # the head gradient on the side stream reads the same scratch
                 if heads:
@@ -558,7 +558,7 @@ class InfoNCEFunction(torch.autograd.Function):
                     def dwall_path():     # ... and the head-weight gradient after it: only the optimiser reads it
                         side.wait_event(ready)
                         with torch.cuda.stream(side):
-                            lib.check(lib.cpc_nce_backward_dwall(_p(c), _p(scratch), _p(dheads), B, S, K, N,
+                            lib.check(lib.cpc_nce_backward_dwall(_p(c), _p(saved), _p(scratch), _p(dheads), B, S, K, N,
                                                                  side.cuda_stream), "nce_backward_dwall")
                             with torch.no_grad():
                                 for k, h in enumerate(heads):
@@ -570,7 +570,7 @@ class InfoNCEFunction(torch.autograd.Function):
                                     else:
                                         h.grad.add_(g)
                                         h.grad.record_stream(side)
-                        for t in (c, scratch, dheads):
+                        for t in (c, scratch, dheads, saved):
                             t.record_stream(side)
                         ev = torch.cuda.Event()
                         ev.record(side)

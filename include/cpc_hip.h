@@ -381,13 +381,21 @@ int cpc_nce_backward_streams(const float* c, const float* z, const float* wall, 
                              float* scratch, float* dc, float* dz, float* dwall, int B, int S, int K, int N,
                              void* stream, void* dz_stream);
 
-int cpc_nce_backward_dz(const float* c, const float* wall, const int* perm, const int* row_ptr, float* scratch,
-                        float* dz, int B, int S, int K, int N, void* stream);
+int cpc_nce_backward_dz(const float* c, const float* wall, const int* perm, const int* row_ptr, const float* saved,
+                        float* scratch, float* dz, int B, int S, int K, int N, void* stream);
 
 /* cpc_nce_backward_streams also accepts dwall == NULL: the head-weight gradient (criterion.py:44-50, the K
  * nn.Linear weights) is then left out and formed later by this call from the dPred kept in `scratch`; nothing on
  * the way to the encoder depends on it.  `stream` must wait for the cpc_nce_backward_streams call. */
-int cpc_nce_backward_dwall(const float* c, float* scratch, float* dwall, int B, int S, int K, int N, void* stream);
+int cpc_nce_backward_dwall(const float* c, const float* saved, float* scratch, float* dwall, int B, int S, int K, int N,
+                           void* stream);
+/* The linear heads' criterion in ONE gather pass (default, 1): the scoring kernel of cpc_nce_forward* carries the softmax-weighted
+ * sum of the candidate rows along with the log-sum-exp (an online softmax over criterion.py:108-116's candidates) and leaves
+ * T = d loss_k / d pred_k for a unit upstream gradient in `saved`; the backward then has no score-gradient pass over the 1 KB
+ * candidate rows (criterion.py:200-201's gather, 1.06 GB at B = 64) -- the heads' upstream gradients are folded into the dc
+ * GEMM's weight operand and the weight gradient's reduction, the dz path forms its score gradients from the saved logits.
+ * 0: the two-pass kernels.  N <= 512 (larger N: two-pass).  A forward and its backward run under the same setting. */
+int cpc_set_nce_fused(int on);
 
 /* The same criterion for predictions formed by the caller -- any prediction network of
  * cpc/criterion/criterion.py:44-118, e.g. K transformer layers (--rnnMode transformer, :82-88):

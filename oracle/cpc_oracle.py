@@ -139,7 +139,9 @@ def tie_report(reset: bool = True) -> Dict[str, float]:
     return tot
 
 
-TIE_FRACTION_BOUND = 2.5e-6
+# measured on MI355X (round 5): 3 of 98.6 M elements at B = 64, 13 of 197 M at B = 128, 2 of 4.6 M at B = 3 (up to 4e-7 on small
+# tensors); the test-only misrounding build overrides ~45 % of the eligible elements of a layer, 3.5e-6 of the tensor
+TIE_FRACTION_BOUND = 5e-7
 TIE_COUNT_SLACK = 3
 
 

@@ -8,17 +8,21 @@ from emu_util import P, emu, rel_err
 from oracle import cpc_oracle as O
 
 
-@pytest.mark.parametrize("B,S,K,N,scale,wide", [(2, 20, 12, 16, 1.0, 0), (3, 19, 5, 32, 40.0, 0), (2, 20, 12, 16, 1.0, 1),
-                                                    (2, 21, 7, 32, 3000.0, 0), (1, 20, 16, 16, 1.0, 0)])
-def test_nce_forward_backward_emulated(B, S, K, N, scale, wide):
+@pytest.mark.parametrize("B,S,K,N,scale,wide,fused", [(2, 20, 12, 16, 1.0, 0, 1), (3, 19, 5, 32, 40.0, 0, 1), (2, 20, 12, 16, 1.0, 1, 1),
+                                                          (2, 21, 7, 32, 3000.0, 0, 1), (1, 20, 16, 16, 1.0, 0, 1),
+                                                          (3, 19, 5, 32, 40.0, 0, 0), (2, 21, 7, 32, 3000.0, 0, 0)])
+def test_nce_forward_backward_emulated(B, S, K, N, scale, wide, fused):
     """wide: the prediction GEMM on the 128 x 256 pipelined tile (cpc_set_gemm_split(3) forces it at test sizes).
-    scale 3000: logits hundreds apart, the softmax is saturated (most score gradients are exactly 0)."""
+    scale 3000: logits hundreds apart, the softmax is saturated (most score gradients are exactly 0) and the running reference of
+    the online softmax moves (scale 40 as well).  fused: the one-pass criterion (default: scores and the unit-gradient dPred from
+    one gather pass, cpc_set_nce_fused) or the two-pass kernels."""
     lib = emu()
-    assert lib.cpc_set_gemm_split(3 if wide else 1) == 0
+    assert lib.cpc_set_gemm_split(3 if wide else 1) == 0 and lib.cpc_set_nce_fused(fused) == 0
     try:
         _nce_forward_backward(lib, B, S, K, N, scale)
     finally:
         lib.cpc_set_gemm_split(1)
+        lib.cpc_set_nce_fused(1)
 
 
 def _nce_forward_backward(lib, B, S, K, N, scale):

@@ -89,8 +89,8 @@ def _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N):
     ggarr = (ctypes.c_void_p * 8)(*[P(t) for t in ggr])
     assert lib.cpc_gru_backward_streams(P(z), P(h0), garr_p, P(gsaved), P(c), P(dc), P(coef), P(nan(gs[2])), P(dx), ggarr, B, S, 2,
                                         None, None) == 0
-    assert lib.cpc_nce_backward_dz(P(c), P(wall), P(perm), P(row_ptr), P(nscr), P(dz), B, S, K, N, None) == 0
-    assert lib.cpc_nce_backward_dwall(P(c), P(nscr), P(dwall), B, S, K, N, None) == 0
+    assert lib.cpc_nce_backward_dz(P(c), P(wall), P(perm), P(row_ptr), P(nsaved), P(nscr), P(dz), B, S, K, N, None) == 0
+    assert lib.cpc_nce_backward_dwall(P(c), P(nsaved), P(nscr), P(dwall), B, S, K, N, None) == 0
     dzt = dz + dx
     egr = [torch.full_like(t, float("nan")) for t in enc_p]
     egarr = (ctypes.c_void_p * 20)(*[P(t) for t in egr])
