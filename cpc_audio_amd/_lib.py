@@ -18,7 +18,7 @@ EXPECTED_ABI = 14          # cpc_abi_version() of the library these signatures w
 DEFAULT_DMA_PIPELINE = 2       # cpc_set_dma_pipeline: the tap-pair walk where the shape allows, two 32-k stages elsewhere
 DEFAULT_WGRAD_DMA_STAGES = 4   # cpc_set_wgrad_dma_stages
 DEFAULT_CONV_SMALL_PIPE = 1    # cpc_set_conv_small_pipe
-DEFAULT_DGRAD_NSPLIT = 0       # cpc_set_dgrad_nsplit
+DEFAULT_DGRAD_NSPLIT = 256     # cpc_set_dgrad_nsplit: the short layers' data gradients on 128 x 128 tiles where that gives >= 256 workgroups
 DEFAULT_STEP_SCHEDULE = (1, 0)  # cpc_set_step_schedule: index preparation behind conv0, dz path beside the recurrence
 
 _P = ctypes.c_void_p

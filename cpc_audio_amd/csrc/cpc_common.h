@@ -79,9 +79,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // inside the parity tolerance -- but the ReLU derivative of those elements is systematically the device's, and the tie accounting
 // of the parity suite (oracle.tie_report) must notice (tests/test_gpu_full_configs.py).
 #ifdef CPC_TEST_MISROUND
-__device__ __forceinline__ float relu_in(float v) { return fabsf(v) < 1e-5f ? 2e-6f : v; }   // (2e-6: survives fp16-piece storage)
+// (s: the power of two the caller has already multiplied v by -- conv0 folds its H2 storage scale into the affine)
+__device__ __forceinline__ float relu_in(float v, float s = 1.0f) { return fabsf(v) < 1e-5f * s ? 2e-6f * s : v; }
 #else
-__device__ __forceinline__ float relu_in(float v) { return v; }
+__device__ __forceinline__ float relu_in(float v, float = 1.0f) { return v; }
 #endif
 
 // ---- "H2" storage of an fp32 tensor (encoder activations that feed the fp16 matrix pipe) -----------------------------

@@ -116,12 +116,12 @@ struct StepHooks {
                                   // BUT layer 1's weight gradient (event kEvWgradRest); kEvWgrad1 is recorded behind that one
     hipStream_t sums_stream = nullptr;   // open tail: the batched column sums of the norm backwards (bias / norm gradients of layers
                                   // 1..4) run HERE, released behind layer 1's norm backward, instead of at the end of the chain
-    hipEvent_t* timers = nullptr; // in-step timing (cpc_set_step_timing): 8 timing-enabled events, or nullptr
+    hipEvent_t* timers = nullptr; // in-step timing (cpc_set_step_timing): 10 timing-enabled events, or nullptr
 };
 StepHooks& step_hooks();
 // record timing event `idx` on `st` if in-step timing is on: [0] before conv0, [1] behind conv0, [7] in front of conv1 (behind
 // its stream waits), [2] behind conv1, [3] / [4] around the forward recurrence's persistent launch(es), [5] / [6] around the
-// backward recurrence's
+// backward recurrence's, [8] / [9] around the criterion's scoring kernel
 inline void step_timer_mark(int idx, hipStream_t st) {
     hipEvent_t* t = step_hooks().timers;
     if (t) (void)hipEventRecord(t[idx], st);

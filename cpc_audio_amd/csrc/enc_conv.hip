@@ -870,9 +870,11 @@ static int g_h2_all = 1;     // what "by problem size" means: 1 (default since r
                              // B >= ~100) only -- cpc_set_h2_layers(1 / 2) selects the round-3 behaviour explicitly
 static int g_force_bm = 0;   // 0 = choose by problem size; 32/64/128 = tuning / test override
 static int g_dma_layer2 = 0; // 1: layer 2 on the DMA-fed kernels whatever the batch (cpc_set_dma_layer2; by default from B ~ 100 on)
-static int g_small_bm = 32;  // rows of the small tile pick_bm() chooses below 32000 rows (cpc_set_conv_small_tile): 32 or 64
+static int g_small_bm = 64;  // rows of the small tile pick_bm() chooses below 32000 rows (cpc_set_conv_small_tile): 32, or 64 (default
+                             // since round 5: eight 32 x 64 waves per 64-row tile on the pipelined schedule -- half the weight bytes
+                             // through L2 per output row at two waves per SIMD; where 64-row tiles would leave CUs empty, 32)
 static int g_small_pipe = 1;
-static int g_dgrad_nsplit = 0;  // > 0: the H2-fed data gradient of the short layers on 128 x 128 tiles when that gives at least this many
+static int g_dgrad_nsplit = 256;  // > 0: the H2-fed data gradient of the short layers on 128 x 128 tiles when that gives at least this many
                                 // workgroups (cpc_set_dgrad_nsplit; 0 = off) // 1: the 32- / 64-row tiles of the H2-fed register-staged kernels on the pipelined 16-k schedule (ConvCfg PIPE)
 static constexpr int g_unfuse_big = 2;   // 2: every dgrad runs unfused + streaming norm backward, 1: only the 128-row tiles,
                                          // 0: fused epilogue (cpc_conv_layer_dgrad fuse=1).  Measured 4.69 / 4.76 / 4.79 ms per step

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(
                 const float gam[4] = {g4.x, g4.y, g4.z, g4.w}, bet[4] = {n4.x, n4.y, n4.z, n4.w};
                 float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = fmaxf(relu_in(fmaf(x[4 * q + e][r] * rs[r], gam[e], bet[e])), 0.f);
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(relu_in(fmaf(x[4 * q + e][r] * rs[r], gam[e], bet[e]), sy), 0.f);
                 if constexpr (YK == 1) {
                     h2_store_slot<NT>(y + row * kC, 16 * q + n, o[0], o[1], o[2], o[3], live);
                 } else if constexpr (YK == 2) {

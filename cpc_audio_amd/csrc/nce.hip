@@ -194,9 +194,7 @@ __global__ __launch_bounds__(256, 3) void nce_fwd_kernel(
 // lane group r4 gathers candidates 4 r4 + q instead of 4 q + r4 -- so the second product costs 64 more MFMAs per 16-candidate
 // tile and no data movement.  The per-head upstream gradients g_head (gloss / (B W C)) are applied by the consumers: the dc GEMM
 // reads the stacked head weights pre-multiplied by g_head, the heads' weight gradient is scaled per 256-row block on its way
-// out of the split reduction, the dz path forms its dS rows from the saved logits (nce_ds_kernel).  T replaces dPred.
-constexpr int kNceFusedMaxN = 512;      // nce_ds_kernel's LDS tile: negatives per window the one-pass path takes
-
+// out of the split reduction, the dz path multiplies the softmax rows this kernel leaves per candidate slot.  T replaces dPred.
 struct Gather16R {                                      // Gather16 with lane group r4 holding rows 4 r4 + q
     float4 v[4][4];                                   // [q][g]: piece c of row 4 r4 + q, column block g
     __device__ __forceinline__ void issue(const float* const (&rowp)[4]) {
@@ -220,7 +218,7 @@ struct Gather16R {                                      // Gather16 with lane gr
 __global__ __launch_bounds__(256, 2) void nce_fwd_fused_kernel(
     const float* __restrict__ pred, const float* __restrict__ z, const int* __restrict__ ext,
     float* __restrict__ logits, float* __restrict__ lse_out, float* __restrict__ rowstat, float* __restrict__ tpred,
-    float* __restrict__ tamax, int BW, int W, int S, int K, int N, unsigned* __restrict__ ticket) {
+    float* __restrict__ tamax, float* __restrict__ ps, int BW, int W, int S, int K, int N, unsigned* __restrict__ ticket) {
     __shared__ float4 tiles[4][256];
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -362,32 +360,24 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_fused_kernel(
     }
     amax = wave_max(amax);
     if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(tamax + (bt & (kAmaxSlots - 1))), __float_as_uint(amax));
-}
-
-// dS rows of the re-associated dz path (nce_bwd_g_kernel) from the saved logits: slot bt * (N + K) + j carries the 16 heads'
-// score gradients of candidate j (j < N: g_head * exp(l - lse); j >= N: the positive of head j - N, g (p0 - 1) on its own head,
-// 0 elsewhere) -- what nce_bwd_dpred_kernel wrote on its way.  One workgroup per window; the (head, candidate) -> (candidate,
-// head) transposition goes through LDS.
-__global__ __launch_bounds__(256) void nce_ds_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
-                                                     const float* __restrict__ gscale, float* __restrict__ dS, int K, int N) {
-    __shared__ float ds_lds[(kNceFusedMaxN + 16) * 16];      // [(N + K)][16]
-    const int bt = blockIdx.x, tid = threadIdx.x;
-    const int NK = N + K;
-    for (int idx = tid; idx < NK * 16; idx += 256) ds_lds[idx] = 0.f;
-    __syncthreads();
-    // (two iterations at a time, the compiler pairs the subtractions / multiplies into v_pk_*_f32: build.py's gate)
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-    for (int idx = tid; idx < K * N; idx += 256) {
-        const int head = idx / N, j = idx - head * N;
-        const float a = gscale[head] * expf(logits[((long)bt * K + head) * (N + 1) + 1 + j] - lse[(long)bt * K + head]);
-        ds_lds[j * 16 + head] = a;
+    // ---- the softmax itself, one 64-byte row of 16 heads per candidate slot bt * (N + K) + j (j < N: exp(l - lse); j >= N: the
+    // positive of head j - N, p0 - 1 on its own head, 0 elsewhere): what the re-associated dz path (nce_bwd_g_kernel) contracts
+    // with the rows of c, times the heads' upstream gradients.  The logits of this window are re-read (just written, 6 KB).
+    float* prow = ps + (long)bt * (N + K) * 16 + i;
+    const float* lrow = logits + ((long)bt * K + (hv ? i : 0)) * (N + 1) + 1 + 4 * kq;
+    for (int nt = 0; nt < N / 16; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pv = hv ? expf(lrow[nt * 16 + r] - lse) : 0.f;
+            prow[(long)(nt * 16 + 4 * kq + r) * 16] = pv;
+        }
     }
-    if (tid < K)
-        ds_lds[(N + tid) * 16 + tid] = gscale[tid] * (expf(logits[((long)bt * K + tid) * (N + 1)] - lse[(long)bt * K + tid]) - 1.0f);
-    __syncthreads();
-    float* out = dS + (long)bt * NK * 16;
-    for (int idx = tid; idx < NK * 4; idx += 256)
-        reinterpret_cast<float4*>(out)[idx] = reinterpret_cast<const float4*>(ds_lds)[idx];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int head = 4 * kq + r;
+        const float dr = __shfl(p0m1, head);
+        if (head < K) prow[(long)(N + head) * 16] = i == head ? dr : 0.f;
+    }
 }
 
 // wallT_g[i][k*256 + o] = g_k * wall[(k*256 + o)*256 + i]: the stacked head weights transposed AND pre-multiplied by the heads'
@@ -594,7 +584,8 @@ constexpr int GATHER_MAX_SORT = 1024;
 __global__ __launch_bounds__(64, 4) void nce_bwd_g_kernel(const float* __restrict__ c, const float* __restrict__ dS,
                                                        const int* __restrict__ perm, const int* __restrict__ row_ptr,
                                                        float* __restrict__ G, int W, int S, int K, int NK,
-                                                       float* __restrict__ amax_slots) {
+                                                       float* __restrict__ amax_slots, const float* __restrict__ gscale = nullptr) {
+    // gscale (one-pass criterion): dS holds the softmax rows of a unit upstream gradient; head i's gradient multiplies them here
     __shared__ int raw[GATHER_MAX_SORT];          // the slot list as filled; after the sort: row of c per sorted slot
     __shared__ int sorted[GATHER_MAX_SORT];
     const int lane = threadIdx.x;
@@ -619,6 +610,7 @@ __global__ __launch_bounds__(64, 4) void nce_bwd_g_kernel(const float* __restric
         __syncthreads();
     }
     const int i = lane & 15, kq = lane >> 4;
+    const float gsi = gscale == nullptr ? 1.0f : (i < K ? gscale[i] : 0.f);
     f32x4 acc[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -630,7 +622,7 @@ __global__ __launch_bounds__(64, 4) void nce_bwd_g_kernel(const float* __restric
             const int pc = ok ? p : 0;                                   // a valid slot: its row is read and multiplied by 0
             const int slot = do_sort ? sorted[pc] : perm[beg + pc];
             const int crow = do_sort ? raw[pc] : crow_of(slot);
-            const float a = ok ? dS[(long)slot * 16 + i] : 0.f;          // d score[head i][slot]
+            const float a = ok ? gsi * dS[(long)slot * 16 + i] : 0.f;    // d score[head i][slot]
             const float* cr = c + (long)crow * kC + 4 * i;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -894,11 +886,11 @@ __global__ __launch_bounds__(256) void nce_fill_kernel(const int* __restrict__ d
 
 // ------------------------------------------------------------------ host side
 int g_nce_fused = 1;       // cpc_set_nce_fused: 1 (default) the one-pass criterion (nce_fwd_fused_kernel: scores and the unit-gradient
-                           // dPred from ONE gather pass; linear heads, N <= 512), 0 the two-pass kernels (nce_fwd_kernel + nce_bwd_dpred_kernel)
+                           // dPred from ONE gather pass; linear heads), 0 the two-pass kernels (nce_fwd_kernel + nce_bwd_dpred_kernel)
 
 struct NceLayout {
     int W, BW;
-    long pred, logits, lse, bounds, tpred, saved_total;
+    long pred, logits, lse, bounds, tpred, ps, saved_total;
     long rowstat, tmp, sums, fwd_total;
     long dpred, wallT, part, gscale, V, dS, G, wcat, part_dz, bwd_total;
 };
@@ -915,6 +907,7 @@ static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     n.lse = o; o += align64l((long)n.BW * K);
     n.bounds = o; o += 3 * kAmaxSlots;       // max|c|, max|wall| as 64 partial maxima each (linear heads only); max|T| slots (fused)
     n.tpred = o; o += align64l((long)n.BW * K * kC);      // T: d loss_k / d pred_k for a unit upstream gradient (one-pass criterion)
+    n.ps = o; o += align64l((long)n.BW * (N + K) * 16);   // ... and the softmax rows per candidate slot (the dz path's dS / g_k)
     n.saved_total = o;
     o = 0;
     n.rowstat = o; o += align64l((long)n.BW * 2 * K);
@@ -948,7 +941,7 @@ static RowMap window_rows(const float* c, int B, int S, int W) {     // rows (b,
 }
 
 // scores, log-softmax, per-head loss / accuracy from given predictions
-static bool nce_fused(int N) { return g_nce_fused && N <= kNceFusedMaxN; }
+static bool nce_fused(int) { return g_nce_fused != 0; }
 // wall^T for dc = dPred . wall: plain, or -- one-pass criterion, whose dPred is the unit-gradient T -- pre-multiplied by the heads'
 // upstream gradients (scratch + gscale must hold them: nce_gscale_kernel on this stream or one it has waited for)
 static int nce_wallT(const float* wall, float* scratch, const NceLayout& n, int K, int N, hipStream_t st) {
@@ -965,13 +958,15 @@ static int nce_scores_forward(const NceLayout& n, const float* pred, const float
     // score gradients come from the saved logits), so a caller that joins `fin` later takes 15 us off its critical path.
     // fused: the one-pass kernel, which also leaves T (unit-gradient dPred) and max|T| in `saved` (slots zeroed by the caller)
     unsigned* ticket = reinterpret_cast<unsigned*>(scratch + n.sums + 32);
+    step_timer_mark(8, st);
     if (fused)
         hipLaunchKernelGGL(nce_fwd_fused_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
-                           saved + n.lse, scratch + n.rowstat, saved + n.tpred, saved + n.bounds + 2 * kAmaxSlots, n.BW, n.W, S,
-                           K, N, ticket);
+                           saved + n.lse, scratch + n.rowstat, saved + n.tpred, saved + n.bounds + 2 * kAmaxSlots, saved + n.ps,
+                           n.BW, n.W, S, K, N, ticket);
     else
     hipLaunchKernelGGL(nce_fwd_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
                        saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket);
+    step_timer_mark(9, st);
     CPC_LAUNCH_CHECK();
     if (fin != nullptr && fin != st) {
         hipEvent_t* ev = stream_events(st);
@@ -1015,14 +1010,13 @@ static int nce_dz_linear_path(const NceLayout& n, const float* c, const float* w
     float* G = scratch + n.G, *wcat = scratch + n.wcat;
     float* bnd = scratch + n.gscale;
     const bool h2 = g_mfma_mode >= 2;
-    // one-pass criterion: nobody has written the dS rows yet -- they come from the saved logits here (46 MB read, 66 MB
-    // written at B = 64), on the stream of the dz path
-    if (saved_for_ds != nullptr)
-        hipLaunchKernelGGL(nce_ds_kernel, dim3(n.BW), dim3(256), 0, st, saved_for_ds + n.logits, saved_for_ds + n.lse,
-                           scratch + n.gscale, scratch + n.dS, K, N);
     hipLaunchKernelGGL(nce_wcat_kernel, dim3(cdiv(K * kC, 4)), dim3(256), 0, st, wall, wcat, K);
+    if (saved_for_ds != nullptr)           // one-pass criterion: the forward left the softmax rows; the heads' gradients apply here
+        hipLaunchKernelGGL(nce_bwd_g_kernel, dim3(B * S), dim3(64), 0, st, c, saved_for_ds + n.ps, perm, row_ptr, G, n.W, S, K, N + K,
+                           h2 ? bnd + 128 : (float*)nullptr, (const float*)(scratch + n.gscale));
+    else
     hipLaunchKernelGGL(nce_bwd_g_kernel, dim3(B * S), dim3(64), 0, st, c, scratch + n.dS, perm, row_ptr, G, n.W, S, K, N + K,
-                       h2 ? bnd + 128 : (float*)nullptr);
+                       h2 ? bnd + 128 : (float*)nullptr, (const float*)nullptr);
     CPC_LAUNCH_CHECK();
     GemmBounds gb;
     if (h2) { gb.a = bnd + 128; gb.a_slots = kAmaxSlots; gb.b = bnd + 18; }

@@ -85,7 +85,7 @@ inline bool wait(hipStream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 
 // INSIDE the step (StepHooks::timers, step_timer_mark); a diagnostic of its own steps, never of the timed ones -- every marker
 // costs the stream 6-8 us
 int g_step_timing = 0;
-hipEvent_t g_timers[8];
+hipEvent_t g_timers[10];
 bool g_timers_made = false;
 
 // the hooks of one cpc_train_step call, restored when it returns
@@ -317,12 +317,12 @@ extern "C" int cpc_train_step_wait(void* main_stream, int which, void* waiting_s
 }
 
 // In-step timing: while on, every cpc_train_step records timing events around layer 0, layer 1 and the two persistent recurrence
-// launches on its main stream.  cpc_get_step_timing waits for the last of them and returns the four durations of the most
-// recent step in microseconds: [0] conv0, [1] conv1, [2] forward recurrence, [3] backward recurrence (the markers' own cost --
-// 6-8 us each, measured by the caller with back-to-back events -- is included).
+// launches and the criterion's scoring kernel on its main stream.  cpc_get_step_timing waits for the last of them and returns the
+// five durations of the most recent step in microseconds: [0] conv0, [1] conv1, [2] forward recurrence, [3] backward recurrence,
+// [4] the scoring kernel (the markers' own cost -- 6-8 us each, measured by the caller with back-to-back events -- is included).
 extern "C" int cpc_set_step_timing(int on) {
     if (on && !g_timers_made) {
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 10; ++i)
             if (hipEventCreate(&g_timers[i]) != hipSuccess) return CPC_ERR_ARG;
         g_timers_made = true;
     }
@@ -332,8 +332,8 @@ extern "C" int cpc_set_step_timing(int on) {
 extern "C" int cpc_get_step_timing(float* us) {
     CPC_RETURN_IF(!us || !g_timers_made, CPC_ERR_ARG);
     CPC_RETURN_IF(hipEventSynchronize(g_timers[6]) != hipSuccess, CPC_ERR_ARG);
-    const int a[4] = {0, 7, 3, 5}, b[4] = {1, 2, 4, 6};
-    for (int i = 0; i < 4; ++i) {
+    const int a[5] = {0, 7, 3, 5, 8}, b[5] = {1, 2, 4, 6, 9};
+    for (int i = 0; i < 5; ++i) {
         float ms = 0.f;
         CPC_RETURN_IF(hipEventElapsedTime(&ms, g_timers[a[i]], g_timers[b[i]]) != hipSuccess, CPC_ERR_ARG);
         us[i] = ms * 1000.f;

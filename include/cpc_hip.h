@@ -393,8 +393,8 @@ int cpc_nce_backward_dwall(const float* c, const float* saved, float* scratch, f
  * sum of the candidate rows along with the log-sum-exp (an online softmax over criterion.py:108-116's candidates) and leaves
  * T = d loss_k / d pred_k for a unit upstream gradient in `saved`; the backward then has no score-gradient pass over the 1 KB
  * candidate rows (criterion.py:200-201's gather, 1.06 GB at B = 64) -- the heads' upstream gradients are folded into the dc
- * GEMM's weight operand and the weight gradient's reduction, the dz path forms its score gradients from the saved logits.
- * 0: the two-pass kernels.  N <= 512 (larger N: two-pass).  A forward and its backward run under the same setting. */
+ * GEMM's weight operand and the weight gradient's reduction, the dz path multiplies the softmax rows the forward leaves per
+ * candidate slot.  0: the two-pass kernels.  A forward and its backward run under the same setting. */
 int cpc_set_nce_fused(int on);
 
 /* The same criterion for predictions formed by the caller -- any prediction network of
@@ -456,9 +456,10 @@ int cpc_train_step_tail(const float* const* params, float* workspace, int B, int
  * open-tailed step left open (layer 1's weight gradient + the bias / norm gradient sums on prep_stream), 2 =
  * cpc_train_step_tail's end (every updated weight and layout), 3 = the heads' weight gradient, 4 = the bias / norm sums alone. */
 int cpc_train_step_wait(void* main_stream, int which, void* waiting_stream);
-/* In-step timing (diagnostic): while on, cpc_train_step records timing events around layer 0, layer 1 and the two persistent
- * recurrence launches on main_stream; cpc_get_step_timing waits for the last and writes the 4 durations of the most recent step
- * in microseconds (conv0, conv1, forward recurrence, backward recurrence; each includes one marker's cost). */
+/* In-step timing (diagnostic): while on, cpc_train_step records timing events around layer 0, layer 1, the two persistent
+ * recurrence launches and the criterion's scoring kernel on main_stream; cpc_get_step_timing waits for the last and writes the
+ * 5 durations of the most recent step in microseconds (conv0, conv1, forward recurrence, backward recurrence, scoring kernel;
+ * each includes one marker's cost). */
 int cpc_set_step_timing(int on);
 /* Measurement switch of the open tail: 0 (default) the next step's layer 0 starts behind the tail, 1 it runs under it and only
  * layer 1 waits (measured slower: layer 0 gets a quarter of its wave slots beside layer 1's weight gradient). */

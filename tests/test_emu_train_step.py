@@ -248,7 +248,7 @@ def test_open_tail_steps_with_the_weight_preparation_at_the_tail_change_no_bit_e
     assert lib.cpc_set_step_timing(1) == 0
     try:
         again = run(True)
-        us = (ctypes.c_float * 4)()
+        us = (ctypes.c_float * 5)()
         assert lib.cpc_get_step_timing(us) == 0
     finally:
         assert lib.cpc_set_step_timing(0) == 0
