@@ -18,6 +18,7 @@ EXPECTED_ABI = 14          # cpc_abi_version() of the library these signatures w
 DEFAULT_DMA_PIPELINE = 2       # cpc_set_dma_pipeline: the tap-pair walk where the shape allows, two 32-k stages elsewhere
 DEFAULT_WGRAD_DMA_STAGES = 4   # cpc_set_wgrad_dma_stages
 DEFAULT_CONV_SMALL_PIPE = 1    # cpc_set_conv_small_pipe
+DEFAULT_FWD_NSPLIT = 0         # cpc_set_fwd_nsplit (built and measured in round 5: no gain at B = 64, off)
 DEFAULT_DGRAD_NSPLIT = 256     # cpc_set_dgrad_nsplit: the short layers' data gradients on 128 x 128 tiles where that gives >= 256 workgroups
 DEFAULT_STEP_SCHEDULE = (1, 0)  # cpc_set_step_schedule: index preparation behind conv0, dz path beside the recurrence
 
@@ -119,6 +120,7 @@ SIGNATURES = {
     "cpc_train_step": (_I, [_P, _P, _P, _P, _F] + [_P] * 7 + [_I] * 5 + [_P] * 4),
     "cpc_train_step_tail": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "cpc_train_step_wait": (_I, [_P, _I, _P]),
+    "cpc_set_fwd_nsplit": (_I, [_I, _I]),
     "cpc_set_step_timing": (_I, [_I]),
     "cpc_set_tail_schedule": (_I, [_I]),
     "cpc_get_step_timing": (_I, [_P]),

@@ -108,12 +108,15 @@ extern "C" int cpc_streams_overlap(void* stream_a, void* stream_b, int* overlap)
 //   bit 0  CPC_DEVERR_GRU_POLL_TIMEOUT   a workgroup of the persistent recurrence gave up waiting for another one (its
 //                                        outputs carry NaN from there on)
 //   bit 1  CPC_DEVERR_NEGATIVE_INDEX     cpc_nce_prepare was given a draw outside [0,B) x [0,S) (clamped)
+//   bit 2  CPC_DEVERR_CONV_EXCHANGE      a workgroup of the N-split conv forward gave up waiting for its partner's row statistics
+//                                        (its rows carry NaN)
 // Synchronises with the device (two 4-byte reads): for logging points and tests, not for the step path.
 // Returns the mask (>= 0), or a negative number if it cannot be read.
 extern "C" int cpc_device_error_flags(int clear) {
-    unsigned a = 0, b = 0;
-    if (cpc::gru_error_flag_fetch(clear, &a) != 0 || cpc::nce_error_flag_fetch(clear, &b) != 0) return -1;
-    return (int)((a ? 1u : 0u) | (b ? 2u : 0u));
+    unsigned a = 0, b = 0, c = 0;
+    if (cpc::gru_error_flag_fetch(clear, &a) != 0 || cpc::nce_error_flag_fetch(clear, &b) != 0 ||
+        cpc::enc_error_flag_fetch(clear, &c) != 0) return -1;
+    return (int)((a ? 1u : 0u) | (b ? 2u : 0u) | (c ? 4u : 0u));
 }
 
 extern "C" int cpc_get_mfma_mode(void) { return cpc::g_mfma_mode; }

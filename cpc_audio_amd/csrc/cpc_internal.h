@@ -155,6 +155,7 @@ int conv0_backward(const float* wave, const float* w, const float* bias, const f
 // device-side error words of the translation units that own them (cpc_device_error_flags)
 int gru_error_flag_fetch(int clear, unsigned* out);
 int nce_error_flag_fetch(int clear, unsigned* out);
+int enc_error_flag_fetch(int clear, unsigned* out);
 
 static inline long align64l(long v) { return (v + 63) & ~63L; }
 

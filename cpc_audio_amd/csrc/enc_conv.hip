@@ -738,6 +738,140 @@ __global__ __launch_bounds__(DgradNsTile::NTHREADS) void conv_dgrad_nsplit_kerne
     }
 }
 
+// The forward of a short layer on the same 128 x 128 tiles: two workgroups per 128-row tile, each 128 of the 256 output channels.
+// ChannelNorm needs the statistics of the whole row, so the pair exchanges two floats per row through global memory -- the sum
+// and the centred sum of squares of its half, combined exactly as a parallel variance is (Chan et al.):
+//     mean = (s_lo + s_hi) / 256,  M2 = M2_lo + M2_hi + (mean_hi - mean_lo)^2 * 64,  var = M2 / 255
+// both halves evaluate this with the same operand order, i.e. to the same bits.  The exchange buffer is pre-filled with 0xFF bytes
+// (no arithmetic result carries that payload: the hand-over scheme of the persistent recurrence, gru.hip); a workgroup stores its
+// 8 bytes per row with one agent-scope atomic and polls its partner's.  Partners are 8 workgroup ids apart -- adjacent in
+// dispatch order and on one XCD -- so the partner of a resident workgroup is resident or next in line; polling is bounded and a
+// partner that never shows up lets NaN through (and sets bit 2 of cpc_device_error_flags) instead of hanging the device.
+static __device__ unsigned g_enc_xch_timeout = 0;
+constexpr unsigned long long kXchEmpty = 0xFFFFFFFFFFFFFFFFull;
+__global__ __launch_bounds__(DgradNsTile::NTHREADS) void conv_fwd_nsplit_kernel(
+    RowMap am, const float* __restrict__ wp, int K, const float* __restrict__ bias, const float* __restrict__ nw,
+    const float* __restrict__ nb, float* __restrict__ y, float* __restrict__ xhat, float* __restrict__ rstd_out,
+    const float* __restrict__ x_amax, const float* __restrict__ w_amax, const float* __restrict__ y_amax,
+    unsigned long long* __restrict__ xch, int spin_limit) {
+    using Tile = DgradNsTile;
+    constexpr int TM = Tile::TM, TN = Tile::TN;
+    __shared__ float smem[Tile::SMEM_FLOATS];
+    __shared__ float red[128][2];
+    __shared__ float stat[128][2];                   // mean, rstd of the whole row
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = (slot >> 1) * 8 + xcd, half = slot & 1;
+    const int m0 = tile * 128, n0 = half * 128;
+    if (m0 >= am.M) return;                          // block-uniform (both workgroups of the pair)
+    f32x16 acc[TM][TN];
+    zero_acc(acc);
+    const float sa = scale_for_amax(*x_amax), sb = scale_for_amax(*w_amax);
+    Tile::run(acc, am, m0, wp, 16, n0, K, smem, 0, kC * 16, (int)((tile * 4u) % (unsigned)(K / Tile::BK)), sa, sb,
+              ((K >> kCLog2) & ((K >> kCLog2) - 1)) == 0 ? 31 - __builtin_clz(K >> kCLog2) : 0);
+    const float inv = 1.0f / (sa * sb);
+    const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 1;
+    int col[TN];
+    float gw[TN], gb[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        col[tn] = n0 + Tile::c_col(tn);
+        const float bc = bias[col[tn]];
+        gw[tn] = nw[col[tn]];
+        gb[tn] = nb[col[tn]];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = fmaf(acc[tm][tn][r], inv, bc);
+    }
+    // ---- this half's statistics: sum, then the sum of squares around the half's own mean
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) v += acc[tm][tn][r];
+            v = half_wave_sum(v);
+            if ((lane & 31) == 0) red[Tile::c_row(tm, r)][wn] = v;
+        }
+    __syncthreads();
+    float hsum[TM][16];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = Tile::c_row(tm, r);
+            hsum[tm][r] = red[row][0] + red[row][1];
+        }
+    const float my_sum = threadIdx.x < 128 ? red[threadIdx.x][0] + red[threadIdx.x][1] : 0.f;     // thread `row` talks for row `row`
+    __syncthreads();
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float hm = hsum[tm][r] * (1.0f / 128);
+            float v = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const float d = acc[tm][tn][r] - hm;
+                v = fmaf(d, d, v);
+            }
+            v = half_wave_sum(v);
+            if ((lane & 31) == 0) red[Tile::c_row(tm, r)][wn] = v;
+        }
+    __syncthreads();
+    // ---- exchange with the partner (thread `row` of either workgroup), combine
+    if (threadIdx.x < 128) {
+        const int row = threadIdx.x;
+        const float my_m2 = red[row][0] + red[row][1];
+        unsigned long long* mine = xch + ((long)tile * 2 + half) * 128 + row;
+        const unsigned long long* theirs = xch + ((long)tile * 2 + (half ^ 1)) * 128 + row;
+        const unsigned long long word = (unsigned long long)__float_as_uint(my_sum) | ((unsigned long long)__float_as_uint(my_m2) << 32);
+        __hip_atomic_store(mine, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long got = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int budget = spin_limit;
+        while (got == kXchEmpty && budget > 0) {          // (a sum / M2 pair of all-ones bits is two NaNs: never a result)
+            __builtin_amdgcn_s_sleep(2);
+            got = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            --budget;
+        }
+        if (got == kXchEmpty) atomicOr(&g_enc_xch_timeout, 1u);      // the fill pattern (NaN) goes through to the output
+        const float o_sum = __uint_as_float((unsigned)got), o_m2 = __uint_as_float((unsigned)(got >> 32));
+        const float s_lo = half ? o_sum : my_sum, s_hi = half ? my_sum : o_sum;
+        const float q_lo = half ? o_m2 : my_m2, q_hi = half ? my_m2 : o_m2;
+        const float mean = (s_lo + s_hi) * (1.0f / kC);
+        const float delta = (s_hi - s_lo) * (1.0f / 128);
+        const float m2 = (q_lo + q_hi) + delta * delta * 64.0f;
+        const float rs = 1.0f / sqrtf(m2 * (1.0f / (kC - 1)) + kNormEps);
+        stat[row][0] = mean;
+        stat[row][1] = rs;
+        const int m = m0 + row;
+        if (half == 0 && m < am.M) rstd_out[m] = rs;
+    }
+    __syncthreads();
+    const bool h2out = y_amax != nullptr;            // block-uniform
+    const float sy = h2out ? scale_for_amax(*y_amax) : 1.0f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = Tile::c_row(tm, r);
+            const float mean = stat[row][0], rs = stat[row][1];
+            const int m = m0 + row;
+            const bool live = m < am.M;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const float xh = (acc[tm][tn][r] - mean) * rs;
+                const float yv = fmaxf(relu_in(fmaf(xh, gw[tn], gb[tn])), 0.f);
+                if (live) __builtin_nontemporal_store(xh, xhat + (long)m * kC + col[tn]);
+                if (h2out)       // (every lane takes part in the swap)
+                    h2_store_lane(reinterpret_cast<unsigned char*>(y) + (long)(live ? m : 0) * (kC * 4), col[tn], yv, sy, live);
+                else if (live)
+                    y[(long)m * kC + col[tn]] = yv;
+            }
+        }
+}
+
 // ------------------------------------------------------------------ wgrad
 // MODE 3: as 2 with the activation operand (x) in H2 storage; MODE 4: both operands are bf16 tensors, one product;
 // MODE 5: as 3 with dx in H2 storage too (scaled for the bound *dx_amax that the norm backward left, norm_bwd_kernel DXH2)
@@ -842,6 +976,7 @@ struct EncLayout {
     long saved_total;
     long wp[5];                            // forward scratch: permuted weights (1..4)
     long famax, fwd_total;                 // famax: kPrepParts partial max|w| per layer
+    long xch[5], xch_total;                // per-layer exchange buffers of the N-split forward (conv_fwd_nsplit_kernel): 2 x rows x 8 bytes
     // backward scratch
     long dx[5], dy0, part, colpart, tmp, small, conv0, bamax;
     long colp[5], tmpq[5];                 // per-layer partials of the stand-alone norm backwards (summed in one batch)
@@ -930,6 +1065,10 @@ static bool enc_layout(int B, int Lw, EncLayout& e) {
     // 1.5x: in split-bf16 mode the re-laid-out weight is three bf16 planes (6 bytes per weight)
     for (int i = 1; i < 5; ++i) { e.wp[i] = o; o += align64((long)kC * kGeom[i].k * kC * 3 / 2); }
     e.famax = o; o += align64(4 * kPrepParts);
+    e.xch[0] = e.xch[1] = -1;
+    const long xch0 = o;
+    for (int i = 2; i < 5; ++i) { e.xch[i] = o; o += align64(4L * cdiv(B * e.L[i], 128) * 128); }     // (sized whatever the switches say)
+    e.xch_total = o - xch0;
     e.fwd_total = o;
 
     o = 0;
@@ -1076,6 +1215,31 @@ extern "C" int cpc_set_dma_tile(int bm) {
     g_dma_bm = bm;
     return 0;
 }
+// > 0: the forward of a short layer (H2 in) on 128 x 128 tiles, two workgroups per row tile with the ChannelNorm statistics
+// exchanged between them (conv_fwd_nsplit_kernel), where that gives at least this many workgroups; 0 (default) = off.
+// Measured at B = 64 inside the step (profiles/r5_ab_fwd_nsplit.txt): conv3 48.4 us against 52 on the 64-row tile, conv2 119.7
+// against 100 on the 128 x 256 tile (it re-reads every input row for both halves and shares the chip with the criterion's index
+// preparation); the step 2.805 against 2.806 ms -- no gain worth a cross-workgroup wait on the default path.
+static int g_fwd_nsplit = 0;
+static int g_fwd_nsplit_spin = 1 << 22;
+extern "C" int cpc_set_fwd_nsplit(int min_wgs, int spin_limit) {
+    CPC_RETURN_IF(min_wgs < 0, CPC_ERR_ARG);
+    g_fwd_nsplit = min_wgs;
+    g_fwd_nsplit_spin = spin_limit < 0 ? (1 << 22) : spin_limit;
+    return 0;
+}
+namespace cpc {
+int enc_error_flag_fetch(int clear, unsigned* out) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_enc_xch_timeout), sizeof(v)) != hipSuccess) return CPC_ERR_ARG;
+    if (clear && v) {
+        const unsigned zero = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_enc_xch_timeout), &zero, sizeof(zero)) != hipSuccess) return CPC_ERR_ARG;
+    }
+    *out = v;
+    return 0;
+}
+}  // namespace cpc
 static int g_tail_conv0_early = 0;      // cpc_set_tail_schedule (see cpc_encoder_forward)
 extern "C" int cpc_set_tail_schedule(int conv0_early) {
     g_tail_conv0_early = conv0_early ? 1 : 0;
@@ -1381,6 +1545,10 @@ static int enc_prepare_weights(const EncLayout& e, const float* const* params, f
     // (the zero row the DMA kernels read for the conv's padding: with the full preparation only -- a partial one runs while the
     // previous step's last weight gradient may still be reading it, and zeros stay zeros)
     if (mask == 63 && g_mfma_mode >= 3 && hipMemsetAsync(saved + e.szero, 0, 64 * sizeof(float), pst) != hipSuccess) return CPC_ERR_ARG;
+    // the exchange slots of the N-split forward: "empty" (0xFF) for every row of the coming forward -- with the full preparation, or
+    // with the tail's share that carries bit 0 (both a whole forward ahead of the kernels that fill them)
+    if ((mask & 1) && g_mfma_mode == 3 && hipMemsetAsync(scratch + e.xch[2], 0xFF, e.xch_total * sizeof(float), pst) != hipSuccess)
+        return CPC_ERR_ARG;
     return 0;
 }
 
@@ -1463,6 +1631,19 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
                               yo, i < 4 && act_h2(i), saved + e.xhat[i], saved + e.rstd[i], saved + e.sbound + i,
                               saved + e.sbound + i + 1, saved + e.szero, B, e.L[i - 1], kGeom[i].k, kGeom[i].s, kGeom[i].p,
                               g_dma_bm ? g_dma_bm : (M >= 256L * 200 ? 256 : 128), st);
+        } else if (i >= 2 && act_h2(i - 1) && g_fwd_nsplit > 0 && g_mfma_mode == 3 && !g_force_bm && (kGeom[i].k * kC) % 64 == 0 &&
+                   2L * cdiv((long)B * e.L[i], 128) >= g_fwd_nsplit) {
+            // 128 x 128 tiles, two workgroups per row tile (1-D grid: partners 8 ids apart, one XCD)
+            const RowMap am = conv_rows(saved + e.y[i - 1], B, e.L[i - 1], e.L[i], kGeom[i].s, kGeom[i].p);
+            const int tiles = cdiv(am.M, 128);
+            const float* wpi = scratch + e.wp[i];
+            hipLaunchKernelGGL(conv_fwd_nsplit_kernel, dim3(16 * cdiv(tiles, 8)), dim3(DgradNsTile::NTHREADS), 0, st, am, wpi,
+                               kGeom[i].k * kC, params[4 * i + 1], params[4 * i + 2], params[4 * i + 3], yo, saved + e.xhat[i],
+                               saved + e.rstd[i], saved + e.sbound + i, wpi + (long)kC * kGeom[i].k * kC,
+                               i < 4 && act_h2(i) ? saved + e.sbound + i + 1 : (const float*)nullptr,
+                               reinterpret_cast<unsigned long long*>(scratch + e.xch[i]), g_fwd_nsplit_spin);
+            CPC_LAUNCH_CHECK();
+            rc = 0;
         } else {
             rc = conv_gemm_forward_impl(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2],
                                         params[4 * i + 3], yo, saved + e.xhat[i], saved + e.rstd[i], saved + e.sbound + i, B,

@@ -50,6 +50,9 @@ def check_device_errors(clear=True):
                     "(outputs contain NaN from that step on)")
     if mask & 2:
         what.append("cpc_nce_prepare received negative-sample indices outside [0,B) x [0,S) (they were clamped)")
+    if mask & 4:
+        what.append("a workgroup of the N-split conv forward timed out waiting for its partner's ChannelNorm statistics "
+                    "(its rows contain NaN)")
     if what:
         raise _lib.CpcHipError("device-side error: " + "; ".join(what))
 

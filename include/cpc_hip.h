@@ -58,11 +58,14 @@ int cpc_get_mfma_mode(void);
  *                                waiting for another one; its outputs carry NaN from that step on
  *   CPC_DEVERR_NEGATIVE_INDEX    cpc_nce_prepare was handed a draw outside batchIdx in [0,B) / seqIdx in [0,S)
  *                                (criterion.py:181-189 draws [0,B) and [1,S)); the index was clamped
+ *   CPC_DEVERR_CONV_EXCHANGE     a workgroup of the N-split conv forward (cpc_set_fwd_nsplit) gave up waiting for its partner's
+ *                                ChannelNorm statistics; its rows carry NaN
  * The reference raises Python exceptions for such things; kernels cannot, so the wrapper (ops.check_device_errors) turns
  * the mask into a RuntimeError.  The call synchronises with the device: logging points and tests, not the step path.
  * Returns the mask (>= 0) or a negative number if the flags cannot be read. */
 #define CPC_DEVERR_GRU_POLL_TIMEOUT 1
 #define CPC_DEVERR_NEGATIVE_INDEX 2
+#define CPC_DEVERR_CONV_EXCHANGE 4
 int cpc_device_error_flags(int clear);
 
 /* ---------------------------------------------------------------- encoder ----
@@ -460,6 +463,11 @@ int cpc_train_step_wait(void* main_stream, int which, void* waiting_stream);
  * recurrence launches and the criterion's scoring kernel on main_stream; cpc_get_step_timing waits for the last and writes the
  * 5 durations of the most recent step in microseconds (conv0, conv1, forward recurrence, backward recurrence, scoring kernel;
  * each includes one marker's cost). */
+/* The forward of a short conv layer (conv2..4 with H2 input, below the 128-row-tile regime; cpc/model.py:87-92,101-104) on
+ * 128 x 128 tiles, two workgroups per 128-row tile with the ChannelNorm statistics (cpc/model.py:50-58) exchanged between the pair
+ * through global memory, wherever that gives at least min_wgs workgroups (default 256; 0 = the full-row tiles).  spin_limit: polls
+ * before a workgroup gives up on its partner (< 0: the default 2^22; tests use 0 to drive CPC_DEVERR_CONV_EXCHANGE). */
+int cpc_set_fwd_nsplit(int min_wgs, int spin_limit);
 int cpc_set_step_timing(int on);
 /* Measurement switch of the open tail: 0 (default) the next step's layer 0 starts behind the tail, 1 it runs under it and only
  * layer 1 waits (measured slower: layer 0 gets a quarter of its wave slots beside layer 1's weight gradient). */

@@ -50,7 +50,8 @@ def _saved_acts(lib, saved, B, L, Ls):
                                           (2, 1280, 0, 0), (1, 1600, 128, 2), (2, 1280, 0, 2), (1, 1370, 64, 2),
                                           (2, 1280, 0, 3), (1, 1370, 64, 3), (3, 1290, 128, 3), (2, 1280, 0, 32),
                                           (1, 1370, 0, 132), (2, 1280, 0, 30), (2, 1280, 0, 34), (1, 1370, 64, 34),
-                                          (3, 1290, 128, 34), (4, 2560, 0, 234), (2, 2560, 32, 334), (1, 1370, 64, 334), (4, 2560, 0, 434), (2, 1280, 0, 534), (2, 2560, 0, 634)])
+                                          (3, 1290, 128, 34), (4, 2560, 0, 234), (2, 2560, 32, 334), (1, 1370, 64, 334), (4, 2560, 0, 434), (2, 1280, 0, 534), (2, 2560, 0, 634),
+                                          (2, 2560, 0, 734), (3, 1290, 0, 734)])
 def test_encoder_forward_backward_emulated(B, L, bm, mode):
     """mode 1: NT GEMMs on the bf16 pipe with 3-piece split operands; mode 0: exact-f32 MFMA; mode 2: fp16 pipe with
     scaled 2-piece split operands; mode 3 (default): mode 2 + layers 1, 2 on the DMA kernel reading H2 activations
@@ -71,7 +72,10 @@ def test_encoder_forward_backward_emulated(B, L, bm, mode):
     assert lib.cpc_set_dma_layer2(1 if mode == 534 else 0) == 0
     # (634: mode 34 with the short layers' data gradients on 128 x 128 tiles, two workgroups per row tile: cpc_set_dgrad_nsplit)
     assert lib.cpc_set_dgrad_nsplit(1 if mode == 634 else 0) == 0
-    mode = 34 if mode in (234, 334, 434, 534, 634) else mode
+    # (734: mode 34 with the short layers' FORWARD on 128 x 128 tiles, two workgroups per row tile exchanging their ChannelNorm
+    # statistics through global memory: cpc_set_fwd_nsplit; the ragged case ends in a partial row tile)
+    assert lib.cpc_set_fwd_nsplit(1 if mode == 734 else 0, -1) == 0
+    mode = 34 if mode in (234, 334, 434, 534, 634, 734) else mode
     assert lib.cpc_set_wgrad_dma_min_rows(min_rows) == 0
     h2_layers, pipe = (4, 0) if mode == 34 else ((2, mode // 100) if mode >= 32 else (0, 0))
     h2_dx = 0 if mode == 30 else 1
@@ -145,6 +149,7 @@ def test_encoder_forward_backward_emulated(B, L, bm, mode):
         lib.cpc_set_wgrad_dma_stages(_L.DEFAULT_WGRAD_DMA_STAGES)
         lib.cpc_set_dma_layer2(0)
         lib.cpc_set_dgrad_nsplit(_L.DEFAULT_DGRAD_NSPLIT)
+        lib.cpc_set_fwd_nsplit(_L.DEFAULT_FWD_NSPLIT, -1)
 
 
 @pytest.mark.parametrize("mode", [1, 2])

@@ -33,6 +33,11 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None):
     h2_layers, stages, small_pipe = 0, 2, 0
     nsplit = 1 if mode == 634 else 0             # 634: + the short layers' data gradients on 128 x 128 tiles (cpc_set_dgrad_nsplit)
     assert lib.cpc_set_dgrad_nsplit(nsplit) == 0
+    # 734: + the short layers' FORWARD on 128 x 128 tiles with the ChannelNorm statistics exchanged between the two workgroups of a
+    # row tile (cpc_set_fwd_nsplit; 1 = wherever the layer reads H2 input, i.e. conv2..4 whatever their size)
+    assert lib.cpc_set_fwd_nsplit(1 if mode == 734 else 0, -1) == 0
+    if mode == 734:
+        h2_layers, mode = 4, 3
     dma2 = 1 if mode == 534 else 0               # 534: + layer 2 on the DMA-fed kernels (what B >= ~100 selects by itself: the B = 128 case)
     assert lib.cpc_set_dma_layer2(dma2) == 0
     if mode in (34, 334, 434, 534, 634):  # mode 3 with every activation and every gradient of layers 1..4 in H2 storage (cpc_set_h2_layers(4));
@@ -78,6 +83,7 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None):
     lib.cpc_set_conv_small_pipe(_L.DEFAULT_CONV_SMALL_PIPE)
     lib.cpc_set_dma_layer2(0)
     lib.cpc_set_dgrad_nsplit(_L.DEFAULT_DGRAD_NSPLIT)
+    lib.cpc_set_fwd_nsplit(_L.DEFAULT_FWD_NSPLIT, -1)
     lib.cpc_set_mfma_mode(_lib_default_mode())
     if dma is not None:
         lib.cpc_set_dma_tile(0)
@@ -118,7 +124,8 @@ def test_encoder_dma_pipelines_match_oracle(pipe):
                                           (1, 4330, 64, 3), (2, 10240, 32, 3), (64, 20480, 0, 3), (8, 20480, 0, 34),
                                           (3, 20480, 128, 34), (1, 4330, 64, 34), (2, 10240, 32, 34), (64, 20480, 0, 34),
                                           (8, 20480, 0, 434), (1, 4330, 64, 434), (64, 20480, 0, 434), (8, 20480, 0, 334),
-                                          (2, 10240, 64, 334), (64, 20480, 0, 334), (8, 20480, 0, 3), (8, 20480, 0, 534), (128, 20480, 0, 34), (8, 20480, 0, 634), (64, 20480, 0, 634)])
+                                          (2, 10240, 64, 334), (64, 20480, 0, 334), (8, 20480, 0, 3), (8, 20480, 0, 534), (128, 20480, 0, 34), (8, 20480, 0, 634), (64, 20480, 0, 634),
+                                          (8, 20480, 0, 734), (3, 4330, 0, 734), (64, 20480, 0, 734)])
 def test_encoder_matches_oracle(B, L, bm, mode):
     """mode 1 = bf16 pipe with 3-piece split operands, mode 0 = exact-f32 MFMA, mode 2 = fp16 pipe with scaled
     2-piece split operands, mode 3 (default) = mode 2 + layers 1, 2 on the DMA kernel reading H2 activations (B = 64:
