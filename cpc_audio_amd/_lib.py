@@ -57,6 +57,7 @@ SIGNATURES = {
     "cpc_set_gemm_fuse": (_I, [_I]),
     "cpc_set_gru_xcd_pack": (_I, [_I]),
     "cpc_set_gru_chunk_tiles": (_I, [_I]),
+    "cpc_set_gru_tiles_per_wg": (_I, [_I]),
     "cpc_set_gru_poll_pacing": (_I, [_I, _I]),
     "cpc_set_dma_rotation": (_I, [_I]),
     "cpc_set_dma_pipeline": (_I, [_I]),

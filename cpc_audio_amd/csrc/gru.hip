@@ -625,7 +625,7 @@ __device__ __forceinline__ void mfma_gates_h2(f32x4 (&acc)[3], const float4 (&a)
 }
 
 struct PersistIds {
-    int layer, j0, b0, tile, ntiles;
+    int layer, j0, b0, tile, ntiles, G;
     bool valid;
     // G batch tiles of 32 workgroups each (2 layers x 16 unit tiles).  pack: workgroup b is dispatched to XCD b % 8, so the
     // grid is 256 * ceil(G / 8) and tile (slot / 32) * 8 + xcd takes the 32 slots of its XCD -- every hand-over of a tile
@@ -647,6 +647,7 @@ struct PersistIds {
         valid = tile < G && tile0 + tile < total;
         tile += tile0;
         ntiles = total;
+        this->G = G;
         b0 = tile * 16;
         layer = rest >> 4;
         j0 = (rest & 15) * 16;
@@ -660,17 +661,25 @@ struct PersistIds {
 constexpr int kPersistThreads = 768;
 constexpr int kMfmaWaves = 8;
 
-template <int LAYER, bool H2>
+// NT (1 or 2): batch tiles per workgroup.  A batch whose 32 workgroups per tile cannot all be resident at once (B = 256 on 256
+// CUs: 16 tiles of 32) used to run as serial launches over chunks of tiles -- two full recurrences of step latency.  With NT = 2 a
+// workgroup owns tiles `tile` and `tile + G` and alternates between them inside every time step: the W slice in its registers
+// serves both, and while the hand-over of one tile's step is in flight (store -> visible -> load, the 1.3 us that bound a step)
+// it computes the other's.  The two recurrences are independent and each keeps the arithmetic and the summation order of the
+// single-tile kernel: bit-identical results (tests/test_emu_gru.py, tests/test_gpu_fused_step.py).
+template <int LAYER, bool H2, int NT>
 __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8][3][256], const PersistIds& id) {
-    const int j0 = id.j0, b0 = id.b0;
+    const int j0 = id.j0;
     constexpr int NII = LAYER == 0 ? 2 : 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int B = p.B, S = p.S;
     float* __restrict__ yl = p.y[LAYER];
+    int tl[NT];                                      // this workgroup's batch tiles (tl[k] >= ntiles: none)
+#pragma unroll
+    for (int k = 0; k < NT; ++k) tl[k] = id.tile + k * id.G;
 
     if (w < kMfmaWaves) {
         const int i = lane & 15, kq = lane >> 4;
-        const bool bok = (b0 + i) < B;
         const bool recurrent = LAYER == 0 || w < 4;  // this wave's product: W_hh h_{t-1}  (else W_ih1 h0_t)
         const int koff = LAYER == 0 ? 32 * w + 4 * kq : 64 * (w & 3) + 4 * kq;
         float4 bw[3][NII];
@@ -682,123 +691,149 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
             inv = 1.0f / (sa * split_gate_weights<NII>(bw, bh));      // powers of two: exact
         }
         const float* __restrict__ xsrc = (recurrent ? p.xh[LAYER] : p.xh[0]) + xpos(i, koff);
+        bool tok[NT], bok[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            tok[k] = tl[k] < id.ntiles;
+            bok[k] = tok[k] && (tl[k] * 16 + i) < B;
+        }
         int budget = p.spin_limit;
         PollPace pace(p.first_sleep);
         for (int t = 0; t < S; ++t) {
-            float4 a[NII];
-            if (recurrent) {
-                if (t == 0) load_row_plain<NII>(p.h0[LAYER] ? p.h0[LAYER] + (long)(b0 + i) * kH + koff : nullptr,
-                                                bok && p.h0[LAYER] != nullptr, a);
-                else poll_row<NII>(xsrc + xtile(t - 1, id.tile, id.ntiles, kH), bok, a, budget, pace);
-            } else {
-                poll_row<NII>(xsrc + xtile(t, id.tile, id.ntiles, kH), bok, a, budget, pace);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                float4 a[NII];
+                if (!tok[k]) {                       // (workgroup-uniform: no second tile -- it still keeps the barrier count)
+#pragma unroll
+                    for (int ii = 0; ii < NII; ++ii) a[ii] = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if (recurrent) {
+                    if (t == 0) load_row_plain<NII>(p.h0[LAYER] ? p.h0[LAYER] + (long)(tl[k] * 16 + i) * kH + koff : nullptr,
+                                                    bok[k] && p.h0[LAYER] != nullptr, a);
+                    else poll_row<NII>(xsrc + xtile(t - 1, tl[k], id.ntiles, kH), bok[k], a, budget, pace);
+                } else {
+                    poll_row<NII>(xsrc + xtile(t, tl[k], id.ntiles, kH), bok[k], a, budget, pace);
+                }
+                f32x4 acc[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (H2) {
+                    mfma_gates_h2<NII>(acc, a, bh, sa);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) acc[g] = scale4(acc[g], inv);
+                } else {
+                    mfma_gates<NII>(acc, a, bw);
+                }
+                float (&pt)[8][3][256] = part[(t * NT + k) & 1];
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pt[w][g][(kq * 4 + r) * 16 + i] = acc[g][r];
+                __syncthreads();
             }
-            f32x4 acc[3];
-#pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (H2) {
-                mfma_gates_h2<NII>(acc, a, bh, sa);
-#pragma unroll
-                for (int g = 0; g < 3; ++g) acc[g] = scale4(acc[g], inv);
-            } else {
-                mfma_gates<NII>(acc, a, bw);
-            }
-            float (&pt)[8][3][256] = part[t & 1];
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pt[w][g][(kq * 4 + r) * 16 + i] = acc[g][r];
-            __syncthreads();
         }
         return;
     }
 
     // ---- gate waves
     const int e = tid - kMfmaWaves * 64;             // == row * 16 + col
-    const int b = b0 + (e >> 4), j = j0 + (e & 15);
-    const bool live = b < B;
-    float bh[3] = {0.f, 0.f, 0.f}, gi[3] = {0.f, 0.f, 0.f}, hp = 0.f;
-    if (live) {
+    const int j = j0 + (e & 15);
+    int b[NT];
+    bool tok[NT], live[NT];
+    float bh[3] = {0.f, 0.f, 0.f}, gi[NT][3], hp[NT];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) bh[g] = p.bhh[LAYER][g * kH + j];
-        if (LAYER == 1) {
+    for (int g = 0; g < 3; ++g) bh[g] = p.bhh[LAYER][g * kH + j];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) gi[g] = p.bih1[g * kH + j];
-        } else {
-            const float* gip = p.x_gi0 + (long)b * S * kG;
-            gi[0] = gip[j]; gi[1] = gip[kH + j]; gi[2] = gip[2 * kH + j];
+    for (int k = 0; k < NT; ++k) {
+        b[k] = tl[k] * 16 + (e >> 4);
+        tok[k] = tl[k] < id.ntiles;
+        live[k] = tok[k] && b[k] < B;
+        gi[k][0] = gi[k][1] = gi[k][2] = 0.f;
+        hp[k] = 0.f;
+        if (live[k]) {
+            if (LAYER == 1) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) gi[k][g] = p.bih1[g * kH + j];
+            } else {
+                const float* gip = p.x_gi0 + (long)b[k] * S * kG;
+                gi[k][0] = gip[j]; gi[k][1] = gip[kH + j]; gi[k][2] = gip[2 * kH + j];
+            }
+            if (p.h0[LAYER]) hp[k] = p.h0[LAYER][(long)b[k] * kH + j];
         }
-        if (p.h0[LAYER]) hp = p.h0[LAYER][(long)b * kH + j];
     }
     float* __restrict__ cf = p.coef[LAYER];
     const int cpos = xpos(e >> 4, j);
     for (int t = 0; t < S; ++t) {
-        __syncthreads();
-        if (!live) {
-            if (cf) {                                             // padding rows of the last tile: zero coefficients, so that
-                const long c = xtile(t, id.tile, id.ntiles, kH) + cpos;     // the backward recurrence can load them unconditionally
-                cf[c] = 0.f; cf[c + p.frag_stride] = 0.f; cf[c + 2 * p.frag_stride] = 0.f; cf[c + 3 * p.frag_stride] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            __syncthreads();
+            if (!live[k]) {
+                if (cf && tok[k]) {                                   // padding rows of the last tile: zero coefficients, so that
+                    const long c = xtile(t, tl[k], id.ntiles, kH) + cpos;     // the backward recurrence can load them unconditionally
+                    cf[c] = 0.f; cf[c + p.frag_stride] = 0.f; cf[c + 2 * p.frag_stride] = 0.f; cf[c + 3 * p.frag_stride] = 0.f;
+                }
+                continue;
             }
-            continue;
-        }
-        const long bt = (long)b * S + t;
-        float (&pt)[8][3][256] = part[t & 1];
-        float gh[3], gi_r = gi[0], gi_z = gi[1], gi_n = gi[2];
-        if (LAYER == 0) {
+            const long bt = (long)b[k] * S + t;
+            float (&pt)[8][3][256] = part[(t * NT + k) & 1];
+            float gh[3], gi_r = gi[k][0], gi_z = gi[k][1], gi_n = gi[k][2];
+            if (LAYER == 0) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-                gh[g] = (((pt[0][g][e] + pt[1][g][e]) + (pt[2][g][e] + pt[3][g][e])) +
-                         ((pt[4][g][e] + pt[5][g][e]) + (pt[6][g][e] + pt[7][g][e]))) + bh[g];
-        } else {
+                for (int g = 0; g < 3; ++g)
+                    gh[g] = (((pt[0][g][e] + pt[1][g][e]) + (pt[2][g][e] + pt[3][g][e])) +
+                             ((pt[4][g][e] + pt[5][g][e]) + (pt[6][g][e] + pt[7][g][e]))) + bh[g];
+            } else {
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-                gh[g] = ((pt[0][g][e] + pt[1][g][e]) + (pt[2][g][e] + pt[3][g][e])) + bh[g];
-            gi_r += (pt[4][0][e] + pt[5][0][e]) + (pt[6][0][e] + pt[7][0][e]);
-            gi_z += (pt[4][1][e] + pt[5][1][e]) + (pt[6][1][e] + pt[7][1][e]);
-            gi_n += (pt[4][2][e] + pt[5][2][e]) + (pt[6][2][e] + pt[7][2][e]);
-        }
-        const float r = sigmoidf_(gi_r + gh[0]);
-        const float z = sigmoidf_(gi_z + gh[1]);
-        const float n = tanhf(gi_n + r * gh[2]);
-        const float h = (1.0f - z) * n + z * hp;
-        store_coherent(p.xh[LAYER] + xtile(t, id.tile, id.ntiles, kH) + xpos(e >> 4, j), h);   // first: others wait for it
-        yl[bt * kH + j] = h;
-        p.R[LAYER][bt * kH + j] = r;
-        p.Z[LAYER][bt * kH + j] = z;
-        p.N[LAYER][bt * kH + j] = n;
-        p.GHN[LAYER][bt * kH + j] = gh[2];
-        if (t == S - 1) p.hN[((long)LAYER * B + b) * kH + j] = h;
-        if (cf) {                                                 // gru_bwd_coef_kernel's arithmetic, on the values it would re-read
-            const float a = (1.0f - z) * (1.0f - n * n);
-            const long c = xtile(t, id.tile, id.ntiles, kH) + cpos;
-            cf[c] = a * gh[2] * r * (1.0f - r);                   // cr
-            cf[c + p.frag_stride] = (hp - n) * z * (1.0f - z);    // cz   (hp: h_{t-1})
-            cf[c + 2 * p.frag_stride] = a * r;                    // cnh
-            cf[c + 3 * p.frag_stride] = a;                        // cni
-        }
-        hp = h;
-        if (LAYER == 0 && t + 1 < S) {                            // next step's input projection, a step ahead
-            const float* gip = p.x_gi0 + (bt + 1) * kG;
-            gi[0] = gip[j]; gi[1] = gip[kH + j]; gi[2] = gip[2 * kH + j];
+                for (int g = 0; g < 3; ++g)
+                    gh[g] = ((pt[0][g][e] + pt[1][g][e]) + (pt[2][g][e] + pt[3][g][e])) + bh[g];
+                gi_r += (pt[4][0][e] + pt[5][0][e]) + (pt[6][0][e] + pt[7][0][e]);
+                gi_z += (pt[4][1][e] + pt[5][1][e]) + (pt[6][1][e] + pt[7][1][e]);
+                gi_n += (pt[4][2][e] + pt[5][2][e]) + (pt[6][2][e] + pt[7][2][e]);
+            }
+            const float r = sigmoidf_(gi_r + gh[0]);
+            const float z = sigmoidf_(gi_z + gh[1]);
+            const float n = tanhf(gi_n + r * gh[2]);
+            const float h = (1.0f - z) * n + z * hp[k];
+            store_coherent(p.xh[LAYER] + xtile(t, tl[k], id.ntiles, kH) + xpos(e >> 4, j), h);   // first: others wait for it
+            yl[bt * kH + j] = h;
+            p.R[LAYER][bt * kH + j] = r;
+            p.Z[LAYER][bt * kH + j] = z;
+            p.N[LAYER][bt * kH + j] = n;
+            p.GHN[LAYER][bt * kH + j] = gh[2];
+            if (t == S - 1) p.hN[((long)LAYER * B + b[k]) * kH + j] = h;
+            if (cf) {                                                 // gru_bwd_coef_kernel's arithmetic, on the values it would re-read
+                const float a = (1.0f - z) * (1.0f - n * n);
+                const long c = xtile(t, tl[k], id.ntiles, kH) + cpos;
+                cf[c] = a * gh[2] * r * (1.0f - r);                   // cr
+                cf[c + p.frag_stride] = (hp[k] - n) * z * (1.0f - z); // cz   (hp: h_{t-1})
+                cf[c + 2 * p.frag_stride] = a * r;                    // cnh
+                cf[c + 3 * p.frag_stride] = a;                        // cni
+            }
+            hp[k] = h;
+            if (LAYER == 0 && t + 1 < S) {                            // next step's input projection, a step ahead
+                const float* gip = p.x_gi0 + (bt + 1) * kG;
+                gi[k][0] = gip[j]; gi[k][1] = gip[kH + j]; gi[k][2] = gip[2 * kH + j];
+            }
         }
     }
 }
 
 // grid = 32 * ceil(B/16) workgroups (1-D), 768 threads; xh[0] and xh[1] pre-filled with 0xFF bytes
+template <int NT>
 __global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_kernel(Gru2Fwd p) {
     __shared__ float part[2][8][3][256];
     const PersistIds id(p.ntiles, p.xcd_pack, p.tile0, p.total_tiles);
     if (!id.valid) return;
-    if (id.layer == 0) persist_fwd<0, false>(p, part, id);
-    else persist_fwd<1, false>(p, part, id);
+    if (id.layer == 0) persist_fwd<0, false, NT>(p, part, id);
+    else persist_fwd<1, false, NT>(p, part, id);
 }
 // the same with the recurrent products on the fp16 pipe (two-piece split operands); h0 must be absent (|h| < 1)
+template <int NT>
 __global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_h2_kernel(Gru2Fwd p) {
     __shared__ float part[2][8][3][256];
     const PersistIds id(p.ntiles, p.xcd_pack, p.tile0, p.total_tiles);
     if (!id.valid) return;
-    if (id.layer == 0) persist_fwd<0, true>(p, part, id);
-    else persist_fwd<1, true>(p, part, id);
+    if (id.layer == 0) persist_fwd<0, true, NT>(p, part, id);
+    else persist_fwd<1, true, NT>(p, part, id);
 }
 
 template <int NU>
@@ -820,16 +855,21 @@ __device__ __forceinline__ void load_coef(float4 (&cf)[NU][3], const float* __re
 // (The fp16-split products of the forward, mfma_gates_h2, were tried here too -- with a per-wave, per-step power-of-two
 // scale taken from the operand's own max, since gate gradients have no a-priori bound: parity was fine, but the extra
 // VALU work (max, scale, 48 conversions per lane and step) and 23 spilled registers made the step 0.23 ms slower.)
-template <int LAYER>
+// NT: batch tiles per workgroup, as in persist_fwd.  With NT = 2 the coefficients of a step are requested together with its
+// first poll instead of one step ahead (two prefetched sets would not fit the register budget of three waves per SIMD); the
+// other tile's work hides them.
+template <int LAYER, int NT>
 __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8][256], const PersistIds& id) {
     constexpr int NU = LAYER == 1 ? 2 : 4;           // unit fragments per lane (x 3 gates = MFMA fragments)
-    const int j0 = id.j0, b0 = id.b0;
+    const int j0 = id.j0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int B = p.B, S = p.S;
+    int tl[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) tl[k] = id.tile + k * id.G;
 
     if (w < kMfmaWaves) {
         const int i = lane & 15, kq = lane >> 4;
-        const bool bok = (b0 + i) < B;
         const bool recurrent = LAYER == 1 || w < 4;  // dGh_{t+1} . W_hh   (else dGi1_t . W_ih1)
         const int unit0 = LAYER == 1 ? 32 * w + 4 * kq : 64 * (w & 3) + 4 * kq;
         float4 bw[NU][3];
@@ -847,35 +887,45 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
         const float* __restrict__ c2 = recurrent ? p.cnh[sl] : p.cni[sl];
         const long lane_off = xpos(i, unit0);
         const float* __restrict__ xsrc = p.xdh[sl] + lane_off;
+        bool tok[NT], bok[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            tok[k] = tl[k] < id.ntiles;
+            bok[k] = tok[k] && (tl[k] * 16 + i) < B;
+        }
         float4 cf[NU][3];
-        if (!recurrent) load_coef<NU>(cf, c0, c1, c2, xtile(S - 1, id.tile, id.ntiles, kH) + lane_off);
+        if (NT == 1 && !recurrent) load_coef<NU>(cf, c0, c1, c2, xtile(S - 1, tl[0], id.ntiles, kH) + lane_off);
         int budget = p.spin_limit;
         PollPace pace(p.first_sleep);
         for (int t = S - 1; t >= 0; --t) {
             const int ts = recurrent ? t + 1 : t;                 // step whose gate gradients are this wave's operand
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ts < S) {
-                float4 dh[NU];
-                poll_row<NU>(xsrc + xtile(ts, id.tile, id.ntiles, kH), bok, dh, budget, pace);
-                f32x4 ag[3];
 #pragma unroll
-                for (int g = 0; g < 3; ++g) ag[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < NT; ++k) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ts < S && tok[k]) {
+                    if (NT > 1) load_coef<NU>(cf, c0, c1, c2, xtile(ts, tl[k], id.ntiles, kH) + lane_off);
+                    float4 dh[NU];
+                    poll_row<NU>(xsrc + xtile(ts, tl[k], id.ntiles, kH), bok[k], dh, budget, pace);
+                    f32x4 ag[3];
 #pragma unroll
-                for (int ii = 0; ii < NU; ++ii)
+                    for (int g = 0; g < 3; ++g) ag[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
+                    for (int ii = 0; ii < NU; ++ii)
 #pragma unroll
-                        for (int g = 0; g < 3; ++g)
-                            ag[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(dh[ii], jj) * f4c(cf[ii][g], jj),
-                                                                         f4c(bw[ii][g], jj), ag[g], 0, 0, 0);
-                acc = add4(acc, add4(add4(ag[0], ag[1]), ag[2]));
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int g = 0; g < 3; ++g)
+                                ag[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(dh[ii], jj) * f4c(cf[ii][g], jj),
+                                                                             f4c(bw[ii][g], jj), ag[g], 0, 0, 0);
+                    acc = add4(acc, add4(add4(ag[0], ag[1]), ag[2]));
+                }
+                if (NT == 1 && t > 0)                             // next iteration's coefficients: step ts - 1
+                    load_coef<NU>(cf, c0, c1, c2, xtile(ts - 1, tl[0], id.ntiles, kH) + lane_off);
+                float (&pt)[8][256] = part[(t * NT + k) & 1];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) pt[w][(kq * 4 + rr) * 16 + i] = acc[rr];
+                __syncthreads();
             }
-            if (t > 0)                                            // next iteration's coefficients: step ts - 1
-                load_coef<NU>(cf, c0, c1, c2, xtile(ts - 1, id.tile, id.ntiles, kH) + lane_off);
-            float (&pt)[8][256] = part[t & 1];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) pt[w][(kq * 4 + rr) * 16 + i] = acc[rr];
-            __syncthreads();
         }
         return;
     }
@@ -883,51 +933,63 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
     // ---- gate waves
     const int e = tid - kMfmaWaves * 64;
     const int row = e >> 4;
-    const int b = b0 + row, j = j0 + (e & 15);
-    const bool live = b < B;
+    const int j = j0 + (e & 15);
     const int xp = xpos(row, j);
-    float dyv = 0.f, z = 0.f, cr = 0.f, cz = 0.f, cnh = 0.f, cni = 0.f;   // operands of the step about to run
-    auto fetch = [&](int t) __attribute__((always_inline)) {
-        const long bt = (long)b * S + t;
-        if (LAYER == 1) dyv = p.dy[bt * kH + j];
-        z = p.Z[LAYER][bt * kH + j];
-        const long c = xtile(t, id.tile, id.ntiles, kH) + xp;
-        cr = p.cr[LAYER][c]; cz = p.cz[LAYER][c]; cnh = p.cnh[LAYER][c]; cni = p.cni[LAYER][c];
+    int b[NT];
+    bool live[NT];
+    float dyv[NT], z[NT], cr[NT], cz[NT], cnh[NT], cni[NT];       // operands of the step about to run
+    float dh_next[NT], z_next[NT];
+    auto fetch = [&](int k, int t) __attribute__((always_inline)) {
+        const long bt = (long)b[k] * S + t;
+        if (LAYER == 1) dyv[k] = p.dy[bt * kH + j];
+        z[k] = p.Z[LAYER][bt * kH + j];
+        const long c = xtile(t, tl[k], id.ntiles, kH) + xp;
+        cr[k] = p.cr[LAYER][c]; cz[k] = p.cz[LAYER][c]; cnh[k] = p.cnh[LAYER][c]; cni[k] = p.cni[LAYER][c];
     };
-    if (live) fetch(S - 1);
-    float dh_next = 0.f, z_next = 0.f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        b[k] = tl[k] * 16 + row;
+        live[k] = tl[k] < id.ntiles && b[k] < B;
+        dyv[k] = z[k] = cr[k] = cz[k] = cnh[k] = cni[k] = 0.f;
+        dh_next[k] = z_next[k] = 0.f;
+        if (live[k]) fetch(k, S - 1);
+    }
     for (int t = S - 1; t >= 0; --t) {
-        __syncthreads();
-        if (!live) continue;
-        const long bt = (long)b * S + t;
-        float (&pt)[8][256] = part[t & 1];
-        float dh0 = LAYER == 1 ? dyv : 0.f;
-        if ((t + 1) < S) dh0 = fmaf(dh_next, z_next, dh0);
-        const float dh = (((pt[0][e] + pt[1][e]) + (pt[2][e] + pt[3][e])) +
-                          ((pt[4][e] + pt[5][e]) + (pt[6][e] + pt[7][e]))) + dh0;
-        store_coherent(p.xdh[LAYER] + xtile(t, id.tile, id.ntiles, kH) + xp, dh);   // first: others wait for it
-        float* gi = p.dGi[LAYER] + bt * kG;
-        float* gh = p.dGh[LAYER] + bt * kG;
-        const float dar = dh * cr, daz = dh * cz;
-        // 200 MB of gate gradients for the weight-gradient GEMMs that follow: streamed past the caches the polling
-        // traffic lives in (non-temporal: 0.834 vs 0.853 ms for the whole backward)
-        __builtin_nontemporal_store(dar, gi + j); __builtin_nontemporal_store(dar, gh + j);
-        __builtin_nontemporal_store(daz, gi + kH + j); __builtin_nontemporal_store(daz, gh + kH + j);
-        __builtin_nontemporal_store(dh * cni, gi + 2 * kH + j); __builtin_nontemporal_store(dh * cnh, gh + 2 * kH + j);
-        __builtin_nontemporal_store(dh, p.DH[LAYER] + bt * kH + j);
-        dh_next = dh;
-        z_next = z;
-        if (t > 0) fetch(t - 1);                                  // a step ahead: memory latency off the chain
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            __syncthreads();
+            if (!live[k]) continue;
+            const long bt = (long)b[k] * S + t;
+            float (&pt)[8][256] = part[(t * NT + k) & 1];
+            float dh0 = LAYER == 1 ? dyv[k] : 0.f;
+            if ((t + 1) < S) dh0 = fmaf(dh_next[k], z_next[k], dh0);
+            const float dh = (((pt[0][e] + pt[1][e]) + (pt[2][e] + pt[3][e])) +
+                              ((pt[4][e] + pt[5][e]) + (pt[6][e] + pt[7][e]))) + dh0;
+            store_coherent(p.xdh[LAYER] + xtile(t, tl[k], id.ntiles, kH) + xp, dh);   // first: others wait for it
+            float* gi = p.dGi[LAYER] + bt * kG;
+            float* gh = p.dGh[LAYER] + bt * kG;
+            const float dar = dh * cr[k], daz = dh * cz[k];
+            // 200 MB of gate gradients for the weight-gradient GEMMs that follow: streamed past the caches the polling
+            // traffic lives in (non-temporal: 0.834 vs 0.853 ms for the whole backward)
+            __builtin_nontemporal_store(dar, gi + j); __builtin_nontemporal_store(dar, gh + j);
+            __builtin_nontemporal_store(daz, gi + kH + j); __builtin_nontemporal_store(daz, gh + kH + j);
+            __builtin_nontemporal_store(dh * cni[k], gi + 2 * kH + j); __builtin_nontemporal_store(dh * cnh[k], gh + 2 * kH + j);
+            __builtin_nontemporal_store(dh, p.DH[LAYER] + bt * kH + j);
+            dh_next[k] = dh;
+            z_next[k] = z[k];
+            if (t > 0) fetch(k, t - 1);                               // a step ahead: memory latency off the chain
+        }
     }
 }
 
 // grid / block as the forward; xdh[0] and xdh[1] pre-filled with 0xFF bytes
+template <int NT>
 __global__ __launch_bounds__(kPersistThreads) void gru2_persist_bwd_kernel(Gru2Bwd p) {
     __shared__ float part[2][8][256];
     const PersistIds id(p.ntiles, p.xcd_pack, p.tile0, p.total_tiles);
     if (!id.valid) return;
-    if (id.layer == 0) persist_bwd<1>(p, part, id);               // the top layer leads
-    else persist_bwd<0>(p, part, id);
+    if (id.layer == 0) persist_bwd<1, NT>(p, part, id);           // the top layer leads
+    else persist_bwd<0, NT>(p, part, id);
 }
 
 // ------------------------------------------------------------------ host side
@@ -1013,6 +1075,17 @@ static int persist_chunk(const void* kernel, int G) {
     return fit >= G ? G : fit;
 }
 
+// How a persistent launch covers `total` batch tiles: *G tile slots (32 workgroups each) per launch, *NT tiles per slot (1, or 2
+// when the batch does not fit the device in one launch and g_gru_tiles_per_wg allows), launches of G * NT tiles one after the
+// other.  fit1 / fit2: tiles whose workgroups can be resident at once for the NT = 1 / NT = 2 kernels (persist_chunk).
+int g_gru_tiles_per_wg = 2;      // cpc_set_gru_tiles_per_wg: 1 = serial chunks only (rounds 2-4), 2 = a workgroup may own two tiles
+static void persist_plan(int total, int fit1, int fit2, int* G, int* NT) {
+    if (fit1 >= total || g_gru_tiles_per_wg < 2 || fit2 <= 0) { *G = fit1 >= total ? total : fit1; *NT = 1; return; }
+    const int slots = (total + 1) / 2;
+    *G = slots < fit2 ? slots : fit2;
+    *NT = 2;
+}
+
 template <class K>
 int persist_grid(K kernel, int G, int* pack) {
     int dev = 0, cus = 0, occ = 0;
@@ -1066,6 +1139,15 @@ extern "C" int cpc_set_gru_poll_pacing(int first_fwd, int first_bwd) {
 extern "C" int cpc_set_gru_chunk_tiles(int tiles) {
     if (tiles < 0) return CPC_ERR_ARG;
     g_gru_chunk_tiles = tiles;
+    return 0;
+}
+
+// Batch tiles (16 sequences) a workgroup of the persistent recurrence may own: 2 (default) lets a batch that does not fit the
+// device in one launch -- B = 256 on 256 CUs -- run as ONE launch with the two tiles of a workgroup interleaved step by step;
+// 1: serial launches over chunks of tiles.  Bit-identical results either way.
+extern "C" int cpc_set_gru_tiles_per_wg(int n) {
+    if (n != 1 && n != 2) return CPC_ERR_ARG;
+    g_gru_tiles_per_wg = n;
     return 0;
 }
 
@@ -1151,20 +1233,29 @@ static int gru_forward_impl(const float* x, const float* h0, const float* const*
         p.total_tiles = cdiv(B, 16);
         p.tile0 = 0;
         const bool h2 = g_gru_mode == 2 && !h0;
-        // a batch whose 32 workgroups per tile cannot all be resident at once runs in chunks of tiles, one launch after the
-        // other (B = 256 on 256 CUs: two launches of 8 tiles)
-        p.ntiles = persist_chunk(h2 ? (const void*)gru2_persist_fwd_h2_kernel : (const void*)gru2_persist_fwd_kernel, p.total_tiles);
+        // a batch whose 32 workgroups per tile cannot all be resident at once: two tiles per workgroup (B = 256 on 256 CUs: ONE
+        // launch of 8 tile slots), and beyond that -- or with cpc_set_gru_tiles_per_wg(1) -- chunks of tiles, one launch after the other
+        int NT = 1;
+        {
+            const int fit1 = persist_chunk(h2 ? (const void*)gru2_persist_fwd_h2_kernel<1> : (const void*)gru2_persist_fwd_kernel<1>, p.total_tiles);
+            const int fit2 = persist_chunk(h2 ? (const void*)gru2_persist_fwd_h2_kernel<2> : (const void*)gru2_persist_fwd_kernel<2>, p.total_tiles);
+            persist_plan(p.total_tiles, fit1, fit2, &p.ntiles, &NT);
+        }
         const int nblocks = g_gru_mode < 1 || p.ntiles <= 0 ? 0
-                            : h2 ? persist_grid(gru2_persist_fwd_h2_kernel, p.ntiles, &p.xcd_pack)
-                                 : persist_grid(gru2_persist_fwd_kernel, p.ntiles, &p.xcd_pack);
+                            : h2 ? (NT == 2 ? persist_grid(gru2_persist_fwd_h2_kernel<2>, p.ntiles, &p.xcd_pack)
+                                            : persist_grid(gru2_persist_fwd_h2_kernel<1>, p.ntiles, &p.xcd_pack))
+                                 : (NT == 2 ? persist_grid(gru2_persist_fwd_kernel<2>, p.ntiles, &p.xcd_pack)
+                                            : persist_grid(gru2_persist_fwd_kernel<1>, p.ntiles, &p.xcd_pack));
         if (nblocks > 0) {
             p.xh[0] = scratch + g.xh; p.xh[1] = scratch + g.xh + g.xh_floats;
             if (coef) { p.coef[0] = coef; p.coef[1] = coef + 4 * g.frag_floats; }
             if (!xh_ready && hipMemsetAsync(p.xh[0], 0xFF, 2 * g.xh_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
             step_timer_mark(3, st);
-            for (p.tile0 = 0; p.tile0 < p.total_tiles; p.tile0 += p.ntiles) {
-                if (h2) hipLaunchKernelGGL(gru2_persist_fwd_h2_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
-                else hipLaunchKernelGGL(gru2_persist_fwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+            for (p.tile0 = 0; p.tile0 < p.total_tiles; p.tile0 += p.ntiles * NT) {
+                if (h2 && NT == 2) hipLaunchKernelGGL(gru2_persist_fwd_h2_kernel<2>, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+                else if (h2) hipLaunchKernelGGL(gru2_persist_fwd_h2_kernel<1>, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+                else if (NT == 2) hipLaunchKernelGGL(gru2_persist_fwd_kernel<2>, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+                else hipLaunchKernelGGL(gru2_persist_fwd_kernel<1>, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
             }
             step_timer_mark(4, st);
             CPC_LAUNCH_CHECK();
@@ -1305,13 +1396,19 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
         p.wih1T = wihT_[1];
         p.total_tiles = cdiv(B, 16);
         p.tile0 = 0;
-        p.ntiles = persist_chunk((const void*)gru2_persist_bwd_kernel, p.total_tiles);
-        const int nblocks = g_gru_mode < 1 || p.ntiles <= 0 ? 0 : persist_grid(gru2_persist_bwd_kernel, p.ntiles, &p.xcd_pack);
+        int NT = 1;
+        persist_plan(p.total_tiles, persist_chunk((const void*)gru2_persist_bwd_kernel<1>, p.total_tiles),
+                     persist_chunk((const void*)gru2_persist_bwd_kernel<2>, p.total_tiles), &p.ntiles, &NT);
+        const int nblocks = g_gru_mode < 1 || p.ntiles <= 0 ? 0
+                            : NT == 2 ? persist_grid(gru2_persist_bwd_kernel<2>, p.ntiles, &p.xcd_pack)
+                                      : persist_grid(gru2_persist_bwd_kernel<1>, p.ntiles, &p.xcd_pack);
         if (nblocks > 0) {
             if (!coef && hipMemsetAsync(p.xdh[0], 0xFF, 2 * g.frag_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
             step_timer_mark(5, st);
-            for (p.tile0 = 0; p.tile0 < p.total_tiles; p.tile0 += p.ntiles)
-                hipLaunchKernelGGL(gru2_persist_bwd_kernel, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+            for (p.tile0 = 0; p.tile0 < p.total_tiles; p.tile0 += p.ntiles * NT) {
+                if (NT == 2) hipLaunchKernelGGL(gru2_persist_bwd_kernel<2>, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+                else hipLaunchKernelGGL(gru2_persist_bwd_kernel<1>, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
+            }
             step_timer_mark(6, st);
         } else {
             const dim3 grid(kH / 16, cdiv(B, 16), 2);

@@ -190,6 +190,10 @@ int cpc_set_gru_xcd_pack(int on);
 /* Persistent recurrence: cap on the 16-sequence batch tiles of one launch (0 = whatever fits the device, the default); a
  * larger batch runs as several launches one after the other (B = 256 on 256 CUs: two launches of 8 tiles). */
 int cpc_set_gru_chunk_tiles(int tiles);
+/* Batch tiles a workgroup of the persistent recurrence may own: 2 (default) = a batch that does not fit the device in one launch
+ * (B = 256 per GPU, BASELINE configs[2], on 256 CUs) runs as ONE launch, each workgroup interleaving its two tiles step by step
+ * (cpc/model.py:193's nn.GRU over the whole batch); 1 = serial launches over chunks of tiles.  Same bits either way. */
+int cpc_set_gru_tiles_per_wg(int n);
 /* Persistent recurrence: the wait before a step's first look at the hand-over buffers (forward / backward kernel), in
  * units of 64 clocks; < 0 (default): every wave steers its own so that looks that cannot succeed yet are not issued
  * (they load the L2s the hand-over itself goes through). */

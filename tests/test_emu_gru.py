@@ -179,13 +179,29 @@ def test_persistent_recurrence_in_chunks_of_batch_tiles_emulated():
     (B = 256 on MI355X: two launches of 8 tiles).  cpc_set_gru_chunk_tiles(1) forces one tile per launch: same bits."""
     lib = emu()
     outs = []
-    for cap in (0, 1):
-        assert lib.cpc_set_gru_chunk_tiles(cap) == 0
+    # (cap, tiles per workgroup): everything resident; one tile per launch, serial chunks (rounds 2-4); TWO tiles per workgroup --
+    # launches of 1 slot x 2 tiles: (0, 1), then (2, none) -- and 2 slots x 2 tiles in ONE launch: (0, 2), (1, none).  With two tiles
+    # a workgroup alternates between its tiles inside every time step (what B = 256 runs as on MI355X); same bits, forward and backward.
+    for cap, tpw in ((0, 2), (1, 1), (1, 2), (2, 2)):
+        assert lib.cpc_set_gru_chunk_tiles(cap) == 0 and lib.cpc_set_gru_tiles_per_wg(tpw) == 0
         try:
             outs.append(_run_gru(lib, 36, 5, 2, False))          # three tiles, the last one ragged
         finally:
             lib.cpc_set_gru_chunk_tiles(0)
+            lib.cpc_set_gru_tiles_per_wg(2)
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
+    # ... and with an initial state (the exact-f32 forward kernel; h0 rows of the second tile)
+    outs = []
+    for cap, tpw in ((0, 2), (1, 2)):
+        assert lib.cpc_set_gru_chunk_tiles(cap) == 0 and lib.cpc_set_gru_tiles_per_wg(tpw) == 0
+        try:
+            outs.append(_run_gru(lib, 20, 4, 2, True))
+        finally:
+            lib.cpc_set_gru_chunk_tiles(0)
+            lib.cpc_set_gru_tiles_per_wg(2)
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+    assert lib.cpc_set_gru_tiles_per_wg(3) != 0
 
 
 def test_gru_backward_with_early_coefficients_emulated():
