@@ -111,7 +111,8 @@ class PredictionNetwork(nn.Module):
     def _predictions(self, c):
         from .transformers import TransformerLayer
         layers = [p[0] if isinstance(p, nn.Sequential) and len(p) == 1 else None for p in self.predictors]
-        if (self.group_predictors and self.rnnMode == "transformer" and len(layers) > 1 and all(isinstance(l, TransformerLayer) for l in layers)
+        if (self.group_predictors and self.rnnMode == "transformer" and len(layers) > 1
+                and all(isinstance(l, TransformerLayer) and l.fused for l in layers)
                 and len({(l.dropout_p, l.training, l.multihead.Att.relpos) for l in layers}) == 1 and c.is_cuda):
             from .ops import TransformerGroupFunction
             l0 = layers[0]

@@ -1404,7 +1404,9 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
                                       : persist_grid(gru2_persist_bwd_kernel<1>, p.ntiles, &p.xcd_pack);
         if (nblocks > 0) {
             if (!coef && hipMemsetAsync(p.xdh[0], 0xFF, 2 * g.frag_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
-            step_timer_mark(5, st);
+            // (in-step timing: the marker in FRONT of this launch is recorded by cpc_train_step before it releases the side
+            // stream's gather kernels -- a marker packet between that release and this launch lets their workgroups take the
+            // CUs first, and the persistent launch then waits 250 us for residency: measured)
             for (p.tile0 = 0; p.tile0 < p.total_tiles; p.tile0 += p.ntiles * NT) {
                 if (NT == 2) hipLaunchKernelGGL(gru2_persist_bwd_kernel<2>, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
                 else hipLaunchKernelGGL(gru2_persist_bwd_kernel<1>, dim3(nblocks), dim3(kPersistThreads), 0, st, p);

@@ -235,6 +235,7 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
             rc = cpc_nce_backward_dz(c, wall, perm, row_ptr, ws + s.nce_saved, ws + s.nce_bscr, dz, B, S, K, N, M);
             if (rc) return rc;
         }
+        step_timer_mark(5, M);           // (in front of the event that releases the side stream: see cpc_gru_backward_streams)
         CPC_RETURN_IF(!rec(ev[3], M) || !wait(M, ev[2]), CPC_ERR_ARG);
         // recurrence: dx on main, its weight / bias gradients straight into `grads` on the wgrad stream (no join here)
         rc = cpc_gru_backward_streams(z, h0, gru_p, ws + s.gru_saved, c, dc, coef, ws + s.gru_bscr, dx, gru_g, B, S, 2, M, S2);

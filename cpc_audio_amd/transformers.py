@@ -3,7 +3,9 @@
 Same class names, constructor signatures, parameter / buffer names (state-dict keys ``multihead.Wo.weight``,
 ``multihead.Att.Krelpos``, ``multihead.Att.z``, ``multihead.Att.mask``, ``ln_multihead.*``, ``ffnetwork.lin1.*`` ...)
 and the same ``buildTransformerAR`` factory (cpc/transformers.py:130-139), so checkpoints load both ways.  A
-``TransformerLayer`` runs as ONE fused HIP layer (csrc/transformer.hip); the sub-modules are parameter holders.
+``TransformerLayer`` of the default geometry runs as ONE fused HIP layer (csrc/transformer.hip); the sub-modules hold its
+parameters and, called on their own (or inside a layer the fused kernels do not cover: more than 128 steps, other widths),
+compute the reference's forward with torch ops.
 
 Dropout: the reference hard-codes p = 0.1 inside TransformerLayer (cpc/transformers.py:18,93,100).  The HIP layer applies
 it in training mode inside its kernels -- Philox4x32-10 keep-masks derived from a 64-bit seed the layer draws per call and
@@ -41,7 +43,22 @@ class ScaledDotProductAttention(nn.Module):
         mat.data.uniform_(-stdv, stdv)
 
     def forward(self, Q, K, V):
-        raise NotImplementedError("attention runs inside the fused TransformerLayer kernel path")
+        """Q, K, V (N, S, dk) -> (N, S, dk), cpc/transformers.py:37-49, as torch ops: the stand-alone form of the sub-module
+        (a TransformerLayer of the default geometry never calls it: its attention runs inside the fused HIP layer).  The
+        reference's relative-position term -- a zero column glued to Q.Krelpos and a reshape -- is the skew
+        ``score[i, j] += q_i . Krelpos[:, sizeSeq - 1 - (i - j)]`` for j <= i, written out as an index here."""
+        S = Q.size(1)
+        if S > self.sizeSeq:
+            raise ValueError(f"sequence of {S} steps in an attention built for sizeSeq = {self.sizeSeq}")
+        score = torch.bmm(Q, K.transpose(1, 2))
+        if self.relpos:
+            rel = torch.matmul(Q, self.Krelpos)                               # (N, S, sizeSeq): column c <-> distance sizeSeq-1-c
+            steps = torch.arange(S, device=Q.device)
+            col = (self.sizeSeq - 1 - (steps.view(S, 1) - steps.view(1, S))).clamp(0, self.sizeSeq - 1)
+            score = score + torch.gather(rel, 2, col.unsqueeze(0).expand(Q.size(0), S, S))   # (j > i: masked below)
+        A = torch.softmax(score / math.sqrt(K.size(-1)) + self.mask[:, :S, :S], dim=2)
+        A = nn.functional.dropout(A, self.dropout_p, self.training)
+        return torch.bmm(A, V)
 
 
 class MultiHeadAttention(nn.Module):
@@ -57,8 +74,15 @@ class MultiHeadAttention(nn.Module):
         self.dk = dmodel // nheads
         self.Att = ScaledDotProductAttention(sizeSeq, self.dk, dropout, not abspos)
 
+    def _heads(self, x):                          # (B, S, h dk) -> (B h, S, dk)
+        B, S = x.size(0), x.size(1)
+        return x.view(B, S, self.nheads, self.dk).transpose(1, 2).reshape(B * self.nheads, S, self.dk)
+
     def forward(self, Q, K, V):
-        raise NotImplementedError("attention runs inside the fused TransformerLayer kernel path")
+        """cpc/transformers.py:79-85 as torch ops (stand-alone use; see ScaledDotProductAttention.forward)."""
+        B, S = Q.size(0), Q.size(1)
+        y = self.Att(self._heads(self.Wq(Q)), self._heads(self.Wk(K)), self._heads(self.Wv(V)))
+        return self.Wo(y.view(B, self.nheads, S, self.dk).transpose(1, 2).reshape(B, S, self.nheads * self.dk))
 
 
 class FFNetwork(nn.Module):
@@ -72,7 +96,8 @@ class FFNetwork(nn.Module):
         self.dropout_p = float(dropout)
 
     def forward(self, x):
-        raise NotImplementedError("the feed-forward block runs inside the fused TransformerLayer kernel path")
+        """cpc/transformers.py:99-100 as torch ops (stand-alone use)."""
+        return self.lin2(nn.functional.dropout(self.relu(self.lin1(x)), self.dropout_p, self.training))
 
 
 class TransformerLayer(nn.Module):
@@ -80,11 +105,11 @@ class TransformerLayer(nn.Module):
 
     def __init__(self, sizeSeq=32, dmodel=512, dff=2048, dropout=0.1, nheads=8, abspos=False):
         super().__init__()
-        if dmodel != 256 or dff != 2048 or nheads != 8:
-            raise NotImplementedError("the HIP transformer layer is built for dmodel=256, dff=2048, nheads=8 "
-                                      "(what buildTransformerAR gives for the 256-d CPC encoder)")
-        if sizeSeq > 128:
-            raise NotImplementedError("the HIP attention kernels hold sequences of at most 128 steps")
+        # The fused HIP layer (csrc/transformer.hip) is built for what BASELINE config 4 uses -- dmodel 256, dff 2048, 8 heads,
+        # sequences of at most 128 steps (the 20480-sample training window).  Anything else -- a layer built for the 400 frames
+        # of a 64000-sample feature-extraction chunk (cpc/feature_loader.py:247-266), another width -- runs through the
+        # sub-modules' torch-op forwards below: correct on any device, differentiable, not the hot path.
+        self.fused = dmodel == 256 and dff == 2048 and nheads == 8 and sizeSeq <= 128
         self.dropout_p = float(dropout)
         self.multihead = MultiHeadAttention(sizeSeq, dropout, dmodel, nheads, abspos)
         self.ln_multihead = nn.LayerNorm(dmodel)
@@ -92,6 +117,11 @@ class TransformerLayer(nn.Module):
         self.ln_ffnetwork = nn.LayerNorm(dmodel)
 
     def forward(self, x):
+        if not (self.fused and x.is_cuda):
+            if self.fused:
+                raise RuntimeError("TransformerLayer: the fused HIP layer needs CUDA tensors (there is no CPU fallback for the hot path)")
+            y = self.ln_multihead(x + self.multihead(x, x, x))                 # cpc/transformers.py:109-111
+            return self.ln_ffnetwork(y + self.ffnetwork(y))
         # nn.Dropout semantics (transformers.py:18,93): active in training mode only.  The masks of a call derive from one
         # 64-bit seed drawn from torch's CPU generator (reproducible under torch.manual_seed, no device synchronisation).
         p, seed = 0.0, 0

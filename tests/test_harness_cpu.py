@@ -143,3 +143,47 @@ def test_build_feature_batches_equal_chunks_and_cuts_like_the_reference():
     plan = H.chunk_plan(64000 * 2 + 12345, 64000, True, 160)
     assert plan == [(0, 64000, None), (64000, 128000, None), (76345, 140345, 77)]
     assert H.chunk_plan(1000, 64000, True, 160) == [(0, 1000, 6)]
+
+
+def test_transformer_submodules_run_stand_alone_and_long_layers_match_the_oracle():
+    """cpc/transformers.py's classes are drop-in one by one: ScaledDotProductAttention / MultiHeadAttention / FFNetwork compute
+    the reference's forward with torch ops when called on their own, and a TransformerLayer the fused HIP kernels do not cover
+    (sizeSeq = 400: a 64000-sample feature-extraction chunk, cpc/feature_loader.py:247-266) composes them -- checked against the
+    oracle's restatement (oracle/transformer_oracle.py, pinned to the imported reference), values and gradients, with and
+    without the relative-position term, also on a sequence shorter than the layer was built for."""
+    import torch
+    from cpc_audio_amd.transformers import TransformerLayer, buildTransformerAR
+    from oracle import transformer_oracle as T
+    torch.manual_seed(0)
+    for abspos, S_built, S in ((False, 400, 400), (True, 160, 160), (False, 144, 130)):
+        ar = buildTransformerAR(256, 1, S_built, abspos, dropout=0.0)
+        layer = ar[-1]
+        assert isinstance(layer, TransformerLayer) and not layer.fused
+        x = torch.randn(2, S, 256, requires_grad=True)
+        y = ar(x)
+        p = {k: v.detach() for k, v in ar.state_dict().items()}
+        xr = x.detach().clone().requires_grad_(True)
+        if S == S_built:
+            yr = T.ar_forward(p, xr, 1, abspos)
+            assert (y - yr).abs().max().item() < 1e-5
+            g = torch.randn_like(y)
+            (y * g).sum().backward()
+            (yr * g).sum().backward()
+            assert (x.grad - xr.grad).abs().max().item() < 1e-5 * max(1.0, xr.grad.abs().max().item())
+        else:
+            # a shorter sequence in a longer layer: the distance-indexed relative term and the sliced mask are those of a layer
+            # built for the short length whose Krelpos is the LAST S columns of this one (distance d lives in column sizeSeq-1-d)
+            q = {k: v for k, v in p.items()}
+            q["0.multihead.Att.Krelpos"] = p["0.multihead.Att.Krelpos"][:, S_built - S:]
+            yr = T.ar_forward(q, xr, 1, abspos)
+            assert (y - yr).abs().max().item() < 1e-5
+    # the sub-modules on their own
+    layer = TransformerLayer(sizeSeq=24, dmodel=64, dff=128, dropout=0.0, nheads=4)
+    x = torch.randn(3, 24, 64)
+    att = layer.multihead(x, x, x)
+    assert att.shape == (3, 24, 64) and torch.isfinite(att).all()
+    assert layer.ffnetwork(x).shape == (3, 24, 64)
+    q = torch.randn(6, 24, 16)
+    a = layer.multihead.Att(q, q, q)
+    # causal: step 0 attends to itself only
+    assert torch.allclose(a[:, 0], q[:, 0], atol=1e-6)
