@@ -36,34 +36,49 @@ class ChannelNorm(nn.Module):
         return torch.addcmul(self.bias, xhat, self.weight) if self.affine else xhat
 
 
-class CPCEncoder(nn.Module):
-    """cpc/model.py:61-105: five strided Conv1d + ChannelNorm + ReLU, downsampling 160.
+class IDModule(nn.Module):
+    """cpc/model.py:17-22 (normMode 'ID')."""
 
-    conv{i} / batchNorm{i} are parameter containers with the reference's names, shapes and
-    default initialisation; forward runs cpc_encoder_forward (HIP)."""
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+    def forward(self, x):
+        return x
+
+
+class CPCEncoder(nn.Module):
+    """cpc/model.py:61-105: five strided Conv1d + norm + ReLU, downsampling 160.
+
+    conv{i} / batchNorm{i} carry the reference's names, shapes and default initialisation.  The configuration every BASELINE
+    config and the reference's defaults use -- 256 channels, normMode 'layerNorm' (ChannelNorm) -- runs cpc_encoder_forward
+    (HIP, ``self.hip``); the reference's other options (``batchNorm`` / ``instanceNorm`` / ``ID``, other widths; cpc/model.py:
+    73-80) are served by the modules' own torch ops: correct on any device, differentiable, not the hot path."""
 
     def __init__(self, sizeHidden=512, normMode="layerNorm"):
         super().__init__()
         validModes = ["batchNorm", "instanceNorm", "ID", "layerNorm"]
         if normMode not in validModes:
             raise ValueError(f"Norm mode must be in {validModes}")
-        if normMode != "layerNorm":
-            raise NotImplementedError("the HIP encoder implements normMode='layerNorm' (ChannelNorm), "
-                                      "the reference default (cpc_default_config.py:60-63)")
-        if sizeHidden != 256:
-            raise NotImplementedError("the HIP encoder is built for hiddenEncoder == 256 "
-                                      "(cpc_default_config.py:17)")
+        self.hip = normMode == "layerNorm" and sizeHidden == 256
+        if normMode == "instanceNorm":
+            def normLayer(c): return nn.InstanceNorm1d(c, affine=True)
+        elif normMode == "ID":
+            normLayer = IDModule
+        elif normMode == "layerNorm":
+            normLayer = ChannelNorm
+        else:
+            normLayer = nn.BatchNorm1d
         self.dimEncoded = sizeHidden
         self.conv0 = nn.Conv1d(1, sizeHidden, 10, stride=5, padding=3)
-        self.batchNorm0 = ChannelNorm(sizeHidden)
+        self.batchNorm0 = normLayer(sizeHidden)
         self.conv1 = nn.Conv1d(sizeHidden, sizeHidden, 8, stride=4, padding=2)
-        self.batchNorm1 = ChannelNorm(sizeHidden)
+        self.batchNorm1 = normLayer(sizeHidden)
         self.conv2 = nn.Conv1d(sizeHidden, sizeHidden, 4, stride=2, padding=1)
-        self.batchNorm2 = ChannelNorm(sizeHidden)
+        self.batchNorm2 = normLayer(sizeHidden)
         self.conv3 = nn.Conv1d(sizeHidden, sizeHidden, 4, stride=2, padding=1)
-        self.batchNorm3 = ChannelNorm(sizeHidden)
+        self.batchNorm3 = normLayer(sizeHidden)
         self.conv4 = nn.Conv1d(sizeHidden, sizeHidden, 4, stride=2, padding=1)
-        self.batchNorm4 = ChannelNorm(sizeHidden)
+        self.batchNorm4 = normLayer(sizeHidden)
         self.DOWNSAMPLING = 160
 
     def getDimOutput(self):
@@ -80,23 +95,26 @@ class CPCEncoder(nn.Module):
         """(B,1,L) -> (B,C,L/160), as the reference.  The kernels work channels-last, so the
         result is a (B,C,S) VIEW of a contiguous (B,S,C) tensor; CPCModel's permute(0,2,1)
         (model.py:287) therefore yields a contiguous (B,S,C) z at no cost."""
+        if not self.hip:
+            for i in range(5):                                 # cpc/model.py:99-105 with the modules' own torch ops
+                x = torch.relu(getattr(self, f"batchNorm{i}")(getattr(self, f"conv{i}")(x)))
+            return x
         z = EncoderFunction.apply(x, *self._flat_params())
         return z.permute(0, 2, 1)
 
 
 class CPCAR(nn.Module):
-    """cpc/model.py:155-204.  baseNet is a torch.nn.GRU used as the parameter container
-    (same keys / gate layout); forward runs cpc_gru_forward (HIP)."""
+    """cpc/model.py:155-204.  For the GRU of the north-star configuration (256 -> 256) baseNet is a torch.nn.GRU used as the
+    parameter container (same keys / gate layout) and forward runs cpc_gru_forward (HIP, ``self.hip``).  The reference's other
+    autoregressors -- ``LSTM`` (its argparse default, cpc_default_config.py:74), ``RNN``, other widths -- run through baseNet's
+    own torch forward: same semantics incl. the carried hidden state, any device, not the hot path."""
 
     def __init__(self, dimEncoded, dimOutput, keepHidden, nLevelsGRU, mode="GRU", reverse=False):
         super().__init__()
         self.RESIDUAL_STD = 0.1
-        if mode in ("LSTM", "RNN"):
-            raise NotImplementedError(f"arMode={mode!r}: the HIP autoregressor implements the GRU "
-                                      "(the north-star configuration, --arMode GRU)")
-        if dimEncoded != 256 or dimOutput != 256:
-            raise NotImplementedError("the HIP GRU is built for hiddenEncoder == hiddenGar == 256")
-        self.baseNet = nn.GRU(dimEncoded, dimOutput, num_layers=nLevelsGRU, batch_first=True)
+        self.hip = mode not in ("LSTM", "RNN") and dimEncoded == 256 and dimOutput == 256
+        cell = nn.LSTM if mode == "LSTM" else (nn.RNN if mode == "RNN" else nn.GRU)
+        self.baseNet = cell(dimEncoded, dimOutput, num_layers=nLevelsGRU, batch_first=True)
         self.hidden = None
         self.keepHidden = keepHidden
         self.reverse = reverse
@@ -114,6 +132,11 @@ class CPCAR(nn.Module):
         """(B, S, 256) -> (B, S, 256).  In reverse mode the sequence is processed back to front and handed back in its
         original order (cpc/model.py:185-204); the final hidden state is kept for the next call when keepHidden is set."""
         flip = (lambda t: torch.flip(t, [1])) if self.reverse else (lambda t: t)
+        if not self.hip:                                       # cpc/model.py:185-204 with baseNet's own torch forward
+            y, h = self.baseNet(flip(x), self.hidden)
+            if self.keepHidden:
+                self.hidden = tuple(t.detach() for t in h) if isinstance(h, tuple) else h.detach()
+            return flip(y)
         # |h_t| <= 1 holds when the recurrence starts from zero or from one of its OWN final states (a convex combination of
         # tanh outputs and the previous state); a state assigned from outside carries no such bound
         bounded = self.hidden is None or self.hidden is getattr(self, "_own_hidden", None)

@@ -128,6 +128,8 @@ class CompositeStep:
                     or getattr(mod, "parametrizations", None)):
                 return False
         ar = m.gAR
+        if not (m.gEncoder.hip and ar.hip):                # (options served by torch ops: model.CPCEncoder / CPCAR)
+            return False
         if ar.reverse or ar.baseNet.num_layers != 2 or cr.mode is not None or cr.wPrediction.scores_apart:
             return False
         if negatives is not None and not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int64 for t in negatives):

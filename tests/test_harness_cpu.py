@@ -187,3 +187,45 @@ def test_transformer_submodules_run_stand_alone_and_long_layers_match_the_oracle
     a = layer.multihead.Att(q, q, q)
     # causal: step 0 attends to itself only
     assert torch.allclose(a[:, 0], q[:, 0], atol=1e-6)
+
+
+def test_reference_options_outside_the_hip_geometry_run_on_the_modules_own_torch_ops():
+    """cpc/model.py:73-80 (normMode batchNorm / instanceNorm / ID, any width) and :168-176 (arMode LSTM -- the reference's argparse
+    default -- / RNN): constructed with the reference's signatures, the reference's state-dict keys, and served by torch ops on
+    any device (``.hip`` is False; the HIP kernels cover the 256-channel ChannelNorm encoder and the 256 -> 256 GRU).  The
+    layerNorm encoder at another width is checked against the oracle; the LSTM carries its (h, c) state like the reference."""
+    import torch
+    from cpc_audio_amd.model import CPCAR, CPCEncoder, CPCModel
+    from oracle import cpc_oracle as O
+    torch.manual_seed(0)
+    wave = O.make_waveform(2, 3200, seed=3)
+    for mode in ("batchNorm", "instanceNorm", "ID", "layerNorm"):
+        enc = CPCEncoder(64, mode)
+        assert not enc.hip and enc.getDimOutput() == 64 and enc.DOWNSAMPLING == 160
+        y = enc(wave)
+        assert y.shape == (2, 64, 20) and torch.isfinite(y).all() and (y >= 0).all()
+        keys = set(enc.state_dict())
+        assert {f"conv{i}.weight" for i in range(5)} <= keys and {f"conv{i}.bias" for i in range(5)} <= keys
+        if mode == "layerNorm":
+            assert enc.state_dict()["batchNorm3.weight"].shape == (1, 64, 1)
+            p = {f"gEncoder.{k}": v for k, v in enc.state_dict().items()}
+            assert (y - O.encoder_forward(p, wave)).abs().max().item() < 1e-5
+    assert CPCEncoder(256, "layerNorm").hip and not CPCEncoder(256, "batchNorm").hip and not CPCEncoder(512).hip
+    x = torch.randn(2, 20, 64)
+    for mode, cell in (("LSTM", torch.nn.LSTM), ("RNN", torch.nn.RNN), ("GRU", torch.nn.GRU)):
+        ar = CPCAR(64, 32, True, 2, mode=mode, reverse=(mode == "RNN"))
+        assert not ar.hip and isinstance(ar.baseNet, cell) and ar.getDimOutput() == 32
+        c1 = ar(x)
+        assert c1.shape == (2, 20, 32)
+        h = ar.hidden
+        assert (isinstance(h, tuple) and len(h) == 2 and not h[0].requires_grad) if mode == "LSTM" else not h.requires_grad
+        c2 = ar(x)                                          # starts from the carried state: differs from the first call
+        assert not torch.allclose(c1, c2)
+        ref = cell(64, 32, num_layers=2, batch_first=True)
+        ref.load_state_dict(ar.baseNet.state_dict())
+        xin = torch.flip(x, [1]) if mode == "RNN" else x
+        want, _ = ref(xin)
+        assert torch.allclose(c1, torch.flip(want, [1]) if mode == "RNN" else want, atol=1e-6)
+    assert CPCAR(256, 256, False, 2).hip and not CPCAR(256, 256, False, 2, mode="LSTM").hip
+    c, z, _ = CPCModel(CPCEncoder(64, "ID"), CPCAR(64, 64, False, 1, mode="LSTM"))(wave, None)
+    assert c.shape == z.shape == (2, 20, 64)
