@@ -115,6 +115,7 @@ SIGNATURES = {
     "cpc_nce_backward_dz": (_I, [_P] * 7 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward_dwall": (_I, [_P] * 4 + [_I, _I, _I, _I, _P]),
     "cpc_set_nce_fused": (_I, [_I]),
+    "cpc_nce_padded_negatives": (_I, [_I]),
     "cpc_set_step_schedule": (_I, [_I, _I]),
     "cpc_train_step_layout": (_I, [_I, _I, _I, _I, _P]),
     "cpc_train_step_prefetch": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

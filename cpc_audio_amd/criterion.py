@@ -183,8 +183,7 @@ class CPCUnsupersivedCriterion(BaseCriterion):
                                              transformerDropout=transformerDropout)
         self.nPredicts = nPredicts
         self.negativeSamplingExt = negativeSamplingExt
-        if negativeSamplingExt % 16 != 0:
-            raise NotImplementedError("negativeSamplingExt must be a multiple of 16 (MFMA tile width)")
+        # (any number: the kernels walk candidates in 16-wide tiles and mask the padding of the last one, ops.prepare_negatives)
         self.lossCriterion = nn.CrossEntropyLoss()   # kept for API parity; the fused kernel computes it
         if mode not in [None, "reverse"]:
             raise ValueError("Invalid mode")
@@ -287,12 +286,12 @@ class CPCUnsupersivedCriterion(BaseCriterion):
                                                    self.negativeSamplingExt)
         if self.wPrediction.scores_apart:
             pred = self.wPrediction.predictions(cFeature[:, :windowSize].contiguous())
-            losses, acc = InfoNCEScoresFunction.apply(pred, encodedData, ext, perm, row_ptr)
+            losses, acc = InfoNCEScoresFunction.apply(pred, encodedData, ext, perm, row_ptr, self.negativeSamplingExt)
         else:
             heads = [p.weight for p in self.wPrediction.predictors]
             # dz may be filled late (on the side stream) only if nobody outside this package can read it first: not in
             # mode 'reverse' (the flip above sits between the criterion and the encoder), not behind a foreign network
             defer = step is not None and step.overlap and ops.dz_may_be_deferred(cFeature, encodedData)
             losses, acc = InfoNCEFunction.apply(cFeature, encodedData, self.wPrediction.stacked_weight(), ext, perm,
-                                                row_ptr, heads, defer, saved)
+                                                row_ptr, heads, defer, saved, self.negativeSamplingExt)
         return losses.view(1, -1), acc.view(1, -1)

@@ -74,7 +74,7 @@ struct Gather16 {
 __global__ __launch_bounds__(256, 3) void nce_fwd_kernel(
     const float* __restrict__ pred, const float* __restrict__ z, const int* __restrict__ ext,
     float* __restrict__ logits, float* __restrict__ lse_out, float* __restrict__ rowstat, int BW, int W,
-    int S, int K, int N, unsigned* __restrict__ ticket) {
+    int S, int K, int N, unsigned* __restrict__ ticket, int Nv) {
     __shared__ float4 tiles[4][256];
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -143,11 +143,11 @@ __global__ __launch_bounds__(256, 3) void nce_fwd_kernel(
         for (int q = 0; q < 4; ++q) rowp[q] = z + (long)ext[(long)bt * N + nt * 16 + 4 * q + kq] * kC + 4 * i;
         gt.issue(rowp);
         const f32x4 acc = score_tile();
-        // acc[r] = score of head i against negative nt*16 + 4 kq + r
+        // acc[r] = score of head i against negative nt*16 + 4 kq + r (padding candidates -- index >= Nv -- weigh nothing)
         float l[4], lmax = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            l[r] = acc[r] * inv;
+            l[r] = nt * 16 + 4 * kq + r < Nv ? acc[r] * inv : -3.0e38f;
             if (hv) logits[((long)bt * K + i) * (N + 1) + 1 + nt * 16 + 4 * kq + r] = l[r];
             lmax = fmaxf(lmax, l[r]);
         }
@@ -218,7 +218,8 @@ struct Gather16R {                                      // Gather16 with lane gr
 __global__ __launch_bounds__(256, 2) void nce_fwd_fused_kernel(
     const float* __restrict__ pred, const float* __restrict__ z, const int* __restrict__ ext,
     float* __restrict__ logits, float* __restrict__ lse_out, float* __restrict__ rowstat, float* __restrict__ tpred,
-    float* __restrict__ tamax, float* __restrict__ ps, int BW, int W, int S, int K, int N, unsigned* __restrict__ ticket) {
+    float* __restrict__ tamax, float* __restrict__ ps, int BW, int W, int S, int K, int N, unsigned* __restrict__ ticket,
+    int Nv) {
     __shared__ float4 tiles[4][256];
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -286,11 +287,11 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_fused_kernel(
         for (int q = 0; q < 4; ++q) rowp[q] = z + (long)ext[(long)bt * N + nt * 16 + 4 * kq + q] * kC + 4 * i;
         gt.issue(rowp);
         const f32x4 acc = score_tile();
-        // acc[r] = score of head i against negative nt*16 + 4 kq + r
+        // acc[r] = score of head i against negative nt*16 + 4 kq + r (padding candidates -- index >= Nv -- weigh nothing)
         float l[4], lmax = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            l[r] = acc[r] * inv;
+            l[r] = nt * 16 + 4 * kq + r < Nv ? acc[r] * inv : -3.0e38f;
             if (hv) logits[((long)bt * K + i) * (N + 1) + 1 + nt * 16 + 4 * kq + r] = l[r];
             lmax = fmaxf(lmax, l[r]);
         }
@@ -800,13 +801,17 @@ static __device__ unsigned g_nce_bad_index = 0;
 // lists in step, gather from a narrow band of z at any moment: it stays in the 4 MB L2 of an XCD instead of coming from
 // Infinity Cache (measured at B = 64: scoring kernel 130 -> 116 us, its backward twin 185 -> 153 us).
 constexpr int kSortMax = 1024;       // negatives per window that are sorted (more: left in draw order)
+// N: negatives per window as drawn; Np >= N: the row pitch of ext -- entries N .. Np-1 are padding (row b*S + t, a valid row; the
+// scoring kernels mask them by POSITION, so the sort below covers the drawn negatives only).
 __global__ __launch_bounds__(256) void nce_rows_kernel(const long* __restrict__ batchIdx, const long* __restrict__ seqIdx,
-                                                       int* __restrict__ ext, int B, int S, int W, int N) {
+                                                       int* __restrict__ ext_, int B, int S, int W, int N, int Np) {
     __shared__ int rows[4][kSortMax];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int bt = blockIdx.x * 4 + wv;
     if (bt >= B * W) return;                             // whole wave
     const int b = bt / W, t = bt - b * W;
+    int* __restrict__ ext = ext_ + (long)bt * (Np - N);  // (rows below are addressed with pitch N: shift by the padding so far)
+    for (int j = N + lane; j < Np; j += 64) ext[(long)bt * N + j] = b * S + t;
     const bool sort = N <= kSortMax;
     for (int j = lane; j < N; j += 64) {
         const long flat = ((long)b * N + j) * W + t;
@@ -890,6 +895,9 @@ int g_nce_fused = 1;       // cpc_set_nce_fused: 1 (default) the one-pass criter
 
 struct NceLayout {
     int W, BW;
+    int N, Nv;      // negatives per window as the kernels walk them (a multiple of 16) / as drawn (criterion.py:176-189): the
+                    // candidates Nv .. N-1 of every window are padding -- a valid row of z, their logit forced to -3e38, so that
+                    // they weigh exactly 0 in the softmax, the arg-max and every gradient
     long pred, logits, lse, bounds, tpred, ps, saved_total;
     long rowstat, tmp, sums, fwd_total;
     long dpred, wallT, part, gscale, V, dS, G, wcat, part_dz, bwd_total;
@@ -898,7 +906,10 @@ struct NceLayout {
 constexpr int kDzSplits = 4;      // K-walk splits the dz GEMM's partial buffer is sized for (SplitK)
 
 static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
-    if (B <= 0 || K <= 0 || K > 16 || S <= K || N <= 0 || N % 16 != 0) return false;
+    if (B <= 0 || K <= 0 || K > 16 || S <= K || N <= 0) return false;
+    n.Nv = N;
+    N = (N + 15) & ~15;                      // (every size below in padded candidates)
+    n.N = N;
     n.W = S - K;
     n.BW = B * n.W;
     long o = 0;
@@ -962,10 +973,10 @@ static int nce_scores_forward(const NceLayout& n, const float* pred, const float
     if (fused)
         hipLaunchKernelGGL(nce_fwd_fused_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
                            saved + n.lse, scratch + n.rowstat, saved + n.tpred, saved + n.bounds + 2 * kAmaxSlots, saved + n.ps,
-                           n.BW, n.W, S, K, N, ticket);
+                           n.BW, n.W, S, K, N, ticket, n.Nv);
     else
     hipLaunchKernelGGL(nce_fwd_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
-                       saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket);
+                       saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket, n.Nv);
     step_timer_mark(9, st);
     CPC_LAUNCH_CHECK();
     if (fin != nullptr && fin != st) {
@@ -1062,10 +1073,15 @@ using namespace cpc;
 extern "C" int cpc_nce_layout(int B, int S, int K, int N, long* sizes) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    N = n.N;                                 // (padded; n.Nv = as drawn)
     sizes[0] = n.saved_total; sizes[1] = n.fwd_total; sizes[2] = n.bwd_total;
     sizes[3] = n.pred; sizes[4] = n.logits; sizes[5] = n.lse;
     return 0;
 }
+
+// Negatives per window as the kernels lay them out: N rounded up to the MFMA tile (16).  ext is (B*W, padded), logits
+// (B*W, K, 1 + padded), the slot lists count padded + K candidates per window; callers size their buffers with it.
+extern "C" int cpc_nce_padded_negatives(int N) { return N <= 0 ? 0 : (N + 15) & ~15; }
 
 // batchIdx, seqIdx: the two int64 draws of sampleClean, B*N*W each, flat in (b,n,t) order.
 // Outputs: ext (B*W*N int32: the rows of each window's negatives, ASCENDING -- see nce_rows_kernel), perm (B*W*(N+K) int32),
@@ -1074,6 +1090,7 @@ extern "C" int cpc_nce_prepare(const long* batchIdx, const long* seqIdx, int* ex
                                int* work, int B, int S, int K, int N, void* stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!batchIdx || !seqIdx || !ext || !perm || !row_ptr || !work, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)n.BW * (N + K);
@@ -1082,7 +1099,7 @@ extern "C" int cpc_nce_prepare(const long* batchIdx, const long* seqIdx, int* ex
     int* count = work + total;
     int* cursor = count + rows + 1;
     (void)hipMemsetAsync(count, 0, sizeof(int) * (rows + 1), st);
-    hipLaunchKernelGGL(nce_rows_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, batchIdx, seqIdx, ext, B, S, n.W, N);
+    hipLaunchKernelGGL(nce_rows_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, batchIdx, seqIdx, ext, B, S, n.W, n.Nv, N);
     hipLaunchKernelGGL(nce_index_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ext, dest, count, B, S, n.W, K, N);
     hipLaunchKernelGGL(nce_scan_kernel, dim3(1), dim3(1024), 0, st, count, row_ptr, cursor, rows);
     hipLaunchKernelGGL(nce_fill_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dest, cursor, perm, total);
@@ -1098,6 +1115,7 @@ static int nce_forward(const float* c, const float* z, const float* wall, const 
                        hipStream_t fin = nullptr) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!c || !z || !wall || !ext || !saved || !scratch || !losses || !acc, CPC_ERR_ARG);
     float* pred = saved + n.pred;
     // operand bounds for the fp16-split GEMMs of this call and of the backward (one small launch: 11 MB read)
@@ -1131,6 +1149,7 @@ extern "C" int cpc_nce_bounds(const float* c, float c_bound, const float* wall, 
                               void* stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!wall || !saved || (!(c_bound > 0.f) && !c), CPC_ERR_ARG);
     const float* xs[3] = {c_bound > 0.f ? nullptr : c, wall, nullptr};
     const long ns[3] = {(long)B * S * kC, (long)K * kC * kC, 0};
@@ -1160,6 +1179,7 @@ extern "C" int cpc_nce_backward_prepare(const float* wall, const float* saved, c
                                         int B, int S, int K, int N, void* stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!wall || !saved || !gloss || !scratch || !dc, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     const bool h2 = g_mfma_mode >= 2;
@@ -1175,6 +1195,7 @@ extern "C" int cpc_nce_scores_forward(const float* pred, const float* z, const i
                                       float* losses, float* acc, int B, int S, int K, int N, void* stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!pred || !z || !ext || !saved || !scratch || !losses || !acc, CPC_ERR_ARG);
     return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, (hipStream_t)stream);
 }
@@ -1185,6 +1206,7 @@ extern "C" int cpc_nce_scores_backward(const float* pred, const float* z, const 
                                        float* dpred, float* dz, int B, int S, int K, int N, void* stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!pred || !z || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dpred || !dz, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     int rc = nce_scores_backward(n, z, ext, saved, gloss, scratch, dpred, B, S, K, N, st);
@@ -1211,6 +1233,7 @@ extern "C" int cpc_nce_backward_dz(const float* c, const float* wall, const int*
                                    float* scratch, float* dz, int B, int S, int K, int N, void* stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!c || !wall || !perm || !row_ptr || !saved || !scratch || !dz, CPC_ERR_ARG);
     return nce_dz_linear_path(n, c, wall, perm, row_ptr, scratch, dz, B, S, K, N, (hipStream_t)stream,
                               nce_fused(N) ? saved : nullptr);
@@ -1240,6 +1263,7 @@ static int nce_backward_impl(const float* c, const float* z, const float* wall, 
                              float* dwall, int B, int S, int K, int N, void* stream, void* dz_stream, bool prepared) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream, st_dz = (hipStream_t)dz_stream;
     const bool fused = nce_fused(N);         // the forward left T (unit-gradient dPred) and max|T| in `saved`: no score-gradient pass
@@ -1293,6 +1317,7 @@ extern "C" int cpc_nce_backward_dwall(const float* c, const float* saved, float*
                                       int N, void* stream) {
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!c || !saved || !scratch || !dwall, CPC_ERR_ARG);
     const bool fused = nce_fused(N);
     GemmBounds gdw;                                               // left by cpc_nce_backward_streams (nce_gscale_kernel)

@@ -44,13 +44,14 @@ bool step_layout(int B, int L, int K, int N, StepLayout& s) {
     if (s.W <= 0 || cpc_gru_layout(B, s.S, 2, s.gru) != 0 || cpc_nce_layout(B, s.S, K, N, s.nce) != 0) return false;
     s.coef = cpc_gru_coef_floats(B, s.S, 2);
     if (s.coef <= 0) return false;
-    const long act = (long)B * s.S * kC, slots = (long)B * s.W * (N + K), rows = (long)B * s.S;
+    const int Np = cpc_nce_padded_negatives(N);      // candidates per window as the criterion's kernels lay them out
+    const long act = (long)B * s.S * kC, slots = (long)B * s.W * (Np + K), rows = (long)B * s.S;
     long o = 0;
     auto take = [&](long n) { const long at = o; o += align64l(n); return at; };
     s.enc_saved = take(s.enc[0]); s.enc_fscr = take(std::max(1L, s.enc[1])); s.z = take(act);
     s.gru_saved = take(s.gru[0]); s.gru_fscr = take(s.gru[1]); s.c = take(act); s.gcoef = take(s.coef);
     s.nce_saved = take(s.nce[0]); s.nce_fscr = take(s.nce[1]);
-    s.ext = take((long)B * s.W * N); s.perm = take(slots); s.row_ptr = take(rows + 1); s.work = take(slots + 2 * rows + 2);
+    s.ext = take((long)B * s.W * Np); s.perm = take(slots); s.row_ptr = take(rows + 1); s.work = take(slots + 2 * rows + 2);
     s.nce_bscr = take(s.nce[2]); s.dc = take(act); s.dz = take(act);
     s.gru_bscr = take(s.gru[2]); s.dx = take(act); s.enc_bscr = take(s.enc[2]);
     s.total = o;

@@ -462,18 +462,21 @@ def candidate_destinations(ext, B, S, K):
 
 
 def prepare_negatives(batchIdx, seqIdx, B, S, K, N):
-    """(ext (B,W,N), perm, row_ptr) int32 from the two int64 draws of sampleClean -- cpc_nce_prepare."""
+    """(ext (B,W,Np), perm, row_ptr) int32 from the two int64 draws of sampleClean -- cpc_nce_prepare.  Np = N rounded up to the
+    kernels' 16-wide candidate tile (cpc_nce_padded_negatives): the padding entries are masked by position in the scoring
+    kernels, so every call that takes these lists is also told N."""
     lib = _lib.get()
     W = S - K
+    Np = int(lib.cpc_nce_padded_negatives(N))
     dev = batchIdx.device
     batchIdx, seqIdx = batchIdx.contiguous(), seqIdx.contiguous()
     if batchIdx.dtype != torch.int64 or seqIdx.dtype != torch.int64 or batchIdx.numel() != B * N * W:
         raise ValueError("prepare_negatives: expected two int64 tensors of B*N*W draws")
     with torch.cuda.device(dev):
-        ext = torch.empty(B, W, N, device=dev, dtype=torch.int32)
-        perm = torch.empty(B * W * (N + K), device=dev, dtype=torch.int32)
+        ext = torch.empty(B, W, Np, device=dev, dtype=torch.int32)
+        perm = torch.empty(B * W * (Np + K), device=dev, dtype=torch.int32)
         row_ptr = torch.empty(B * S + 1, device=dev, dtype=torch.int32)
-        work = torch.empty(B * W * (N + K) + 2 * B * S + 2, device=dev, dtype=torch.int32)
+        work = torch.empty(B * W * (Np + K) + 2 * B * S + 2, device=dev, dtype=torch.int32)
         lib.check(lib.cpc_nce_prepare(_p(batchIdx), _p(seqIdx), _p(ext), _p(perm), _p(row_ptr), _p(work), B, S, K, N,
                                       _stream()), "nce_prepare")
     return ext, perm, row_ptr
@@ -486,13 +489,18 @@ class InfoNCEFunction(torch.autograd.Function):
     (bit-identical values; ``wall`` itself receives no gradient), which takes that GEMM off the path to the encoder."""
 
     @staticmethod
-    def forward(ctx, c, z, wall, ext, perm, row_ptr, heads=None, defer_dz=False, saved=None):
-        """saved: optionally the workspace of this call with the GEMM operand bounds already in it (nce_bounds_into)."""
+    def forward(ctx, c, z, wall, ext, perm, row_ptr, heads=None, defer_dz=False, saved=None, n_valid=None):
+        """saved: optionally the workspace of this call with the GEMM operand bounds already in it (nce_bounds_into).
+        n_valid: negatives per window as drawn when ext's rows are padded to the 16-wide tile (prepare_negatives)."""
         _require_cuda(c, "InfoNCEFunction")
         lib = _lib.get()
         B, S, H = c.shape
         K = wall.shape[0] // _HID
         W, N = ext.shape[1], ext.shape[2]
+        if n_valid is not None:
+            if int(lib.cpc_nce_padded_negatives(int(n_valid))) != N:
+                raise ValueError("InfoNCEFunction: ext is not padded for n_valid negatives")
+            N = int(n_valid)
         if H != _HID or z.shape != (B, S, _HID) or W != S - K or ext.dtype != torch.int32:
             raise ValueError("InfoNCEFunction: inconsistent shapes")
         c, z, wall, ext = c.contiguous(), z.contiguous(), wall.detach().contiguous(), ext.contiguous()
@@ -584,7 +592,7 @@ class InfoNCEFunction(torch.autograd.Function):
                 lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
                                                _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
                                                _stream()), "nce_backward")
-        return dc, dz, dwall, None, None, None, None, None, None
+        return dc, dz, dwall, None, None, None, None, None, None, None
 
 
 def nce_bounds_into(wall, c_bound, B, S, K, N):
@@ -603,11 +611,15 @@ class InfoNCEScoresFunction(torch.autograd.Function):
     """pred (B,W,K*256) from any prediction network, z (B,S,256), ext, perm, row_ptr -> losses (K), acc (K)."""
 
     @staticmethod
-    def forward(ctx, pred, z, ext, perm, row_ptr):
+    def forward(ctx, pred, z, ext, perm, row_ptr, n_valid=None):
         _require_cuda(pred, "InfoNCEScoresFunction")
         lib = _lib.get()
         B, S, H = z.shape
         W, N = ext.shape[1], ext.shape[2]
+        if n_valid is not None:                       # (ext rows padded to the 16-wide tile: prepare_negatives)
+            if int(lib.cpc_nce_padded_negatives(int(n_valid))) != N:
+                raise ValueError("InfoNCEScoresFunction: ext is not padded for n_valid negatives")
+            N = int(n_valid)
         K = S - W
         if H != _HID or pred.shape != (B, W, K * _HID) or ext.dtype != torch.int32:
             raise ValueError("InfoNCEScoresFunction: inconsistent shapes")
@@ -638,7 +650,7 @@ class InfoNCEScoresFunction(torch.autograd.Function):
             lib.check(lib.cpc_nce_scores_backward(_p(pred), _p(z), _p(ext), _p(perm), _p(row_ptr), _p(saved), _p(gloss),
                                                   _p(scratch), _p(dpred), _p(dz), B, S, K, N, _stream()),
                       "nce_scores_backward")
-        return dpred, dz, None, None, None
+        return dpred, dz, None, None, None, None
 
 
 class TransformerGroupFunction(torch.autograd.Function):

@@ -335,6 +335,11 @@ int cpc_dropout_keep_mask(float* out, long n, int site, int S, float p, unsigned
  * K <= 16, N % 16 == 0.  sizes[0..2] = saved / fwd-scratch / bwd-scratch floats,
  * sizes[3..5] = offsets of pred, logits (B*W,K,1+N), lse (B*W,K) inside `saved`. */
 int cpc_nce_layout(int B, int S, int K, int N, long* sizes);
+/* Negatives per window as the kernels lay them out: N (criterion.py:176-189 draws any number) rounded up to the 16-wide MFMA
+ * tile.  The padding candidates are valid rows whose logits the scoring kernels force to -3e38: weight 0 in the softmax, the
+ * arg-max and every gradient.  ext is (B*W, padded) int32, logits (B*W, K, 1 + padded), perm / work count padded + K candidates
+ * per window; the draws (batchIdx / seqIdx) stay B*N*W. */
+int cpc_nce_padded_negatives(int N);
 /* Index preparation: the two int64 draws of sampleClean (criterion.py:181-189; B*N*W each, flat (b,n,t)
  * order) -> ext (the rows of criterion.py:191-199, laid out (b,t,n) with the N rows of a window in ASCENDING order: the
  * criterion is invariant under a permutation of a window's negatives, and sorted lists keep the gathers of the scoring

@@ -33,7 +33,9 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert bound.cpc_encoder_layout(0, 20480, sizes) == 1          # CPC_ERR_SHAPE
     assert bound.cpc_encoder_layout(2, 20480, sizes) == 0 and sizes[7] == 128
     assert bound.cpc_nce_layout(2, 128, 17, 128, sizes) == 1        # K > 16
-    assert bound.cpc_nce_layout(2, 128, 12, 100, sizes) == 1        # N % 16
+    assert bound.cpc_nce_layout(2, 128, 12, 100, sizes) == 0        # (N % 16 != 0: candidate tiles padded and masked)
+    assert bound.cpc_nce_padded_negatives(100) == 112 and bound.cpc_nce_padded_negatives(128) == 128
+    assert bound.cpc_nce_layout(2, 128, 12, 0, sizes) == 1          # no negatives
     assert bound.cpc_set_conv_tile(48) == 2                         # CPC_ERR_ARG
 
 

@@ -172,3 +172,55 @@ def test_nce_scores_of_foreign_predictions_emulated(B, S, K, N):
                                        P(dz), B, S, K, N, None) == 0
     assert rel_err(dpred, pred.grad) < 1e-5
     assert rel_err(dz, zr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,S,K,N,fused", [(2, 20, 12, 24, 1), (2, 19, 5, 40, 1), (2, 20, 12, 24, 0), (1, 18, 3, 7, 1)])
+def test_negatives_not_a_multiple_of_16_emulated(B, S, K, N, fused):
+    """criterion.py:176-189 draws any number of negatives; the kernels walk candidates in 16-wide MFMA tiles.  The lists are padded
+    to the tile (cpc_nce_padded_negatives; padding = a valid row of z) and the scoring kernels force the padding's logits to -3e38:
+    weight 0 in the softmax, the arg-max and every gradient.  Whole criterion against the oracle with exactly N negatives."""
+    lib = emu()
+    assert lib.cpc_set_nce_fused(fused) == 0
+    try:
+        torch.manual_seed(3)
+        W = S - K
+        Np = lib.cpc_nce_padded_negatives(N)
+        assert Np % 16 == 0 and 0 <= Np - N < 16
+        p = O.make_params(seed=5, n_predicts=K, head_scale=20.0)
+        heads = O.head_weights(p, K)
+        wall = torch.cat(heads, dim=0).contiguous()
+        c = torch.tanh(torch.randn(B, S, 256))
+        z = torch.relu(torch.randn(B, S, 256))
+        g = torch.Generator().manual_seed(11)
+        bi, si = O.draw_negative_indices(B, S, W, N, generator=g)
+        ext_ref = O.negative_rows(bi, si, B, S, W, N)                   # (B, N, W)
+        ext = torch.full((B, W, Np), -1, dtype=torch.int32)
+        perm = torch.full((B * W * (Np + K),), -1, dtype=torch.int32)
+        row_ptr = torch.full((B * S + 1,), -1, dtype=torch.int32)
+        work = torch.zeros(B * W * (Np + K) + 2 * B * S + 2, dtype=torch.int32)
+        assert lib.cpc_nce_prepare(P(bi), P(si), P(ext), P(perm), P(row_ptr), P(work), B, S, K, N, None) == 0
+        assert torch.equal(ext[:, :, :N], torch.sort(ext_ref.permute(0, 2, 1).to(torch.int32), dim=2).values)
+        assert (ext[:, :, N:] >= 0).all() and (ext[:, :, N:] < B * S).all()
+        sizes = (ctypes.c_long * 6)()
+        assert lib.cpc_nce_layout(B, S, K, N, sizes) == 0
+        saved = torch.full((sizes[0],), float("nan"))
+        fscr = torch.full((sizes[1],), float("nan"))
+        losses = torch.full((K,), float("nan")); acc = torch.full((K,), float("nan"))
+        assert lib.cpc_nce_forward(P(c), P(z), P(wall), P(ext), P(saved), P(fscr), P(losses), P(acc), B, S, K, N, None) == 0
+        leaves = {f"wPrediction.predictors.{k}.weight": heads[k].clone().requires_grad_(True) for k in range(K)}
+        cr = c.clone().requires_grad_(True); zr = z.clone().requires_grad_(True)
+        lr, ar = O.criterion_forward(leaves, cr, zr, ext_ref, K)
+        assert (losses - lr[0]).abs().max().item() < 1e-5 * max(1.0, lr[0].abs().max().item())
+        assert (acc - ar[0]).abs().max().item() < 1e-6
+        gl = torch.randn(K)
+        (lr[0] * gl).sum().backward()
+        bscr = torch.full((sizes[2],), float("nan"))
+        dc = torch.full((B, S, 256), float("nan")); dz = torch.full((B, S, 256), float("nan"))
+        dwall = torch.full((K * 256, 256), float("nan"))
+        assert lib.cpc_nce_backward(P(c), P(z), P(wall), P(ext), P(perm), P(row_ptr), P(saved), P(gl), P(bscr), P(dc), P(dz),
+                                    P(dwall), B, S, K, N, None) == 0
+        assert rel_err(dc, cr.grad) < 1e-5 and rel_err(dz, zr.grad) < 1e-5
+        ref_dw = torch.cat([leaves[f"wPrediction.predictors.{k}.weight"].grad for k in range(K)], dim=0)
+        assert rel_err(dwall, ref_dw) < 1e-5
+    finally:
+        lib.cpc_set_nce_fused(1)

@@ -152,7 +152,8 @@ def test_composite_step_argument_errors():
     lib = emu()
     sizes = (ctypes.c_long * 8)()
     assert lib.cpc_train_step_layout(0, 3200, 4, 16, sizes) == 1              # CPC_ERR_SHAPE
-    assert lib.cpc_train_step_layout(2, 3200, 4, 10, sizes) == 1              # N % 16
+    assert lib.cpc_train_step_layout(2, 3200, 4, 10, sizes) == 0              # (N % 16 != 0: padded tiles since round 5)
+    assert lib.cpc_train_step_layout(2, 3200, 4, 0, sizes) == 1               # no negatives
     assert lib.cpc_train_step_layout(2, 1600, 12, 16, sizes) == 1             # S = 10 <= K
     assert lib.cpc_set_step_schedule(4, 0) == 2 and lib.cpc_set_step_schedule(0, 8) == 2
     assert lib.cpc_train_step(None, None, None, None, 1.0, None, None, None, None, None, None, None, 2, 3200, 4, 16, 3,

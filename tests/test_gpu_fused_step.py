@@ -271,3 +271,49 @@ def test_open_tailed_steps_in_the_bf16_storage_variant_and_across_a_mode_switch(
     assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0])
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+def test_whole_step_with_100_negatives_matches_the_oracle_on_both_step_paths():
+    """negativeSamplingExt = 100 (criterion.py:176-189 draws any number; not a multiple of the kernels' 16-wide candidate tile):
+    the lists are padded to 112 and the padding masked by the scoring kernels.  First step against the oracle run with exactly
+    100 negatives (losses, accuracies, every gradient), composite and autograd paths bit-identical over three steps."""
+    dev = _dev()
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
+    B, N, steps = 3, 100, 3
+    p = O.make_params(seed=39, head_scale=64.0)
+    wave = O.make_waveform(B, 20480, seed=111)
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    g = torch.Generator().manual_seed(23)
+    draws = [O.draw_negative_indices(B, 128, 116, N, generator=g) for _ in range(steps)]
+    ora = O.train_step(p, wave, draws[0][0], draws[0][1], n_neg=N)
+    res = []
+    for fused in (False, True):
+        model, crit = build_model().to(dev), build_criterion(negativeSamplingExt=N).to(dev)
+        load_flat_params(model, crit, p)
+        tr = Trainer(model, crit, fused=fused)
+        opt_step, tr.optimizer.step = tr.optimizer.step, (lambda *a, **k: None)       # keep the gradients of step 0
+        zero, tr.optimizer.zero_grad = tr.optimizer.zero_grad, (lambda *a, **k: None)
+        l, a = tr.step(wave.to(dev), label, negatives=(draws[0][0].to(dev), draws[0][1].to(dev)))
+        torch.cuda.synchronize()
+        assert (tr._fused is not None) == fused
+        assert (l.cpu() - ora["losses"]).abs().max().item() < 1e-4
+        assert (a.cpu() - ora["acc"]).abs().max().item() < 1.5 / (B * 116)
+        named = dict(model.state_dict(keep_vars=True))
+        named.update(crit.state_dict(keep_vars=True))
+        bad = {}
+        for k, ref in ora["grads"].items():
+            rel = ((named[k].grad.cpu() - ref).norm() / (ref.norm() + 1e-30)).item()
+            if not rel < (5e-3 if k.startswith("gEncoder") else 2e-4):
+                bad[k] = rel
+        assert not bad, (fused, bad)
+        tr.optimizer.step, tr.optimizer.zero_grad = opt_step, zero
+        tr.optimizer.zero_grad()
+        losses = []
+        for i in range(steps):
+            l, a = tr.step(wave.to(dev), label, negatives=(draws[i][0].to(dev), draws[i][1].to(dev)))
+            losses.append(torch.cat([l, a]).cpu())
+        torch.cuda.synchronize()
+        res.append((torch.stack(losses), _state(model, crit)))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
