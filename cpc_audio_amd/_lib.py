@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcpc_hip.so")
 DEFAULT_GRU_MODE = 2       # cpc_set_gru_mode: persistent recurrence, forward products on the fp16 split
 DEFAULT_MFMA_MODE = 3      # what libcpc_hip starts in (cpc_set_mfma_mode): mode 2's arithmetic (two fp16 pieces, 3 MFMAs per
 #                            product) with conv1 / its gradients on the DMA-fed kernels reading H2-stored activations
-EXPECTED_ABI = 14          # cpc_abi_version() of the library these signatures were written for: a stale or variant build that
+EXPECTED_ABI = 15          # cpc_abi_version() of the library these signatures were written for: a stale or variant build that
 #                            exports every symbol with OLDER argument lists would corrupt memory instead of raising -- bind() refuses it
 DEFAULT_DMA_PIPELINE = 2       # cpc_set_dma_pipeline: the tap-pair walk where the shape allows, two 32-k stages elsewhere
 DEFAULT_WGRAD_DMA_STAGES = 4   # cpc_set_wgrad_dma_stages
@@ -116,6 +116,7 @@ SIGNATURES = {
     "cpc_nce_backward_dwall": (_I, [_P] * 4 + [_I, _I, _I, _I, _P]),
     "cpc_set_nce_fused": (_I, [_I]),
     "cpc_nce_padded_negatives": (_I, [_I]),
+    "cpc_nce_head_group": (_I, [_I, _I]),
     "cpc_set_step_schedule": (_I, [_I, _I]),
     "cpc_train_step_layout": (_I, [_I, _I, _I, _I, _P]),
     "cpc_train_step_prefetch": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

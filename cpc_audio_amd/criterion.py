@@ -5,10 +5,14 @@ exported at cpc/criterion/__init__.py:5-6), constructor signatures and state-dic
 (``wPrediction.predictors.{k}.weight``).  forward/backward of the criterion run in the
 fused InfoNCE kernels of libcpc_hip.so; negatives are never materialised.
 """
+import math
+
 import torch
 import torch.nn as nn
 
 from .ops import InfoNCEFunction, InfoNCEScoresFunction, prepare_negatives
+
+_HEAD_TILE = 16          # prediction heads per call of the score kernels (a wavefront's MFMA tile; ops.head_group walks more)
 
 
 class _Stacked(torch.autograd.Function):
@@ -58,23 +62,81 @@ _LAYER_PARAMS = (lambda l: l.multihead.Wo.weight, lambda l: l.multihead.Wk.weigh
                  lambda l: l.ln_ffnetwork.weight, lambda l: l.ln_ffnetwork.bias)
 
 
+class _Equalized(nn.Module):
+    """cpc/criterion/custom_layers.py:45-78 as the criterion uses it (``equalized=True``): the wrapped layer (parameter keys
+    ``module.weight`` / ``module.bias``) starts from N(0, 1) weights and a zero bias, and its output is multiplied at run time by
+    He's constant sqrt(2 / fan_in) (custom_layers.py:33-42), kept in the plain attribute ``weight`` as in the reference."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+        with torch.no_grad():
+            module.weight.normal_(0, 1)
+            if module.bias is not None:
+                module.bias.zero_()
+        self.equalized = True
+        self.weight = math.sqrt(2.0 / module.weight[0].numel())
+
+    def forward(self, x):
+        return self.module(x) * self.weight
+
+
+class FFNetwork(nn.Module):
+    """cpc/criterion/criterion.py:11-20 (``--rnnMode ffd``): lin2(drop(relu(lin1 x))) on equalized linear layers."""
+
+    def __init__(self, din, dout, dff, dropout):
+        super().__init__()
+        self.lin1 = _Equalized(nn.Linear(din, dff, bias=True))
+        self.lin2 = _Equalized(nn.Linear(dff, dout, bias=True))
+        self.relu = nn.ReLU()
+        self.drop = nn.Dropout(dropout)
+
+    def forward(self, x):
+        return self.lin2(self.drop(self.relu(self.lin1(x))))
+
+
+class ShiftedConv(nn.Module):
+    """cpc/criterion/criterion.py:23-41 (``--rnnMode conv4 / conv8 / conv12``): a causal convolution over the time axis of a
+    (N, S, C) sequence -- kernelSize - 1 zero frames in front, an equalized Conv1d, back to (N, S, C)."""
+
+    def __init__(self, dimOutputAR, dimOutputEncoder, kernelSize):
+        super().__init__()
+        self.module = _Equalized(nn.Conv1d(dimOutputAR, dimOutputEncoder, kernelSize, padding=0))
+        self.kernelSize = kernelSize
+
+    def forward(self, x):
+        y = nn.functional.pad(x.transpose(1, 2), (self.kernelSize - 1, 0))
+        return self.module(y).transpose(1, 2)
+
+
+_TORCH_PREDICTORS = {
+    # criterion.py:63-81.  nn.RNN is built WITHOUT batch_first there (:64-65) and so walks the batch axis of the (B, W, C)
+    # context as its time axis; kept, since a checkpoint trained that way means exactly that
+    "RNN": lambda a, e: nn.RNN(a, e),
+    "LSTM": lambda a, e: nn.LSTM(a, e, batch_first=True),
+    "ffd": lambda a, e: FFNetwork(a, e, e, 0),
+    "conv4": lambda a, e: ShiftedConv(a, e, 4),
+    "conv8": lambda a, e: ShiftedConv(a, e, 8),
+    "conv12": lambda a, e: ShiftedConv(a, e, 12),
+}
+
+
 class PredictionNetwork(nn.Module):
     """cpc/criterion/criterion.py:44-118: K prediction networks.  ``--rnnMode linear`` (the ``else`` branch at
     :89-95, north-star configuration): K bias-free nn.Linear(dimOutputAR, dimOutputEncoder) fused into the
     criterion kernels; ``--rnnMode transformer`` (:82-88, BASELINE.json config 4): K one-layer transformers
     ``buildTransformerAR(dimOutputEncoder, 1, sizeInputSeq, False)`` on the HIP transformer layer
-    (``transformerDropout`` is an addition -- the reference's layers always use 0.1, which has no parity)."""
+    (``transformerDropout`` is an addition -- the reference's layers always use 0.1, which has no parity).  The reference's
+    other choices (:63-81: ``RNN``, ``LSTM``, ``ffd``, ``conv4/8/12``; none in a BASELINE config) are torch modules with the
+    reference's parameter names whose predictions the HIP score kernels take as a tensor (``scores_apart``)."""
 
     def __init__(self, nPredicts, dimOutputAR, dimOutputEncoder, rnnMode=None, dropout=False,
                  sizeInputSeq=116, transformerDropout=0.1):
         super().__init__()
-        if rnnMode in ("RNN", "LSTM", "ffd", "conv4", "conv8", "conv12"):
-            raise NotImplementedError(f"rnnMode={rnnMode!r}: the HIP criterion implements the linear prediction heads "
-                                      "(--rnnMode linear) and the transformer predictors (--rnnMode transformer)")
         if dimOutputAR != 256 or dimOutputEncoder != 256:
             raise NotImplementedError("the HIP criterion is built for hiddenGar == hiddenEncoder == 256")
-        if nPredicts > 16:
-            raise NotImplementedError("the fused score kernel holds at most 16 heads per wavefront tile")
+        # (any number of prediction steps: the score tiles hold 16 heads per wavefront, a larger criterion is walked in groups of
+        # 16 -- CPCUnsupersivedCriterion._forward_in_head_groups)
         self.predictors = nn.ModuleList()
         self.RESIDUAL_STD = 0.01
         self.dimOutputAR = dimOutputAR
@@ -89,6 +151,8 @@ class PredictionNetwork(nn.Module):
                 from .transformers import buildTransformerAR
                 self.predictors.append(buildTransformerAR(dimOutputEncoder, 1, sizeInputSeq, False,
                                                           dropout=transformerDropout))
+            elif rnnMode in _TORCH_PREDICTORS:
+                self.predictors.append(_TORCH_PREDICTORS[rnnMode](dimOutputAR, dimOutputEncoder))
             else:
                 self.predictors.append(nn.Linear(dimOutputAR, dimOutputEncoder, bias=False))
 
@@ -96,7 +160,8 @@ class PredictionNetwork(nn.Module):
     def scores_apart(self):
         """True where the predictions exist as a tensor between the prediction networks and the scores (transformer predictors;
         any predictor with the reference's dropout active): InfoNCEScoresFunction instead of the fused InfoNCEFunction."""
-        return self.rnnMode == "transformer" or (self.dropout is not None and self.training)
+        return (self.rnnMode == "transformer" or self.rnnMode in _TORCH_PREDICTORS
+                or (self.dropout is not None and self.training))
 
     group_predictors = True      # False: the transformer predictors run head by head (the path a mixed set falls back to; tests)
 
@@ -127,7 +192,8 @@ class PredictionNetwork(nn.Module):
             return TransformerGroupFunction.apply(c, p, seed, len(layers), *kinds)
         if all(isinstance(p, nn.Linear) and p.bias is None for p in self.predictors):
             return torch.nn.functional.linear(c, self.stacked_weight())
-        return torch.cat([p(c) for p in self.predictors], dim=2)
+        out = [p(c) for p in self.predictors]
+        return torch.cat([o[0] if isinstance(o, tuple) else o for o in out], dim=2)     # (recurrent cells return (y, state))
 
     def stacked_weight(self):
         """(K*256, 256): the K head weights stacked along the output dimension (stacked_parameters: no per-step cat)."""
@@ -141,6 +207,8 @@ class PredictionNetwork(nn.Module):
         out = []
         for k in range(len(self.predictors)):
             locC = self.predictors[k](c)
+            if isinstance(locC, tuple):
+                locC = locC[0]
             if self.dropout is not None:
                 locC = self.dropout(locC)
             locC = locC.view(locC.size(0), 1, locC.size(1), locC.size(2))
@@ -216,7 +284,8 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         network and the first GEMM.  forward() picks the result up when the shapes match and falls back to doing it in line
         otherwise; calling this is optional."""
         from . import ops
-        if step is None or not step.overlap or torch.device(device).type != "cuda" or self.mode == "reverse":
+        if (step is None or not step.overlap or torch.device(device).type != "cuda" or self.mode == "reverse"
+                or self.nPredicts > _HEAD_TILE):
             return
         K, N = self.nPredicts, self.negativeSamplingExt
         W = seqSize - K
@@ -245,6 +314,8 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         batchSize, seqSize, _ = cFeature.size()
         windowSize = seqSize - self.nPredicts
         from . import ops
+        if self.nPredicts > _HEAD_TILE:
+            return self._forward_in_head_groups(cFeature, encodedData, negatives)
         step = ops.current()
         prepared, saved = (step.prepared if step is not None else None), None
         if step is not None:
@@ -295,3 +366,30 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             losses, acc = InfoNCEFunction.apply(cFeature, encodedData, self.wPrediction.stacked_weight(), ext, perm,
                                                 row_ptr, heads, defer, saved, self.negativeSamplingExt)
         return losses.view(1, -1), acc.view(1, -1)
+
+    def _forward_in_head_groups(self, cFeature, encodedData, negatives):
+        """nPredicts > 16 (no BASELINE config; the reference takes any): the same kernels on 16 heads at a time
+        (ops.head_group -- every group sees the W = S - nPredicts windows of the whole criterion and the same negatives, head
+        k's positive is z[t + k + 1]); the per-head losses and accuracies are independent, autograd adds the groups' dc / dz.
+        Single stream, no overlap: not the tuned path."""
+        B, S, _ = cFeature.size()
+        K, N = self.nPredicts, self.negativeSamplingExt
+        W = S - K
+        if negatives is None:
+            negatives = self.drawNegatives(B, S, W, cFeature.device)
+        wp = self.wPrediction
+        pred = wp.predictions(cFeature[:, :W].contiguous()) if wp.scores_apart else None
+        wall = None if wp.scores_apart else wp.stacked_weight()
+        losses, accs = [], []
+        for k0 in range(0, K, _HEAD_TILE):
+            kg = min(_HEAD_TILE, K - k0)
+            ext, perm, row_ptr = prepare_negatives(negatives[0], negatives[1], B, S, kg, N, group=(k0, K))
+            if wp.scores_apart:
+                l, a = InfoNCEScoresFunction.apply(pred[:, :, k0 * 256:(k0 + kg) * 256], encodedData, ext, perm, row_ptr, N,
+                                                   (k0, K))
+            else:
+                l, a = InfoNCEFunction.apply(cFeature, encodedData, wall[k0 * 256:(k0 + kg) * 256], ext, perm, row_ptr, None,
+                                             False, None, N, (k0, K))
+            losses.append(l)
+            accs.append(a)
+        return torch.cat(losses).view(1, -1), torch.cat(accs).view(1, -1)

@@ -60,7 +60,7 @@ extern "C" int cpc_release_stream(void* stream) {
     return 0;
 }
 
-extern "C" int cpc_abi_version(void) { return 14; }
+extern "C" int cpc_abi_version(void) { return 15; }
 
 // A kernel that keeps one wavefront busy for `ticks` of the 100 MHz wall clock (bounded: it gives up after ~2^14 sleeps).
 __global__ void spin_kernel(unsigned long long ticks) {

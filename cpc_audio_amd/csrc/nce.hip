@@ -74,7 +74,7 @@ struct Gather16 {
 __global__ __launch_bounds__(256, 3) void nce_fwd_kernel(
     const float* __restrict__ pred, const float* __restrict__ z, const int* __restrict__ ext,
     float* __restrict__ logits, float* __restrict__ lse_out, float* __restrict__ rowstat, int BW, int W,
-    int S, int K, int N, unsigned* __restrict__ ticket, int Nv) {
+    int S, int K, int N, unsigned* __restrict__ ticket, int Nv, int koff) {
     __shared__ float4 tiles[4][256];
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 3) void nce_fwd_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int head = 4 * q + kq;
-            rowp[q] = z + ((long)b * S + t + (head < K ? head : 0) + 1) * kC + 4 * i;
+            rowp[q] = z + ((long)b * S + t + koff + (head < K ? head : 0) + 1) * kC + 4 * i;
         }
         gt.issue(rowp);
         const f32x4 acc = score_tile();
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_fused_kernel(
     const float* __restrict__ pred, const float* __restrict__ z, const int* __restrict__ ext,
     float* __restrict__ logits, float* __restrict__ lse_out, float* __restrict__ rowstat, float* __restrict__ tpred,
     float* __restrict__ tamax, float* __restrict__ ps, int BW, int W, int S, int K, int N, unsigned* __restrict__ ticket,
-    int Nv) {
+    int Nv, int koff) {
     __shared__ float4 tiles[4][256];
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_fused_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int head = 4 * kq + q;
-            rowp[q] = z + ((long)b * S + t + (head < K ? head : 0) + 1) * kC + 4 * i;
+            rowp[q] = z + ((long)b * S + t + koff + (head < K ? head : 0) + 1) * kC + 4 * i;
         }
         gt.issue(rowp);
         const f32x4 acc = score_tile();
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_fused_kernel(
         const int head = 4 * kq + r;
         const float fr = __shfl(fac, head), dr = __shfl(p0m1, head);       // convergent: before the guard
         if (head < K) {
-            const float* zp = z + ((long)b * S + t + head + 1) * kC + 4 * i;
+            const float* zp = z + ((long)b * S + t + koff + head + 1) * kC + 4 * i;
             float* op = tpred + ((long)bt * K + head) * kC + 4 * i;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -493,7 +493,7 @@ constexpr int kDsTile = 256 + 48;       // 16 candidates x 16 heads; the four la
 __global__ __launch_bounds__(256, 3) void nce_bwd_dpred_kernel(
     const float* __restrict__ z, const int* __restrict__ ext, const float* __restrict__ logits,
     const float* __restrict__ lse, const float* __restrict__ gscale, float* __restrict__ dpred, int BW,
-    int W, int S, int K, int N, float* __restrict__ amax_slots, float* __restrict__ dS) {
+    int W, int S, int K, int N, float* __restrict__ amax_slots, float* __restrict__ dS, int koff) {
     __shared__ float ds_tile[4][kDsTile];
     const int lane = threadIdx.x & 63;
     const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256, 3) void nce_bwd_dpred_kernel(
         if (head < K) {
             const float d0 = gscale[head] * (expf(logits[((long)bt * K + head) * (N + 1)] - lse[(long)bt * K + head]) - 1.0f);
             if (dS != nullptr) dS[((long)bt * (N + K) + N + head) * 16 + i] = i == head ? d0 : 0.f;
-            const float* zp = z + ((long)b * S + t + head + 1) * kC + 4 * i;
+            const float* zp = z + ((long)b * S + t + koff + head + 1) * kC + 4 * i;
             float* op = dpred + ((long)bt * K + head) * kC + 4 * i;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(const long* __restrict__ 
 
 __global__ __launch_bounds__(256) void nce_index_kernel(const int* __restrict__ ext, int* __restrict__ dest,
                                                         int* __restrict__ count, int B, int S, int W, int K,
-                                                        int N) {
+                                                        int N, int koff) {
     const long slot = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)B * W * (N + K);
     if (slot >= total) return;
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256) void nce_index_kernel(const int* __restrict__ 
     if (j < N) {
         d = ext[(long)bt * N + j];
     } else {
-        d = b * S + t + (j - N) + 1;                    // positive of head j-N (criterion.py:210-215)
+        d = b * S + t + koff + (j - N) + 1;             // positive of head koff + j-N (criterion.py:210-215)
     }
     dest[slot] = d;
     atomicAdd(&count[d], 1);
@@ -895,6 +895,7 @@ int g_nce_fused = 1;       // cpc_set_nce_fused: 1 (default) the one-pass criter
 
 struct NceLayout {
     int W, BW;
+    int koff;       // first head of this call within the criterion's heads (cpc_nce_head_group; 0 unless K > 16 is walked in groups)
     int N, Nv;      // negatives per window as the kernels walk them (a multiple of 16) / as drawn (criterion.py:176-189): the
                     // candidates Nv .. N-1 of every window are padding -- a valid row of z, their logit forced to -3e38, so that
                     // they weigh exactly 0 in the softmax, the arg-max and every gradient
@@ -905,12 +906,20 @@ struct NceLayout {
 
 constexpr int kDzSplits = 4;      // K-walk splits the dz GEMM's partial buffer is sized for (SplitK)
 
+// Head groups (cpc_nce_head_group): the score tiles hold 16 heads per wavefront, so a criterion with more prediction steps is
+// walked 16 heads at a time -- every cpc_nce_* call of the calling thread then works on heads k0 .. k0 + K - 1 of k_total: its
+// windows are the W = S - k_total of the whole criterion and head k's positive is z[b, t + k0 + k + 1] (criterion.py:210-215).
+// The groups share nothing but the inputs: losses / accuracies are per head, the gradients add.
+static thread_local int g_head_off = 0, g_head_total = 0;
+
 static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
-    if (B <= 0 || K <= 0 || K > 16 || S <= K || N <= 0) return false;
+    const int Ktot = g_head_total > 0 ? g_head_total : K;
+    if (B <= 0 || K <= 0 || K > 16 || g_head_off + K > Ktot || S <= Ktot || N <= 0) return false;
     n.Nv = N;
     N = (N + 15) & ~15;                      // (every size below in padded candidates)
     n.N = N;
-    n.W = S - K;
+    n.koff = g_head_total > 0 ? g_head_off : 0;
+    n.W = S - Ktot;
     n.BW = B * n.W;
     long o = 0;
     n.pred = o; o += align64l((long)n.BW * K * kC);
@@ -973,10 +982,10 @@ static int nce_scores_forward(const NceLayout& n, const float* pred, const float
     if (fused)
         hipLaunchKernelGGL(nce_fwd_fused_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
                            saved + n.lse, scratch + n.rowstat, saved + n.tpred, saved + n.bounds + 2 * kAmaxSlots, saved + n.ps,
-                           n.BW, n.W, S, K, N, ticket, n.Nv);
+                           n.BW, n.W, S, K, N, ticket, n.Nv, n.koff);
     else
     hipLaunchKernelGGL(nce_fwd_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
-                       saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket, n.Nv);
+                       saved + n.lse, scratch + n.rowstat, n.BW, n.W, S, K, N, ticket, n.Nv, n.koff);
     step_timer_mark(9, st);
     CPC_LAUNCH_CHECK();
     if (fin != nullptr && fin != st) {
@@ -1049,7 +1058,7 @@ static int nce_scores_backward(const NceLayout& n, const float* z, const int* ex
     hipLaunchKernelGGL(nce_gscale_kernel, dim3(dc_tail ? 1 + 128 : 1), dim3(64), 0, st, gloss, gscale, K, gs, fwd_bounds, dc_tail, B,
                        S, n.W);
     hipLaunchKernelGGL(nce_bwd_dpred_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, z, ext, logits, lse, gscale, dpred, n.BW,
-                       n.W, S, K, N, fwd_bounds ? gscale + 64 : (float*)nullptr, dS);
+                       n.W, S, K, N, fwd_bounds ? gscale + 64 : (float*)nullptr, dS, n.koff);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -1100,7 +1109,7 @@ extern "C" int cpc_nce_prepare(const long* batchIdx, const long* seqIdx, int* ex
     int* cursor = count + rows + 1;
     (void)hipMemsetAsync(count, 0, sizeof(int) * (rows + 1), st);
     hipLaunchKernelGGL(nce_rows_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, batchIdx, seqIdx, ext, B, S, n.W, n.Nv, N);
-    hipLaunchKernelGGL(nce_index_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ext, dest, count, B, S, n.W, K, N);
+    hipLaunchKernelGGL(nce_index_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ext, dest, count, B, S, n.W, K, N, n.koff);
     hipLaunchKernelGGL(nce_scan_kernel, dim3(1), dim3(1024), 0, st, count, row_ptr, cursor, rows);
     hipLaunchKernelGGL(nce_fill_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dest, cursor, perm, total);
     CPC_LAUNCH_CHECK();
@@ -1334,6 +1343,16 @@ extern "C" int cpc_nce_backward_dwall(const float* c, const float* saved, float*
 // 1 (default): the linear heads' criterion in one gather pass -- the forward leaves T, the unit-gradient dPred, in its saved
 // workspace and the backward starts with the dc GEMM; 0: the two-pass kernels (nce_fwd_kernel, nce_bwd_dpred_kernel).  A forward
 // and its backward must run under the same setting.
+// Head group of the calling thread's following cpc_nce_* calls (see g_head_off): heads k0 .. of a criterion with k_total prediction
+// steps; (0, 0) = none (the default: a call's K heads are the whole criterion).  The caller brackets every group's calls --
+// layout, prepare, forward, backward: all of them -- with the group and (0, 0); the composite step (cpc_train_step) does not use it.
+extern "C" int cpc_nce_head_group(int k0, int k_total) {
+    CPC_RETURN_IF(k0 < 0 || k_total < 0 || (k_total == 0 && k0 != 0) || (k_total > 0 && k0 >= k_total), CPC_ERR_ARG);
+    g_head_off = k0;
+    g_head_total = k_total;
+    return 0;
+}
+
 extern "C" int cpc_set_nce_fused(int on) {
     g_nce_fused = on ? 1 : 0;
     return 0;

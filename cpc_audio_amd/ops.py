@@ -461,12 +461,31 @@ def candidate_destinations(ext, B, S, K):
     return perm.to(torch.int32), row_ptr.to(torch.int32)
 
 
-def prepare_negatives(batchIdx, seqIdx, B, S, K, N):
+class head_group:
+    """``with head_group(lib, (k0, k_total)):`` -- the cpc_nce_* calls inside work on heads k0 .. of a criterion with k_total
+    prediction steps (cpc_nce_head_group: the score tiles hold 16 heads, more are walked in groups).  The setting belongs to the
+    calling thread, so every function that makes such calls -- autograd runs backward on a thread of its own -- brackets its own."""
+
+    def __init__(self, lib, group):
+        self.lib, self.group = lib, group
+
+    def __enter__(self):
+        if self.group is not None:
+            self.lib.check(self.lib.cpc_nce_head_group(int(self.group[0]), int(self.group[1])), "nce_head_group")
+
+    def __exit__(self, *exc):
+        if self.group is not None:
+            self.lib.cpc_nce_head_group(0, 0)
+        return False
+
+
+def prepare_negatives(batchIdx, seqIdx, B, S, K, N, group=None):
     """(ext (B,W,Np), perm, row_ptr) int32 from the two int64 draws of sampleClean -- cpc_nce_prepare.  Np = N rounded up to the
     kernels' 16-wide candidate tile (cpc_nce_padded_negatives): the padding entries are masked by position in the scoring
-    kernels, so every call that takes these lists is also told N."""
+    kernels, so every call that takes these lists is also told N.  ``group`` = (k0, k_total): the lists of heads k0 .. k0+K-1 of
+    a criterion with k_total > 16 prediction steps (head_group)."""
     lib = _lib.get()
-    W = S - K
+    W = S - (K if group is None else group[1])
     Np = int(lib.cpc_nce_padded_negatives(N))
     dev = batchIdx.device
     batchIdx, seqIdx = batchIdx.contiguous(), seqIdx.contiguous()
@@ -477,8 +496,9 @@ def prepare_negatives(batchIdx, seqIdx, B, S, K, N):
         perm = torch.empty(B * W * (Np + K), device=dev, dtype=torch.int32)
         row_ptr = torch.empty(B * S + 1, device=dev, dtype=torch.int32)
         work = torch.empty(B * W * (Np + K) + 2 * B * S + 2, device=dev, dtype=torch.int32)
-        lib.check(lib.cpc_nce_prepare(_p(batchIdx), _p(seqIdx), _p(ext), _p(perm), _p(row_ptr), _p(work), B, S, K, N,
-                                      _stream()), "nce_prepare")
+        with head_group(lib, group):
+            lib.check(lib.cpc_nce_prepare(_p(batchIdx), _p(seqIdx), _p(ext), _p(perm), _p(row_ptr), _p(work), B, S, K, N,
+                                          _stream()), "nce_prepare")
     return ext, perm, row_ptr
 
 
@@ -489,9 +509,10 @@ class InfoNCEFunction(torch.autograd.Function):
     (bit-identical values; ``wall`` itself receives no gradient), which takes that GEMM off the path to the encoder."""
 
     @staticmethod
-    def forward(ctx, c, z, wall, ext, perm, row_ptr, heads=None, defer_dz=False, saved=None, n_valid=None):
+    def forward(ctx, c, z, wall, ext, perm, row_ptr, heads=None, defer_dz=False, saved=None, n_valid=None, group=None):
         """saved: optionally the workspace of this call with the GEMM operand bounds already in it (nce_bounds_into).
-        n_valid: negatives per window as drawn when ext's rows are padded to the 16-wide tile (prepare_negatives)."""
+        n_valid: negatives per window as drawn when ext's rows are padded to the 16-wide tile (prepare_negatives).
+        group: (k0, k_total) when ``wall`` holds heads k0 .. of a criterion with k_total > 16 prediction steps (head_group)."""
         _require_cuda(c, "InfoNCEFunction")
         lib = _lib.get()
         B, S, H = c.shape
@@ -501,11 +522,11 @@ class InfoNCEFunction(torch.autograd.Function):
             if int(lib.cpc_nce_padded_negatives(int(n_valid))) != N:
                 raise ValueError("InfoNCEFunction: ext is not padded for n_valid negatives")
             N = int(n_valid)
-        if H != _HID or z.shape != (B, S, _HID) or W != S - K or ext.dtype != torch.int32:
+        if H != _HID or z.shape != (B, S, _HID) or W != S - (K if group is None else group[1]) or ext.dtype != torch.int32:
             raise ValueError("InfoNCEFunction: inconsistent shapes")
         c, z, wall, ext = c.contiguous(), z.contiguous(), wall.detach().contiguous(), ext.contiguous()
-        with torch.cuda.device(c.device):
-            sizes = _layout("nce_layout", lib.cpc_nce_layout, 6, B, S, K, N)
+        with torch.cuda.device(c.device), head_group(lib, group):
+            sizes = _layout(f"nce_layout{group or ''}", lib.cpc_nce_layout, 6, B, S, K, N)
             fwd = lib.cpc_nce_forward_prepared
             if saved is None or saved.numel() != sizes[0] or saved.device != c.device:
                 saved = torch.empty(sizes[0], device=c.device, dtype=torch.float32)
@@ -517,6 +538,7 @@ class InfoNCEFunction(torch.autograd.Function):
                           _stream()), "nce_forward")
         ctx.save_for_backward(c, z, wall, ext, saved, perm, row_ptr)
         ctx.dims = (B, S, K, N, sizes[2])
+        ctx.group = group
         ctx.set_materialize_grads(False)       # no zero-filled gradient for the accuracies
         ctx.heads = list(heads) if heads is not None else None
         ctx.step = current()
@@ -536,7 +558,7 @@ class InfoNCEFunction(torch.autograd.Function):
             scratch = torch.empty(nscr, device=c.device, dtype=torch.float32)
             dc, dz, dwall = torch.empty_like(c), torch.empty_like(z), torch.empty_like(wall)
             step = ctx.step
-            if _overlap(step):
+            if _overlap(step) and ctx.group is None:
                 main, side = torch.cuda.current_stream(), step.side_stream(c.device)
                 ready = torch.cuda.Event()
                 heads = ctx.heads if ctx.heads is not None and any(h.requires_grad for h in ctx.heads) else None
@@ -589,10 +611,11 @@ class InfoNCEFunction(torch.autograd.Function):
                     step.deferred.append(dwall_path)
                     dwall = None
             else:
-                lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
-                                               _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
-                                               _stream()), "nce_backward")
-        return dc, dz, dwall, None, None, None, None, None, None, None
+                with head_group(lib, ctx.group):
+                    lib.check(lib.cpc_nce_backward(_p(c), _p(z), _p(wall), _p(ext), _p(perm), _p(row_ptr), _p(saved),
+                                                   _p(gloss), _p(scratch), _p(dc), _p(dz), _p(dwall), B, S, K, N,
+                                                   _stream()), "nce_backward")
+        return dc, dz, dwall, None, None, None, None, None, None, None, None
 
 
 def nce_bounds_into(wall, c_bound, B, S, K, N):
@@ -611,7 +634,7 @@ class InfoNCEScoresFunction(torch.autograd.Function):
     """pred (B,W,K*256) from any prediction network, z (B,S,256), ext, perm, row_ptr -> losses (K), acc (K)."""
 
     @staticmethod
-    def forward(ctx, pred, z, ext, perm, row_ptr, n_valid=None):
+    def forward(ctx, pred, z, ext, perm, row_ptr, n_valid=None, group=None):
         _require_cuda(pred, "InfoNCEScoresFunction")
         lib = _lib.get()
         B, S, H = z.shape
@@ -620,12 +643,13 @@ class InfoNCEScoresFunction(torch.autograd.Function):
             if int(lib.cpc_nce_padded_negatives(int(n_valid))) != N:
                 raise ValueError("InfoNCEScoresFunction: ext is not padded for n_valid negatives")
             N = int(n_valid)
-        K = S - W
-        if H != _HID or pred.shape != (B, W, K * _HID) or ext.dtype != torch.int32:
+        K = S - W if group is None else pred.shape[2] // _HID        # (group = (k0, k_total): pred holds heads k0 .. k0+K-1)
+        if (H != _HID or pred.shape != (B, W, K * _HID) or ext.dtype != torch.int32
+                or (group is not None and W != S - group[1])):
             raise ValueError("InfoNCEScoresFunction: inconsistent shapes")
         pred, z, ext = pred.contiguous(), z.contiguous(), ext.contiguous()
-        with torch.cuda.device(z.device):
-            sizes = _layout("nce_layout", lib.cpc_nce_layout, 6, B, S, K, N)
+        with torch.cuda.device(z.device), head_group(lib, group):
+            sizes = _layout(f"nce_layout{group or ''}", lib.cpc_nce_layout, 6, B, S, K, N)
             saved = torch.empty(sizes[0], device=z.device, dtype=torch.float32)
             scratch = torch.empty(sizes[1], device=z.device, dtype=torch.float32)
             losses = torch.empty(K, device=z.device, dtype=torch.float32)
@@ -634,6 +658,7 @@ class InfoNCEScoresFunction(torch.autograd.Function):
                                                  B, S, K, N, _stream()), "nce_scores_forward")
         ctx.save_for_backward(pred, z, ext, saved, perm, row_ptr)
         ctx.dims = (B, S, K, N, sizes[2])
+        ctx.group = group
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(acc)
         return losses, acc
@@ -644,13 +669,13 @@ class InfoNCEScoresFunction(torch.autograd.Function):
         pred, z, ext, saved, perm, row_ptr = ctx.saved_tensors
         B, S, K, N, nscr = ctx.dims
         gloss = torch.zeros(K, device=z.device) if gloss is None else gloss.contiguous()
-        with torch.cuda.device(z.device):
+        with torch.cuda.device(z.device), head_group(lib, ctx.group):
             scratch = torch.empty(nscr, device=z.device, dtype=torch.float32)
             dpred, dz = torch.empty_like(pred), torch.empty_like(z)
             lib.check(lib.cpc_nce_scores_backward(_p(pred), _p(z), _p(ext), _p(perm), _p(row_ptr), _p(saved), _p(gloss),
                                                   _p(scratch), _p(dpred), _p(dz), B, S, K, N, _stream()),
                       "nce_scores_backward")
-        return dpred, dz, None, None, None, None
+        return dpred, dz, None, None, None, None, None
 
 
 class TransformerGroupFunction(torch.autograd.Function):

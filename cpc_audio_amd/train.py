@@ -130,7 +130,8 @@ class CompositeStep:
         ar = m.gAR
         if not (m.gEncoder.hip and ar.hip):                # (options served by torch ops: model.CPCEncoder / CPCAR)
             return False
-        if ar.reverse or ar.baseNet.num_layers != 2 or cr.mode is not None or cr.wPrediction.scores_apart:
+        if (ar.reverse or ar.baseNet.num_layers != 2 or cr.mode is not None or cr.wPrediction.scores_apart
+                or cr.nPredicts > 16):                       # (more heads: walked in groups by the criterion module)
             return False
         if negatives is not None and not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int64 for t in negatives):
             return False

@@ -332,7 +332,7 @@ int cpc_dropout_keep_mask(float* out, long n, int site, int S, float p, unsigned
  *   ext  : (B*W, N) int32, ext[(b*W+t)*N + n] = row of z.view(B*S,256) used as negative n
  *          of window (b,t)  ==  criterion.py:199's extIdx[b,n,t]
  *   losses, acc : K floats (criterion.py:256-257)
- * K <= 16, N % 16 == 0.  sizes[0..2] = saved / fwd-scratch / bwd-scratch floats,
+ * K <= 16 per call (cpc_nce_head_group walks more), any N > 0.  sizes[0..2] = saved / fwd-scratch / bwd-scratch floats,
  * sizes[3..5] = offsets of pred, logits (B*W,K,1+N), lse (B*W,K) inside `saved`. */
 int cpc_nce_layout(int B, int S, int K, int N, long* sizes);
 /* Negatives per window as the kernels lay them out: N (criterion.py:176-189 draws any number) rounded up to the 16-wide MFMA
@@ -340,6 +340,12 @@ int cpc_nce_layout(int B, int S, int K, int N, long* sizes);
  * arg-max and every gradient.  ext is (B*W, padded) int32, logits (B*W, K, 1 + padded), perm / work count padded + K candidates
  * per window; the draws (batchIdx / seqIdx) stay B*N*W. */
 int cpc_nce_padded_negatives(int N);
+/* More than 16 prediction steps (criterion.py:225-257 takes any nPredicts): the score tiles hold 16 heads, so such a criterion
+ * is walked in groups of at most 16.  After cpc_nce_head_group(k0, k_total) every cpc_nce_* call of the CALLING THREAD works on
+ * heads k0 .. k0+K-1 of a criterion with k_total steps: W = S - k_total windows per sequence, head k's positive is
+ * z[b, t + k0 + k + 1]; `wall` / `pred` / losses / acc are the group's K heads.  Per-head results are independent, dc / dz of the
+ * groups add.  (0, 0) ends it; every call of a group -- layout, prepare, forward, backward -- is made under the same setting. */
+int cpc_nce_head_group(int k0, int k_total);
 /* Index preparation: the two int64 draws of sampleClean (criterion.py:181-189; B*N*W each, flat (b,n,t)
  * order) -> ext (the rows of criterion.py:191-199, laid out (b,t,n) with the N rows of a window in ASCENDING order: the
  * criterion is invariant under a permutation of a window's negatives, and sorted lists keep the gathers of the scoring

@@ -95,6 +95,42 @@ def test_prediction_dropout_option_has_the_reference_surface():
     assert isinstance(crit.wPrediction.dropout, torch.nn.Dropout)
 
 
+@pytest.mark.parametrize("mode", ["RNN", "LSTM", "ffd", "conv4", "conv8", "conv12"])
+def test_other_prediction_networks_reproduce_the_reference(mode):
+    """cpc/criterion/criterion.py:63-81: the reference's other ``--rnnMode`` choices.  tests/golden/predictors.npz holds what the
+    REFERENCE's PredictionNetwork returned (oracle/make_golden_predictors.py: seeded parameters under the reference's own
+    state-dict keys, seeded context and candidates); this package's class must take the same state dict (strict) and give the
+    same per-head scores and the same gradient w.r.t. the context -- including nn.RNN walking the batch axis (criterion.py:64-65)."""
+    import json
+    import os
+    import numpy as np
+    import torch
+    from cpc_audio_amd.criterion import PredictionNetwork
+    from oracle.make_golden_predictors import inputs, seeded_state
+    gold = os.path.join(ROOT, "tests", "golden")
+    meta = json.load(open(os.path.join(gold, "predictors_meta.json")))
+    data = np.load(os.path.join(gold, "predictors.npz"))
+    m = meta["modes"][mode]
+    net = PredictionNetwork(meta["heads"], 256, 256, rnnMode=mode, dropout=False, sizeInputSeq=meta["window"])
+    shapes = {k: tuple(v) for k, v in m["keys"].items()}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == shapes          # names, order and shapes
+    assert net.scores_apart
+    net.load_state_dict(seeded_state(shapes, m["param_seed"]), strict=True)
+    c, cand = inputs(m["input_seed"])
+    cr = c.clone().requires_grad_(True)
+    out = net(cr, cand)
+    sum(o.sum() for o in out).backward()
+    ref_out, ref_dc = torch.from_numpy(data[f"{mode}:out"]), torch.from_numpy(data[f"{mode}:dc"])
+    assert (torch.stack(out).detach() - ref_out).abs().max().item() <= 2e-6 * max(1.0, ref_out.abs().max().item())
+    assert ((cr.grad - ref_dc).norm() / ref_dc.norm()).item() <= 1e-5
+    # the (B, W, K*256) tensor the HIP score kernels read is the same predictions, head k at columns k*256..
+    pred = net.predictions(c)
+    assert pred.shape == (c.shape[0], c.shape[1], meta["heads"] * 256)
+    for k in range(meta["heads"]):
+        s_k = (pred[:, :, k * 256:(k + 1) * 256].unsqueeze(1) * cand[k]).mean(dim=3)
+        assert (s_k.detach() - ref_out[k]).abs().max().item() <= 2e-6 * max(1.0, ref_out.abs().max().item())
+
+
 def test_library_contains_no_packed_fp32_arithmetic():
     """build.py's gate with an EMPTY allow-list (round 4): no code object of the library contains v_pk_{fma,mul,add}_f32 -- the
     instruction class behind the co-residency corruption of rounds 1-2."""

@@ -98,6 +98,84 @@ def _nce_forward_backward(lib, B, S, K, N, scale):
     assert rel_err(dc, cr.grad) < 1e-5 and rel_err(dz, zr.grad) < 1e-5 and rel_err(dwall, ref_dw) < 1e-5
 
 
+@pytest.mark.parametrize("B,S,K,N,fused", [(2, 28, 20, 16, 1), (1, 41, 35, 24, 1), (2, 28, 20, 16, 0)])
+def test_more_than_sixteen_heads_walked_in_groups_emulated(B, S, K, N, fused):
+    """criterion.py:225-257 takes any nPredicts; the score tiles hold 16 heads.  cpc_nce_head_group(k0, K) makes the following
+    calls work on heads k0 .. of a K-step criterion (W = S - K windows, positives z[t + k0 + k + 1]): the groups' losses /
+    accuracies side by side and their dc / dz summed must be the oracle's K-head criterion; the linear heads' path and the
+    given-predictions path (cpc_nce_scores_*), with the lists cpc_nce_prepare makes under the same setting."""
+    lib = emu()
+    assert lib.cpc_set_nce_fused(fused) == 0
+    try:
+        torch.manual_seed(3)
+        W = S - K
+        p = O.make_params(seed=4, n_predicts=K, head_scale=20.0)
+        heads = O.head_weights(p, K)
+        c = torch.tanh(torch.randn(B, S, 256))
+        z = torch.relu(torch.randn(B, S, 256))
+        bi, si = O.draw_negative_indices(B, S, W, N, generator=torch.Generator().manual_seed(9))
+        ext = O.negative_rows(bi, si, B, S, W, N)
+        leaves = {f"wPrediction.predictors.{k}.weight": heads[k].clone().requires_grad_(True) for k in range(K)}
+        cr = c.clone().requires_grad_(True); zr = z.clone().requires_grad_(True)
+        lr, ar = O.criterion_forward(leaves, cr, zr, ext, K)
+        gl = torch.randn(K)
+        (lr[0] * gl).sum().backward()
+        Np = lib.cpc_nce_padded_negatives(N)
+        assert lib.cpc_nce_layout(B, S, K, N, (ctypes.c_long * 6)()) != 0          # no group set: K > 16 is not one call
+        for apart in (False, True):
+            dc_sum, dz_sum = torch.zeros(B, S, 256), torch.zeros(B, S, 256)
+            for k0 in range(0, K, 16):
+                kg = min(16, K - k0)
+                wall = torch.cat(heads[k0:k0 + kg], dim=0).contiguous()
+                assert lib.cpc_nce_head_group(k0, K) == 0
+                try:
+                    sizes = (ctypes.c_long * 6)()
+                    assert lib.cpc_nce_layout(B, S, kg, N, sizes) == 0
+                    ext_k = torch.full((B, W, Np), -1, dtype=torch.int32)
+                    perm = torch.full((B * W * (Np + kg),), -1, dtype=torch.int32)
+                    row_ptr = torch.full((B * S + 1,), -1, dtype=torch.int32)
+                    work = torch.zeros(B * W * (Np + kg) + 2 * B * S + 2, dtype=torch.int32)
+                    assert lib.cpc_nce_prepare(P(bi), P(si), P(ext_k), P(perm), P(row_ptr), P(work), B, S, kg, N, None) == 0
+                    saved = torch.full((sizes[0],), float("nan")); fscr = torch.full((sizes[1],), float("nan"))
+                    bscr = torch.full((sizes[2],), float("nan"))
+                    losses = torch.full((kg,), float("nan")); acc = torch.full((kg,), float("nan"))
+                    dc = torch.full((B, S, 256), float("nan")); dz = torch.full((B, S, 256), float("nan"))
+                    g_ = gl[k0:k0 + kg].contiguous()
+                    if not apart:
+                        dwall = torch.full((kg * 256, 256), float("nan"))
+                        assert lib.cpc_nce_forward(P(c), P(z), P(wall), P(ext_k), P(saved), P(fscr), P(losses), P(acc), B, S, kg, N,
+                                                   None) == 0
+                        assert lib.cpc_nce_backward(P(c), P(z), P(wall), P(ext_k), P(perm), P(row_ptr), P(saved), P(g_), P(bscr),
+                                                    P(dc), P(dz), P(dwall), B, S, kg, N, None) == 0
+                        ref_dw = torch.cat([leaves[f"wPrediction.predictors.{k}.weight"].grad for k in range(k0, k0 + kg)], dim=0)
+                        assert rel_err(dwall, ref_dw) < 1e-5
+                    else:
+                        pred = (c[:, :W] @ wall.t()).contiguous()                       # (B, W, kg*256)
+                        dpred = torch.full_like(pred, float("nan"))
+                        assert lib.cpc_nce_scores_forward(P(pred), P(z), P(ext_k), P(saved), P(fscr), P(losses), P(acc), B, S, kg, N,
+                                                          None) == 0
+                        assert lib.cpc_nce_scores_backward(P(pred), P(z), P(ext_k), P(perm), P(row_ptr), P(saved), P(g_), P(bscr),
+                                                           P(dpred), P(dz), B, S, kg, N, None) == 0
+                        dc = torch.zeros(B, S, 256)
+                        dc[:, :W] = dpred @ wall
+                finally:
+                    assert lib.cpc_nce_head_group(0, 0) == 0
+                tol = 1e-5 * max(1.0, lr[0].abs().max().item())
+                assert (losses - lr[0, k0:k0 + kg].detach()).abs().max().item() < tol, (k0, losses, lr)
+                assert (acc - ar[0, k0:k0 + kg]).abs().max().item() < 1e-6
+                dc_sum += dc
+                dz_sum += dz
+            assert rel_err(dc_sum, cr.grad) < 1e-5, apart
+            assert rel_err(dz_sum, zr.grad) < 1e-5, apart
+        assert lib.cpc_nce_head_group(3, 2) != 0 and lib.cpc_nce_head_group(-1, 4) != 0 and lib.cpc_nce_head_group(1, 0) != 0
+        assert lib.cpc_nce_head_group(16, 20) == 0
+        assert lib.cpc_nce_layout(B, S, 5, N, (ctypes.c_long * 6)()) != 0          # heads 16..20 of 20: at most 4
+        assert lib.cpc_nce_head_group(0, 0) == 0
+    finally:
+        lib.cpc_nce_head_group(0, 0)
+        lib.cpc_set_nce_fused(1)
+
+
 def test_out_of_range_negative_indices_are_clamped_and_flagged():
     """cpc_nce_prepare validates caller-supplied draws (criterion.py:181-189 draws batchIdx in [0,B), seqIdx in [1,S)):
     an index outside the batch would otherwise count and gather out of bounds.  The device flag is read through

@@ -317,3 +317,79 @@ def test_whole_step_with_100_negatives_matches_the_oracle_on_both_step_paths():
     assert torch.equal(res[0][0], res[1][0])
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+@pytest.mark.parametrize("rnnMode", ["linear", "transformer"])
+def test_whole_step_with_20_prediction_steps_matches_the_oracle(rnnMode):
+    """nPredicts = 20 (criterion.py:225-257 takes any; the score tiles hold 16 heads): the criterion walks the heads in groups
+    (cpc_nce_head_group) -- with 100 negatives on top, so both paddings are in play.  One step through the Trainer (which takes
+    the autograd path: the composite step covers K <= 16) against the oracle's 20-head step: losses, accuracies, every gradient;
+    with transformer predictors (their predictions handed over as a tensor) losses and the gradients in front of them."""
+    dev = _dev()
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
+    B, N, K = 2, 100, 20
+    W = 128 - K
+    p = O.make_params(seed=41, n_predicts=K, head_scale=64.0)
+    wave = O.make_waveform(B, 20480, seed=113)
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    bi, si = O.draw_negative_indices(B, 128, W, N, generator=torch.Generator().manual_seed(29))
+    if rnnMode == "linear":
+        ora = O.train_step(p, wave, bi, si, n_predicts=K, n_neg=N)
+        model, crit = build_model().to(dev), build_criterion(nPredicts=K, negativeSamplingExt=N).to(dev)
+        load_flat_params(model, crit, p)
+        tr = Trainer(model, crit)
+        tr.optimizer.step = tr.optimizer.zero_grad = lambda *a, **k: None           # keep the gradients of the step
+        l, a = tr.step(wave.to(dev), label, negatives=(bi.to(dev), si.to(dev)))
+        torch.cuda.synchronize()
+        assert tr._fused is None
+        assert l.shape == (1, K) and (l.cpu() - ora["losses"]).abs().max().item() < 1e-4
+        assert (a.cpu() - ora["acc"]).abs().max().item() < 1.5 / (B * W)
+        named = dict(model.state_dict(keep_vars=True))
+        named.update(crit.state_dict(keep_vars=True))
+        bad = {}
+        for k, ref in ora["grads"].items():
+            rel = ((named[k].grad.cpu() - ref).norm() / (ref.norm() + 1e-30)).item()
+            if not rel < (5e-3 if k.startswith("gEncoder") else 2e-4):
+                bad[k] = rel
+        assert not bad, bad
+        return
+    from cpc_audio_amd import ops
+    from oracle import transformer_oracle as T
+    for k in range(K):
+        p.pop(f"wPrediction.predictors.{k}.weight")
+        p.update(T.make_layer_params(60 + k, 256, W, False, prefix=f"wPrediction.predictors.{k}.0."))
+    model = build_model().to(dev)
+    crit = build_criterion(nPredicts=K, negativeSamplingExt=N, rnnMode="transformer", transformerDropout=0.0).to(dev)
+    model.load_state_dict({k: v for k, v in p.items() if not k.startswith("wPrediction")}, strict=True)
+    cm = crit.load_state_dict({k: v for k, v in p.items() if k.startswith("wPrediction")}, strict=False)
+    assert not cm.unexpected_keys and all(k.endswith(("Att.z", "Att.mask")) for k in cm.missing_keys), cm
+    ops.debug_last.pop("transformer", None)
+    ops.KEEP_DEBUG = True
+    try:
+        c, z, _ = model(wave.to(dev), None)
+        losses, acc = crit(c, z, None, negatives=(bi.to(dev), si.to(dev)))
+    finally:
+        ops.KEEP_DEBUG = False
+    # the device's ReLU decisions in the K feed-forward blocks, for the oracle (an element within rounding of zero may fall
+    # either way; tests/test_gpu_transformer.py does the same)
+    tmasks = [(saved[sizes[7]: sizes[7] + B * W * 2048].view(B, W, 2048) > 0).cpu() for saved, sizes in ops.debug_last["transformer"]]
+    assert len(tmasks) == K
+    losses.sum().backward()
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    co, zo, _ = O.model_forward(leaves, wave)
+    ext = O.negative_rows(bi, si, B, 128, W, N)
+    lo, ao = O.criterion_forward(leaves, co, zo, ext, K,
+                                 predict=lambda k, cw: T.layer_forward(leaves, cw, prefix=f"wPrediction.predictors.{k}.0.",
+                                                                       relu_override=tmasks[k]))
+    lo.sum().backward()
+    assert (losses.detach().cpu() - lo.detach()).abs().max().item() < 1e-4
+    assert (acc.detach().cpu() - ao).abs().max().item() < 1.5 / (B * W)
+    rel = lambda a_, b_: ((a_ - b_).norm() / (b_.norm() + 1e-30)).item()
+    bad = {}
+    for name, v in crit.named_parameters():
+        r = rel(v.grad.cpu(), leaves[name].grad)
+        if not r < 2e-4:
+            bad[name] = r
+    assert not bad, bad
+    assert rel(model.gAR.baseNet.weight_hh_l1.grad.cpu(), leaves["gAR.baseNet.weight_hh_l1"].grad) < 2e-4
+    assert rel(model.gEncoder.conv4.weight.grad.cpu(), leaves["gEncoder.conv4.weight"].grad) < 5e-3

@@ -343,6 +343,49 @@ def test_prediction_dropout_option_matches_the_oracle_with_the_same_masks():
     assert (le.cpu() - plain).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("mode", ["LSTM", "RNN", "ffd", "conv8"])
+def test_other_prediction_networks_score_through_the_hip_kernels(mode):
+    """criterion.py:63-81 (``--rnnMode LSTM / RNN / ffd / conv4-12``): torch modules with the reference's parameter names
+    (tests/test_abi_symbols.py pins them against the reference's outputs) whose predictions the HIP score kernels take as a
+    tensor.  Losses, accuracies and the gradients of the predictors and of everything in front of the criterion must equal the
+    oracle's with ``predict(k, cw)`` = a CPU copy of head k."""
+    import copy
+    dev = _dev()
+    from cpc_audio_amd.train import build_criterion, build_model, load_flat_params
+    B, K, N, L = 2, 12, 128, 20480
+    S = L // 160
+    W = S - K
+    p = O.make_params(seed=7, head_scale=128.0)
+    model = build_model()
+    torch.manual_seed(3)
+    crit = build_criterion(rnnMode=mode)
+    assert crit.wPrediction.scores_apart
+    lin = build_criterion()                                   # the linear heads only carry the flat parameters' names here
+    load_flat_params(model, lin, p)
+    heads = copy.deepcopy(crit.wPrediction.predictors)        # CPU copies for the oracle
+    model, crit = model.to(dev), crit.to(dev)
+    wave = O.make_waveform(B, L, seed=10)
+    bi, si = O.draw_negative_indices(B, S, W, N, generator=torch.Generator().manual_seed(5))
+    c, z, _ = model(wave.to(dev), None)
+    losses, acc = crit(c, z, None, negatives=(bi.to(dev), si.to(dev)))
+    losses.sum().backward()
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    co, zo, _ = O.model_forward(leaves, wave)
+    ext = O.negative_rows(bi, si, B, S, W, N)
+
+    def predict(k, cw):
+        y = heads[k](cw)
+        return y[0] if isinstance(y, tuple) else y
+    lo, ao = O.criterion_forward(leaves, co, zo, ext, K, predict=predict)
+    lo.sum().backward()
+    assert (losses.detach().cpu() - lo.detach()).abs().max().item() < 1e-4
+    assert (acc.detach().cpu() - ao).abs().max().item() < 2e-3
+    for (name, got), want in zip(crit.wPrediction.predictors.named_parameters(), heads.parameters()):
+        assert _rel(got.grad.cpu(), want.grad) < 2e-4, name
+    assert _rel(model.gAR.baseNet.weight_hh_l1.grad.cpu(), leaves["gAR.baseNet.weight_hh_l1"].grad) < 2e-4
+    assert _rel(model.gEncoder.conv4.weight.grad.cpu(), leaves["gEncoder.conv4.weight"].grad) < 5e-3
+
+
 def test_prediction_dropout_with_torchs_own_masks_trains_through_the_trainer():
     """The real nn.Dropout: the Trainer takes the autograd path (the composite step does not cover it), losses are finite and
     above the no-dropout loss of the same parameters on average."""
