@@ -109,8 +109,55 @@ def pick_concurrent_stream(device, priority, beside):
 # The side streams themselves are per process and device, shared by every StepContext: a second train loop in the process (a
 # second Trainer, the bench's bf16 pass) has nothing to gain from more of them (four hardware queues serve them all).  Two loops on two threads then
 # enqueue on the same side streams: each orders its own work with its own events, the streams only add FIFO order between them.
+# What two threads must NOT share is the MAIN stream: the C side's pooled events are keyed by it (csrc/capi.hip, stream_events),
+# and a record of one thread between another's record and wait re-targets that wait -- with the shared side streams behind
+# it, possibly in a circle.  Every step is therefore issued under a claim on (device, current stream), see issuing_step.
 _side_streams = {}
 _side_streams_lock = threading.Lock()
+_issuing = {}                       # (device index, stream handle) -> [thread ident, depth] while a step is being issued
+_issuing_lock = threading.Lock()
+
+
+class issuing_step:
+    """``with issuing_step(device):`` around the host-side issue of one train step (StepContext.__enter__ .. __exit__, the
+    composite step's calls).  A second thread that starts issuing on the same device AND the same current stream meanwhile
+    gets a RuntimeError instead of a step whose stream order is undefined: concurrent train loops on one device (threaded
+    data-parallel replicas) each need a stream of their own -- ``with torch.cuda.stream(torch.cuda.Stream()):`` around the loop
+    (tests/test_gpu_modules.py::test_two_trainers_on_two_threads_...).  The same thread may nest."""
+
+    def __init__(self, device=None):
+        self.device, self.key = device, None
+
+    def __enter__(self):
+        if not torch.cuda.is_available():
+            return self
+        dev = torch.cuda.current_device() if self.device is None else torch.device(self.device).index
+        if dev is None:
+            dev = torch.cuda.current_device()
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        me = threading.get_ident()
+        with _issuing_lock:
+            held = _issuing.get(key)
+            if held is not None and held[0] != me:
+                raise RuntimeError(f"cpc_audio_amd: two threads are issuing train steps on the same stream of cuda:{dev}; give "
+                                   "every concurrent train loop its own stream (with torch.cuda.stream(torch.cuda.Stream()): ...)")
+            if held is None:
+                _issuing[key] = [me, 1]
+            else:
+                held[1] += 1
+        self.key = key
+        return self
+
+    def __exit__(self, *exc):
+        if self.key is not None:
+            with _issuing_lock:
+                held = _issuing.get(self.key)
+                if held is not None:
+                    held[1] -= 1
+                    if held[1] <= 0:
+                        del _issuing[self.key]
+            self.key = None
+        return False
 
 
 def _new_side_stream(key, device, which):
@@ -203,6 +250,7 @@ class StepContext:
             cur.wait_event(self.wgrad_events.pop())
 
     def __enter__(self):
+        self._claim = issuing_step().__enter__()          # (raises before anything of this context is touched)
         self._prev = getattr(_tls, "ctx", None)
         _tls.ctx = self
         # where the step starts on the caller's stream: side-stream work that depends on nothing of the step (the negative
@@ -216,6 +264,7 @@ class StepContext:
 
     def __exit__(self, et, ev, tb):
         _tls.ctx = self._prev
+        self._claim.__exit__(et, ev, tb)
         if et is not None:
             self.abandon()
         return False

@@ -194,7 +194,8 @@ class CompositeStep:
         ar = m.gAR
         B, _, L = batchData.shape
         K, N, S = cr.nPredicts, cr.negativeSamplingExt, f["S"]
-        with torch.cuda.device(dev):
+        from .ops import issuing_step
+        with torch.cuda.device(dev), issuing_step(dev):
             main = torch.cuda.current_stream(dev)
             side, prep, wst = ctx.side_stream(dev, 0), ctx.side_stream(dev, 1), ctx.side_stream(dev, 2)
             pkey = (B, L, K, N)
@@ -378,7 +379,8 @@ class Trainer:
                 t0 = time.perf_counter()
                 done.pop(0).synchronize()
                 self.wait_seconds = getattr(self, "wait_seconds", 0.0) + (time.perf_counter() - t0)
-        with torch.cuda.device(batchData.device):
+        from .ops import issuing_step
+        with torch.cuda.device(batchData.device), issuing_step(batchData.device):
             losses, acc = self._composite.forward_backward(batchData, negatives,
                                                            prefetch=self.prefetch_negatives and not self._capturing,
                                                            open_tail=self.pipeline_tail and not self._capturing)

@@ -402,3 +402,38 @@ def test_prediction_dropout_with_torchs_own_masks_trains_through_the_trainer():
         first = losses if first is None else first
     assert tr._fused is None                    # never went through cpc_train_step
     assert float(losses.mean()) < float(first.mean())
+
+
+def test_a_second_thread_issuing_on_the_same_stream_is_refused():
+    """ops.issuing_step: the C side's pooled events are keyed by the main stream, so two threads issuing steps on ONE stream of
+    a device at the same time have no defined order (csrc/capi.hip).  The second one gets a RuntimeError that says what to do;
+    the same thread may nest, another stream is fine, and the claim is gone when the step has been issued."""
+    import threading
+    dev = _dev()
+    from cpc_audio_amd import ops
+    seen = {}
+
+    def other(use_own_stream):
+        try:
+            with torch.cuda.device(dev):
+                if use_own_stream:
+                    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                        with ops.issuing_step(dev):
+                            seen[use_own_stream] = "ok"
+                else:
+                    with ops.issuing_step(dev):
+                        seen[use_own_stream] = "ok"
+        except RuntimeError as e:
+            seen[use_own_stream] = str(e)
+
+    with torch.cuda.device(dev), ops.StepContext():
+        with ops.issuing_step(dev):                           # the same thread nests
+            for own in (False, True):
+                t = threading.Thread(target=other, args=(own,))
+                t.start()
+                t.join()
+    assert "its own stream" in seen[False] and seen[True] == "ok", seen
+    t = threading.Thread(target=other, args=(False,))         # ... and afterwards the stream is free again
+    t.start()
+    t.join()
+    assert seen[False] == "ok" and not ops._issuing
