@@ -1602,10 +1602,16 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
         // re-layout, one bf16 MFMA per product, fp32 accumulators and ChannelNorm statistics; z stays fp32
         int rc = conv0_forward_bf16(wave, params[0], params[1], params[2], params[3], saved + e.y[0], saved + e.mean0,
                                     saved + e.rstd[0], B, L, st);
-        if (!rc && t_after_conv0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
+        // In-step timing (cpc_set_step_timing): the side stream's release moves behind the markers, directly in front of layer 1's
+        // launch -- where the untimed step has it relative to that launch.  With two marker packets between the release and the
+        // launch the side stream's kernels get the CUs first and layer 1 measures 290 us instead of 235 in about half of the
+        // timed steps (never in an untimed one: rocprofv3, 45 steps, max 254).
+        const bool timing = step_hooks().timers != nullptr;
+        if (!timing && !rc && t_after_conv0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
         step_timer_mark(1, st);
         if (!join_prep()) return CPC_ERR_ARG;
         step_timer_mark(7, st);
+        if (timing && !rc && t_after_conv0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
         for (int i = 1; i < 5 && !rc; ++i) {
             rc = conv_fwd_dma_bf16(saved + e.y[i - 1], scratch + e.wp[i], params[4 * i + 1], params[4 * i + 2], params[4 * i + 3],
                                    i == 4 ? z : saved + e.y[i], i == 4, saved + e.xhat[i], saved + e.rstd[i], saved + e.szero,
@@ -1617,10 +1623,17 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
     int rc = cpc_conv0_forward_h2(wave, params[0], params[1], params[2], params[3], saved + e.y[0], saved + e.mean0,
                                   saved + e.rstd[0], act_h2(0) ? saved + e.sbound + 1 : nullptr, B, L, stream);
     if (rc) return rc;
-    if (t_after_conv0 && t_event_layer == 0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
+    // In-step timing (cpc_set_step_timing): the side stream's release moves behind the markers, directly in front of layer 1's
+    // launch -- where the untimed step has it relative to that launch.  With two marker packets between the release and the launch
+    // the side stream's kernels get the CUs first and layer 1 measures 290 us instead of 235 in about half of the timed steps
+    // (never in an untimed one: rocprofv3, 45 steps, max 254).
+    const bool timing = step_hooks().timers != nullptr;
+    const bool release0 = t_after_conv0 && t_event_layer == 0;
+    if (!timing && release0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
     step_timer_mark(1, st);
     if (!join_prep()) return CPC_ERR_ARG;
     step_timer_mark(7, st);
+    if (timing && release0 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;
     for (int i = 1; i < 5; ++i) {
         if (i == 2) step_timer_mark(2, st);
         if (i == 2 && t_after_conv0 && t_event_layer == 1 && hipEventRecord(t_after_conv0, st) != hipSuccess) return CPC_ERR_ARG;

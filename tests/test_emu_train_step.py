@@ -202,13 +202,13 @@ def test_open_tail_steps_with_the_weight_preparation_at_the_tail_change_no_bit_e
     and gradient equal bit for bit.  (The emulator runs streams in issue order: this pins the arithmetic -- buffers, parities,
     what is skipped -- not the cross-stream ordering, which tests/test_gpu_fused_step.py checks on hardware.)"""
     lib = emu()
-    B, L, K, N = 2, 2560, 4, 16
+    B, L, K, N = 2, 1920, 4, 16
     _, wave, S, bidx, sidx, plist0 = _setup(B, L, K, N, seed=4)
     sizes = (ctypes.c_long * 8)()
     assert lib.cpc_train_step_layout(B, L, K, N, sizes) == 0
     apart = [ctypes.c_void_p(h) for h in (64, 128, 192)]
 
-    def run(pipelined):
+    def run(pipelined, steps=3):
         plist = [t.clone() for t in plist0]
         ws = torch.full((sizes[0],), float("nan"))
         grads = [torch.full_like(t, float("nan")) for t in plist]
@@ -216,7 +216,7 @@ def test_open_tail_steps_with_the_weight_preparation_at_the_tail_change_no_bit_e
         garr = (ctypes.c_void_p * 29)(*[P(t) for t in grads])
         ones = torch.ones(K)
         res, parity, ready = [], 0, False
-        for step in range(3):
+        for step in range(steps):
             out, hN = torch.full((2, K), float("nan")), torch.full((2, B, 256), float("nan"))
             phases = 3
             if pipelined:
@@ -248,9 +248,9 @@ def test_open_tail_steps_with_the_weight_preparation_at_the_tail_change_no_bit_e
     # in-step timing markers on: same results (the emulator's events carry no time)
     assert lib.cpc_set_step_timing(1) == 0
     try:
-        again = run(True)
+        again = run(True, steps=2)
         us = (ctypes.c_float * 5)()
         assert lib.cpc_get_step_timing(us) == 0
     finally:
         assert lib.cpc_set_step_timing(0) == 0
-    assert torch.equal(again[2][0], ref[2][0])
+    assert torch.equal(again[1][0], ref[1][0])
