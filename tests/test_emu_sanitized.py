@@ -14,22 +14,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
 
 SUBSET = [
-    "tests/test_emu_nce.py::test_nce_forward_backward_emulated[2-20-12-16-1.0-0-1]",
     "tests/test_emu_nce.py::test_nce_forward_backward_emulated[2-21-7-32-3000.0-0-1]",
     "tests/test_emu_nce.py::test_nce_forward_backward_emulated[2-21-7-32-3000.0-0-0]",
     "tests/test_emu_encoder.py::test_encoder_forward_backward_emulated[3-1290-0-734]",
     "tests/test_emu_gru.py::test_persistent_recurrence_in_chunks_of_batch_tiles_emulated",
     "tests/test_emu_nce.py::test_nce_scores_of_foreign_predictions_emulated[2-21-7-32]",
     "tests/test_emu_nce.py::test_out_of_range_negative_indices_are_clamped_and_flagged",
+    "tests/test_emu_nce.py::test_more_than_sixteen_heads_walked_in_groups_emulated[1-41-35-24-1]",
     "tests/test_emu_adam.py",
-    "tests/test_emu_encoder.py::test_encoder_forward_backward_emulated[2-1280-0-3]",
     "tests/test_emu_encoder.py::test_encoder_forward_backward_emulated[1-1370-64-1]",
-    "tests/test_emu_encoder.py::test_encoder_forward_backward_emulated[2-1280-0-34]",
     "tests/test_emu_train_step.py::test_prefetched_index_lists_give_the_same_step_emulated",
     "tests/test_emu_train_step.py::test_composite_step_argument_errors",
     "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[2-131-4-2-1-256-False-0]",
     "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[1-70-8-4-2-256-True-1]",
-    "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[1-300-8-4-2-256-True-4]",
     "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[1-300-8-4-2-256-True-6]",
     "tests/test_emu_gru.py::test_gru_forward_backward_emulated[3-6-2-False]",
     "tests/test_emu_gru.py::test_gru_persistent_equals_stepwise_emulated[3-6-False]",
