@@ -807,8 +807,8 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(const long* __restrict__ 
                                                        int* __restrict__ ext_, int B, int S, int W, int N, int Np) {
     __shared__ int rows[4][kSortMax];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int bt = blockIdx.x * 4 + wv;
-    if (bt >= B * W) return;                             // whole wave
+    // (a wave per window; with a capped grid -- cpc_set_index_prep_groups -- a wave walks several)
+    for (int bt = blockIdx.x * 4 + wv; bt < B * W; bt += gridDim.x * 4) {
     const int b = bt / W, t = bt - b * W;
     int* __restrict__ ext = ext_ + (long)bt * (Np - N);  // (rows below are addressed with pitch N: shift by the padding so far)
     for (int j = N + lane; j < Np; j += 64) ext[(long)bt * N + j] = b * S + t;
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(const long* __restrict__ 
         const int d = (int)((si + t) % S) + (int)bi * S;
         if (sort) rows[wv][j] = d; else ext[(long)bt * N + j] = d;
     }
-    if (!sort) return;
+    if (!sort) continue;
     __builtin_amdgcn_wave_barrier();
     for (int j = lane; j < N; j += 64) {
         const int e = rows[wv][j];
@@ -835,24 +835,26 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(const long* __restrict__ 
         }
         ext[(long)bt * N + rank] = e;
     }
+    __builtin_amdgcn_wave_barrier();                     // (the next window's rows overwrite the tile)
+    }
 }
 
 __global__ __launch_bounds__(256) void nce_index_kernel(const int* __restrict__ ext, int* __restrict__ dest,
                                                         int* __restrict__ count, int B, int S, int W, int K,
                                                         int N, int koff) {
-    const long slot = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)B * W * (N + K);
-    if (slot >= total) return;
-    const int bt = (int)(slot / (N + K)), j = (int)(slot - (long)bt * (N + K));
-    const int b = bt / W, t = bt - b * W;
-    int d;
-    if (j < N) {
-        d = ext[(long)bt * N + j];
-    } else {
-        d = b * S + t + koff + (j - N) + 1;             // positive of head koff + j-N (criterion.py:210-215)
+    for (long slot = (long)blockIdx.x * 256 + threadIdx.x; slot < total; slot += (long)gridDim.x * 256) {
+        const int bt = (int)(slot / (N + K)), j = (int)(slot - (long)bt * (N + K));
+        const int b = bt / W, t = bt - b * W;
+        int d;
+        if (j < N) {
+            d = ext[(long)bt * N + j];
+        } else {
+            d = b * S + t + koff + (j - N) + 1;         // positive of head koff + j-N (criterion.py:210-215)
+        }
+        dest[slot] = d;
+        atomicAdd(&count[d], 1);
     }
-    dest[slot] = d;
-    atomicAdd(&count[d], 1);
 }
 
 // exclusive scan of count[0..n) -> row_ptr[0..n], cursor[0..n) = row_ptr[0..n)   (single workgroup)
@@ -883,13 +885,18 @@ __global__ __launch_bounds__(1024) void nce_scan_kernel(const int* __restrict__ 
 
 __global__ __launch_bounds__(256) void nce_fill_kernel(const int* __restrict__ dest, int* __restrict__ cursor,
                                                        int* __restrict__ perm, long total) {
-    const long slot = (long)blockIdx.x * 256 + threadIdx.x;
-    if (slot >= total) return;
-    const int pos = atomicAdd(&cursor[dest[slot]], 1);
-    perm[pos] = (int)slot;
+    for (long slot = (long)blockIdx.x * 256 + threadIdx.x; slot < total; slot += (long)gridDim.x * 256) {
+        const int pos = atomicAdd(&cursor[dest[slot]], 1);
+        perm[pos] = (int)slot;
+    }
 }
 
 // ------------------------------------------------------------------ host side
+int g_index_prep_groups = -1;  // cpc_set_index_prep_groups: -1 (default) = at most one workgroup per CU and launch, 0 = a workgroup per
+                               // 4 windows / 256 slots, n > 0 = at most n.  The preparation runs beside conv1 / conv2 with ~0.8 ms in
+                               // hand: one resident workgroup per CU walking its share costs the conv layers less than thousands of
+                               // short ones queueing for their CUs (same-box A/B at B = 64: 2.822 vs 2.837 ms per step sustained;
+                               // 128 / 192: 2.830, 384: 2.845, 512: 2.855, 64: 2.99, 16: 3.94 -- then the lists are late)
 int g_nce_fused = 1;       // cpc_set_nce_fused: 1 (default) the one-pass criterion (nce_fwd_fused_kernel: scores and the unit-gradient
                            // dPred from ONE gather pass; linear heads), 0 the two-pass kernels (nce_fwd_kernel + nce_bwd_dpred_kernel)
 
@@ -1108,10 +1115,19 @@ extern "C" int cpc_nce_prepare(const long* batchIdx, const long* seqIdx, int* ex
     int* count = work + total;
     int* cursor = count + rows + 1;
     (void)hipMemsetAsync(count, 0, sizeof(int) * (rows + 1), st);
-    hipLaunchKernelGGL(nce_rows_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, batchIdx, seqIdx, ext, B, S, n.W, n.Nv, N);
-    hipLaunchKernelGGL(nce_index_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ext, dest, count, B, S, n.W, K, N, n.koff);
+    // (cpc_set_index_prep_groups: at most that many workgroups per launch, each walking several windows / slots -- the
+    // preparation runs on a side stream beside the first conv layers and has ~0.8 ms until the criterion needs it)
+    long cap = g_index_prep_groups;
+    if (cap < 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        cap = cus;
+    }
+    const auto capped = [cap](long wgs) { return (unsigned)(cap > 0 ? std::min<long>(wgs, cap) : wgs); };
+    hipLaunchKernelGGL(nce_rows_kernel, dim3(capped(cdiv(n.BW, 4))), dim3(256), 0, st, batchIdx, seqIdx, ext, B, S, n.W, n.Nv, N);
+    hipLaunchKernelGGL(nce_index_kernel, dim3(capped(cdiv(total, 256))), dim3(256), 0, st, ext, dest, count, B, S, n.W, K, N, n.koff);
     hipLaunchKernelGGL(nce_scan_kernel, dim3(1), dim3(1024), 0, st, count, row_ptr, cursor, rows);
-    hipLaunchKernelGGL(nce_fill_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dest, cursor, perm, total);
+    hipLaunchKernelGGL(nce_fill_kernel, dim3(capped(cdiv(total, 256))), dim3(256), 0, st, dest, cursor, perm, total);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -1350,6 +1366,13 @@ extern "C" int cpc_nce_head_group(int k0, int k_total) {
     CPC_RETURN_IF(k0 < 0 || k_total < 0 || (k_total == 0 && k0 != 0) || (k_total > 0 && k0 >= k_total), CPC_ERR_ARG);
     g_head_off = k0;
     g_head_total = k_total;
+    return 0;
+}
+
+// Tuning switch: workgroups per launch of the index preparation (cpc_nce_prepare); -1 = one per CU (default), 0 = uncapped.
+extern "C" int cpc_set_index_prep_groups(int n) {
+    CPC_RETURN_IF(n < -1, CPC_ERR_ARG);
+    g_index_prep_groups = n;
     return 0;
 }
 

@@ -414,6 +414,9 @@ int cpc_nce_backward_dwall(const float* c, const float* saved, float* scratch, f
  * GEMM's weight operand and the weight gradient's reduction, the dz path multiplies the softmax rows the forward leaves per
  * candidate slot.  0: the two-pass kernels.  A forward and its backward run under the same setting. */
 int cpc_set_nce_fused(int on);
+/* Tuning switch: at most n workgroups per launch of cpc_nce_prepare's kernels (each then walks several windows / slots);
+ * -1 (default) = the device's CU count, 0 = one per 4 windows / 256 slots.  Same lists either way. */
+int cpc_set_index_prep_groups(int n);
 
 /* The same criterion for predictions formed by the caller -- any prediction network of
  * cpc/criterion/criterion.py:44-118, e.g. K transformer layers (--rnnMode transformer, :82-88):

@@ -176,6 +176,37 @@ def test_more_than_sixteen_heads_walked_in_groups_emulated(B, S, K, N, fused):
         lib.cpc_set_nce_fused(1)
 
 
+def test_index_preparation_with_a_capped_grid_gives_the_same_lists():
+    """cpc_set_index_prep_groups(n): at most n workgroups per launch of cpc_nce_prepare's kernels, each walking several windows /
+    slots.  ext and row_ptr must be identical, every destination row's slot set too (the order inside a row is set by atomics)."""
+    lib = emu()
+    B, S, K, N = 3, 25, 5, 24
+    W = S - K
+    Np = lib.cpc_nce_padded_negatives(N)
+    bi, si = O.draw_negative_indices(B, S, W, N, generator=torch.Generator().manual_seed(17))
+
+    def prepare(cap):
+        assert lib.cpc_set_index_prep_groups(cap) == 0
+        try:
+            ext = torch.full((B, W, Np), -1, dtype=torch.int32)
+            perm = torch.full((B * W * (Np + K),), -1, dtype=torch.int32)
+            row_ptr = torch.full((B * S + 1,), -1, dtype=torch.int32)
+            work = torch.zeros(B * W * (Np + K) + 2 * B * S + 2, dtype=torch.int32)
+            assert lib.cpc_nce_prepare(P(bi), P(si), P(ext), P(perm), P(row_ptr), P(work), B, S, K, N, None) == 0
+        finally:
+            assert lib.cpc_set_index_prep_groups(-1) == 0
+        return ext, perm, row_ptr
+
+    ref = prepare(0)
+    for cap in (1, 3):
+        got = prepare(cap)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]), cap
+        for r in range(B * S):
+            lo, hi = int(ref[2][r]), int(ref[2][r + 1])
+            assert sorted(got[1][lo:hi].tolist()) == sorted(ref[1][lo:hi].tolist()), (cap, r)
+    assert lib.cpc_set_index_prep_groups(-2) != 0
+
+
 def test_out_of_range_negative_indices_are_clamped_and_flagged():
     """cpc_nce_prepare validates caller-supplied draws (criterion.py:181-189 draws batchIdx in [0,B), seqIdx in [1,S)):
     an index outside the batch would otherwise count and gather out of bounds.  The device flag is read through
