@@ -202,3 +202,13 @@ def test_train_epoch_through_the_composite_step_equals_the_autograd_loop():
             assert (res[0][0][k] == res[1][0][k]).all(), k
         for k in res[0][1]:
             assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+def test_graft_entry_smoke_runs():
+    """__graft_entry__.smoke(): the driver's one-call check (a small train step on cuda:0 against the oracle, tie accounting
+    included) -- run here too, so that an interface change that breaks it fails the suite and not the round-end run."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import importlib
+    entry = importlib.import_module("__graft_entry__")
+    entry.smoke()
