@@ -134,7 +134,7 @@ def test_composite_step_phase_split_and_schedule_switches_change_no_bit_emulated
     """phases 1 then 2 (what a data-parallel rank issues around its early gradient bucket) and every value of
     cpc_set_step_schedule move launches between streams and calls, never arithmetic."""
     lib = emu()
-    B, L, K, N = 2, 2560, 4, 16
+    B, L, K, N = 2, 1920, 4, 16
     p, wave, S, bidx, sidx, plist = _setup(B, L, K, N, seed=1)
     ref = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N)
     # (distinct stream handles take the branches that fork work onto the side streams -- e.g. the conv weight layouts prepared
