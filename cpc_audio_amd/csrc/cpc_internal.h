@@ -98,11 +98,12 @@ extern int g_mfma_mode;
 // per-(device, caller stream) pool of events for the two-stream entry points: [0..4] encoder backward, [5] everything of the
 // weight-gradient stream but layer 1's weight gradient is done (recorded there by the encoder's backward: what a mid gradient
 // bucket / an open-tailed step waits for), [7] layer 1's weight gradient reduced, [8] GRU backward, [9] criterion backward
-// (score gradients -> dz stream), [12..20] the composite train step (train_step.hip), [21] conv1's updated weight and its
+// (score gradients -> dz stream), [10] criterion forward (loss reduction on its own stream), [11] the recurrence's weight gradients
+// when the composite step runs them on the preparation stream, [12..20] the composite train step (train_step.hip), [21] conv1's updated weight and its
 // layouts ready for the next step (cpc_train_step_tail), [22] the same for every other parameter but conv0's, [6] / [23] open
 // tail: the last stand-alone norm backward is done (main) / the batched column sums are (sums stream)
 constexpr int kStreamEvents = 24;
-constexpr int kEvWgradRest = 5, kEvNorm1 = 6, kEvWgrad1 = 7, kEvNextConv1 = 21, kEvNextRest = 22, kEvSums = 23;
+constexpr int kEvWgradRest = 5, kEvNorm1 = 6, kEvWgrad1 = 7, kEvGruWgrad = 11, kEvNextConv1 = 21, kEvNextRest = 22, kEvSums = 23;
 hipEvent_t* stream_events(hipStream_t caller_stream);
 
 // ---- hooks of the composite step into the per-stage entry points (train_step.hip sets them around its calls; per host

@@ -76,6 +76,11 @@ int g_prep_point = 1;     // where the criterion's index preparation is released
 int g_no_early = 0;
 int g_weight_prep_apart = 0;   // 1: the conv weight layouts on the preparation stream beside layer 0 instead of in front of it on main
                                // (measured: +8 us per step -- the 36 us they free on main, layer 0 and layer 1's wait give back)
+int g_gru_wgrad_prep = 1; // 1 (default): the recurrence's weight / bias gradients on the PREPARATION stream, which is idle during the
+                          // backward, instead of in front of the conv layers' on the weight-gradient stream (single-rank steps,
+                          // phases 3; cpc_set_gru_wgrad_stream).  The conv layers' weight gradients then start 0.2 ms earlier and
+                          // layer 2's no longer runs beside layer 1's data gradient: 2.764 against 2.779 ms per step sustained
+                          // (open tail), 2.784 against 2.798 (closed), three alternations each (profiles/r5_ab_gru_wgrad_stream.txt)
 int g_dz_early = 0;       // 1: the dz path on MAIN before the recurrence's backward (which then has the memory system to itself)
                           // instead of beside it on the side stream
 
@@ -106,6 +111,11 @@ void enc_set_weight_prep_stream(hipStream_t st, hipEvent_t done);
 }  // namespace cpc
 
 using namespace cpc;
+
+extern "C" int cpc_set_gru_wgrad_stream(int on_prep) {
+    g_gru_wgrad_prep = on_prep ? 1 : 0;
+    return 0;
+}
 
 extern "C" int cpc_set_step_schedule(int prep_point, int dz_early) {
     CPC_RETURN_IF(prep_point < 0 || prep_point > 3 || dz_early < 0 || dz_early > 7, CPC_ERR_ARG);
@@ -239,8 +249,11 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
         step_timer_mark(5, M);           // (in front of the event that releases the side stream: see cpc_gru_backward_streams)
         CPC_RETURN_IF(!rec(ev[3], M) || !wait(M, ev[2]), CPC_ERR_ARG);
         // recurrence: dx on main, its weight / bias gradients straight into `grads` on the wgrad stream (no join here)
-        rc = cpc_gru_backward_streams(z, h0, gru_p, ws + s.gru_saved, c, dc, coef, ws + s.gru_bscr, dx, gru_g, B, S, 2, M, S2);
+        const bool gru_wgrad_prep = g_gru_wgrad_prep && (phases & 3) == 3 && S1 != M && S1 != S2;
+        rc = cpc_gru_backward_streams(z, h0, gru_p, ws + s.gru_saved, c, dc, coef, ws + s.gru_bscr, dx, gru_g, B, S, 2, M,
+                                      gru_wgrad_prep ? S1 : S2);
         if (rc) return rc;
+        if (gru_wgrad_prep) CPC_RETURN_IF(!rec(pool[kEvGruWgrad], S1), CPC_ERR_ARG);
         // ... and only now, with the persistent recurrence in flight (its 768-thread workgroups could not become resident beside
         // a chip full of gather blocks), the dz path and behind it the heads' gradient on the side stream
         CPC_RETURN_IF(!wait(S0, ev[3]), CPC_ERR_ARG);
@@ -249,6 +262,8 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
             if (rc) return rc;
             CPC_RETURN_IF(!rec(ev[4], S0), CPC_ERR_ARG);
         }
+        // (the heads' weight gradient stays behind the dz path on the side stream: moved behind the recurrence's weight gradients on
+        // the preparation stream -- it needs neither -- it lands beside the short layers' data gradients and costs 40 us, measured)
         rc = cpc_nce_backward_dwall(c, ws + s.nce_saved, ws + s.nce_bscr, dwall, B, S, K, N, S0);
         if (rc) return rc;
         CPC_RETURN_IF(!rec(ev[5], S0), CPC_ERR_ARG);
@@ -261,6 +276,10 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
         rc = cpc_encoder_backward_streams(wave, enc_p, ws + s.enc_saved, z, dz, ws + s.enc_bscr, enc_g, B, L, M, S2);
         if (rc) return rc;          // (joins the wgrad stream -- the recurrence's gradients were queued there before the conv layers')
         CPC_RETURN_IF(!wait(M, ev[5]), CPC_ERR_ARG);
+        // (the recurrence's gradients on the preparation stream: a closed step joins it too; after an open-tailed one the optimiser's
+        // share for them runs on that very stream, behind them)
+        if (g_gru_wgrad_prep && (phases & 3) == 3 && !(phases & 4) && S1 != M && S1 != S2)
+            CPC_RETURN_IF(!wait(M, pool[kEvGruWgrad]), CPC_ERR_ARG);
     }
     return 0;
 }
@@ -310,7 +329,7 @@ extern "C" int cpc_train_step_wait(void* main_stream, int which, void* waiting_s
     hipStream_t w = (hipStream_t)waiting_stream;
     bool ok = true;
     if (which == 0) ok = wait(w, pool[kEvWgradRest]);
-    else if (which == 1) ok = wait(w, pool[kEvWgrad1]) && wait(w, pool[kEvSums]);
+    else if (which == 1) ok = wait(w, pool[kEvWgrad1]) && wait(w, pool[kEvSums]) && wait(w, pool[kEvGruWgrad]);
     else if (which == 2) ok = wait(w, pool[kEvNextConv1]) && wait(w, pool[kEvNextRest]);
     else if (which == 3) ok = wait(w, pool[12 + 5]);
     else ok = wait(w, pool[kEvSums]);

@@ -417,6 +417,10 @@ int cpc_set_nce_fused(int on);
 /* Tuning switch: at most n workgroups per launch of cpc_nce_prepare's kernels (each then walks several windows / slots);
  * -1 (default) = the device's CU count, 0 = one per 4 windows / 256 slots.  Same lists either way. */
 int cpc_set_index_prep_groups(int n);
+/* Tuning switch of the composite step (single-rank calls, phases 3): 1 (default) = the recurrence's weight / bias gradients run on
+ * the preparation stream, which is idle during the backward, instead of in front of the conv layers' on the weight-gradient
+ * stream (0).  Same kernels, same values. */
+int cpc_set_gru_wgrad_stream(int on_prep);
 
 /* The same criterion for predictions formed by the caller -- any prediction network of
  * cpc/criterion/criterion.py:44-118, e.g. K transformer layers (--rnnMode transformer, :82-88):

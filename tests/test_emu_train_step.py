@@ -146,6 +146,13 @@ def test_composite_step_phase_split_and_schedule_switches_change_no_bit_emulated
         assert torch.equal(ref[0], got[0]) and torch.equal(ref[3], got[3]) and torch.equal(ref[4], got[4])
         for a, b in zip(ref[2], got[2]):
             assert torch.equal(a, b), (phases, schedule)
+    # the recurrence's weight gradients on the weight-gradient stream again (cpc_set_gru_wgrad_stream(0)): another stream, the same values
+    assert lib.cpc_set_gru_wgrad_stream(0) == 0               # (1 is the default: the other runs above had them there)
+    try:
+        got = _composite(lib, wave, bidx, sidx, None, 1.0, plist, B, L, K, N, streams=apart)
+    finally:
+        assert lib.cpc_set_gru_wgrad_stream(1) == 0
+    assert torch.equal(ref[0], got[0]) and all(torch.equal(a, b) for a, b in zip(ref[2], got[2]))
 
 
 def test_composite_step_argument_errors():
