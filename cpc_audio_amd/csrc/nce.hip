@@ -825,16 +825,25 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(const long* __restrict__ 
         if (sort) rows[wv][j] = d; else ext[(long)bt * N + j] = d;
     }
     if (!sort) continue;
+    // bitonic sort of the window's rows in the wave's LDS tile, padded to a power of two with a key above every row (equal rows
+    // are indistinguishable, so any sorting network gives the list a stable rank sort gives): 28 compare-exchange stages of one
+    // pair per lane at N = 128, where ranking every element against every other took 2 x 128 LDS reads per lane
+    int P = 64;
+    while (P < N) P <<= 1;
+    for (int j = N + lane; j < P; j += 64) rows[wv][j] = 0x7fffffff;
     __builtin_amdgcn_wave_barrier();
-    for (int j = lane; j < N; j += 64) {
-        const int e = rows[wv][j];
-        int rank = 0;
-        for (int q = 0; q < N; ++q) {
-            const int o = rows[wv][q];
-            rank += (o < e || (o == e && q < j)) ? 1 : 0;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int pr = lane; pr < P / 2; pr += 64) {
+                const int i = ((pr / j) * 2 * j) + (pr % j), q = i + j;      // the pair (i, i ^ j), bit j of i clear
+                const int a = rows[wv][i], c = rows[wv][q];
+                const bool up = (i & k) == 0;
+                if ((a > c) == up) { rows[wv][i] = c; rows[wv][q] = a; }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        ext[(long)bt * N + rank] = e;
     }
+    for (int j = lane; j < N; j += 64) ext[(long)bt * N + j] = rows[wv][j];
     __builtin_amdgcn_wave_barrier();                     // (the next window's rows overwrite the tile)
     }
 }
