@@ -118,7 +118,6 @@ SIGNATURES = {
     "cpc_nce_backward_dwall": (_I, [_P] * 4 + [_I, _I, _I, _I, _P]),
     "cpc_set_nce_fused": (_I, [_I]),
     "cpc_set_index_prep_groups": (_I, [_I]),
-    "cpc_set_index_fused": (_I, [_I]),
     "cpc_set_gru_wgrad_stream": (_I, [_I]),
     "cpc_nce_padded_negatives": (_I, [_I]),
     "cpc_nce_head_group": (_I, [_I, _I]),

@@ -803,11 +803,8 @@ static __device__ unsigned g_nce_bad_index = 0;
 constexpr int kSortMax = 1024;       // negatives per window that are sorted (more: left in draw order)
 // N: negatives per window as drawn; Np >= N: the row pitch of ext -- entries N .. Np-1 are padding (row b*S + t, a valid row; the
 // scoring kernels mask them by POSITION, so the sort below covers the drawn negatives only).
-// count (or NULL): the histogram of destination rows over the window's Np candidates and K positives (what nce_index_kernel
-// did in a pass of its own): the rows are in the wave's hands here.
 __global__ __launch_bounds__(256) void nce_rows_kernel(const long* __restrict__ batchIdx, const long* __restrict__ seqIdx,
-                                                       int* __restrict__ ext_, int B, int S, int W, int N, int Np,
-                                                       int* __restrict__ count, int K, int koff) {
+                                                       int* __restrict__ ext_, int B, int S, int W, int N, int Np) {
     __shared__ int rows[4][kSortMax];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // (a wave per window; with a capped grid -- cpc_set_index_prep_groups -- a wave walks several)
@@ -815,10 +812,6 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(const long* __restrict__ 
     const int b = bt / W, t = bt - b * W;
     int* __restrict__ ext = ext_ + (long)bt * (Np - N);  // (rows below are addressed with pitch N: shift by the padding so far)
     for (int j = N + lane; j < Np; j += 64) ext[(long)bt * N + j] = b * S + t;
-    if (count != nullptr) {
-        if (lane == 0 && Np > N) atomicAdd(&count[b * S + t], Np - N);                     // the padding candidates
-        for (int k = lane; k < K; k += 64) atomicAdd(&count[b * S + t + koff + k + 1], 1);  // the positives (criterion.py:210-215)
-    }
     const bool sort = N <= kSortMax;
     for (int j = lane; j < N; j += 64) {
         const long flat = ((long)b * N + j) * W + t;
@@ -829,7 +822,6 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(const long* __restrict__ 
             bi = bi < 0 ? 0 : (bi >= B ? B - 1 : bi);
         }
         const int d = (int)((si + t) % S) + (int)bi * S;
-        if (count != nullptr) atomicAdd(&count[d], 1);
         if (sort) rows[wv][j] = d; else ext[(long)bt * N + j] = d;
     }
     if (!sort) continue;
@@ -907,23 +899,8 @@ __global__ __launch_bounds__(256) void nce_fill_kernel(const int* __restrict__ d
         perm[pos] = (int)slot;
     }
 }
-// the same from the lists themselves, a wave per window (no destination array, no division per slot): slot bt * (N + K) + j holds
-// candidate j < N of the window (ext, pitch N) or positive j - N
-__global__ __launch_bounds__(256) void nce_fill_rows_kernel(const int* __restrict__ ext, int* __restrict__ cursor,
-                                                            int* __restrict__ perm, int B, int S, int W, int K, int N, int koff) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int bt = blockIdx.x * 4 + wv; bt < B * W; bt += gridDim.x * 4) {
-        const int b = bt / W, t = bt - b * W;
-        for (int j = lane; j < N + K; j += 64) {
-            const int d = j < N ? ext[(long)bt * N + j] : b * S + t + koff + (j - N) + 1;
-            const int pos = atomicAdd(&cursor[d], 1);
-            perm[pos] = bt * (N + K) + j;
-        }
-    }
-}
 
 // ------------------------------------------------------------------ host side
-int g_index_fused = 1;         // cpc_set_index_fused: 1 = destination histogram inside nce_rows_kernel, slot placement a wave per window
 int g_index_prep_groups = -1;  // cpc_set_index_prep_groups: -1 (default) = at most one workgroup per CU and launch, 0 = a workgroup per
                                // 4 windows / 256 slots, n > 0 = at most n.  The preparation runs beside conv1 / conv2 with ~0.8 ms in
                                // hand: one resident workgroup per CU walking its share costs the conv layers less than thousands of
@@ -1156,19 +1133,10 @@ extern "C" int cpc_nce_prepare(const long* batchIdx, const long* seqIdx, int* ex
         cap = cus;
     }
     const auto capped = [cap](long wgs) { return (unsigned)(cap > 0 ? std::min<long>(wgs, cap) : wgs); };
-    if (g_index_fused) {
-        // the histogram of destinations by the kernel that forms the lists, the slot placement by a wave per window from the lists
-        hipLaunchKernelGGL(nce_rows_kernel, dim3(capped(cdiv(n.BW, 4))), dim3(256), 0, st, batchIdx, seqIdx, ext, B, S, n.W, n.Nv, N,
-                           count, K, n.koff);
-        hipLaunchKernelGGL(nce_scan_kernel, dim3(1), dim3(1024), 0, st, count, row_ptr, cursor, rows);
-        hipLaunchKernelGGL(nce_fill_rows_kernel, dim3(capped(cdiv(n.BW, 4))), dim3(256), 0, st, ext, cursor, perm, B, S, n.W, K, N, n.koff);
-    } else {
-    hipLaunchKernelGGL(nce_rows_kernel, dim3(capped(cdiv(n.BW, 4))), dim3(256), 0, st, batchIdx, seqIdx, ext, B, S, n.W, n.Nv, N,
-                       (int*)nullptr, K, n.koff);
+    hipLaunchKernelGGL(nce_rows_kernel, dim3(capped(cdiv(n.BW, 4))), dim3(256), 0, st, batchIdx, seqIdx, ext, B, S, n.W, n.Nv, N);
     hipLaunchKernelGGL(nce_index_kernel, dim3(capped(cdiv(total, 256))), dim3(256), 0, st, ext, dest, count, B, S, n.W, K, N, n.koff);
     hipLaunchKernelGGL(nce_scan_kernel, dim3(1), dim3(1024), 0, st, count, row_ptr, cursor, rows);
     hipLaunchKernelGGL(nce_fill_kernel, dim3(capped(cdiv(total, 256))), dim3(256), 0, st, dest, cursor, perm, total);
-    }
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -1407,12 +1375,6 @@ extern "C" int cpc_nce_head_group(int k0, int k_total) {
     CPC_RETURN_IF(k0 < 0 || k_total < 0 || (k_total == 0 && k0 != 0) || (k_total > 0 && k0 >= k_total), CPC_ERR_ARG);
     g_head_off = k0;
     g_head_total = k_total;
-    return 0;
-}
-
-// Tuning switch (A/B): 0 = the destination histogram and the slot placement as per-slot passes of their own (until round 5).
-extern "C" int cpc_set_index_fused(int on) {
-    g_index_fused = on ? 1 : 0;
     return 0;
 }
 

@@ -417,9 +417,6 @@ int cpc_set_nce_fused(int on);
 /* Tuning switch: at most n workgroups per launch of cpc_nce_prepare's kernels (each then walks several windows / slots);
  * -1 (default) = the device's CU count, 0 = one per 4 windows / 256 slots.  Same lists either way. */
 int cpc_set_index_prep_groups(int n);
-/* 1 (default): cpc_nce_prepare counts the destination rows inside the kernel that forms the lists and places the slots a wave per
- * window; 0: per-slot passes of their own.  Same lists (the order inside a destination row is set by atomics either way). */
-int cpc_set_index_fused(int on);
 /* Tuning switch of the composite step (single-rank calls, phases 3): 1 (default) = the recurrence's weight / bias gradients run on
  * the preparation stream, which is idle during the backward, instead of in front of the conv layers' on the weight-gradient
  * stream (0).  Same kernels, same values. */

@@ -205,16 +205,6 @@ def test_index_preparation_with_a_capped_grid_gives_the_same_lists():
             lo, hi = int(ref[2][r]), int(ref[2][r + 1])
             assert sorted(got[1][lo:hi].tolist()) == sorted(ref[1][lo:hi].tolist()), (cap, r)
     assert lib.cpc_set_index_prep_groups(-2) != 0
-    # ... and with the destination histogram / slot placement as per-slot passes of their own (cpc_set_index_fused(0))
-    assert lib.cpc_set_index_fused(0) == 0
-    try:
-        got = prepare(0)
-    finally:
-        assert lib.cpc_set_index_fused(1) == 0
-    assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
-    for r in range(B * S):
-        lo, hi = int(ref[2][r]), int(ref[2][r + 1])
-        assert sorted(got[1][lo:hi].tolist()) == sorted(ref[1][lo:hi].tolist()), r
 
 
 def test_out_of_range_negative_indices_are_clamped_and_flagged():
