@@ -229,3 +229,44 @@ def test_reference_options_outside_the_hip_geometry_run_on_the_modules_own_torch
     assert CPCAR(256, 256, False, 2).hip and not CPCAR(256, 256, False, 2, mode="LSTM").hip
     c, z, _ = CPCModel(CPCEncoder(64, "ID"), CPCAR(64, 64, False, 1, mode="LSTM"))(wave, None)
     assert c.shape == z.shape == (2, 20, 64)
+
+
+def test_issue_guard_refuses_a_second_thread_on_the_same_stream(monkeypatch):
+    """ops.issuing_step (the claim on (device, current stream) a step is issued under), with torch.cuda stubbed out: the same
+    thread may nest, another thread on the same stream is refused, another stream is fine, and the claim is gone afterwards.
+    (tests/test_gpu_modules.py has the same on real streams.)"""
+    import threading
+    import types
+    import torch
+    from cpc_audio_amd import ops
+    stream_of = {}                                           # thread ident -> fake stream handle
+
+    def current_stream(dev=None):
+        return types.SimpleNamespace(cuda_stream=stream_of.get(threading.get_ident(), 7))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "current_stream", current_stream)
+    seen = {}
+
+    def other(key, own_stream):
+        if own_stream:
+            stream_of[threading.get_ident()] = 11
+        try:
+            with ops.issuing_step(0):
+                seen[key] = "ok"
+        except RuntimeError as e:
+            seen[key] = str(e)
+
+    with ops.issuing_step(0):
+        with ops.issuing_step(0):                            # nesting on one thread
+            for key, own in (("same", False), ("own", True)):
+                t = threading.Thread(target=other, args=(key, own))
+                t.start()
+                t.join()
+        assert ops._issuing                                  # the outer claim is still held
+    assert "its own stream" in seen["same"] and seen["own"] == "ok", seen
+    assert not ops._issuing
+    t = threading.Thread(target=other, args=("after", False))
+    t.start()
+    t.join()
+    assert seen["after"] == "ok" and not ops._issuing
