@@ -44,7 +44,7 @@ def _build(force, OUT, LIB, extra):
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + \
         glob.glob(os.path.join(HERE, "include", "hip", "*.h"))
     hdr_m = max(os.path.getmtime(h) for h in hdrs)
-    flags = ["-O2", "-std=c++17", "-fPIC", "-x", "c++", "-I", os.path.join(HERE, "include"),
+    flags = ["-O2", "-march=native", "-std=c++17", "-fPIC", "-x", "c++", "-I", os.path.join(HERE, "include"),
              "-ffp-contract=off", "-Wno-unused-value", "-Wno-unknown-pragmas", "-Wno-pass-failed",
              "-Wno-unused-variable", *extra]
     jobs, objs = [], []

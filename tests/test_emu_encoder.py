@@ -46,10 +46,11 @@ def _saved_acts(lib, saved, B, L, Ls):
     return out
 
 
-@pytest.mark.parametrize("B,L,bm,mode", [(1, 1370, 64, 1), (3, 1290, 128, 0), (1, 1370, 64, 2),
-                                          (1, 1370, 64, 3), (2, 1280, 0, 32),
-                                          (1, 1370, 0, 132), (2, 1280, 0, 30), (1, 1370, 64, 34),
-                                          (4, 2560, 0, 234), (2, 2560, 32, 334), (4, 2560, 0, 434), (2, 1280, 0, 534), (2, 2560, 0, 634),
+@pytest.mark.parametrize("B,L,bm,mode", [(2, 1280, 0, 1), (1, 1370, 64, 1), (1, 1600, 128, 1), (3, 1290, 128, 0),
+                                          (2, 1280, 0, 0), (1, 1600, 128, 2), (2, 1280, 0, 2), (1, 1370, 64, 2),
+                                          (2, 1280, 0, 3), (1, 1370, 64, 3), (3, 1290, 128, 3), (2, 1280, 0, 32),
+                                          (1, 1370, 0, 132), (2, 1280, 0, 30), (2, 1280, 0, 34), (1, 1370, 64, 34),
+                                          (3, 1290, 128, 34), (4, 2560, 0, 234), (2, 2560, 32, 334), (1, 1370, 64, 334), (4, 2560, 0, 434), (2, 1280, 0, 534), (2, 2560, 0, 634),
                                           (2, 2560, 0, 734), (3, 1290, 0, 734)])
 def test_encoder_forward_backward_emulated(B, L, bm, mode):
     """mode 1: NT GEMMs on the bf16 pipe with 3-piece split operands; mode 0: exact-f32 MFMA; mode 2: fp16 pipe with

@@ -22,11 +22,14 @@ SUBSET = [
     "tests/test_emu_nce.py::test_out_of_range_negative_indices_are_clamped_and_flagged",
     "tests/test_emu_nce.py::test_more_than_sixteen_heads_walked_in_groups_emulated[1-41-35-24-1]",
     "tests/test_emu_adam.py",
+    "tests/test_emu_encoder.py::test_encoder_forward_backward_emulated[2-1280-0-3]",
     "tests/test_emu_encoder.py::test_encoder_forward_backward_emulated[1-1370-64-1]",
+    "tests/test_emu_encoder.py::test_encoder_forward_backward_emulated[2-1280-0-34]",
     "tests/test_emu_train_step.py::test_prefetched_index_lists_give_the_same_step_emulated",
     "tests/test_emu_train_step.py::test_composite_step_argument_errors",
     "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[2-131-4-2-1-256-False-0]",
     "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[1-70-8-4-2-256-True-1]",
+    "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[1-300-8-4-2-256-True-4]",
     "tests/test_emu_encoder.py::test_dma_conv_kernel_matches_the_register_staged_kernel_emulated[1-300-8-4-2-256-True-6]",
     "tests/test_emu_gru.py::test_gru_forward_backward_emulated[3-6-2-False]",
     "tests/test_emu_gru.py::test_gru_persistent_equals_stepwise_emulated[3-6-False]",
