@@ -38,6 +38,21 @@ def build(force=False, sanitize=False):
     return _build(force, OUT, LIB, [])
 
 
+def _host_key(flags):
+    """What the cached objects were compiled for: the compile flags and this host's CPU feature list (-march=native)."""
+    import hashlib
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    cpu = line
+                    break
+    except OSError:
+        pass
+    return hashlib.sha1((" ".join(flags) + "|" + cpu).encode()).hexdigest()
+
+
 def _build(force, OUT, LIB, extra):
     os.makedirs(OUT, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(HERE, "hipemu.cpp")]
@@ -47,6 +62,13 @@ def _build(force, OUT, LIB, extra):
     flags = ["-O2", "-march=native", "-std=c++17", "-fPIC", "-x", "c++", "-I", os.path.join(HERE, "include"),
              "-ffp-contract=off", "-Wno-unused-value", "-Wno-unknown-pragmas", "-Wno-pass-failed",
              "-Wno-unused-variable", *extra]
+    # objects of another flag set or another host (the -march=native code of a machine with other vector units) are stale
+    key, key_file = _host_key(flags), os.path.join(OUT, "host.key")
+    try:
+        with open(key_file) as f:
+            force = force or f.read().strip() != key
+    except OSError:
+        force = True
     jobs, objs = [], []
     for s in srcs:
         o = os.path.join(OUT, os.path.basename(s) + ".o")
@@ -67,6 +89,8 @@ def _build(force, OUT, LIB, extra):
         r = subprocess.run([_cxx(), "-shared", "-fPIC", *extra, *objs, "-o", LIB, "-lpthread"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"emu link failed:\n{r.stderr[-4000:]}")
+    with open(key_file, "w") as f:
+        f.write(key)
     return LIB
 
 
