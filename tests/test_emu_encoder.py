@@ -51,7 +51,7 @@ def _saved_acts(lib, saved, B, L, Ls):
                                           (2, 1280, 0, 3), (1, 1370, 64, 3), (3, 1290, 128, 3), (2, 1280, 0, 32),
                                           (1, 1370, 0, 132), (2, 1280, 0, 30), (2, 1280, 0, 34), (1, 1370, 64, 34),
                                           (3, 1290, 128, 34), (4, 2560, 0, 234), (2, 2560, 32, 334), (1, 1370, 64, 334), (4, 2560, 0, 434), (2, 1280, 0, 534), (2, 2560, 0, 634),
-                                          (2, 2560, 0, 734), (3, 1290, 0, 734)])
+                                          (2, 2560, 0, 734), (3, 1290, 0, 734), (1, 170, 0, 734), (2, 485, 0, 734), (1, 170, 0, 0)])
 def test_encoder_forward_backward_emulated(B, L, bm, mode):
     """mode 1: NT GEMMs on the bf16 pipe with 3-piece split operands; mode 0: exact-f32 MFMA; mode 2: fp16 pipe with
     scaled 2-piece split operands; mode 3 (default): mode 2 + layers 1, 2 on the DMA kernel reading H2 activations

@@ -98,6 +98,61 @@ def _nce_forward_backward(lib, B, S, K, N, scale):
     assert rel_err(dc, cr.grad) < 1e-5 and rel_err(dz, zr.grad) < 1e-5 and rel_err(dwall, ref_dw) < 1e-5
 
 
+@pytest.mark.parametrize("B,S,K,N,fused", [(1, 13, 12, 1, 1), (1, 13, 12, 1, 0), (3, 5, 1, 3, 1), (1, 6, 2, 1040, 1), (1, 6, 2, 1040, 0),
+                                            (2, 9, 16, 5, 1)])
+def test_criterion_at_the_edges_of_its_shapes_emulated(B, S, K, N, fused):
+    """One window per sequence (S = K + 1), a single negative, a single head, more negatives than the per-window sort holds
+    (kSortMax = 1024: such lists stay in draw order), S <= K (no window: refused)."""
+    lib = emu()
+    sizes = (ctypes.c_long * 6)()
+    if S <= K:
+        assert lib.cpc_nce_layout(B, S, K, N, sizes) != 0
+        return
+    assert lib.cpc_set_nce_fused(fused) == 0
+    try:
+        torch.manual_seed(6)
+        W = S - K
+        p = O.make_params(seed=5, n_predicts=K, head_scale=8.0)
+        heads = O.head_weights(p, K)
+        wall = torch.cat(heads, dim=0).contiguous()
+        c = torch.tanh(torch.randn(B, S, 256))
+        z = torch.relu(torch.randn(B, S, 256))
+        bi, si = O.draw_negative_indices(B, S, W, N, generator=torch.Generator().manual_seed(3))
+        ext = O.negative_rows(bi, si, B, S, W, N)
+        Np = lib.cpc_nce_padded_negatives(N)
+        assert lib.cpc_nce_layout(B, S, K, N, sizes) == 0
+        ext_k = torch.full((B, W, Np), -1, dtype=torch.int32)
+        perm = torch.full((B * W * (Np + K),), -1, dtype=torch.int32)
+        row_ptr = torch.full((B * S + 1,), -1, dtype=torch.int32)
+        work = torch.zeros(B * W * (Np + K) + 2 * B * S + 2, dtype=torch.int32)
+        assert lib.cpc_nce_prepare(P(bi), P(si), P(ext_k), P(perm), P(row_ptr), P(work), B, S, K, N, None) == 0
+        got_rows = ext_k[:, :, :N]
+        want_rows = ext.permute(0, 2, 1).to(torch.int32)
+        if N <= 1024:
+            assert torch.equal(got_rows, torch.sort(want_rows, dim=2).values)
+        else:
+            assert torch.equal(got_rows, want_rows)                      # beyond the sort tile: draw order
+        saved = torch.full((sizes[0],), float("nan")); fscr = torch.full((sizes[1],), float("nan"))
+        bscr = torch.full((sizes[2],), float("nan"))
+        losses = torch.full((K,), float("nan")); acc = torch.full((K,), float("nan"))
+        assert lib.cpc_nce_forward(P(c), P(z), P(wall), P(ext_k), P(saved), P(fscr), P(losses), P(acc), B, S, K, N, None) == 0
+        leaves = {f"wPrediction.predictors.{k}.weight": heads[k].clone().requires_grad_(True) for k in range(K)}
+        cr = c.clone().requires_grad_(True); zr = z.clone().requires_grad_(True)
+        lr, ar = O.criterion_forward(leaves, cr, zr, ext, K)
+        assert (losses - lr[0].detach()).abs().max().item() < 1e-5 * max(1.0, lr[0].abs().max().item())
+        assert (acc - ar[0]).abs().max().item() < 1e-6
+        gl = torch.randn(K)
+        (lr[0] * gl).sum().backward()
+        dc = torch.full((B, S, 256), float("nan")); dz = torch.full((B, S, 256), float("nan"))
+        dwall = torch.full((K * 256, 256), float("nan"))
+        assert lib.cpc_nce_backward(P(c), P(z), P(wall), P(ext_k), P(perm), P(row_ptr), P(saved), P(gl), P(bscr), P(dc), P(dz),
+                                    P(dwall), B, S, K, N, None) == 0
+        ref_dw = torch.cat([leaves[f"wPrediction.predictors.{k}.weight"].grad for k in range(K)], dim=0)
+        assert rel_err(dc, cr.grad) < 1e-5 and rel_err(dz, zr.grad) < 1e-5 and rel_err(dwall, ref_dw) < 1e-5
+    finally:
+        lib.cpc_set_nce_fused(1)
+
+
 @pytest.mark.parametrize("B,S,K,N,fused", [(2, 28, 20, 16, 1), (1, 41, 35, 24, 1), (2, 28, 20, 16, 0)])
 def test_more_than_sixteen_heads_walked_in_groups_emulated(B, S, K, N, fused):
     """criterion.py:225-257 takes any nPredicts; the score tiles hold 16 heads.  cpc_nce_head_group(k0, K) makes the following

@@ -21,6 +21,11 @@ SUBSET = [
     "tests/test_emu_nce.py::test_nce_scores_of_foreign_predictions_emulated[2-21-7-32]",
     "tests/test_emu_nce.py::test_out_of_range_negative_indices_are_clamped_and_flagged",
     "tests/test_emu_nce.py::test_more_than_sixteen_heads_walked_in_groups_emulated[1-41-35-24-1]",
+    "tests/test_emu_nce.py::test_criterion_at_the_edges_of_its_shapes_emulated[1-13-12-1-1]",
+    "tests/test_emu_nce.py::test_criterion_at_the_edges_of_its_shapes_emulated[1-6-2-1040-1]",
+    "tests/test_emu_nce.py::test_criterion_at_the_edges_of_its_shapes_emulated[3-5-1-3-1]",
+    "tests/test_emu_train_step.py::test_composite_step_matches_oracle_and_the_stagewise_step_emulated[1-800-2-1-False]",
+    "tests/test_emu_encoder.py::test_encoder_forward_backward_emulated[1-170-0-734]",
     "tests/test_emu_adam.py",
     "tests/test_emu_encoder.py::test_encoder_forward_backward_emulated[2-1280-0-3]",
     "tests/test_emu_encoder.py::test_encoder_forward_backward_emulated[1-1370-64-1]",

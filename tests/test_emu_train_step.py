@@ -62,10 +62,11 @@ def _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N):
     es, gs, ns = (ctypes.c_long * 22)(), (ctypes.c_long * 3)(), (ctypes.c_long * 6)()
     assert lib.cpc_encoder_layout(B, L, es) == 0 and lib.cpc_gru_layout(B, S, 2, gs) == 0 and lib.cpc_nce_layout(B, S, K, N, ns) == 0
     nan = lambda n: torch.full((max(1, n),), float("nan"))
-    ext = torch.zeros(B * W * N, dtype=torch.int32)
-    perm = torch.zeros(B * W * (N + K), dtype=torch.int32)
+    Np = lib.cpc_nce_padded_negatives(N)                      # (the lists are padded to the kernels' 16-wide candidate tile)
+    ext = torch.zeros(B * W * Np, dtype=torch.int32)
+    perm = torch.zeros(B * W * (Np + K), dtype=torch.int32)
     row_ptr = torch.zeros(B * S + 1, dtype=torch.int32)
-    work = torch.zeros(B * W * (N + K) + 2 * B * S + 2, dtype=torch.int32)
+    work = torch.zeros(B * W * (Np + K) + 2 * B * S + 2, dtype=torch.int32)
     assert lib.cpc_nce_prepare(P(bidx), P(sidx), P(ext), P(perm), P(row_ptr), P(work), B, S, K, N, None) == 0
     nsaved = nan(ns[0])
     assert lib.cpc_nce_bounds(None, 1.0, P(wall), P(nsaved), B, S, K, N, None) == 0
@@ -98,7 +99,7 @@ def _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N):
     return torch.stack([losses, acc]), hN, egr + ggr + [dwall], z, c
 
 
-@pytest.mark.parametrize("B,L,K,N,use_h0", [(2, 3200, 4, 16, False), (3, 2880, 5, 32, True)])
+@pytest.mark.parametrize("B,L,K,N,use_h0", [(2, 3200, 4, 16, False), (3, 2880, 5, 32, True), (1, 800, 2, 1, False), (1, 485, 2, 7, True)])
 def test_composite_step_matches_oracle_and_the_stagewise_step_emulated(B, L, K, N, use_h0):
     lib = emu()
     p, wave, S, bidx, sidx, plist = _setup(B, L, K, N)
