@@ -153,7 +153,7 @@ def test_criterion_at_the_edges_of_its_shapes_emulated(B, S, K, N, fused):
         lib.cpc_set_nce_fused(1)
 
 
-@pytest.mark.parametrize("B,S,K,N,fused", [(2, 28, 20, 16, 1), (1, 41, 35, 24, 1), (2, 28, 20, 16, 0)])
+@pytest.mark.parametrize("B,S,K,N,fused", [(2, 28, 20, 16, 1), (1, 41, 35, 24, 1), (2, 28, 20, 16, 0), (1, 19, 17, 5, 1), (1, 34, 32, 16, 1)])
 def test_more_than_sixteen_heads_walked_in_groups_emulated(B, S, K, N, fused):
     """criterion.py:225-257 takes any nPredicts; the score tiles hold 16 heads.  cpc_nce_head_group(k0, K) makes the following
     calls work on heads k0 .. of a K-step criterion (W = S - K windows, positives z[t + k0 + k + 1]): the groups' losses /
