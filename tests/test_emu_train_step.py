@@ -61,7 +61,11 @@ def _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N):
     enc_p, gru_p, wall = plist[:20], plist[20:28], plist[28]
     es, gs, ns = (ctypes.c_long * 22)(), (ctypes.c_long * 3)(), (ctypes.c_long * 6)()
     assert lib.cpc_encoder_layout(B, L, es) == 0 and lib.cpc_gru_layout(B, S, 2, gs) == 0 and lib.cpc_nce_layout(B, S, K, N, ns) == 0
-    nan = lambda n: torch.full((max(1, n),), float("nan"))
+    keep = []                                                # (a scratch tensor must outlive the call that gets its pointer)
+
+    def nan(n):
+        keep.append(torch.full((max(1, n),), float("nan")))
+        return keep[-1]
     Np = lib.cpc_nce_padded_negatives(N)                      # (the lists are padded to the kernels' 16-wide candidate tile)
     ext = torch.zeros(B * W * Np, dtype=torch.int32)
     perm = torch.zeros(B * W * (Np + K), dtype=torch.int32)
@@ -101,8 +105,13 @@ def _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N):
 
 @pytest.mark.parametrize("B,L,K,N,use_h0", [(2, 3200, 4, 16, False), (3, 2880, 5, 32, True), (1, 800, 2, 1, False), (1, 485, 2, 7, True)])
 def test_composite_step_matches_oracle_and_the_stagewise_step_emulated(B, L, K, N, use_h0):
-    lib = emu()
-    p, wave, S, bidx, sidx, plist = _setup(B, L, K, N)
+    check_composite_step(emu(), B, L, K, N, use_h0)
+
+
+def check_composite_step(lib, B, L, K, N, use_h0, seed=0):
+    """One composite step against the oracle (outputs, losses, accuracies, every gradient) and, bit for bit, against the
+    stage-wise entry points (also used by tests/test_emu_shapes.py)."""
+    p, wave, S, bidx, sidx, plist = _setup(B, L, K, N, seed=seed)
     h0 = (0.3 * torch.randn(2, B, 256, generator=torch.Generator().manual_seed(9))) if use_h0 else None
     out, hN, grads, z, c = _composite(lib, wave, bidx, sidx, h0, 0.0 if use_h0 else 1.0, plist, B, L, K, N)
     # ---- the oracle: losses, accuracies, outputs, every gradient
