@@ -33,7 +33,7 @@ def run_layer(lib, p, x, dy, S):
     return out, dx, {k: g for k, g in zip(ORDER, grads) if g is not None}
 
 
-@pytest.mark.parametrize("B,S,abspos", [(2, 128, False), (1, 116, False), (1, 40, False), (1, 128, True), (1, 37, False)])
+@pytest.mark.parametrize("B,S,abspos", [(2, 128, False), (1, 116, False), (1, 40, False), (1, 128, True), (1, 37, False), (1, 1, False), (2, 33, True), (3, 65, False)])
 def test_transformer_layer_forward_backward_emulated(B, S, abspos):
     # (S = 37: not a multiple of four -- the element-wise staging of Krelpos and a ragged last Philox row block)
     lib = emu()
