@@ -956,6 +956,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgReduceJobs j)
     j.dw[q][((long)co * kC + ci) * k + kk] = sum;
 }
 
+// Input steps a data-gradient GEMM never reaches.  Its s phases cover the steps tau = q s + r - p, q <= Lout: up to
+// s (Lout + 1) - p - 1.  A layer input longer than that -- (Lin + 2p - k) % s leaves steps at the end that no output window
+// touches; with this encoder's geometry only layer 1 (k 8, s 4, p 2) can: Lin = 4 Lout + 3 -- has zero gradient there, and the
+// buffer the phases write must say so: rows [first, Lin) of every sequence := 0 (16-byte pieces; row16 = pieces per row).
+__global__ __launch_bounds__(256) void zero_tail_rows_kernel(int4* __restrict__ dst, int Lin, int first, int row16) {
+    const int n = (Lin - first) * row16;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[((long)blockIdx.y * Lin + first) * row16 + i] = make_int4(0, 0, 0, 0);
+}
+static void zero_uncovered_rows(void* dst, int B, int Lin, int Lout, int s, int p, int row_bytes, hipStream_t st) {
+    const int first = s * (Lout + 1) - p;
+    if (first >= Lin) return;
+    const int row16 = row_bytes / 16;
+    hipLaunchKernelGGL(zero_tail_rows_kernel, dim3(cdiv((Lin - first) * row16, 256), B), dim3(256), 0, st,
+                       reinterpret_cast<int4*>(dst), Lin, first, row16);
+}
+
 struct GradPtrs { float* p[12]; };
 // small[i] = [d norm.weight | d norm.bias | d conv.bias] of layer i+1 -> the 12 parameter-gradient tensors
 __global__ __launch_bounds__(256) void small_to_grads_kernel(const float* __restrict__ small, GradPtrs g) {
@@ -1374,8 +1391,10 @@ extern "C" int cpc_conv_layer_dgrad(const float* dx, const float* w, float* wd, 
             dx_amax = w_amax + 1;
         }
     }
-    return conv_dgrad_core(dx, wd, fuse, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, tmp, small3, dx_amax,
-                           dprev_amax, B, Lin, k, s, p, st);
+    const int rc = conv_dgrad_core(dx, wd, fuse, xhat_prev, y_prev, rstd_prev, nw_prev, dprev, colpart, tmp, small3, dx_amax,
+                                   dprev_amax, B, Lin, k, s, p, st);
+    if (rc == 0) zero_uncovered_rows(dprev, B, Lin, Lout, s, p, kC * 4, st);     // input steps no output window touches: gradient 0
+    return rc;
 }
 
 // The dgrad GEMM on a weight already in the dgrad layout (max|w| behind it in the fp16-split mode).
@@ -1817,6 +1836,7 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
             rc = conv_dgrad_dma_bf16(scratch + e.dx[i], saved + e.swd[i], tmpd, saved + e.szero, B, e.L[i - 1], kGeom[i].k,
                                      kGeom[i].s, kGeom[i].p, st);
             if (rc) return rc;
+            zero_uncovered_rows(tmpd, B, e.L[i - 1], e.L[i], kGeom[i].s, kGeom[i].p, kC * 2, st);
             if (i >= 2) norm_bwd(i - 1, tmpd, xin, scratch + e.dx[i - 1]);
         } else if (i >= 2 && (e.dxh2[i] || e.dxh2[i - 1] || (g_unfuse_big && (g_unfuse_big == 2 || pick_bm(B * (e.L[i] + 1)) == 128)))) {
             // the fused ReLU'/ChannelNorm-backward epilogue is latency-bound (row-by-row reductions between the loads); a
@@ -1836,6 +1856,7 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                                      nullptr, nullptr, amax + i * kAmaxSlots, nullptr, B, e.L[i - 1], kGeom[i].k, kGeom[i].s,
                                      kGeom[i].p, st, kAmaxSlots, slots);
             if (rc) return rc;
+            zero_uncovered_rows(tmpd, B, e.L[i - 1], e.L[i], kGeom[i].s, kGeom[i].p, kC * 4, st);      // (none for k 4, s 2, p 1)
             norm_bwd(i - 1, tmpd, xin, scratch + e.dx[i - 1]);
         } else if (i >= 2) {
             rc = conv_dgrad_core(scratch + e.dx[i], saved + e.swd[i], 1, saved + e.xhat[i - 1], xin,
@@ -1851,6 +1872,9 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                                  kGeom[1].s, kGeom[1].p, st, kAmaxSlots);
         }
         if (rc) return rc;
+        // layer 0's output is 4 L1 + 3 steps long for some window lengths (e.g. 978 samples: 195 -> 48): its last step feeds no
+        // window of layer 1 and gets no gradient from the phase GEMMs -- conv0's backward must read a zero row there
+        if (i == 1 && !e.bf16) zero_uncovered_rows(scratch + e.dy0, B, e.L[0], e.L[1], kGeom[1].s, kGeom[1].p, kC * 4, st);
         if (i == 2 && sums_st) {         // (layer 1's norm backward has just been queued: every partial of the sums is final behind it)
             if (hipEventRecord(ev[kEvNorm1], st) != hipSuccess || hipStreamWaitEvent(sums_st, ev[kEvNorm1], 0) != hipSuccess)
                 return CPC_ERR_ARG;

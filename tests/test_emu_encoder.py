@@ -31,8 +31,12 @@ def _params(seed=0):
 def _oracle_encoder(p, wave, dz, relu_override=None):
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("gEncoder")}
     acts = []
-    z = O.encoder_forward(leaves, wave, collect=acts, relu_override=relu_override).permute(0, 2, 1)
-    (z * dz).sum().backward()
+    # (oneDNN off: torch 2.10's oneDNN conv1d backward returns wrong input gradients for the first six steps of every sequence at
+    # some shapes -- e.g. B = 2, C = 256, k 8 / s 4 / p 2, 58 or 121 input steps: 1.6e-2 off its own float64 and native-fp32
+    # results -- which the odd window lengths of this file hit; the reference's shapes and the fixtures' are not among them)
+    with torch.backends.mkldnn.flags(enabled=False):
+        z = O.encoder_forward(leaves, wave, collect=acts, relu_override=relu_override).permute(0, 2, 1)
+        (z * dz).sum().backward()
     return z.detach(), [a.detach().permute(0, 2, 1).contiguous() for a in acts], leaves
 
 
@@ -51,7 +55,11 @@ def _saved_acts(lib, saved, B, L, Ls):
                                           (2, 1280, 0, 3), (1, 1370, 64, 3), (3, 1290, 128, 3), (2, 1280, 0, 32),
                                           (1, 1370, 0, 132), (2, 1280, 0, 30), (2, 1280, 0, 34), (1, 1370, 64, 34),
                                           (3, 1290, 128, 34), (4, 2560, 0, 234), (2, 2560, 32, 334), (1, 1370, 64, 334), (4, 2560, 0, 434), (2, 1280, 0, 534), (2, 2560, 0, 634),
-                                          (2, 2560, 0, 734), (3, 1290, 0, 734), (1, 170, 0, 734), (2, 485, 0, 734), (1, 170, 0, 0)])
+                                          (2, 2560, 0, 734), (3, 1290, 0, 734), (1, 170, 0, 734), (2, 485, 0, 734), (1, 170, 0, 0),
+                                          # 978 / 2594 samples: layer 0's output is 4 L1 + 3 steps long -- its last step feeds no window of
+                                          # layer 1 and must get a ZERO gradient (found by a shape sweep in round 5: it got none);
+                                          # 290 / 2319: shapes at which torch's oneDNN conv backward is wrong (_oracle_encoder)
+                                          (2, 978, 0, 734), (2, 978, 0, 0), (1, 2594, 0, 34), (2, 290, 0, 734), (2, 2319, 0, 3)])
 def test_encoder_forward_backward_emulated(B, L, bm, mode):
     """mode 1: NT GEMMs on the bf16 pipe with 3-piece split operands; mode 0: exact-f32 MFMA; mode 2: fp16 pipe with
     scaled 2-piece split operands; mode 3 (default): mode 2 + layers 1, 2 on the DMA kernel reading H2 activations
