@@ -6,7 +6,7 @@ import random
 import pytest
 
 from emu_util import emu
-from test_emu_train_step import check_composite_step
+from test_emu_train_step import check_composite_step, frames
 
 
 def _shapes(n, seed):
@@ -14,8 +14,8 @@ def _shapes(n, seed):
     out = []
     while len(out) < n:
         B = rng.choice([1, 2, 3, 5])
-        S = rng.randint(3, 14)
-        L = 160 * S + rng.choice([0, 0, 1, 3, 4])              # (still S frames: the extra samples only reach the last taps)
+        L = rng.randint(480, 2300)                             # any window length (--sizeWindow is free in the reference)
+        S = frames(L)
         K = rng.randint(1, min(S - 1, 6))
         N = rng.choice([1, 3, 16, 17, 32, 40])
         out.append((B, L, K, N, rng.random() < 0.5))

@@ -17,11 +17,18 @@ ENC = [f"gEncoder.{n}{i}.{w}" for i in range(5)
 GRU = [f"gAR.baseNet.{n}_l{l}" for l in range(2) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
 
 
+def frames(L):
+    """Encoder output steps for L samples (cpc/model.py:83-92: k 10/8/4/4/4, s 5/4/2/2/2, p 3/2/1/1/1); L // 160 for multiples of 160."""
+    for k, s, p in ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1)):
+        L = (L + 2 * p - k) // s + 1
+    return L
+
+
 def _setup(B, L, K, N, seed=0, head_scale=64.0):
     p = O.make_params(seed=seed, head_scale=head_scale)
     p = {k: v for k, v in p.items() if not k.startswith("wPrediction") or int(k.split(".")[2]) < K}
     wave = O.make_waveform(B, L, seed=5)
-    S = L // 160
+    S = frames(L)
     g = torch.Generator().manual_seed(3)
     bidx, sidx = O.draw_negative_indices(B, S, S - K, N, generator=g)
     wall = torch.cat([p[f"wPrediction.predictors.{k}.weight"] for k in range(K)], 0).contiguous()
@@ -56,7 +63,7 @@ def _composite(lib, wave, bidx, sidx, h0, c_bound, plist, B, L, K, N, phases=(3,
 
 def _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N):
     """The same step through the per-stage entry points, in the order ops.py / train.Trainer issue them."""
-    S = L // 160
+    S = frames(L)
     W = S - K
     enc_p, gru_p, wall = plist[:20], plist[20:28], plist[28]
     es, gs, ns = (ctypes.c_long * 22)(), (ctypes.c_long * 3)(), (ctypes.c_long * 6)()
@@ -115,7 +122,8 @@ def check_composite_step(lib, B, L, K, N, use_h0, seed=0):
     h0 = (0.3 * torch.randn(2, B, 256, generator=torch.Generator().manual_seed(9))) if use_h0 else None
     out, hN, grads, z, c = _composite(lib, wave, bidx, sidx, h0, 0.0 if use_h0 else 1.0, plist, B, L, K, N)
     # ---- the oracle: losses, accuracies, outputs, every gradient
-    ora = O.train_step(p, wave, bidx, sidx, n_predicts=K, n_neg=N, h0=h0)
+    with torch.backends.mkldnn.flags(enabled=False):     # (torch's oneDNN conv backward is wrong at some odd shapes: test_emu_encoder._oracle_encoder)
+        ora = O.train_step(p, wave, bidx, sidx, n_predicts=K, n_neg=N, h0=h0)
     assert (z - ora["z"]).abs().max().item() < 1e-4 and (c - ora["c"]).abs().max().item() < 1e-4
     assert (out[0] - ora["losses"].view(-1)).abs().max().item() < 1e-4
     assert (out[1] - ora["acc"].view(-1)).abs().max().item() < 1.5 / (B * (S - K))
