@@ -279,7 +279,7 @@ def test_dma_conv_kernel_matches_the_register_staged_kernel_emulated(B, Lin, k, 
     assert (y - y_ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("B,L", [(2, 1280), (1, 1370)])
+@pytest.mark.parametrize("B,L", [(2, 1280), (1, 1370), (2, 978)])          # (978: an input step of layer 1 that no window touches)
 def test_bf16_storage_encoder_emulated(B, L):
     """cpc_set_mfma_mode(4), the bf16-storage variant of BASELINE configs[1]: activations y0..y3, the saved xhat1..4 and every
     gradient tensor of the encoder are bf16 (half the bytes), weights are rounded to bf16 by the re-layout, every product
