@@ -220,14 +220,14 @@ def test_prefetched_index_lists_give_the_same_step_emulated():
                               P(hN), B, L, K, N, 3, None, None, None, None) == 2
 
 
-def test_open_tail_steps_with_the_weight_preparation_at_the_tail_change_no_bit_emulated():
+@pytest.mark.parametrize("B,L,K,N", [(2, 1920, 4, 16), (1, 978, 2, 7), (3, 1123, 3, 40)])
+def test_open_tail_steps_with_the_weight_preparation_at_the_tail_change_no_bit_emulated(B, L, K, N):
     """Three consecutive steps, parameters updated in between: (a) every step closed, its weight layouts prepared at its head
     (phases 3) against (b) open tails (phases + 4), the next step's layouts / bounds prepared by cpc_train_step_tail for the
     other parity (phases + 8, alternating + 16), one persistent workspace.  Same kernels on the same values: every loss, output
     and gradient equal bit for bit.  (The emulator runs streams in issue order: this pins the arithmetic -- buffers, parities,
     what is skipped -- not the cross-stream ordering, which tests/test_gpu_fused_step.py checks on hardware.)"""
     lib = emu()
-    B, L, K, N = 2, 1920, 4, 16
     _, wave, S, bidx, sidx, plist0 = _setup(B, L, K, N, seed=4)
     sizes = (ctypes.c_long * 8)()
     assert lib.cpc_train_step_layout(B, L, K, N, sizes) == 0
