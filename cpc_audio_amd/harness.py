@@ -156,24 +156,58 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
     # a third of the host time; its gradients live in a flat buffer (the all-reduce's, or a private one without a process
     # group).  Anything else takes the autograd-driven path below.
     in_flight = []                                        # at most two steps ahead of the GPU (train.Trainer.MAX_IN_FLIGHT)
-    for step, (batch, label) in enumerate(loader):
-        batch, label = _to_device(batch, device), _to_device(label, device)
-        n_ex += batch.size(0)
-        if device.type == "cuda" and len(in_flight) >= 2:
-            in_flight.pop(0).synchronize()
-        if composite is not None and COMPOSITE_STEP and composite.ok(batch):
-            # (open tail: the next step's conv0 under this step's last weight gradient, train.CompositeStep; this loop touches
-            # no parameter between two steps, and joins before it returns)
-            all_losses, all_acc = composite.forward_backward(batch, open_tail=PIPELINE_TAIL)
+    try:
+        for step, (batch, label) in enumerate(loader):
+            batch, label = _to_device(batch, device), _to_device(label, device)
+            n_ex += batch.size(0)
+            if device.type == "cuda" and len(in_flight) >= 2:
+                in_flight.pop(0).synchronize()
+            if composite is not None and COMPOSITE_STEP and composite.ok(batch):
+                # (open tail: the next step's conv0 under this step's last weight gradient, train.CompositeStep; this loop touches
+                # no parameter between two steps, and joins before it returns)
+                all_losses, all_acc = composite.forward_backward(batch, open_tail=PIPELINE_TAIL)
+                if allreduce is not None:
+                    allreduce(mid_wait=composite.mid_wait)
+                if not composite.finish(optimizer):
+                    optimizer.step()
+                optimizer.zero_grad()
+                in_flight.append(torch.cuda.Event())
+                in_flight[-1].record()
+                with torch.no_grad():
+                    l, a = all_losses.mean(dim=0), all_acc.mean(dim=0)
+                    sum_loss = l if sum_loss is None else sum_loss + l
+                    sum_acc = a if sum_acc is None else sum_acc + a
+                n_iter += 1
+                if verbose and (step + 1) % logging_step == 0:
+                    el = time.perf_counter() - t0
+                    print(f"Update {step + 1}: {1000.0 * el / logging_step:.1f} ms per batch, "
+                          f"{1000.0 * el / n_ex:.2f} ms / example, loss {float((sum_loss / n_iter).mean()):.4f}")
+                    t0, n_ex = time.perf_counter(), 0
+                continue
+            if composite is not None:
+                composite.join()
+            try:
+                with step_ctx as sc:                          # side streams for the dz path / weight gradients (ops.StepContext)
+                    prepare_criterion(sc, model, criterion, batch)
+                    c_feature, encoded, label = model(batch, label)
+                    all_losses, all_acc = criterion(c_feature, encoded, label)
+                    if ones is None or ones.shape != all_losses.shape or ones.device != all_losses.device:
+                        ones = torch.ones_like(all_losses)
+                    torch.autograd.backward([all_losses], [ones])  # = all_losses.sum().backward() (train.py:85-87), 3 kernels less
+                    sc.wait()
+            except BaseException:
+                if allreduce is not None:
+                    allreduce.abort()
+                raise
             if allreduce is not None:
-                allreduce(mid_wait=composite.mid_wait)
-            if not composite.finish(optimizer):
-                optimizer.step()
+                allreduce()
+            optimizer.step()
             optimizer.zero_grad()
-            in_flight.append(torch.cuda.Event())
-            in_flight[-1].record()
-            with torch.no_grad():
-                l, a = all_losses.mean(dim=0), all_acc.mean(dim=0)
+            if device.type == "cuda":
+                in_flight.append(torch.cuda.Event())
+                in_flight[-1].record()
+            with torch.no_grad():                             # accumulate on device, no per-step sync
+                l, a = all_losses.detach().mean(dim=0), all_acc.mean(dim=0)
                 sum_loss = l if sum_loss is None else sum_loss + l
                 sum_acc = a if sum_acc is None else sum_acc + a
             n_iter += 1
@@ -182,39 +216,13 @@ def train_epoch(loader, model, criterion, optimizer, scheduler=None, logging_ste
                 print(f"Update {step + 1}: {1000.0 * el / logging_step:.1f} ms per batch, "
                       f"{1000.0 * el / n_ex:.2f} ms / example, loss {float((sum_loss / n_iter).mean()):.4f}")
                 t0, n_ex = time.perf_counter(), 0
-            continue
+    except BaseException:
+        # a loader error, a device error or a KeyboardInterrupt in the middle of an epoch: the open tail of the last step (layer
+        # 1's weight gradient, conv1.weight's update) is taken back by the current stream before the caller's except / finally
+        # reads parameters or optimiser state
         if composite is not None:
             composite.join()
-        try:
-            with step_ctx as sc:                          # side streams for the dz path / weight gradients (ops.StepContext)
-                prepare_criterion(sc, model, criterion, batch)
-                c_feature, encoded, label = model(batch, label)
-                all_losses, all_acc = criterion(c_feature, encoded, label)
-                if ones is None or ones.shape != all_losses.shape or ones.device != all_losses.device:
-                    ones = torch.ones_like(all_losses)
-                torch.autograd.backward([all_losses], [ones])  # = all_losses.sum().backward() (train.py:85-87), 3 kernels less
-                sc.wait()
-        except BaseException:
-            if allreduce is not None:
-                allreduce.abort()
-            raise
-        if allreduce is not None:
-            allreduce()
-        optimizer.step()
-        optimizer.zero_grad()
-        if device.type == "cuda":
-            in_flight.append(torch.cuda.Event())
-            in_flight[-1].record()
-        with torch.no_grad():                             # accumulate on device, no per-step sync
-            l, a = all_losses.detach().mean(dim=0), all_acc.mean(dim=0)
-            sum_loss = l if sum_loss is None else sum_loss + l
-            sum_acc = a if sum_acc is None else sum_acc + a
-        n_iter += 1
-        if verbose and (step + 1) % logging_step == 0:
-            el = time.perf_counter() - t0
-            print(f"Update {step + 1}: {1000.0 * el / logging_step:.1f} ms per batch, "
-                  f"{1000.0 * el / n_ex:.2f} ms / example, loss {float((sum_loss / n_iter).mean()):.4f}")
-            t0, n_ex = time.perf_counter(), 0
+        raise
     if composite is not None:
         composite.join()                                  # parameters and optimiser state are the current stream's again
     if scheduler is not None:

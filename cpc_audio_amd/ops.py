@@ -250,16 +250,24 @@ class StepContext:
             cur.wait_event(self.wgrad_events.pop())
 
     def __enter__(self):
-        self._claim = issuing_step().__enter__()          # (raises before anything of this context is touched)
+        claim = issuing_step()
+        claim.__enter__()                                 # (raises before anything of this context is touched)
+        try:
+            # where the step starts on the caller's stream: side-stream work that depends on nothing of the step (the negative
+            # draws) forks from HERE -- early enough to run beside the encoder, and an explicit fork, which a stream capture
+            # (train.Trainer(graph=True)) needs to see the side stream's work as part of the step
+            begin = None
+            if self.overlap and torch.cuda.is_available():
+                begin = torch.cuda.Event()
+                begin.record()
+        except BaseException as e:
+            # __exit__ does not run when __enter__ raises: give the (device, stream) claim back here, or every other thread
+            # is refused on this stream until the process ends
+            claim.__exit__(type(e), e, e.__traceback__)
+            raise
+        self._claim, self.begin = claim, begin
         self._prev = getattr(_tls, "ctx", None)
         _tls.ctx = self
-        # where the step starts on the caller's stream: side-stream work that depends on nothing of the step (the negative
-        # draws) forks from HERE -- early enough to run beside the encoder, and an explicit fork, which a stream capture
-        # (train.Trainer(graph=True)) needs to see the side stream's work as part of the step
-        self.begin = None
-        if self.overlap and torch.cuda.is_available():
-            self.begin = torch.cuda.Event()
-            self.begin.record()
         return self
 
     def __exit__(self, et, ev, tb):

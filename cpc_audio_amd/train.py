@@ -63,7 +63,21 @@ class CompositeStep:
     def join(self):
         """The current stream waits for the tail of the last open-tailed step (no host synchronisation)."""
         f = self.tables
-        if f is not None and f.get("open"):
+        if f is None:
+            return
+        # whoever joins is about to touch parameters outside the composite -- possibly through raw pointers (optim.Adam's
+        # launches do not bump torch's version counters): the layouts the tail prepared are not trusted afterwards, the next
+        # composite step prepares its own (one ~45 us preparation per join, i.e. per epoch / validation pass)
+        f["ready"] = None
+        if f.get("tail"):
+            # forward_backward(open_tail=True) whose finish() never ran (an exception in between): close the tail
+            from . import _lib
+            dev = f["ws"].device
+            with torch.cuda.device(dev):
+                _lib.get().check(_lib.get().cpc_train_step_wait(f["main"], 1, torch.cuda.current_stream(dev).cuda_stream),
+                                 "train_step_wait")
+            f["tail"] = False
+        if f.get("open"):
             from . import _lib
             dev = f["ws"].device
             with torch.cuda.device(dev):
@@ -123,7 +137,10 @@ class CompositeStep:
         if not (type(m) is CPCModel and type(m.gEncoder) is CPCEncoder and type(m.gAR) is CPCAR
                 and type(cr) is CPCUnsupersivedCriterion):
             return False
-        for mod in list(m.modules()) + list(cr.modules()):
+        mods = self.__dict__.get("_mods")
+        if mods is None or mods[0] is not m or mods[1] is not cr:       # (the module tree of a CPCModel / criterion is fixed)
+            mods = self._mods = (m, cr, list(m.modules()) + list(cr.modules()))
+        for mod in mods[2]:
             if (mod._forward_hooks or mod._forward_pre_hooks or mod._backward_hooks or mod._backward_pre_hooks
                     or getattr(mod, "parametrizations", None)):
                 return False
@@ -381,12 +398,19 @@ class Trainer:
                 self.wait_seconds = getattr(self, "wait_seconds", 0.0) + (time.perf_counter() - t0)
         from .ops import issuing_step
         with torch.cuda.device(batchData.device), issuing_step(batchData.device):
-            losses, acc = self._composite.forward_backward(batchData, negatives,
-                                                           prefetch=self.prefetch_negatives and not self._capturing,
-                                                           open_tail=self.pipeline_tail and not self._capturing)
-            self.allreduce(mid_wait=self._composite.mid_wait)
-            if not self._composite.finish(self.optimizer):
-                self.optimizer.step()
+            try:
+                losses, acc = self._composite.forward_backward(batchData, negatives,
+                                                               prefetch=self.prefetch_negatives and not self._capturing,
+                                                               open_tail=self.pipeline_tail and not self._capturing)
+                self.allreduce(mid_wait=self._composite.mid_wait)
+                if not self._composite.finish(self.optimizer):
+                    self.optimizer.step()
+            except BaseException:
+                # a step that dies between forward_backward(open_tail=True) and finish() leaves layer 1's weight gradient on
+                # its stream: the current stream takes it back before anybody's except / finally reads parameters
+                if not self._capturing:
+                    self._composite.join()
+                raise
             self.optimizer.zero_grad()
             if throttle:
                 ev = torch.cuda.Event()

@@ -37,16 +37,21 @@ def _setup(B, L, K, N, seed=0, head_scale=64.0):
 
 
 def _composite(lib, wave, bidx, sidx, h0, c_bound, plist, B, L, K, N, phases=(3,), schedule=_L.DEFAULT_STEP_SCHEDULE,
-               streams=(None, None, None, None)):
+               streams=(None, None, None, None), device=None):
+    """device: None = host tensors (the emulator library); a cuda device = the product library on hardware
+    (tests/test_gpu_shapes.py), results brought back to the host."""
     sizes = (ctypes.c_long * 8)()
     assert lib.cpc_train_step_layout(B, L, K, N, sizes) == 0
-    ws = torch.full((sizes[0],), float("nan"))
+    if device is not None:
+        wave, bidx, sidx, plist = wave.to(device), bidx.to(device), sidx.to(device), [t.to(device) for t in plist]
+        h0 = None if h0 is None else h0.to(device)
+    ws = torch.full((sizes[0],), float("nan"), device=device)
     grads = [torch.full_like(t, float("nan")) for t in plist]
     parr = (ctypes.c_void_p * 29)(*[P(t) for t in plist])
     garr = (ctypes.c_void_p * 29)(*[P(t) for t in grads])
-    out = torch.full((2, K), float("nan"))
-    hN = torch.full((2, B, 256), float("nan"))
-    ones = torch.ones(K)
+    out = torch.full((2, K), float("nan"), device=device)
+    hN = torch.full((2, B, 256), float("nan"), device=device)
+    ones = torch.ones(K, device=device)
     assert lib.cpc_set_step_schedule(*schedule) == 0
     try:
         for ph in phases:
@@ -56,28 +61,33 @@ def _composite(lib, wave, bidx, sidx, h0, c_bound, plist, B, L, K, N, phases=(3,
     finally:
         lib.cpc_set_step_schedule(*_L.DEFAULT_STEP_SCHEDULE)
     S = sizes[3]
+    if device is not None:
+        torch.cuda.synchronize(device)
     z = ws[sizes[1]:sizes[1] + B * S * 256].view(B, S, 256).clone()
     c = ws[sizes[2]:sizes[2] + B * S * 256].view(B, S, 256).clone()
-    return out, hN, grads, z, c
+    return out.cpu(), hN.cpu(), [g.cpu() for g in grads], z.cpu(), c.cpu()
 
 
-def _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N):
+def _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N, device=None):
     """The same step through the per-stage entry points, in the order ops.py / train.Trainer issue them."""
     S = frames(L)
     W = S - K
+    if device is not None:
+        wave, bidx, sidx, plist = wave.to(device), bidx.to(device), sidx.to(device), [t.to(device) for t in plist]
+        h0 = None if h0 is None else h0.to(device)
     enc_p, gru_p, wall = plist[:20], plist[20:28], plist[28]
     es, gs, ns = (ctypes.c_long * 22)(), (ctypes.c_long * 3)(), (ctypes.c_long * 6)()
     assert lib.cpc_encoder_layout(B, L, es) == 0 and lib.cpc_gru_layout(B, S, 2, gs) == 0 and lib.cpc_nce_layout(B, S, K, N, ns) == 0
     keep = []                                                # (a scratch tensor must outlive the call that gets its pointer)
 
     def nan(n):
-        keep.append(torch.full((max(1, n),), float("nan")))
+        keep.append(torch.full((max(1, n),), float("nan"), device=device))
         return keep[-1]
     Np = lib.cpc_nce_padded_negatives(N)                      # (the lists are padded to the kernels' 16-wide candidate tile)
-    ext = torch.zeros(B * W * Np, dtype=torch.int32)
-    perm = torch.zeros(B * W * (Np + K), dtype=torch.int32)
-    row_ptr = torch.zeros(B * S + 1, dtype=torch.int32)
-    work = torch.zeros(B * W * (Np + K) + 2 * B * S + 2, dtype=torch.int32)
+    ext = torch.zeros(B * W * Np, dtype=torch.int32, device=device)
+    perm = torch.zeros(B * W * (Np + K), dtype=torch.int32, device=device)
+    row_ptr = torch.zeros(B * S + 1, dtype=torch.int32, device=device)
+    work = torch.zeros(B * W * (Np + K) + 2 * B * S + 2, dtype=torch.int32, device=device)
     assert lib.cpc_nce_prepare(P(bidx), P(sidx), P(ext), P(perm), P(row_ptr), P(work), B, S, K, N, None) == 0
     nsaved = nan(ns[0])
     assert lib.cpc_nce_bounds(None, 1.0, P(wall), P(nsaved), B, S, K, N, None) == 0
@@ -93,7 +103,7 @@ def _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N):
     assert lib.cpc_nce_forward_prepared(P(c), P(z), P(wall), P(ext), P(nsaved), P(nan(ns[1])), P(losses), P(acc), B, S, K, N,
                                         None) == 0
     nscr, dc, dz, dwall = nan(ns[2]), torch.full_like(c, float("nan")), torch.full_like(z, float("nan")), torch.full_like(wall, float("nan"))
-    ones = torch.ones(K)
+    ones = torch.ones(K, device=device)
     assert lib.cpc_nce_backward_streams(P(c), P(z), P(wall), P(ext), P(perm), P(row_ptr), P(nsaved), P(ones), P(nscr), P(dc), None,
                                         None, B, S, K, N, None, None) == 0
     dx = torch.full_like(z, float("nan"))
@@ -107,7 +117,9 @@ def _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N):
     egr = [torch.full_like(t, float("nan")) for t in enc_p]
     egarr = (ctypes.c_void_p * 20)(*[P(t) for t in egr])
     assert lib.cpc_encoder_backward_streams(P(wave), earr, P(esaved), P(z), P(dzt), P(nan(es[2])), egarr, B, L, None, None) == 0
-    return torch.stack([losses, acc]), hN, egr + ggr + [dwall], z, c
+    if device is not None:
+        torch.cuda.synchronize(device)
+    return torch.stack([losses, acc]).cpu(), hN.cpu(), [g.cpu() for g in egr + ggr + [dwall]], z.cpu(), c.cpu()
 
 
 @pytest.mark.parametrize("B,L,K,N,use_h0", [(2, 3200, 4, 16, False), (3, 2880, 5, 32, True), (1, 800, 2, 1, False), (1, 485, 2, 7, True)])
@@ -115,12 +127,13 @@ def test_composite_step_matches_oracle_and_the_stagewise_step_emulated(B, L, K, 
     check_composite_step(emu(), B, L, K, N, use_h0)
 
 
-def check_composite_step(lib, B, L, K, N, use_h0, seed=0):
+def check_composite_step(lib, B, L, K, N, use_h0, seed=0, device=None):
     """One composite step against the oracle (outputs, losses, accuracies, every gradient) and, bit for bit, against the
-    stage-wise entry points (also used by tests/test_emu_shapes.py)."""
+    stage-wise entry points (also used by tests/test_emu_shapes.py and, with a cuda ``device`` and the product library, by
+    tests/test_gpu_shapes.py)."""
     p, wave, S, bidx, sidx, plist = _setup(B, L, K, N, seed=seed)
     h0 = (0.3 * torch.randn(2, B, 256, generator=torch.Generator().manual_seed(9))) if use_h0 else None
-    out, hN, grads, z, c = _composite(lib, wave, bidx, sidx, h0, 0.0 if use_h0 else 1.0, plist, B, L, K, N)
+    out, hN, grads, z, c = _composite(lib, wave, bidx, sidx, h0, 0.0 if use_h0 else 1.0, plist, B, L, K, N, device=device)
     # ---- the oracle: losses, accuracies, outputs, every gradient
     with torch.backends.mkldnn.flags(enabled=False):     # (torch's oneDNN conv backward is wrong at some odd shapes: test_emu_encoder._oracle_encoder)
         ora = O.train_step(p, wave, bidx, sidx, n_predicts=K, n_neg=N, h0=h0)
@@ -142,7 +155,7 @@ def check_composite_step(lib, B, L, K, N, use_h0, seed=0):
     assert not bad, bad
     # ---- bit-identical to the stage-by-stage issue order of the Python loop (its a-priori |c| bound needs h0 = None)
     if not use_h0:
-        out2, hN2, grads2, z2, c2 = _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N)
+        out2, hN2, grads2, z2, c2 = _stagewise(lib, wave, bidx, sidx, h0, plist, B, L, K, N, device=device)
         assert torch.equal(out, out2) and torch.equal(hN, hN2) and torch.equal(z, z2) and torch.equal(c, c2)
         for n, a, b in zip(names + ["wall"], grads, grads2):
             assert torch.equal(a, b), n

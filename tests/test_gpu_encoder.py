@@ -28,7 +28,7 @@ def _names():
             for n, w in (("conv", "weight"), ("conv", "bias"), ("batchNorm", "weight"), ("batchNorm", "bias"))]
 
 
-def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None):
+def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None, onednn=True):
     from cpc_audio_amd._lib import ptr as P
     h2_layers, stages, small_pipe = 0, 2, 0
     nsplit = 1 if mode == 634 else 0             # 634: + the short layers' data gradients on 128 x 128 tiles (cpc_set_dgrad_nsplit)
@@ -94,12 +94,15 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None):
     # ReLU derivative of numerically tied pre-activations follows the device path (see oracle)
     ys = [t.cpu() for t in ys] + [z.cpu()]
     O.tie_report()
-    zr = O.encoder_forward(leaves, wave, collect=acts,
-                           relu_override=[(y > 0).permute(0, 2, 1) for y in ys]).permute(0, 2, 1)
-    ties = O.tie_report()                    # (how many elements took the device's ReLU derivative: oracle.tie_report)
-    print(f"relu ties [B={B} L={L} mode={mode}]: {ties}")
-    assert O.tie_ok(ties) and ties["disagree_outside"] == 0, ties
-    (zr * dz).sum().backward()
+    # onednn=False (tests/test_gpu_shapes.py): torch 2.10's oneDNN conv1d backward returns wrong input gradients for the first
+    # six steps of every sequence at some odd lengths (tests/test_emu_encoder._oracle_encoder); the fixtures' shapes are unaffected
+    with torch.backends.mkldnn.flags(enabled=onednn):
+        zr = O.encoder_forward(leaves, wave, collect=acts,
+                               relu_override=[(y > 0).permute(0, 2, 1) for y in ys]).permute(0, 2, 1)
+        ties = O.tie_report()                    # (how many elements took the device's ReLU derivative: oracle.tie_report)
+        print(f"relu ties [B={B} L={L} mode={mode}]: {ties}")
+        assert O.tie_ok(ties) and ties["disagree_outside"] == 0, ties
+        (zr * dz).sum().backward()
     return dict(z=z.cpu(), z_ref=zr.detach(), grads=[g_.cpu() for g_ in grads],
                 ref_grads=[leaves[n].grad for n in _names()], saved=saved, sizes=sizes, Ls=Ls, acts=acts, ys=ys)
 

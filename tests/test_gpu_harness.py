@@ -212,3 +212,57 @@ def test_graft_entry_smoke_runs():
     import importlib
     entry = importlib.import_module("__graft_entry__")
     entry.smoke()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "sequential", "samespeaker", "samesequence"])
+@pytest.mark.parametrize("offset_on", [False, True])
+def test_device_window_plans_against_the_reference_fixture(tmp_path, kind, offset_on):
+    """The device-resident data path against what the REFERENCE's AudioBatchData / samplers / loaders produced on the same
+    corpus (tests/golden/dataset.json, oracle/make_golden_dataset.py; cpc/dataset.py:20-258,318-408): boundaries, the plan of a
+    pass at the reference's own random offset -- bit-equal for 'sequential', the same window grid / whole batches for 'uniform'
+    (another generator), per interval the same windows and batch sizes for the grouped types (order random in both) -- and
+    every served batch's samples and speaker labels."""
+    dev = _dev()
+    from test_dataset_golden import GOLD, W, _load, check_grouped, interval_of, write_corpus
+    write_corpus(tmp_path)
+    g = GOLD["one_pack"]
+    ds = _load(tmp_path).to(dev)
+    assert ds.data.is_cuda and ds.data.numel() == g["n_samples"]
+    assert [int(x) for x in ds.speakerLabel] == g["speakerLabel"] and [int(x) for x in ds.seqLabel] == g["seqLabel"]
+    assert float(ds.data.double().sum()) == g["sum"]
+    ref = [b["starts"] for b in g["loaders"][f"{kind}/{int(offset_on)}"]["batches"]]
+    bounds = g["speakerLabel"] if kind != "samesequence" else g["seqLabel"]
+    if kind in ("uniform", "sequential"):
+        offset = min(x for b in ref for x in b)                                        # the first window of the pack starts at it
+    else:
+        offset = min(x - bounds[interval_of(bounds, x)] for b in ref for x in b)
+    assert (offset > 0) == offset_on
+    plan = ds.window_plan(kind, 3, offset)
+    assert plan.starts.is_cuda
+    served = plan.batches()
+    if kind == "sequential":
+        assert served == ref
+    elif kind == "uniform":
+        flat = [x for b in served for x in b]
+        n_win = g["n_samples"] // W - (1 if offset > 0 else 0)
+        assert len(served) == len(ref) and all(len(b) == 3 for b in served) and len(set(flat)) == len(flat)
+        assert set(flat) <= {offset + W * i for i in range(n_win)} and {x for b in ref for x in b} <= {offset + W * i for i in range(n_win)}
+    else:
+        check_grouped(served, ref, bounds, 3)
+    host = ds.data.cpu()
+    for index in plan:
+        batch, labels = ds.get_batch(index)
+        assert batch.is_cuda and labels.is_cuda
+        for row, s in enumerate(index.tolist()):
+            assert torch.equal(batch[row, 0].cpu(), host[s:s + W])
+            assert int(labels[row]) == interval_of(g["speakerLabel"], s)               # cpc/dataset.py:181-183 on the reference's bounds
+
+
+def test_chunked_feature_extraction_on_the_device_against_the_reference_fixture():
+    """build_feature with the waveform and the recording feature maker on the GPU: the chunks cpc/feature_loader.py:228-269 cut
+    and the features it returned (tests/golden/harness.json), incl. strict tails that keep 0 frames' worth and files shorter
+    than a chunk."""
+    dev = _dev()
+    from test_harness_golden import GOLD as HG, check_chunks
+    for case in HG["chunks"]:
+        check_chunks(case, device=dev)
