@@ -36,7 +36,10 @@ def bf16_mode():
     cpc_audio_amd.set_activation_storage("fp32")
 
 
-@pytest.mark.parametrize("B,L", [(8, 20480), (1, 4330), (64, 20480)])
+# (3, 978) / (2, 20494): window lengths whose layer-0 output is 4 L1 + 3 steps long -- the last step feeds no window of layer 1 and its
+# gradient row is zero-filled (enc_conv.hip: zero_uncovered_rows, the bf16 branch); oracle with oneDNN off there (torch's oneDNN conv
+# backward is wrong at some odd lengths, tests/test_gpu_shapes.py)
+@pytest.mark.parametrize("B,L", [(8, 20480), (1, 4330), (64, 20480), (3, 978), (2, 20494)])
 def test_bf16_storage_encoder_against_the_fp32_oracle(bf16_mode, B, L):
     dev = _dev()
     from cpc_audio_amd import _lib
@@ -73,9 +76,10 @@ def test_bf16_storage_encoder_against_the_fp32_oracle(bf16_mode, B, L):
     # the fp32 oracle at the same size (B = 64 included: the variant's quoted configuration), layer by layer
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("gEncoder")}
     acts = []
-    zr = O.encoder_forward(leaves, wave, collect=acts, relu_override=[(y > 0).permute(0, 2, 1) for y in ys + [z.cpu()]],
-                           tie_eps=0.08).permute(0, 2, 1)
-    (zr * dz).sum().backward()
+    with torch.backends.mkldnn.flags(enabled=(L % 160 == 0 or L == 4330)):
+        zr = O.encoder_forward(leaves, wave, collect=acts, relu_override=[(y > 0).permute(0, 2, 1) for y in ys + [z.cpu()]],
+                               tie_eps=0.08).permute(0, 2, 1)
+        (zr * dz).sum().backward()
     layer_rel = [_rel(ys[i], acts[i].detach().permute(0, 2, 1)) for i in range(4)] + [_rel(z.cpu(), zr.detach())]
     err = (z.cpu() - zr.detach()).abs().max().item()
     grad_rel = {n: _rel(g.cpu().view_as(leaves[n].grad), leaves[n].grad) for n, g in zip(names, grads)}

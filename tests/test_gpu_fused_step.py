@@ -224,10 +224,11 @@ def test_open_tailed_steps_equal_the_closed_steps_bit_for_bit(B, steps):
                 with torch.no_grad():
                     model.gEncoder.conv1.weight.mul_(1.0009765625)
                     model.gEncoder.batchNorm0.weight.mul_(1.03125)
-        tr.join()
-        torch.cuda.synchronize()
         f = tr._fused
-        assert f is not None and (f["ready"] is not None) == pipe
+        assert f is not None and (f["ready"] is not None) == pipe          # (the tail really was open: layouts prepared for the next step)
+        tr.join()
+        assert f["ready"] is None        # whoever joined may change parameters through raw pointers: the layouts are not trusted afterwards
+        torch.cuda.synchronize()
         from cpc_audio_amd import ops
         ops.check_device_errors()
         res.append((torch.stack(losses).cpu(), _state(model, crit), tr.optimizer.state_dict()))
@@ -239,6 +240,42 @@ def test_open_tailed_steps_equal_the_closed_steps_bit_for_bit(B, steps):
     for i in s0:
         assert float(s0[i]["step"]) == float(s1[i]["step"]) == steps
         assert torch.equal(s0[i]["exp_avg"], s1[i]["exp_avg"]) and torch.equal(s0[i]["exp_avg_sq"], s1[i]["exp_avg_sq"])
+
+
+def test_an_autograd_step_between_open_tailed_composite_steps_does_not_leave_stale_weight_layouts():
+    """Round-5 advice: an open-tailed composite step prepares the NEXT step's weight layouts at its tail and marks them ready by
+    torch's version counters -- which this package's Adam (raw pointers) never bumps.  If the next step takes the autograd path
+    (here: ops.KEEP_DEBUG for one step) and updates every weight, a following composite step must not run on the layouts prepared
+    two updates ago.  join() now drops them; the trajectory equals the closed-tail Trainer's bit for bit."""
+    dev = _dev()
+    from cpc_audio_amd import ops
+    from cpc_audio_amd.train import Trainer, build_criterion, build_model, load_flat_params
+    B, steps = 4, 6
+    p = O.make_params(seed=39, head_scale=64.0)
+    waves = [O.make_waveform(B, 20480, seed=80 + i).to(dev) for i in range(steps)]
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    res = []
+    for pipe in (False, True):
+        model, crit = build_model().to(dev), build_criterion().to(dev)
+        load_flat_params(model, crit, p)
+        tr = Trainer(model, crit, lr=2e-3, pipeline_tail=pipe)               # (a large step: stale layouts move the losses visibly)
+        torch.manual_seed(6)
+        losses = []
+        for i in range(steps):
+            ops.KEEP_DEBUG = i == 2                                         # step 2 on the autograd path (CompositeStep.ok() refuses)
+            try:
+                l, a = tr.step(waves[i], label)
+            finally:
+                ops.KEEP_DEBUG = False
+            losses.append(torch.cat([l, a]))
+        tr.join()
+        torch.cuda.synchronize()
+        ops.check_device_errors()
+        res.append((torch.stack(losses).cpu(), _state(model, crit)))
+        del tr, model, crit
+    assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
 
 
 def test_open_tailed_steps_in_the_bf16_storage_variant_and_across_a_mode_switch():
