@@ -117,6 +117,9 @@ SIGNATURES = {
     "cpc_nce_backward_dz": (_I, [_P] * 7 + [_I, _I, _I, _I, _P]),
     "cpc_nce_backward_dwall": (_I, [_P] * 4 + [_I, _I, _I, _I, _P]),
     "cpc_set_nce_fused": (_I, [_I]),
+    "cpc_get_nce_fused": (_I, []),
+    "cpc_set_nce_grid": (_I, [_I]),
+    "cpc_nce_prepare_z": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "cpc_set_index_prep_groups": (_I, [_I]),
     "cpc_set_gru_wgrad_stream": (_I, [_I]),
     "cpc_nce_padded_negatives": (_I, [_I]),

@@ -381,6 +381,297 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_fused_kernel(
     }
 }
 
+// ------------------------------------------------------------------ the same pass on the 16-bit matrix pipe (round 6)
+// nce_fwd_fused_kernel spends 128 exact-f32 MFMAs (4096 matrix-pipe cycles) per 16-candidate tile and holds every gathered row
+// in registers (252 VGPRs).  Here both products run on fp16 pieces -- x s = h + l, hh + hl + lh, the arithmetic of the conv
+// layers (gemm_tile.h) -- from a gather source kept in H2 storage (cpc_common.h: the same 1 KB rows, two fp16 pieces per
+// channel): zh, a copy of z made by nce_rows_to_h2_kernel.  A tile's sixteen rows go global -> LDS by DMA (global_load_lds_dwordx4,
+// one row per wave instruction, no VGPRs), and both products read their fragments from there:
+//   * scores (contraction over channels): A = the rows as they lie -- lane (row i, k group kq) reads the 16-byte h and l pieces
+//     of channels 32 s + 8 kq .. -- against P (the window's K predictions, split once per window, 64 VGPRs);
+//     24 v_mfma_f32_16x16x32_f16 per tile;
+//   * weighted row sum (contraction over CANDIDATES): the B operand wants four candidates of one channel per lane -- the
+//     transpose of how the rows lie -- which ds_read_b64_tr_b16 hands out directly (lane q of a 16-lane group points at row
+//     4 kq + (q >> 2), channels 4 (q & 3).., and receives rows 4 kq .. + 3 of channel q); A = the softmax weights exp(l - M) of
+//     (head i, candidates 4 kq ..) exactly where the first product's accumulator left them; 48 v_mfma_f32_16x16x16_f16 per tile.
+// LDS image of a tile: 16-byte piece p (0..63) of row r at slot p ^ swz(r), swz(r) = (r & 1) | (r & 6) << 1 -- the DMA lane that
+// fills slot L fetches piece L ^ swz(r); found by search over linear swizzles: both read patterns then touch every bank once
+// per LDS cycle (ds_read_b128's 16-lane service groups, the transposing read's 32-lane halves; MI355X_MICROARCH.md, LDS).
+// The weights: exp(l - M) <= e^4 with the reference M moved whenever a logit exceeds it by 4 (f32 kernel: 40), times 1024 -> fp16
+// range; the sum of weights is >= 1 at all times (the positive, or the element that moved M), so a piece that underflows (2^-35
+// absolute) is 2^-35 of the softmax's denominator.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4t __attribute__((ext_vector_type(4)));
+constexpr int kRowBytes = kC * 4;                  // an fp32 row and an H2 row alike
+constexpr int kTileBytes = 16 * kRowBytes;
+constexpr float kPwScale = 1024.0f;                // the softmax weights are split as fp16 pieces of 1024 exp(l - M) (<= 55.9 k)
+constexpr float kMoveRef = 4.0f;                   // the reference M moves when a logit exceeds it by this much
+__host__ __device__ constexpr int tile_swz(int r) { return (r & 1) | ((r & 6) << 1); }
+
+// sixteen 1 KB rows `rows[r]` (wave-uniform) of `base` -> the wave's LDS tile
+__device__ __forceinline__ void tile_dma16(const unsigned char* __restrict__ base, const int (&rows)[16], unsigned char* tile) {
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_wave_barrier();                 // every lane's reads of the tile's previous contents are issued (convergent)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        dma16_to_lds(base + (long)rows[r] * kRowBytes + 16 * (lane ^ tile_swz(r)), tile + r * kRowBytes);
+}
+__device__ __forceinline__ f16x4 tile_read_tr(const unsigned char* p) {
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4t __attribute__((address_space(3)))*)(p)));
+}
+// Lane addresses into a tile.  p1(c): this lane's 16-byte piece c + 2 kq of row i (product 1's fragment / an fp32 row's float4;
+// c = 8 s + hl).  p2(c): the 8 bytes this lane points the transposing read at for pieces c + 2 ((q & 3) >> 1) of row
+// 4 kq + (q >> 2), q = i (c = 4 ct + hl).  Slot = c ^ L with L < 16, so c's bits 4, 5 are an immediate offset and its low bits
+// select one of 4 (c & 9) / 8 (c & 13) precomputed addresses: c must be a compile-time constant.
+struct TileAddr {
+    const unsigned char* a1[4];
+    const unsigned char* a2[8];
+    __device__ __forceinline__ TileAddr(const unsigned char* tile, int i, int kq) {
+        const int L1 = (2 * kq) ^ tile_swz(i);
+        const int rho = 4 * kq + (i >> 2);
+        const int L2 = (2 * ((i & 3) >> 1)) ^ tile_swz(rho);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a1[m] = tile + i * kRowBytes + 16 * (((m & 1) | ((m & 2) << 2)) ^ L1);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) a2[m] = tile + rho * kRowBytes + 8 * (i & 1) + 16 * (((m & 1) | ((m & 6) << 1)) ^ L2);
+    }
+    __device__ __forceinline__ const unsigned char* p1(int c) const { return a1[(c & 1) | ((c & 8) >> 2)] + 16 * (c & 0x30); }
+    __device__ __forceinline__ const unsigned char* p2(int c) const { return a2[(c & 1) | ((c & 12) >> 1)] + 16 * (c & 0x30); }
+};
+struct F16Pair { f16x8 h, l; };
+__device__ __forceinline__ F16Pair split8(const float4& u, const float4& v, float s) {
+    const float x[8] = {u.x * s, u.y * s, u.z * s, u.w * s, v.x * s, v.y * s, v.z * s, v.w * s};
+    F16Pair f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 hi = (_Float16)x[e];
+        f.h[e] = hi;
+        f.l[e] = (_Float16)(x[e] - (float)hi);
+    }
+    return f;
+}
+__device__ __forceinline__ void split4(const float (&v)[4], float s, f16x4& h, f16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e] * s;
+        const _Float16 hi = (_Float16)x;
+        h[e] = hi;
+        l[e] = (_Float16)(x - (float)hi);
+    }
+}
+
+// fp32 rows -> H2 rows scaled for the bound in `bound` (kAmaxSlots partial maxima): the gather source of the kernels below.
+// One wave per row; plain stores (the copy is gathered from right away: it should stay in L2).
+__global__ __launch_bounds__(256) void nce_rows_to_h2_kernel(const float* __restrict__ x, unsigned char* __restrict__ xh,
+                                                             const float* __restrict__ bound, long rows) {
+    const int lane = threadIdx.x & 63;
+    const float s = scale_for_amax(fold_amax(bound, kAmaxSlots));
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4 v = ld4(x + row * kC + 4 * lane);
+    _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
+    h2_split(v.x, s, h0, l0); h2_split(v.y, s, h1, l1); h2_split(v.z, s, h2, l2); h2_split(v.w, s, h3, l3);
+    const unsigned hw0 = __builtin_bit_cast(unsigned, f16x2{h0, h1}), hw1 = __builtin_bit_cast(unsigned, f16x2{h2, h3});
+    const unsigned lw0 = __builtin_bit_cast(unsigned, f16x2{l0, l1}), lw1 = __builtin_bit_cast(unsigned, f16x2{l2, l3});
+    const bool odd = lane & 1;                       // (h2_store_row_nt's neighbour swap, with a plain store)
+    const unsigned r0 = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, odd ? hw0 : lw0)));
+    const unsigned r1 = __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, odd ? hw1 : lw1)));
+    f32x4 o;
+    o.x = __builtin_bit_cast(float, odd ? r0 : hw0);
+    o.y = __builtin_bit_cast(float, odd ? r1 : hw1);
+    o.z = __builtin_bit_cast(float, odd ? lw0 : r0);
+    o.w = __builtin_bit_cast(float, odd ? lw1 : r1);
+    *reinterpret_cast<f32x4*>(xh + row * kRowBytes + 16 * lane) = o;
+}
+
+// as nce_fwd_fused_kernel; zh / zbound: the H2 copy of z and the bound it was scaled for.  The grid may be smaller than the
+// number of window quads: a workgroup then walks windows 4 blockIdx.x + wave, + 4 gridDim.x, ... (cpc_set_nce_grid)
+__global__ __launch_bounds__(256, 2) void nce_fwd_h2_kernel(
+    const float* __restrict__ pred, const float* __restrict__ z, const unsigned char* __restrict__ zh,
+    const float* __restrict__ zbound, const int* __restrict__ ext, float* __restrict__ logits, float* __restrict__ lse_out,
+    float* __restrict__ rowstat, float* __restrict__ tpred, float* __restrict__ tamax, float* __restrict__ ps, int BW, int W,
+    int S, int K, int N, unsigned* __restrict__ ticket, int Nv, int koff) {
+    __shared__ __attribute__((aligned(16))) unsigned char tiles[4][kTileBytes];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;
+    unsigned char* tile = tiles[wv];
+    const int i = lane & 15, kq = lane >> 4;
+    const bool hv = i < K;
+    // product 1's fragment of row i: pieces 8 s + 2 kq (+ 1) -> slot (8 s + hl) ^ L1;  the transposing read of product 2: lane
+    // q = i of group kq points at row 4 kq + (q >> 2), pieces 4 ct + 2 ((q & 3) >> 1) (+ 1), half q & 1 -> slot (4 ct + hl) ^ L2
+    // (the swizzle touches bits 0..3 of the slot only: the bits of the compile-time part above them are an immediate offset, the
+    //  rest gives 4 / 8 distinct lane addresses -- kept in registers instead of one address per read)
+    const TileAddr ta(tile, i, kq);
+    const float sz = scale_for_amax(fold_amax(zbound, kAmaxSlots));
+    float amax_t = 0.f;
+    for (int btv = blockIdx.x * 4 + wv; btv < BW; btv += gridDim.x * 4) {
+        const int bt = __builtin_amdgcn_readfirstlane(btv);
+        const int b = bt / W, t = bt - b * W;
+        int rows[16];
+        // ---- P: the window's predictions, through the tile, split once
+        F16Pair pp[8];
+        float inv;
+        {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rows[r] = bt * K + (r < K ? r : 0);
+            tile_dma16(reinterpret_cast<const unsigned char*>(pred), rows, tile);
+            CPC_WAIT_VMCNT(0);
+            __builtin_amdgcn_wave_barrier();
+            float m = 0.f;                                          // (two passes over the tile: the scale needs the window's maximum)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {                          // q = 2 s + half: channels 32 s + 8 kq + 4 half ..
+                const float4 v = *reinterpret_cast<const float4*>(ta.p1((q >> 1) * 8 + (q & 1)));
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+            const float sp = scale_for_amax(wave_max(hv ? m : 0.f));
+            inv = 1.0f / (kC * sz * sp);                            // (powers of two: exact)
+            const float spv = hv ? sp : 0.f;                        // (padding heads alias head 0's row: exactly 0)
+#pragma unroll
+            for (int sx = 0; sx < 8; ++sx)
+                pp[sx] = split8(*reinterpret_cast<const float4*>(ta.p1(8 * sx)), *reinterpret_cast<const float4*>(ta.p1(8 * sx + 1)), spv);
+        }
+        auto score_tile = [&]() __attribute__((always_inline)) {   // the tile holds 16 rows of zh: scores of row 4 kq + r against head i
+            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll
+            for (int sx = 0; sx < 8; ++sx) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(ta.p1(8 * sx));
+                const f16x8 al = *reinterpret_cast<const f16x8*>(ta.p1(8 * sx + 1));
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, pp[sx].h, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, pp[sx].l, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, pp[sx].h, a2, 0, 0, 0);
+            }
+            f32x4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = (a0[r] + (a1[r] + a2[r])) * inv;
+            return acc;
+        };
+        // ---- positives: head h <-> z[b, t + h + 1], through the SAME chain as the negatives (a negative that happens to be the
+        // positive row scores bit-identically: the arg-max tie resolves to class 0 as in the reference, criterion.py:253)
+        float posl;
+        {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rows[r] = b * S + t + koff + (r < K ? r : 0) + 1;
+            tile_dma16(zh, rows, tile);
+            CPC_WAIT_VMCNT(0);
+            __builtin_amdgcn_wave_barrier();
+            const f32x4 acc = score_tile();
+            const float mine = (i & 3) == 0 ? acc[0] : (i & 3) == 1 ? acc[1] : (i & 3) == 2 ? acc[2] : acc[3];
+            posl = __shfl(mine, i + 16 * (i >> 2));
+        }
+        float M = posl;
+        float ssum = kq == 0 ? 1.0f : 0.0f;
+        float mneg = -3.0e38f;
+        f32x4 U[16];                                     // U[ct][r]: head 4 kq + r, channel 16 ct + i
+#pragma unroll
+        for (int q = 0; q < 16; ++q) U[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < N / 16; ++nt) {
+            const int* e = ext + (long)bt * N + nt * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rows[r] = e[r];
+            tile_dma16(zh, rows, tile);
+            CPC_WAIT_VMCNT(0);
+            __builtin_amdgcn_wave_barrier();
+            const f32x4 acc = score_tile();
+            float l[4], lmax = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                l[r] = nt * 16 + 4 * kq + r < Nv ? acc[r] : -3.0e38f;
+                if (hv) logits[((long)bt * K + i) * (N + 1) + 1 + nt * 16 + 4 * kq + r] = l[r];
+                lmax = fmaxf(lmax, l[r]);
+            }
+            mneg = fmaxf(mneg, lmax);
+            if (__any(lmax - M > kMoveRef)) {              // (wave-uniform) move the reference
+                float tm = fmaxf(lmax, __shfl_xor(lmax, 16));
+                tm = fmaxf(tm, __shfl_xor(tm, 32));
+                const float Mn = fmaxf(M, tm), alpha = expf(M - Mn);
+                ssum *= alpha;
+                M = Mn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ar = __shfl(alpha, 4 * kq + r);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) U[q][r] *= ar;
+                }
+            }
+            float pw[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pw[r] = hv ? expf(l[r] - M) : 0.f;
+                ssum += hv ? pw[r] : expf(l[r] - M);
+            }
+            f16x4 wh, wl;
+            split4(pw, kPwScale, wh, wl);
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {                // four channel tiles at a time: 8 transposing reads, 12 MFMAs
+                f16x4 bh[4], bl[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ct = 4 * c4 + u;
+                    bh[u] = tile_read_tr(ta.p2(4 * ct));
+                    bl[u] = tile_read_tr(ta.p2(4 * ct + 1));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) U[4 * c4 + u] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, bh[u], U[4 * c4 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) U[4 * c4 + u] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, bl[u], U[4 * c4 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) U[4 * c4 + u] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl, bh[u], U[4 * c4 + u], 0, 0, 0);
+            }
+        }
+        ssum += __shfl_xor(ssum, 16);
+        ssum += __shfl_xor(ssum, 32);
+        mneg = fmaxf(mneg, __shfl_xor(mneg, 16));
+        mneg = fmaxf(mneg, __shfl_xor(mneg, 32));
+        const float lse = M + logf(ssum);
+        if (kq == 0 && hv) {
+            logits[((long)bt * K + i) * (N + 1)] = posl;
+            lse_out[(long)bt * K + i] = lse;
+            rowstat[(long)bt * 2 * K + i] = lse - posl;
+            rowstat[(long)bt * 2 * K + K + i] = posl >= mneg ? 1.f : 0.f;
+        }
+        // ---- T = exp(M - lse) * U + (p0 - 1) * pos, out through the tile so that a head's 1 KB row leaves as one store instruction
+        const float fac = expf(M - lse) / (kPwScale * sz), p0m1 = expf(posl - lse) - 1.0f;       // per head i
+        __builtin_amdgcn_wave_barrier();                 // (the last tile's transposing reads are done: in order with the writes below)
+        float* tf = reinterpret_cast<float*>(tile);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float fr = __shfl(fac, 4 * kq + r);
+#pragma unroll
+            for (int ct = 0; ct < 16; ++ct) tf[(4 * kq + r) * kC + 16 * ct + i] = fr * U[ct][r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int head = 0; head < K; ++head) {
+            const float dr = __shfl(p0m1, head);
+            const float4 u = *reinterpret_cast<const float4*>(tf + head * kC + 4 * lane);
+            const float4 zv = ld4(z + ((long)b * S + t + koff + head + 1) * kC + 4 * lane);
+            f32x4 o;
+            o.x = fmaf(dr, zv.x, u.x); o.y = fmaf(dr, zv.y, u.y); o.z = fmaf(dr, zv.z, u.z); o.w = fmaf(dr, zv.w, u.w);
+            *reinterpret_cast<f32x4*>(tpred + ((long)bt * K + head) * kC + 4 * lane) = o;
+            amax_t = fmaxf(fmaxf(amax_t, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
+        // ---- the softmax rows per candidate slot (nce_fwd_fused_kernel's layout), from the logits just written
+        float* prow = ps + (long)bt * (N + K) * 16 + i;
+        const float* lrow = logits + ((long)bt * K + (hv ? i : 0)) * (N + 1) + 1 + 4 * kq;
+        for (int nt = 0; nt < N / 16; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = hv ? expf(lrow[nt * 16 + r] - lse) : 0.f;
+                prow[(long)(nt * 16 + 4 * kq + r) * 16] = pv;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int head = 4 * kq + r;
+            const float dr = __shfl(p0m1, head);
+            if (head < K) prow[(long)(N + head) * 16] = i == head ? dr : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();                 // (the tile is refilled by the next window's DMA)
+    }
+    amax_t = wave_max(amax_t);
+    if (lane == 0 && amax_t > 0.f)
+        atomicMax(reinterpret_cast<unsigned*>(tamax + ((blockIdx.x * 4 + wv) & (kAmaxSlots - 1))), __float_as_uint(amax_t));
+}
+
 // wallT_g[i][k*256 + o] = g_k * wall[(k*256 + o)*256 + i]: the stacked head weights transposed AND pre-multiplied by the heads'
 // upstream gradients -- the B operand of dc = T . wallT_g^T (the one-pass criterion keeps T, the unit-gradient dPred)
 __global__ __launch_bounds__(256) void nce_wallT_scaled_kernel(const float* __restrict__ wall, const float* __restrict__ gscale,
@@ -656,6 +947,108 @@ __global__ __launch_bounds__(64, 4) void nce_bwd_g_kernel(const float* __restric
     }
 }
 
+// The same gather-GEMM on fp16 pieces (round 6): the rows of c come from an H2 copy (ch, scaled for the bound of |c| the forward
+// left: nce_rows_to_h2_kernel) by DMA into a 16 KB LDS tile, sixteen sorted slots at a time; the contraction runs over the
+// SLOTS, so the B operand is fetched with the transposing LDS read exactly as the forward kernel's weighted row sum
+// (nce_fwd_h2_kernel: same tile image, same swizzle); A = g_head * softmax row of (head i, slots 4 kq .. + 3), split with the
+// power-of-two scale of max|g| (softmax rows are in [-1, 1]).  48 v_mfma_f32_16x16x16_f16 per 16 slots where the f32 kernel
+// issues 256 v_mfma_f32_16x16x4_f32.  G leaves through the tile: one 1 KB store instruction per head.
+constexpr int GATHER_H2_SORT = 512;                 // slots per destination row that are sorted (more: fill order -- never at N = 128)
+__global__ __launch_bounds__(64, 2) void nce_bwd_g_h2_kernel(const unsigned char* __restrict__ ch, const float* __restrict__ cbound,
+                                                             const float* __restrict__ dS, const int* __restrict__ perm,
+                                                             const int* __restrict__ row_ptr, float* __restrict__ G, int W, int S,
+                                                             int K, int NK, float* __restrict__ amax_slots,
+                                                             const float* __restrict__ gscale) {
+    __shared__ int raw[GATHER_H2_SORT];           // the slot list as filled; after the sort: row of c per sorted slot
+    __shared__ int sorted[GATHER_H2_SORT];
+    __shared__ __attribute__((aligned(16))) unsigned char tile[kTileBytes];
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x;
+    const int beg = row_ptr[j], len = row_ptr[j + 1] - beg;
+    const bool do_sort = len <= GATHER_H2_SORT;
+    auto crow_of = [&](int slot) __attribute__((always_inline)) {
+        const int bt = slot / NK, b = bt / W;
+        return b * S + (bt - b * W);
+    };
+    if (do_sort) {
+        for (int q = lane; q < len; q += 64) raw[q] = perm[beg + q];
+        __syncthreads();
+        for (int q = lane; q < len; q += 64) {
+            const int e = raw[q];
+            int rank = 0;
+            for (int v = 0; v < len; ++v) rank += raw[v] < e ? 1 : 0;      // slots are unique
+            sorted[rank] = e;
+        }
+        __syncthreads();
+        for (int q = lane; q < len; q += 64) raw[q] = crow_of(sorted[q]);
+        __syncthreads();
+    }
+    const int i = lane & 15, kq = lane >> 4;
+    const float gsi = gscale == nullptr ? 1.0f : (i < K ? gscale[i] : 0.f);
+    const float sa = scale_for_amax(gscale == nullptr ? 1.0f : wave_max(fabsf(gsi)));
+    const float sc = scale_for_amax(fold_amax(cbound, kAmaxSlots));
+    const TileAddr ta(tile, i, kq);
+    f32x4 acc[16];                                // acc[ct][r]: head 4 kq + r, channel 16 ct + i
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p0 = 0; p0 < len; p0 += 16) {
+        int rows[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pc = p0 + r < len ? p0 + r : 0;                        // (past the end: a valid row, weight 0)
+            rows[r] = __builtin_amdgcn_readfirstlane(do_sort ? raw[pc] : crow_of(perm[beg + pc]));
+        }
+        __builtin_amdgcn_wave_barrier();             // (the previous tile's transposing reads are done)
+        tile_dma16(ch, rows, tile);
+        float a[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = p0 + 4 * kq + r;
+            const bool ok = p < len;
+            const int slot = do_sort ? sorted[ok ? p : 0] : perm[beg + (ok ? p : 0)];
+            a[r] = ok ? gsi * dS[(long)slot * 16 + i] : 0.f;                 // d score[head i][slot]
+        }
+        f16x4 wh, wl;
+        split4(a, sa, wh, wl);
+        CPC_WAIT_VMCNT(0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            f16x4 bh[4], bl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ct = 4 * c4 + u;
+                bh[u] = tile_read_tr(ta.p2(4 * ct));
+                bl[u] = tile_read_tr(ta.p2(4 * ct + 1));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[4 * c4 + u] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, bh[u], acc[4 * c4 + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[4 * c4 + u] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, bl[u], acc[4 * c4 + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[4 * c4 + u] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl, bh[u], acc[4 * c4 + u], 0, 0, 0);
+        }
+    }
+    const float inv = 1.0f / (sa * sc);
+    __builtin_amdgcn_wave_barrier();
+    float* tf = reinterpret_cast<float*>(tile);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct) tf[(4 * kq + r) * kC + 16 * ct + i] = acc[ct][r] * inv;
+    __builtin_amdgcn_wave_barrier();
+    float amax = 0.f;
+    for (int head = 0; head < K; ++head) {
+        const float4 u = *reinterpret_cast<const float4*>(tf + head * kC + 4 * lane);
+        *reinterpret_cast<float4*>(G + ((long)j * K + head) * kC + 4 * lane) = u;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(u.x), fabsf(u.y))), fmaxf(fabsf(u.z), fabsf(u.w)));
+    }
+    if (amax_slots != nullptr) {
+        amax = wave_max(amax);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(amax_slots + (j & (kAmaxSlots - 1))), __float_as_uint(amax));
+    }
+}
+
 // ------------------------------------------------------------------ backward: dz, any prediction network
 // Every candidate (negative n or positive k of window (b,t)) contributes one 256-float row to
 // dz[its row of z].  Destinations are random, so instead of 32k float atomics per window the
@@ -907,7 +1300,11 @@ int g_index_prep_groups = -1;  // cpc_set_index_prep_groups: -1 (default) = at m
                                // short ones queueing for their CUs (same-box A/B at B = 64: 2.822 vs 2.837 ms per step sustained;
                                // 128 / 192: 2.830, 384: 2.845, 512: 2.855, 64: 2.99, 16: 3.94 -- then the lists are late)
 int g_nce_fused = 1;       // cpc_set_nce_fused: 1 (default) the one-pass criterion (nce_fwd_fused_kernel: scores and the unit-gradient
-                           // dPred from ONE gather pass; linear heads), 0 the two-pass kernels (nce_fwd_kernel + nce_bwd_dpred_kernel)
+                           // dPred from ONE gather pass; linear heads), 0 the two-pass kernels (nce_fwd_kernel + nce_bwd_dpred_kernel),
+                           // 2 the one-pass criterion on fp16 pieces (nce_fwd_h2_kernel, nce_bwd_g_h2_kernel: H2 copies of z / c
+                           // as gather sources, DMA'd tiles, transposing LDS reads)
+int g_nce_grid = 0;        // cpc_set_nce_grid: workgroups of nce_fwd_h2_kernel -- 0 one per four windows, -1 two per CU (each
+                           // walking windows 4 wg + wave, + 4 grid, ...: all waves sweep the sorted candidate lists in step), n > 0
 
 struct NceLayout {
     int W, BW;
@@ -915,9 +1312,9 @@ struct NceLayout {
     int N, Nv;      // negatives per window as the kernels walk them (a multiple of 16) / as drawn (criterion.py:176-189): the
                     // candidates Nv .. N-1 of every window are padding -- a valid row of z, their logit forced to -3e38, so that
                     // they weigh exactly 0 in the softmax, the arg-max and every gradient
-    long pred, logits, lse, bounds, tpred, ps, saved_total;
+    long pred, logits, lse, bounds, tpred, ps, zh, saved_total;
     long rowstat, tmp, sums, fwd_total;
-    long dpred, wallT, part, gscale, V, dS, G, wcat, part_dz, bwd_total;
+    long dpred, wallT, part, gscale, V, dS, G, wcat, part_dz, ch, bwd_total;
 };
 
 constexpr int kDzSplits = 4;      // K-walk splits the dz GEMM's partial buffer is sized for (SplitK)
@@ -927,6 +1324,7 @@ constexpr int kDzSplits = 4;      // K-walk splits the dz GEMM's partial buffer 
 // windows are the W = S - k_total of the whole criterion and head k's positive is z[b, t + k0 + k + 1] (criterion.py:210-215).
 // The groups share nothing but the inputs: losses / accuracies are per head, the gradients add.
 static thread_local int g_head_off = 0, g_head_total = 0;
+static thread_local bool g_zh_ready = false;     // cpc_nce_prepare_z ran for the calling thread's next forward
 
 static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     const int Ktot = g_head_total > 0 ? g_head_total : K;
@@ -941,9 +1339,11 @@ static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     n.pred = o; o += align64l((long)n.BW * K * kC);
     n.logits = o; o += align64l((long)n.BW * K * (N + 1));
     n.lse = o; o += align64l((long)n.BW * K);
-    n.bounds = o; o += 3 * kAmaxSlots;       // max|c|, max|wall| as 64 partial maxima each (linear heads only); max|T| slots (fused)
+    n.bounds = o; o += 4 * kAmaxSlots;       // max|c|, max|wall| as 64 partial maxima each (linear heads only); max|T| slots (fused);
+                                             // max|z| (fp16-piece kernels: the scale of zh)
     n.tpred = o; o += align64l((long)n.BW * K * kC);      // T: d loss_k / d pred_k for a unit upstream gradient (one-pass criterion)
     n.ps = o; o += align64l((long)n.BW * (N + K) * 16);   // ... and the softmax rows per candidate slot (the dz path's dS / g_k)
+    n.zh = o; o += align64l((long)B * S * kC);            // z in H2 storage: the gather source of nce_fwd_h2_kernel
     n.saved_total = o;
     o = 0;
     n.rowstat = o; o += align64l((long)n.BW * 2 * K);
@@ -965,6 +1365,7 @@ static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     n.G = q; q += align64l((long)B * S * K * kC);
     n.wcat = q; q += (long)kC * K * kC;
     n.part_dz = q; q += align64l((long)kDzSplits * B * S * kC);
+    n.ch = q; q += align64l((long)B * S * kC);             // c in H2 storage: the gather source of nce_bwd_g_h2_kernel
     n.bwd_total = std::max(o + v_floats, q);
     return true;
 }
@@ -977,25 +1378,55 @@ static RowMap window_rows(const float* c, int B, int S, int W) {     // rows (b,
 }
 
 // scores, log-softmax, per-head loss / accuracy from given predictions
-static bool nce_fused(int) { return g_nce_fused != 0; }
+static int nce_fused(int) { return g_nce_fused; }
 // wall^T for dc = dPred . wall: plain, or -- one-pass criterion, whose dPred is the unit-gradient T -- pre-multiplied by the heads'
 // upstream gradients (scratch + gscale must hold them: nce_gscale_kernel on this stream or one it has waited for)
 static int nce_wallT(const float* wall, float* scratch, const NceLayout& n, int K, int N, hipStream_t st) {
-    if (!nce_fused(N)) return transpose(wall, scratch + n.wallT, K * kC, kC, st);
+    if (nce_fused(N) == 0) return transpose(wall, scratch + n.wallT, K * kC, kC, st);
     hipLaunchKernelGGL(nce_wallT_scaled_kernel, dim3(kC / 32, cdiv(K * kC, 32)), dim3(256), 0, st, wall, scratch + n.gscale,
                        scratch + n.wallT, K);
     CPC_LAUNCH_CHECK();
     return 0;
 }
+// fp32 rows -> H2 rows scaled for `bound` (kAmaxSlots partial maxima, on `st` or a stream it has waited for)
+static int nce_rows_to_h2(const float* x, float* xh, const float* bound, long rows, hipStream_t st) {
+    hipLaunchKernelGGL(nce_rows_to_h2_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, reinterpret_cast<unsigned char*>(xh), bound, rows);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+// zh and its bound for the fp16-piece scoring kernel: max|z| into the fourth slot array of `saved`, then the H2 copy
+static int nce_prepare_zh(const NceLayout& n, const float* z, float* saved, int B, int S, hipStream_t st) {
+    const float* xs[1] = {z};
+    const long ns[1] = {(long)B * S * kC};
+    int rc = absmax_slots(xs, ns, 1, saved + n.bounds + 3 * kAmaxSlots, st);
+    if (rc) return rc;
+    return nce_rows_to_h2(z, saved + n.zh, saved + n.bounds + 3 * kAmaxSlots, (long)B * S, st);
+}
 static int nce_scores_forward(const NceLayout& n, const float* pred, const float* z, const int* ext, float* saved,
                               float* scratch, float* losses, float* acc, int S, int K, int N, hipStream_t st,
-                              hipStream_t fin = nullptr, bool fused = false) {
+                              hipStream_t fin = nullptr, int fused = 0) {
     // fin (nullptr: st): the stream the loss / accuracy reduction runs on.  Nothing of the backward reads its results (the
     // score gradients come from the saved logits), so a caller that joins `fin` later takes 15 us off its critical path.
     // fused: the one-pass kernel, which also leaves T (unit-gradient dPred) and max|T| in `saved` (slots zeroed by the caller)
     unsigned* ticket = reinterpret_cast<unsigned*>(scratch + n.sums + 32);
     step_timer_mark(8, st);
-    if (fused)
+    if (fused == 2) {
+        // (zh: nce_prepare_zh, queued by the caller on this stream)
+        long wgs = cdiv(n.BW, 4);
+        if (g_nce_grid != 0) {
+            long cap = g_nce_grid;
+            if (cap < 0) {
+                int dev = 0, cus = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+                cap = 2L * cus;
+            }
+            if (cap > 0) wgs = std::min(wgs, cap);
+        }
+        hipLaunchKernelGGL(nce_fwd_h2_kernel, dim3((unsigned)wgs), dim3(256), 0, st, pred, z,
+                           reinterpret_cast<const unsigned char*>(saved + n.zh), saved + n.bounds + 3 * kAmaxSlots, ext, saved + n.logits,
+                           saved + n.lse, scratch + n.rowstat, saved + n.tpred, saved + n.bounds + 2 * kAmaxSlots, saved + n.ps,
+                           n.BW, n.W, S, K, N, ticket, n.Nv, n.koff);
+    } else if (fused)
         hipLaunchKernelGGL(nce_fwd_fused_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
                            saved + n.lse, scratch + n.rowstat, saved + n.tpred, saved + n.bounds + 2 * kAmaxSlots, saved + n.ps,
                            n.BW, n.W, S, K, N, ticket, n.Nv, n.koff);
@@ -1047,7 +1478,13 @@ static int nce_dz_linear_path(const NceLayout& n, const float* c, const float* w
     float* bnd = scratch + n.gscale;
     const bool h2 = g_mfma_mode >= 2;
     hipLaunchKernelGGL(nce_wcat_kernel, dim3(cdiv(K * kC, 4)), dim3(256), 0, st, wall, wcat, K);
-    if (saved_for_ds != nullptr)           // one-pass criterion: the forward left the softmax rows; the heads' gradients apply here
+    if (saved_for_ds != nullptr && nce_fused(N) == 2) {     // ... on fp16 pieces, from an H2 copy of c scaled for the forward's bound of |c|
+        int rc = nce_rows_to_h2(c, scratch + n.ch, saved_for_ds + n.bounds, (long)B * S, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(nce_bwd_g_h2_kernel, dim3(B * S), dim3(64), 0, st, reinterpret_cast<const unsigned char*>(scratch + n.ch),
+                           saved_for_ds + n.bounds, saved_for_ds + n.ps, perm, row_ptr, G, n.W, S, K, N + K,
+                           h2 ? bnd + 128 : (float*)nullptr, (const float*)(scratch + n.gscale));
+    } else if (saved_for_ds != nullptr)           // one-pass criterion: the forward left the softmax rows; the heads' gradients apply here
         hipLaunchKernelGGL(nce_bwd_g_kernel, dim3(B * S), dim3(64), 0, st, c, saved_for_ds + n.ps, perm, row_ptr, G, n.W, S, K, N + K,
                            h2 ? bnd + 128 : (float*)nullptr, (const float*)(scratch + n.gscale));
     else
@@ -1165,6 +1602,11 @@ static int nce_forward(const float* c, const float* z, const float* wall, const 
     gb.b = saved + n.bounds + kAmaxSlots; gb.b_slots = kAmaxSlots;
     int rc = nt_gemm(window_rows(c, B, S, n.W), wall, kC, nullptr, pred, (long)K * kC, K * kC, kC, st, 0, 0, gb);
     if (rc) return rc;
+    if (nce_fused(N) == 2 && !g_zh_ready) {                 // (cpc_nce_prepare_z: ahead of time, on another stream)
+        rc = nce_prepare_zh(n, z, saved, B, S, st);
+        if (rc) return rc;
+    }
+    g_zh_ready = false;
     return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, st, fin, nce_fused(N));
 }
 
@@ -1270,7 +1712,7 @@ extern "C" int cpc_nce_backward_dz(const float* c, const float* wall, const int*
     N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!c || !wall || !perm || !row_ptr || !saved || !scratch || !dz, CPC_ERR_ARG);
     return nce_dz_linear_path(n, c, wall, perm, row_ptr, scratch, dz, B, S, K, N, (hipStream_t)stream,
-                              nce_fused(N) ? saved : nullptr);
+                              nce_fused(N) != 0 ? saved : nullptr);
 }
 
 // As cpc_nce_backward, with the dz path launched on `dz_stream` behind an event recorded on `stream` once the score
@@ -1300,7 +1742,7 @@ static int nce_backward_impl(const float* c, const float* z, const float* wall, 
     N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!c || !z || !wall || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dc, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream, st_dz = (hipStream_t)dz_stream;
-    const bool fused = nce_fused(N);         // the forward left T (unit-gradient dPred) and max|T| in `saved`: no score-gradient pass
+    const bool fused = nce_fused(N) != 0;    // the forward left T (unit-gradient dPred) and max|T| in `saved`: no score-gradient pass
     float* dpred = fused ? const_cast<float*>(saved) + n.tpred : scratch + n.dpred, *wallT = scratch + n.wallT;
     const bool h2 = g_mfma_mode >= 2;        // the forward left the operand bounds in `saved`
     int rc = 0;
@@ -1353,7 +1795,7 @@ extern "C" int cpc_nce_backward_dwall(const float* c, const float* saved, float*
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!c || !saved || !scratch || !dwall, CPC_ERR_ARG);
-    const bool fused = nce_fused(N);
+    const bool fused = nce_fused(N) != 0;
     GemmBounds gdw;                                               // left by cpc_nce_backward_streams (nce_gscale_kernel)
     GemmGroup grp;
     if (g_mfma_mode >= 2) {
@@ -1386,6 +1828,28 @@ extern "C" int cpc_set_index_prep_groups(int n) {
 }
 
 extern "C" int cpc_set_nce_fused(int on) {
-    g_nce_fused = on ? 1 : 0;
+    CPC_RETURN_IF(on < 0 || on > 2, CPC_ERR_ARG);
+    g_nce_fused = on;
     return 0;
+}
+extern "C" int cpc_get_nce_fused(void) { return g_nce_fused; }
+
+// Workgroups of the fp16-piece scoring kernel: 0 = one per four windows (dispatch order), -1 = two per CU, n > 0 = at most n;
+// a capped grid walks its windows with a stride of the grid (cpc_set_nce_fused(2) only).
+extern "C" int cpc_set_nce_grid(int wgs) {
+    CPC_RETURN_IF(wgs < -1, CPC_ERR_ARG);
+    g_nce_grid = wgs;
+    return 0;
+}
+
+// The H2 copy of z the fp16-piece scoring kernel gathers from (cpc_set_nce_fused(2)), ahead of time: z is final when the encoder
+// has run, long before the criterion -- a caller with a second stream queues this there (behind the encoder) and the calling
+// thread's next cpc_nce_forward* skips it.  A no-op in the other modes.
+extern "C" int cpc_nce_prepare_z(const float* z, float* saved, int B, int S, int K, int N, void* stream) {
+    NceLayout n;
+    CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!z || !saved, CPC_ERR_ARG);
+    if (nce_fused(n.N) != 2) return 0;
+    g_zh_ready = true;
+    return nce_prepare_zh(n, z, saved, B, S, (hipStream_t)stream);
 }

@@ -414,6 +414,16 @@ int cpc_nce_backward_dwall(const float* c, const float* saved, float* scratch, f
  * GEMM's weight operand and the weight gradient's reduction, the dz path multiplies the softmax rows the forward leaves per
  * candidate slot.  0: the two-pass kernels.  A forward and its backward run under the same setting. */
 int cpc_set_nce_fused(int on);
+/* (on = 2, round 6: the same one-pass criterion on the 16-bit matrix pipe -- both products as hh + hl + lh of two fp16 pieces,
+ * the arithmetic of the conv layers -- gathering from H2 copies of z (forward) and c (the dz path's gather-GEMM) that go
+ * global -> LDS by DMA, the contraction over candidates fed by the transposing LDS read.  Same interface, same saved tensors.) */
+int cpc_get_nce_fused(void);
+/* cpc_set_nce_fused(2): workgroups of the scoring kernel -- 0 = one per four windows, -1 = two per CU, n > 0 = at most n (a capped
+ * grid walks its windows with the grid's stride, so that all resident waves sweep their ascending candidate lists in step). */
+int cpc_set_nce_grid(int wgs);
+/* cpc_set_nce_fused(2): the H2 copy of z (criterion.py:200-201's gather source) ahead of time on `stream` -- z is final when
+ * the encoder has run; the calling thread's next cpc_nce_forward* then skips the two small launches.  No-op in other modes. */
+int cpc_nce_prepare_z(const float* z, float* saved, int B, int S, int K, int N, void* stream);
 /* Tuning switch: at most n workgroups per launch of cpc_nce_prepare's kernels (each then walks several windows / slots);
  * -1 (default) = the device's CU count, 0 = one per 4 windows / 256 slots.  Same lists either way. */
 int cpc_set_index_prep_groups(int n);

@@ -255,6 +255,30 @@ inline f32x4 mfma_f32_16x16x32_f16(f16x8_ a, f16x8_ b, f32x4 c, int, int, int) {
     return c;
 }
 
+// v_mfma_f32_16x16x16_f16: lane l supplies A[i = l&15][k = 4*(l>>4) + e], B[k = 4*(l>>4) + e][j = l&15] (four halves each);
+// D as for 16x16x4
+typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+inline f32x4 mfma_f32_16x16x16f16(f16x4_ a, f16x4_ b, f32x4 c, int, int, int) {
+    WaveBuf& w = my_wave();
+    int ph = w.phase, l = lane_id();
+    memcpy(w.va[ph][l], &a, 8);
+    memcpy(w.vb[ph][l], &b, 8);
+    wave_sync();
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            _Float16 x, y;
+            memcpy(&x, &w.va[ph][row + 16 * (k >> 2)][k & 3], 2);
+            memcpy(&y, &w.vb[ph][col + 16 * (k >> 2)][k & 3], 2);
+            acc = fmaf((float)x, (float)y, acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+
 // v_mfma_f32_32x32x16_f16: same operand layout with IEEE half elements
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 inline f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c, int, int, int) {
@@ -350,6 +374,7 @@ static inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu::mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu::mfma_f32_32x32x16_f16
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 hipemu::mfma_f32_16x16x32_f16
+#define __builtin_amdgcn_mfma_f32_16x16x16f16 hipemu::mfma_f32_16x16x16f16
 static inline unsigned __float_as_uint(float x) { return hipemu::bits(x); }
 static inline float __uint_as_float(unsigned u) { return hipemu::unbits<float>(u); }
 #define __builtin_amdgcn_readfirstlane(x) (x)
