@@ -19,6 +19,7 @@ DEFAULT_DMA_PIPELINE = 2       # cpc_set_dma_pipeline: the tap-pair walk where t
 DEFAULT_WGRAD_DMA_STAGES = 4   # cpc_set_wgrad_dma_stages
 DEFAULT_CONV_SMALL_PIPE = 1    # cpc_set_conv_small_pipe
 DEFAULT_GRU_WGRAD_STREAM = 1   # cpc_set_gru_wgrad_stream: the recurrence's weight gradients on the preparation stream (single-rank composite steps)
+DEFAULT_NCE_FUSED = 2          # cpc_set_nce_fused: the one-pass criterion with its scoring kernel on fp16 pieces (round 6; 1 = exact-f32 MFMAs)
 DEFAULT_INDEX_PREP_GROUPS = -1 # cpc_set_index_prep_groups: one workgroup per CU and launch of the criterion's index preparation
 DEFAULT_FWD_NSPLIT = 0         # cpc_set_fwd_nsplit (built and measured in round 5: no gain at B = 64, off)
 DEFAULT_DGRAD_NSPLIT = 256     # cpc_set_dgrad_nsplit: the short layers' data gradients on 128 x 128 tiles where that gives >= 256 workgroups
@@ -119,6 +120,8 @@ SIGNATURES = {
     "cpc_set_nce_fused": (_I, [_I]),
     "cpc_get_nce_fused": (_I, []),
     "cpc_set_nce_grid": (_I, [_I]),
+    "cpc_set_nce_debug": (_I, [_I]),
+    "cpc_set_nce_rows_apart": (_I, [_I]),
     "cpc_nce_prepare_z": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "cpc_set_index_prep_groups": (_I, [_I]),
     "cpc_set_gru_wgrad_stream": (_I, [_I]),

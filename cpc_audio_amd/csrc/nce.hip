@@ -409,12 +409,16 @@ constexpr float kMoveRef = 4.0f;                   // the reference M moves when
 __host__ __device__ constexpr int tile_swz(int r) { return (r & 1) | ((r & 6) << 1); }
 
 // sixteen 1 KB rows `rows[r]` (wave-uniform) of `base` -> the wave's LDS tile
+// (`tile` must be wave-uniform in a way the compiler can see -- derived from a readfirstlane -- so that the sixteen LDS bases are
+// scalar additions; the global side is a uniform 64-bit row address + a 32-bit lane offset, eight distinct ones per wave)
 __device__ __forceinline__ void tile_dma16(const unsigned char* __restrict__ base, const int (&rows)[16], unsigned char* tile) {
-    const int lane = threadIdx.x & 63;
+    const unsigned lane = threadIdx.x & 63;
     __builtin_amdgcn_wave_barrier();                 // every lane's reads of the tile's previous contents are issued (convergent)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        dma16_to_lds(base + (long)rows[r] * kRowBytes + 16 * (lane ^ tile_swz(r)), tile + r * kRowBytes);
+    for (int r = 0; r < 16; ++r) {
+        const unsigned char* rowp = base + (long)rows[r] * kRowBytes;
+        dma16_to_lds(rowp + 16u * (lane ^ (unsigned)tile_swz(r)), tile + r * kRowBytes);
+    }
 }
 __device__ __forceinline__ f16x4 tile_read_tr(const unsigned char* p) {
     return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4t __attribute__((address_space(3)))*)(p)));
@@ -484,15 +488,60 @@ __global__ __launch_bounds__(256) void nce_rows_to_h2_kernel(const float* __rest
     *reinterpret_cast<f32x4*>(xh + row * kRowBytes + 16 * lane) = o;
 }
 
+// The softmax rows per candidate slot (ps: what the dz path contracts with c, nce_fwd_fused_kernel's layout) from the saved logits
+// and log-sum-exps, as a launch of its own: nothing of the forward's chain reads them, so a caller with a second stream runs this
+// beside the backward's first GEMMs instead of inside the scoring kernel (20 us of its 175 at B = 64).  One wave per window;
+// lane L takes candidate L / 4 of a 16-candidate tile and heads 4 (L % 4) .. + 3: four strided loads, one 16-byte store -- a
+// tile's sixteen 64-byte rows leave as ONE contiguous 1 KB per wave instruction.
+__global__ __launch_bounds__(256) void nce_softmax_rows_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                               float* __restrict__ ps, int BW, int K, int N) {
+    const int lane = threadIdx.x & 63;
+    const int bt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bt >= BW) return;
+    const int cand = lane >> 2, h0 = 4 * (lane & 3);
+    float ls[4];
+    const float* lp[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int head = h0 + e < K ? h0 + e : 0;
+        ls[e] = lse[(long)bt * K + head];
+        lp[e] = logits + ((long)bt * K + head) * (N + 1);
+    }
+    float* prow = ps + (long)bt * (N + K) * 16 + 4 * lane;
+    for (int nt0 = 0; nt0 < N / 16; nt0 += 4) {
+        float lv[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lv[q][e] = nt0 + q < N / 16 ? lp[e][1 + (nt0 + q) * 16 + cand] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (nt0 + q < N / 16) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = h0 + e < K ? expf(lv[q][e] - ls[e]) : 0.f;
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(prow + (long)(nt0 + q) * 256));
+            }
+        }
+    }
+    // the positives: slot N + head carries p0 - 1 on its own head, 0 elsewhere
+    if (cand < K) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = h0 + e == cand ? expf(lp[e][0] - ls[e]) - 1.0f : 0.f;
+        *reinterpret_cast<f32x4*>(ps + ((long)bt * (N + K) + N + cand) * 16 + h0) = o;
+    }
+}
+
 // as nce_fwd_fused_kernel; zh / zbound: the H2 copy of z and the bound it was scaled for.  The grid may be smaller than the
 // number of window quads: a workgroup then walks windows 4 blockIdx.x + wave, + 4 gridDim.x, ... (cpc_set_nce_grid)
 __global__ __launch_bounds__(256, 2) void nce_fwd_h2_kernel(
     const float* __restrict__ pred, const float* __restrict__ z, const unsigned char* __restrict__ zh,
     const float* __restrict__ zbound, const int* __restrict__ ext, float* __restrict__ logits, float* __restrict__ lse_out,
     float* __restrict__ rowstat, float* __restrict__ tpred, float* __restrict__ tamax, float* __restrict__ ps, int BW, int W,
-    int S, int K, int N, unsigned* __restrict__ ticket, int Nv, int koff) {
+    int S, int K, int N, unsigned* __restrict__ ticket, int Nv, int koff, int dbg) {
     __shared__ __attribute__((aligned(16))) unsigned char tiles[4][kTileBytes];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;
     unsigned char* tile = tiles[wv];
     const int i = lane & 15, kq = lane >> 4;
@@ -576,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_h2_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 l[r] = nt * 16 + 4 * kq + r < Nv ? acc[r] : -3.0e38f;
-                if (hv) logits[((long)bt * K + i) * (N + 1) + 1 + nt * 16 + 4 * kq + r] = l[r];
+                if (hv && !(dbg & 8)) logits[((long)bt * K + i) * (N + 1) + 1 + nt * 16 + 4 * kq + r] = l[r];
                 lmax = fmaxf(lmax, l[r]);
             }
             mneg = fmaxf(mneg, lmax);
@@ -601,6 +650,7 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_h2_kernel(
             }
             f16x4 wh, wl;
             split4(pw, kPwScale, wh, wl);
+            if (!(dbg & 4))
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {                // four channel tiles at a time: 8 transposing reads, 12 MFMAs
                 f16x4 bh[4], bl[4];
@@ -640,23 +690,43 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_h2_kernel(
             for (int ct = 0; ct < 16; ++ct) tf[(4 * kq + r) * kC + 16 * ct + i] = fr * U[ct][r];
         }
         __builtin_amdgcn_wave_barrier();
-        for (int head = 0; head < K; ++head) {
-            const float dr = __shfl(p0m1, head);
-            const float4 u = *reinterpret_cast<const float4*>(tf + head * kC + 4 * lane);
-            const float4 zv = ld4(z + ((long)b * S + t + koff + head + 1) * kC + 4 * lane);
-            f32x4 o;
-            o.x = fmaf(dr, zv.x, u.x); o.y = fmaf(dr, zv.y, u.y); o.z = fmaf(dr, zv.z, u.z); o.w = fmaf(dr, zv.w, u.w);
-            *reinterpret_cast<f32x4*>(tpred + ((long)bt * K + head) * kC + 4 * lane) = o;
-            amax_t = fmaxf(fmaxf(amax_t, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        if (!(dbg & 2)) {
+            // (every positive row requested before the first is used: one trip to L2 per window instead of one per head -- U's
+            //  registers are free by now)
+            for (int h0 = 0; h0 < K; h0 += 8) {
+                float4 zv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (h0 + q < K) zv[q] = ld4(z + ((long)b * S + t + koff + h0 + q + 1) * kC + 4 * lane);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (h0 + q < K) {                     // (wave-uniform)
+                        const float dr = __shfl(p0m1, h0 + q);
+                        const float4 u = *reinterpret_cast<const float4*>(tf + (h0 + q) * kC + 4 * lane);
+                        f32x4 o;
+                        o.x = fmaf(dr, zv[q].x, u.x); o.y = fmaf(dr, zv[q].y, u.y);
+                        o.z = fmaf(dr, zv[q].z, u.z); o.w = fmaf(dr, zv[q].w, u.w);
+                        *reinterpret_cast<f32x4*>(tpred + ((long)bt * K + h0 + q) * kC + 4 * lane) = o;
+                        amax_t = fmaxf(fmaxf(amax_t, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+                    }
+                }
+            }
         }
         // ---- the softmax rows per candidate slot (nce_fwd_fused_kernel's layout), from the logits just written
         float* prow = ps + (long)bt * (N + K) * 16 + i;
         const float* lrow = logits + ((long)bt * K + (hv ? i : 0)) * (N + 1) + 1 + 4 * kq;
-        for (int nt = 0; nt < N / 16; ++nt) {
+        for (int nt0 = 0; nt0 < ((dbg & 1) ? 0 : N / 16); nt0 += 4) {       // (four tiles' logits requested before the first exp)
+            float lv[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = hv ? expf(lrow[nt * 16 + r] - lse) : 0.f;
-                prow[(long)(nt * 16 + 4 * kq + r) * 16] = pv;
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lv[q][r] = nt0 + q < N / 16 ? lrow[(nt0 + q) * 16 + r] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (nt0 + q < N / 16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) prow[(long)((nt0 + q) * 16 + 4 * kq + r) * 16] = hv ? expf(lv[q][r] - lse) : 0.f;
+                }
             }
         }
 #pragma unroll
@@ -991,42 +1061,46 @@ __global__ __launch_bounds__(64, 2) void nce_bwd_g_h2_kernel(const unsigned char
     f32x4 acc[16];                                // acc[ct][r]: head 4 kq + r, channel 16 ct + i
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int p0 = 0; p0 < len; p0 += 16) {
+    // One tile = sixteen sorted slots.  Its rows are requested (DMA) and its weights loaded while the previous tile's 48 MFMAs run
+    // from REGISTERS: as soon as a tile has landed, its 32 transposed fragments are read out of LDS and the next request goes out.
+    auto request = [&](int p0, float (&a)[4]) __attribute__((always_inline)) {
+        const int pl = p0 + (lane & 15) < len ? p0 + (lane & 15) : 0;                  // (past the end: a valid row, weight 0)
+        const int mine = do_sort ? raw[pl] : crow_of(perm[beg + pl]);                  // lane r (and r + 16 ..): row of slot p0 + r
         int rows[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int pc = p0 + r < len ? p0 + r : 0;                        // (past the end: a valid row, weight 0)
-            rows[r] = __builtin_amdgcn_readfirstlane(do_sort ? raw[pc] : crow_of(perm[beg + pc]));
-        }
-        __builtin_amdgcn_wave_barrier();             // (the previous tile's transposing reads are done)
+        for (int r = 0; r < 16; ++r) rows[r] = __builtin_amdgcn_readlane(mine, r);
         tile_dma16(ch, rows, tile);
-        float a[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int p = p0 + 4 * kq + r;
             const bool ok = p < len;
             const int slot = do_sort ? sorted[ok ? p : 0] : perm[beg + (ok ? p : 0)];
-            a[r] = ok ? gsi * dS[(long)slot * 16 + i] : 0.f;                 // d score[head i][slot]
+            a[r] = ok ? gsi * dS[(long)slot * 16 + i] : 0.f;                           // d score[head i][slot]
         }
-        f16x4 wh, wl;
-        split4(a, sa, wh, wl);
+    };
+    float a[4];
+    if (len > 0) request(0, a);
+    for (int p0 = 0; p0 < len; p0 += 16) {
         CPC_WAIT_VMCNT(0);
         __builtin_amdgcn_wave_barrier();
+        f16x4 wh, wl;
+        split4(a, sa, wh, wl);
+        f16x4 bh[16], bl[16];
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct) {
+            bh[ct] = tile_read_tr(ta.p2(4 * ct));
+            bl[ct] = tile_read_tr(ta.p2(4 * ct + 1));
+        }
+        CPC_WAIT_LGKMCNT0();                             // (the fragments are in registers: the tile may be overwritten)
+        if (p0 + 16 < len) request(p0 + 16, a);
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
-            f16x4 bh[4], bl[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ct = 4 * c4 + u;
-                bh[u] = tile_read_tr(ta.p2(4 * ct));
-                bl[u] = tile_read_tr(ta.p2(4 * ct + 1));
-            }
+            for (int u = 0; u < 4; ++u) acc[4 * c4 + u] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, bh[4 * c4 + u], acc[4 * c4 + u], 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[4 * c4 + u] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, bh[u], acc[4 * c4 + u], 0, 0, 0);
+            for (int u = 0; u < 4; ++u) acc[4 * c4 + u] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, bl[4 * c4 + u], acc[4 * c4 + u], 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[4 * c4 + u] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, bl[u], acc[4 * c4 + u], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[4 * c4 + u] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl, bh[u], acc[4 * c4 + u], 0, 0, 0);
+            for (int u = 0; u < 4; ++u) acc[4 * c4 + u] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl, bh[4 * c4 + u], acc[4 * c4 + u], 0, 0, 0);
         }
     }
     const float inv = 1.0f / (sa * sc);
@@ -1299,10 +1373,15 @@ int g_index_prep_groups = -1;  // cpc_set_index_prep_groups: -1 (default) = at m
                                // hand: one resident workgroup per CU walking its share costs the conv layers less than thousands of
                                // short ones queueing for their CUs (same-box A/B at B = 64: 2.822 vs 2.837 ms per step sustained;
                                // 128 / 192: 2.830, 384: 2.845, 512: 2.855, 64: 2.99, 16: 3.94 -- then the lists are late)
-int g_nce_fused = 1;       // cpc_set_nce_fused: 1 (default) the one-pass criterion (nce_fwd_fused_kernel: scores and the unit-gradient
+int g_nce_fused = 2;       // cpc_set_nce_fused: 1 the one-pass criterion (nce_fwd_fused_kernel: scores and the unit-gradient
                            // dPred from ONE gather pass; linear heads), 0 the two-pass kernels (nce_fwd_kernel + nce_bwd_dpred_kernel),
-                           // 2 the one-pass criterion on fp16 pieces (nce_fwd_h2_kernel, nce_bwd_g_h2_kernel: H2 copies of z / c
-                           // as gather sources, DMA'd tiles, transposing LDS reads)
+                           // 2 (default since round 6) the one-pass criterion with the scoring kernel on fp16 pieces (nce_fwd_h2_kernel: an H2 copy of z as
+                           // gather source, DMA'd tiles, transposing LDS reads), 3 = 2 + the dz path's gather-GEMM likewise
+                           // (nce_bwd_g_h2_kernel, from an H2 copy of c)
+int g_nce_dbg = 0;         // cpc_set_nce_debug: measurement switches of nce_fwd_h2_kernel (tools/time_nce.py) -- bit 0 no softmax-row
+                           // pass, 1 no T epilogue, 2 no weighted row sum, 3 no logits stores; results are then WRONG
+int g_nce_rows_apart = 1;  // cpc_set_nce_rows_apart: the softmax rows of the fp16-piece scoring kernel by a launch of their own (on the
+                           // loss reduction's stream) instead of inside it
 int g_nce_grid = 0;        // cpc_set_nce_grid: workgroups of nce_fwd_h2_kernel -- 0 one per four windows, -1 two per CU (each
                            // walking windows 4 wg + wave, + 4 grid, ...: all waves sweep the sorted candidate lists in step), n > 0
 
@@ -1410,7 +1489,7 @@ static int nce_scores_forward(const NceLayout& n, const float* pred, const float
     // fused: the one-pass kernel, which also leaves T (unit-gradient dPred) and max|T| in `saved` (slots zeroed by the caller)
     unsigned* ticket = reinterpret_cast<unsigned*>(scratch + n.sums + 32);
     step_timer_mark(8, st);
-    if (fused == 2) {
+    if (fused >= 2) {
         // (zh: nce_prepare_zh, queued by the caller on this stream)
         long wgs = cdiv(n.BW, 4);
         if (g_nce_grid != 0) {
@@ -1425,7 +1504,7 @@ static int nce_scores_forward(const NceLayout& n, const float* pred, const float
         hipLaunchKernelGGL(nce_fwd_h2_kernel, dim3((unsigned)wgs), dim3(256), 0, st, pred, z,
                            reinterpret_cast<const unsigned char*>(saved + n.zh), saved + n.bounds + 3 * kAmaxSlots, ext, saved + n.logits,
                            saved + n.lse, scratch + n.rowstat, saved + n.tpred, saved + n.bounds + 2 * kAmaxSlots, saved + n.ps,
-                           n.BW, n.W, S, K, N, ticket, n.Nv, n.koff);
+                           n.BW, n.W, S, K, N, ticket, n.Nv, n.koff, g_nce_dbg | (g_nce_rows_apart ? 1 : 0));
     } else if (fused)
         hipLaunchKernelGGL(nce_fwd_fused_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
                            saved + n.lse, scratch + n.rowstat, saved + n.tpred, saved + n.bounds + 2 * kAmaxSlots, saved + n.ps,
@@ -1440,6 +1519,12 @@ static int nce_scores_forward(const NceLayout& n, const float* pred, const float
         CPC_RETURN_IF(!ev, CPC_ERR_ARG);
         CPC_RETURN_IF(hipEventRecord(ev[10], st) != hipSuccess || hipStreamWaitEvent(fin, ev[10], 0) != hipSuccess, CPC_ERR_ARG);
         st = fin;
+    }
+    if (fused >= 2 && g_nce_rows_apart && !(g_nce_dbg & 1)) {
+        // the softmax rows, on the stream the reduction runs on (fin: off the forward's chain where the caller has one)
+        hipLaunchKernelGGL(nce_softmax_rows_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, saved + n.logits, saved + n.lse, saved + n.ps,
+                           n.BW, K, N);
+        CPC_LAUNCH_CHECK();
     }
     {                                                   // 2 K <= 32 columns (nce_layout): rows_sum's groups and order of additions
         int groups = n.BW > 64 ? kRowsSumGroups : 1;
@@ -1478,7 +1563,7 @@ static int nce_dz_linear_path(const NceLayout& n, const float* c, const float* w
     float* bnd = scratch + n.gscale;
     const bool h2 = g_mfma_mode >= 2;
     hipLaunchKernelGGL(nce_wcat_kernel, dim3(cdiv(K * kC, 4)), dim3(256), 0, st, wall, wcat, K);
-    if (saved_for_ds != nullptr && nce_fused(N) == 2) {     // ... on fp16 pieces, from an H2 copy of c scaled for the forward's bound of |c|
+    if (saved_for_ds != nullptr && nce_fused(N) == 3) {     // ... on fp16 pieces, from an H2 copy of c scaled for the forward's bound of |c|
         int rc = nce_rows_to_h2(c, scratch + n.ch, saved_for_ds + n.bounds, (long)B * S, st);
         if (rc) return rc;
         hipLaunchKernelGGL(nce_bwd_g_h2_kernel, dim3(B * S), dim3(64), 0, st, reinterpret_cast<const unsigned char*>(scratch + n.ch),
@@ -1602,7 +1687,7 @@ static int nce_forward(const float* c, const float* z, const float* wall, const 
     gb.b = saved + n.bounds + kAmaxSlots; gb.b_slots = kAmaxSlots;
     int rc = nt_gemm(window_rows(c, B, S, n.W), wall, kC, nullptr, pred, (long)K * kC, K * kC, kC, st, 0, 0, gb);
     if (rc) return rc;
-    if (nce_fused(N) == 2 && !g_zh_ready) {                 // (cpc_nce_prepare_z: ahead of time, on another stream)
+    if (nce_fused(N) >= 2 && !g_zh_ready) {                 // (cpc_nce_prepare_z: ahead of time, on another stream)
         rc = nce_prepare_zh(n, z, saved, B, S, st);
         if (rc) return rc;
     }
@@ -1828,11 +1913,14 @@ extern "C" int cpc_set_index_prep_groups(int n) {
 }
 
 extern "C" int cpc_set_nce_fused(int on) {
-    CPC_RETURN_IF(on < 0 || on > 2, CPC_ERR_ARG);
+    CPC_RETURN_IF(on < 0 || on > 3, CPC_ERR_ARG);
     g_nce_fused = on;
     return 0;
 }
 extern "C" int cpc_get_nce_fused(void) { return g_nce_fused; }
+extern "C" int cpc_set_nce_rows_apart(int on) { g_nce_rows_apart = on ? 1 : 0; return 0; }
+/* measurement only (tools/time_nce.py): leave parts of nce_fwd_h2_kernel out -- results are wrong while mask != 0 */
+extern "C" int cpc_set_nce_debug(int mask) { g_nce_dbg = mask; return 0; }
 
 // Workgroups of the fp16-piece scoring kernel: 0 = one per four windows (dispatch order), -1 = two per CU, n > 0 = at most n;
 // a capped grid walks its windows with a stride of the grid (cpc_set_nce_fused(2) only).
@@ -1849,7 +1937,7 @@ extern "C" int cpc_nce_prepare_z(const float* z, float* saved, int B, int S, int
     NceLayout n;
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!z || !saved, CPC_ERR_ARG);
-    if (nce_fused(n.N) != 2) return 0;
+    if (nce_fused(n.N) < 2) return 0;
     g_zh_ready = true;
     return nce_prepare_zh(n, z, saved, B, S, (hipStream_t)stream);
 }

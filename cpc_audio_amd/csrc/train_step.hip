@@ -222,6 +222,15 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
             CPC_RETURN_IF(!rec(ev[6], M) || !wait(S0, ev[6]), CPC_ERR_ARG);
             if ((rc = prepare())) return rc;
         }
+        // the fp16-piece scoring kernel (cpc_set_nce_fused(2 / 3)) gathers from an H2 copy of z: made on the side stream as soon as the
+        // encoder is done (behind the index lists), beside the recurrence; the event main waits for in front of the criterion is
+        // recorded again behind it
+        if (cpc_get_nce_fused() >= 2 && S0 != M) {
+            CPC_RETURN_IF(!rec(pool[kEvEncoderDone], M) || !wait(S0, pool[kEvEncoderDone]), CPC_ERR_ARG);
+            rc = cpc_nce_prepare_z(z, ws + s.nce_saved, B, S, K, N, S0);
+            if (rc) return rc;
+            CPC_RETURN_IF(!rec(ev[1], S0), CPC_ERR_ARG);
+        }
         CPC_RETURN_IF(!wait(M, ev[7]), CPC_ERR_ARG);
         rc = cpc_gru_forward_coef_prepared(z, h0, gru_p, ws + s.gru_saved, ws + s.gru_fscr, c, hN, coef, B, S, 2, M);
         if (rc) return rc;
@@ -232,8 +241,9 @@ extern "C" int cpc_train_step(const float* wave, const long* batchIdx, const lon
         CPC_RETURN_IF(!rec(ev[2], S1) || !wait(M, ev[1]), CPC_ERR_ARG);
         // (the loss / accuracy reduction runs on the side stream: the backward reads the saved logits, not the losses; the side
         // stream is joined before the step ends)
+        // (... and, with the fp16-piece scoring kernel, the softmax rows the dz path reads -- which therefore must run on S0 as well)
         rc = cpc_nce_forward_streams(c, z, wall, ext, ws + s.nce_saved, ws + s.nce_fscr, losses, acc, B, S, K, N, bounds_early ? 1 : 0, M,
-                                     early ? S0 : M);
+                                     early && !g_dz_early ? S0 : M);
         if (rc) return rc;
         // ---- backward ----
         // criterion: score gradients, dPred and dc on main; the dz path and the heads' weight gradient are held back

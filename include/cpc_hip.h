@@ -407,21 +407,28 @@ int cpc_nce_backward_dz(const float* c, const float* wall, const int* perm, cons
  * the way to the encoder depends on it.  `stream` must wait for the cpc_nce_backward_streams call. */
 int cpc_nce_backward_dwall(const float* c, const float* saved, float* scratch, float* dwall, int B, int S, int K, int N,
                            void* stream);
-/* The linear heads' criterion in ONE gather pass (default, 1): the scoring kernel of cpc_nce_forward* carries the softmax-weighted
+/* The linear heads' criterion in ONE gather pass (1; default since round 6: 2, below): the scoring kernel of cpc_nce_forward* carries the softmax-weighted
  * sum of the candidate rows along with the log-sum-exp (an online softmax over criterion.py:108-116's candidates) and leaves
  * T = d loss_k / d pred_k for a unit upstream gradient in `saved`; the backward then has no score-gradient pass over the 1 KB
  * candidate rows (criterion.py:200-201's gather, 1.06 GB at B = 64) -- the heads' upstream gradients are folded into the dc
  * GEMM's weight operand and the weight gradient's reduction, the dz path multiplies the softmax rows the forward leaves per
  * candidate slot.  0: the two-pass kernels.  A forward and its backward run under the same setting. */
 int cpc_set_nce_fused(int on);
-/* (on = 2, round 6: the same one-pass criterion on the 16-bit matrix pipe -- both products as hh + hl + lh of two fp16 pieces,
- * the arithmetic of the conv layers -- gathering from H2 copies of z (forward) and c (the dz path's gather-GEMM) that go
- * global -> LDS by DMA, the contraction over candidates fed by the transposing LDS read.  Same interface, same saved tensors.) */
+/* (on = 2, round 6: the same one-pass criterion with the scoring kernel on the 16-bit matrix pipe -- both products as hh + hl + lh
+ * of two fp16 pieces, the arithmetic of the conv layers -- gathering from an H2 copy of z that goes global -> LDS by DMA, the
+ * contraction over candidates fed by the transposing LDS read; on = 3: the dz path's gather-GEMM likewise, from an H2 copy of c.
+ * Same interface, same saved tensors.) */
 int cpc_get_nce_fused(void);
-/* cpc_set_nce_fused(2): workgroups of the scoring kernel -- 0 = one per four windows, -1 = two per CU, n > 0 = at most n (a capped
+/* cpc_set_nce_fused(2 / 3): workgroups of the scoring kernel -- 0 = one per four windows, -1 = two per CU, n > 0 = at most n (a capped
  * grid walks its windows with the grid's stride, so that all resident waves sweep their ascending candidate lists in step). */
 int cpc_set_nce_grid(int wgs);
-/* cpc_set_nce_fused(2): the H2 copy of z (criterion.py:200-201's gather source) ahead of time on `stream` -- z is final when
+/* cpc_set_nce_fused(2 / 3): 1 (default) = the softmax rows the dz path reads are written by a launch of their own, on the stream
+ * the loss reduction runs on (cpc_nce_forward_streams' finalize_stream: off the forward's chain), 0 = inside the scoring kernel. */
+int cpc_set_nce_rows_apart(int on);
+/* Measurement switch of the cpc_set_nce_fused(2) scoring kernel (tools/time_nce.py: what each part of it costs): bit 0 leaves the
+ * softmax-row pass out, 1 the T epilogue, 2 the weighted row sum, 3 the logits stores.  Results are WRONG while mask != 0. */
+int cpc_set_nce_debug(int mask);
+/* cpc_set_nce_fused(2 / 3): the H2 copy of z (criterion.py:200-201's gather source) ahead of time on `stream` -- z is final when
  * the encoder has run; the calling thread's next cpc_nce_forward* then skips the two small launches.  No-op in other modes. */
 int cpc_nce_prepare_z(const float* z, float* saved, int B, int S, int K, int N, void* stream);
 /* Tuning switch: at most n workgroups per launch of cpc_nce_prepare's kernels (each then walks several windows / slots);

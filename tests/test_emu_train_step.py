@@ -127,13 +127,27 @@ def test_composite_step_matches_oracle_and_the_stagewise_step_emulated(B, L, K, 
     check_composite_step(emu(), B, L, K, N, use_h0)
 
 
-def check_composite_step(lib, B, L, K, N, use_h0, seed=0, device=None):
+@pytest.mark.parametrize("mode", [2, 3])
+def test_composite_step_with_the_criterion_on_fp16_pieces_emulated(mode):
+    """cpc_set_nce_fused(2 / 3): the scoring kernel (and the dz path's gather-GEMM) on fp16 pieces; the composite step makes the H2
+    copy of z on the side stream behind the encoder (cpc_nce_prepare_z), the stage-wise order inside cpc_nce_forward: same bits."""
+    lib = emu()
+    assert lib.cpc_set_nce_fused(mode) == 0
+    try:
+        check_composite_step(lib, 2, 3200, 4, 16, False)
+        check_composite_step(lib, 3, 2880, 5, 33, True, streams=(None, 64, 128, 192))
+    finally:
+        assert lib.cpc_set_nce_fused(_L.DEFAULT_NCE_FUSED) == 0
+
+
+def check_composite_step(lib, B, L, K, N, use_h0, seed=0, device=None, streams=(None, None, None, None)):
     """One composite step against the oracle (outputs, losses, accuracies, every gradient) and, bit for bit, against the
     stage-wise entry points (also used by tests/test_emu_shapes.py and, with a cuda ``device`` and the product library, by
     tests/test_gpu_shapes.py)."""
     p, wave, S, bidx, sidx, plist = _setup(B, L, K, N, seed=seed)
     h0 = (0.3 * torch.randn(2, B, 256, generator=torch.Generator().manual_seed(9))) if use_h0 else None
-    out, hN, grads, z, c = _composite(lib, wave, bidx, sidx, h0, 0.0 if use_h0 else 1.0, plist, B, L, K, N, device=device)
+    out, hN, grads, z, c = _composite(lib, wave, bidx, sidx, h0, 0.0 if use_h0 else 1.0, plist, B, L, K, N, device=device,
+                                      streams=streams)
     # ---- the oracle: losses, accuracies, outputs, every gradient
     with torch.backends.mkldnn.flags(enabled=False):     # (torch's oneDNN conv backward is wrong at some odd shapes: test_emu_encoder._oracle_encoder)
         ora = O.train_step(p, wave, bidx, sidx, n_predicts=K, n_neg=N, h0=h0)

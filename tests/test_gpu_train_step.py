@@ -58,8 +58,8 @@ def _hip_step(p, wave, bidx, sidx, dev):
 
 @pytest.fixture
 def nce_mode(request):
-    """cpc_set_nce_fused for the test: 1 the one-pass criterion on exact-f32 MFMAs, 2 on fp16 pieces (H2 gather sources, DMA'd
-    tiles, transposing LDS reads -- round 6); restored afterwards."""
+    """cpc_set_nce_fused for the test: 1 the one-pass criterion on exact-f32 MFMAs, 2 its scoring kernel on fp16 pieces (H2 gather source, DMA'd
+    tiles, transposing LDS reads -- round 6), 3 the dz path's gather-GEMM as well; restored afterwards."""
     from cpc_audio_amd import _lib
     lib = _lib.get()
     before = lib.cpc_get_nce_fused()
@@ -68,7 +68,7 @@ def nce_mode(request):
     lib.check(lib.cpc_set_nce_fused(before), "set_nce_fused")
 
 
-@pytest.mark.parametrize("nce_mode", [1, 2], indirect=True)
+@pytest.mark.parametrize("nce_mode", [1, 2, 3], indirect=True)
 @pytest.mark.parametrize("case", ["b2_init", "b2_hot", "b8_cfg1"])
 def test_train_step_matches_oracle_and_reference_golden(case, golden_dir, nce_mode):
     dev = _dev()
