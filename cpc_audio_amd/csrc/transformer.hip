@@ -1,6 +1,7 @@
 // Transformer layer of the reference (cpc/transformers.py), forward + backward, d_model 256, 8 heads of 32,
 // d_ff 2048, sequence length S <= 128 (128 as the auto-regressive network, --arMode transformer; 116 as a
-// prediction network, --rnnMode transformer).  BASELINE.json config 4.
+// prediction network, --rnnMode transformer).  BASELINE.json config 4.  Forward only (inference, no dropout) also for
+// 128 < S <= 512: a layer built for a longer window, e.g. the 400 frames of a 64000-sample feature-extraction chunk.
 //
 //   q,k,v = x Wq^T, x Wk^T, x Wv^T                         cpc/transformers.py:60-63, 82-84 (bias-free)
 //   score[i,j] = (q_i.k_j + q_i.P[:, S-1-(i-j)]) / sqrt(32), j <= i      :37-48 (relative positions through the
@@ -288,6 +289,122 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         if (i < S) {
             o[(row0 + i) * kC + h * kDk + l31] = ov[r];
             m = fmaxf(m, fabsf(ov[r]));
+        }
+    }
+    publish_amax(o_amax, m);
+}
+
+// ------------------------------------------------------------------ attention forward, 128 < S <= 512 (inference)
+// A layer built for a 64000-sample feature-extraction window (cpc/feature_loader.py:247-266 feeds 400 frames; cpc/transformers.py
+// :22-49 at sizeSeq = 400) does not fit attn_fwd_kernel's one-tile-per-sequence LDS image.  Forward only, no dropout, no saved
+// probabilities: grid = (B * 8, ceil(S / 128), G); a workgroup takes 128 query rows (wave w: rows 32 w ..) and walks the key blocks
+// up to its own diagonal with a running softmax (row maximum, denominator and the output tile rescaled as the maximum moves).
+// Per 32-key tile: scores Q.K^T (16 MFMAs), the relative-position term E = Q . P[:, c0 .. c0 + 63] for the 63 distances the tile
+// can see (32 MFMAs, P's columns straight from L2 as the B operand -- Krelpos is 51 KB at S = 400), read back skewed as in the
+// short kernel, then probabilities . V (16 MFMAs); every product on v_mfma_f32_32x32x2_f32.
+constexpr int kSlong = 512;
+constexpr int kLdE = 64 + 1;       // per-wave 32 x 64 work tile: E, then the tile's probabilities
+__global__ __launch_bounds__(256) void attn_fwd_long_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                            float* __restrict__ o, int S, TfStrides gs, float* __restrict__ o_amax) {
+    __shared__ float lds[3 * kSmax * kLdH + 4 * 32 * kLdE];           // 84 KB
+    {
+        const long g = blockIdx.z;
+        qkv += g * gs.saved; o += g * gs.saved;
+        if (o_amax != nullptr) o_amax += g * gs.saved;
+        if (P != nullptr) P += g * gs.par[4];
+    }
+    float* Qs = lds;
+    float* Ks = Qs + kSmax * kLdH;
+    float* Vs = Ks + kSmax * kLdH;
+    const int bh = blockIdx.x, b = bh / kTH, h = bh % kTH, qb = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const long row0 = (long)b * S;
+    const int q0 = 128 * qb, i0 = q0 + 32 * w;        // this wave's first query row
+    float* Ww = Vs + kSmax * kLdH + w * 32 * kLdE;
+    store_head(Qs, load_head<256>(qkv, row0 + q0, 3 * kC, h * kDk, S - q0));
+    const float* qrow = Qs + (32 * w + l31) * kLdH;
+    const float scale = 0.17677669529663687f;         // 1 / sqrt(32)
+    float mrow[16], lrow[16];
+    f32x16 ov;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; ov[r] = 0.f; }
+    for (int kb = 0; kb <= qb; ++kb) {
+        const int k0 = 128 * kb;
+        const HeadPieces<256> pk = load_head<256>(qkv, row0 + k0, 3 * kC, kC + h * kDk, S - k0),
+                              pv = load_head<256>(qkv, row0 + k0, 3 * kC, 2 * kC + h * kDk, S - k0);
+        __syncthreads();                              // every wave is done with the previous block (and Q is staged)
+        store_head(Ks, pk); store_head(Vs, pv);
+        __syncthreads();
+        if (i0 >= S) continue;                        // wave-uniform: no query rows here (the barriers above are still met)
+        for (int ct = 0; ct < 4; ++ct) {
+            const int j0 = k0 + 32 * ct;
+            if (j0 > i0 + 31 || j0 >= S) break;       // wave-uniform: entirely in the future / past the sequence
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* krow = Ks + (ct * 32 + l31) * kLdH;
+#pragma unroll
+            for (int kk = 0; kk < kDk / 2; ++kk) {
+                const int k = 2 * kk + khalf;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[k], krow[k], acc, 0, 0, 0);
+            }
+            if (P != nullptr) {
+                // E[il][cc] = q_(i0 + il) . P[:, cbase + cc]; score (il, jl) needs distance column S - 1 - i + j = cbase + 31 - il + jl
+                const int cbase = S - 1 - (i0 + 31) + j0;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int cc = min(max(cbase + 32 * u + l31, 0), S - 1);      // (clamped columns belong to masked entries)
+                    f32x16 e;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e[r] = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < kDk / 2; ++kk) {
+                        const int k = 2 * kk + khalf;
+                        e = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[k], P[(long)k * S + cc], e, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Ww[c_row(r, lane) * kLdE + 32 * u + l31] = e[r];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            float sc[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = c_row(r, lane), i = i0 + il, j = j0 + l31;
+                const float rel = P != nullptr ? Ww[il * kLdE + 31 - il + l31] : 0.f;
+                sc[r] = (j <= i && i < S) ? (acc[r] + rel) * scale : -INFINITY;
+            }
+            __builtin_amdgcn_wave_barrier();          // every lane has read E: the tile now takes the probabilities
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = c_row(r, lane);
+                const float mn = fmaxf(mrow[r], half_max(sc[r]));
+                const float pr = sc[r] > -INFINITY ? expf(sc[r] - mn) : 0.f;
+                const float alpha = mrow[r] > -INFINITY ? expf(mrow[r] - mn) : 1.0f;      // (nothing accumulated yet: lrow, ov are 0)
+                lrow[r] = lrow[r] * alpha + half_sum(pr);
+                ov[r] *= alpha;
+                mrow[r] = mn;
+                Ww[il * kLdE + l31] = pr;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float* arow = Ww + l31 * kLdE;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int k = 2 * kk + khalf;
+                ov = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k], Vs[(32 * ct + k) * kLdH + l31], ov, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();          // (the next tile's E overwrites the probabilities)
+        }
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = i0 + c_row(r, lane);
+        if (i < S) {
+            const float v = ov[r] / lrow[r];          // (row i always sees key i: lrow > 0)
+            o[(row0 + i) * kC + h * kDk + l31] = v;
+            m = fmaxf(m, fabsf(v));
         }
     }
     publish_amax(o_amax, m);
@@ -723,11 +840,11 @@ enum { kBX = 0, kBWq, kBWk, kBWv, kBWo, kBW1, kBW2, kBWqkv, kBO, kBY, kBHid, kTf
 enum { kBDs2 = 0, kBDh, kBDs1, kBDqkv, kTfBwdBounds };
 
 static bool tf_layout(int B, int S, TfLayout& t) {
-    if (B <= 0 || S <= 0 || S > kSmax) return false;
+    if (B <= 0 || S <= 0 || S > kSlong) return false;
     const long M = (long)B * S;
     long o = 0;
     t.qkv = o; o += align64l(M * 3 * kC);
-    t.A = o; o += align64l((long)B * kTH * S * S);
+    t.A = o; o += S > kSmax ? 0 : align64l((long)B * kTH * S * S);     // (longer sequences: forward only, attn_fwd_long_kernel)
     t.o = o; o += align64l(M * kC);
     t.xhat1 = o; o += align64l(M * kC);
     t.rstd1 = o; o += align64l(M);
@@ -791,6 +908,7 @@ static int tf_forward(const TfGroup& tg, const float* x, const float* const* par
                       int B, int S, float p, unsigned long long seed, hipStream_t st) {
     TfLayout t;
     if (!tf_layout(B, S, t)) return CPC_ERR_SHAPE;
+    if (S > kSmax && p > 0.f) return CPC_ERR_SHAPE;   // beyond 128 steps: inference only (no dropout masks, nothing saved for a backward)
     const int M = B * S, G = tg.G;
     const long sv = tg.ks.saved, sc = tg.ks.scratch;
     const long* ps = tg.ks.par;
@@ -828,6 +946,10 @@ static int tf_forward(const TfGroup& tg, const float* x, const float* const* par
     if ((rc = nt_gemm(xm, Wq, kC, nullptr, qkv, 3 * kC, kC, kC, st, 0, 0, gbnd(kBX, kBWq), grp(tg.x, ps[2], 0, sv)))) return rc;
     if ((rc = nt_gemm(xm, Wk, kC, nullptr, qkv + kC, 3 * kC, kC, kC, st, 0, 0, gbnd(kBX, kBWk), grp(tg.x, ps[1], 0, sv)))) return rc;
     if ((rc = nt_gemm(xm, Wv, kC, nullptr, qkv + 2 * kC, 3 * kC, kC, kC, st, 0, 0, gbnd(kBX, kBWv), grp(tg.x, ps[3], 0, sv)))) return rc;
+    if (S > kSmax)       // (inference: checked by the caller -- no dropout, no backward)
+        hipLaunchKernelGGL(attn_fwd_long_kernel, dim3(B * kTH, cdiv(S, kSmax), G), dim3(256), 0, st, qkv, P, saved + t.o, S, tg.ks,
+                           slot(kBO));
+    else
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * kTH, G), dim3(256), 0, st, qkv, P, saved + t.o, saved + t.A, S, p, seed, tg.ks,
                        slot(kBO));
     CPC_LAUNCH_CHECK();
@@ -863,7 +985,7 @@ static int tf_backward(const TfGroup& tg, const float* x, const float* const* pa
                        float* scratch, float* dx, float* const* grads, int B, int S, float p, unsigned long long seed,
                        hipStream_t st) {
     TfLayout t;
-    if (!tf_layout(B, S, t)) return CPC_ERR_SHAPE;
+    if (!tf_layout(B, S, t) || S > kSmax) return CPC_ERR_SHAPE;      // (sequences beyond 128 steps: forward only)
     const int M = B * S, G = tg.G;
     const long sv = tg.ks.saved, sc = tg.ks.scratch;
     const long* ps = tg.ks.par;

@@ -748,8 +748,12 @@ class TransformerGroupFunction(torch.autograd.Function):
         B, S, D = x.shape
         if D != _HID:
             raise NotImplementedError("the HIP transformer layer is built for d_model == 256")
-        if S > 128:
-            raise NotImplementedError("the HIP attention kernels hold sequences of at most 128 steps")
+        if S > 512:
+            raise NotImplementedError("the HIP attention kernels hold sequences of at most 512 steps")
+        if S > 128 and (float(drop_p) > 0 or (torch.is_grad_enabled() and (x.requires_grad or any(
+                p is not None and p.requires_grad for p in params)))):
+            # (callers -- transformers.TransformerLayer -- route such calls to the torch-op forward)
+            raise NotImplementedError("beyond 128 steps the HIP transformer layer is forward-only (inference, no dropout)")
         x = x.contiguous()
         params = [None if p is None else p.detach().contiguous() for p in params]
         if any(p is not None and p.shape[0] != G for p in params):
@@ -804,8 +808,12 @@ class TransformerLayerFunction(torch.autograd.Function):
         B, S, D = x.shape
         if D != _HID:
             raise NotImplementedError("the HIP transformer layer is built for d_model == 256")
-        if S > 128:
-            raise NotImplementedError("the HIP attention kernels hold sequences of at most 128 steps")
+        if S > 512:
+            raise NotImplementedError("the HIP attention kernels hold sequences of at most 512 steps")
+        if S > 128 and (float(drop_p) > 0 or (torch.is_grad_enabled() and (x.requires_grad or any(
+                p is not None and p.requires_grad for p in params)))):
+            # (callers -- transformers.TransformerLayer -- route such calls to the torch-op forward)
+            raise NotImplementedError("beyond 128 steps the HIP transformer layer is forward-only (inference, no dropout)")
         x = x.contiguous()
         params = [None if p is None else p.detach().contiguous() for p in params]
         if params[4] is not None and tuple(params[4].shape) != (32, S):

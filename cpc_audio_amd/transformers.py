@@ -106,19 +106,29 @@ class TransformerLayer(nn.Module):
     def __init__(self, sizeSeq=32, dmodel=512, dff=2048, dropout=0.1, nheads=8, abspos=False):
         super().__init__()
         # The fused HIP layer (csrc/transformer.hip) is built for what BASELINE config 4 uses -- dmodel 256, dff 2048, 8 heads,
-        # sequences of at most 128 steps (the 20480-sample training window).  Anything else -- a layer built for the 400 frames
-        # of a 64000-sample feature-extraction chunk (cpc/feature_loader.py:247-266), another width -- runs through the
-        # sub-modules' torch-op forwards below: correct on any device, differentiable, not the hot path.
-        self.fused = dmodel == 256 and dff == 2048 and nheads == 8 and sizeSeq <= 128
+        # sequences of at most 128 steps (the 20480-sample training window), forward and backward -- and, forward only (inference:
+        # no gradient, no dropout), for layers built for up to 512 steps: the 400 frames of a 64000-sample feature-extraction
+        # chunk (cpc/feature_loader.py:247-266).  Anything else -- training at more than 128 steps, another width, more than 512
+        # steps -- runs through the sub-modules' torch-op forwards below: correct on any device, differentiable, not the hot path.
+        self.fused = dmodel == 256 and dff == 2048 and nheads == 8 and sizeSeq <= 512
+        self.fused_train = self.fused and sizeSeq <= 128
+        self.sizeSeq = sizeSeq
         self.dropout_p = float(dropout)
         self.multihead = MultiHeadAttention(sizeSeq, dropout, dmodel, nheads, abspos)
         self.ln_multihead = nn.LayerNorm(dmodel)
         self.ffnetwork = FFNetwork(dmodel, dmodel, dff, dropout)
         self.ln_ffnetwork = nn.LayerNorm(dmodel)
 
+    def _needs_autograd(self, x):
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+
     def forward(self, x):
-        if not (self.fused and x.is_cuda):
-            if self.fused:
+        # beyond 128 steps the kernels are forward-only: a call that must be differentiable, or drops out, composes torch ops
+        # (... as does a sequence of another length than the long layer was built for: the torch-op forward slices Krelpos / the mask)
+        long_train = self.fused and not self.fused_train and x.is_cuda and (
+            self._needs_autograd(x) or (self.training and self.dropout_p > 0) or x.size(1) != self.sizeSeq)
+        if not (self.fused and x.is_cuda) or long_train:
+            if self.fused_train:
                 raise RuntimeError("TransformerLayer: the fused HIP layer needs CUDA tensors (there is no CPU fallback for the hot path)")
             y = self.ln_multihead(x + self.multihead(x, x, x))                 # cpc/transformers.py:109-111
             return self.ln_ffnetwork(y + self.ffnetwork(y))

@@ -294,7 +294,10 @@ int cpc_gru_backward_streams(const float* x, const float* h0, const float* const
  * multihead.Att.Krelpos (32,S) (NULL = abspos layer without the relative term), ln_multihead.weight, .bias,
  * ffnetwork.lin1.weight (2048,256), .bias, ffnetwork.lin2.weight (256,2048), .bias, ln_ffnetwork.weight, .bias.
  * sizes[0] = saved floats, [1] = forward scratch floats, [2] = backward scratch floats, [3..7] = offsets inside
- * `saved` of qkv (B*S,768), A (B*8,S,S), o, y (B*S,256), hid (B*S,2048) = relu(lin1(y)). */
+ * `saved` of qkv (B*S,768), A (B*8,S,S), o, y (B*S,256), hid (B*S,2048) = relu(lin1(y)).
+ * 128 < S <= 512 (a layer built for a longer window -- the 400 frames of a 64000-sample feature-extraction chunk,
+ * cpc/feature_loader.py:247-266): FORWARD ONLY, without dropout -- attention as a running-softmax walk over 128-key blocks
+ * (attn_fwd_long_kernel); the attention probabilities A are not kept (size 0), the backward entry points refuse such S. */
 int cpc_transformer_layout(int B, int S, long* sizes);
 int cpc_transformer_layer_forward(const float* x, const float* const* params, float* saved, float* scratch,
                                   float* out, int B, int S, void* stream);

@@ -52,6 +52,35 @@ def test_transformer_layer_forward_backward_emulated(B, S, abspos):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("B,S,abspos", [(1, 160, False), (2, 129, False), (1, 400, False), (1, 257, True)])
+def test_transformer_layer_forward_beyond_128_steps_emulated(B, S, abspos):
+    """128 < S <= 512: forward only (attn_fwd_long_kernel: 128-row query blocks, key blocks up to the diagonal, running softmax,
+    the relative-position term from the 63 distance columns a 32 x 32 tile sees) against the oracle; the backward entry point
+    refuses, the layout keeps no attention probabilities.  S = 400: a 64000-sample feature-extraction chunk."""
+    lib = emu()
+    p = T.make_layer_params(seed=3 + S, size_seq=S, abspos=abspos)
+    g = torch.Generator().manual_seed(S)
+    x = torch.randn(B, S, 256, generator=g)
+    plist = [p[k].contiguous() if k in p else None for k in ORDER]
+    sizes = (ctypes.c_long * 8)()
+    assert lib.cpc_transformer_layout(B, S, sizes) == 0
+    assert sizes[5] == sizes[4]                                     # A (B*8,S,S) takes no room
+    saved = torch.full((sizes[0],), float("nan"))
+    fscr = torch.full((sizes[1],), float("nan"))
+    out = torch.full((B, S, 256), float("nan"))
+    parr = (ctypes.c_void_p * 13)(*[P(t) for t in plist])
+    assert lib.cpc_transformer_layer_forward(P(x), parr, P(saved), P(fscr), P(out), B, S, None) == 0
+    yr = T.layer_forward(p, x)
+    assert (out - yr).abs().max().item() < 1e-5
+    assert lib.cpc_transformer_layer_forward_dropout(P(x), parr, P(saved), P(fscr), P(out), B, S, 0.1, 5, None) != 0
+    bscr = torch.zeros(max(1, sizes[2]))
+    grads = [torch.zeros_like(t) if t is not None else None for t in plist]
+    garr = (ctypes.c_void_p * 13)(*[P(t) for t in grads])
+    dx = torch.zeros(B, S, 256)
+    assert lib.cpc_transformer_layer_backward(P(x), parr, P(saved), P(out), P(bscr), P(dx), garr, B, S, None) != 0
+    assert lib.cpc_transformer_layout(1, 513, sizes) != 0
+
+
 @pytest.fixture(params=[1, 3], ids=["elementwise-relu", "relu-in-gemm-epilogue"])
 def gemm_split(request):
     """cpc_set_gemm_split(3) puts every product on the wide fp16-piece tile however small the grid, which is the tile whose

@@ -268,3 +268,69 @@ def test_feed_forward_epilogues_equal_the_elementwise_kernels_bit_for_bit(p_drop
             assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()       # another order of the same 8192 terms
         else:
             assert torch.equal(a, b), i
+
+
+@pytest.mark.parametrize("B,S,abspos", [(2, 400, False), (3, 129, False), (1, 512, False), (2, 257, True)])
+def test_transformer_layer_beyond_128_steps_runs_on_the_kernels_in_inference(B, S, abspos):
+    """A layer built for more than 128 steps (sizeSeq = 400: a 64000-sample feature-extraction window, cpc/feature_loader.py
+    :247-266 with cpc/transformers.py:22-49 at that length) runs on the HIP kernels when no gradient is asked for -- attention as
+    a running-softmax walk over key blocks (attn_fwd_long_kernel) -- and matches the oracle; the same module asked for a
+    gradient, or in training mode with dropout, composes torch ops (differentiable) and matches as well."""
+    dev = _dev()
+    from cpc_audio_amd import _lib
+    from cpc_audio_amd.transformers import TransformerLayer, buildTransformerAR
+    first = 1 if abspos else 0
+    p = T.make_layer_params(11 + S, 256, S, abspos, prefix=f"{first}.")
+    net = buildTransformerAR(256, 1, S, abspos, dropout=0.1).to(dev)
+    net.load_state_dict(p, strict=False)
+    layer = net[-1]
+    assert isinstance(layer, TransformerLayer) and layer.fused and not layer.fused_train
+    x = torch.randn(B, S, 256, generator=torch.Generator().manual_seed(S))
+    yr = T.ar_forward(p, x, 1, abspos)
+    net.eval()
+    calls = []
+    lib = _lib.get()
+    orig = lib.cpc_transformer_layer_forward_dropout
+    lib.cpc_transformer_layer_forward_dropout = lambda *a: (calls.append(a[6:8]), orig(*a))[1]     # (B, S) of every kernel call
+    try:
+        with torch.no_grad():
+            y = net(x.to(dev))
+        torch.cuda.synchronize()
+        assert calls == [(B, S)]                                  # the HIP layer ran, once
+        assert (y.cpu() - yr).abs().max().item() < 1e-5
+        # with a gradient: torch ops (no kernel call), same values, gradients against the oracle
+        xd = x.to(dev).requires_grad_(True)
+        y2 = net(xd)
+        assert len(calls) == 1 and (y2.detach().cpu() - yr).abs().max().item() < 1e-4
+        g = torch.randn(B, S, 256, generator=torch.Generator().manual_seed(1))
+        (y2 * g.to(dev)).sum().backward()
+        xr = x.clone().requires_grad_(True)
+        (T.ar_forward(p, xr, 1, abspos) * g).sum().backward()
+        assert _rel(xd.grad.cpu(), xr.grad) < 1e-4
+    finally:
+        lib.cpc_transformer_layer_forward_dropout = orig
+
+
+def test_feature_extraction_with_a_transformer_context_network_built_for_400_frames():
+    """build_feature (cpc/feature_loader.py:228-269) on a model whose --arMode transformer network was built for the 64000-sample
+    window (sizeSeq = 400): encoder and the transformer layer on the HIP kernels, chunks batched, against the oracle."""
+    dev = _dev()
+    from cpc_audio_amd import harness as H
+    from cpc_audio_amd.train import build_model
+    model = build_model(arMode="transformer", sizeWindow=64000, transformerDropout=0.1).to(dev)
+    p = O.make_params(seed=5)
+    ep = {k: v for k, v in p.items() if k.startswith("gEncoder")}
+    tp = T.make_layer_params(21, 256, 400, False, prefix="0.")
+    missing = model.load_state_dict({**ep, **{"gAR." + k: v for k, v in tp.items()}}, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith(("Att.z", "Att.mask")) for k in missing.missing_keys), missing
+    n = 64000 * 3
+    seq = (0.1 * torch.randn(1, n, generator=torch.Generator().manual_seed(2))).clamp_(-1, 1)
+    fm = H.FeatureModule(model, get_encoded=False).eval()
+    feats = H.build_feature(fm, seq, strict=True, max_size_seq=64000)
+    ref = []
+    for start in range(0, n, 64000):
+        z = O.encoder_forward(p, seq[:, start:start + 64000].reshape(1, 1, -1)).permute(0, 2, 1)
+        ref.append(T.ar_forward(tp, z, 1, False))
+    ref = torch.cat(ref, dim=1)
+    assert feats.shape == ref.shape == (1, 1200, 256)
+    assert (feats - ref).abs().max().item() < 1e-4
