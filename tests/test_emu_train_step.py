@@ -140,6 +140,17 @@ def test_composite_step_with_the_criterion_on_fp16_pieces_emulated(mode):
         assert lib.cpc_set_nce_fused(_L.DEFAULT_NCE_FUSED) == 0
 
 
+def _grad_err(g, ref):
+    """Relative error in the 2-norm; for a reference gradient that is EXACTLY zero (every negative of the batch drawn on its own
+    positive -- B = 1, two frames, one negative: the loss is ln 2 whatever the parameters) the largest absolute entry scaled so
+    that 1e-6 passes the 2e-4 bar: the scores on fp16 pieces (cpc_set_nce_fused(2)) leave ~1e-8 there where fp32 cancels."""
+    if not torch.isfinite(g).all():
+        return float("inf")
+    if ref.norm().item() == 0.0:
+        return g.abs().max().item() * 2e2
+    return rel_err(g, ref)
+
+
 def check_composite_step(lib, B, L, K, N, use_h0, seed=0, device=None, streams=(None, None, None, None)):
     """One composite step against the oracle (outputs, losses, accuracies, every gradient) and, bit for bit, against the
     stage-wise entry points (also used by tests/test_emu_shapes.py and, with a cuda ``device`` and the product library, by
@@ -159,11 +170,11 @@ def check_composite_step(lib, B, L, K, N, use_h0, seed=0, device=None, streams=(
     bad = {}
     for n, g in zip(names, grads[:28]):
         ref = ora["grads"][n]
-        e = rel_err(g.view_as(ref), ref) if torch.isfinite(g).all() else float("inf")
+        e = _grad_err(g.view_as(ref), ref)
         if not e < (5e-3 if n.startswith("gEncoder") else 2e-4):       # encoder: a ReLU tie may flip a row
             bad[n] = e
     dwall_ref = torch.cat([ora["grads"][f"wPrediction.predictors.{k}.weight"] for k in range(K)], 0)
-    e = rel_err(grads[28], dwall_ref)
+    e = _grad_err(grads[28], dwall_ref)
     if not e < 2e-4:
         bad["wall"] = e
     assert not bad, bad

@@ -291,7 +291,7 @@ def test_transformer_layer_beyond_128_steps_runs_on_the_kernels_in_inference(B, 
     calls = []
     lib = _lib.get()
     orig = lib.cpc_transformer_layer_forward_dropout
-    lib.cpc_transformer_layer_forward_dropout = lambda *a: (calls.append(a[6:8]), orig(*a))[1]     # (B, S) of every kernel call
+    lib.cpc_transformer_layer_forward_dropout = lambda *a: (calls.append(a[5:7]), orig(*a))[1]     # (B, S) of every kernel call
     try:
         with torch.no_grad():
             y = net(x.to(dev))
