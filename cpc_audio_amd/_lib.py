@@ -11,6 +11,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcpc_hip.so")
 DEFAULT_GRU_MODE = 2       # cpc_set_gru_mode: persistent recurrence, forward products on the fp16 split
+DEFAULT_GRU_XCD_LOCAL = 1  # cpc_set_gru_xcd_local: forward hand-over through one XCD's L2 for batches of at most half the device (round 6)
+DEFAULT_GRU_POLL_PLAIN = 15  # cpc_set_gru_poll_plain: every first look of the persistent recurrence through the XCD's L2 (round 6)
 DEFAULT_MFMA_MODE = 3      # what libcpc_hip starts in (cpc_set_mfma_mode): mode 2's arithmetic (two fp16 pieces, 3 MFMAs per
 #                            product) with conv1 / its gradients on the DMA-fed kernels reading H2-stored activations
 EXPECTED_ABI = 15          # cpc_abi_version() of the library these signatures were written for: a stale or variant build that
@@ -59,6 +61,8 @@ SIGNATURES = {
     "cpc_set_gemm_split": (_I, [_I]),
     "cpc_set_gemm_fuse": (_I, [_I]),
     "cpc_set_gru_xcd_pack": (_I, [_I]),
+    "cpc_set_gru_poll_plain": (_I, [_I]),
+    "cpc_set_gru_xcd_local": (_I, [_I]),
     "cpc_set_gru_chunk_tiles": (_I, [_I]),
     "cpc_set_gru_tiles_per_wg": (_I, [_I]),
     "cpc_set_gru_poll_pacing": (_I, [_I, _I]),

@@ -191,6 +191,9 @@ struct Gru2Fwd {
     int ntiles, xcd_pack;      // persistent launch only: see PersistIds
     int tile0, total_tiles;    // persistent launch only: this launch covers batch tiles [tile0, tile0 + ntiles) of total_tiles
     int first_sleep;           // persistent launch only: see PollPace (< 0: self-steering)
+    int poll_plain;            // persistent launch only: which waves take their FIRST look with plain (L2-cached) loads (cpc_set_gru_poll_plain)
+    unsigned* xsync;           // persistent launch only: NULL, or two words per batch tile (0xFFFFFFFF) for the placement check of the
+                               // XCD-local hand-over (tile_on_one_xcd; cpc_set_gru_xcd_local)
 };
 
 // Component-wise f32x4 arithmetic on MFMA accumulators written out scalar by scalar: f32x4 operators compile to v_pk_{add,mul}_f32,
@@ -326,6 +329,9 @@ struct Gru2Bwd {
     int ntiles, xcd_pack;      // persistent launch only: see PersistIds
     int tile0, total_tiles;    // persistent launch only: this launch covers batch tiles [tile0, tile0 + ntiles) of total_tiles
     int first_sleep;           // persistent launch only: see PollPace (< 0: self-steering)
+    int poll_plain;            // persistent launch only: which waves take their FIRST look with plain (L2-cached) loads (cpc_set_gru_poll_plain)
+    unsigned* xsync;           // persistent launch only: NULL, or two words per batch tile (0xFFFFFFFF) for the placement check of the
+                               // XCD-local hand-over (tile_on_one_xcd; cpc_set_gru_xcd_local)
 };
 
 // Everything in the gate derivatives that does not depend on dh, for all (b, t, j) at once and in fragment
@@ -490,12 +496,47 @@ __device__ __forceinline__ float4 load4_coherent(const float* p) {
     return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
                        __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
 }
+// the same 16 bytes by PLAIN loads (wavefront-scope atomics: global_load without sc bits -- served by this XCD's L2, which the
+// workgroups of a tile on the XCD then share; what it returns may be stale, so only a FIRST look may use it: poll_row)
+__device__ __forceinline__ float4 load4_plain(const float* p) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                       __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+}
 __device__ __forceinline__ bool ready4(float4 v) {
     return __float_as_uint(v.x) != kNotReady && __float_as_uint(v.y) != kNotReady &&
            __float_as_uint(v.z) != kNotReady && __float_as_uint(v.w) != kNotReady;
 }
 __device__ __forceinline__ void store_coherent(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// XCD-local hand-over (cpc_set_gru_xcd_local).  A device-scope store is written through to memory and a device-scope load of a line
+// its L2 holds clean goes back there: 1.5-2 k clocks each way.  When the 32 workgroups of a batch tile all sit on ONE XCD (the
+// packed numbering, PersistIds) the producers can store PLAIN instead -- the per-CU cache is write-through, the value stops in that
+// XCD's L2 -- and the consumers' device-scope loads find the dirty line there (measured coherent inside an XCD, tools/probe_sync4.hip;
+// the round 2.0 -> 1.45 us alone).  Workgroup placement is the dispatcher's (id % 8 on an idle MI355X) and not a contract, so
+// every tile checks it once, at the start of the launch: each workgroup clears the bit of its XCC_ID in a word of ones and counts
+// itself in (device scope), waits for the other 31, and the tile takes the local path only if exactly one bit went.  A tile that
+// straddles XCDs -- or a wait that runs out of budget -- keeps the device-scope stores: correct either way.
+__device__ __forceinline__ void store_handover(float* p, float v, bool local) {
+    if (local) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool tile_on_one_xcd(unsigned* sync, int spin_limit) {
+    __shared__ unsigned verdict;
+    if (threadIdx.x == 0) {
+        const unsigned xid = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;       // hwreg(HW_REG_XCC_ID), bits 3:0
+        __hip_atomic_fetch_and(sync, ~(1u << xid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);     // 0xFFFFFFFF + 32 arrivals = 31
+        int budget = spin_limit < 4096 ? spin_limit : 4096;
+        while (__hip_atomic_load(sync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 31u && budget-- > 0) __builtin_amdgcn_s_sleep(8);
+        const unsigned gone = ~__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        verdict = (budget > 0 && gone != 0u && (gone & (gone - 1u)) == 0u) ? 1u : 0u;
+    }
+    __syncthreads();
+    return verdict != 0u;
 }
 
 // Fetch NII float4 fragments (k += 16 apart) of this lane's row, re-reading until every lane of the wave
@@ -521,14 +562,23 @@ struct PollPace {
     }
 };
 
+// plain_first: the first look with plain loads (load4_plain) -- a hand-over address is read once per launch by a wave, the
+// buffers were filled by a previous launch and written since by write-through stores only, so a line this XCD's L2 does not hold
+// yet comes from memory as it is now, and the other workgroups of the tile on this XCD hit it there instead of crossing the
+// fabric each; a line fetched too early stays stale in that L2, which the repeated looks (always device scope) get around.
 template <int NII>
 __device__ __forceinline__ void poll_row(const float* __restrict__ row, bool ok, float4 (&a)[NII], int& budget,
-                                         PollPace& pace) {
+                                         PollPace& pace, bool plain_first = false) {
     for (int q = 0; q < pace.delay; ++q) __builtin_amdgcn_s_sleep(1);
     // Unconditional loads (a predicated load costs a branch and a full vmcnt(0) each): rows past the batch
     // are inside the buffer, never written, and masked out below.
+    if (plain_first) {                                            // wave-uniform
 #pragma unroll
-    for (int ii = 0; ii < NII; ++ii) a[ii] = load4_coherent(row + kXStride * ii);
+        for (int ii = 0; ii < NII; ++ii) a[ii] = load4_plain(row + kXStride * ii);
+    } else {
+#pragma unroll
+        for (int ii = 0; ii < NII; ++ii) a[ii] = load4_coherent(row + kXStride * ii);
+    }
     int repeats = 0;
     for (;;) {
         bool rdy = true;
@@ -624,6 +674,41 @@ __device__ __forceinline__ void mfma_gates_h2(f32x4 (&acc)[3], const float4 (&a)
     }
 }
 
+// Phase trace of the persistent kernels (tools/time_gru_phases.py; library built with -DCPC_GRU_TIMING by tools/build_timing_lib.sh;
+// in the product build every member is empty): shader-clock laps of one lane per wave, summed over the steps 16 .. S - 16, per
+// (direction, workgroup, wave).  MFMA waves: 0 poll, 1 operand math + MFMAs until their results are in LDS-store flight, 2 LDS
+// stores + barrier; gate waves: 3 barrier wait, 4 partial sums + gate math until the coherent store is issued, 5 the other
+// stores and the next step's prefetch.
+#ifdef CPC_GRU_TIMING
+__device__ unsigned long long g_gru_phase[2][512][12][8];
+struct PhaseClock {
+    unsigned long long last, sum[8];
+    __device__ PhaseClock() : last(0) { for (int i = 0; i < 8; ++i) sum[i] = 0; }
+    __device__ __forceinline__ void start() {
+        __builtin_amdgcn_sched_barrier(0);
+        last = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void lap(int i, bool on) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (on) sum[i] += now - last;
+        last = now;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void flush(int dir) {
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 512)
+            for (int i = 0; i < 8; ++i) g_gru_phase[dir][blockIdx.x][threadIdx.x >> 6][i] = sum[i];
+    }
+};
+#else
+struct PhaseClock {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void lap(int, bool) {}
+    __device__ __forceinline__ void flush(int) {}
+};
+#endif
+
 struct PersistIds {
     int layer, j0, b0, tile, ntiles, G;
     bool valid;
@@ -668,7 +753,7 @@ constexpr int kMfmaWaves = 8;
 // it computes the other's.  The two recurrences are independent and each keeps the arithmetic and the summation order of the
 // single-tile kernel: bit-identical results (tests/test_emu_gru.py, tests/test_gpu_fused_step.py).
 template <int LAYER, bool H2, int NT>
-__device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8][3][256], const PersistIds& id) {
+__device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8][3][256], const PersistIds& id, bool local) {
     const int j0 = id.j0;
     constexpr int NII = LAYER == 0 ? 2 : 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -699,7 +784,10 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
         }
         int budget = p.spin_limit;
         PollPace pace(p.first_sleep);
+        PhaseClock pc;
+        pc.start();
         for (int t = 0; t < S; ++t) {
+            const bool traced = t >= 16 && t < S - 16;
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 float4 a[NII];
@@ -709,10 +797,11 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
                 } else if (recurrent) {
                     if (t == 0) load_row_plain<NII>(p.h0[LAYER] ? p.h0[LAYER] + (long)(tl[k] * 16 + i) * kH + koff : nullptr,
                                                     bok[k] && p.h0[LAYER] != nullptr, a);
-                    else poll_row<NII>(xsrc + xtile(t - 1, tl[k], id.ntiles, kH), bok[k], a, budget, pace);
+                    else poll_row<NII>(xsrc + xtile(t - 1, tl[k], id.ntiles, kH), bok[k], a, budget, pace, (p.poll_plain & 4) != 0);
                 } else {
-                    poll_row<NII>(xsrc + xtile(t, tl[k], id.ntiles, kH), bok[k], a, budget, pace);
+                    poll_row<NII>(xsrc + xtile(t, tl[k], id.ntiles, kH), bok[k], a, budget, pace, (p.poll_plain & 1) != 0);
                 }
+                pc.lap(0, traced);
                 f32x4 acc[3];
 #pragma unroll
                 for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -728,9 +817,12 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
                 for (int g = 0; g < 3; ++g)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pt[w][g][(kq * 4 + r) * 16 + i] = acc[g][r];
+                pc.lap(1, traced);
                 __syncthreads();
+                pc.lap(2, traced);
             }
         }
+        pc.flush(0);
         return;
     }
 
@@ -762,10 +854,14 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
     }
     float* __restrict__ cf = p.coef[LAYER];
     const int cpos = xpos(e >> 4, j);
+    PhaseClock pc;
+    pc.start();
     for (int t = 0; t < S; ++t) {
+        const bool traced = t >= 16 && t < S - 16;
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             __syncthreads();
+            pc.lap(3, traced);
             if (!live[k]) {
                 if (cf && tok[k]) {                                   // padding rows of the last tile: zero coefficients, so that
                     const long c = xtile(t, tl[k], id.ntiles, kH) + cpos;     // the backward recurrence can load them unconditionally
@@ -793,7 +889,8 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
             const float z = sigmoidf_(gi_z + gh[1]);
             const float n = tanhf(gi_n + r * gh[2]);
             const float h = (1.0f - z) * n + z * hp[k];
-            store_coherent(p.xh[LAYER] + xtile(t, tl[k], id.ntiles, kH) + xpos(e >> 4, j), h);   // first: others wait for it
+            store_handover(p.xh[LAYER] + xtile(t, tl[k], id.ntiles, kH) + xpos(e >> 4, j), h, local);   // first: others wait for it
+            pc.lap(4, traced);
             yl[bt * kH + j] = h;
             p.R[LAYER][bt * kH + j] = r;
             p.Z[LAYER][bt * kH + j] = z;
@@ -813,8 +910,10 @@ __device__ __forceinline__ void persist_fwd(const Gru2Fwd& p, float (&part)[2][8
                 const float* gip = p.x_gi0 + (bt + 1) * kG;
                 gi[k][0] = gip[j]; gi[k][1] = gip[kH + j]; gi[k][2] = gip[2 * kH + j];
             }
+            pc.lap(5, traced);
         }
     }
+    pc.flush(0);
 }
 
 // grid = 32 * ceil(B/16) workgroups (1-D), 768 threads; xh[0] and xh[1] pre-filled with 0xFF bytes
@@ -823,8 +922,9 @@ __global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_kernel(Gru2F
     __shared__ float part[2][8][3][256];
     const PersistIds id(p.ntiles, p.xcd_pack, p.tile0, p.total_tiles);
     if (!id.valid) return;
-    if (id.layer == 0) persist_fwd<0, false, NT>(p, part, id);
-    else persist_fwd<1, false, NT>(p, part, id);
+    const bool local = p.xsync != nullptr && tile_on_one_xcd(p.xsync + 2 * id.tile, p.spin_limit);
+    if (id.layer == 0) persist_fwd<0, false, NT>(p, part, id, local);
+    else persist_fwd<1, false, NT>(p, part, id, local);
 }
 // the same with the recurrent products on the fp16 pipe (two-piece split operands); h0 must be absent (|h| < 1)
 template <int NT>
@@ -832,8 +932,9 @@ __global__ __launch_bounds__(kPersistThreads) void gru2_persist_fwd_h2_kernel(Gr
     __shared__ float part[2][8][3][256];
     const PersistIds id(p.ntiles, p.xcd_pack, p.tile0, p.total_tiles);
     if (!id.valid) return;
-    if (id.layer == 0) persist_fwd<0, true, NT>(p, part, id);
-    else persist_fwd<1, true, NT>(p, part, id);
+    const bool local = p.xsync != nullptr && tile_on_one_xcd(p.xsync + 2 * id.tile, p.spin_limit);
+    if (id.layer == 0) persist_fwd<0, true, NT>(p, part, id, local);
+    else persist_fwd<1, true, NT>(p, part, id, local);
 }
 
 template <int NU>
@@ -859,7 +960,7 @@ __device__ __forceinline__ void load_coef(float4 (&cf)[NU][3], const float* __re
 // first poll instead of one step ahead (two prefetched sets would not fit the register budget of three waves per SIMD); the
 // other tile's work hides them.
 template <int LAYER, int NT>
-__device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8][256], const PersistIds& id) {
+__device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8][256], const PersistIds& id, bool local) {
     constexpr int NU = LAYER == 1 ? 2 : 4;           // unit fragments per lane (x 3 gates = MFMA fragments)
     const int j0 = id.j0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -897,36 +998,60 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
         if (NT == 1 && !recurrent) load_coef<NU>(cf, c0, c1, c2, xtile(S - 1, tl[0], id.ntiles, kH) + lane_off);
         int budget = p.spin_limit;
         PollPace pace(p.first_sleep);
+        PhaseClock pc;
+        pc.start();
         for (int t = S - 1; t >= 0; --t) {
             const int ts = recurrent ? t + 1 : t;                 // step whose gate gradients are this wave's operand
+            const bool traced = t >= 16 && t < S - 16;
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (ts < S && tok[k]) {
                     if (NT > 1) load_coef<NU>(cf, c0, c1, c2, xtile(ts, tl[k], id.ntiles, kH) + lane_off);
                     float4 dh[NU];
-                    poll_row<NU>(xsrc + xtile(ts, tl[k], id.ntiles, kH), bok[k], dh, budget, pace);
+                    poll_row<NU>(xsrc + xtile(ts, tl[k], id.ntiles, kH), bok[k], dh, budget, pace,
+                                 (p.poll_plain & (recurrent ? 8 : 2)) != 0);
+                    pc.lap(0, traced);
                     f32x4 ag[3];
 #pragma unroll
                     for (int g = 0; g < 3; ++g) ag[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    // every operand dh * coefficient FIRST, then the MFMAs back to back: a VALU multiply between two MFMAs costs
+                    // the matrix pipe ~30 clocks each (measured with tools/time_gru_phases.py: 60-66 clocks per MFMA with the
+                    // products computed on the way, against the instruction's 32)
+                    // (in two halves: 48 live products on top of the weights and the coefficients would spill at three waves per SIMD)
 #pragma unroll
-                    for (int ii = 0; ii < NU; ++ii)
+                    for (int hf = 0; hf < 2; ++hf) {
+                        float4 op[NU / 2][3];
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
+                        for (int ii = 0; ii < NU / 2; ++ii)
 #pragma unroll
-                            for (int g = 0; g < 3; ++g)
-                                ag[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(dh[ii], jj) * f4c(cf[ii][g], jj),
-                                                                             f4c(bw[ii][g], jj), ag[g], 0, 0, 0);
+                            for (int g = 0; g < 3; ++g) {
+                                const float4 d = dh[hf * (NU / 2) + ii], c = cf[hf * (NU / 2) + ii][g];
+                                op[ii][g] = make_float4(d.x * c.x, d.y * c.y, d.z * c.z, d.w * c.w);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ii = 0; ii < NU / 2; ++ii)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                                for (int g = 0; g < 3; ++g)
+                                    ag[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(op[ii][g], jj), f4c(bw[hf * (NU / 2) + ii][g], jj), ag[g], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     acc = add4(acc, add4(add4(ag[0], ag[1]), ag[2]));
                 }
-                if (NT == 1 && t > 0)                             // next iteration's coefficients: step ts - 1
-                    load_coef<NU>(cf, c0, c1, c2, xtile(ts - 1, tl[0], id.ntiles, kH) + lane_off);
                 float (&pt)[8][256] = part[(t * NT + k) & 1];
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) pt[w][(kq * 4 + rr) * 16 + i] = acc[rr];
+                pc.lap(1, traced);
+                if (NT == 1 && t > 0)                             // next iteration's coefficients: step ts - 1 (behind the partials:
+                    load_coef<NU>(cf, c0, c1, c2, xtile(ts - 1, tl[0], id.ntiles, kH) + lane_off);    // the gate waves wait for those)
                 __syncthreads();
+                pc.lap(2, traced);
             }
         }
+        pc.flush(1);
         return;
     }
 
@@ -954,10 +1079,14 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
         dh_next[k] = z_next[k] = 0.f;
         if (live[k]) fetch(k, S - 1);
     }
+    PhaseClock pc;
+    pc.start();
     for (int t = S - 1; t >= 0; --t) {
+        const bool traced = t >= 16 && t < S - 16;
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             __syncthreads();
+            pc.lap(3, traced);
             if (!live[k]) continue;
             const long bt = (long)b[k] * S + t;
             float (&pt)[8][256] = part[(t * NT + k) & 1];
@@ -965,7 +1094,8 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
             if ((t + 1) < S) dh0 = fmaf(dh_next[k], z_next[k], dh0);
             const float dh = (((pt[0][e] + pt[1][e]) + (pt[2][e] + pt[3][e])) +
                               ((pt[4][e] + pt[5][e]) + (pt[6][e] + pt[7][e]))) + dh0;
-            store_coherent(p.xdh[LAYER] + xtile(t, tl[k], id.ntiles, kH) + xp, dh);   // first: others wait for it
+            store_handover(p.xdh[LAYER] + xtile(t, tl[k], id.ntiles, kH) + xp, dh, local);   // first: others wait for it
+            pc.lap(4, traced);
             float* gi = p.dGi[LAYER] + bt * kG;
             float* gh = p.dGh[LAYER] + bt * kG;
             const float dar = dh * cr[k], daz = dh * cz[k];
@@ -978,8 +1108,10 @@ __device__ __forceinline__ void persist_bwd(const Gru2Bwd& p, float (&part)[2][8
             dh_next[k] = dh;
             z_next[k] = z[k];
             if (t > 0) fetch(k, t - 1);                               // a step ahead: memory latency off the chain
+            pc.lap(5, traced);
         }
     }
+    pc.flush(1);
 }
 
 // grid / block as the forward; xdh[0] and xdh[1] pre-filled with 0xFF bytes
@@ -988,8 +1120,9 @@ __global__ __launch_bounds__(kPersistThreads) void gru2_persist_bwd_kernel(Gru2B
     __shared__ float part[2][8][256];
     const PersistIds id(p.ntiles, p.xcd_pack, p.tile0, p.total_tiles);
     if (!id.valid) return;
-    if (id.layer == 0) persist_bwd<1, NT>(p, part, id);           // the top layer leads
-    else persist_bwd<0, NT>(p, part, id);
+    const bool local = p.xsync != nullptr && tile_on_one_xcd(p.xsync + 2 * id.tile, p.spin_limit);
+    if (id.layer == 0) persist_bwd<1, NT>(p, part, id, local);    // the top layer leads
+    else persist_bwd<0, NT>(p, part, id, local);
 }
 
 // ------------------------------------------------------------------ host side
@@ -1000,6 +1133,7 @@ struct GruLayout {
     long whhT, wihT, dGi, dGh, DH, mid[2], part, tmp;
     long whhT2, wihT2, dGi2, dGh2, DH2;      // second set for the two-layer wavefront
     long coef, xdh, frag_floats;             // two-layer path: 8 coefficient arrays, 2 hand-over buffers (fragment order)
+    long sync_floats;                        // ... and, behind either pair of hand-over buffers, two words per batch tile (tile_on_one_xcd)
     long bwd_total;
 };
 
@@ -1020,7 +1154,8 @@ static bool gru_layout(int B, int S, int nl, GruLayout& g) {
     g.gi = 0;
     g.xh = align64l((long)B * S * kG);
     g.xh_floats = nl == 2 ? align64l((long)S * tiles16 * kH) : 0;
-    g.fwd_total = g.xh + 2 * g.xh_floats;
+    g.sync_floats = nl == 2 ? align64l(2L * cdiv(B, 16)) : 0;
+    g.fwd_total = g.xh + 2 * g.xh_floats + g.sync_floats;
     o = 0;
     g.whhT = o; o += (long)kH * kG;
     g.wihT = o; o += (long)kH * kG;
@@ -1038,7 +1173,7 @@ static bool gru_layout(int B, int S, int nl, GruLayout& g) {
     g.DH2 = o; o += bsh;
     g.frag_floats = nl == 2 ? align64l((long)S * tiles16 * kH) : 0;
     g.coef = o; o += 8 * g.frag_floats;
-    g.xdh = o; o += 2 * g.frag_floats;
+    g.xdh = o; o += 2 * g.frag_floats + g.sync_floats;
     g.bwd_total = o;
     return true;
 }
@@ -1050,6 +1185,13 @@ using namespace cpc;
 namespace {
 int g_gru_spin_limit = kSpinLimit;
 int g_gru_first_sleep[2] = {-1, -1};   // forward, backward (cpc_set_gru_poll_pacing); < 0: self-steering
+int g_gru_poll_plain = 15; // cpc_set_gru_poll_plain
+int g_gru_xcd_local = 1;   // cpc_set_gru_xcd_local: bit 0 forward, bit 1 backward (launches with one batch tile per workgroup: B <= 128
+                           // on MI355X), bits 2 / 3 the same for any launch
+// (defaults from profiles/r6_ab_gru_handover.txt, MI355X: B = 64 forward alone 317 -> 272 us with the local hand-over and plain
+//  first looks, B = 128 351 -> 290, step at B = 64 2.77 -> 2.71 ms; the backward -- which runs beside the criterion's dz path -- gains
+//  from the plain first looks only and LOSES with the packed numbering in the step (2.84 ms); with two tiles per workgroup
+//  (B = 256) the local forward loses (518 -> 583 us) and so do the backward's plain looks (1620 -> 1758 us): both stay off there)
 int g_gru_xcd_pack = 0;    // persistent launches: 0 (default) = tiles interleaved over the XCDs, 1 = one batch tile per XCD where the
                            // device has 8 (PersistIds; measured slower: B = 64 forward +42 us, backward +70 us -- what a tile gains
                            // in hand-over distance it loses to 32 instead of 16 polling workgroups on its L2), 2 = packed numbering
@@ -1086,8 +1228,13 @@ static void persist_plan(int total, int fit1, int fit2, int* G, int* NT) {
     *NT = 2;
 }
 
+// dirbit: 0 forward, 1 backward; NT: batch tiles per workgroup of the launch (the measured win is NT == 1: B <= 128 on MI355X)
+static bool xcd_local_wanted(int dirbit, int NT) {
+    if (g_gru_xcd_local & (4 << dirbit)) return true;
+    return (g_gru_xcd_local & (1 << dirbit)) && NT == 1;
+}
 template <class K>
-int persist_grid(K kernel, int G, int* pack) {
+int persist_grid(K kernel, int G, int* pack, bool want_pack = false) {
     int dev = 0, cus = 0, occ = 0;
     *pack = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
@@ -1095,7 +1242,7 @@ int persist_grid(K kernel, int G, int* pack) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kPersistThreads, 0) != hipSuccess) return 0;
     const long room = (long)cus * occ;
     if (32L * G > room) return 0;
-    if (g_gru_xcd_pack == 2 || (g_gru_xcd_pack == 1 && cus % 8 == 0 && 32L * cdiv(G, 8) <= (long)(cus / 8) * occ)) {
+    if (g_gru_xcd_pack == 2 || ((g_gru_xcd_pack == 1 || want_pack) && cus % 8 == 0 && 32L * cdiv(G, 8) <= (long)(cus / 8) * occ)) {
         *pack = 1;
         return 256 * cdiv(G, 8);
     }
@@ -1151,6 +1298,27 @@ extern "C" int cpc_set_gru_tiles_per_wg(int n) {
     return 0;
 }
 
+// Which waves of the persistent recurrence take the FIRST look at a hand-over fragment with plain loads through their XCD's L2
+// (poll_row) instead of device-scope ones: bit 0 forward layer 1's look at layer 0's output of the same step, bit 1 backward layer
+// 0's look at layer 1's gradient of the same step (both produced steps earlier as a rule), bit 2 / bit 3 the recurrent looks of
+// forward / backward (the backward's bits only count in launches with one batch tile per workgroup unless bit 4 is set as well).
+// Results do not change (a stale line only costs a repeated look).  Default 15.
+extern "C" int cpc_set_gru_poll_plain(int mask) {
+    if (mask < 0 || mask > 31) return CPC_ERR_ARG;
+    g_gru_poll_plain = mask;
+    return 0;
+}
+
+// XCD-local hand-over of the persistent recurrence (store_handover / tile_on_one_xcd): bit 0 the forward launch, bit 1 the backward
+// launch take the packed numbering (one batch tile per XCD, where the device has 8 with room for it) and, tile by tile, plain
+// stores when the placement check finds the tile's 32 workgroups on one XCD -- in launches with one batch tile per workgroup
+// (the measured win); bits 2 / 3: in any launch.  Same bits as the device-scope hand-over.  Default 1.
+extern "C" int cpc_set_gru_xcd_local(int mask) {
+    if (mask < 0 || mask > 15) return CPC_ERR_ARG;
+    g_gru_xcd_local = mask;
+    return 0;
+}
+
 extern "C" int cpc_set_gru_xcd_pack(int on) {
     if (on < 0 || on > 2) return CPC_ERR_ARG;
     g_gru_xcd_pack = on;
@@ -1197,7 +1365,7 @@ extern "C" int cpc_gru_forward_prepare(float* scratch, int B, int S, int nl, voi
     GruLayout g;
     CPC_RETURN_IF(nl != 2 || !gru_layout(B, S, nl, g), CPC_ERR_SHAPE);
     CPC_RETURN_IF(!scratch, CPC_ERR_ARG);
-    if (hipMemsetAsync(scratch + g.xh, 0xFF, 2 * g.xh_floats * sizeof(float), (hipStream_t)stream) != hipSuccess) return CPC_ERR_ARG;
+    if (hipMemsetAsync(scratch + g.xh, 0xFF, (2 * g.xh_floats + g.sync_floats) * sizeof(float), (hipStream_t)stream) != hipSuccess) return CPC_ERR_ARG;
     return 0;
 }
 extern "C" int cpc_gru_forward_coef_prepared(const float* x, const float* h0, const float* const* params, float* saved,
@@ -1227,7 +1395,9 @@ static int gru_forward_impl(const float* x, const float* h0, const float* const*
         p.y[0] = saved + g.Y[0]; p.y[1] = y;
         p.hN = hN; p.B = B; p.S = S; p.spin_limit = g_gru_spin_limit;
         p.first_sleep = g_gru_first_sleep[0];
+        p.poll_plain = g_gru_poll_plain;
         p.xh[0] = p.xh[1] = nullptr;
+        p.xsync = nullptr;
         p.coef[0] = p.coef[1] = nullptr;
         p.frag_stride = g.frag_floats;
         p.total_tiles = cdiv(B, 16);
@@ -1242,14 +1412,15 @@ static int gru_forward_impl(const float* x, const float* h0, const float* const*
             persist_plan(p.total_tiles, fit1, fit2, &p.ntiles, &NT);
         }
         const int nblocks = g_gru_mode < 1 || p.ntiles <= 0 ? 0
-                            : h2 ? (NT == 2 ? persist_grid(gru2_persist_fwd_h2_kernel<2>, p.ntiles, &p.xcd_pack)
-                                            : persist_grid(gru2_persist_fwd_h2_kernel<1>, p.ntiles, &p.xcd_pack))
-                                 : (NT == 2 ? persist_grid(gru2_persist_fwd_kernel<2>, p.ntiles, &p.xcd_pack)
-                                            : persist_grid(gru2_persist_fwd_kernel<1>, p.ntiles, &p.xcd_pack));
+                            : h2 ? (NT == 2 ? persist_grid(gru2_persist_fwd_h2_kernel<2>, p.ntiles, &p.xcd_pack, xcd_local_wanted(0, NT))
+                                            : persist_grid(gru2_persist_fwd_h2_kernel<1>, p.ntiles, &p.xcd_pack, xcd_local_wanted(0, NT)))
+                                 : (NT == 2 ? persist_grid(gru2_persist_fwd_kernel<2>, p.ntiles, &p.xcd_pack, xcd_local_wanted(0, NT))
+                                            : persist_grid(gru2_persist_fwd_kernel<1>, p.ntiles, &p.xcd_pack, xcd_local_wanted(0, NT)));
         if (nblocks > 0) {
             p.xh[0] = scratch + g.xh; p.xh[1] = scratch + g.xh + g.xh_floats;
             if (coef) { p.coef[0] = coef; p.coef[1] = coef + 4 * g.frag_floats; }
-            if (!xh_ready && hipMemsetAsync(p.xh[0], 0xFF, 2 * g.xh_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+            if (!xh_ready && hipMemsetAsync(p.xh[0], 0xFF, (2 * g.xh_floats + g.sync_floats) * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+            p.xsync = xcd_local_wanted(0, NT) && p.xcd_pack ? reinterpret_cast<unsigned*>(scratch + g.xh + 2 * g.xh_floats) : nullptr;
             step_timer_mark(3, st);
             for (p.tile0 = 0; p.tile0 < p.total_tiles; p.tile0 += p.ntiles * NT) {
                 if (h2 && NT == 2) hipLaunchKernelGGL(gru2_persist_fwd_h2_kernel<2>, dim3(nblocks), dim3(kPersistThreads), 0, st, p);
@@ -1295,7 +1466,7 @@ extern "C" long cpc_gru_coef_floats(int B, int S, int nl) {
     GruLayout g;
     if (nl != 2 || !gru_layout(B, S, nl, g)) return 0;
     // 8 coefficient arrays + the two hand-over buffers of the persistent backward + the four transposed weight matrices
-    return 10 * g.frag_floats + 4L * kG * kH;
+    return 10 * g.frag_floats + g.sync_floats + 4L * kG * kH;
 }
 
 static void launch_gru_coef(const GruLayout& g, const float* h0, const float* saved, const float* y, float* coef,
@@ -1321,14 +1492,14 @@ extern "C" int cpc_gru_backward_coef(const float* h0, const float* const* params
     CPC_RETURN_IF(!params || !saved || !y || !coef, CPC_ERR_ARG);
     if (!coef_done) launch_gru_coef(g, h0, saved, y, coef, B, S, (hipStream_t)stream);     // (else: cpc_gru_forward_coef wrote them)
     {   // (3H,H) -> (H,3H), the four weight matrices in one launch: W_hh0, W_ih0, W_hh1, W_ih1 behind the hand-over buffers
-        float* wT = coef + 10 * g.frag_floats;
+        float* wT = coef + 10 * g.frag_floats + g.sync_floats;
         const float* tin[4] = {params[1], params[0], params[5], params[4]};
         float* tout[4] = {wT, wT + (long)kG * kH, wT + 2L * kG * kH, wT + 3L * kG * kH};
         int rc = transpose_batch(tin, tout, 4, kG, kH, (hipStream_t)stream);
         if (rc) return rc;
     }
     // ... and the hand-over buffers of the persistent backward, pre-filled with the "not written yet" pattern
-    if (hipMemsetAsync(coef + 8 * g.frag_floats, 0xFF, 2 * g.frag_floats * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    if (hipMemsetAsync(coef + 8 * g.frag_floats, 0xFF, (2 * g.frag_floats + g.sync_floats) * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return CPC_ERR_ARG;
     CPC_LAUNCH_CHECK();
     return 0;
@@ -1366,7 +1537,7 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
     const int M = B * S;
     if (nl == 2) {                                   // two-layer wavefront (see gru2_bwd_kernel)
         // (the transposed weights come with `coef` when the caller prepared it, cpc_gru_backward_coef)
-        float* cwT = coef ? const_cast<float*>(coef) + 10 * g.frag_floats : nullptr;
+        float* cwT = coef ? const_cast<float*>(coef) + 10 * g.frag_floats + g.sync_floats : nullptr;
         float* whhT_[2] = {coef ? cwT : scratch + g.whhT, coef ? cwT + 2L * kG * kH : scratch + g.whhT2};
         float* wihT_[2] = {coef ? cwT + (long)kG * kH : scratch + g.wihT, coef ? cwT + 3L * kG * kH : scratch + g.wihT2};
         float* dGi_[2] = {scratch + g.dGi, scratch + g.dGi2};
@@ -1375,6 +1546,7 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
         Gru2Bwd p;
         p.dy = dy; p.B = B; p.S = S; p.spin_limit = g_gru_spin_limit;
         p.first_sleep = g_gru_first_sleep[1];
+        p.poll_plain = g_gru_poll_plain;                  // (narrowed below once the launch plan is known)
         const float* yl[2] = {saved + g.Y[0], y};
         const float* h0l[2] = {h0, h0 ? h0 + (long)B * kH : nullptr};
         int rc = 0;
@@ -1394,16 +1566,19 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
         }
         if (!coef) launch_gru_coef(g, h0, saved, y, scratch + g.coef, B, S, st);
         p.wih1T = wihT_[1];
+        p.xsync = nullptr;
         p.total_tiles = cdiv(B, 16);
         p.tile0 = 0;
         int NT = 1;
         persist_plan(p.total_tiles, persist_chunk((const void*)gru2_persist_bwd_kernel<1>, p.total_tiles),
                      persist_chunk((const void*)gru2_persist_bwd_kernel<2>, p.total_tiles), &p.ntiles, &NT);
+        if (NT == 2 && !(g_gru_poll_plain & 16)) p.poll_plain = 0;     // two tiles per workgroup: the backward's plain looks lose
         const int nblocks = g_gru_mode < 1 || p.ntiles <= 0 ? 0
-                            : NT == 2 ? persist_grid(gru2_persist_bwd_kernel<2>, p.ntiles, &p.xcd_pack)
-                                      : persist_grid(gru2_persist_bwd_kernel<1>, p.ntiles, &p.xcd_pack);
+                            : NT == 2 ? persist_grid(gru2_persist_bwd_kernel<2>, p.ntiles, &p.xcd_pack, xcd_local_wanted(1, NT))
+                                      : persist_grid(gru2_persist_bwd_kernel<1>, p.ntiles, &p.xcd_pack, xcd_local_wanted(1, NT));
         if (nblocks > 0) {
-            if (!coef && hipMemsetAsync(p.xdh[0], 0xFF, 2 * g.frag_floats * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+            if (!coef && hipMemsetAsync(p.xdh[0], 0xFF, (2 * g.frag_floats + g.sync_floats) * sizeof(float), st) != hipSuccess) return CPC_ERR_ARG;
+            p.xsync = xcd_local_wanted(1, NT) && p.xcd_pack ? reinterpret_cast<unsigned*>(p.xdh[0] + 2 * g.frag_floats) : nullptr;
             // (in-step timing: the marker in FRONT of this launch is recorded by cpc_train_step before it releases the side
             // stream's gather kernels -- a marker packet between that release and this launch lets their workgroups take the
             // CUs first, and the persistent launch then waits 250 us for residency: measured)
@@ -1508,3 +1683,10 @@ extern "C" int cpc_gru_backward_streams(const float* x, const float* h0, const f
     }
     return 0;
 }
+
+#ifdef CPC_GRU_TIMING
+// host[2][512][12][8]: the phase sums of the last persistent forward (0) / backward (1) launch (PhaseClock)
+extern "C" int cpc_debug_gru_phases(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(cpc::g_gru_phase), sizeof(unsigned long long) * 2 * 512 * 12 * 8) == hipSuccess ? 0 : CPC_ERR_ARG;
+}
+#endif

@@ -187,6 +187,8 @@ int cpc_set_gru_mode(int mode);
  * faster) interleaves the tiles over the XCDs (grid of 32 * tiles); 2 forces the packed numbering whatever the device
  * reports (tests). */
 int cpc_set_gru_xcd_pack(int on);
+int cpc_set_gru_xcd_local(int mask);    /* bit 0 forward, bit 1 backward: one batch tile per XCD, hand-over through that XCD's L2 (gru.hip) */
+int cpc_set_gru_poll_plain(int mask);   /* first looks of the persistent recurrence through the XCD's L2 (gru.hip); default 0 */
 /* Persistent recurrence: cap on the 16-sequence batch tiles of one launch (0 = whatever fits the device, the default); a
  * larger batch runs as several launches one after the other (B = 256 on 256 CUs: two launches of 8 tiles). */
 int cpc_set_gru_chunk_tiles(int tiles);

@@ -385,9 +385,13 @@ static inline float __uint_as_float(unsigned u) { return hipemu::unbits<float>(u
 // ---- inter-workgroup exchange support (persistent kernels): agent-scope atomics are host atomics,
 // s_sleep hands the OS thread to the other (co-resident) blocks.
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
 template <class T> static inline T hipemu_atomic_load(const T* p, int order) { T v; __atomic_load(p, &v, order); return v; }
 template <class T, class V> static inline void hipemu_atomic_store(T* p, V v, int order) { T t = (T)v; __atomic_store(p, &t, order); }
 #define __hip_atomic_load(p, order, scope) hipemu_atomic_load((p), (order))
+#define __hip_atomic_fetch_and(p, v, order, scope) __atomic_fetch_and((p), (v), (order))
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
+static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }     // hardware registers (XCC_ID ...): one XCD, id 0
 #define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store((p), (v), (order))
 static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }

@@ -14,6 +14,7 @@ def _lib_default_mode():
     from cpc_audio_amd._lib import DEFAULT_MFMA_MODE
     return DEFAULT_MFMA_MODE
 
+from cpc_audio_amd import _lib as _L
 from emu_util import P, emu, rel_err
 from oracle import cpc_oracle as O
 
@@ -172,6 +173,39 @@ def test_persistent_recurrence_with_one_batch_tile_per_xcd_emulated():
             lib.cpc_set_gru_xcd_pack(0)
     assert all(torch.equal(a, b) for a, b in zip(*outs))
     assert lib.cpc_set_gru_xcd_pack(3) != 0
+
+
+def test_persistent_recurrence_with_plain_first_looks_emulated():
+    """cpc_set_gru_poll_plain: which waves take their first look at a hand-over fragment through their XCD's L2 -- a matter of
+    memory scope only, the same bits for every mask (on the emulator both loads are host atomics: this pins the plumbing)."""
+    lib = emu()
+    outs = []
+    for mask in (0, 15, 3):
+        assert lib.cpc_set_gru_poll_plain(mask) == 0
+        try:
+            outs.append(_run_gru(lib, 20, 5, 2, False))
+        finally:
+            lib.cpc_set_gru_poll_plain(_L.DEFAULT_GRU_POLL_PLAIN)
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])) and all(torch.equal(a, b) for a, b in zip(outs[0], outs[2]))
+    assert lib.cpc_set_gru_poll_plain(32) != 0
+
+
+def test_persistent_recurrence_with_xcd_local_handover_emulated():
+    """cpc_set_gru_xcd_local: packed numbering + the placement check at the start of the launch (every workgroup of a tile clears
+    the bit of its XCD and counts itself in) + plain stores where a tile sits on one XCD -- the emulator reports XCD 0 for every
+    workgroup, so with the packed numbering forced (2) the tiles take the local path: same bits; forward and backward bits apart."""
+    lib = emu()
+    outs = []
+    for mask, pack in ((0, 0), (15, 2), (5, 2), (10, 2), (3, 0), (3, 2)):
+        assert lib.cpc_set_gru_xcd_local(mask) == 0 and lib.cpc_set_gru_xcd_pack(pack) == 0
+        try:
+            outs.append(_run_gru(lib, 20, 5, 2, False))
+        finally:
+            lib.cpc_set_gru_xcd_local(_L.DEFAULT_GRU_XCD_LOCAL)
+            lib.cpc_set_gru_xcd_pack(0)
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
+    assert lib.cpc_set_gru_xcd_local(16) != 0
 
 
 def test_persistent_recurrence_in_chunks_of_batch_tiles_emulated():
