@@ -59,6 +59,7 @@ SIGNATURES = {
     "cpc_set_wgrad_dma_stages": (_I, [_I]),
     "cpc_set_wgrad_dma_min_rows": (_I, [_I]),
     "cpc_set_gemm_split": (_I, [_I]),
+    "cpc_set_gemm_dma": (_I, [_I]),
     "cpc_set_gemm_fuse": (_I, [_I]),
     "cpc_set_gru_xcd_pack": (_I, [_I]),
     "cpc_set_gru_poll_plain": (_I, [_I]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "cpc_nce_scores_forward": (_I, [_P] * 7 + [_I, _I, _I, _I, _P]),
     "cpc_nce_scores_backward": (_I, [_P] * 10 + [_I, _I, _I, _I, _P]),
     "cpc_transformer_layout": (_I, [_I, _I, _P]),
+    "cpc_transformer_hidden": (_I, [_P, _P, _I, _I, _P]),
     "cpc_transformer_layer_forward": (_I, [_P] * 5 + [_I, _I, _P]),
     "cpc_transformer_layer_backward": (_I, [_P] * 7 + [_I, _I, _P]),
     "cpc_transformer_layer_forward_dropout": (_I, [_P] * 5 + [_I, _I, _F, ctypes.c_ulonglong, _P]),

@@ -91,6 +91,31 @@ int transpose(const float* in, float* out, int R, int Cn, hipStream_t st, int G 
 // n <= 4 matrices of one shape in one launch
 int transpose_batch(const float* const* in, float* const* out, int n, int R, int Cn, hipStream_t st);
 
+// ---- gemm_dma.hip: plain GEMMs on the DMA-fed tile, operands in H2 storage (every stride in floats = H2 elements; bounds as
+// kAmaxSlots partial maxima; G problems per launch, problem g at + g * the *_gs strides)
+bool gemm_dma_wanted(int M, int G);                                  // cpc_set_gemm_dma: do a call's launches fill the chip?
+// B(n, k) = w[n * sn + k * sk] -> the K-tile-major H2 rows gemm_nt_dma reads (N * K floats), scaled for max|w| (`amax`);
+// l1 (or NULL; zeroed by the caller): max_n sum_k |B(n, k)| -- |A . B^T| <= max|A| * that
+int gemm_weight_h2(const float* w, long sn, long sk, int N, int K, float* wq, const float* amax, float* l1, int G, long w_gs,
+                   long wq_gs, long amax_gs, long l1_gs, hipStream_t st);
+int rows_to_h2(const float* x, float* xh, const float* bound, long rows, int G, long x_gs, long xh_gs, long bound_gs, hipStream_t st);
+// C (fp32) = A . B^T + bias; amax_out (or NULL; zeroed by the caller): max|C|.  N % 256 == 0, K = 256 * 2^j
+int gemm_nt_dma(const float* a_h2, int lda, const float* wq, const float* bias, float* C, long ldc, int M, int N, int K,
+                const float* a_bound, const float* w_amax, float* amax_out, int G, long a_gs, long wq_gs, long bias_gs, long c_gs,
+                long a_bound_gs, long w_amax_gs, long amax_gs, hipStream_t st);
+// C (H2, scaled for max|A| * l1 * scale) = (A . B^T) * scale where the bit of mask_h2 (one bit per element of C, N / 8 bytes per
+// row, mask_gs in floats) is set, else 0;
+// colsum (or NULL): [ceil(M / 256)][N] column sums per row tile; out_slots (or NULL): kAmaxSlots floats, every one = that bound
+int gemm_nt_dma_masked(const float* a_h2, int lda, const float* wq, float* c_h2, long ldc, const float* mask_h2, float scale, int M,
+                       int N, int K, const float* a_bound, const float* w_amax, const float* w_l1, float* colsum, float* out_slots, int G,
+                       long a_gs, long wq_gs, long c_gs, long mask_gs, long a_bound_gs, long w_amax_gs, long w_l1_gs, long colsum_gs,
+                       hipStream_t st);
+// C[N1, N2] = A^T . B over M rows (both H2); part: gemm_tn_dma_part_floats(M, N1, N2, G) floats per problem
+long gemm_tn_dma_part_floats(int M, int N1, int N2, int G);
+int gemm_tn_dma(const float* a_h2, int lda, int N1, const float* b_h2, int ldb, int N2, int M, float* part, float* C,
+                const float* a_bound, const float* b_bound, int G, long a_gs, long b_gs, long part_gs, long c_gs, long a_bound_gs,
+                long b_bound_gs, hipStream_t st);
+
 // 1 (default): NT GEMMs run on the bf16 matrix pipe with 3-piece split operands (NtTileX3, fp32-level
 // accuracy); 0: exact-f32 MFMA (NtTile).  Set through cpc_set_mfma_mode().
 extern int g_mfma_mode;

@@ -754,6 +754,85 @@ __global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, int M,
     }
     publish_amax_block(x_amax, m);
 }
+// The same pass for the DMA-fed feed-forward GEMMs (gemm_dma.hip): x (M, 2048) fp32 = lin1's output is replaced IN PLACE by the
+// hidden layer in H2 storage (two fp16 pieces per element, the 32 bytes of eight channels hold [8 h | 8 l]) -- what lin2 and the
+// weight gradient of lin2 copy into LDS as it lies.  Scaled for bound = max|lin1 output| / (1 - p) (lin_amax: the slots lin1's
+// epilogue left), which block 0 writes into every slot of hid_bound for the consumers; flag[0] = 1 marks the storage
+// (cpc_transformer_hidden).  A thread takes EIGHT channels of four consecutive rows -- its own 32-byte groups, so the in-place
+// rewrite races with nobody -- and draws the same Philox blocks as relu_kernel: the same masks.
+__global__ __launch_bounds__(256) void relu_h2_kernel(float* __restrict__ x, int M, float drop_p, unsigned long long seed, long x_gs,
+                                                      const float* __restrict__ lin_amax, float* __restrict__ hid_bound,
+                                                      float* __restrict__ flag, unsigned char* __restrict__ bits) {
+    // bits: [hid != 0] as one bit per element, row-major, 256 bytes per row (bit c & 7 of byte c >> 3) -- what the backward's
+    // ReLU-derivative epilogue reads instead of the 730 MB tensor (gemm_nt_dma_kernel<2>: ONE 16-byte load per accumulator row)
+    x += (long)blockIdx.y * x_gs;
+    bits += (long)blockIdx.y * x_gs * 4;
+    lin_amax += (long)blockIdx.y * x_gs; hid_bound += (long)blockIdx.y * x_gs; flag += (long)blockIdx.y * x_gs;
+    seed += (unsigned long long)blockIdx.y;
+    const unsigned th = drop_threshold(drop_p);
+    const float sc = 1.0f / (1.0f - drop_p);
+    const float bound = fold_amax(lin_amax, kAmaxSlots) * sc;
+    const float s = scale_for_amax(bound);
+    if (blockIdx.x == 0 && threadIdx.x < kAmaxSlots) {
+        hid_bound[threadIdx.x] = bound;
+        if (threadIdx.x == 0) flag[0] = 1.0f;
+    }
+    const long npiece = (long)((M + 3) >> 2) * (kDff / 8);
+    for (int it = 0; it < kReluIters; ++it) {
+        const long e = ((long)blockIdx.x * kReluIters + it) * 256 + threadIdx.x;
+        if (e >= npiece) break;
+        const long row0 = (e / (kDff / 8)) * 4;
+        const int c8 = (int)(e % (kDff / 8)) * 8;
+        float4 v[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                 // rows past M: re-read the last row (unconditional loads), never stored
+            const float* r = x + min(row0 + q, (long)M - 1) * kDff + c8;
+            v[q][0] = *reinterpret_cast<const float4*>(r);
+            v[q][1] = *reinterpret_cast<const float4*>(r + 4);
+        }
+        unsigned keep = 0xFFFFFFFFu;                  // bit 4 * column + row
+        if (drop_p > 0.f) {
+            keep = 0u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const Philox4 r = philox4x32_10(seed, 1u, ffn_drop_block(row0, c8 + c));
+                keep |= ((r.x >= th ? 1u : 0u) | (r.y >= th ? 2u : 0u) | (r.z >= th ? 4u : 0u) | (r.w >= th ? 8u : 0u)) << (4 * c);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float u[8];
+            const float* f0 = reinterpret_cast<const float*>(&v[q][0]);
+            const float* f1 = reinterpret_cast<const float*>(&v[q][1]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float t = fmaxf(c < 4 ? f0[c] : f1[c - 4], 0.f);
+                if (drop_p > 0.f) t = ((keep >> (4 * c + q)) & 1u) ? t * sc : 0.f;
+                u[c] = t;
+            }
+            if (row0 + q < M) {
+                unsigned char* row = reinterpret_cast<unsigned char*>(x + (row0 + q) * kDff);
+                h2_store4(row, c8, u[0], u[1], u[2], u[3], s);
+                h2_store4(row, c8 + 4, u[4], u[5], u[6], u[7], s);
+                unsigned b = 0u;                  // (an element whose high piece rounds to zero -- below 2^-39 of the bound -- counts as cut)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) b |= ((float)(_Float16)(u[c] * s) != 0.f ? 1u : 0u) << c;
+                bits[(row0 + q) * (kDff / 8) + (c8 >> 3)] = (unsigned char)b;
+            }
+        }
+    }
+}
+// the hidden layer back as fp32 (tests, inspection): out[m][c] = (h + l) / scale_for_amax(bound)
+__global__ __launch_bounds__(256) void hid_h2_decode_kernel(const unsigned char* __restrict__ hid, const float* __restrict__ bound,
+                                                            float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const float inv = 1.0f / scale_for_amax(fold_amax(bound, kAmaxSlots));
+    if (i >= n) return;
+    const long row = i / kDff;
+    const int c = (int)(i - row * kDff);
+    const unsigned char* p = hid + row * (kDff * 4) + h2_byte_of(c);
+    out[i] = h2_join(*reinterpret_cast<const unsigned short*>(p), *reinterpret_cast<const unsigned short*>(p + 16), inv);
+}
 // g *= (y > 0) * scale, y the SAVED hidden layer: it is zero where the ReLU cut or the dropout dropped, so the product of
 // the two derivatives is scale = 1 / (1 - p) exactly where y > 0
 constexpr int kReluBwdIters = 16;
@@ -830,14 +909,14 @@ __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const f
 
 // ------------------------------------------------------------------ host side
 struct TfLayout {
-    long qkv, A, o, xhat1, rstd1, y, hid, xhat2, rstd2, bounds, saved_total;   // saved for backward
-    long fwd_total;                                                        // forward scratch: one (M,256) buffer
-    long ds2, dhid, dyb, ds1, dob, dqkv, w2t, w1t, wot, wqkv, wqkvt, part, lnpart, tmp, dppart, bbounds, colpart, bwd_total;
+    long qkv, A, o, xhat1, rstd1, y, hid, xhat2, rstd2, bounds, yh, hbits, saved_total;   // saved for backward (yh: y in H2 storage, DMA-fed GEMMs)
+    long wq1, wq2, fwd_total;                                              // forward scratch: one (M,256) buffer + lin1 / lin2's weights as the DMA tiles read them
+    long ds2, dhid, dyb, ds1, dob, dqkv, w2t, w1t, wot, wqkv, wqkvt, part, lnpart, tmp, dppart, bbounds, colpart, ds2h, bwd_total;
 };
 // GEMM operand bounds (publish_amax), kAmaxSlots floats each.  Forward's live in `saved` (the backward reads them again; a
 // group keeps them in layer 0's copy), the gradients' in the backward scratch.
-enum { kBX = 0, kBWq, kBWk, kBWv, kBWo, kBW1, kBW2, kBWqkv, kBO, kBY, kBHid, kTfBounds };
-enum { kBDs2 = 0, kBDh, kBDs1, kBDqkv, kTfBwdBounds };
+enum { kBX = 0, kBWq, kBWk, kBWv, kBWo, kBW1, kBW2, kBWqkv, kBO, kBY, kBHid, kBLin1, kBFlag, kTfBounds };   // (kBO on: zeroed per forward)
+enum { kBDs2 = 0, kBDh, kBDs1, kBDqkv, kBW2L1, kTfBwdBounds };
 
 static bool tf_layout(int B, int S, TfLayout& t) {
     if (B <= 0 || S <= 0 || S > kSlong) return false;
@@ -853,8 +932,12 @@ static bool tf_layout(int B, int S, TfLayout& t) {
     t.xhat2 = o; o += align64l(M * kC);
     t.rstd2 = o; o += align64l(M);
     t.bounds = o; o += (long)kTfBounds * kAmaxSlots;
+    t.yh = o; o += align64l(M * kC);
+    t.hbits = o; o += align64l(M * (kDff / 32));                       // [hid != 0], one bit per element
     t.saved_total = o;
-    t.fwd_total = align64l(M * kC);
+    t.wq1 = align64l(M * kC);
+    t.wq2 = t.wq1 + (long)kDff * kC;
+    t.fwd_total = t.wq2 + (long)kDff * kC;
     o = 0;
     t.ds2 = o; o += align64l(M * kC);
     t.dhid = o; o += align64l(M * kDff);
@@ -867,13 +950,14 @@ static bool tf_layout(int B, int S, TfLayout& t) {
     t.wot = o; o += (long)kC * kC;
     t.wqkv = o; o += 3L * kC * kC;
     t.wqkvt = o; o += 3L * kC * kC;
-    t.part = o; o += align64l(tn_gemm_part_floats((int)M, kDff, kC));
+    t.part = o; o += align64l(std::max(tn_gemm_part_floats((int)M, kDff, kC), gemm_tn_dma_part_floats((int)M, kDff, kC, 1)));
     const long nblk = cdiv(M, kLnRowsPerBlock);
     t.lnpart = o; o += align64l(nblk * 2 * kC);
     t.tmp = o; o += align64l((long)kRowsSumGroups * (kDk * S > kDff ? kDk * S : kDff));
     t.dppart = o; o += align64l((long)B * kTH * kDk * S);
     t.bbounds = o; o += (long)kTfBwdBounds * kAmaxSlots;
     t.colpart = o; o += align64l((long)cdiv(M, 128) * kDff);          // column sums of dh per 128-row tile (GemmEpilogue::colsum)
+    t.ds2h = o; o += align64l(M * kC);                                // ds2 in H2 storage (DMA-fed GEMMs)
     t.bwd_total = o;
     return true;
 }
@@ -958,6 +1042,24 @@ static int tf_forward(const TfGroup& tg, const float* x, const float* const* par
         return rc;
     hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, kLnFwdRows), G), dim3(256), 0, st, x, att, params[5], params[6],
                        saved + t.y, saved + t.xhat1, saved + t.rstd1, M, tg.x, sc, ps[5], sv, kC, sv, slot(kBY));
+    float* ff = scratch;
+    // The feed-forward network on the DMA-fed tiles (gemm_dma.hip) where the call's launches fill the chip -- the K predictors as a
+    // group: y -> H2 (its bound: the slots add_ln_fwd left), lin1 / lin2's weights -> the K-tile-major H2 rows of the tile, lin1 ->
+    // fp32 + max|.|, ReLU + dropout -> the hidden layer in H2 storage IN PLACE of it, lin2.  The backward takes the same branch
+    // (tf_backward asks gemm_dma_wanted with the same arguments; cpc_set_gemm_dma must not change between the two).
+    if (bounded && gemm_dma_wanted(M, G)) {
+        if ((rc = rows_to_h2(saved + t.y, saved + t.yh, slot(kBY), M, G, sv, sv, sv, st))) return rc;
+        if ((rc = gemm_weight_h2(params[7], kC, 1, kDff, kC, scratch + t.wq1, slot(kBW1), nullptr, G, ps[7], sc, sv, 0, st))) return rc;
+        if ((rc = gemm_weight_h2(params[9], kDff, 1, kC, kDff, scratch + t.wq2, slot(kBW2), nullptr, G, ps[9], sc, sv, 0, st))) return rc;
+        if ((rc = gemm_nt_dma(saved + t.yh, kC, scratch + t.wq1, params[8], saved + t.hid, kDff, M, kDff, kC, slot(kBY), slot(kBW1),
+                              slot(kBLin1), G, sv, sc, ps[8], sv, sv, sv, sv, st))) return rc;
+        hipLaunchKernelGGL(relu_h2_kernel, dim3(cdiv((long)cdiv(M, 4) * (kDff / 8), 256 * kReluIters), G), dim3(256), 0, st,
+                           saved + t.hid, M, p, seed, sv, slot(kBLin1), slot(kBHid), slot(kBFlag),
+                           reinterpret_cast<unsigned char*>(saved + t.hbits));
+        CPC_LAUNCH_CHECK();
+        if ((rc = gemm_nt_dma(saved + t.hid, kDff, scratch + t.wq2, params[10], ff, kC, M, kC, kDff, slot(kBHid), slot(kBW2), nullptr,
+                              G, sv, sc, ps[10], sc, sv, sv, 0, st))) return rc;
+    } else {
     // hid = dropout(relu(y W1^T + b1)): as the GEMM's epilogue where it runs on the tile that has one, else a pass behind it
     // (with dropout the elementwise kernel draws its Philox blocks at eight waves per SIMD; in the epilogue of a tile that runs
     // two per SIMD the same draws cost more than the pass they save: 698 vs 377 + 284 us per group at B = 64)
@@ -972,9 +1074,9 @@ static int tf_forward(const TfGroup& tg, const float* x, const float* const* par
     hipLaunchKernelGGL(relu_kernel, dim3(cdiv((long)cdiv(M, 4) * (kDff / 4), 256 * kReluIters), G), dim3(256), 0, st,
                        saved + t.hid, M, p, seed, sv, slot(kBHid));
     }
-    float* ff = scratch;
     if ((rc = nt_gemm(plain_rows(saved + t.hid, M, kDff), params[9], kDff, params[10], ff, kC, kC, kDff, st, 0, 0, gbnd(kBHid, kBW2),
                       grp(sv, ps[9], ps[10], sc)))) return rc;
+    }
     hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(M, kLnFwdRows), G), dim3(256), 0, st, saved + t.y, ff, params[11], params[12],
                        out, saved + t.xhat2, saved + t.rstd2, M, sv, sc, ps[11], tg.out, tg.out_ld, sv, (float*)nullptr);
     CPC_LAUNCH_CHECK();
@@ -1019,6 +1121,30 @@ static int tf_backward(const TfGroup& tg, const float* x, const float* const* pa
     if ((rc = rows_sum(lnpart, nblk, 2 * kC, tmp, dhid, st, G, sc, sc, sc))) return rc;          // dhid as a 512-float staging area
     gcopy(grads[11], dhid, kC, G, ps[11], sc, st);
     gcopy(grads[12], dhid + kC, kC, G, ps[12], sc, st);
+    if (bounded && gemm_dma_wanted(M, G)) {
+        // the feed-forward network's backward on the DMA-fed tiles (the forward left hid and y in H2 storage, tf_forward)
+        float* ds2h = scratch + t.ds2h;
+        if ((rc = rows_to_h2(ds2, ds2h, slot(kBDs2), M, G, sc, sc, sc, st))) return rc;
+        // dW2 (256, 2048) = ds2^T . hid
+        if ((rc = gemm_tn_dma(ds2h, kC, kC, saved + t.hid, kDff, kDff, M, part, grads[9], slot(kBDs2), bnd + kBHid * kAmaxSlots, G, sc, sv,
+                              sc, ps[9], sc, sv, st))) return rc;
+        if ((rc = rows_sum(ds2, M, kC, tmp, grads[10], st, G, sc, sc, ps[10]))) return rc;
+        // dh = (ds2 W2) * [hid > 0] / (1 - p), straight into H2 storage: B(n, k) = W2[k][n]; its bound is a-priori,
+        // max|ds2| * max_n sum_k |W2[k][n]| / (1 - p) -- the l1 slots the weight layout kernel leaves
+        if ((rc = gemm_weight_h2(W2, 1, kDff, kDff, kC, scratch + t.w2t, bnd + kBW2 * kAmaxSlots, slot(kBW2L1), G, ps[9], sc, sv, sc, st)))
+            return rc;
+        if ((rc = gemm_nt_dma_masked(ds2h, kC, scratch + t.w2t, dhid, kDff, saved + t.hbits, 1.0f / (1.0f - p), M, kDff, kC, slot(kBDs2),
+                                     bnd + kBW2 * kAmaxSlots, slot(kBW2L1), scratch + t.colpart, slot(kBDh), G, sc, sc, sc, sv, sc, sv, sc,
+                                     sc, st))) return rc;
+        // dW1 (2048, 256) = dh^T . y;  db1 = column sums of dh (per 256-row tile from the epilogue)
+        if ((rc = gemm_tn_dma(dhid, kDff, kDff, saved + t.yh, kC, kC, M, part, grads[7], slot(kBDh), bnd + kBY * kAmaxSlots, G, sc, sv, sc,
+                              ps[7], sc, sv, st))) return rc;
+        if ((rc = rows_sum(scratch + t.colpart, cdiv(M, 256), kDff, tmp, grads[8], st, G, sc, sc, ps[8]))) return rc;
+        // dy_ff = dh . W1: B(n, k) = W1[k][n]
+        if ((rc = gemm_weight_h2(W1, 1, kC, kC, kDff, scratch + t.w1t, bnd + kBW1 * kAmaxSlots, nullptr, G, ps[7], sc, sv, 0, st))) return rc;
+        if ((rc = gemm_nt_dma(dhid, kDff, scratch + t.w1t, nullptr, dyb, kC, M, kC, kDff, slot(kBDh), bnd + kBW1 * kAmaxSlots, nullptr, G,
+                              sc, sc, 0, sc, sc, sv, 0, st))) return rc;
+    } else {
     // ff = hid W2^T + b2
     const RowMap ds2m = plain_rows(ds2, M, kC), hidm = plain_rows(saved + t.hid, M, kDff);
     if ((rc = tn_gemm(ds2m, kC, hidm, kDff, part, grads[9], 0, st, gbnd(kBDs2, kBHid), grp(sc, sv, ps[9])))) return rc;   // dW2 (256,2048)
@@ -1046,6 +1172,7 @@ static int tf_backward(const TfGroup& tg, const float* x, const float* const* pa
     if (rc) return rc;
     if ((rc = transpose(W1, scratch + t.w1t, kDff, kC, st, G, ps[7], sc))) return rc;           // (2048,256) -> (256,2048)
     if ((rc = nt_gemm(dhm, scratch + t.w1t, kDff, nullptr, dyb, kC, kC, kDff, st, 0, 0, gbnd(kBDh, kBW1), grp(sc, sc, sc)))) return rc;
+    }
     hipLaunchKernelGGL(add_kernel, dim3(cdiv(n4, 256), G), dim3(256), 0, st, dyb, ds2, n4, sc, sc);   // dy_total = ds2 + dhid W1
     // y = LN1(x + att)
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk, G), dim3(256), 0, st, dyb, saved + t.xhat1, saved + t.rstd1, params[5],
@@ -1164,6 +1291,25 @@ extern "C" int cpc_transformer_group_backward(const float* x, const float* const
     tg.ks.scratch = t.bwd_total;
     tg.dy = kC; tg.dy_ld = G * kC;
     return tf_backward(tg, x, params, saved, dy, scratch, dx, grads, B, S, p, seed, (hipStream_t)stream);
+}
+
+// The hidden layer (B*S, 2048) of the forward call that filled `saved` (one layer's workspace), as fp32 whatever its storage: the
+// DMA-fed feed-forward path keeps it in H2 storage (tf_forward).  Tests / inspection; synchronises `stream`.
+extern "C" int cpc_transformer_hidden(const float* saved, float* out, int B, int S, void* stream) {
+    TfLayout t;
+    CPC_RETURN_IF(!tf_layout(B, S, t), CPC_ERR_SHAPE);
+    CPC_RETURN_IF(!saved || !out, CPC_ERR_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    const long n = (long)B * S * kDff;
+    float flag = 0.f;
+    if (hipMemcpyAsync(&flag, saved + t.bounds + kBFlag * kAmaxSlots, sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) return CPC_ERR_ARG;
+    if (flag == 1.0f)
+        hipLaunchKernelGGL(hid_h2_decode_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(saved + t.hid),
+                           saved + t.bounds + kBHid * kAmaxSlots, out, n);
+    else if (hipMemcpyAsync(out, saved + t.hid, sizeof(float) * n, hipMemcpyDeviceToDevice, st) != hipSuccess) return CPC_ERR_ARG;
+    CPC_LAUNCH_CHECK();
+    return 0;
 }
 
 // Test helper: out[i] = keep_i / (1 - p) for element i of dropout site `site` (0: attention probabilities, flat

@@ -314,6 +314,12 @@ int cpc_transformer_layer_forward_dropout(const float* x, const float* const* pa
 int cpc_transformer_layer_backward_dropout(const float* x, const float* const* params, const float* saved,
                                            const float* dy, float* scratch, float* dx, float* const* grads, int B,
                                            int S, float p, unsigned long long seed, void* stream);
+/* the hidden layer (B*S, 2048) of the forward call that filled `saved`, as fp32 whatever its storage (the DMA-fed feed-forward
+ * GEMMs keep it as two fp16 pieces per element); tests / inspection; synchronises `stream` */
+int cpc_transformer_hidden(const float* saved, float* out, int B, int S, void* stream);
+/* feed-forward GEMMs of the transformer layer (cpc/transformers.py:86-101) on the DMA-fed tiles: 0 off, 1 (default) where a
+ * call's launches fill the chip (the K predictors as a group), 2 always; must not change between a forward and its backward */
+int cpc_set_gemm_dma(int mode);
 /* G transformer layers of one shape on ONE input x (B,S,256), every kernel launched once for all of them: the K predictors
  * of the criterion in --rnnMode transformer (cpc/criterion/criterion.py:82-88, :97-118).  params[i] / grads[i]: the G
  * tensors of kind i stacked, layer g at + g * numel; saved / scratch: G workspaces of cpc_transformer_layout's sizes back

@@ -81,16 +81,51 @@ def test_transformer_layer_forward_beyond_128_steps_emulated(B, S, abspos):
     assert lib.cpc_transformer_layout(1, 513, sizes) != 0
 
 
-@pytest.fixture(params=[1, 3], ids=["elementwise-relu", "relu-in-gemm-epilogue"])
+@pytest.fixture(params=[1, 3, "dma"], ids=["elementwise-relu", "relu-in-gemm-epilogue", "dma-fed-ffn"])
 def gemm_split(request):
     """cpc_set_gemm_split(3) puts every product on the wide fp16-piece tile however small the grid, which is the tile whose
     epilogue carries the feed-forward ReLU + dropout (forward) and the ReLU derivative (backward) -- at the sizes of these tests
-    the default takes the small tiles with the elementwise kernels behind them.  Both must produce what the oracle produces
-    with the masks cpc_dropout_keep_mask reports."""
+    the default takes the small tiles with the elementwise kernels behind them.  "dma": cpc_set_gemm_dma(2), the feed-forward
+    network on the DMA-fed tiles of gemm_dma.hip (hidden layer, y and the gradients kept as two fp16 pieces per element; what the
+    K predictors run as a group on MI355X).  All must produce what the oracle produces with the masks cpc_dropout_keep_mask
+    reports.  (Returned value: 1 / 3 = the gemm_split setting; the DMA variant reports 1 -- small generic tiles around it.)"""
     lib = emu()
+    if request.param == "dma":
+        assert lib.cpc_set_gemm_dma(2) == 0
+        yield 1
+        lib.cpc_set_gemm_dma(1)
+        return
     assert lib.cpc_set_gemm_split(request.param) == 0
     yield request.param
     lib.cpc_set_gemm_split(1)
+
+
+def test_hidden_layer_readback_on_either_storage_emulated():
+    """cpc_transformer_hidden: the saved hidden layer as fp32 whether the forward kept it as fp32 (generic tiles) or as two fp16
+    pieces per element (DMA-fed feed-forward GEMMs) -- equal to 2^-21 of its bound -- and both equal to the oracle's."""
+    lib = emu()
+    B, S = 1, 40
+    prm = T.make_layer_params(seed=5, size_seq=S, abspos=False)
+    x = torch.randn(B, S, 256, generator=torch.Generator().manual_seed(2))
+    plist = [prm[k].contiguous() if k in prm else None for k in ORDER]
+    sizes = (ctypes.c_long * 8)()
+    assert lib.cpc_transformer_layout(B, S, sizes) == 0
+    parr = (ctypes.c_void_p * 13)(*[P(t) for t in plist])
+    hids = []
+    for mode in (0, 2):
+        assert lib.cpc_set_gemm_dma(mode) == 0
+        try:
+            saved = torch.full((sizes[0],), float("nan")); fscr = torch.full((sizes[1],), float("nan"))
+            out = torch.full((B, S, 256), float("nan"))
+            assert lib.cpc_transformer_layer_forward(P(x), parr, P(saved), P(fscr), P(out), B, S, None) == 0
+            hid = torch.full((B * S, 2048), float("nan"))
+            assert lib.cpc_transformer_hidden(P(saved), P(hid), B, S, None) == 0
+            hids.append(hid)
+        finally:
+            lib.cpc_set_gemm_dma(1)
+    assert torch.isfinite(hids[0]).all() and torch.isfinite(hids[1]).all()
+    assert (hids[0] - hids[1]).abs().max().item() <= 2e-6 * hids[0].abs().max().item()
+    assert ((hids[0] > 0) == (hids[1] > 0)).all()
 
 
 @pytest.mark.parametrize("B,S,abspos,p_drop", [(1, 40, False, 0.1), (1, 48, True, 0.3), (1, 37, False, 0.2)])

@@ -15,6 +15,9 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     dev = torch.device("cuda:0")
+    if os.environ.get("CPC_GEMM_DMA"):            # A/B: cpc_set_gemm_dma
+        from cpc_audio_amd import _lib
+        _lib.get().check(_lib.get().cpc_set_gemm_dma(int(os.environ["CPC_GEMM_DMA"])), "set_gemm_dma")
     torch.manual_seed(0)
     model = build_model(arMode="transformer").to(dev)
     crit = build_criterion(rnnMode="transformer").to(dev)
