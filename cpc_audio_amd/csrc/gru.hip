@@ -545,19 +545,24 @@ __device__ __forceinline__ bool tile_on_one_xcd(unsigned* sync, int spin_limit) 
 // looking flat out slow one another's hand-over down (measured at B = 64: forward 0.41 -> 0.28 ms, backward 0.77 -> 0.67 ms
 // once the looks that cannot succeed are left out).  The data cannot be there before the producers' gate math is done, so a
 // wave first sleeps `delay` x 64 clocks.  The right delay depends on the kernel, the batch and on what else runs on the
-// chip, so each wave steers its own (PollPace): a look that had to be repeated came too early (delay += 4), four first-time
+// chip, so each wave steers its own (PollPace): a look that had to be repeated came too early (delay += 2; 4 until round 6), four first-time
 // hits in a row may have come late (delay -= 1); the steady state is about one repeated look in twenty steps.
 // fixed >= 0 pins the delay instead (cpc_set_gru_poll_pacing).
 struct PollPace {
-    int delay, streak, fixed;
-    __device__ explicit PollPace(int fixed_) : delay(fixed_ > 0 ? fixed_ : 0), streak(0), fixed(fixed_) {}
+    int delay, streak, fixed, up, clean;
+    // fixed_ >= 0: pinned delay; -1: self-steering with the default steps (up 2, one down per 4 clean steps -- round 6: (2, 4)
+    // against the (4, 4) of rounds 2-5 is worth 4 us forward and 9 us backward at B = 64, tools/ab_gru_pace.py); <= -2: self-steering
+    // with up = (-fixed_) >> 4, clean = (-fixed_) & 15 (cpc_set_gru_poll_pacing: A/B of the steering constants)
+    __device__ explicit PollPace(int fixed_) : delay(fixed_ > 0 ? fixed_ : 0), streak(0), fixed(fixed_), up(2), clean(4) {
+        if (fixed_ <= -2) { up = (-fixed_) >> 4; clean = (-fixed_) & 15; if (clean < 1) clean = 1; }
+    }
     __device__ __forceinline__ void update(int repeats) {     // wave-uniform
         if (fixed >= 0) return;
         if (repeats == 0) {
-            if (++streak >= 4) { streak = 0; delay = delay > 0 ? delay - 1 : 0; }
+            if (++streak >= clean) { streak = 0; delay = delay > 0 ? delay - 1 : 0; }
         } else {
             streak = 0;
-            delay = delay + 4 < 96 ? delay + 4 : 96;
+            delay = delay + up < 96 ? delay + up : 96;
         }
     }
 };
@@ -1275,9 +1280,9 @@ extern "C" int cpc_set_gru_spin_limit(int limit) {
 // Wait before a step's first look at the hand-over buffers in the persistent recurrence (forward / backward kernel), in units
 // of 64 clocks; < 0 (default): every wave steers its own (PollPace).
 extern "C" int cpc_set_gru_poll_pacing(int first_fwd, int first_bwd) {
-    if (first_fwd > 200 || first_bwd > 200) return CPC_ERR_ARG;
-    g_gru_first_sleep[0] = first_fwd < 0 ? -1 : first_fwd;
-    g_gru_first_sleep[1] = first_bwd < 0 ? -1 : first_bwd;
+    if (first_fwd > 200 || first_bwd > 200 || first_fwd < -255 || first_bwd < -255) return CPC_ERR_ARG;
+    g_gru_first_sleep[0] = first_fwd;          // (< -1: steering constants, PollPace)
+    g_gru_first_sleep[1] = first_bwd;
     return 0;
 }
 

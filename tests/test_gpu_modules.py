@@ -171,6 +171,46 @@ def test_gru_persistent_launch_equals_stepwise(B, S):
         assert torch.equal(a, b) and torch.equal(b, c)
 
 
+@pytest.mark.parametrize("B,S", [(64, 128), (20, 33), (128, 16), (256, 24)])
+def test_gru_handover_modes_change_no_bit(B, S):
+    """Round 6: how the persistent recurrence hands h / dh over is a matter of memory scope and placement, never of arithmetic --
+    plain (L2) first looks (cpc_set_gru_poll_plain), one batch tile per XCD with the placement check and plain stores
+    (cpc_set_gru_xcd_local, for either direction and forced for any launch plan: bits 2 / 3), the steering constants of the poll
+    pacing: every combination leaves output, input gradient and parameter gradients bit-identical to the device-scope hand-over of
+    rounds 2-5, with no polling time-out.  B = 20: a ragged second tile; B = 256: two batch tiles per workgroup."""
+    dev = _dev()
+    from cpc_audio_amd import _lib, ops
+    from cpc_audio_amd.model import CPCAR
+    lib = _lib.get()
+    p = O.make_params(seed=4)
+    ar = CPCAR(256, 256, False, 2, mode="GRU").to(dev)
+    ar.load_state_dict({k[len("gAR."):]: v for k, v in p.items() if k.startswith("gAR.")})
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    x = torch.randn(B, S, 256, generator=g).to(dev)
+    dy = torch.randn(B, S, 256, generator=g).to(dev)
+    outs = []
+    try:
+        for plain, local, pace in ((0, 0, -1), (_lib.DEFAULT_GRU_POLL_PLAIN, _lib.DEFAULT_GRU_XCD_LOCAL, -1), (15, 15, -1), (31, 3, -(16 * 4 + 4)),
+                                   (5, 12, -(16 * 1 + 1))):
+            assert lib.cpc_set_gru_poll_plain(plain) == 0 and lib.cpc_set_gru_xcd_local(local) == 0
+            assert lib.cpc_set_gru_poll_pacing(pace, pace) == 0
+            ar.zero_grad(set_to_none=True)
+            xd = x.clone().requires_grad_(True)
+            y = ar(xd)
+            (y * dy).sum().backward()
+            torch.cuda.synchronize()
+            ops.check_device_errors()
+            outs.append([y.detach().clone(), xd.grad.clone()] + [q.grad.clone() for q in ar.parameters()])
+    finally:
+        lib.cpc_set_gru_poll_plain(_lib.DEFAULT_GRU_POLL_PLAIN)
+        lib.cpc_set_gru_xcd_local(_lib.DEFAULT_GRU_XCD_LOCAL)
+        lib.cpc_set_gru_poll_pacing(-1, -1)
+    assert all(torch.isfinite(t).all() for t in outs[0])
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+
+
 def test_gru_fp16_split_forward_is_within_fp32_rounding_of_exact_products():
     """cpc_set_gru_mode(2) (default) against mode 1 (exact-f32 MFMAs) over the full 128-step recurrence at B = 64:
     the two-piece fp16 split keeps 22 mantissa bits per operand; tolerance 2e-6 absolute on |y| < 1."""
