@@ -302,17 +302,24 @@ __device__ __forceinline__ void dma_gemm(f32x16 (&acc)[C::TM][C::TN], const RowM
     for (int j = 0; j < C::NST - 1; ++j)
         if (j < nkt) issue(j, j);
     int stage = 0;
+#ifdef CPC_DMA_TIMING
+    unsigned long long stamp[12] = {};
+#endif
     for (int kt = 0; kt < nkt; ++kt) {
+        CPC_STAMP(0);
         const int younger = min(C::NST - 2, nkt - 1 - kt);      // issued after stage kt and allowed to be in flight (uniform)
         if (younger >= 2) { CPC_WAIT_VMCNT(2 * C::NPS); }
         else if (younger == 1) { CPC_WAIT_VMCNT(C::NPS); }
         else { CPC_WAIT_VMCNT(0); }
+        CPC_STAMP(1);
         __builtin_amdgcn_s_barrier();
+        CPC_STAMP(2);
         if (kt + C::NST - 1 < nkt) {
             int st = stage + C::NST - 1;
             st = st >= C::NST ? st - C::NST : st;
             issue(kt + C::NST - 1, st);
         }
+        CPC_STAMP(3);
         const unsigned char* As = smem + stage * C::STAGE;
         const unsigned char* Bs = As + C::A_BYTES;
 #pragma unroll
@@ -354,8 +361,14 @@ __device__ __forceinline__ void dma_gemm(f32x16 (&acc)[C::TM][C::TN], const RowM
                                                                               __builtin_bit_cast(bf16x8, bf[tn]), acc[tm][tn], 0, 0, 0);
             }
         }
+        CPC_STAMP(4);
+        CPC_STAMP(5);
         stage = stage + 1 == C::NST ? 0 : stage + 1;
     }
+#ifdef CPC_DMA_TIMING
+    if (blockIdx.x == 37 && lane == 0)
+        for (int i = 0; i < 12; ++i) g_dma_stamps[wave * 12 + i] = stamp[i];
+#endif
     __syncthreads();                            // the stage buffers are free (the epilogues reuse them)
 }
 

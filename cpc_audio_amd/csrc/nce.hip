@@ -1483,7 +1483,7 @@ static int nce_prepare_zh(const NceLayout& n, const float* z, float* saved, int 
 }
 static int nce_scores_forward(const NceLayout& n, const float* pred, const float* z, const int* ext, float* saved,
                               float* scratch, float* losses, float* acc, int S, int K, int N, hipStream_t st,
-                              hipStream_t fin = nullptr, int fused = 0) {
+                              hipStream_t fin = nullptr, int fused = 0, bool want_rows = true) {
     // fin (nullptr: st): the stream the loss / accuracy reduction runs on.  Nothing of the backward reads its results (the
     // score gradients come from the saved logits), so a caller that joins `fin` later takes 15 us off its critical path.
     // fused: the one-pass kernel, which also leaves T (unit-gradient dPred) and max|T| in `saved` (slots zeroed by the caller)
@@ -1504,7 +1504,7 @@ static int nce_scores_forward(const NceLayout& n, const float* pred, const float
         hipLaunchKernelGGL(nce_fwd_h2_kernel, dim3((unsigned)wgs), dim3(256), 0, st, pred, z,
                            reinterpret_cast<const unsigned char*>(saved + n.zh), saved + n.bounds + 3 * kAmaxSlots, ext, saved + n.logits,
                            saved + n.lse, scratch + n.rowstat, saved + n.tpred, saved + n.bounds + 2 * kAmaxSlots, saved + n.ps,
-                           n.BW, n.W, S, K, N, ticket, n.Nv, n.koff, g_nce_dbg | (g_nce_rows_apart ? 1 : 0));
+                           n.BW, n.W, S, K, N, ticket, n.Nv, n.koff, g_nce_dbg | ((g_nce_rows_apart || !want_rows) ? 1 : 0));
     } else if (fused)
         hipLaunchKernelGGL(nce_fwd_fused_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, pred, z, ext, saved + n.logits,
                            saved + n.lse, scratch + n.rowstat, saved + n.tpred, saved + n.bounds + 2 * kAmaxSlots, saved + n.ps,
@@ -1520,7 +1520,7 @@ static int nce_scores_forward(const NceLayout& n, const float* pred, const float
         CPC_RETURN_IF(hipEventRecord(ev[10], st) != hipSuccess || hipStreamWaitEvent(fin, ev[10], 0) != hipSuccess, CPC_ERR_ARG);
         st = fin;
     }
-    if (fused >= 2 && g_nce_rows_apart && !(g_nce_dbg & 1)) {
+    if (fused >= 2 && want_rows && g_nce_rows_apart && !(g_nce_dbg & 1)) {
         // the softmax rows, on the stream the reduction runs on (fin: off the forward's chain where the caller has one)
         hipLaunchKernelGGL(nce_softmax_rows_kernel, dim3(cdiv(n.BW, 4)), dim3(256), 0, st, saved + n.logits, saved + n.lse, saved + n.ps,
                            n.BW, K, N);
@@ -1582,6 +1582,18 @@ static int nce_dz_linear_path(const NceLayout& n, const float* c, const float* w
     sk.part = scratch + n.part_dz;
     sk.floats = (long)kDzSplits * B * S * kC;
     return nt_gemm(plain_rows(G, B * S, K * kC), wcat, K * kC, nullptr, dz, kC, kC, K * kC, st, 0, 0, gb, GemmGroup(), sk);
+}
+
+// dpred[bw][k][:] = gscale[k] * T[bw][k][:]: the one-pass kernel's unit-gradient dPred with the heads' upstream gradients applied
+// (predictions of a foreign network: its backward wants dPred itself).  One float4 per thread.
+__global__ __launch_bounds__(256) void nce_scale_tpred_kernel(const float* __restrict__ T, const float* __restrict__ gscale,
+                                                              float* __restrict__ dpred, long n4, int K) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float g = gscale[(int)((i / (kC / 4)) % K)];
+    float4 v = reinterpret_cast<const float4*>(T)[i];
+    v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+    reinterpret_cast<float4*>(dpred)[i] = v;
 }
 
 // dPred (and, for the linear heads, the dS rows of the re-associated dz path) from the upstream per-head gradients.
@@ -1758,7 +1770,21 @@ extern "C" int cpc_nce_scores_forward(const float* pred, const float* z, const i
     CPC_RETURN_IF(!nce_layout(B, S, K, N, n), CPC_ERR_SHAPE);
     N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!pred || !z || !ext || !saved || !scratch || !losses || !acc, CPC_ERR_ARG);
-    return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (nce_fused(N) >= 2) {
+        // the one-pass kernel on fp16 pieces for a foreign network's predictions too (round 6): scores AND the unit-gradient dPred
+        // from ONE gather pass over the H2 copy of z; the backward then only scales T by the heads' upstream gradients
+        // (cpc_nce_scores_backward) instead of gathering the candidate rows a second time (nce_bwd_dpred_kernel: 150 us at B = 64)
+        const float* none[1] = {nullptr};
+        const long zero_n[1] = {0};
+        const float cv[1] = {0.f};
+        int rc = absmax_slots(none, zero_n, 1, saved + n.bounds + 2 * kAmaxSlots, st, cv);      // max|T| slots, cleared
+        if (rc) return rc;
+        if (!g_zh_ready && (rc = nce_prepare_zh(n, z, saved, B, S, st))) return rc;
+        g_zh_ready = false;
+        return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, st, nullptr, 2, false);
+    }
+    return nce_scores_forward(n, pred, z, ext, saved, scratch, losses, acc, S, K, N, st);
 }
 
 // dpred (B*W, K*256) and dz (B,S,256) are overwritten.
@@ -1770,8 +1796,17 @@ extern "C" int cpc_nce_scores_backward(const float* pred, const float* z, const 
     N = n.N;                                 // (padded; n.Nv = as drawn)
     CPC_RETURN_IF(!pred || !z || !ext || !perm || !row_ptr || !saved || !gloss || !scratch || !dpred || !dz, CPC_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
-    int rc = nce_scores_backward(n, z, ext, saved, gloss, scratch, dpred, B, S, K, N, st);
-    if (rc) return rc;
+    int rc = 0;
+    if (nce_fused(N) >= 2) {           // (the forward ran the one-pass kernel: T is in `saved`; a forward and its backward share the setting)
+        hipLaunchKernelGGL(nce_gscale_kernel, dim3(1), dim3(64), 0, st, gloss, scratch + n.gscale, K, 1.0f / ((float)n.BW * (float)kC),
+                           (const float*)nullptr, (float*)nullptr, 0, 0, 0);
+        const long n4 = (long)n.BW * K * (kC / 4);
+        hipLaunchKernelGGL(nce_scale_tpred_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, saved + n.tpred, scratch + n.gscale, dpred, n4, K);
+        CPC_LAUNCH_CHECK();
+    } else {
+        rc = nce_scores_backward(n, z, ext, saved, gloss, scratch, dpred, B, S, K, N, st);
+        if (rc) return rc;
+    }
     return nce_dz_rows_path(n, pred, saved, gloss, perm, row_ptr, scratch, scratch + n.gscale, dz, B, S, K, N, st, false);
 }
 

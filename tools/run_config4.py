@@ -18,6 +18,10 @@ def main():
     if os.environ.get("CPC_GEMM_DMA"):            # A/B: cpc_set_gemm_dma
         from cpc_audio_amd import _lib
         _lib.get().check(_lib.get().cpc_set_gemm_dma(int(os.environ["CPC_GEMM_DMA"])), "set_gemm_dma")
+    for spec in filter(None, os.environ.get("CPC_CALLS", "").split(";")):      # A/B: "cpc_set_nce_fused=1;cpc_set_gemm_dma=0"
+        from cpc_audio_amd import _lib
+        name, _, vals = spec.partition("=")
+        _lib.get().check(getattr(_lib.get(), name)(*[int(v) for v in vals.split(",")]), name)
     torch.manual_seed(0)
     model = build_model(arMode="transformer").to(dev)
     crit = build_criterion(rnnMode="transformer").to(dev)

@@ -46,6 +46,8 @@ def main():
     host = (ctypes.c_ulonglong * 96)()
     assert raw.cpc_debug_dma_stamps(host) == 0
     t00 = min(host[w_ * 12] for w_ in range(8))
+    if pipe == 1:
+        print("(generic two-stage loop: stamps = top | vmcnt wait | barrier | DMA issue of the next stage | LDS reads + MFMAs | -)")
     print("wave | iteration 40: t0 reads+dma waits barrier mfma barrier | iteration 41 ...   (clocks, relative to the first stamp)")
     for w_ in range(8):
         v = [host[w_ * 12 + i] - t00 for i in range(12)]
