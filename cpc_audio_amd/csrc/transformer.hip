@@ -294,6 +294,162 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     publish_amax(o_amax, m);
 }
 
+constexpr int kSlong = 512;
+constexpr int kLdE = 64 + 1;       // per-wave 32 x 64 work tile: E, then the tile's probabilities
+// ------------------------------------------------------------------ attention forward, two workgroups per CU (round 6)
+// attn_fwd_kernel keeps Q, K, V, Krelpos and a 32 x 128 work tile per wave in LDS: 133 KB, ONE workgroup of four waves per CU --
+// one wave per SIMD, which cannot issue back to back, and nothing to run while it waits for its loads or streams the
+// probabilities out (per workgroup ~28 us for ~5 us of MFMAs, rocprofv3 at B = 64).  This form needs 67 KB: Q lives in
+// registers (a lane's 16 operand values of its own row), Krelpos is read from L2 as the MFMA's B operand (16 KB per layer), and
+// the relative-position term E = Q . P is formed per 32 x 32 score tile from the 63 distance columns that tile can see
+// (attn_fwd_long_kernel's scheme) in a 32 x 64 work tile per wave, which then takes the tile's probabilities for the product
+// with V.  Two workgroups share a CU: one's loads, softmax, Philox draws and probability stores run in the other's MFMA time.
+// Same operands into the same MFMA chains in the same order as attn_fwd_kernel (E per column, the scores, the product with V
+// tile by tile): BIT-IDENTICAL o and A (tests/test_gpu_transformer.py); 96 more MFMAs for the last wave (E twice per tile).
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                           float* __restrict__ o, float* __restrict__ A, int S, float drop_p,
+                                                           unsigned long long seed, TfStrides gs, float* __restrict__ o_amax) {
+    __shared__ float lds[2 * kSmax * kLdH + 4 * 32 * kLdE];            // 67 KB
+    {
+        const long g = blockIdx.y;
+        qkv += g * gs.saved; o += g * gs.saved; A += g * gs.saved;
+        if (o_amax != nullptr) o_amax += g * gs.saved;
+        if (P != nullptr) P += g * gs.par[4];
+        seed += (unsigned long long)g;
+    }
+    float* Ks = lds;
+    float* Vs = Ks + kSmax * kLdH;
+    const int bh = blockIdx.x, b = bh / kTH, h = bh % kTH;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const long row0 = (long)b * S;
+    float* Ww = Vs + kSmax * kLdH + w * 32 * kLdE;
+    const int i0 = 32 * w;
+    // this lane's operand values of query row i0 + l31: q[2 kk + khalf], kk = 0..15 (the row is 128 contiguous bytes; rows past
+    // S: the last row, never used unmasked)
+    float qreg[16];
+    {
+        const float* qp = qkv + (row0 + min(i0 + l31, S - 1)) * (3 * kC) + h * kDk;
+        float4 qv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) qv[u] = *reinterpret_cast<const float4*>(qp + 4 * u);
+        const HeadPieces<256> pk = load_head<256>(qkv, row0, 3 * kC, kC + h * kDk, S), pv = load_head<256>(qkv, row0, 3 * kC, 2 * kC + h * kDk, S);
+        store_head(Ks, pk); store_head(Vs, pv);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                 // elements 4u .. 4u+3: k = 4u + {0,1,2,3} -> kk = 2u, 2u + 1 for either parity
+            qreg[2 * u] = khalf ? qv[u].y : qv[u].x;
+            qreg[2 * u + 1] = khalf ? qv[u].w : qv[u].z;
+        }
+    }
+    __syncthreads();
+    if (i0 >= S) return;                              // wave-uniform: no query rows here (no barrier follows)
+
+    const float scale = 0.17677669529663687f;         // 1 / sqrt(32)
+    f32x16 sc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[ct][r] = -INFINITY;
+        if (ct <= w) {                                // tiles right of the diagonal are entirely in the future
+            const int j0 = 32 * ct;
+            if (P != nullptr) {
+                // E[il][cc] = q_(i0 + il) . P[:, cbase + cc]; score (il, jl) needs distance column S - 1 - i + j = cbase + 31 - il + jl
+                const int cbase = S - 1 - (i0 + 31) + j0;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int cc = min(max(cbase + 32 * u + l31, 0), S - 1);      // (clamped columns belong to masked entries)
+                    float pcol[16];
+#pragma unroll
+                    for (int kk = 0; kk < kDk / 2; ++kk) pcol[kk] = P[(long)(2 * kk + khalf) * S + cc];
+                    f32x16 e;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e[r] = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < kDk / 2; ++kk) e = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[kk], pcol[kk], e, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Ww[c_row(r, lane) * kLdE + 32 * u + l31] = e[r];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* krow = Ks + (j0 + l31) * kLdH;
+#pragma unroll
+            for (int kk = 0; kk < kDk / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[kk], krow[2 * kk + khalf], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = c_row(r, lane), i = i0 + il, j = j0 + l31;
+                if (j <= i && i < S) {
+                    const float rel = P != nullptr ? Ww[il * kLdE + 31 - il + l31] : 0.f;
+                    sc[ct][r] = (acc[r] + rel) * scale;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();          // every lane has read E: the tile is free for the next one
+        }
+    }
+
+    unsigned keep[4] = {0u, 0u, 0u, 0u};
+    if (drop_p > 0.f) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            if (ct <= w) keep[ct] = attn_keep_bits(seed, bh, S, w, lane, ct * 32 + l31, drop_threshold(drop_p));
+    }
+    // softmax over the row (registers), A out; the kept probabilities stay in sc for the product with V
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int il = c_row(r, lane), i = i0 + il;
+        float m = fmaxf(fmaxf(sc[0][r], sc[1][r]), fmaxf(sc[2][r], sc[3][r]));
+        m = half_max(m);
+        float p[4], sum = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            p[ct] = (i < S && sc[ct][r] > -INFINITY) ? expf(sc[ct][r] - m) : 0.f;
+            sum += p[ct];
+        }
+        sum = half_sum(sum);
+        const float inv = i < S ? 1.0f / sum : 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const float a = p[ct] * inv;
+            const int j = ct * 32 + l31;
+            float kept = a;
+            if (drop_p > 0.f && i < S && j <= i) kept = ((keep[ct] >> r) & 1u) ? a * (1.0f / (1.0f - drop_p)) : 0.f;
+            sc[ct][r] = kept;
+            if (i < S && j < S) A[((long)bh * S + i) * S + j] = a;
+        }
+    }
+
+    f32x16 ov;                                        // o_w = A_w (32 x 32(w+1)) . V, key tile by key tile through the work tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ov[r] = 0.f;
+    const float* arow = Ww + l31 * kLdE;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        if (ct <= w) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ww[c_row(r, lane) * kLdE + l31] = sc[ct][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int k = 2 * kk + khalf;
+                ov = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k], Vs[(32 * ct + k) * kLdH + l31], ov, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();          // (the next tile's probabilities overwrite these)
+        }
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = i0 + c_row(r, lane);
+        if (i < S) {
+            o[(row0 + i) * kC + h * kDk + l31] = ov[r];
+            m = fmaxf(m, fabsf(ov[r]));
+        }
+    }
+    publish_amax(o_amax, m);
+}
+
 // ------------------------------------------------------------------ attention forward, 128 < S <= 512 (inference)
 // A layer built for a 64000-sample feature-extraction window (cpc/feature_loader.py:247-266 feeds 400 frames; cpc/transformers.py
 // :22-49 at sizeSeq = 400) does not fit attn_fwd_kernel's one-tile-per-sequence LDS image.  Forward only, no dropout, no saved
@@ -302,8 +458,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 // Per 32-key tile: scores Q.K^T (16 MFMAs), the relative-position term E = Q . P[:, c0 .. c0 + 63] for the 63 distances the tile
 // can see (32 MFMAs, P's columns straight from L2 as the B operand -- Krelpos is 51 KB at S = 400), read back skewed as in the
 // short kernel, then probabilities . V (16 MFMAs); every product on v_mfma_f32_32x32x2_f32.
-constexpr int kSlong = 512;
-constexpr int kLdE = 64 + 1;       // per-wave 32 x 64 work tile: E, then the tile's probabilities
 __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                             float* __restrict__ o, int S, TfStrides gs, float* __restrict__ o_amax) {
     __shared__ float lds[3 * kSmax * kLdH + 4 * 32 * kLdE];           // 84 KB
@@ -908,6 +1062,7 @@ __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const f
 }
 
 // ------------------------------------------------------------------ host side
+int g_attn_fwd = 1;        // cpc_set_attn_fwd: 1 = attn_fwd2_kernel (67 KB of LDS, two workgroups per CU), 0 = attn_fwd_kernel (133 KB)
 struct TfLayout {
     long qkv, A, o, xhat1, rstd1, y, hid, xhat2, rstd2, bounds, yh, hbits, saved_total;   // saved for backward (yh: y in H2 storage, DMA-fed GEMMs)
     long wq1, wq2, fwd_total;                                              // forward scratch: one (M,256) buffer + lin1 / lin2's weights as the DMA tiles read them
@@ -1032,6 +1187,9 @@ static int tf_forward(const TfGroup& tg, const float* x, const float* const* par
     if ((rc = nt_gemm(xm, Wv, kC, nullptr, qkv + 2 * kC, 3 * kC, kC, kC, st, 0, 0, gbnd(kBX, kBWv), grp(tg.x, ps[3], 0, sv)))) return rc;
     if (S > kSmax)       // (inference: checked by the caller -- no dropout, no backward)
         hipLaunchKernelGGL(attn_fwd_long_kernel, dim3(B * kTH, cdiv(S, kSmax), G), dim3(256), 0, st, qkv, P, saved + t.o, S, tg.ks,
+                           slot(kBO));
+    else if (g_attn_fwd == 1)
+        hipLaunchKernelGGL(attn_fwd2_kernel, dim3(B * kTH, G), dim3(256), 0, st, qkv, P, saved + t.o, saved + t.A, S, p, seed, tg.ks,
                            slot(kBO));
     else
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * kTH, G), dim3(256), 0, st, qkv, P, saved + t.o, saved + t.A, S, p, seed, tg.ks,
@@ -1309,6 +1467,14 @@ extern "C" int cpc_transformer_hidden(const float* saved, float* out, int B, int
                            saved + t.bounds + kBHid * kAmaxSlots, out, n);
     else if (hipMemcpyAsync(out, saved + t.hid, sizeof(float) * n, hipMemcpyDeviceToDevice, st) != hipSuccess) return CPC_ERR_ARG;
     CPC_LAUNCH_CHECK();
+    return 0;
+}
+
+// Forward attention kernel of the transformer layer (S <= 128): 1 (default) the two-workgroups-per-CU form, 0 the one-tile-in-LDS
+// form of rounds 1-5.  Bit-identical outputs and saved probabilities.
+extern "C" int cpc_set_attn_fwd(int variant) {
+    CPC_RETURN_IF(variant != 0 && variant != 1, CPC_ERR_ARG);
+    cpc::g_attn_fwd = variant;
     return 0;
 }
 

@@ -320,6 +320,7 @@ int cpc_transformer_hidden(const float* saved, float* out, int B, int S, void* s
 /* feed-forward GEMMs of the transformer layer (cpc/transformers.py:86-101) on the DMA-fed tiles: 0 off, 1 (default) where a
  * call's launches fill the chip (the K predictors as a group), 2 always; must not change between a forward and its backward */
 int cpc_set_gemm_dma(int mode);
+int cpc_set_attn_fwd(int variant);       /* forward attention kernel (S <= 128): 1 = two workgroups per CU (default), 0 = one; same bits */
 /* G transformer layers of one shape on ONE input x (B,S,256), every kernel launched once for all of them: the K predictors
  * of the criterion in --rnnMode transformer (cpc/criterion/criterion.py:82-88, :97-118).  params[i] / grads[i]: the G
  * tensors of kind i stacked, layer g at + g * numel; saved / scratch: G workspaces of cpc_transformer_layout's sizes back

@@ -292,6 +292,42 @@ def test_feed_forward_epilogues_equal_the_elementwise_kernels_bit_for_bit(p_drop
             assert torch.equal(a, b), i
 
 
+@pytest.mark.parametrize("B,S,abspos,p_drop", [(64, 128, False, 0.1), (5, 116, False, 0.0), (3, 37, True, 0.2)])
+def test_attention_forward_kernels_agree_bit_for_bit(B, S, abspos, p_drop):
+    """cpc_set_attn_fwd: the two-workgroups-per-CU forward attention kernel (Q in registers, Krelpos from L2, E per score tile; the
+    default since round 6) feeds the same operands into the same MFMA chains as the one-tile-in-LDS kernel of rounds 1-5: layer
+    output, attention output and the saved probabilities are bit-identical, with and without dropout / relative positions."""
+    dev = _dev()
+    from cpc_audio_amd import _lib
+    from cpc_audio_amd._lib import ptr as P
+    import ctypes
+    lib = _lib.get()
+    prm = T.make_layer_params(41 + S, 256, S, abspos)
+    order = ["multihead.Wo.weight", "multihead.Wk.weight", "multihead.Wq.weight", "multihead.Wv.weight", "multihead.Att.Krelpos",
+             "ln_multihead.weight", "ln_multihead.bias", "ffnetwork.lin1.weight", "ffnetwork.lin1.bias", "ffnetwork.lin2.weight",
+             "ffnetwork.lin2.bias", "ln_ffnetwork.weight", "ln_ffnetwork.bias"]
+    plist = [prm[k].contiguous().to(dev) if k in prm else None for k in order]
+    x = torch.randn(B, S, 256, generator=torch.Generator().manual_seed(S)).to(dev)
+    sizes = (ctypes.c_long * 8)()
+    lib.check(lib.cpc_transformer_layout(B, S, sizes), "layout")
+    parr = (ctypes.c_void_p * 13)(*[P(t) for t in plist])
+    st = torch.cuda.current_stream().cuda_stream
+    res = []
+    try:
+        for variant in (0, 1):
+            lib.check(lib.cpc_set_attn_fwd(variant), "attn_fwd")
+            saved = torch.full((sizes[0],), float("nan"), device=dev); fscr = torch.empty(sizes[1], device=dev)
+            out = torch.empty(B, S, 256, device=dev)
+            lib.check(lib.cpc_transformer_layer_forward_dropout(P(x), parr, P(saved), P(fscr), P(out), B, S, p_drop, 4242, st), "fwd")
+            torch.cuda.synchronize()
+            res.append((out.clone(), saved[sizes[4]:sizes[4] + B * 8 * S * S].clone(), saved[sizes[5]:sizes[5] + B * S * 256].clone()))
+    finally:
+        lib.cpc_set_attn_fwd(1)
+    assert torch.isfinite(res[1][0]).all()
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,S,abspos", [(2, 400, False), (3, 129, False), (1, 512, False), (2, 257, True)])
 def test_transformer_layer_beyond_128_steps_runs_on_the_kernels_in_inference(B, S, abspos):
     """A layer built for more than 128 steps (sizeSeq = 400: a 64000-sample feature-extraction window, cpc/feature_loader.py
