@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void rows_to_h2_kernel(const float* __restrict
 //        colsum[row tile][N] -- the bias gradient of the layer in front, summed over the row tiles by rows_sum afterwards
 struct NtDmaArgs {
     RowMap am;                               // rows of A in ELEMENTS of 4 bytes
+    int m_base;                              // first row of this launch's tiles (a product may be cut into a 256-row and a 128-row launch)
     const unsigned char* wq; int K, N;
     const float* bias;
     float* C; long ldc;                      // EPI 2: the H2 tensor, ldc in elements
@@ -124,16 +125,26 @@ struct NtDmaArgs {
          out_l1_gs = 0, colsum_gs = 0;
 };
 
-template <int EPI>
-__global__ __launch_bounds__(GCfg::NTHREADS) void gemm_nt_dma_kernel(NtDmaArgs a) {
-    using C = GCfg;
+template <int EPI, int BM = 256>
+__global__ __launch_bounds__((DmaCfg<BM, 32, 2, 2>::NTHREADS)) void gemm_nt_dma_kernel(NtDmaArgs a) {
+    using C = DmaCfg<BM, 32, 2, 2>;
     constexpr int TM = C::TM, TN = C::TN;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES];
+    constexpr int kMaskBytes = EPI == 2 ? BM * 32 : 0;       // EPI 2: the tile's mask bits (BM rows x 256 columns), DMA'd up front
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES + kMaskBytes];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long g = blockIdx.z;
-    const int m0 = blockIdx.x * 256, n0 = blockIdx.y * 256;
+    const int m0 = a.m_base + blockIdx.x * BM, n0 = blockIdx.y * 256;
     a.am.base += g * a.a_gs;
     const unsigned char* wq = a.wq + g * a.wq_gs + (long)blockIdx.y * a.K * 1024;
+    if constexpr (EPI == 2) {
+        // one DMA instruction per wave: rows 32 wave + lane / 2 of the tile, 16-byte half lane & 1 of their 32 mask bytes -- in
+        // flight under the whole main loop (older than every request of dma_gemm: its counted waits cover it), read from LDS by the
+        // epilogue behind dma_gemm's closing barrier (the 32 exposed global round trips per lane cost the epilogue ~4 us)
+        static_assert(BM == 256, "the mask tile is dealt to eight waves");
+        const int row = 32 * wave + (lane >> 1);
+        const unsigned char* src = a.mask + g * a.mask_gs * 4 + (long)min(m0 + row, a.am.M - 1) * (a.N >> 3) + (n0 >> 3) + 16 * (lane & 1);
+        dma16_to_lds(src, smem + C::SMEM_BYTES + wave * 1024);
+    }
     f32x16 acc[TM][TN];
     dma_gemm<C>(acc, a.am, m0, wq, a.K, g_gemm_zero, 3, smem);
     const float sa = scale_for_amax(fold_amax(a.a_bound + g * a.a_bound_gs, kAmaxSlots));
@@ -176,7 +187,6 @@ __global__ __launch_bounds__(GCfg::NTHREADS) void gemm_nt_dma_kernel(NtDmaArgs a
         }
     } else {
         unsigned char* Ch = reinterpret_cast<unsigned char*>(a.C) + g * a.c_gs * 4;
-        const unsigned char* mk = a.mask + g * a.mask_gs * 4;                // bit mask, N / 8 bytes per row
         // the bound the output is stored for: max|A| * max_n sum_k |B(n, k)| * scale (both factors as slots)
         const float ob = fold_amax(a.out_bound + g * a.out_bound_gs, kAmaxSlots) * fold_amax(a.out_l1 + g * a.out_l1_gs, kAmaxSlots) * a.scale;
         const float so = scale_for_amax(ob);
@@ -190,32 +200,37 @@ __global__ __launch_bounds__(GCfg::NTHREADS) void gemm_nt_dma_kernel(NtDmaArgs a
         float csum[TN];
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) csum[tn] = 0.f;
-        // mask: one bit per element, N / 8 bytes per row; the 128 columns a wave's lanes hold of one row are 16 aligned bytes, the
-        // 32 lanes of a half-wave ask for the same address -- 16 loads per accumulator-row block, requested together
-        const int cbyte = (n0 + (wave & 1) * 128) >> 3;
+        // mask: one bit per element; the 128 columns a wave's lanes hold of one row are 16 aligned bytes of the tile in LDS
+        const unsigned char* mlds = smem + C::SMEM_BYTES + 16 * (wave & 1);     // [row][32 bytes]: this wave's 128 columns = one half
         const int bit = lane & 31;
+        long cboff[TN];                                                   // byte of this lane's dword inside a row, per column tile
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) cboff[tn] = h2_byte_of(col[tn] & ~1) + (odd ? 16 : 0);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             uint4 mb[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                mb[r] = *reinterpret_cast<const uint4*>(mk + (long)min(m0 + dma_c_row(tm, r), a.am.M - 1) * (a.N >> 3) + cbyte);
+            for (int r = 0; r < 16; ++r) mb[r] = *reinterpret_cast<const uint4*>(mlds + dma_c_row(tm, r) * 32);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + dma_c_row(tm, r);
                 const bool live = m < a.am.M;                             // uniform over each half-wave (one row)
                 const unsigned w4[4] = {mb[r].x, mb[r].y, mb[r].z, mb[r].w};
+                unsigned word[TN];
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
+                for (int tn = 0; tn < TN; ++tn) {                         // (the neighbour swap runs on every lane: convergent)
                     const float v = (live && ((w4[tn] >> bit) & 1u)) ? acc[tm][tn][r] * f : 0.f;
                     csum[tn] += v;
                     _Float16 h, l;
                     h2_split(v, so, h, l);
                     const unsigned mine_h = __builtin_bit_cast(unsigned short, h), mine_l = __builtin_bit_cast(unsigned short, l);
                     const unsigned got = swap1(odd ? mine_h : mine_l);    // even lane: the pair's h pieces, odd lane: its l pieces
-                    const unsigned word = odd ? (got | (mine_l << 16)) : (mine_h | (got << 16));
-                    if (live)
-                        *reinterpret_cast<unsigned*>(Ch + (long)m * a.ldc * 4 + h2_byte_of(col[tn] & ~1) + (odd ? 16 : 0)) = word;
+                    word[tn] = odd ? (got | (mine_l << 16)) : (mine_h | (got << 16));
+                }
+                if (live) {                                               // ONE guard per row (a guard per store: 128 exec-mask round trips)
+                    unsigned char* rowp = Ch + (long)m * a.ldc * 4;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) *reinterpret_cast<unsigned*>(rowp + cboff[tn]) = word[tn];
                 }
             }
         }
@@ -361,6 +376,8 @@ __global__ __launch_bounds__(256) void tn_dma_reduce_kernel(const float* __restr
 
 // ------------------------------------------------------------------ host side
 int g_gemm_dma = 1;        // cpc_set_gemm_dma: 0 off, 1 (default) where the launches fill the chip, 2 always (tests, emulator)
+int g_gemm_tail_cus = 0;   // cpc_set_gemm_tail_cus: CU count the tail split plans for (0: the device's; tests)
+int g_gemm_tail_split = 1; // cpc_set_gemm_dma(.. + 4 clears it): a one-tile-wide NT product's last partial round as 128-row tiles
 
 bool gemm_dma_wanted(int M, int G) {
     if (g_mfma_mode < 2 || g_gemm_dma == 0) return false;
@@ -402,7 +419,27 @@ int gemm_nt_dma(const float* a_h2, int lda, const float* wq, const float* bias, 
     a.bias = bias; a.C = C; a.ldc = ldc; a.a_bound = a_bound; a.w_amax = w_amax; a.amax_out = amax_out;
     a.a_gs = a_gs; a.wq_gs = wq_gs * 4; a.bias_gs = bias_gs; a.c_gs = c_gs; a.a_bound_gs = a_bound_gs; a.w_amax_gs = w_amax_gs;
     a.amax_gs = amax_gs;
-    hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3(cdiv(M, 256), N / 256, G), dim3(GCfg::NTHREADS), 0, st, a);
+    a.m_base = 0;
+    // One workgroup per CU (128 KB of LDS): T tiles on C CUs take ceil(T / C) rounds, and a last round that is a third full costs a
+    // whole one -- 348 tiles of the K = 2048 products of the predictors' group on 256 CUs run two rounds for 1.36 rounds of work.
+    // Such a product is cut by rows: as many 256-row tiles per problem as fill whole rounds, the rest as 128-row tiles (half the
+    // time each): 252 + 192 workgroups = 1 + 0.55 rounds.  Only where N is one tile wide (the wide-N products have > 10 rounds).
+    int dev = 0, cus = 0;
+    const long tiles = (long)cdiv(M, 256) * G;
+    if (g_gemm_tail_cus > 0) cus = g_gemm_tail_cus;
+    else if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    if (g_gemm_tail_split && N == 256 && cus > 0 && tiles > cus &&
+        tiles % cus != 0 && tiles % cus < (3 * cus) / 4) {
+        const int n256 = (int)((tiles / cus) * cus / G);              // 256-row tiles per problem in the first launch
+        if (n256 > 0 && n256 < cdiv(M, 256)) {
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256>), dim3(n256, 1, G), dim3(DmaCfg<256, 32, 2, 2>::NTHREADS), 0, st, a);
+            a.m_base = n256 * 256;
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 128>), dim3(cdiv(M - a.m_base, 128), 1, G), dim3(DmaCfg<128, 32, 2, 2>::NTHREADS), 0, st, a);
+            CPC_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256>), dim3(cdiv(M, 256), N / 256, G), dim3(GCfg::NTHREADS), 0, st, a);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -420,7 +457,8 @@ int gemm_nt_dma_masked(const float* a_h2, int lda, const float* wq, float* c_h2,
     a.out_slots = out_slots;
     a.a_gs = a_gs; a.wq_gs = wq_gs * 4; a.c_gs = c_gs; a.mask_gs = mask_gs; a.a_bound_gs = a_bound_gs; a.w_amax_gs = w_amax_gs;
     a.out_bound_gs = a_bound_gs; a.out_l1_gs = w_l1_gs; a.colsum_gs = colsum_gs;
-    hipLaunchKernelGGL(gemm_nt_dma_kernel<2>, dim3(cdiv(M, 256), N / 256, G), dim3(GCfg::NTHREADS), 0, st, a);
+    a.m_base = 0;
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 256>), dim3(cdiv(M, 256), N / 256, G), dim3(GCfg::NTHREADS), 0, st, a);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -467,7 +505,16 @@ int gemm_tn_dma(const float* a_h2, int lda, int N1, const float* b_h2, int ldb, 
 // of this file where a call's launches fill the chip (the K predictors as a group); 2: always (tests).  Results agree to summation
 // order (same pieces, same products).
 extern "C" int cpc_set_gemm_dma(int mode) {
-    if (mode < 0 || mode > 2) return CPC_ERR_ARG;
-    cpc::g_gemm_dma = mode;
+    if (mode < 0 || mode > 6 || (mode & 3) == 3) return CPC_ERR_ARG;
+    cpc::g_gemm_dma = mode & 3;
+    cpc::g_gemm_tail_split = (mode & 4) ? 0 : 1;      // + 4: no 128-row tail launch (A/B)
+    return 0;
+}
+
+// CU count the tail split of the DMA-fed NT products plans for: 0 (default) = the device's; tests set a small one to walk the
+// two-launch form (256-row tiles, then 128-row tiles) at sizes the emulator can run.
+extern "C" int cpc_set_gemm_tail_cus(int cus) {
+    if (cus < 0) return CPC_ERR_ARG;
+    cpc::g_gemm_tail_cus = cus;
     return 0;
 }
