@@ -93,7 +93,8 @@ int transpose_batch(const float* const* in, float* const* out, int n, int R, int
 
 // ---- gemm_dma.hip: plain GEMMs on the DMA-fed tile, operands in H2 storage (every stride in floats = H2 elements; bounds as
 // kAmaxSlots partial maxima; G problems per launch, problem g at + g * the *_gs strides)
-bool gemm_dma_wanted(int M, int G);                                  // cpc_set_gemm_dma: do a call's launches fill the chip?
+bool gemm_dma_wanted(int M, int G);
+bool gemm_dma_relu_fused();                                          // lin1's ReLU + dropout + H2 storage in its epilogue?                                  // cpc_set_gemm_dma: do a call's launches fill the chip?
 // B(n, k) = w[n * sn + k * sk] -> the K-tile-major H2 rows gemm_nt_dma reads (N * K floats), scaled for max|w| (`amax`);
 // l1 (or NULL; zeroed by the caller): max_n sum_k |B(n, k)| -- |A . B^T| <= max|A| * that
 int gemm_weight_h2(const float* w, long sn, long sk, int N, int K, float* wq, const float* amax, float* l1, int G, long w_gs,
@@ -103,6 +104,13 @@ int rows_to_h2(const float* x, float* xh, const float* bound, long rows, int G, 
 int gemm_nt_dma(const float* a_h2, int lda, const float* wq, const float* bias, float* C, long ldc, int M, int N, int K,
                 const float* a_bound, const float* w_amax, float* amax_out, int G, long a_gs, long wq_gs, long bias_gs, long c_gs,
                 long a_bound_gs, long w_amax_gs, long amax_gs, hipStream_t st);
+// C (H2) = dropout(relu(A . B^T + bias)) (Philox site 1, stream seed + problem), scaled for (max|A| * w_l1 + max|bias|) / (1 - p),
+// which goes to every slot of out_slots; bits: [C != 0], one bit per element (N / 8 bytes per row); flag[0] = 1.  N = 2048.
+// (w_amax, w_l1, bias_amax: slot arrays w_gs apart per problem; out_slots / flag: out_gs apart)
+int gemm_nt_dma_relu(const float* a_h2, int lda, const float* wq, const float* bias, float* c_h2, long ldc, float* bits, float drop_p,
+                     unsigned long long seed, int M, int N, int K, const float* a_bound, const float* w_amax, const float* w_l1,
+                     const float* bias_amax, float* out_slots, float* flag, int G, long a_gs, long wq_gs, long bias_gs, long c_gs,
+                     long bits_gs, long a_bound_gs, long w_gs, long out_gs, hipStream_t st);
 // C (H2, scaled for max|A| * l1 * scale) = (A . B^T) * scale where the bit of mask_h2 (one bit per element of C, N / 8 bytes per
 // row, mask_gs in floats) is set, else 0;
 // colsum (or NULL): [ceil(M / 256)][N] column sums per row tile; out_slots (or NULL): kAmaxSlots floats, every one = that bound

@@ -120,7 +120,10 @@ struct NtDmaArgs {
     const float* a_bound; const float* w_amax;
     float* amax_out;
     const unsigned char* mask; float scale; const float* out_bound; const float* out_l1; float* colsum;
-    float* out_slots;                        // EPI 2: every slot = the bound the output was stored for (written by workgroup (0, 0))
+    float* out_slots;                        // EPI 1 / 2: every slot = the bound the output was stored for (written by workgroup (0, 0))
+    // EPI 1: C (H2) = dropout(relu(A . B^T + bias)), scaled for (max|A| * l1 + max|bias|) / (1 - p); bits: its [. != 0] mask
+    float drop_p; unsigned long long seed; const float* bias_amax; unsigned char* bits; float* flag;
+    long bias_amax_gs = 0, bits_gs = 0;
     long a_gs = 0, wq_gs = 0, bias_gs = 0, c_gs = 0, a_bound_gs = 0, w_amax_gs = 0, amax_gs = 0, mask_gs = 0, out_bound_gs = 0,
          out_l1_gs = 0, colsum_gs = 0;
 };
@@ -153,7 +156,71 @@ __global__ __launch_bounds__((DmaCfg<BM, 32, 2, 2>::NTHREADS)) void gemm_nt_dma_
     int col[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) col[tn] = n0 + dma_c_col(tn);
-    if constexpr (EPI == 0) {
+    if constexpr (EPI == 1) {
+        // The feed-forward hidden layer straight out of lin1's accumulators (cpc/transformers.py:93,100): bias, ReLU, dropout by the
+        // Philox blocks relu_kernel draws (registers 4 q .. 4 q + 3 of an accumulator tile are four consecutive rows of one column =
+        // one block), the two fp16 pieces, and the bit mask [hid != 0] by wave ballots -- the 730 MB fp32 round trip of a separate
+        // ReLU pass (0.31 ms per step at B = 64) is gone; the storage bound is a-priori: (max|y| * max_n sum_k |W1[n][k]| + max|b1|) / (1 - p).
+        unsigned char* Ch = reinterpret_cast<unsigned char*>(a.C) + g * a.c_gs * 4;
+        unsigned* bits = reinterpret_cast<unsigned*>(a.bits + g * a.bits_gs * 4);
+        const float keep_scale = 1.0f / (1.0f - a.drop_p);
+        const float ob = (fold_amax(a.a_bound + g * a.a_bound_gs, kAmaxSlots) * fold_amax(a.out_l1 + g * a.out_l1_gs, kAmaxSlots) +
+                          fold_amax(a.bias_amax + g * a.bias_amax_gs, kAmaxSlots)) * keep_scale;
+        const float so = scale_for_amax(ob);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kAmaxSlots) {
+            a.out_slots[g * a.out_bound_gs + threadIdx.x] = ob;
+            if (threadIdx.x == 0) a.flag[g * a.out_bound_gs] = 1.0f;
+        }
+        const unsigned th = drop_threshold(a.drop_p);
+        const unsigned long long seed = a.seed + (unsigned long long)g;
+        const bool odd = lane & 1;
+        auto swap1 = [](unsigned v) __attribute__((always_inline)) {
+            return __builtin_bit_cast(unsigned, dpp_mov<0xB1>(__builtin_bit_cast(float, v)));
+        };
+        float bv[TN];
+        long cboff[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            bv[tn] = a.bias ? a.bias[g * a.bias_gs + col[tn]] : 0.f;
+            cboff[tn] = h2_byte_of(col[tn] & ~1) + (odd ? 16 : 0);
+        }
+        const int dw0 = (n0 + (wave & 1) * 128) >> 5;                     // dword of this wave's first column tile in a mask row
+        const int ndw = a.N >> 5;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int mq = m0 + dma_c_row(tm, 4 * q4);                // rows mq .. mq + 3 (a multiple of four)
+                Philox4 draw[TN];
+                if (a.drop_p > 0.f) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) draw[tn] = philox4x32_10(seed, 1u, ffn_drop_block(mq, col[tn]));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * q4 + j, m = mq + j;
+                    const bool live = m < a.am.M;                         // uniform over each half-wave (one row)
+                    unsigned word[TN];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        float v = fmaxf(fmaf(acc[tm][tn][r], inv, bv[tn]), 0.f);
+                        if (a.drop_p > 0.f) v = philox_word(draw[tn], j) >= th ? v * keep_scale : 0.f;
+                        _Float16 h, l;
+                        h2_split(v, so, h, l);
+                        const unsigned long long nz = __ballot(live && (float)h != 0.f);      // lanes 0-31: row m, 32-63: row m + 4
+                        if ((lane & 31) == 0 && live) bits[(long)m * ndw + dw0 + tn] = (unsigned)(lane ? (nz >> 32) : nz);
+                        const unsigned mine_h = __builtin_bit_cast(unsigned short, h), mine_l = __builtin_bit_cast(unsigned short, l);
+                        const unsigned got = swap1(odd ? mine_h : mine_l);
+                        word[tn] = odd ? (got | (mine_l << 16)) : (mine_h | (got << 16));
+                    }
+                    if (live) {
+                        unsigned char* rowp = Ch + (long)m * a.ldc * 4;
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) *reinterpret_cast<unsigned*>(rowp + cboff[tn]) = word[tn];
+                    }
+                }
+            }
+    } else if constexpr (EPI == 0) {
         float* Cg = a.C + g * a.c_gs;
         float bv[TN];
 #pragma unroll
@@ -376,6 +443,8 @@ __global__ __launch_bounds__(256) void tn_dma_reduce_kernel(const float* __restr
 
 // ------------------------------------------------------------------ host side
 int g_gemm_dma = 1;        // cpc_set_gemm_dma: 0 off, 1 (default) where the launches fill the chip, 2 always (tests, emulator)
+int g_gemm_relu_fused = 1; // cpc_set_gemm_dma(.. + 8 clears it): lin1's ReLU + dropout + H2 storage in its epilogue (else relu_h2_kernel behind it)
+bool gemm_dma_relu_fused() { return g_gemm_relu_fused != 0; }
 int g_gemm_tail_cus = 0;   // cpc_set_gemm_tail_cus: CU count the tail split plans for (0: the device's; tests)
 int g_gemm_tail_split = 1; // cpc_set_gemm_dma(.. + 4 clears it): a one-tile-wide NT product's last partial round as 128-row tiles
 
@@ -463,6 +532,24 @@ int gemm_nt_dma_masked(const float* a_h2, int lda, const float* wq, float* c_h2,
     return 0;
 }
 
+int gemm_nt_dma_relu(const float* a_h2, int lda, const float* wq, const float* bias, float* c_h2, long ldc, float* bits, float drop_p,
+                     unsigned long long seed, int M, int N, int K, const float* a_bound, const float* w_amax, const float* w_l1,
+                     const float* bias_amax, float* out_slots, float* flag, int G, long a_gs, long wq_gs, long bias_gs, long c_gs,
+                     long bits_gs, long a_bound_gs, long w_gs, long out_gs, hipStream_t st) {
+    if (!nt_shape_ok(M, N, K) || N != kFfnWidth) return CPC_ERR_SHAPE;
+    NtDmaArgs a{};
+    a.am = plain_rows(a_h2, M, lda);
+    a.m_base = 0;
+    a.wq = reinterpret_cast<const unsigned char*>(wq); a.K = K; a.N = N;
+    a.bias = bias; a.C = c_h2; a.ldc = ldc; a.a_bound = a_bound; a.w_amax = w_amax; a.out_l1 = w_l1; a.bias_amax = bias_amax;
+    a.bits = reinterpret_cast<unsigned char*>(bits); a.drop_p = drop_p; a.seed = seed; a.out_slots = out_slots; a.flag = flag;
+    a.a_gs = a_gs; a.wq_gs = wq_gs * 4; a.bias_gs = bias_gs; a.c_gs = c_gs; a.bits_gs = bits_gs; a.a_bound_gs = a_bound_gs;
+    a.w_amax_gs = w_gs; a.out_l1_gs = w_gs; a.bias_amax_gs = w_gs; a.out_bound_gs = out_gs;
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<1, 256>), dim3(cdiv(M, 256), N / 256, G), dim3(GCfg::NTHREADS), 0, st, a);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
 // row splits: ~512 workgroups over the T tiles of the G problems, a multiple of 8 splits (one XCD each), whole 64-row blocks, at
 // least 512 rows per split (every split costs a partial tile written and read again, and a prologue)
 void gemm_tn_dma_plan(int M, int N1, int N2, int G, int* splits, int* rows) {
@@ -505,9 +592,10 @@ int gemm_tn_dma(const float* a_h2, int lda, int N1, const float* b_h2, int ldb, 
 // of this file where a call's launches fill the chip (the K predictors as a group); 2: always (tests).  Results agree to summation
 // order (same pieces, same products).
 extern "C" int cpc_set_gemm_dma(int mode) {
-    if (mode < 0 || mode > 6 || (mode & 3) == 3) return CPC_ERR_ARG;
+    if (mode < 0 || mode > 14 || (mode & 3) == 3) return CPC_ERR_ARG;
     cpc::g_gemm_dma = mode & 3;
     cpc::g_gemm_tail_split = (mode & 4) ? 0 : 1;      // + 4: no 128-row tail launch (A/B)
+    cpc::g_gemm_relu_fused = (mode & 8) ? 0 : 1;      // + 8: the ReLU / dropout pass behind lin1 instead of in its epilogue (A/B, tests)
     return 0;
 }
 

@@ -1070,7 +1070,7 @@ struct TfLayout {
 };
 // GEMM operand bounds (publish_amax), kAmaxSlots floats each.  Forward's live in `saved` (the backward reads them again; a
 // group keeps them in layer 0's copy), the gradients' in the backward scratch.
-enum { kBX = 0, kBWq, kBWk, kBWv, kBWo, kBW1, kBW2, kBWqkv, kBO, kBY, kBHid, kBLin1, kBFlag, kTfBounds };   // (kBO on: zeroed per forward)
+enum { kBX = 0, kBWq, kBWk, kBWv, kBWo, kBW1, kBW2, kBWqkv, kBO, kBY, kBHid, kBLin1, kBFlag, kBW1L1, kBB1, kTfBounds };   // (kBO on: zeroed per forward)
 enum { kBDs2 = 0, kBDh, kBDs1, kBDqkv, kBW2L1, kTfBwdBounds };
 
 static bool tf_layout(int B, int S, TfLayout& t) {
@@ -1207,14 +1207,26 @@ static int tf_forward(const TfGroup& tg, const float* x, const float* const* par
     // (tf_backward asks gemm_dma_wanted with the same arguments; cpc_set_gemm_dma must not change between the two).
     if (bounded && gemm_dma_wanted(M, G)) {
         if ((rc = rows_to_h2(saved + t.y, saved + t.yh, slot(kBY), M, G, sv, sv, sv, st))) return rc;
-        if ((rc = gemm_weight_h2(params[7], kC, 1, kDff, kC, scratch + t.wq1, slot(kBW1), nullptr, G, ps[7], sc, sv, 0, st))) return rc;
+        const bool fuse_relu = gemm_dma_relu_fused();
+        if ((rc = gemm_weight_h2(params[7], kC, 1, kDff, kC, scratch + t.wq1, slot(kBW1), fuse_relu ? slot(kBW1L1) : nullptr, G, ps[7], sc, sv,
+                                 sv, st))) return rc;
         if ((rc = gemm_weight_h2(params[9], kDff, 1, kC, kDff, scratch + t.wq2, slot(kBW2), nullptr, G, ps[9], sc, sv, 0, st))) return rc;
+        if (fuse_relu) {
+            // bias, ReLU, dropout, the two fp16 pieces and the mask bits in lin1's epilogue (gemm_nt_dma_kernel<1>)
+            const float* bx[1] = {params[8]};
+            const long bn[1] = {kDff}, bg[1] = {ps[8]};
+            if ((rc = absmax_group(bx, bn, bg, 1, G, slot(kBB1), sv, st))) return rc;
+            if ((rc = gemm_nt_dma_relu(saved + t.yh, kC, scratch + t.wq1, params[8], saved + t.hid, kDff, saved + t.hbits, p, seed, M, kDff, kC,
+                                       slot(kBY), slot(kBW1), slot(kBW1L1), slot(kBB1), slot(kBHid), slot(kBFlag), G, sv, sc, ps[8], sv, sv,
+                                       sv, sv, sv, st))) return rc;
+        } else {
         if ((rc = gemm_nt_dma(saved + t.yh, kC, scratch + t.wq1, params[8], saved + t.hid, kDff, M, kDff, kC, slot(kBY), slot(kBW1),
                               slot(kBLin1), G, sv, sc, ps[8], sv, sv, sv, sv, st))) return rc;
         hipLaunchKernelGGL(relu_h2_kernel, dim3(cdiv((long)cdiv(M, 4) * (kDff / 8), 256 * kReluIters), G), dim3(256), 0, st,
                            saved + t.hid, M, p, seed, sv, slot(kBLin1), slot(kBHid), slot(kBFlag),
                            reinterpret_cast<unsigned char*>(saved + t.hbits));
         CPC_LAUNCH_CHECK();
+        }
         if ((rc = gemm_nt_dma(saved + t.hid, kDff, scratch + t.wq2, params[10], ff, kC, M, kC, kDff, slot(kBHid), slot(kBW2), nullptr,
                               G, sv, sc, ps[10], sc, sv, sv, 0, st))) return rc;
     } else {

@@ -319,7 +319,7 @@ int cpc_transformer_layer_backward_dropout(const float* x, const float* const* p
 int cpc_transformer_hidden(const float* saved, float* out, int B, int S, void* stream);
 /* feed-forward GEMMs of the transformer layer (cpc/transformers.py:86-101) on the DMA-fed tiles: 0 off, 1 (default) where a
  * call's launches fill the chip (the K predictors as a group), 2 always; + 4: without the 128-row tail launch of the one-tile-wide
- * products (A/B); must not change between a forward and its backward */
+ * products, + 8: ReLU / dropout as a pass behind lin1 instead of in its epilogue (A/B); must not change between a forward and its backward */
 int cpc_set_gemm_dma(int mode);
 int cpc_set_gemm_tail_cus(int cus);     /* CU count the DMA-fed NT products' tail split plans for (0 = the device's; tests) */
 int cpc_set_attn_fwd(int variant);       /* forward attention kernel (S <= 128): 1 = two workgroups per CU (default), 0 = one; same bits */

@@ -412,6 +412,14 @@ static inline bool __any(bool pred) {
         if (base + l < hipemu::blk->nthreads) r = r || buf[l] != 0;
     return r;
 }
+static inline unsigned long long __ballot(bool pred) {
+    const uint32_t* buf = hipemu::exchange(pred ? 1u : 0u);
+    unsigned long long r = 0;
+    const int base = (hipemu::cur->lin / hipemu::WAVE) * hipemu::WAVE;
+    for (int l = 0; l < hipemu::WAVE; ++l)
+        if (base + l < hipemu::blk->nthreads && buf[l] != 0) r |= 1ull << l;
+    return r;
+}
 // device queries: the "device" has as many CUs as the emulator has worker threads
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }

@@ -81,7 +81,7 @@ def test_transformer_layer_forward_beyond_128_steps_emulated(B, S, abspos):
     assert lib.cpc_transformer_layout(1, 513, sizes) != 0
 
 
-@pytest.fixture(params=[1, 3, "dma"], ids=["elementwise-relu", "relu-in-gemm-epilogue", "dma-fed-ffn"])
+@pytest.fixture(params=[1, 3, "dma", "dma-pass"], ids=["elementwise-relu", "relu-in-gemm-epilogue", "dma-fed-ffn", "dma-fed-ffn-relu-pass"])
 def gemm_split(request):
     """cpc_set_gemm_split(3) puts every product on the wide fp16-piece tile however small the grid, which is the tile whose
     epilogue carries the feed-forward ReLU + dropout (forward) and the ReLU derivative (backward) -- at the sizes of these tests
@@ -90,8 +90,9 @@ def gemm_split(request):
     K predictors run as a group on MI355X).  All must produce what the oracle produces with the masks cpc_dropout_keep_mask
     reports.  (Returned value: 1 / 3 = the gemm_split setting; the DMA variant reports 1 -- small generic tiles around it.)"""
     lib = emu()
-    if request.param == "dma":
-        assert lib.cpc_set_gemm_dma(2) == 0
+    if request.param in ("dma", "dma-pass"):
+        # ("dma": ReLU + dropout + the fp16 pieces + the mask bits in lin1's epilogue, the default; "dma-pass": + 8 = as a pass behind it)
+        assert lib.cpc_set_gemm_dma(2 if request.param == "dma" else 10) == 0
         yield 1
         lib.cpc_set_gemm_dma(1)
         return
