@@ -62,6 +62,7 @@ SIGNATURES = {
     "cpc_set_gemm_dma": (_I, [_I]),
     "cpc_set_attn_fwd": (_I, [_I]),
     "cpc_set_gemm_tail_cus": (_I, [_I]),
+    "cpc_set_dma_wave_rows": (_I, [_I]),
     "cpc_set_gemm_fuse": (_I, [_I]),
     "cpc_set_gru_xcd_pack": (_I, [_I]),
     "cpc_set_gru_poll_plain": (_I, [_I]),

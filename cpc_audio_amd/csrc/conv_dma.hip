@@ -160,14 +160,14 @@ constexpr int kStoreF32 = 0, kStoreH2 = 1, kStoreBf16 = 2;
 // rows (permute_w_h2 / permute_w_bf16), for NP = 2 max|w| behind it.  y is written as `ykind` says (H2: scaled by
 // scale_for_amax(*y_amax)), xhat as `xkind` (fp32 or bf16), rstd fp32.
 // zeros: >= 128 bytes of zeros (the rows of the conv's zero padding and of the ragged last tile read them).
-template <int BM, int BKE, int NST, int NP, int WALK = 0>      // WALK 1: dma_gemm_pair; 2, 3, 4: ping-pong slots with 0, 2, 4 pieces issued among the MFMAs
-__global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd_dma_kernel(
+template <int BM, int BKE, int NST, int NP, int WALK = 0, int WR = 64>      // WALK 1: dma_gemm_pair; 2, 3, 4: ping-pong slots with 0, 2, 4 pieces issued among the MFMAs
+__global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP, WR>::NTHREADS)) void conv_fwd_dma_kernel(
     RowMap am, const unsigned char* __restrict__ wq, int K, const float* __restrict__ bias,
     const float* __restrict__ nw, const float* __restrict__ nb, void* __restrict__ y, int ykind,
     void* __restrict__ xhat, int xkind, float* __restrict__ rstd_out, const float* __restrict__ x_amax,
     const float* __restrict__ w_amax, const float* __restrict__ y_amax, const unsigned char* __restrict__ zeros,
     int rot_step) {
-    using C = DmaCfg<BM, BKE, NST, NP>;
+    using C = DmaCfg<BM, BKE, NST, NP, WR>;
     constexpr int TM = C::TM, TN = C::TN;
     // ONE LDS object: a second one makes the compiler drain the DMA queue (vmcnt(0)) before every ds_read of the loop
     constexpr bool PAIR = WALK == 1;
@@ -203,14 +203,14 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd
         for (int r = 0; r < 16; ++r) {
             float v = (acc[tm][0][r] + acc[tm][1][r]) + (acc[tm][2][r] + acc[tm][3][r]);
             v = half_wave_sum(v);
-            if ((lane & 31) == 0) red[dma_c_row(tm, r)][wn] = v;
+            if ((lane & 31) == 0) red[dma_c_row<C::WR>(tm, r)][wn] = v;
         }
     __syncthreads();
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = dma_c_row(tm, r);
+            const int row = dma_c_row<C::WR>(tm, r);
             mean[tm][r] = (red[row][0] + red[row][1]) * (1.0f / kC);
         }
     __syncthreads();
@@ -225,7 +225,7 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd
                 v = fmaf(d, d, v);
             }
             v = half_wave_sum(v);
-            if ((lane & 31) == 0) red[dma_c_row(tm, r)][wn] = v;
+            if ((lane & 31) == 0) red[dma_c_row<C::WR>(tm, r)][wn] = v;
         }
     __syncthreads();
     const float sy = ykind == kStoreH2 ? scale_for_amax(*y_amax) : 1.0f;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = dma_c_row(tm, r);
+            const int row = dma_c_row<C::WR>(tm, r);
             const float var = (red[row][0] + red[row][1]) * (1.0f / (kC - 1));
             const float rs = 1.0f / sqrtf(var + kNormEps);
             const int m = m0 + row;
@@ -291,12 +291,12 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_fwd
 //   NP = 2: dx is H2 storage scaled by scale_for_amax(*dx_bound) (the norm backward that wrote it chose the bound, enc_conv.hip),
 //           wd H2 rows (permute_w_dgrad_h2_elem) with max|w| in *w_amax; dprev is fp32, and amax_out (or NULL) receives
 //           max|dprev| spread over kAmaxSlots addresses (fold_amax).
-template <int BM, int BKE, int NST, int NP>
-__global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_dgrad_dma_kernel(
+template <int BM, int BKE, int NST, int NP, int WR = 64>
+__global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP, WR>::NTHREADS)) void conv_dgrad_dma_kernel(
     RowMap am, const unsigned char* __restrict__ wd, int s, int p, int Lin, void* __restrict__ dprev,
     const unsigned char* __restrict__ zeros, int rot_step, const float* __restrict__ dx_bound,
     const float* __restrict__ w_amax, float* __restrict__ amax_out) {
-    using C = DmaCfg<BM, BKE, NST, NP>;
+    using C = DmaCfg<BM, BKE, NST, NP, WR>;
     constexpr int TM = C::TM, TN = C::TN;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES];
     const int lane = threadIdx.x & 63;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__((DmaCfg<BM, BKE, NST, NP>::NTHREADS)) void conv_dgr
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + dma_c_row(tm, r);
+            const int m = m0 + dma_c_row<C::WR>(tm, r);
             long o = -1;
             if (m < am.M) {
                 const int b = m / am.R, q = m - b * am.R + q0;
@@ -672,6 +672,7 @@ __global__ __launch_bounds__(256) void h2_encode_kernel(const float* __restrict_
 
 static int g_dma_rot = 5;     // K-walk rotation step between neighbouring workgroups (0: all walk in lockstep); measured on
                               // layer 1 at B = 64: 0.224 / 0.217 / 0.209 ms for steps 0 / 1 / 5 (two 32-k stages)
+static int g_dgrad_wave_rows = 64;   // cpc_set_dma_pipeline(.. + 8): the 256-row data-gradient tiles as four 128 x 128 waves (dma_tile.h, W128 loop)
 static int g_dma_pipe = 2;    // main-loop schedule of the forward kernel on 256-row tiles (cpc_set_dma_pipeline), layer 1 at B = 64,
                               // clocks per 32 k of contraction and CU with zero operands (= at the full clock; floor 3072 = the
                               // MFMAs of two waves per SIMD), tools/bench_conv_k.py:
@@ -680,6 +681,7 @@ static int g_dma_pipe = 2;    // main-loop schedule of the forward kernel on 256
                               //   0: four 16-k stages, three in flight                 slower than 1 (64-byte rows, twice the barriers)
                               //   3, 4, 5: ping-pong slots with 0 / 2 / 4 DMA pieces among the MFMAs   5600-6400
                               //   6: skewed slots (16 + 8 MFMAs per slot and wave)     6400
+                              //   7: four 128 x 128 waves, ONE per SIMD, four 16-k stages (dma_tile.h, the W128 loop; round 6)
                               // Inside the train step all of them take 205-210 us (the kernel runs against
                               // the chip's power budget there, random operands cost 35-40 % over zeros in every schedule).
 
@@ -712,6 +714,9 @@ int conv_fwd_dma(const float* x_h2, const float* wq, const float* bias, const fl
     else if (bm == 256 && g_dma_pipe == 5) CPC_LAUNCH_PP(4);
     else if (bm == 256 && g_dma_pipe == 6) CPC_LAUNCH_PP(5);                    // skewed slots
 #undef CPC_LAUNCH_PP
+    else if (bm == 256 && g_dma_pipe == 7)                                      // four 128 x 128 waves, one per SIMD (dma_tile.h)
+        hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 16, 4, 2, 0, 128>), dim3(cdiv(am.M, 256)), dim3(256), 0, st, am, wqb, K, bias, nw, nb,
+                           (void*)y, ykind, (void*)xhat, kStoreF32, rstd, x_amax, w_amax, y_amax, zb, g_dma_rot);
     else if (bm == 256 && g_dma_pipe == 0) CPC_LAUNCH_DMA(256, 16, 4);
     else if (bm == 256) CPC_LAUNCH_DMA(256, 32, 2);
     else if (g_dma_pipe == 0) CPC_LAUNCH_DMA(128, 16, 4);
@@ -787,7 +792,10 @@ int conv_dgrad_dma_h2(const void* dx_h2, const float* wd, float* dprev, const fl
 #define CPC_LAUNCH_DMA(BM_)                                                                                                    \
     hipLaunchKernelGGL((conv_dgrad_dma_kernel<BM_, 32, 2, 2>), dim3(8 * s * cdiv(cdiv(am.M, BM_), 8)), dim3(DmaCfg<BM_, 32, 2, 2>::NTHREADS), 0, \
                        st, am, wdb, s, p, Lin, (void*)dprev, zb, g_dma_rot, dx_bound, w_amax, amax_out)
-    if ((long)am.M * s >= 256L * 200) CPC_LAUNCH_DMA(256);
+    if ((long)am.M * s >= 256L * 200 && g_dgrad_wave_rows == 128)
+        hipLaunchKernelGGL((conv_dgrad_dma_kernel<256, 16, 4, 2, 128>), dim3(8 * s * cdiv(cdiv(am.M, 256), 8)), dim3(256), 0, st, am, wdb, s, p,
+                           Lin, (void*)dprev, zb, g_dma_rot, dx_bound, w_amax, amax_out);
+    else if ((long)am.M * s >= 256L * 200) CPC_LAUNCH_DMA(256);
     else CPC_LAUNCH_DMA(128);
 #undef CPC_LAUNCH_DMA
     CPC_LAUNCH_CHECK();
@@ -843,8 +851,9 @@ extern "C" int cpc_debug_dma_stamps(unsigned long long* host) {
 }
 #endif
 extern "C" int cpc_set_dma_pipeline(int variant) {   // 2: as 1, with the pair walk (dma_gemm_pair) where the shape allows; 3: ping-pong slots
-    CPC_RETURN_IF(variant < 0 || variant > 6, CPC_ERR_ARG);
-    g_dma_pipe = variant;
+    CPC_RETURN_IF(variant < 0 || (variant & 7) > 7 || variant > 15, CPC_ERR_ARG);      // + 8: the data gradient's 256-row tiles as four 128 x 128 waves
+    g_dma_pipe = variant & 7;
+    g_dgrad_wave_rows = (variant & 8) ? 128 : 64;
     return 0;
 }
 

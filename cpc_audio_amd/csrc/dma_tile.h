@@ -11,9 +11,13 @@ namespace cpc {
 // BKE: contraction elements per LDS stage, NST: LDS stages, NP: storage of the operands -- 2 = H2 (two fp16 pieces per
 // element, 4 bytes, three MFMAs per product: the fp32-accurate path), 1 = bf16 (2 bytes, one MFMA per product: the
 // bf16-storage variant, cpc_set_mfma_mode(4)).  Rows of a stage are ROWB = 64 or 128 bytes in either storage.
-template <int BM, int BKE_, int NST_, int NP_>
+// WR: rows of a wave's accumulator tile -- 64 (default: eight waves of 64 x 128 per 256-row tile, two per SIMD) or 128 (four waves of
+// 128 x 128, ONE per SIMD, accumulators in the upper half of the 512-register file: a third less LDS traffic per MFMA, and a wave's
+// LDS reads / DMA instructions sit between its own MFMAs instead of in its SIMD partner's matrix time -- dma_gemm's W128 loop)
+template <int BM, int BKE_, int NST_, int NP_, int WR_ = 64>
 struct DmaCfg {
     static constexpr int BN = kC;
+    static constexpr int WR = WR_;
     static constexpr int BKE = BKE_, NST = NST_, NP = NP_;
     static constexpr int ESZ = 2 * NP;                 // bytes per element
     static constexpr int ROWB = BKE * ESZ;             // bytes per row and stage
@@ -22,13 +26,14 @@ struct DmaCfg {
     static constexpr int RPP = 1024 / ROWB;            // rows per 1 KB DMA piece (16 or 8)
     static constexpr int SWSH = PPR == 8 ? 1 : 2;      // swizzle: piece ^= (row >> SWSH) & (PPR - 1)
     static constexpr int KS = BKE / 16;                // MFMA k-steps per stage
-    static constexpr int WAVES_N = 2, WAVES_M = BM / 64, NW = WAVES_M * WAVES_N;
+    static constexpr int WAVES_N = 2, WAVES_M = BM / WR, NW = WAVES_M * WAVES_N;
     static constexpr int NTHREADS = 64 * NW;
-    static constexpr int TM = 2, TN = 4;               // 32 x 32 accumulator tiles per wave (64 x 128)
+    static constexpr int TM = WR / 32, TN = 4;         // 32 x 32 accumulator tiles per wave (64 x 128 or 128 x 128)
     static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     static constexpr int A_PER = (BM / RPP) / NW, B_PER = (BN / RPP) / NW;    // 1 KB DMA pieces per wave and stage
     static constexpr int NPS = A_PER + B_PER;          // DMA instructions per wave and stage (vmcnt bookkeeping)
     static constexpr int SMEM_BYTES = NST * STAGE;
+    static_assert(WR == 64 || WR == 128, "wave tiles of 64 or 128 rows");
     static_assert(NP == 1 || NP == 2, "bf16 or two fp16 pieces");
     static_assert(ROWB == 64 || ROWB == 128, "rows of 4 or 8 pieces");
     static_assert(NST >= 2 && NST <= 4, "2..4 stages");
@@ -38,9 +43,10 @@ struct DmaCfg {
 };
 
 // row of the C tile held in accumulator register `reg` of tile tm / column held by this lane for tile tn
+template <int WR = 64>
 __device__ __forceinline__ int dma_c_row(int tm, int reg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    return (wave >> 1) * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    return (wave >> 1) * WR + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
 }
 __device__ __forceinline__ int dma_c_col(int tn) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -76,7 +82,11 @@ __device__ __forceinline__ void dma_gemm(f32x16 (&acc)[C::TM][C::TN], const RowM
     const int nkt = K / C::BKE;
     const int taps = K >> kCLog2;                                  // power of two for every caller (8, 4, 2)
     const int tshift = 31 - __builtin_clz(taps);
-    const int rot = (int)((blockIdx.x * (unsigned)rot_step) % (unsigned)nkt);
+    // (the 128-row wave tile walks K in the 32-element chunks of the two-stage loop, two 16-k stages per chunk: the same order of
+    // summation, the same bits)
+    constexpr int WALK = C::WR == 128 ? 32 : C::BKE, SUB = WALK / C::BKE;
+    const int nwalk = K / WALK;
+    const int rot = (int)((blockIdx.x * (unsigned)rot_step) % (unsigned)nwalk);
 
     // ---- per-lane DMA sources.  A piece = RPP rows x ROWB bytes (1 KB); lane l of the piece covers row (l / PPR), LDS
     // slot (l % PPR), which holds global piece (l % PPR) ^ ((row >> SWSH) & (PPR - 1)) of that row.
@@ -107,15 +117,15 @@ __device__ __forceinline__ void dma_gemm(f32x16 (&acc)[C::TM][C::TN], const RowM
     const unsigned char* zsrc = zeros + (lane % C::PPR) * 16;
     // pieces [lo, hi) of a wave's NPS DMA pieces of stage kt (A pieces first)
     auto issue_part = [&](int kt, int stage, int lo, int hi) __attribute__((always_inline)) {
-        int q = kt + rot;
-        q = q >= nkt ? q - nkt : q;
+        int q = kt / SUB + rot;
+        q = q >= nwalk ? q - nwalk : q;
         // tap-fastest walk (gemm_tile.h, tshift), the taps in the order 0, s, 1, s+1, ...: tap j of output row t and tap
         // j + s of row t - 1 are the same input row, so the two reads of every input row are ONE stage apart and the second
         // one hits L2 (in plain tap order they are s stages = 4 x 32 KB per CU apart: 671 MB fetched for a 268 MB
         // activation on layer 1, PMC)
         const int ti = q & (taps - 1);
-        q = ((ti >> 1) + (taps >> 1) * (ti & 1)) * (nkt >> tshift) + (q >> tshift);
-        const int k0 = q * C::BKE;
+        q = ((ti >> 1) + (taps >> 1) * (ti & 1)) * (nwalk >> tshift) + (q >> tshift);
+        const int k0 = q * WALK + (kt % SUB) * C::BKE;
         const int tap = k0 >> kCLog2;
         const long koff = (long)k0 * C::ESZ;                               // bytes into an A row
         const long boff = (long)(k0 / C::KPR) * (C::BN * 128) + (k0 % C::KPR) * C::ESZ;
@@ -141,8 +151,85 @@ __device__ __forceinline__ void dma_gemm(f32x16 (&acc)[C::TM][C::TN], const RowM
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     const int sw = ((lane & 31) >> C::SWSH) & (C::PPR - 1), kg = lane >> 5;
-    const int a_row0 = (wm * 64 + (lane & 31)) * C::ROWB, b_row0 = (wn * 128 + (lane & 31)) * C::ROWB;
+    const int a_row0 = (wm * C::WR + (lane & 31)) * C::ROWB, b_row0 = (wn * 128 + (lane & 31)) * C::ROWB;
 
+    if constexpr (C::WR == 128) {
+        // ONE wave per SIMD, 128 x 128 per wave.  A stage is one 16-k step; the fragments of step kt are in registers (set kt & 1)
+        // when iteration kt starts, so all FOUR stage buffers hold younger steps: kt + 1 (read into the other register set during
+        // this iteration), kt + 2, kt + 3 (landed or in flight) and kt + 4, DMA'd into the buffer step kt was read from an iteration
+        // ago -- a request has three iterations (~4600 clocks of MFMAs) to land.  Per iteration a wave issues 48 MFMAs and, one
+        // behind every second MFMA, its 16 fragment reads and 8 DMA pieces: nothing of it waits for a partner wave's slot.  One
+        // barrier per iteration: it publishes step kt + 2 and retires everybody's reads of step kt + 1.
+        // Accumulation order per element as in the two-stage loop (per k-step l*h, h*l, h*h): the same bits.
+        static_assert(C::KS == 1 && C::NST == 4 && C::NP == 2 && C::NPS == 8 && TM == 4 && TN == 4,
+                      "one k-step per stage, four stages, H2 operands, eight DMA pieces per wave and stage");
+        using SP = SplitPlanes<2>;
+        s16x8 fa[2][TM][2], fb[2][TN][2];
+        // fragment x (0..15) of the stage at `As` into register set `set`: planes 0 (x < 8) and 1, A tiles then B tiles
+        auto read_frag = [&](const unsigned char* As, int set, int x) __attribute__((always_inline)) {
+            const int pl = x >> 3, t = x & 7;
+            const int off = ((2 * kg + pl) ^ sw) * 16;
+            if (t < TM) fa[set][t][pl] = *reinterpret_cast<const s16x8*>(As + a_row0 + t * 32 * C::ROWB + off);
+            else fb[set][t - TM][pl] = *reinterpret_cast<const s16x8*>(As + C::A_BYTES + b_row0 + (t - TM) * 32 * C::ROWB + off);
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nkt) issue(j, j);
+        CPC_WAIT_VMCNT(3 * C::NPS);
+        __builtin_amdgcn_s_barrier();                           // step 0 has landed for everybody
+#pragma unroll
+        for (int x = 0; x < 16; ++x) read_frag(smem, 0, x);
+        CPC_WAIT_LGKMCNT0();
+        CPC_WAIT_VMCNT(2 * C::NPS);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                           // step 1 has landed, step 0 is in everybody's registers
+        __builtin_amdgcn_sched_barrier(0);
+        // DMA: issue the pieces of step kt + 4 (the main part of the loop); LEFT: DMA requests of mine that may stay in flight
+        // across the closing barrier (step kt + 2 must have landed: everything older than the youngest LEFT)
+        auto step = [&](int kt, auto set_tag, auto dma_tag, auto left_tag) __attribute__((always_inline)) {
+            constexpr int set = decltype(set_tag)::value, LEFT = decltype(left_tag)::value;
+            constexpr bool DMA = decltype(dma_tag)::value;
+            const unsigned char* As = smem + ((kt + 1) & 3) * C::STAGE;
+#pragma unroll
+            for (int i = 0; i < 3 * TM * TN; ++i) {
+                const int q = i / (TM * TN), tm = (i / TN) % TM, tn = i % TN;
+                acc[tm][tn] = SP::mfma(fa[set][tm][SP::pa(q)], fb[set][tn][SP::pb(q)], acc[tm][tn]);
+                // behind MFMAs 0, 2, .., 30 a fragment read of the next step (the last iteration reads a stale buffer into registers
+                // nobody uses); behind MFMAs 3, 9, .., 45 a DMA piece -- 192 clocks of MFMAs apart: a piece occupies the wave's issue
+                // for 60+ clocks (MI355X_MICROARCH.md), packed back to back they stall the matrix pipe
+                if (i % 2 == 0 && i < 32) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frag(As, set ^ 1, i / 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (DMA && i % 6 == 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_part(kt + 4, kt & 3, i / 6, i / 6 + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            CPC_WAIT_LGKMCNT0();
+            CPC_WAIT_VMCNT(LEFT);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using Yes = std::integral_constant<bool, true>;
+        using No = std::integral_constant<bool, false>;
+        int kt = 0;
+        for (; kt + 4 < nkt; kt += 2) {                         // (nkt is a multiple of 16: K = 256 * 2^j)
+            step(kt, I0{}, Yes{}, std::integral_constant<int, 2 * C::NPS>{});
+            step(kt + 1, I1{}, Yes{}, std::integral_constant<int, 2 * C::NPS>{});
+        }
+        step(kt, I0{}, No{}, std::integral_constant<int, C::NPS>{});        // kt = nkt - 4: steps up to nkt - 1 are issued
+        step(kt + 1, I1{}, No{}, I0{});
+        step(kt + 2, I0{}, No{}, I0{});
+        step(kt + 3, I1{}, No{}, I0{});
+        __syncthreads();
+        return;
+    }
     if constexpr (SKEW) {
         static_assert(C::KS == 1 && C::NST == 4 && C::NP == 2 && C::NPS == 4, "one k-step per stage, four stages, H2 operands");
         using SP = SplitPlanes<2>;

@@ -128,9 +128,10 @@ struct NtDmaArgs {
          out_l1_gs = 0, colsum_gs = 0;
 };
 
-template <int EPI, int BM = 256>
-__global__ __launch_bounds__((DmaCfg<BM, 32, 2, 2>::NTHREADS)) void gemm_nt_dma_kernel(NtDmaArgs a) {
-    using C = DmaCfg<BM, 32, 2, 2>;
+template <int EPI, int BM = 256, int WR = 64>
+__global__ __launch_bounds__((DmaCfg<BM, WR == 128 ? 16 : 32, WR == 128 ? 4 : 2, 2, WR>::NTHREADS)) void gemm_nt_dma_kernel(NtDmaArgs a) {
+    using C = DmaCfg<BM, WR == 128 ? 16 : 32, WR == 128 ? 4 : 2, 2, WR>;
+    static_assert(WR == 64 || EPI == 0, "the 128-row wave tile: plain epilogue only");
     constexpr int TM = C::TM, TN = C::TN;
     constexpr int kMaskBytes = EPI == 2 ? BM * 32 : 0;       // EPI 2: the tile's mask bits (BM rows x 256 columns), DMA'd up front
     __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES + kMaskBytes];
@@ -230,7 +231,7 @@ __global__ __launch_bounds__((DmaCfg<BM, 32, 2, 2>::NTHREADS)) void gemm_nt_dma_
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + dma_c_row(tm, r);
+                const int m = m0 + dma_c_row<C::WR>(tm, r);
                 if (m < a.am.M) {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
@@ -446,6 +447,7 @@ int g_gemm_dma = 1;        // cpc_set_gemm_dma: 0 off, 1 (default) where the lau
 int g_gemm_relu_fused = 1; // cpc_set_gemm_dma(.. + 8 clears it): lin1's ReLU + dropout + H2 storage in its epilogue (else relu_h2_kernel behind it)
 bool gemm_dma_relu_fused() { return g_gemm_relu_fused != 0; }
 int g_gemm_tail_cus = 0;   // cpc_set_gemm_tail_cus: CU count the tail split plans for (0: the device's; tests)
+int g_dma_wave_rows = 64;  // cpc_set_dma_wave_rows: 128 = the plain NT products' 256-row tiles as four 128 x 128 waves (dma_tile.h, W128 loop)
 int g_gemm_tail_split = 1; // cpc_set_gemm_dma(.. + 4 clears it): a one-tile-wide NT product's last partial round as 128-row tiles
 
 bool gemm_dma_wanted(int M, int G) {
@@ -501,14 +503,16 @@ int gemm_nt_dma(const float* a_h2, int lda, const float* wq, const float* bias, 
         tiles % cus != 0 && tiles % cus < (3 * cus) / 4) {
         const int n256 = (int)((tiles / cus) * cus / G);              // 256-row tiles per problem in the first launch
         if (n256 > 0 && n256 < cdiv(M, 256)) {
-            hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256>), dim3(n256, 1, G), dim3(DmaCfg<256, 32, 2, 2>::NTHREADS), 0, st, a);
+            if (g_dma_wave_rows == 128) hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256, 128>), dim3(n256, 1, G), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256>), dim3(n256, 1, G), dim3(DmaCfg<256, 32, 2, 2>::NTHREADS), 0, st, a);
             a.m_base = n256 * 256;
             hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 128>), dim3(cdiv(M - a.m_base, 128), 1, G), dim3(DmaCfg<128, 32, 2, 2>::NTHREADS), 0, st, a);
             CPC_LAUNCH_CHECK();
             return 0;
         }
     }
-    hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256>), dim3(cdiv(M, 256), N / 256, G), dim3(GCfg::NTHREADS), 0, st, a);
+    if (g_dma_wave_rows == 128) hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256, 128>), dim3(cdiv(M, 256), N / 256, G), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256>), dim3(cdiv(M, 256), N / 256, G), dim3(GCfg::NTHREADS), 0, st, a);
     CPC_LAUNCH_CHECK();
     return 0;
 }
@@ -596,6 +600,14 @@ extern "C" int cpc_set_gemm_dma(int mode) {
     cpc::g_gemm_dma = mode & 3;
     cpc::g_gemm_tail_split = (mode & 4) ? 0 : 1;      // + 4: no 128-row tail launch (A/B)
     cpc::g_gemm_relu_fused = (mode & 8) ? 0 : 1;      // + 8: the ReLU / dropout pass behind lin1 instead of in its epilogue (A/B, tests)
+    return 0;
+}
+
+// Wave tile of the DMA-fed plain NT products' 256-row tiles: 64 (default: eight waves of 64 x 128) or 128 (four waves of 128 x 128,
+// one per SIMD -- dma_tile.h, the W128 loop).  Same products in the same order: the same bits.
+extern "C" int cpc_set_dma_wave_rows(int rows) {
+    if (rows != 64 && rows != 128) return CPC_ERR_ARG;
+    cpc::g_dma_wave_rows = rows;
     return 0;
 }
 

@@ -321,6 +321,9 @@ int cpc_transformer_hidden(const float* saved, float* out, int B, int S, void* s
  * call's launches fill the chip (the K predictors as a group), 2 always; + 4: without the 128-row tail launch of the one-tile-wide
  * products, + 8: ReLU / dropout as a pass behind lin1 instead of in its epilogue (A/B); must not change between a forward and its backward */
 int cpc_set_gemm_dma(int mode);
+/* wave tile of the DMA-fed plain NT products' 256-row tiles: 64 = eight waves of 64 x 128 (two per SIMD), 128 = four waves of
+ * 128 x 128 (one per SIMD, accumulators in AGPRs, a four-stage 16-k loop: csrc/dma_tile.h); same products in the same order: same bits */
+int cpc_set_dma_wave_rows(int rows);
 int cpc_set_gemm_tail_cus(int cus);     /* CU count the DMA-fed NT products' tail split plans for (0 = the device's; tests) */
 int cpc_set_attn_fwd(int variant);       /* forward attention kernel (S <= 128): 1 = two workgroups per CU (default), 0 = one; same bits */
 /* G transformer layers of one shape on ONE input x (B,S,256), every kernel launched once for all of them: the K predictors

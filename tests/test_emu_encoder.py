@@ -232,7 +232,8 @@ def test_fp16_split_scaling_extremes_emulated(xs, ws):
                                                     (1, 300, 8, 4, 2, 256, True, 3), (2, 131, 4, 2, 1, 256, False, 3),
                                                     (1, 300, 8, 4, 2, 256, True, 4), (2, 131, 4, 2, 1, 256, False, 5),
                                                     (1, 300, 8, 4, 2, 256, True, 6), (2, 131, 4, 2, 1, 256, False, 6),
-                                                    (1, 300, 8, 4, 2, 256, True, 2)])       # Lout % 256 != 0: the pair walk falls back
+                                                    (1, 300, 8, 4, 2, 256, True, 2),        # Lout % 256 != 0: the pair walk falls back
+                                                    (1, 300, 8, 4, 2, 256, True, 7), (2, 131, 4, 2, 1, 256, False, 7)])   # 7: four 128 x 128 waves
 def test_dma_conv_kernel_matches_the_register_staged_kernel_emulated(B, Lin, k, s, p, bm, y_h2, pipe):
     """cpc_conv_gemm_forward_h2 (both operands DMA'd into XOR-swizzled LDS rows, H2 storage) against
     cpc_conv_layer_forward in mode 2 on the same fp32 data: same pieces, same products, same ChannelNorm -- results agree

@@ -118,14 +118,24 @@ def test_dma_fed_ffn_with_the_tail_split_and_several_row_tiles_emulated():
     (yr * dy).sum().backward()
     assert lib.cpc_set_gemm_dma(2) == 0
     try:
-        for cus in (0, 2):
+        ref = {}
+        for cus, rows in ((0, 64), (2, 64), (0, 128), (2, 128)):
             assert lib.cpc_set_gemm_tail_cus(cus) == 0
+            assert lib.cpc_set_dma_wave_rows(rows) == 0
             out, dx, grads = run_layer(lib, p, x, dy, S)
-            assert (out - yr).abs().max().item() < 1e-5, cus
-            assert rel_err(dx, xr.grad) < 1e-5, cus
+            assert (out - yr).abs().max().item() < 1e-5, (cus, rows)
+            assert rel_err(dx, xr.grad) < 1e-5, (cus, rows)
             bad = {k: rel_err(gr, leaves[k].grad) for k, gr in grads.items() if not rel_err(gr, leaves[k].grad) < 1e-5}
-            assert not bad, (cus, bad)
+            assert not bad, (cus, rows, bad)
+            # four 128 x 128 waves (one per SIMD, the four-stage 16-k loop) accumulate the same products in the same order as the
+            # eight 64 x 128 waves: the same bits
+            if rows == 64:
+                ref[cus] = (out, dx, grads)
+            else:
+                assert torch.equal(out, ref[cus][0]) and torch.equal(dx, ref[cus][1]), (cus, rows)
+                assert all(torch.equal(grads[k], ref[cus][2][k]) for k in grads), (cus, rows)
     finally:
+        lib.cpc_set_dma_wave_rows(64)
         lib.cpc_set_gemm_tail_cus(0)
         lib.cpc_set_gemm_dma(1)
 

@@ -107,13 +107,14 @@ def _run(lib, B, L, dev, pseed=0, bm=0, mode=1, dma=None, onednn=True):
                 ref_grads=[leaves[n].grad for n in _names()], saved=saved, sizes=sizes, Ls=Ls, acts=acts, ys=ys)
 
 
-@pytest.mark.parametrize("pipe", [1, 2, 3, 5, 6])
-def test_encoder_dma_pipelines_match_oracle(pipe):
+@pytest.mark.parametrize("pipe,B", [(1, 8), (2, 8), (3, 8), (5, 8), (6, 8), (7, 8), (15, 64)])
+def test_encoder_dma_pipelines_match_oracle(pipe, B):
     """Layer 1 on 256-row tiles of the DMA kernel at a size the oracle finishes quickly: the two-stage walk (1), the ping-pong slots (3) and the
-    tap-pair walk (2: every input row brought to LDS once, used by both taps that read it)."""
+    tap-pair walk (2: every input row brought to LDS once, used by both taps that read it); 7: four 128 x 128 waves, one per SIMD
+    (dma_tile.h, the W128 loop); 15 = 7 + 8: layer 1's data gradient on that tile as well (256-row tiles: the benchmark's batch)."""
     dev = _dev()
     from cpc_audio_amd import _lib
-    r = _run(_lib.get(), 8, 20480, dev, mode=3, dma=(256, pipe))
+    r = _run(_lib.get(), B, 20480, dev, mode=3, dma=(256, pipe))
     assert (r["z"] - r["z_ref"]).abs().max().item() < 1e-4
     for i in range(4):
         assert (r["ys"][i] - r["acts"][i].permute(0, 2, 1)).abs().max().item() < 1e-4, i

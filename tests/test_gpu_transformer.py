@@ -237,6 +237,14 @@ def test_config4_at_its_quoted_batch_is_finite_reproducible_and_grouped_equals_p
             assert worst < 2e-5, (mode, worst)
             if mode == 2:
                 ldma, gdma = l1, g1
+                # the plain NT products' 256-row tiles as four 128 x 128 waves, one per SIMD (cpc_set_dma_wave_rows(128): the
+                # four-stage 16-k loop of dma_tile.h): the same products in the same order -- the same bits
+                lib.check(lib.cpc_set_dma_wave_rows(128), "set_dma_wave_rows")
+                try:
+                    l4, g4 = run(True)
+                finally:
+                    lib.cpc_set_dma_wave_rows(64)
+                assert torch.equal(l4, l1) and all(torch.equal(a, b) for a, b in zip(g4, g1)), "wave tiles of 128 rows differ"
         # ... and the two paths against each other: losses to rounding, gradients to the few ReLU ties
         assert (ldma - l1).abs().max().item() < 1e-5
         assert max(_rel(a, b) for a, b in zip(gdma, g1)) < 2e-3
