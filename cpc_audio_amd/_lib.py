@@ -131,6 +131,7 @@ SIGNATURES = {
     "cpc_set_nce_grid": (_I, [_I]),
     "cpc_set_nce_debug": (_I, [_I]),
     "cpc_set_nce_rows_apart": (_I, [_I]),
+    "cpc_set_nce_heads_dma": (_I, [_I]),
     "cpc_nce_prepare_z": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "cpc_set_index_prep_groups": (_I, [_I]),
     "cpc_set_gru_wgrad_stream": (_I, [_I]),

@@ -104,6 +104,9 @@ int rows_to_h2(const float* x, float* xh, const float* bound, long rows, int G, 
 int gemm_nt_dma(const float* a_h2, int lda, const float* wq, const float* bias, float* C, long ldc, int M, int N, int K,
                 const float* a_bound, const float* w_amax, float* amax_out, int G, long a_gs, long wq_gs, long bias_gs, long c_gs,
                 long a_bound_gs, long w_amax_gs, long amax_gs, hipStream_t st);
+// one product whose A rows are a RowMap over an H2 tensor (strides in H2 elements), C fp32 with rows ldc apart, no bias
+int gemm_nt_dma_rows(const RowMap& am_h2, const float* wq, float* C, long ldc, int N, int K, const float* a_bound, const float* w_amax,
+                     hipStream_t st);
 // C (H2) = dropout(relu(A . B^T + bias)) (Philox site 1, stream seed + problem), scaled for (max|A| * w_l1 + max|bias|) / (1 - p),
 // which goes to every slot of out_slots; bits: [C != 0], one bit per element (N / 8 bytes per row); flag[0] = 1.  N = 2048.
 // (w_amax, w_l1, bias_amax: slot arrays w_gs apart per problem; out_slots / flag: out_gs apart)

@@ -480,6 +480,35 @@ static bool nt_shape_ok(int M, int N, int K) {
     return M > 0 && N % 256 == 0 && K % 256 == 0 && ((K >> 8) & ((K >> 8) - 1)) == 0;      // K = 256 * 2^j (dma_gemm's K walk)
 }
 
+// the plain product's launches: one workgroup per CU (128 KB of LDS): T tiles on C CUs take ceil(T / C) rounds, and a last round
+// that is a third full costs a whole one -- 348 tiles of the K = 2048 products of the predictors' group on 256 CUs run two rounds
+// for 1.36 rounds of work.  Such a product is cut by rows: as many 256-row tiles per problem as fill whole rounds, the rest as
+// 128-row tiles (half the time each): 252 + 192 workgroups = 1 + 0.55 rounds.  (The wide-N products of the feed-forward network have
+// > 10 rounds and are left alone: `wide_ok` is the criterion's heads' product, 29 x 12 tiles.)
+static int launch_nt_plain(NtDmaArgs& a, int M, int N, int G, bool wide_ok, hipStream_t st) {
+    a.m_base = 0;
+    int dev = 0, cus = 0;
+    const int per_row = (N / 256) * G;                                 // workgroups per row tile
+    const long tiles = (long)cdiv(M, 256) * per_row;
+    if (g_gemm_tail_cus > 0) cus = g_gemm_tail_cus;
+    else if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    if (g_gemm_tail_split && (N == 256 || wide_ok) && cus > 0 && tiles > cus && tiles % cus != 0 && tiles % cus < (3 * cus) / 4) {
+        const int n256 = (int)((tiles / cus) * cus / per_row);         // 256-row tiles per problem in the first launch
+        if (n256 > 0 && n256 < cdiv(M, 256)) {
+            if (g_dma_wave_rows == 128) hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256, 128>), dim3(n256, N / 256, G), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256>), dim3(n256, N / 256, G), dim3(DmaCfg<256, 32, 2, 2>::NTHREADS), 0, st, a);
+            a.m_base = n256 * 256;
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 128>), dim3(cdiv(M - a.m_base, 128), N / 256, G), dim3(DmaCfg<128, 32, 2, 2>::NTHREADS), 0, st, a);
+            CPC_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    if (g_dma_wave_rows == 128) hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256, 128>), dim3(cdiv(M, 256), N / 256, G), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256>), dim3(cdiv(M, 256), N / 256, G), dim3(GCfg::NTHREADS), 0, st, a);
+    CPC_LAUNCH_CHECK();
+    return 0;
+}
+
 int gemm_nt_dma(const float* a_h2, int lda, const float* wq, const float* bias, float* C, long ldc, int M, int N, int K,
                 const float* a_bound, const float* w_amax, float* amax_out, int G, long a_gs, long wq_gs, long bias_gs, long c_gs,
                 long a_bound_gs, long w_amax_gs, long amax_gs, hipStream_t st) {
@@ -490,31 +519,18 @@ int gemm_nt_dma(const float* a_h2, int lda, const float* wq, const float* bias, 
     a.bias = bias; a.C = C; a.ldc = ldc; a.a_bound = a_bound; a.w_amax = w_amax; a.amax_out = amax_out;
     a.a_gs = a_gs; a.wq_gs = wq_gs * 4; a.bias_gs = bias_gs; a.c_gs = c_gs; a.a_bound_gs = a_bound_gs; a.w_amax_gs = w_amax_gs;
     a.amax_gs = amax_gs;
-    a.m_base = 0;
-    // One workgroup per CU (128 KB of LDS): T tiles on C CUs take ceil(T / C) rounds, and a last round that is a third full costs a
-    // whole one -- 348 tiles of the K = 2048 products of the predictors' group on 256 CUs run two rounds for 1.36 rounds of work.
-    // Such a product is cut by rows: as many 256-row tiles per problem as fill whole rounds, the rest as 128-row tiles (half the
-    // time each): 252 + 192 workgroups = 1 + 0.55 rounds.  Only where N is one tile wide (the wide-N products have > 10 rounds).
-    int dev = 0, cus = 0;
-    const long tiles = (long)cdiv(M, 256) * G;
-    if (g_gemm_tail_cus > 0) cus = g_gemm_tail_cus;
-    else if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-    if (g_gemm_tail_split && N == 256 && cus > 0 && tiles > cus &&
-        tiles % cus != 0 && tiles % cus < (3 * cus) / 4) {
-        const int n256 = (int)((tiles / cus) * cus / G);              // 256-row tiles per problem in the first launch
-        if (n256 > 0 && n256 < cdiv(M, 256)) {
-            if (g_dma_wave_rows == 128) hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256, 128>), dim3(n256, 1, G), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256>), dim3(n256, 1, G), dim3(DmaCfg<256, 32, 2, 2>::NTHREADS), 0, st, a);
-            a.m_base = n256 * 256;
-            hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 128>), dim3(cdiv(M - a.m_base, 128), 1, G), dim3(DmaCfg<128, 32, 2, 2>::NTHREADS), 0, st, a);
-            CPC_LAUNCH_CHECK();
-            return 0;
-        }
-    }
-    if (g_dma_wave_rows == 128) hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256, 128>), dim3(cdiv(M, 256), N / 256, G), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256>), dim3(cdiv(M, 256), N / 256, G), dim3(GCfg::NTHREADS), 0, st, a);
-    CPC_LAUNCH_CHECK();
-    return 0;
+    return launch_nt_plain(a, M, N, G, false, st);
+}
+
+// One product whose A rows are a RowMap over an H2 tensor (the criterion's heads: the rows (b, t < W) of the context c), C fp32
+int gemm_nt_dma_rows(const RowMap& am_h2, const float* wq, float* C, long ldc, int N, int K, const float* a_bound, const float* w_amax,
+                     hipStream_t st) {
+    if (!nt_shape_ok(am_h2.M, N, K)) return CPC_ERR_SHAPE;
+    NtDmaArgs a{};
+    a.am = am_h2;
+    a.wq = reinterpret_cast<const unsigned char*>(wq); a.K = K; a.N = N;
+    a.C = C; a.ldc = ldc; a.a_bound = a_bound; a.w_amax = w_amax;
+    return launch_nt_plain(a, am_h2.M, N, 1, true, st);
 }
 
 int gemm_nt_dma_masked(const float* a_h2, int lda, const float* wq, float* c_h2, long ldc, const float* mask_h2, float scale, int M,

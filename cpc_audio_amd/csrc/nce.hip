@@ -1378,6 +1378,10 @@ int g_nce_fused = 2;       // cpc_set_nce_fused: 1 the one-pass criterion (nce_f
                            // 2 (default since round 6) the one-pass criterion with the scoring kernel on fp16 pieces (nce_fwd_h2_kernel: an H2 copy of z as
                            // gather source, DMA'd tiles, transposing LDS reads), 3 = 2 + the dz path's gather-GEMM likewise
                            // (nce_bwd_g_h2_kernel, from an H2 copy of c)
+int g_nce_heads_dma = 1;   // cpc_set_nce_heads_dma: the prediction product pred = c . wall^T (criterion.py:108-116: the K linear heads, one NT GEMM
+                           // with N = K * 256, K = 256) on the DMA-fed tile of gemm_dma.hip -- c as an H2 copy (its bound is the GRU's |h| < 1 or
+                           // the measured max|c|), the stacked weights re-laid once per step beside the bounds -- instead of the
+                           // register-staged generic tile (80 us at B = 64: 0.18 of the fp16-piece roof)
 int g_nce_dbg = 0;         // cpc_set_nce_debug: measurement switches of nce_fwd_h2_kernel (tools/time_nce.py) -- bit 0 no softmax-row
                            // pass, 1 no T epilogue, 2 no weighted row sum, 3 no logits stores; results are then WRONG
 int g_nce_rows_apart = 1;  // cpc_set_nce_rows_apart: the softmax rows of the fp16-piece scoring kernel by a launch of their own (on the
@@ -1391,7 +1395,7 @@ struct NceLayout {
     int N, Nv;      // negatives per window as the kernels walk them (a multiple of 16) / as drawn (criterion.py:176-189): the
                     // candidates Nv .. N-1 of every window are padding -- a valid row of z, their logit forced to -3e38, so that
                     // they weigh exactly 0 in the softmax, the arg-max and every gradient
-    long pred, logits, lse, bounds, tpred, ps, zh, saved_total;
+    long pred, logits, lse, bounds, tpred, ps, zh, chf, wqh, saved_total;
     long rowstat, tmp, sums, fwd_total;
     long dpred, wallT, part, gscale, V, dS, G, wcat, part_dz, ch, bwd_total;
 };
@@ -1404,6 +1408,7 @@ constexpr int kDzSplits = 4;      // K-walk splits the dz GEMM's partial buffer 
 // The groups share nothing but the inputs: losses / accuracies are per head, the gradients add.
 static thread_local int g_head_off = 0, g_head_total = 0;
 static thread_local bool g_zh_ready = false;     // cpc_nce_prepare_z ran for the calling thread's next forward
+static thread_local bool g_wqh_ready = false;    // cpc_nce_bounds laid the head weights out for the calling thread's next forward
 
 static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     const int Ktot = g_head_total > 0 ? g_head_total : K;
@@ -1423,6 +1428,8 @@ static bool nce_layout(int B, int S, int K, int N, NceLayout& n) {
     n.tpred = o; o += align64l((long)n.BW * K * kC);      // T: d loss_k / d pred_k for a unit upstream gradient (one-pass criterion)
     n.ps = o; o += align64l((long)n.BW * (N + K) * 16);   // ... and the softmax rows per candidate slot (the dz path's dS / g_k)
     n.zh = o; o += align64l((long)B * S * kC);            // z in H2 storage: the gather source of nce_fwd_h2_kernel
+    n.chf = o; o += align64l((long)B * S * kC);           // c in H2 storage and the stacked head weights in the K-tile-major H2 rows of
+    n.wqh = o; o += align64l((long)K * kC * kC + 64);     // gemm_dma.hip: the operands of the prediction product on the DMA-fed tile
     n.saved_total = o;
     o = 0;
     n.rowstat = o; o += align64l((long)n.BW * 2 * K);
@@ -1458,6 +1465,8 @@ static RowMap window_rows(const float* c, int B, int S, int W) {     // rows (b,
 
 // scores, log-softmax, per-head loss / accuracy from given predictions
 static int nce_fused(int) { return g_nce_fused; }
+// the prediction product on the DMA-fed tile?  (fp16-piece arithmetic; the generic tile otherwise)
+static bool nce_heads_dma(int K) { return g_nce_heads_dma && g_mfma_mode >= 2 && K > 0; }
 // wall^T for dc = dPred . wall: plain, or -- one-pass criterion, whose dPred is the unit-gradient T -- pre-multiplied by the heads'
 // upstream gradients (scratch + gscale must hold them: nce_gscale_kernel on this stream or one it has waited for)
 static int nce_wallT(const float* wall, float* scratch, const NceLayout& n, int K, int N, hipStream_t st) {
@@ -1697,7 +1706,21 @@ static int nce_forward(const float* c, const float* z, const float* wall, const 
     GemmBounds gb;
     gb.a = saved + n.bounds; gb.a_slots = kAmaxSlots;
     gb.b = saved + n.bounds + kAmaxSlots; gb.b_slots = kAmaxSlots;
-    int rc = nt_gemm(window_rows(c, B, S, n.W), wall, kC, nullptr, pred, (long)K * kC, K * kC, kC, st, 0, 0, gb);
+    int rc = 0;
+    if (nce_heads_dma(K)) {
+        // the same product on the DMA-fed tile: an H2 copy of c (8 MB at B = 64), the weights in K-tile-major H2 rows (ahead of time
+        // where the bounds were: cpc_nce_bounds), 256 x 256 tiles of the conv layers' main loop
+        if (!g_wqh_ready) rc = gemm_weight_h2(wall, kC, 1, K * kC, kC, saved + n.wqh, saved + n.bounds + kAmaxSlots, nullptr, 1, 0, 0, 0, 0, st);
+        g_wqh_ready = false;
+        if (rc) return rc;
+        rc = nce_rows_to_h2(c, saved + n.chf, saved + n.bounds, (long)B * S, st);
+        if (rc) return rc;
+        rc = gemm_nt_dma_rows(window_rows(saved + n.chf, B, S, n.W), saved + n.wqh, pred, (long)K * kC, K * kC, kC, saved + n.bounds,
+                              saved + n.bounds + kAmaxSlots, st);
+    } else {
+        g_wqh_ready = false;
+        rc = nt_gemm(window_rows(c, B, S, n.W), wall, kC, nullptr, pred, (long)K * kC, K * kC, kC, st, 0, 0, gb);
+    }
     if (rc) return rc;
     if (nce_fused(N) >= 2 && !g_zh_ready) {                 // (cpc_nce_prepare_z: ahead of time, on another stream)
         rc = nce_prepare_zh(n, z, saved, B, S, st);
@@ -1727,7 +1750,13 @@ extern "C" int cpc_nce_bounds(const float* c, float c_bound, const float* wall, 
     const float* xs[3] = {c_bound > 0.f ? nullptr : c, wall, nullptr};
     const long ns[3] = {(long)B * S * kC, (long)K * kC * kC, 0};
     const float cv[3] = {c_bound, 0.f, 0.f};
-    return absmax_slots(xs, ns, 3, saved + n.bounds, (hipStream_t)stream, cv);
+    int rc = absmax_slots(xs, ns, 3, saved + n.bounds, (hipStream_t)stream, cv);
+    if (rc) return rc;
+    if (nce_heads_dma(K)) {          // ... and the head weights in the rows the DMA-fed prediction product reads (needs max|wall|: just written)
+        rc = gemm_weight_h2(wall, kC, 1, K * kC, kC, saved + n.wqh, saved + n.bounds + kAmaxSlots, nullptr, 1, 0, 0, 0, 0, (hipStream_t)stream);
+        g_wqh_ready = rc == 0;
+    }
+    return rc;
 }
 
 extern "C" int cpc_nce_forward_prepared(const float* c, const float* z, const float* wall, const int* ext, float* saved,
@@ -1953,6 +1982,7 @@ extern "C" int cpc_set_nce_fused(int on) {
     return 0;
 }
 extern "C" int cpc_get_nce_fused(void) { return g_nce_fused; }
+extern "C" int cpc_set_nce_heads_dma(int on) { g_nce_heads_dma = on ? 1 : 0; return 0; }
 extern "C" int cpc_set_nce_rows_apart(int on) { g_nce_rows_apart = on ? 1 : 0; return 0; }
 /* measurement only (tools/time_nce.py): leave parts of nce_fwd_h2_kernel out -- results are wrong while mask != 0 */
 extern "C" int cpc_set_nce_debug(int mask) { g_nce_dbg = mask; return 0; }

@@ -442,6 +442,10 @@ int cpc_set_nce_grid(int wgs);
 /* cpc_set_nce_fused(2 / 3): 1 (default) = the softmax rows the dz path reads are written by a launch of their own, on the stream
  * the loss reduction runs on (cpc_nce_forward_streams' finalize_stream: off the forward's chain), 0 = inside the scoring kernel. */
 int cpc_set_nce_rows_apart(int on);
+/* The prediction product pred = c . wall^T of the K linear heads (cpc/criterion/criterion.py:108-116): 1 (default) = on the DMA-fed
+ * 256 x 256 tile of csrc/gemm_dma.hip (c as an H2 copy, the stacked weights re-laid beside the operand bounds), 0 = on the generic
+ * register-staged tile.  Same fp16-piece arithmetic, another order of summation. */
+int cpc_set_nce_heads_dma(int on);
 /* Measurement switch of the cpc_set_nce_fused(2) scoring kernel (tools/time_nce.py: what each part of it costs): bit 0 leaves the
  * softmax-row pass out, 1 the T epilogue, 2 the weighted row sum, 3 the logits stores.  Results are WRONG while mask != 0. */
 int cpc_set_nce_debug(int mask);

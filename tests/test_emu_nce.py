@@ -23,11 +23,15 @@ def test_nce_forward_backward_emulated(B, S, K, N, scale, wide, fused):
     tiles, transposing LDS reads: nce_fwd_h2_kernel; 3: + nce_bwd_g_h2_kernel)."""
     lib = emu()
     assert lib.cpc_set_gemm_split(3 if wide else 1) == 0 and lib.cpc_set_nce_fused(fused) == 0
+    # (the prediction product runs on the DMA-fed tile by default -- cpc_set_nce_heads_dma, round 6 --; the `wide` case and the
+    # two-pass criterion keep the generic tiles covered)
+    assert lib.cpc_set_nce_heads_dma(0 if (wide or fused == 0) else 1) == 0
     try:
         _nce_forward_backward(lib, B, S, K, N, scale)
     finally:
         lib.cpc_set_gemm_split(1)
         lib.cpc_set_nce_fused(_L.DEFAULT_NCE_FUSED)
+        lib.cpc_set_nce_heads_dma(1)
 
 
 def _nce_forward_backward(lib, B, S, K, N, scale):
