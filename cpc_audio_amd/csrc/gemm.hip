@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
     [[maybe_unused]] float csum[NtG::TN];
 #pragma unroll
     for (int tn = 0; tn < NtG::TN; ++tn) csum[tn] = 0.f;
-    const unsigned th = EPI == 1 ? drop_threshold(ep.drop_p) : 0u;
+    const unsigned th = EPI == 1 ? drop_threshold16(ep.drop_p) : 0u;
     const float keep_scale = EPI == 1 ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
 #pragma unroll
     for (int tn = 0; tn < NtG::TN; ++tn) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NtG::NTHREADS) void nt_gemm_kernel(RowMap am, const
                     float v = H2 ? fmaf(acc[tm][tn][r], inv, bv) : acc[tm][tn][r] + bv;
                     if constexpr (EPI == 1) {
                         v = fmaxf(v, 0.f);
-                        if (ep.drop_p > 0.f) v = philox_word(draw, r & 3) >= th ? v * keep_scale : 0.f;
+                        if (ep.drop_p > 0.f) v = ffn_drop_field(draw, r & 3, col) >= th ? v * keep_scale : 0.f;
                     }
                     if constexpr (EPI == 2) v = mk[r] > 0.f ? v * ep.scale : 0.f;
                     if constexpr (EPI != 0) cmax = fmaxf(cmax, fabsf(v));

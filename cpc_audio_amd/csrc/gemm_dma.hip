@@ -35,11 +35,10 @@ __global__ __launch_bounds__(256) void gemm_weight_h2_kernel(const float* __rest
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     const long g = blockIdx.y;
     w += g * w_gs; wq += g * wq_gs; amax += g * amax_gs;
-    if (n >= N) return;                                   // wave-uniform
     const float s = scale_for_amax(fold_amax(amax, kAmaxSlots));
     unsigned char* tile = wq + (long)(n >> 8) * K * 1024;
     float sum = 0.f;
-    for (int k4 = 4 * lane; k4 < K; k4 += 256) {
+    for (int k4 = 4 * lane; k4 < K && n < N; k4 += 256) {  // (rows past N -- wave-uniform -- do nothing, but meet the barrier below)
         float v[4];
         if (sk == 1) {
             const float4 q = *reinterpret_cast<const float4*>(w + (long)n * sn + k4);
@@ -52,9 +51,14 @@ __global__ __launch_bounds__(256) void gemm_weight_h2_kernel(const float* __rest
         unsigned char* row = tile + ((long)(k4 >> 5) * 256 + (n & 255)) * 128;
         h2_store4(row, k4 & 31, v[0], v[1], v[2], v[3], s);
     }
-    if (l1 != nullptr) {
+    if (l1 != nullptr) {                                  // (block-uniform) one atomic per workgroup: the largest of its four rows' sums
+        __shared__ float rowsum[4];
         sum = wave_sum(sum);
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(l1 + g * l1_gs) + (n & (kAmaxSlots - 1)), __float_as_uint(sum));
+        if (lane == 0) rowsum[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(reinterpret_cast<unsigned*>(l1 + g * l1_gs) + (blockIdx.x & (kAmaxSlots - 1)),
+                      __float_as_uint(fmaxf(fmaxf(rowsum[0], rowsum[1]), fmaxf(rowsum[2], rowsum[3]))));
     }
 }
 
@@ -76,20 +80,32 @@ __global__ __launch_bounds__(64) void gemm_weight_h2_t_kernel(const float* __res
         h2_store4(row, 4 * q, src[0], src[sk], src[2 * sk], src[3 * sk], s);
     }
 }
-// l1[slot] = max over n of sum_k |w[k * sk + n]| (atomicMax; zeroed by the caller): one thread per n, coalesced over n
+// l1[slot] = max over n of sum_k |w[k * sk + n]| (atomicMax; zeroed by the caller).  A workgroup takes 64 columns n (lane = n: the
+// reads of a k are coalesced) and cuts K over its four waves, whose partial sums meet in LDS in a fixed order (one thread per n over
+// all of K ran 96 workgroups of serial 2048-term sums: 41 us for 25 MB).  grid (N / 64, G).
 __global__ __launch_bounds__(256) void col_l1_kernel(const float* __restrict__ w, long sk, int N, int K, float* __restrict__ l1,
                                                      long w_gs, long l1_gs) {
+    __shared__ float part[4][64];
     const long g = blockIdx.y;
     w += g * w_gs;
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    float s0 = 0.f, s1 = 0.f;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int kq = (K + 3) / 4, k0 = wv * kq, k1 = min(K, k0 + kq);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (n < N) {
-        int k = 0;
-        for (; k + 1 < K; k += 2) { s0 += fabsf(w[(long)k * sk + n]); s1 += fabsf(w[(long)(k + 1) * sk + n]); }
-        if (k < K) s0 += fabsf(w[(long)k * sk + n]);
+        int k = k0;
+        for (; k + 3 < k1; k += 4) {
+            s0 += fabsf(w[(long)k * sk + n]); s1 += fabsf(w[(long)(k + 1) * sk + n]);
+            s2 += fabsf(w[(long)(k + 2) * sk + n]); s3 += fabsf(w[(long)(k + 3) * sk + n]);
+        }
+        for (; k < k1; ++k) s0 += fabsf(w[(long)k * sk + n]);
     }
-    const float m = wave_max(s0 + s1);
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(l1 + g * l1_gs) + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kAmaxSlots - 1)), __float_as_uint(m));
+    part[wv][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wv == 0) {
+        const float m = wave_max((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(l1 + g * l1_gs) + (blockIdx.x & (kAmaxSlots - 1)), __float_as_uint(m));
+    }
 }
 
 // fp32 rows of 256 -> H2 rows scaled for `bound` (kAmaxSlots partial maxima).  One wave per row; blockIdx.y: tensor of a group.
@@ -172,7 +188,7 @@ __global__ __launch_bounds__((DmaCfg<BM, WR == 128 ? 16 : 32, WR == 128 ? 4 : 2,
             a.out_slots[g * a.out_bound_gs + threadIdx.x] = ob;
             if (threadIdx.x == 0) a.flag[g * a.out_bound_gs] = 1.0f;
         }
-        const unsigned th = drop_threshold(a.drop_p);
+        const unsigned th = drop_threshold16(a.drop_p);
         const unsigned long long seed = a.seed + (unsigned long long)g;
         const bool odd = lane & 1;
         auto swap1 = [](unsigned v) __attribute__((always_inline)) {
@@ -192,10 +208,10 @@ __global__ __launch_bounds__((DmaCfg<BM, WR == 128 ? 16 : 32, WR == 128 ? 4 : 2,
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int mq = m0 + dma_c_row(tm, 4 * q4);                // rows mq .. mq + 3 (a multiple of four)
-                Philox4 draw[TN];
+                Philox4 draw[TN / 2];                                    // column tiles 2 u and 2 u + 1 (32 columns apart) share a block
                 if (a.drop_p > 0.f) {
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) draw[tn] = philox4x32_10(seed, 1u, ffn_drop_block(mq, col[tn]));
+                    for (int u = 0; u < TN / 2; ++u) draw[u] = philox4x32_10(seed, 1u, ffn_drop_block(mq, col[2 * u]));
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -205,7 +221,7 @@ __global__ __launch_bounds__((DmaCfg<BM, WR == 128 ? 16 : 32, WR == 128 ? 4 : 2,
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         float v = fmaxf(fmaf(acc[tm][tn][r], inv, bv[tn]), 0.f);
-                        if (a.drop_p > 0.f) v = philox_word(draw[tn], j) >= th ? v * keep_scale : 0.f;
+                        if (a.drop_p > 0.f) v = ffn_drop_field(draw[tn >> 1], j, col[tn]) >= th ? v * keep_scale : 0.f;
                         _Float16 h, l;
                         h2_split(v, so, h, l);
                         const unsigned long long nz = __ballot(live && (float)h != 0.f);      // lanes 0-31: row m, 32-63: row m + 4
@@ -461,7 +477,7 @@ int gemm_weight_h2(const float* w, long sn, long sk, int N, int K, float* wq, co
     if (sn == 1 && sk != 1) {
         hipLaunchKernelGGL(gemm_weight_h2_t_kernel, dim3(N / 64, K / 32, G), dim3(64), 0, st, w, sk, N, K,
                            reinterpret_cast<unsigned char*>(wq), amax, w_gs, wq_gs * 4, amax_gs);
-        if (l1 != nullptr) hipLaunchKernelGGL(col_l1_kernel, dim3(cdiv(N, 256), G), dim3(256), 0, st, w, sk, N, K, l1, w_gs, l1_gs);
+        if (l1 != nullptr) hipLaunchKernelGGL(col_l1_kernel, dim3(cdiv(N, 64), G), dim3(256), 0, st, w, sk, N, K, l1, w_gs, l1_gs);
     } else
     hipLaunchKernelGGL(gemm_weight_h2_kernel, dim3(cdiv(N, 4), G), dim3(256), 0, st, w, sn, sk, N, K,
                        reinterpret_cast<unsigned char*>(wq), amax, l1, w_gs, wq_gs * 4, amax_gs, l1_gs);

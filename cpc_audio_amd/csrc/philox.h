@@ -24,14 +24,24 @@ __device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsign
 }
 // an element is dropped iff its 32 random bits fall below p * 2^32
 __device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)((double)p * 4294967296.0); }
-// Site 1 (feed-forward hidden layer, rows of kFfnWidth): as site 0 the four words of a block belong to four consecutive ROWS of
-// one column -- block (row >> 2) * 2048 + col, word row & 3 -- which is what a lane of a GEMM tile's accumulator holds.
+// Site 1 (feed-forward hidden layer, rows of kFfnWidth): a Philox block decides EIGHT elements -- four consecutive ROWS (word
+// row & 3) of the two columns c and c + 32 (c & 32 == 0: the low / high 16 bits of the word), which is what a lane of a GEMM tile's
+// accumulators holds in two neighbouring 32-column tiles.  An element is dropped iff its 16 bits fall below p * 2^16 (p = 0.1:
+// 6553 / 65536 = 0.09999 -- a keep probability within 1.1e-5 of 1 - p; the survivors are scaled by the nominal 1 / (1 - p)).
+// Round 6: lin1's fused epilogue (gemm_dma.hip) spent most of its time in one ten-round block per FOUR elements -- half of that now.
 constexpr int kFfnWidth = 2048;
 __device__ __forceinline__ unsigned long long ffn_drop_block(long row, int col) {
-    return (unsigned long long)(row >> 2) * kFfnWidth + col;
+    return (unsigned long long)(row >> 2) * (kFfnWidth / 2) + (unsigned)(((col >> 6) << 5) | (col & 31));
 }
+__device__ __forceinline__ unsigned drop_threshold16(float p) { return (unsigned)((double)p * 65536.0); }
 __device__ __forceinline__ unsigned philox_word(const Philox4& r, int word) {
     return word == 0 ? r.x : (word == 1 ? r.y : (word == 2 ? r.z : r.w));
+}
+
+// the 16 bits of element (row with row & 3 == word, col) in its block's draw
+__device__ __forceinline__ unsigned ffn_drop_field(const Philox4& r, int word, int col) {
+    const unsigned w = philox_word(r, word);
+    return (col & 32) ? (w >> 16) : (w & 0xFFFFu);
 }
 
 }  // namespace cpc

@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, int M,
     x += (long)blockIdx.y * x_gs;                     // layer blockIdx.y of a group, dropout stream seed + layer
     if (x_amax != nullptr) x_amax += (long)blockIdx.y * x_gs;
     seed += (unsigned long long)blockIdx.y;
-    const unsigned th = drop_threshold(drop_p);
+    const unsigned th = drop_threshold16(drop_p);
     const float sc = 1.0f / (1.0f - drop_p);
     const long npiece = (long)((M + 3) >> 2) * (kDff / 4);
     float m = 0.f;
@@ -888,7 +888,8 @@ __global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, int M,
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const Philox4 r = philox4x32_10(seed, 1u, ffn_drop_block(row0, c4 + c));
-                keep |= ((r.x >= th ? 1u : 0u) | (r.y >= th ? 2u : 0u) | (r.z >= th ? 4u : 0u) | (r.w >= th ? 8u : 0u)) << (4 * c);
+                keep |= ((ffn_drop_field(r, 0, c4 + c) >= th ? 1u : 0u) | (ffn_drop_field(r, 1, c4 + c) >= th ? 2u : 0u) |
+                         (ffn_drop_field(r, 2, c4 + c) >= th ? 4u : 0u) | (ffn_drop_field(r, 3, c4 + c) >= th ? 8u : 0u)) << (4 * c);
             }
         }
 #pragma unroll
@@ -923,7 +924,7 @@ __global__ __launch_bounds__(256) void relu_h2_kernel(float* __restrict__ x, int
     bits += (long)blockIdx.y * x_gs * 4;
     lin_amax += (long)blockIdx.y * x_gs; hid_bound += (long)blockIdx.y * x_gs; flag += (long)blockIdx.y * x_gs;
     seed += (unsigned long long)blockIdx.y;
-    const unsigned th = drop_threshold(drop_p);
+    const unsigned th = drop_threshold16(drop_p);
     const float sc = 1.0f / (1.0f - drop_p);
     const float bound = fold_amax(lin_amax, kAmaxSlots) * sc;
     const float s = scale_for_amax(bound);
@@ -950,7 +951,8 @@ __global__ __launch_bounds__(256) void relu_h2_kernel(float* __restrict__ x, int
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const Philox4 r = philox4x32_10(seed, 1u, ffn_drop_block(row0, c8 + c));
-                keep |= ((r.x >= th ? 1u : 0u) | (r.y >= th ? 2u : 0u) | (r.z >= th ? 4u : 0u) | (r.w >= th ? 8u : 0u)) << (4 * c);
+                keep |= ((ffn_drop_field(r, 0, c8 + c) >= th ? 1u : 0u) | (ffn_drop_field(r, 1, c8 + c) >= th ? 2u : 0u) |
+                         (ffn_drop_field(r, 2, c8 + c) >= th ? 4u : 0u) | (ffn_drop_field(r, 3, c8 + c) >= th ? 8u : 0u)) << (4 * c);
             }
         }
 #pragma unroll
@@ -1025,8 +1027,10 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ o
         word = row & 3;
     } else {
         const long row = i / kFfnWidth;
-        r = philox4x32_10(seed, 1u, ffn_drop_block(row, (int)(i - row * kFfnWidth)));
-        word = (int)(row & 3);
+        const int col = (int)(i - row * kFfnWidth);
+        r = philox4x32_10(seed, 1u, ffn_drop_block(row, col));
+        out[i] = ffn_drop_field(r, (int)(row & 3), col) >= drop_threshold16(drop_p) ? sc : 0.f;
+        return;
     }
     out[i] = philox_word(r, word) >= th ? sc : 0.f;
 }
