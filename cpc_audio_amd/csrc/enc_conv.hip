@@ -396,7 +396,10 @@ constexpr int NB_ROWS = 32;   // rows per block (8 per wave)
 // 316 to the typical rstd and of 18 to ~2, i.e. 2^8..2^11 -- inside the 2^17 that the two-piece storage absorbs without any
 // loss (gemm_tile.h); workgroup 0 leaves it in *dx_bound for the readers.
 constexpr float kNormBwdBound = 316.22777f * 18.1f;      // 2 + sqrt(255) * 1.002 = 18.0, rounded up
-constexpr int NBW = 4;        // rows a wave works on at a time
+#ifndef CPC_NBW
+#define CPC_NBW 8
+#endif
+constexpr int NBW = CPC_NBW;        // rows a wave works on at a time (all of its eight: one batch of loads, one round of reductions)
 __device__ __forceinline__ f32x4 load4_as_f32(const float* base, long elem, bool bf16) {
     if (bf16) {
         const uint2 d = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
