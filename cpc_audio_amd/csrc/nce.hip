@@ -1710,7 +1710,9 @@ static int nce_forward(const float* c, const float* z, const float* wall, const 
     if (nce_heads_dma(K)) {
         // the same product on the DMA-fed tile: an H2 copy of c (8 MB at B = 64), the weights in K-tile-major H2 rows (ahead of time
         // where the bounds were: cpc_nce_bounds), 256 x 256 tiles of the conv layers' main loop
-        if (!g_wqh_ready) rc = gemm_weight_h2(wall, kC, 1, K * kC, kC, saved + n.wqh, saved + n.bounds + kAmaxSlots, nullptr, 1, 0, 0, 0, 0, st);
+        // (the layout of cpc_nce_bounds counts only for a caller that says its bounds -- in THIS workspace -- are ready)
+        if (!(bounds_ready && g_wqh_ready))
+            rc = gemm_weight_h2(wall, kC, 1, K * kC, kC, saved + n.wqh, saved + n.bounds + kAmaxSlots, nullptr, 1, 0, 0, 0, 0, st);
         g_wqh_ready = false;
         if (rc) return rc;
         rc = nce_rows_to_h2(c, saved + n.chf, saved + n.bounds, (long)B * S, st);
