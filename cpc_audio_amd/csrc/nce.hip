@@ -1386,7 +1386,8 @@ int g_nce_dbg = 0;         // cpc_set_nce_debug: measurement switches of nce_fwd
                            // pass, 1 no T epilogue, 2 no weighted row sum, 3 no logits stores; results are then WRONG
 int g_nce_rows_apart = 1;  // cpc_set_nce_rows_apart: the softmax rows of the fp16-piece scoring kernel by a launch of their own (on the
                            // loss reduction's stream) instead of inside it
-int g_nce_grid = 0;        // cpc_set_nce_grid: workgroups of nce_fwd_h2_kernel -- 0 one per four windows, -1 two per CU (each
+int g_nce_grid = -1;       // cpc_set_nce_grid: workgroups of nce_fwd_h2_kernel -- 0 one per four windows, -1 (default since the end of round 6:
+                           // -10 us per step sustained at B = 64, three alternations, profiles/r6_sweep_knobs.txt) two per CU (each
                            // walking windows 4 wg + wave, + 4 grid, ...: all waves sweep the sorted candidate lists in step), n > 0
 
 struct NceLayout {

@@ -436,7 +436,7 @@ int cpc_set_nce_fused(int on);
  * contraction over candidates fed by the transposing LDS read; on = 3: the dz path's gather-GEMM likewise, from an H2 copy of c.
  * Same interface, same saved tensors.) */
 int cpc_get_nce_fused(void);
-/* cpc_set_nce_fused(2 / 3): workgroups of the scoring kernel -- 0 = one per four windows, -1 = two per CU, n > 0 = at most n (a capped
+/* cpc_set_nce_fused(2 / 3): workgroups of the scoring kernel -- 0 = one per four windows, -1 (default) = two per CU, n > 0 = at most n (a capped
  * grid walks its windows with the grid's stride, so that all resident waves sweep their ascending candidate lists in step). */
 int cpc_set_nce_grid(int wgs);
 /* cpc_set_nce_fused(2 / 3): 1 (default) = the softmax rows the dz path reads are written by a launch of their own, on the stream

@@ -34,6 +34,19 @@ def test_nce_forward_backward_emulated(B, S, K, N, scale, wide, fused):
         lib.cpc_set_nce_heads_dma(1)
 
 
+@pytest.mark.parametrize("grid", [0, 1, 3])
+def test_scoring_kernel_with_a_capped_grid_emulated(grid):
+    """cpc_set_nce_grid: the fp16-piece scoring kernel as at most `grid` workgroups that walk their windows with the grid's stride
+    (the default, -1, is two per CU: 512 workgroups for the 1856 of B = 64 on MI355X; 0 = one per four windows) -- every window is
+    still scored by one wave on its own, so losses, logits and every gradient are those of the oracle whatever the cap."""
+    lib = emu()
+    assert lib.cpc_set_nce_grid(grid) == 0
+    try:
+        _nce_forward_backward(lib, 3, 19, 5, 32, 40.0)
+    finally:
+        lib.cpc_set_nce_grid(-1)
+
+
 def _nce_forward_backward(lib, B, S, K, N, scale):
     torch.manual_seed(2)
     W = S - K
