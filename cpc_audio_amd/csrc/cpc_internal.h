@@ -139,9 +139,10 @@ extern int g_mfma_mode;
 // layouts ready for the next step (cpc_train_step_tail), [22] the same for every other parameter but conv0's, [6] / [23] open
 // tail: the last stand-alone norm backward is done (main) / the batched column sums are (sums stream)
 // [24] the encoder's forward is done (composite step: the criterion's H2 copy of z is made beside the recurrence)
-constexpr int kStreamEvents = 25;
+// [25] layer 1's weight-gradient GEMM is done (recorded in front of its split reduction: cpc_set_tail_schedule(3))
+constexpr int kStreamEvents = 26;
 constexpr int kEvWgradRest = 5, kEvNorm1 = 6, kEvWgrad1 = 7, kEvGruWgrad = 11, kEvNextConv1 = 21, kEvNextRest = 22, kEvSums = 23,
-              kEvEncoderDone = 24;
+              kEvEncoderDone = 24, kEvWgrad1Gemm = 25;
 hipEvent_t* stream_events(hipStream_t caller_stream);
 
 // ---- hooks of the composite step into the per-stage entry points (train_step.hip sets them around its calls; per host

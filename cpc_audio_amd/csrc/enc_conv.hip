@@ -1260,9 +1260,11 @@ int enc_error_flag_fetch(int clear, unsigned* out) {
     return 0;
 }
 }  // namespace cpc
-static int g_tail_conv0_early = 0;      // cpc_set_tail_schedule (see cpc_encoder_forward)
+static int g_tail_conv0_early = 2;      // cpc_set_tail_schedule (see cpc_encoder_forward); 2 since the end of round 6: 2.638 / 2.632 / 2.634 ->
+                                        // 2.620 / 2.621 / 2.622 ms per step sustained (three alternations, profiles/r6_ab_tail_schedule.txt)
 extern "C" int cpc_set_tail_schedule(int conv0_early) {
-    g_tail_conv0_early = conv0_early ? 1 : 0;
+    if (conv0_early < 0 || conv0_early > 3) return CPC_ERR_ARG;
+    g_tail_conv0_early = conv0_early;
     return 0;
 }
 // 0 (default): layer 1's weight gradient is released behind its data gradient; 1: together with dx1, i.e. beside that data gradient
@@ -1618,6 +1620,13 @@ extern "C" int cpc_encoder_forward(const float* wave, const float* const* params
         return !apart || hipStreamWaitEvent(st, t_prep_done, 0) == hipSuccess;
     };
     if (!g_tail_conv0_early && !wait_tail()) return CPC_ERR_ARG;
+    // 2 / 3: layer 0 starts behind layer 1's weight gradient itself -- behind its split reduction (2) or already behind its GEMM (3) --
+    // and runs beside what is left of the tail, four short launches on the weight-gradient stream (the reduction, the optimiser's
+    // update of conv1.weight, its maximum and its layouts: ~50 us with their gaps); layer 1 then waits for the tail as in 1
+    if (g_tail_conv0_early >= 2 && hk.conv1_wait[0] != nullptr) {
+        hipEvent_t* pool = stream_events(st);
+        if (!pool || hipStreamWaitEvent(st, pool[g_tail_conv0_early == 3 ? kEvWgrad1Gemm : kEvWgrad1], 0) != hipSuccess) return CPC_ERR_ARG;
+    }
     step_timer_mark(0, st);
     if (e.bf16) {
         // bf16-storage variant: y0..y3 and xhat1..4 as bf16 (half the activation bytes), weights rounded to bf16 by the
@@ -1786,6 +1795,7 @@ static int encoder_backward_impl(const float* wave, const float* const* params, 
                 }
                 return 0;
             }
+            if (i == 1 && ev && g_tail_conv0_early == 3 && hipEventRecord(ev[kEvWgrad1Gemm], wst) != hipSuccess) return CPC_ERR_ARG;
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, wst, part, S, kGeom[i].k,
                                grads[4 * i]);
             return 0;

@@ -529,8 +529,10 @@ int cpc_train_step_wait(void* main_stream, int which, void* waiting_stream);
  * before a workgroup gives up on its partner (< 0: the default 2^22; tests use 0 to drive CPC_DEVERR_CONV_EXCHANGE). */
 int cpc_set_fwd_nsplit(int min_wgs, int spin_limit);
 int cpc_set_step_timing(int on);
-/* Measurement switch of the open tail: 0 (default) the next step's layer 0 starts behind the tail, 1 it runs under it and only
- * layer 1 waits (measured slower: layer 0 gets a quarter of its wave slots beside layer 1's weight gradient). */
+/* Where the next step's layer 0 takes up an open tail: 0 behind the whole tail (layer 1's weight gradient, its split reduction, the
+ * update of conv1.weight and that weight's layouts), 1 under it -- only layer 1 waits (layer 0 gets a quarter of its wave slots
+ * beside layer 1's weight gradient) --, 2 (default since the end of round 6: -13 us per step) behind the weight gradient and its
+ * reduction, beside the update and the layouts, 3 already behind the weight gradient's GEMM (an event more on that stream: no gain). */
 int cpc_set_tail_schedule(int conv0_early);
 int cpc_get_step_timing(float* us);
 /* Measurement switches of cpc_train_step's schedule.  prep_point: where the criterion's index preparation (190 MB of index
