@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-6 final evidence: the whole -m gpu suite, the step profiles (kernel stats, timeline, bf16), PMC, config-4 stats, the bench line
 export TMPDIR=/tmp
-O=gpurun_out/r6_final4
+O=gpurun_out/r6_final6
 mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; echo "pytest rc $?"; grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" $O/pytest_gpu.log | tail -4
 bash tools/collect_profiles.sh r6 > $O/collect.log 2>&1; tail -6 $O/collect.log
